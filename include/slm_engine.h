@@ -1,0 +1,189 @@
+/*
+ * slm_engine.h -- C ABI of the MI355X (gfx950) proximal-gradient fit engine that replaces the
+ * cvxpy solve of CederGroupHub/sparse-lm's Lasso-family estimators.
+ *
+ * Drop-in boundary.  The one reference interface this library stands in for is
+ *
+ *     CVXRegressor._solve(self, X, y, solver_options) -> beta
+ *         src/sparselm/model/_base.py:512-519        (problem.solve(...); return beta.value)
+ *     overridden by AdaptiveLasso._solve
+ *         src/sparselm/model/_adaptive_lasso.py:206-232  (re-weighting loop around the same solve)
+ *
+ * called once per fit at src/sparselm/model/_base.py:201 with already validated, centred and
+ * re-weighted float64 arrays.  The problem solved is the one the reference assembles in cvxpy:
+ *
+ *     minimise_beta  1/(2n) ||X beta - y||^2                      (model/_lasso.py:109-121)
+ *                  + sum_j a_j |beta_j|                           (Lasso :99-107, SGL :627-639,
+ *                                                                  AdaptiveLasso _adaptive_lasso.py:167-175)
+ *                  + sum_g b_g ||beta_g||_2                       (GroupLasso :267-275,
+ *                                                                  AdaptiveGroupLasso _adaptive_lasso.py:354-362)
+ *                  + 1/2 sum_g d_g ||beta_g||_2^2                 (RidgedGroupLasso :795-811)
+ *
+ * Conventions: plain C types only; every function returns an slm_status (0 = ok); no C++
+ * exception crosses the ABI; slm_last_error() returns a thread-local message for the last failure
+ * on the calling thread.  All floating-point buffers are IEEE fp64.  A handle is not thread-safe;
+ * different handles are.  Host pointers are borrowed only for the duration of a call.
+ * There is NO CPU fallback: every entry point needs a visible gfx950 device and fails with
+ * SLM_ERR_NO_DEVICE / SLM_ERR_HIP otherwise.
+ */
+#ifndef SLM_ENGINE_H
+#define SLM_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLM_ABI_VERSION 1
+
+typedef enum slm_status {
+  SLM_OK = 0,
+  SLM_ERR_BAD_ARG = 1,      /* -> ValueError  */
+  SLM_ERR_OOM = 2,          /* -> MemoryError */
+  SLM_ERR_HIP = 3,          /* -> RuntimeError (HIP runtime / kernel failure) */
+  SLM_ERR_NO_DEVICE = 4,    /* -> RuntimeError (no gfx950 device visible) */
+  SLM_ERR_COMM = 5,         /* -> RuntimeError (RCCL failure) */
+  SLM_ERR_NOT_CONVERGED = 6,/* informational: reported per path point, never returned by solve */
+  SLM_ERR_NON_FINITE = 7,   /* -> RuntimeError: non-finite value in the iterate (the reference's
+                               counterpart is cvxpy's SolverError / "infeasible" RuntimeError,
+                               model/_adaptive_lasso.py:216-220) */
+  SLM_ERR_UNSUPPORTED = 8
+} slm_status;
+
+typedef struct slm_engine slm_engine;   /* one per (process, device): stream, workspace          */
+typedef struct slm_dataset slm_dataset; /* device-resident (X, y[, row weights][, groups]) + state */
+
+/* ---- library ------------------------------------------------------------------------------- */
+int slm_abi_version(void);
+const char* slm_last_error(void);
+int slm_device_count(int* count_out);
+
+/* ---- engine lifecycle ------------------------------------------------------------------------ */
+int slm_engine_create(int device_id, slm_engine** out);
+int slm_engine_destroy(slm_engine* eng);
+/* Blocks until all work queued on the engine's stream has finished. */
+int slm_engine_synchronize(slm_engine* eng);
+/* Device facts used by bench.py / DESIGN.md: out[0]=compute units, out[1]=LDS bytes per CU,
+   out[2]=total HBM bytes, out[3]=free HBM bytes, out[4]=wavefront size, out[5]=clock kHz. */
+int slm_engine_device_info(slm_engine* eng, int64_t out[6], char* name_out, int name_len);
+
+/* ---- dataset --------------------------------------------------------------------------------- */
+/*
+ * Upload the (already preprocessed) design matrix and target the reference hands to _solve
+ * (model/_base.py:201).  X is n x p with element (i, j) at X[i*row_stride + j*col_stride]
+ * (strides in elements): C-order (col_stride == 1) and F-order (row_stride == 1) are accepted.
+ * The engine keeps its own padded row-major copy in HBM; `row_weight` (nullable, length n, >= 0)
+ * multiplies each row's squared residual: loss = 1/(2n) sum_i w_i (x_i beta - y_i)^2  -- used
+ * for CV-fold masks and sample weights without re-uploading X.
+ */
+int slm_dataset_create(slm_engine* eng, const double* X, int64_t n, int64_t p, int64_t row_stride,
+                       int64_t col_stride, const double* y, const double* row_weight,
+                       slm_dataset** out);
+/*
+ * Same, from buffers that already live in this device's HBM (row-major, leading dimension ld >= p
+ * elements).  The data are copied into the engine's padded layout; the caller keeps ownership.
+ */
+int slm_dataset_create_device(slm_engine* eng, const double* dX, int64_t n, int64_t p, int64_t ld,
+                              const double* dy, const double* d_row_weight, slm_dataset** out);
+/*
+ * Synthetic regression problem generated on the device (no host array): X_ij ~ N(0,1) iid from a
+ * counter-based generator keyed by (seed, row_offset + i, j); y = X coef + noise_sd * N(0,1).
+ * `coef` is a host vector of length p.  This is the law of sklearn.datasets.make_regression used by
+ * BASELINE.json's configs; `row_offset` lets rank r of a row-sharded job own rows
+ * [row_offset, row_offset + n) of one global matrix.
+ */
+int slm_dataset_create_synthetic(slm_engine* eng, int64_t n, int64_t p, uint64_t seed,
+                                 int64_t row_offset, const double* coef, double noise_sd,
+                                 slm_dataset** out);
+int slm_dataset_destroy(slm_dataset* ds);
+int slm_dataset_shape(slm_dataset* ds, int64_t* n, int64_t* p, int64_t* ld);
+/* Copy the engine's X (dense n x p, C-order) and/or y back to the host (either may be NULL). */
+int slm_dataset_download(slm_dataset* ds, double* X_out, double* y_out);
+/* Replace the row weights (NULL => all ones).  Invalidates the cached Lipschitz constant. */
+int slm_dataset_set_row_weights(slm_dataset* ds, const double* row_weight);
+/*
+ * Group structure: gid[j] in [0, n_groups) is the dense group index of feature j in the
+ * reference's order (i-th sorted unique label <-> group i, model/_lasso.py:248).  Groups need not
+ * be contiguous.  NULL / never called => every feature is its own group (model/_lasso.py:211-217).
+ */
+int slm_dataset_set_groups(slm_dataset* ds, const int32_t* gid, int32_t n_groups);
+/* lambda_max(X^T W X)/n estimate (device power iteration, cached); safe upper-side margin applied. */
+int slm_dataset_lipschitz(slm_dataset* ds, double* L_out);
+/*
+ * One evaluation of the hot kernel: g = X^T W (X z - y) / n  (g_out: length p, host) and
+ * loss = 1/(2n) sum_i w_i (x_i z - y_i)^2 (loss_out nullable).  z == NULL means z = 0, which gives
+ * -X^T W y / n (used for alpha_max).  `reps` > 1 repeats the launch and reports the mean kernel
+ * time in ms through ms_out (nullable) -- the roofline probe.
+ */
+int slm_gradient(slm_dataset* ds, const double* z, double* g_out, double* loss_out, int32_t reps,
+                 double* ms_out);
+
+/* ---- solve ----------------------------------------------------------------------------------- */
+typedef struct slm_penalty {
+  const double* a; /* length p, per-coefficient l1 weight; NULL => all ones            */
+  const double* b; /* length G, per-group l2 weight;       NULL => all ones            */
+  const double* d; /* length G, per-group ridge weight;    NULL => all ones            */
+} slm_penalty;
+
+/* Penalty at path point k is (sa*a, sb*b, sd*d). */
+typedef struct slm_path_point {
+  double sa, sb, sd;
+} slm_path_point;
+
+#define SLM_FLAG_NO_RESTART 1u   /* disable the gradient-scheme momentum restart        */
+#define SLM_FLAG_PROFILE 2u      /* bracket every gradient launch with HIP events        */
+#define SLM_FLAG_COLD_START 4u   /* do not warm-start point k+1 from point k             */
+
+typedef struct slm_solve_opts {
+  double tol;          /* stop when ||beta+ - z||_2 <= tol * ||beta+||_2; <= 0 => 1e-8   */
+  int32_t max_iter;    /* per path point; <= 0 => 10000                                  */
+  int32_t check_every; /* iterations queued between host polls; <= 0 => automatic        */
+  double L;            /* Lipschitz constant to use; <= 0 => slm_dataset_lipschitz()     */
+  uint32_t flags;
+} slm_solve_opts;
+
+typedef struct slm_point_info {
+  int32_t n_iter;    /* gradient evaluations spent on this point                         */
+  int32_t status;    /* SLM_OK or SLM_ERR_NOT_CONVERGED                                  */
+  double resid;      /* ||beta+ - z||_2 at exit                                          */
+  double beta_norm;  /* ||beta||_2                                                       */
+  double loss;       /* 1/(2n)||X z - y||_W^2 at the last gradient point                 */
+  double L;          /* Lipschitz constant in use at exit                                */
+} slm_point_info;
+
+typedef struct slm_solve_stats {
+  int64_t grad_launches;  /* gradient kernels that did work                              */
+  double grad_ms_total;   /* sum of their device durations (SLM_FLAG_PROFILE only)       */
+  double wall_ms;         /* host wall clock of the call                                 */
+  double lipschitz_ms;    /* part of wall_ms spent estimating L (0 if cached / given)    */
+} slm_solve_stats;
+
+/*
+ * Warm-started regularisation path: for k = 0..n_points-1 minimise the objective with penalty
+ * (sa_k a, sb_k b, sd_k d), each point started from the previous solution (the first from
+ * beta0, NULL => 0).  The whole path runs as one device-resident state machine; the host only
+ * queues iterations and polls a flag.  betas_out: n_points x p (C-order, host);
+ * group_norms_out: n_points x G (nullable); infos: n_points (nullable); stats nullable.
+ * n_points == 1 is the plain _solve().
+ */
+int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,
+                   int32_t n_points, const slm_solve_opts* opts, const double* beta0,
+                   double* betas_out, double* group_norms_out, slm_point_info* infos,
+                   slm_solve_stats* stats);
+
+/* ---- row-sharded mode (very tall X split by rows over ranks; one all-reduce per iteration) ---- */
+#define SLM_COMM_ID_BYTES 128
+/* Rank 0 creates the id and distributes the 128 bytes to the other ranks out of band. */
+int slm_comm_unique_id(uint8_t id_out[SLM_COMM_ID_BYTES]);
+/* Collective over all ranks: afterwards slm_gradient / slm_solve_path on datasets of this engine
+   sum X^T r (and the loss / n) over ranks with RCCL; n_global replaces n in the 1/n scaling. */
+int slm_comm_init(slm_engine* eng, int32_t rank, int32_t n_ranks,
+                  const uint8_t id[SLM_COMM_ID_BYTES]);
+int slm_dataset_set_global_rows(slm_dataset* ds, int64_t n_global);
+int slm_comm_destroy(slm_engine* eng);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLM_ENGINE_H */

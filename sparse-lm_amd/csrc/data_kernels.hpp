@@ -1,0 +1,100 @@
+// Data-movement and synthetic-data kernels (one-off per dataset; not on the per-iteration path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tail_kernels.hpp"  // mix64
+
+namespace slm {
+
+// F-order (column-major, leading dimension = n) -> padded row-major.  32x32 LDS tile.
+__global__ __launch_bounds__(256) void transpose_f2c_kernel(const double* __restrict__ src, int64_t n,
+                                                            int64_t p, double* __restrict__ dst,
+                                                            int64_t ld) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t i0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
+  for (int k = ty; k < 32; k += 8) {  // read: consecutive lanes walk rows i (contiguous in F-order)
+    const int64_t i = i0 + tx, j = j0 + k;
+    tile[k][tx] = (i < n && j < p) ? src[j * n + i] : 0.0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {  // write: consecutive lanes walk columns j (contiguous in C-order)
+    const int64_t i = i0 + k, j = j0 + tx;
+    if (i < n && j < p) dst[i * ld + j] = tile[tx][k];
+  }
+}
+
+// Row-major copy with different leading dimensions (device -> device), pad columns left untouched.
+__global__ __launch_bounds__(256) void copy_rows_kernel(const double* __restrict__ src, int64_t n,
+                                                        int64_t p, int64_t lds_, double* __restrict__ dst,
+                                                        int64_t ld) {
+  const int64_t total = n * p;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / p, j = e - i * p;
+    dst[i * ld + j] = src[i * lds_ + j];
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(double* dst, int64_t count, double value) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;
+       e += (int64_t)gridDim.x * blockDim.x)
+    dst[e] = value;
+}
+
+// Two independent N(0,1) draws from a 64-bit counter (Box-Muller on two 53-bit uniforms).
+__device__ __forceinline__ void normal_pair(uint64_t key, uint64_t ctr, double& n0, double& n1) {
+  const uint64_t h1 = mix64(key ^ mix64(ctr + 0x632be59bd9b4e019ull));
+  const uint64_t h2 = mix64(h1 + 0x9e3779b97f4a7c15ull);
+  const double u1 = ((double)(h1 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)(h2 >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  const double r = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincospi(2.0 * u2, &s, &c);
+  n0 = r * c;
+  n1 = r * s;
+}
+
+// X_ij ~ N(0,1) keyed by (seed, global row, column pair): independent of the launch geometry and of
+// how rows are sharded over ranks.
+__global__ __launch_bounds__(256) void synth_x_kernel(double* __restrict__ X, int64_t n, int64_t p,
+                                                      int64_t ld, uint64_t seed, int64_t row_offset) {
+  const int64_t pairs = (p + 1) / 2;
+  const int64_t total = n * pairs;
+  const uint64_t key = mix64(seed ^ 0x5851f42d4c957f2dull);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / pairs, jp = e - i * pairs;
+    double a, b;
+    normal_pair(key, (uint64_t)(row_offset + i) * (uint64_t)pairs + (uint64_t)jp, a, b);
+    double* row = X + i * ld;
+    row[2 * jp] = a;
+    if (2 * jp + 1 < p) row[2 * jp + 1] = b;
+  }
+}
+
+// y_i = x_i . coef + noise_sd * N(0,1): one wavefront per row.
+__global__ __launch_bounds__(256) void synth_y_kernel(const double* __restrict__ X, int64_t n, int64_t p,
+                                                      int64_t ld, const double* __restrict__ coef,
+                                                      double noise_sd, uint64_t seed,
+                                                      int64_t row_offset, double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const uint64_t key = mix64(seed ^ 0x2545f4914f6cdd1dull);
+  for (int64_t i = wave; i < n; i += nwaves) {
+    const double* row = X + i * ld;
+    double s = 0.0;
+    for (int64_t j = lane; j < p; j += 64) s = __builtin_fma(row[j], coef[j], s);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+      double e0, e1;
+      normal_pair(key, (uint64_t)(row_offset + i), e0, e1);
+      y[i] = s + noise_sd * e0;
+    }
+  }
+}
+
+}  // namespace slm

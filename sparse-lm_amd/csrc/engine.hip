@@ -1,0 +1,971 @@
+// Host side of the MI355X fit engine: handles, HBM layout, launch logic, the C ABI of
+// include/slm_engine.h.  Replaces the cvxpy `problem.solve` call of
+// /root/reference/src/sparselm/model/_base.py:512-519 (and the inner solve of
+// model/_adaptive_lasso.py:213-215) with a device-resident FISTA state machine.
+//
+// gfx950 only; there is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <chrono>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/slm_engine.h"
+#include "data_kernels.hpp"
+#include "grad_kernel.hpp"
+#include "tail_kernels.hpp"
+
+using namespace slm;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return fail(e__ == hipErrorOutOfMemory ? SLM_ERR_OOM : SLM_ERR_HIP, "%s failed: %s (%s:%d)", \
+                  #expr, hipGetErrorString(e__), __FILE__, __LINE__);                       \
+  } while (0)
+
+#define SLM_TRY(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != SLM_OK) return rc__; \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// RCCL, loaded lazily (single-GPU use never touches it)
+// ------------------------------------------------------------------------------------------------
+typedef struct { char internal[SLM_COMM_ID_BYTES]; } rcclUniqueId_t;
+typedef void* rcclComm_t;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(rcclUniqueId_t*) = nullptr;
+  int (*CommInitRank)(rcclComm_t*, int, rcclUniqueId_t, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+  int (*CommDestroy)(rcclComm_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static const int kNcclFloat64 = 8;  // ncclDouble
+static const int kNcclSum = 0;      // ncclSum
+
+static int load_rccl() {
+  if (g_rccl.lib) return SLM_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* lib = nullptr;
+  for (const char* nm : names) {
+    lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(SLM_ERR_COMM, "cannot load librccl: %s", dlerror());
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+  g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    return fail(SLM_ERR_COMM, "librccl is missing required symbols");
+  g_rccl.lib = lib;
+  return SLM_OK;
+}
+
+#define RCCL_TRY(expr)                                                                      \
+  do {                                                                                      \
+    int e__ = (expr);                                                                       \
+    if (e__ != 0)                                                                           \
+      return fail(SLM_ERR_COMM, "%s failed: %s", #expr,                                     \
+                  g_rccl.GetErrorString ? g_rccl.GetErrorString(e__) : "rccl error");       \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// gradient kernel table
+// ------------------------------------------------------------------------------------------------
+struct GradKernel {
+  int W, C, R;
+  void (*fn)(GradArgs);
+};
+
+#define SLM_GK(W, C, R) {W, C, R, grad_fused_kernel<W, C, R>}
+// Default choice per capacity (64*W*C chunks of 16 bytes), ordered by capacity.
+static const GradKernel kGradDefault[] = {
+    SLM_GK(1, 1, 4), SLM_GK(2, 1, 4), SLM_GK(4, 1, 4), SLM_GK(8, 1, 4), SLM_GK(8, 2, 4),
+    SLM_GK(8, 3, 4), SLM_GK(8, 4, 2), SLM_GK(8, 5, 2), SLM_GK(8, 6, 2), SLM_GK(8, 8, 1),
+    SLM_GK(8, 10, 1),
+};
+// Extra instantiations reachable through SLM_GRAD_CONFIG=W,C,R (tuning sweeps).
+static const GradKernel kGradExtra[] = {
+    SLM_GK(8, 5, 1), SLM_GK(8, 4, 4), SLM_GK(8, 3, 2), SLM_GK(8, 6, 1), SLM_GK(4, 10, 1),
+    SLM_GK(4, 5, 2), SLM_GK(4, 6, 2), SLM_GK(4, 8, 2),  SLM_GK(4, 10, 2), SLM_GK(4, 5, 4),
+    SLM_GK(2, 10, 2), SLM_GK(1, 2, 4), SLM_GK(2, 2, 4), SLM_GK(4, 2, 4),  SLM_GK(4, 3, 4),
+    SLM_GK(4, 4, 4),
+};
+static const int64_t kMaxChunks = 64 * 8 * 10;  // largest row the fused kernel covers (p <= 10240)
+
+static const GradKernel* pick_grad_kernel(int64_t p2) {
+  const char* env = getenv("SLM_GRAD_CONFIG");
+  if (env) {
+    int W = 0, C = 0, R = 0;
+    if (sscanf(env, "%d,%d,%d", &W, &C, &R) == 3) {
+      for (const auto& k : kGradDefault)
+        if (k.W == W && k.C == C && k.R == R && 64LL * W * C >= p2) return &k;
+      for (const auto& k : kGradExtra)
+        if (k.W == W && k.C == C && k.R == R && 64LL * W * C >= p2) return &k;
+    }
+  }
+  for (const auto& k : kGradDefault)
+    if (64LL * k.W * k.C >= p2) return &k;
+  return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+struct slm_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop;
+  int cus = 0;
+  // row-sharded mode
+  rcclComm_t comm = nullptr;
+  int rank = 0, n_ranks = 1;
+};
+
+struct slm_dataset {
+  slm_engine* eng = nullptr;
+  int64_t n = 0, p = 0, ld = 0, n_global = 0;
+  double *X = nullptr, *y = nullptr, *rw = nullptr, *yzero = nullptr;
+  // group structure (group-sorted permutation)
+  int G = 0, singleton = 1, team = 1;
+  int *order = nullptr, *gsorted = nullptr, *gstart = nullptr;
+  // gradient launch
+  const GradKernel* gk = nullptr;
+  int nblk = 0;
+  double *partial = nullptr, *loss_partial = nullptr;
+  // iteration state
+  double *g = nullptr, *z = nullptr, *beta = nullptr, *zprev = nullptr, *gprev = nullptr;
+  double *u = nullptr, *gscale = nullptr, *a0 = nullptr, *b0 = nullptr, *d0 = nullptr;
+  double* lambda = nullptr;
+  PathCtl* ctl = nullptr;
+  PathCtl* hctl = nullptr;  // pinned, 2 slots
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  // path buffers (grown on demand)
+  int cap_points = 0, cap_gn = 0;
+  slm_path_point* pts = nullptr;
+  double *betas_out = nullptr, *gn_out = nullptr;
+  slm_point_info* infos = nullptr;
+  std::vector<hipEvent_t> prof;
+  // cached Lipschitz constant
+  double L = 0.0;
+  bool L_valid = false;
+};
+
+template <typename T>
+static int dalloc(T** out, size_t count) {
+  *out = nullptr;
+  if (count == 0) count = 1;
+  HIP_TRY(hipMalloc((void**)out, count * sizeof(T)));
+  return SLM_OK;
+}
+template <typename T>
+static void dfree(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// library
+// ------------------------------------------------------------------------------------------------
+extern "C" int slm_abi_version(void) { return SLM_ABI_VERSION; }
+extern "C" const char* slm_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int slm_device_count(int* count_out) {
+  if (!count_out) return fail(SLM_ERR_BAD_ARG, "count_out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count_out = 0;
+    return fail(SLM_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count_out = n;
+  return SLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------------
+extern "C" int slm_engine_create(int device_id, slm_engine** out) {
+  if (!out) return fail(SLM_ERR_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(SLM_ERR_NO_DEVICE, "no HIP device visible (%s); this engine has no CPU fallback",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n)
+    return fail(SLM_ERR_BAD_ARG, "device_id %d out of range [0, %d)", device_id, n);
+  HIP_TRY(hipSetDevice(device_id));
+  slm_engine* eng = new slm_engine();
+  eng->device = device_id;
+  e = hipGetDeviceProperties(&eng->prop, device_id);
+  if (e != hipSuccess) {
+    delete eng;
+    return fail(SLM_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  }
+  if (strncmp(eng->prop.gcnArchName, "gfx950", 6) != 0 && !getenv("SLM_ALLOW_ANY_ARCH")) {
+    std::string arch = eng->prop.gcnArchName;
+    delete eng;
+    return fail(SLM_ERR_NO_DEVICE, "device %d is %s; this library only carries gfx950 (MI355X) code",
+                device_id, arch.c_str());
+  }
+  eng->cus = eng->prop.multiProcessorCount;
+  e = hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete eng;
+    return fail(SLM_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  *out = eng;
+  return SLM_OK;
+}
+
+extern "C" int slm_comm_destroy(slm_engine* eng);
+
+extern "C" int slm_engine_destroy(slm_engine* eng) {
+  if (!eng) return SLM_OK;
+  (void)hipSetDevice(eng->device);
+  if (eng->comm) (void)slm_comm_destroy(eng);
+  if (eng->stream) (void)hipStreamDestroy(eng->stream);
+  delete eng;
+  return SLM_OK;
+}
+
+extern "C" int slm_engine_synchronize(slm_engine* eng) {
+  if (!eng) return fail(SLM_ERR_BAD_ARG, "engine is NULL");
+  HIP_TRY(hipSetDevice(eng->device));
+  HIP_TRY(hipStreamSynchronize(eng->stream));
+  return SLM_OK;
+}
+
+extern "C" int slm_engine_device_info(slm_engine* eng, int64_t out[6], char* name_out, int name_len) {
+  if (!eng || !out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(eng->device));
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  out[0] = eng->prop.multiProcessorCount;
+  out[1] = (int64_t)eng->prop.maxSharedMemoryPerMultiProcessor;
+  out[2] = (int64_t)total_b;
+  out[3] = (int64_t)free_b;
+  out[4] = eng->prop.warpSize;
+  out[5] = eng->prop.clockRate;
+  if (name_out && name_len > 0) {
+    snprintf(name_out, (size_t)name_len, "%s (%s)", eng->prop.name, eng->prop.gcnArchName);
+  }
+  return SLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dataset
+// ------------------------------------------------------------------------------------------------
+static void dataset_free(slm_dataset* ds) {
+  if (!ds) return;
+  dfree(ds->X); dfree(ds->y); dfree(ds->rw); dfree(ds->yzero);
+  dfree(ds->order); dfree(ds->gsorted); dfree(ds->gstart);
+  dfree(ds->partial); dfree(ds->loss_partial);
+  dfree(ds->g); dfree(ds->z); dfree(ds->beta); dfree(ds->zprev); dfree(ds->gprev);
+  dfree(ds->u); dfree(ds->gscale); dfree(ds->a0); dfree(ds->b0); dfree(ds->d0);
+  dfree(ds->lambda); dfree(ds->ctl);
+  dfree(ds->pts); dfree(ds->betas_out); dfree(ds->gn_out); dfree(ds->infos);
+  if (ds->hctl) (void)hipHostFree(ds->hctl);
+  for (auto& e : ds->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : ds->prof) (void)hipEventDestroy(e);
+  delete ds;
+}
+
+static int set_singleton_groups(slm_dataset* ds) {
+  const int p = (int)ds->p;
+  std::vector<int> ident(p), start(p + 1);
+  std::iota(ident.begin(), ident.end(), 0);
+  std::iota(start.begin(), start.end(), 0);
+  dfree(ds->order); dfree(ds->gsorted); dfree(ds->gstart); dfree(ds->gscale);
+  SLM_TRY(dalloc(&ds->order, p));
+  SLM_TRY(dalloc(&ds->gsorted, p));
+  SLM_TRY(dalloc(&ds->gstart, p + 1));
+  SLM_TRY(dalloc(&ds->gscale, p));
+  HIP_TRY(hipMemcpy(ds->order, ident.data(), sizeof(int) * p, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ds->gsorted, ident.data(), sizeof(int) * p, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ds->gstart, start.data(), sizeof(int) * (p + 1), hipMemcpyHostToDevice));
+  ds->G = p;
+  ds->singleton = 1;
+  ds->team = 1;
+  return SLM_OK;
+}
+
+// Allocates everything that depends only on (n, p): padded X, vectors, work space.
+static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** out) {
+  if (n <= 0 || p <= 0) return fail(SLM_ERR_BAD_ARG, "n and p must be positive (got %lld x %lld)",
+                                    (long long)n, (long long)p);
+  if (p > 2 * kMaxChunks)
+    return fail(SLM_ERR_UNSUPPORTED, "p = %lld exceeds the fused kernel's row capacity (%lld columns)",
+                (long long)p, (long long)(2 * kMaxChunks));
+  if (n > (int64_t)2000000000) return fail(SLM_ERR_UNSUPPORTED, "n too large");
+  slm_dataset* ds = new slm_dataset();
+  ds->eng = eng;
+  ds->n = n;
+  ds->p = p;
+  ds->n_global = n;
+  ds->ld = (p + 15) / 16 * 16;
+  const int64_t ld = ds->ld;
+  ds->gk = pick_grad_kernel(ld / 2);
+  if (!ds->gk) {
+    delete ds;
+    return fail(SLM_ERR_UNSUPPORTED, "no gradient kernel covers p = %lld", (long long)p);
+  }
+  int occ = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)ds->gk->fn,
+                                                              ds->gk->W * 64, 0);
+  if (e != hipSuccess || occ < 1) occ = 1;
+  int per_cu = occ;
+  if (const char* env = getenv("SLM_GRAD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(env));
+  int64_t nblk = (int64_t)eng->cus * per_cu;
+  const int64_t steps = (n + ds->gk->R - 1) / ds->gk->R;
+  nblk = std::max<int64_t>(1, std::min<int64_t>(nblk, steps));
+  ds->nblk = (int)nblk;
+
+  int rc = SLM_OK;
+  auto A = [&](int r) { if (rc == SLM_OK) rc = r; };
+  A(dalloc(&ds->X, (size_t)n * ld));
+  A(dalloc(&ds->y, n));
+  A(dalloc(&ds->yzero, n));
+  A(dalloc(&ds->partial, (size_t)nblk * ld));
+  A(dalloc(&ds->loss_partial, nblk));
+  A(dalloc(&ds->g, ld + 16));
+  A(dalloc(&ds->z, ld));
+  A(dalloc(&ds->beta, ld));
+  A(dalloc(&ds->zprev, ld));
+  A(dalloc(&ds->gprev, ld));
+  A(dalloc(&ds->u, ld));
+  A(dalloc(&ds->a0, ld));
+  A(dalloc(&ds->b0, ld));
+  A(dalloc(&ds->d0, ld));
+  A(dalloc(&ds->lambda, 1));
+  A(dalloc(&ds->ctl, 1));
+  if (rc == SLM_OK) {
+    hipError_t e2 = hipHostMalloc((void**)&ds->hctl, 2 * sizeof(PathCtl), hipHostMallocDefault);
+    if (e2 != hipSuccess) rc = fail(SLM_ERR_OOM, "hipHostMalloc: %s", hipGetErrorString(e2));
+  }
+  for (int k = 0; k < 2 && rc == SLM_OK; ++k) {
+    hipError_t e2 = hipEventCreateWithFlags(&ds->ev[k], hipEventDisableTiming);
+    if (e2 != hipSuccess) rc = fail(SLM_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e2));
+  }
+  if (rc == SLM_OK) rc = set_singleton_groups(ds);
+  if (rc == SLM_OK) {
+    hipStream_t s = eng->stream;
+    hipError_t e3 = hipMemsetAsync(ds->X, 0, sizeof(double) * (size_t)n * ld, s);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->yzero, 0, sizeof(double) * n, s);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->z, 0, sizeof(double) * ld, s);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->beta, 0, sizeof(double) * ld, s);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->zprev, 0, sizeof(double) * ld, s);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->gprev, 0, sizeof(double) * ld, s);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->g, 0, sizeof(double) * (ld + 16), s);
+    if (e3 == hipSuccess) e3 = hipStreamSynchronize(s);
+    if (e3 != hipSuccess) rc = fail(SLM_ERR_HIP, "memset: %s", hipGetErrorString(e3));
+  }
+  if (rc != SLM_OK) {
+    dataset_free(ds);
+    return rc;
+  }
+  *out = ds;
+  return SLM_OK;
+}
+
+static int upload_row_weights(slm_dataset* ds, const double* rw_host) {
+  ds->L_valid = false;
+  if (!rw_host) {
+    dfree(ds->rw);
+    return SLM_OK;
+  }
+  for (int64_t i = 0; i < ds->n; ++i)
+    if (!(rw_host[i] >= 0.0)) return fail(SLM_ERR_BAD_ARG, "row_weight[%lld] is negative or NaN", (long long)i);
+  if (!ds->rw) SLM_TRY(dalloc(&ds->rw, ds->n));
+  HIP_TRY(hipMemcpy(ds->rw, rw_host, sizeof(double) * ds->n, hipMemcpyHostToDevice));
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_create(slm_engine* eng, const double* X, int64_t n, int64_t p,
+                                  int64_t row_stride, int64_t col_stride, const double* y,
+                                  const double* row_weight, slm_dataset** out) {
+  if (!eng || !X || !y || !out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(eng->device));
+  const bool c_order = (col_stride == 1 || p == 1) && (row_stride >= p || n == 1);
+  const bool f_order = !c_order && (row_stride == 1 || n == 1) && col_stride >= n;
+  if (!c_order && !f_order)
+    return fail(SLM_ERR_BAD_ARG, "X must be C- or F-contiguous along one axis (strides %lld, %lld)",
+                (long long)row_stride, (long long)col_stride);
+  slm_dataset* ds = nullptr;
+  SLM_TRY(dataset_alloc(eng, n, p, &ds));
+  int rc = SLM_OK;
+  hipError_t e = hipSuccess;
+  if (c_order) {
+    const int64_t rs = (n == 1) ? p : row_stride;
+    e = hipMemcpy2D(ds->X, sizeof(double) * ds->ld, X, sizeof(double) * rs, sizeof(double) * p, n,
+                    hipMemcpyHostToDevice);
+  } else {
+    double* tmp = nullptr;
+    const int64_t cs = (p == 1) ? n : col_stride;
+    rc = dalloc(&tmp, (size_t)n * p);
+    if (rc == SLM_OK) {
+      e = hipMemcpy2D(tmp, sizeof(double) * n, X, sizeof(double) * cs, sizeof(double) * n, p,
+                      hipMemcpyHostToDevice);
+      if (e == hipSuccess) {
+        dim3 grid((unsigned)((n + 31) / 32), (unsigned)((p + 31) / 32));
+        hipLaunchKernelGGL(transpose_f2c_kernel, grid, dim3(256), 0, eng->stream, tmp, n, p, ds->X, ds->ld);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(eng->stream);
+      }
+      dfree(tmp);
+    }
+  }
+  if (rc == SLM_OK && e != hipSuccess) rc = fail(SLM_ERR_HIP, "upload of X failed: %s", hipGetErrorString(e));
+  if (rc == SLM_OK) {
+    e = hipMemcpy(ds->y, y, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(SLM_ERR_HIP, "upload of y failed: %s", hipGetErrorString(e));
+  }
+  if (rc == SLM_OK) rc = upload_row_weights(ds, row_weight);
+  if (rc != SLM_OK) {
+    dataset_free(ds);
+    return rc;
+  }
+  *out = ds;
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_create_device(slm_engine* eng, const double* dX, int64_t n, int64_t p,
+                                         int64_t ld_in, const double* dy, const double* d_row_weight,
+                                         slm_dataset** out) {
+  if (!eng || !dX || !dy || !out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  *out = nullptr;
+  if (ld_in < p) return fail(SLM_ERR_BAD_ARG, "ld (%lld) < p (%lld)", (long long)ld_in, (long long)p);
+  HIP_TRY(hipSetDevice(eng->device));
+  slm_dataset* ds = nullptr;
+  SLM_TRY(dataset_alloc(eng, n, p, &ds));
+  hipError_t e = hipMemcpy2DAsync(ds->X, sizeof(double) * ds->ld, dX, sizeof(double) * ld_in,
+                                  sizeof(double) * p, n, hipMemcpyDeviceToDevice, eng->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(ds->y, dy, sizeof(double) * n, hipMemcpyDeviceToDevice, eng->stream);
+  int rc = SLM_OK;
+  if (e == hipSuccess && d_row_weight) {
+    rc = dalloc(&ds->rw, n);
+    if (rc == SLM_OK)
+      e = hipMemcpyAsync(ds->rw, d_row_weight, sizeof(double) * n, hipMemcpyDeviceToDevice, eng->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(eng->stream);
+  if (rc == SLM_OK && e != hipSuccess) rc = fail(SLM_ERR_HIP, "device copy failed: %s", hipGetErrorString(e));
+  if (rc != SLM_OK) {
+    dataset_free(ds);
+    return rc;
+  }
+  *out = ds;
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_create_synthetic(slm_engine* eng, int64_t n, int64_t p, uint64_t seed,
+                                            int64_t row_offset, const double* coef, double noise_sd,
+                                            slm_dataset** out) {
+  if (!eng || !coef || !out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(eng->device));
+  slm_dataset* ds = nullptr;
+  SLM_TRY(dataset_alloc(eng, n, p, &ds));
+  // coef rides in ds->u for the duration of the generation
+  hipError_t e = hipMemcpy(ds->u, coef, sizeof(double) * p, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    const int blocks = eng->cus * 8;
+    hipLaunchKernelGGL(synth_x_kernel, dim3(blocks), dim3(256), 0, eng->stream, ds->X, n, p, ds->ld, seed,
+                       row_offset);
+    hipLaunchKernelGGL(synth_y_kernel, dim3(blocks), dim3(256), 0, eng->stream, ds->X, n, p, ds->ld, ds->u,
+                       noise_sd, seed, row_offset, ds->y);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(eng->stream);
+  }
+  if (e != hipSuccess) {
+    dataset_free(ds);
+    return fail(SLM_ERR_HIP, "synthetic generation failed: %s", hipGetErrorString(e));
+  }
+  *out = ds;
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_destroy(slm_dataset* ds) {
+  if (!ds) return SLM_OK;
+  (void)hipSetDevice(ds->eng->device);
+  (void)hipStreamSynchronize(ds->eng->stream);
+  dataset_free(ds);
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_shape(slm_dataset* ds, int64_t* n, int64_t* p, int64_t* ld) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  if (n) *n = ds->n;
+  if (p) *p = ds->p;
+  if (ld) *ld = ds->ld;
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_download(slm_dataset* ds, double* X_out, double* y_out) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  HIP_TRY(hipStreamSynchronize(ds->eng->stream));
+  if (X_out)
+    HIP_TRY(hipMemcpy2D(X_out, sizeof(double) * ds->p, ds->X, sizeof(double) * ds->ld,
+                        sizeof(double) * ds->p, ds->n, hipMemcpyDeviceToHost));
+  if (y_out) HIP_TRY(hipMemcpy(y_out, ds->y, sizeof(double) * ds->n, hipMemcpyDeviceToHost));
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_set_row_weights(slm_dataset* ds, const double* row_weight) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  HIP_TRY(hipStreamSynchronize(ds->eng->stream));
+  return upload_row_weights(ds, row_weight);
+}
+
+extern "C" int slm_dataset_set_global_rows(slm_dataset* ds, int64_t n_global) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  if (n_global < ds->n) return fail(SLM_ERR_BAD_ARG, "n_global (%lld) < local rows (%lld)",
+                                     (long long)n_global, (long long)ds->n);
+  ds->n_global = n_global;
+  ds->L_valid = false;
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_set_groups(slm_dataset* ds, const int32_t* gid, int32_t n_groups) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  HIP_TRY(hipStreamSynchronize(ds->eng->stream));
+  if (!gid) return set_singleton_groups(ds);
+  const int p = (int)ds->p;
+  if (n_groups <= 0 || n_groups > p)
+    return fail(SLM_ERR_BAD_ARG, "n_groups = %d must be in [1, p = %d]", n_groups, p);
+  std::vector<int> count(n_groups, 0);
+  for (int j = 0; j < p; ++j) {
+    if (gid[j] < 0 || gid[j] >= n_groups)
+      return fail(SLM_ERR_BAD_ARG, "gid[%d] = %d outside [0, %d)", j, gid[j], n_groups);
+    count[gid[j]]++;
+  }
+  std::vector<int> start(n_groups + 1, 0);
+  int max_size = 1;
+  for (int g = 0; g < n_groups; ++g) {
+    start[g + 1] = start[g] + count[g];
+    max_size = std::max(max_size, count[g]);
+  }
+  std::vector<int> order(p), gsorted(p), fill(start.begin(), start.end() - 1);
+  for (int j = 0; j < p; ++j) {  // stable: members keep their feature order inside a group
+    const int k = fill[gid[j]]++;
+    order[k] = j;
+    gsorted[k] = gid[j];
+  }
+  int team = 1;
+  while (team < max_size && team < 64) team <<= 1;
+  dfree(ds->order); dfree(ds->gsorted); dfree(ds->gstart); dfree(ds->gscale);
+  SLM_TRY(dalloc(&ds->order, p));
+  SLM_TRY(dalloc(&ds->gsorted, p));
+  SLM_TRY(dalloc(&ds->gstart, n_groups + 1));
+  SLM_TRY(dalloc(&ds->gscale, n_groups));
+  HIP_TRY(hipMemcpy(ds->order, order.data(), sizeof(int) * p, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ds->gsorted, gsorted.data(), sizeof(int) * p, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ds->gstart, start.data(), sizeof(int) * (n_groups + 1), hipMemcpyHostToDevice));
+  ds->G = n_groups;
+  ds->singleton = 0;
+  ds->team = team;
+  return SLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launches
+// ------------------------------------------------------------------------------------------------
+static GradArgs make_grad_args(slm_dataset* ds, const double* y, const double* z, const int* done) {
+  GradArgs a;
+  a.X = ds->X;
+  a.y = y;
+  a.rw = ds->rw;
+  a.z = z;
+  a.partial = ds->partial;
+  a.loss_partial = ds->loss_partial;
+  a.done = done;
+  a.n = ds->n;
+  a.ld = ds->ld;
+  a.rows_base = ds->n / ds->nblk;
+  a.rows_rem = ds->n % ds->nblk;
+  a.p2 = (int)(ds->ld / 2);
+  return a;
+}
+
+static inline void launch_grad(slm_dataset* ds, const GradArgs& a) {
+  hipLaunchKernelGGL(ds->gk->fn, dim3(ds->nblk), dim3(ds->gk->W * 64), 0, ds->eng->stream, a);
+}
+
+// grad -> reduce (-> all-reduce).  g = X^T W (X z - y) / n_global in ds->g, loss in ds->g[ld].
+static int enqueue_gradient(slm_dataset* ds, const double* y, const double* z, const int* done,
+                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+  hipStream_t s = ds->eng->stream;
+  GradArgs ga = make_grad_args(ds, y, z, done);
+  if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
+  launch_grad(ds, ga);
+  if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
+  ReduceArgs ra;
+  ra.partial = ds->partial;
+  ra.loss_partial = ds->loss_partial;
+  ra.g = ds->g;
+  ra.done = done;
+  ra.nblk = ds->nblk;
+  ra.ld = ds->ld;
+  ra.scale = 1.0 / (double)ds->n_global;
+  ra.loss_scale = 0.5 / (double)ds->n_global;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(ds->ld / 16 + 1)), dim3(256), 0, s, ra);
+  if (ds->eng->comm && ds->eng->n_ranks > 1) {
+    RCCL_TRY(g_rccl.AllReduce(ds->g, ds->g, (size_t)(ds->ld + 16), kNcclFloat64, kNcclSum, ds->eng->comm, s));
+  }
+  return SLM_OK;
+}
+
+static int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SLM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return SLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lipschitz constant
+// ------------------------------------------------------------------------------------------------
+static int estimate_lipschitz(slm_dataset* ds, double* L_out) {
+  if (ds->L_valid) {
+    *L_out = ds->L;
+    return SLM_OK;
+  }
+  hipStream_t s = ds->eng->stream;
+  int iters = 16;
+  if (const char* env = getenv("SLM_POWER_ITERS")) iters = std::max(2, atoi(env));
+  hipLaunchKernelGGL(power_init_kernel, dim3(1), dim3(TAIL_THREADS), 0, s, ds->z, (int)ds->p, ds->ld);
+  for (int k = 0; k < iters; ++k) {
+    SLM_TRY(enqueue_gradient(ds, ds->yzero, ds->z, nullptr, nullptr, nullptr));
+    PowerArgs pa;
+    pa.g = ds->g;
+    pa.v = ds->z;
+    pa.lambda = ds->lambda;
+    pa.p = (int)ds->p;
+    hipLaunchKernelGGL(power_step_kernel, dim3(1), dim3(TAIL_THREADS), 0, s, pa);
+  }
+  SLM_TRY(check_launch());
+  double lam = 0.0;
+  HIP_TRY(hipMemcpyAsync(&lam, ds->lambda, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (!std::isfinite(lam)) return fail(SLM_ERR_NON_FINITE, "power iteration produced a non-finite value");
+  // ||A v|| after k steps under-estimates lambda_max by a few per cent on flat spectra; the margin
+  // below plus the in-loop curvature guard (fista_tail_kernel) keep the step 1/L safe.
+  double L = lam * 1.05;
+  if (!(L > 0.0)) L = 1.0;  // X == 0
+  ds->L = L;
+  ds->L_valid = true;
+  *L_out = L;
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_lipschitz(slm_dataset* ds, double* L_out) {
+  if (!ds || !L_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  return estimate_lipschitz(ds, L_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// single gradient evaluation (tests, alpha_max, roofline probe)
+// ------------------------------------------------------------------------------------------------
+extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, double* loss_out,
+                            int32_t reps, double* ms_out) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  hipStream_t s = ds->eng->stream;
+  HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * ds->ld, s));
+  if (z) HIP_TRY(hipMemcpyAsync(ds->z, z, sizeof(double) * ds->p, hipMemcpyHostToDevice, s));
+  SLM_TRY(enqueue_gradient(ds, ds->y, ds->z, nullptr, nullptr, nullptr));
+  SLM_TRY(check_launch());
+  HIP_TRY(hipStreamSynchronize(s));
+  if (g_out) HIP_TRY(hipMemcpy(g_out, ds->g, sizeof(double) * ds->p, hipMemcpyDeviceToHost));
+  if (loss_out) HIP_TRY(hipMemcpy(loss_out, ds->g + ds->ld, sizeof(double), hipMemcpyDeviceToHost));
+  if (ms_out) {
+    *ms_out = 0.0;
+    if (reps < 1) reps = 1;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    GradArgs ga = make_grad_args(ds, ds->y, ds->z, nullptr);
+    launch_grad(ds, ga);  // warm
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) launch_grad(ds, ga);
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = (double)ms / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    SLM_TRY(check_launch());
+  }
+  return SLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// path solve
+// ------------------------------------------------------------------------------------------------
+static int upload_vec_or_const(double* dst, const double* src, int64_t count, double fill, hipStream_t s,
+                               std::vector<double>& scratch) {
+  if (src) {
+    for (int64_t i = 0; i < count; ++i)
+      if (!(src[i] >= 0.0) || !std::isfinite(src[i]))
+        return fail(SLM_ERR_BAD_ARG, "penalty weights must be finite and >= 0 (index %lld)", (long long)i);
+    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyHostToDevice, s));
+  } else {
+    scratch.assign((size_t)count, fill);
+    HIP_TRY(hipMemcpyAsync(dst, scratch.data(), sizeof(double) * count, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // scratch is reused
+  }
+  return SLM_OK;
+}
+
+extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,
+                              int32_t n_points, const slm_solve_opts* opts, const double* beta0,
+                              double* betas_out, double* group_norms_out, slm_point_info* infos,
+                              slm_solve_stats* stats) {
+  if (!ds || !points || !betas_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  if (n_points <= 0) return fail(SLM_ERR_BAD_ARG, "n_points must be positive");
+  for (int k = 0; k < n_points; ++k) {
+    const slm_path_point& q = points[k];
+    if (!(q.sa >= 0.0) || !(q.sb >= 0.0) || !(q.sd >= 0.0) || !std::isfinite(q.sa + q.sb + q.sd))
+      return fail(SLM_ERR_BAD_ARG, "path point %d has a negative or non-finite scale", k);
+  }
+  slm_engine* eng = ds->eng;
+  HIP_TRY(hipSetDevice(eng->device));
+  hipStream_t s = eng->stream;
+  const auto t_begin = std::chrono::steady_clock::now();
+  const int64_t p = ds->p, ld = ds->ld;
+  const int G = ds->G;
+
+  slm_solve_opts o;
+  memset(&o, 0, sizeof(o));
+  if (opts) o = *opts;
+  if (!(o.tol > 0.0)) o.tol = 1e-8;
+  if (o.max_iter <= 0) o.max_iter = 10000;
+  const bool profile = (o.flags & SLM_FLAG_PROFILE) != 0;
+
+  // ---- Lipschitz constant ------------------------------------------------------------------
+  double L = o.L;
+  double lipschitz_ms = 0.0;
+  if (!(L > 0.0)) {
+    const bool cached = ds->L_valid;
+    const auto t0 = std::chrono::steady_clock::now();
+    SLM_TRY(estimate_lipschitz(ds, &L));
+    if (!cached)
+      lipschitz_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+
+  // ---- buffers -----------------------------------------------------------------------------
+  if (n_points > ds->cap_points) {
+    dfree(ds->pts); dfree(ds->betas_out); dfree(ds->infos);
+    ds->cap_points = 0;
+    SLM_TRY(dalloc(&ds->pts, n_points));
+    SLM_TRY(dalloc(&ds->betas_out, (size_t)n_points * p));
+    SLM_TRY(dalloc(&ds->infos, n_points));
+    ds->cap_points = n_points;
+  }
+  if (group_norms_out && (int64_t)n_points * G > ds->cap_gn) {
+    dfree(ds->gn_out);
+    ds->cap_gn = 0;
+    SLM_TRY(dalloc(&ds->gn_out, (size_t)n_points * G));
+    ds->cap_gn = (int)std::min<int64_t>((int64_t)n_points * G, 2147483647);
+  }
+  std::vector<double> scratch;
+  SLM_TRY(upload_vec_or_const(ds->a0, pen ? pen->a : nullptr, p, 1.0, s, scratch));
+  SLM_TRY(upload_vec_or_const(ds->b0, pen ? pen->b : nullptr, G, 1.0, s, scratch));
+  SLM_TRY(upload_vec_or_const(ds->d0, pen ? pen->d : nullptr, G, 1.0, s, scratch));
+  HIP_TRY(hipMemcpyAsync(ds->pts, points, sizeof(slm_path_point) * n_points, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(ds->beta, 0, sizeof(double) * ld, s));
+  if (beta0) {
+    for (int64_t j = 0; j < p; ++j)
+      if (!std::isfinite(beta0[j])) return fail(SLM_ERR_BAD_ARG, "beta0[%lld] is not finite", (long long)j);
+    HIP_TRY(hipMemcpyAsync(ds->beta, beta0, sizeof(double) * p, hipMemcpyHostToDevice, s));
+  }
+  HIP_TRY(hipMemcpyAsync(ds->z, ds->beta, sizeof(double) * ld, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemsetAsync(ds->zprev, 0, sizeof(double) * ld, s));
+  HIP_TRY(hipMemsetAsync(ds->gprev, 0, sizeof(double) * ld, s));
+  HIP_TRY(hipMemsetAsync(ds->infos, 0, sizeof(slm_point_info) * n_points, s));
+
+  PathCtl h;
+  memset(&h, 0, sizeof(h));
+  h.n_points = n_points;
+  h.max_iter = o.max_iter;
+  h.t = 1.0;
+  h.L = L;
+  h.tol = o.tol;
+  h.flags = o.flags;
+  HIP_TRY(hipMemcpyAsync(ds->ctl, &h, sizeof(PathCtl), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // host staging buffers (h, points, beta0) are free again
+
+  TailArgs ta;
+  ta.ctl = ds->ctl;
+  ta.pts = ds->pts;
+  ta.p = (int)p;
+  ta.G = G;
+  ta.singleton = ds->singleton;
+  ta.team = ds->team;
+  ta.beta = ds->beta;
+  ta.z = ds->z;
+  ta.g = ds->g;
+  ta.ld = ld;
+  ta.zprev = ds->zprev;
+  ta.gprev = ds->gprev;
+  ta.u = ds->u;
+  ta.gscale = ds->gscale;
+  ta.a0 = ds->a0;
+  ta.b0 = ds->b0;
+  ta.d0 = ds->d0;
+  ta.order = ds->order;
+  ta.gsorted = ds->gsorted;
+  ta.gstart = ds->gstart;
+  ta.betas_out = ds->betas_out;
+  ta.gn_out = group_norms_out ? ds->gn_out : nullptr;
+  ta.infos = ds->infos;
+
+  // ---- queue iterations; the device decides when each point (and the path) is finished ---------
+  int chunk = o.check_every;
+  if (chunk <= 0) {
+    const double est_us = std::max(12.0, (double)ds->n * (double)ld * 8.0 / 5.0e6);
+    chunk = (int)std::min(32.0, std::max(2.0, 400.0 / est_us));
+  }
+  const int64_t max_total = (int64_t)n_points * o.max_iter;
+  int64_t enq = 0;
+  int slot = 0;
+  bool pending[2] = {false, false};
+  bool done = false;
+  const int* done_flag = &ds->ctl->done;
+  while (!done) {
+    for (int i = 0; i < chunk; ++i) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (profile) {
+        while ((int64_t)ds->prof.size() < 2 * (enq + 1)) {
+          hipEvent_t ev;
+          HIP_TRY(hipEventCreate(&ev));
+          ds->prof.push_back(ev);
+        }
+        e0 = ds->prof[2 * enq];
+        e1 = ds->prof[2 * enq + 1];
+      }
+      SLM_TRY(enqueue_gradient(ds, ds->y, ds->z, done_flag, e0, e1));
+      hipLaunchKernelGGL(fista_tail_kernel, dim3(1), dim3(TAIL_THREADS), 0, s, ta);
+      ++enq;
+    }
+    SLM_TRY(check_launch());
+    HIP_TRY(hipMemcpyAsync(&ds->hctl[slot], ds->ctl, sizeof(PathCtl), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(ds->ev[slot], s));
+    pending[slot] = true;
+    const int other = slot ^ 1;
+    if (pending[other]) {
+      HIP_TRY(hipEventSynchronize(ds->ev[other]));
+      pending[other] = false;
+      if (ds->hctl[other].done) done = true;
+    }
+    slot = other;
+    if (!done && enq >= max_total + 2 * (int64_t)chunk) {
+      HIP_TRY(hipStreamSynchronize(s));
+      return fail(SLM_ERR_HIP, "internal error: path state machine did not terminate");
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  PathCtl fin;
+  HIP_TRY(hipMemcpy(&fin, ds->ctl, sizeof(PathCtl), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(betas_out, ds->betas_out, sizeof(double) * (size_t)n_points * p, hipMemcpyDeviceToHost));
+  if (group_norms_out)
+    HIP_TRY(hipMemcpy(group_norms_out, ds->gn_out, sizeof(double) * (size_t)n_points * G, hipMemcpyDeviceToHost));
+  if (infos) HIP_TRY(hipMemcpy(infos, ds->infos, sizeof(slm_point_info) * n_points, hipMemcpyDeviceToHost));
+  if (stats) {
+    stats->grad_launches = fin.total_iter;
+    stats->grad_ms_total = 0.0;
+    if (profile) {
+      double tot = 0.0;
+      for (int64_t k = 0; k < fin.total_iter && 2 * k + 1 < (int64_t)ds->prof.size(); ++k) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ds->prof[2 * k], ds->prof[2 * k + 1]) == hipSuccess) tot += ms;
+      }
+      stats->grad_ms_total = tot;
+    }
+    stats->lipschitz_ms = lipschitz_ms;
+    stats->wall_ms =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  if (fin.nonfinite)
+    return fail(SLM_ERR_NON_FINITE, "non-finite iterate at path point %d (diverged or non-finite data)",
+                fin.point - 1);
+  return SLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-sharded mode
+// ------------------------------------------------------------------------------------------------
+extern "C" int slm_comm_unique_id(uint8_t id_out[SLM_COMM_ID_BYTES]) {
+  if (!id_out) return fail(SLM_ERR_BAD_ARG, "id_out is NULL");
+  SLM_TRY(load_rccl());
+  rcclUniqueId_t id;
+  RCCL_TRY(g_rccl.GetUniqueId(&id));
+  memcpy(id_out, id.internal, SLM_COMM_ID_BYTES);
+  return SLM_OK;
+}
+
+extern "C" int slm_comm_init(slm_engine* eng, int32_t rank, int32_t n_ranks,
+                             const uint8_t id_in[SLM_COMM_ID_BYTES]) {
+  if (!eng || !id_in) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(SLM_ERR_BAD_ARG, "bad rank %d of %d", rank, n_ranks);
+  if (eng->comm) return fail(SLM_ERR_BAD_ARG, "communicator already initialised");
+  SLM_TRY(load_rccl());
+  HIP_TRY(hipSetDevice(eng->device));
+  rcclUniqueId_t id;
+  memcpy(id.internal, id_in, SLM_COMM_ID_BYTES);
+  RCCL_TRY(g_rccl.CommInitRank(&eng->comm, n_ranks, id, rank));
+  eng->rank = rank;
+  eng->n_ranks = n_ranks;
+  return SLM_OK;
+}
+
+extern "C" int slm_comm_destroy(slm_engine* eng) {
+  if (!eng) return fail(SLM_ERR_BAD_ARG, "engine is NULL");
+  if (eng->comm) {
+    (void)hipSetDevice(eng->device);
+    (void)hipStreamSynchronize(eng->stream);
+    if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(eng->comm);
+    eng->comm = nullptr;
+    eng->n_ranks = 1;
+    eng->rank = 0;
+  }
+  return SLM_OK;
+}

@@ -1,0 +1,477 @@
+"""ctypes binding of the C ABI in ``include/slm_engine.h`` (``libslm_hip.so``).
+
+This is the only place Python touches the HIP engine.  There is no CPU fallback: if the shared
+library is missing, or no gfx950 device is visible, every entry point raises.  The GIL is released
+for the duration of each foreign call (ctypes does that for ``CDLL`` functions).
+
+The boundary mirrors ``CVXRegressor._solve(X, y, solver_options) -> beta`` of the reference
+(src/sparselm/model/_base.py:512-519): ``Dataset`` holds the preprocessed ``(X, y)`` in HBM and
+``Dataset.solve_path`` returns the minimiser(s).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from dataclasses import dataclass
+
+import numpy as np
+
+_LIB_NAME = "libslm_hip.so"
+_LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
+
+SLM_OK = 0
+SLM_ERR_BAD_ARG = 1
+SLM_ERR_OOM = 2
+SLM_ERR_HIP = 3
+SLM_ERR_NO_DEVICE = 4
+SLM_ERR_COMM = 5
+SLM_ERR_NOT_CONVERGED = 6
+SLM_ERR_NON_FINITE = 7
+SLM_ERR_UNSUPPORTED = 8
+
+FLAG_NO_RESTART = 1
+FLAG_PROFILE = 2
+FLAG_COLD_START = 4
+
+COMM_ID_BYTES = 128
+
+# every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "slm_abi_version",
+    "slm_last_error",
+    "slm_device_count",
+    "slm_engine_create",
+    "slm_engine_destroy",
+    "slm_engine_synchronize",
+    "slm_engine_device_info",
+    "slm_dataset_create",
+    "slm_dataset_create_device",
+    "slm_dataset_create_synthetic",
+    "slm_dataset_destroy",
+    "slm_dataset_shape",
+    "slm_dataset_download",
+    "slm_dataset_set_row_weights",
+    "slm_dataset_set_groups",
+    "slm_dataset_lipschitz",
+    "slm_gradient",
+    "slm_solve_path",
+    "slm_comm_unique_id",
+    "slm_comm_init",
+    "slm_dataset_set_global_rows",
+    "slm_comm_destroy",
+)
+
+
+class EngineError(RuntimeError):
+    """HIP / RCCL / device failure reported by the engine."""
+
+
+class NonFiniteError(EngineError):
+    """The iterate became non-finite (counterpart of cvxpy's SolverError / 'infeasible')."""
+
+
+class _PenaltyStruct(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("d", C.c_void_p)]
+
+
+class _PathPoint(C.Structure):
+    _fields_ = [("sa", C.c_double), ("sb", C.c_double), ("sd", C.c_double)]
+
+
+class _SolveOpts(C.Structure):
+    _fields_ = [
+        ("tol", C.c_double),
+        ("max_iter", C.c_int32),
+        ("check_every", C.c_int32),
+        ("L", C.c_double),
+        ("flags", C.c_uint32),
+    ]
+
+
+class _PointInfo(C.Structure):
+    _fields_ = [
+        ("n_iter", C.c_int32),
+        ("status", C.c_int32),
+        ("resid", C.c_double),
+        ("beta_norm", C.c_double),
+        ("loss", C.c_double),
+        ("L", C.c_double),
+    ]
+
+
+class _SolveStats(C.Structure):
+    _fields_ = [
+        ("grad_launches", C.c_int64),
+        ("grad_ms_total", C.c_double),
+        ("wall_ms", C.c_double),
+        ("lipschitz_ms", C.c_double),
+    ]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def library_path() -> str:
+    return os.environ.get("SLM_HIP_LIBRARY", os.path.join(_LIB_DIR, _LIB_NAME))
+
+
+def load_library():
+    """dlopen the engine; raises ``EngineError`` with build instructions if it is missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            raise EngineError(
+                f"{path} not found: build the HIP engine first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or "
+                "`python sparse-lm_amd/build.py`). sparselm_amd has no CPU fallback."
+            )
+        try:
+            lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError as exc:  # missing ROCm runtime etc.
+            raise EngineError(f"cannot load {path}: {exc}") from exc
+        vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+        P = C.POINTER
+        lib.slm_abi_version.restype = C.c_int
+        lib.slm_last_error.restype = C.c_char_p
+        sigs = {
+            "slm_device_count": [P(C.c_int)],
+            "slm_engine_create": [C.c_int, P(vp)],
+            "slm_engine_destroy": [vp],
+            "slm_engine_synchronize": [vp],
+            "slm_engine_device_info": [vp, P(i64), C.c_char_p, C.c_int],
+            "slm_dataset_create": [vp, vp, i64, i64, i64, i64, vp, vp, P(vp)],
+            "slm_dataset_create_device": [vp, vp, i64, i64, i64, vp, vp, P(vp)],
+            "slm_dataset_create_synthetic": [vp, i64, i64, C.c_uint64, i64, vp, dbl, P(vp)],
+            "slm_dataset_destroy": [vp],
+            "slm_dataset_shape": [vp, P(i64), P(i64), P(i64)],
+            "slm_dataset_download": [vp, vp, vp],
+            "slm_dataset_set_row_weights": [vp, vp],
+            "slm_dataset_set_groups": [vp, vp, i32],
+            "slm_dataset_lipschitz": [vp, P(dbl)],
+            "slm_gradient": [vp, vp, vp, P(dbl), i32, P(dbl)],
+            "slm_solve_path": [
+                vp,
+                P(_PenaltyStruct),
+                P(_PathPoint),
+                i32,
+                P(_SolveOpts),
+                vp,
+                vp,
+                vp,
+                P(_PointInfo),
+                P(_SolveStats),
+            ],
+            "slm_comm_unique_id": [vp],
+            "slm_comm_init": [vp, i32, i32, vp],
+            "slm_dataset_set_global_rows": [vp, i64],
+            "slm_comm_destroy": [vp],
+        }
+        for name, argtypes in sigs.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        _lib = lib
+        return lib
+
+
+def _check(rc: int):
+    if rc == SLM_OK:
+        return
+    msg = (_lib.slm_last_error() or b"").decode("utf-8", "replace")
+    if rc == SLM_ERR_BAD_ARG:
+        raise ValueError(msg)
+    if rc == SLM_ERR_OOM:
+        raise MemoryError(msg)
+    if rc == SLM_ERR_NON_FINITE:
+        raise NonFiniteError(msg)
+    if rc == SLM_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise EngineError(f"[slm status {rc}] {msg}")
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = C.c_int(0)
+    rc = lib.slm_device_count(C.byref(n))
+    return n.value if rc == SLM_OK else 0
+
+
+def _f64(arr, name, shape=None):
+    a = np.ascontiguousarray(arr, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"{name} has shape {a.shape}, expected {shape}")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class PathResult:
+    betas: np.ndarray  # (n_points, p)
+    group_norms: np.ndarray | None  # (n_points, G)
+    n_iter: np.ndarray  # (n_points,)
+    status: np.ndarray  # (n_points,) SLM_OK or SLM_ERR_NOT_CONVERGED
+    resid: np.ndarray
+    beta_norm: np.ndarray
+    loss: np.ndarray
+    L: float
+    grad_launches: int
+    grad_ms_total: float
+    wall_ms: float
+    lipschitz_ms: float
+
+    @property
+    def converged(self) -> bool:
+        return bool(np.all(self.status == SLM_OK))
+
+
+class Engine:
+    """One engine per (process, device): owns a HIP stream and, optionally, an RCCL communicator."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        _check(self._lib.slm_engine_create(int(device_id), C.byref(h)))
+        self._h = h
+        self.device_id = int(device_id)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.slm_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self._lib.slm_engine_synchronize(self._h))
+
+    def device_info(self) -> dict:
+        out = (C.c_int64 * 6)()
+        name = C.create_string_buffer(256)
+        _check(self._lib.slm_engine_device_info(self._h, out, name, 256))
+        return {
+            "name": name.value.decode(),
+            "compute_units": out[0],
+            "lds_bytes_per_cu": out[1],
+            "hbm_total_bytes": out[2],
+            "hbm_free_bytes": out[3],
+            "wavefront": out[4],
+            "clock_khz": out[5],
+        }
+
+    # -- datasets -----------------------------------------------------------------------------
+    def dataset(self, X, y, row_weight=None) -> "Dataset":
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError("X must be 2-D")
+        if not (X.flags.c_contiguous or X.flags.f_contiguous):
+            X = np.ascontiguousarray(X)
+        n, p = X.shape
+        y = _f64(y, "y", (n,))
+        rw = None if row_weight is None else _f64(row_weight, "row_weight", (n,))
+        rs, cs = (X.strides[0] // 8, X.strides[1] // 8)
+        if X.flags.c_contiguous:
+            rs, cs = p, 1
+        elif X.flags.f_contiguous:
+            rs, cs = 1, n
+        h = C.c_void_p()
+        _check(self._lib.slm_dataset_create(self._h, _ptr(X), n, p, rs, cs, _ptr(y), _ptr(rw), C.byref(h)))
+        return Dataset(self, h, n, p)
+
+    def dataset_from_device(self, dX_ptr: int, n: int, p: int, ld: int, dy_ptr: int, drw_ptr: int = 0):
+        h = C.c_void_p()
+        _check(
+            self._lib.slm_dataset_create_device(
+                self._h, C.c_void_p(dX_ptr), n, p, ld, C.c_void_p(dy_ptr), C.c_void_p(drw_ptr or None), C.byref(h)
+            )
+        )
+        return Dataset(self, h, n, p)
+
+    def synthetic_dataset(self, n, p, seed, coef, noise_sd=0.0, row_offset=0) -> "Dataset":
+        coef = _f64(coef, "coef", (p,))
+        h = C.c_void_p()
+        _check(
+            self._lib.slm_dataset_create_synthetic(
+                self._h, n, p, C.c_uint64(seed), row_offset, _ptr(coef), float(noise_sd), C.byref(h)
+            )
+        )
+        return Dataset(self, h, n, p)
+
+    # -- row-sharded mode -----------------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        _check(self._lib.slm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, rank: int, n_ranks: int, unique_id: bytes):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be 128 bytes")
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(self._lib.slm_comm_init(self._h, rank, n_ranks, buf))
+
+    def comm_destroy(self):
+        _check(self._lib.slm_comm_destroy(self._h))
+
+
+class Dataset:
+    """Device-resident (X, y[, row weights][, groups]) plus the solver state that goes with it."""
+
+    def __init__(self, engine: Engine, handle, n: int, p: int):
+        self.engine = engine
+        self._lib = engine._lib
+        self._h = handle
+        self.n, self.p = int(n), int(p)
+        self.n_groups = self.p
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.slm_dataset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def ld(self) -> int:
+        n, p, ld = C.c_int64(), C.c_int64(), C.c_int64()
+        _check(self._lib.slm_dataset_shape(self._h, C.byref(n), C.byref(p), C.byref(ld)))
+        return ld.value
+
+    def download(self, want_X=True, want_y=True):
+        X = np.empty((self.n, self.p)) if want_X else None
+        y = np.empty(self.n) if want_y else None
+        _check(self._lib.slm_dataset_download(self._h, _ptr(X), _ptr(y)))
+        return X, y
+
+    def set_row_weights(self, row_weight):
+        rw = None if row_weight is None else _f64(row_weight, "row_weight", (self.n,))
+        _check(self._lib.slm_dataset_set_row_weights(self._h, _ptr(rw)))
+
+    def set_global_rows(self, n_global: int):
+        _check(self._lib.slm_dataset_set_global_rows(self._h, int(n_global)))
+
+    def set_groups(self, gidx, n_groups=None):
+        """``gidx``: dense group index per feature (0..G-1, reference order model/_lasso.py:248)."""
+        if gidx is None:
+            _check(self._lib.slm_dataset_set_groups(self._h, None, 0))
+            self.n_groups = self.p
+            return
+        g = np.ascontiguousarray(gidx, dtype=np.int32)
+        if g.shape != (self.p,):
+            raise ValueError(f"gidx must have shape ({self.p},)")
+        G = int(g.max()) + 1 if n_groups is None else int(n_groups)
+        _check(self._lib.slm_dataset_set_groups(self._h, _ptr(g), G))
+        self.n_groups = G
+
+    def lipschitz(self) -> float:
+        L = C.c_double()
+        _check(self._lib.slm_dataset_lipschitz(self._h, C.byref(L)))
+        return L.value
+
+    def gradient(self, z=None, reps: int = 0):
+        """g = X^T W (X z - y)/n, loss = 1/(2n)||Xz - y||_W^2[, mean kernel ms over ``reps`` launches]."""
+        zz = None if z is None else _f64(z, "z", (self.p,))
+        g = np.empty(self.p)
+        loss = C.c_double()
+        ms = C.c_double()
+        _check(
+            self._lib.slm_gradient(
+                self._h, _ptr(zz), _ptr(g), C.byref(loss), int(reps), C.byref(ms) if reps > 0 else None
+            )
+        )
+        return (g, loss.value, ms.value) if reps > 0 else (g, loss.value)
+
+    def solve_path(
+        self,
+        points,
+        a=None,
+        b=None,
+        d=None,
+        beta0=None,
+        tol: float = 1e-8,
+        max_iter: int = 10000,
+        check_every: int = 0,
+        L: float = 0.0,
+        flags: int = 0,
+        want_group_norms: bool = False,
+    ) -> PathResult:
+        """Warm-started path; ``points`` is (K, 3) of (sa, sb, sd) scales applied to (a, b, d).
+
+        ``a`` (p,), ``b`` (G,), ``d`` (G,): ``None`` means all ones.  K == 1 is the reference's
+        single ``_solve``.
+        """
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        K = pts.shape[0]
+        G = self.n_groups
+        a_ = None if a is None else _f64(np.broadcast_to(a, (self.p,)), "a")
+        b_ = None if b is None else _f64(np.broadcast_to(b, (G,)), "b")
+        d_ = None if d is None else _f64(np.broadcast_to(d, (G,)), "d")
+        b0 = None if beta0 is None else _f64(beta0, "beta0", (self.p,))
+        pen = _PenaltyStruct(_ptr(a_), _ptr(b_), _ptr(d_))
+        cpts = (_PathPoint * K)(*[_PathPoint(*row) for row in pts])
+        opts = _SolveOpts(float(tol), int(max_iter), int(check_every), float(L), int(flags))
+        betas = np.empty((K, self.p))
+        gn = np.empty((K, G)) if want_group_norms else None
+        infos = (_PointInfo * K)()
+        stats = _SolveStats()
+        _check(
+            self._lib.slm_solve_path(
+                self._h, C.byref(pen), cpts, K, C.byref(opts), _ptr(b0), _ptr(betas), _ptr(gn), infos, C.byref(stats)
+            )
+        )
+        return PathResult(
+            betas=betas,
+            group_norms=gn,
+            n_iter=np.array([i.n_iter for i in infos]),
+            status=np.array([i.status for i in infos]),
+            resid=np.array([i.resid for i in infos]),
+            beta_norm=np.array([i.beta_norm for i in infos]),
+            loss=np.array([i.loss for i in infos]),
+            L=float(infos[K - 1].L),
+            grad_launches=int(stats.grad_launches),
+            grad_ms_total=float(stats.grad_ms_total),
+            wall_ms=float(stats.wall_ms),
+            lipschitz_ms=float(stats.lipschitz_ms),
+        )
+
+
+# -- default engine per process / device ------------------------------------------------------------
+_engines: dict[tuple[int, int], Engine] = {}
+_engines_lock = threading.Lock()
+
+
+def get_engine(device_id: int | None = None) -> Engine:
+    """Process-wide engine for ``device_id`` (default: ``LOCAL_RANK`` or 0).  Fork-safe by keying on pid."""
+    if device_id is None:
+        device_id = int(os.environ.get("SLM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = device_count()
+        if n > 0:
+            device_id %= n
+    key = (os.getpid(), int(device_id))
+    with _engines_lock:
+        eng = _engines.get(key)
+        if eng is None:
+            eng = Engine(device_id)
+            _engines[key] = eng
+        return eng
