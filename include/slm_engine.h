@@ -134,6 +134,7 @@ typedef struct slm_path_point {
 #define SLM_FLAG_NO_RESTART 1u   /* disable the gradient-scheme momentum restart        */
 #define SLM_FLAG_PROFILE 2u      /* bracket every gradient launch with HIP events        */
 #define SLM_FLAG_COLD_START 4u   /* do not warm-start point k+1 from point k             */
+#define SLM_FLAG_FRESH_L 8u      /* re-estimate the Lipschitz constant even if cached     */
 
 typedef struct slm_solve_opts {
   double tol;          /* stop when ||beta+ - z||_2 <= tol * ||beta+||_2; <= 0 => 1e-8   */

@@ -64,7 +64,7 @@ double oracle_gradient(const double* X, int64_t n, int64_t p, int64_t ld, const 
 
 static double soft(double v, double thr) {
   const double m = fabs(v) - thr;
-  return m > 0.0 ? copysign(m, v) : 0.0;
+  return m <= 0.0 ? 0.0 : copysign(m, v);
 }
 
 /* out = prox_{step * penalty}(v) */

@@ -784,6 +784,7 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
   double L = o.L;
   double lipschitz_ms = 0.0;
   if (!(L > 0.0)) {
+    if (o.flags & SLM_FLAG_FRESH_L) ds->L_valid = false;
     const bool cached = ds->L_valid;
     const auto t0 = std::chrono::steady_clock::now();
     SLM_TRY(estimate_lipschitz(ds, &L));

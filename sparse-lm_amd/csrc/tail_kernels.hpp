@@ -69,7 +69,7 @@ struct TailArgs {
 
 __device__ __forceinline__ double soft(double v, double thr) {
   const double m = fabs(v) - thr;
-  return m > 0.0 ? copysign(m, v) : 0.0;
+  return m <= 0.0 ? 0.0 : copysign(m, v);  // NaN propagates (NaN <= 0 is false)
 }
 
 // Sum NV values over the 1024-thread workgroup; every thread gets bit-identical totals.
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   block_sum<7>(s, red);
 
   // ---- phase 4: uniform decisions -------------------------------------------------------------
-  const bool nonfinite = s[6] > 0.0 || !isfinite(s[0]);
+  const bool nonfinite = s[6] > 0.0 || !isfinite(s[0]) || !isfinite(s[1]) || !isfinite(a.g[a.ld]);
   // Curvature guard: ||A dz|| / ||dz|| is a lower bound on lambda_max(A), A = X^T W X / n.  If it
   // exceeds L the step 1/L was too long: raise L, discard the step and restart from beta.
   bool l_bad = false;

@@ -34,6 +34,7 @@ SLM_ERR_UNSUPPORTED = 8
 FLAG_NO_RESTART = 1
 FLAG_PROFILE = 2
 FLAG_COLD_START = 4
+FLAG_FRESH_L = 8
 
 COMM_ID_BYTES = 128
 
