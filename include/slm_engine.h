@@ -126,13 +126,17 @@ typedef struct slm_penalty {
   const double* d; /* length G, per-group ridge weight;    NULL => all ones            */
 } slm_penalty;
 
-/* Penalty at path point k is (sa*a, sb*b, sd*d). */
+/* Penalty at path point k is (sa*a, sb*b, sd*d).  `extrap` (k >= 2 only; 0 = plain warm start)
+   starts point k from beta_{k-1} + extrap * (beta_{k-1} - beta_{k-2}): a secant prediction along
+   the path (exact for the piecewise-linear Lasso path between kinks when
+   extrap = (alpha_k - alpha_{k-1}) / (alpha_{k-1} - alpha_{k-2})).  It only moves the starting
+   point; the solution of point k is unaffected. */
 typedef struct slm_path_point {
-  double sa, sb, sd;
+  double sa, sb, sd, extrap;
 } slm_path_point;
 
 #define SLM_FLAG_NO_RESTART 1u   /* disable the gradient-scheme momentum restart        */
-#define SLM_FLAG_PROFILE 2u      /* bracket every gradient launch with HIP events        */
+#define SLM_FLAG_PROFILE 2u      /* bracket every 4th gradient launch with HIP events     */
 #define SLM_FLAG_COLD_START 4u   /* do not warm-start point k+1 from point k             */
 #define SLM_FLAG_FRESH_L 8u      /* re-estimate the Lipschitz constant even if cached     */
 
@@ -155,7 +159,8 @@ typedef struct slm_point_info {
 
 typedef struct slm_solve_stats {
   int64_t grad_launches;  /* gradient kernels that did work                              */
-  double grad_ms_total;   /* sum of their device durations (SLM_FLAG_PROFILE only)       */
+  int64_t grad_timed;     /* how many of them were bracketed by events (SLM_FLAG_PROFILE) */
+  double grad_ms_total;   /* sum of the device durations of the timed ones               */
   double wall_ms;         /* host wall clock of the call                                 */
   double lipschitz_ms;    /* part of wall_ms spent estimating L (0 if cached / given)    */
 } slm_solve_stats;

@@ -122,6 +122,7 @@ static const GradKernel kGradExtra[] = {
     SLM_GK(2, 10, 2), SLM_GK(1, 2, 4), SLM_GK(2, 2, 4), SLM_GK(4, 2, 4),  SLM_GK(4, 3, 4),
     SLM_GK(4, 4, 4),
 };
+static const int kProfStride = 4;  // SLM_FLAG_PROFILE times every 4th gradient launch
 static const int64_t kMaxChunks = 64 * 8 * 10;  // largest row the fused kernel covers (p <= 10240)
 
 static const GradKernel* pick_grad_kernel(int64_t p2) {
@@ -159,7 +160,7 @@ struct slm_dataset {
   double *X = nullptr, *y = nullptr, *rw = nullptr, *yzero = nullptr;
   // group structure (group-sorted permutation)
   int G = 0, singleton = 1, team = 1;
-  int *order = nullptr, *gsorted = nullptr, *gstart = nullptr;
+  int *order = nullptr, *gid = nullptr, *gstart = nullptr;
   // gradient launch
   const GradKernel* gk = nullptr;
   int nblk = 0;
@@ -291,7 +292,7 @@ extern "C" int slm_engine_device_info(slm_engine* eng, int64_t out[6], char* nam
 static void dataset_free(slm_dataset* ds) {
   if (!ds) return;
   dfree(ds->X); dfree(ds->y); dfree(ds->rw); dfree(ds->yzero);
-  dfree(ds->order); dfree(ds->gsorted); dfree(ds->gstart);
+  dfree(ds->order); dfree(ds->gid); dfree(ds->gstart);
   dfree(ds->partial); dfree(ds->loss_partial);
   dfree(ds->g); dfree(ds->z); dfree(ds->beta); dfree(ds->zprev); dfree(ds->gprev);
   dfree(ds->u); dfree(ds->gscale); dfree(ds->a0); dfree(ds->b0); dfree(ds->d0);
@@ -309,13 +310,13 @@ static int set_singleton_groups(slm_dataset* ds) {
   std::vector<int> ident(p), start(p + 1);
   std::iota(ident.begin(), ident.end(), 0);
   std::iota(start.begin(), start.end(), 0);
-  dfree(ds->order); dfree(ds->gsorted); dfree(ds->gstart); dfree(ds->gscale);
+  dfree(ds->order); dfree(ds->gid); dfree(ds->gstart); dfree(ds->gscale);
   SLM_TRY(dalloc(&ds->order, p));
-  SLM_TRY(dalloc(&ds->gsorted, p));
+  SLM_TRY(dalloc(&ds->gid, p));
   SLM_TRY(dalloc(&ds->gstart, p + 1));
   SLM_TRY(dalloc(&ds->gscale, p));
   HIP_TRY(hipMemcpy(ds->order, ident.data(), sizeof(int) * p, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ds->gsorted, ident.data(), sizeof(int) * p, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ds->gid, ident.data(), sizeof(int) * p, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ds->gstart, start.data(), sizeof(int) * (p + 1), hipMemcpyHostToDevice));
   ds->G = p;
   ds->singleton = 1;
@@ -582,21 +583,17 @@ extern "C" int slm_dataset_set_groups(slm_dataset* ds, const int32_t* gid, int32
     start[g + 1] = start[g] + count[g];
     max_size = std::max(max_size, count[g]);
   }
-  std::vector<int> order(p), gsorted(p), fill(start.begin(), start.end() - 1);
-  for (int j = 0; j < p; ++j) {  // stable: members keep their feature order inside a group
-    const int k = fill[gid[j]]++;
-    order[k] = j;
-    gsorted[k] = gid[j];
-  }
+  std::vector<int> order(p), fill(start.begin(), start.end() - 1);
+  for (int j = 0; j < p; ++j) order[fill[gid[j]]++] = j;  // stable inside a group
   int team = 1;
   while (team < max_size && team < 64) team <<= 1;
-  dfree(ds->order); dfree(ds->gsorted); dfree(ds->gstart); dfree(ds->gscale);
+  dfree(ds->order); dfree(ds->gid); dfree(ds->gstart); dfree(ds->gscale);
   SLM_TRY(dalloc(&ds->order, p));
-  SLM_TRY(dalloc(&ds->gsorted, p));
+  SLM_TRY(dalloc(&ds->gid, p));
   SLM_TRY(dalloc(&ds->gstart, n_groups + 1));
   SLM_TRY(dalloc(&ds->gscale, n_groups));
   HIP_TRY(hipMemcpy(ds->order, order.data(), sizeof(int) * p, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ds->gsorted, gsorted.data(), sizeof(int) * p, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ds->gid, gid, sizeof(int) * p, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ds->gstart, start.data(), sizeof(int) * (n_groups + 1), hipMemcpyHostToDevice));
   ds->G = n_groups;
   ds->singleton = 0;
@@ -652,6 +649,19 @@ static int enqueue_gradient(slm_dataset* ds, const double* y, const double* z, c
   return SLM_OK;
 }
 
+// E = features per thread of the single-workgroup tail kernel (p <= 1024 * E <= 10240)
+static void launch_tail(const TailArgs& ta, hipStream_t s) {
+  const int E = (ta.p + TAIL_THREADS - 1) / TAIL_THREADS;
+  switch (E) {
+#define SLM_TAIL_CASE(N) \
+  case N: hipLaunchKernelGGL(fista_tail_kernel<N>, dim3(1), dim3(TAIL_THREADS), 0, s, ta); break;
+    SLM_TAIL_CASE(1) SLM_TAIL_CASE(2) SLM_TAIL_CASE(3) SLM_TAIL_CASE(4) SLM_TAIL_CASE(5)
+    SLM_TAIL_CASE(6) SLM_TAIL_CASE(7) SLM_TAIL_CASE(8) SLM_TAIL_CASE(9)
+    default: hipLaunchKernelGGL(fista_tail_kernel<10>, dim3(1), dim3(TAIL_THREADS), 0, s, ta); break;
+#undef SLM_TAIL_CASE
+  }
+}
+
 static int check_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(SLM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -667,7 +677,7 @@ static int estimate_lipschitz(slm_dataset* ds, double* L_out) {
     return SLM_OK;
   }
   hipStream_t s = ds->eng->stream;
-  int iters = 16;
+  int iters = 10;
   if (const char* env = getenv("SLM_POWER_ITERS")) iters = std::max(2, atoi(env));
   hipLaunchKernelGGL(power_init_kernel, dim3(1), dim3(TAIL_THREADS), 0, s, ds->z, (int)ds->p, ds->ld);
   for (int k = 0; k < iters; ++k) {
@@ -686,7 +696,7 @@ static int estimate_lipschitz(slm_dataset* ds, double* L_out) {
   if (!std::isfinite(lam)) return fail(SLM_ERR_NON_FINITE, "power iteration produced a non-finite value");
   // ||A v|| after k steps under-estimates lambda_max by a few per cent on flat spectra; the margin
   // below plus the in-loop curvature guard (fista_tail_kernel) keep the step 1/L safe.
-  double L = lam * 1.05;
+  double L = lam * 1.08;
   if (!(L > 0.0)) L = 1.0;  // X == 0
   ds->L = L;
   ds->L_valid = true;
@@ -765,6 +775,8 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
     const slm_path_point& q = points[k];
     if (!(q.sa >= 0.0) || !(q.sb >= 0.0) || !(q.sd >= 0.0) || !std::isfinite(q.sa + q.sb + q.sd))
       return fail(SLM_ERR_BAD_ARG, "path point %d has a negative or non-finite scale", k);
+    if (!std::isfinite(q.extrap) || std::fabs(q.extrap) > 1e3)
+      return fail(SLM_ERR_BAD_ARG, "path point %d has an unreasonable extrapolation factor", k);
   }
   slm_engine* eng = ds->eng;
   HIP_TRY(hipSetDevice(eng->device));
@@ -847,13 +859,12 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
   ta.ld = ld;
   ta.zprev = ds->zprev;
   ta.gprev = ds->gprev;
-  ta.u = ds->u;
   ta.gscale = ds->gscale;
   ta.a0 = ds->a0;
   ta.b0 = ds->b0;
   ta.d0 = ds->d0;
   ta.order = ds->order;
-  ta.gsorted = ds->gsorted;
+  ta.gid = ds->gid;
   ta.gstart = ds->gstart;
   ta.betas_out = ds->betas_out;
   ta.gn_out = group_norms_out ? ds->gn_out : nullptr;
@@ -874,17 +885,18 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
   while (!done) {
     for (int i = 0; i < chunk; ++i) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (profile) {
-        while ((int64_t)ds->prof.size() < 2 * (enq + 1)) {
+      if (profile && enq % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time
+        const int64_t slot_id = enq / kProfStride;
+        while ((int64_t)ds->prof.size() < 2 * (slot_id + 1)) {
           hipEvent_t ev;
           HIP_TRY(hipEventCreate(&ev));
           ds->prof.push_back(ev);
         }
-        e0 = ds->prof[2 * enq];
-        e1 = ds->prof[2 * enq + 1];
+        e0 = ds->prof[2 * slot_id];
+        e1 = ds->prof[2 * slot_id + 1];
       }
       SLM_TRY(enqueue_gradient(ds, ds->y, ds->z, done_flag, e0, e1));
-      hipLaunchKernelGGL(fista_tail_kernel, dim3(1), dim3(TAIL_THREADS), 0, s, ta);
+      launch_tail(ta, s);
       ++enq;
     }
     SLM_TRY(check_launch());
@@ -913,13 +925,20 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
   if (stats) {
     stats->grad_launches = fin.total_iter;
     stats->grad_ms_total = 0.0;
+    stats->grad_timed = 0;
     if (profile) {
       double tot = 0.0;
-      for (int64_t k = 0; k < fin.total_iter && 2 * k + 1 < (int64_t)ds->prof.size(); ++k) {
+      int64_t cnt = 0;
+      // iterations 0, kProfStride, 2 kProfStride, ... below total_iter did real work and were timed
+      for (int64_t k = 0; k * kProfStride < fin.total_iter && 2 * k + 1 < (int64_t)ds->prof.size(); ++k) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ds->prof[2 * k], ds->prof[2 * k + 1]) == hipSuccess) tot += ms;
+        if (hipEventElapsedTime(&ms, ds->prof[2 * k], ds->prof[2 * k + 1]) == hipSuccess) {
+          tot += ms;
+          ++cnt;
+        }
       }
       stats->grad_ms_total = tot;
+      stats->grad_timed = cnt;
     }
     stats->lipschitz_ms = lipschitz_ms;
     stats->wall_ms =

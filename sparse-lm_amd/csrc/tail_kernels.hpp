@@ -7,11 +7,12 @@
 // prox with step s:  u = soft(v, s a);  per group  u_g * max(0, 1 - s b_g/||u_g||) / (1 + s d_g).
 //
 // One workgroup of 1024 threads runs the whole O(p) tail (p is a few thousand: 40 KB vectors that
-// live in L2), so every reduction is a fixed-order tree and results are bit-reproducible.
+// live in L2), so every reduction is a fixed-order tree and results are bit-reproducible.  Each
+// thread keeps its E = ceil(p/1024) features in registers from the first load to the last store.
 // Per-group l2 norms use sub-wavefront "teams" of TW lanes (TW = power of two <= 64 chosen from the
-// largest group): a team strides over one group's members (features are visited in group-sorted
-// order through a permutation, so arbitrary non-contiguous labels cost nothing) and finishes with a
-// TW-wide xor-butterfly.
+// largest group): a team strides over one group's members, gathering them from an LDS image of the
+// thresholded vector through the group-sorted permutation (arbitrary non-contiguous labels cost
+// nothing), and finishes with a TW-wide xor-butterfly.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -54,13 +55,12 @@ struct TailArgs {
   int64_t ld;
   double* zprev;     // [ld]
   double* gprev;     // [ld]
-  double* u;         // [p] scratch, group-sorted order
   double* gscale;    // [G] scratch
   const double* a0;  // [p]
   const double* b0;  // [G]
   const double* d0;  // [G]
   const int* order;  // [p] feature index of the k-th element in group-sorted order
-  const int* gsorted;// [p] group of the k-th element in group-sorted order
+  const int* gid;    // [p] group of feature j
   const int* gstart; // [G+1]
   double* betas_out; // [n_points][p]
   double* gn_out;    // [n_points][G] or nullptr
@@ -73,6 +73,9 @@ __device__ __forceinline__ double soft(double v, double thr) {
 }
 
 // Sum NV values over the 1024-thread workgroup; every thread gets bit-identical totals.
+// Stage 1: 64-wide xor butterfly per wavefront.  Stage 2: the 16 wavefront partials go through LDS
+// and every 16-lane group folds them with a 16-wide xor butterfly (commutative pairing => the same
+// bits in every lane).
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double (*lds)[TAIL_WAVES]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -89,18 +92,19 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double (*lds)[TAIL_WA
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    double t = 0.0;
+    double t = lds[k][lane & (TAIL_WAVES - 1)];
 #pragma unroll
-    for (int w = 0; w < TAIL_WAVES; ++w) t += lds[k][w];
+    for (int off = TAIL_WAVES / 2; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
     v[k] = t;
   }
 }
 
-// Per-group sum of squares of src (group-sorted order) by teams of `team` lanes.
+// Per-group sum of squares by teams of `team` lanes: group g owns the features order[gstart[g] ..
+// gstart[g+1]) (group-sorted permutation); src is indexed by FEATURE (an LDS image).
 // fn(g, sumsq) is called by lane 0 of the team.
 template <typename F>
-__device__ __forceinline__ void for_each_group_sumsq(const double* src, const int* gstart, int G,
-                                                     int team, F fn) {
+__device__ __forceinline__ void for_each_group_sumsq(const double* src, const int* order,
+                                                     const int* gstart, int G, int team, F fn) {
   const int tid = threadIdx.x;
   const int nteams = TAIL_THREADS / team;
   const int my_team = tid / team, tl = tid % team;
@@ -110,7 +114,7 @@ __device__ __forceinline__ void for_each_group_sumsq(const double* src, const in
     if (g < G) {
       const int k1 = gstart[g + 1];
       for (int k = gstart[g] + tl; k < k1; k += team) {
-        const double x = src[k];
+        const double x = src[order[k]];
         s = __builtin_fma(x, x, s);
       }
     }
@@ -119,12 +123,36 @@ __device__ __forceinline__ void for_each_group_sumsq(const double* src, const in
   }
 }
 
+// E = elements per thread (p <= 1024 * E).  Everything a thread needs of its E features is loaded
+// once into registers (independent loads: one L2 round trip), the group phase goes through LDS, the
+// only other global round trips are the control block and -- for real group penalties -- the group
+// tables.
+template <int E>
 __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   __shared__ double red[8][TAIL_WAVES];
+  __shared__ double us[E * TAIL_THREADS];
   PathCtl* ctl = a.ctl;
   if (ctl->done != 0) return;
   const int tid = threadIdx.x;
   const int p = a.p, G = a.G;
+
+  // ---- phase 0: per-feature loads (independent of the control block) ---------------------------
+  double zj[E], gj[E], bo[E], a0j[E], gpv[E], zpv[E];
+  int gi[E];
+  bool ok[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = tid + e * TAIL_THREADS;
+    ok[e] = j < p;
+    const int jj = ok[e] ? j : 0;
+    zj[e] = a.z[jj];
+    gj[e] = a.g[jj];
+    bo[e] = a.beta[jj];
+    a0j[e] = a.a0[jj];
+    gpv[e] = a.gprev[jj];
+    zpv[e] = a.zprev[jj];
+    gi[e] = a.singleton ? jj : a.gid[jj];
+  }
 
   // uniform snapshot of the control block (read-only until the final single-thread update)
   const int point = ctl->point;
@@ -134,56 +162,71 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   const double tol = ctl->tol;
   const uint32_t flags = ctl->flags;
   const int64_t total_iter = ctl->total_iter;
+  const int n_points = ctl->n_points;
+  const int max_iter = ctl->max_iter;
   const slm_path_point pt = a.pts[point];
+  const double loss_z = a.g[a.ld];
   const double step = 1.0 / L;
   const bool group_pen = (pt.sb != 0.0) || (pt.sd != 0.0);
 
-  // ---- phase 1: gradient step + elementwise soft threshold (group-sorted order) ----------------
-  for (int k = tid; k < p; k += TAIL_THREADS) {
-    const int j = a.order[k];
-    const double v = a.z[j] - step * a.g[j];
-    double u = soft(v, step * pt.sa * a.a0[j]);
-    if (group_pen && a.singleton) {
-      const double nrm = fabs(u);
-      const double sc = nrm > 0.0 ? fmax(0.0, 1.0 - step * pt.sb * a.b0[j] / nrm) : 0.0;
-      u *= sc / (1.0 + step * pt.sd * a.d0[j]);
+  // ---- phase 1: gradient step, soft threshold, curvature-guard sums -----------------------------
+  //  s[0] = ||b+ - z||^2   s[1] = ||b+||^2   s[2] = (z - b+).(b+ - b)   s[3] = ||g - gprev||^2
+  //  s[4] = ||z - zprev||^2   s[5] = ||z||^2   s[6] = #non-finite
+  double s[7] = {0, 0, 0, 0, 0, 0, 0};
+  double u[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = tid + e * TAIL_THREADS;
+    u[e] = 0.0;
+    if (ok[e]) {
+      const double dg = gj[e] - gpv[e], dzz = zj[e] - zpv[e];
+      s[3] = __builtin_fma(dg, dg, s[3]);
+      s[4] = __builtin_fma(dzz, dzz, s[4]);
+      s[5] = __builtin_fma(zj[e], zj[e], s[5]);
+      a.gprev[j] = gj[e];
+      a.zprev[j] = zj[e];
+      double uu = soft(zj[e] - step * gj[e], step * pt.sa * a0j[e]);
+      if (group_pen && a.singleton) {
+        const double nrm = fabs(uu);
+        const double sc = nrm > 0.0 ? fmax(0.0, 1.0 - step * pt.sb * a.b0[j] / nrm) : 0.0;
+        uu *= sc / (1.0 + step * pt.sd * a.d0[j]);
+      }
+      u[e] = uu;
     }
-    a.u[k] = u;
   }
-  // ---- phase 2: block soft threshold + ridge shrink per group ----------------------------------
+  // ---- phase 2: block soft threshold + ridge shrink per group (teams gather through LDS) --------
   if (group_pen && !a.singleton) {
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (ok[e]) us[tid + e * TAIL_THREADS] = u[e];
     __syncthreads();
-    for_each_group_sumsq(a.u, a.gstart, G, a.team, [&](int g, double ss) {
+    for_each_group_sumsq(us, a.order, a.gstart, G, a.team, [&](int g, double ss) {
       const double nrm = sqrt(ss);
       const double sc = nrm > 0.0 ? fmax(0.0, 1.0 - step * pt.sb * a.b0[g] / nrm) : 0.0;
       a.gscale[g] = sc / (1.0 + step * pt.sd * a.d0[g]);
     });
     __syncthreads();
-    for (int k = tid; k < p; k += TAIL_THREADS) a.u[k] *= a.gscale[a.gsorted[k]];
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (ok[e]) u[e] *= a.gscale[gi[e]];
   }
-  // (each thread only re-reads the u[k] it wrote itself from here on)
 
   // ---- phase 3: reductions --------------------------------------------------------------------
-  //  s[0] = ||b+ - z||^2   s[1] = ||b+||^2   s[2] = (z - b+).(b+ - b)   s[3] = ||g - gprev||^2
-  //  s[4] = ||z - zprev||^2   s[5] = ||z||^2   s[6] = #non-finite
-  double s[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int k = tid; k < p; k += TAIL_THREADS) {
-    const int j = a.order[k];
-    const double bn = a.u[k], zj = a.z[j], bo = a.beta[j], gj = a.g[j];
-    const double dz = bn - zj;
-    s[0] = __builtin_fma(dz, dz, s[0]);
-    s[1] = __builtin_fma(bn, bn, s[1]);
-    s[2] = __builtin_fma(-dz, bn - bo, s[2]);
-    const double dg = gj - a.gprev[j], dzz = zj - a.zprev[j];
-    s[3] = __builtin_fma(dg, dg, s[3]);
-    s[4] = __builtin_fma(dzz, dzz, s[4]);
-    s[5] = __builtin_fma(zj, zj, s[5]);
-    if (!isfinite(bn)) s[6] += 1.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (ok[e]) {
+      const double bn = u[e];
+      const double dz = bn - zj[e];
+      s[0] = __builtin_fma(dz, dz, s[0]);
+      s[1] = __builtin_fma(bn, bn, s[1]);
+      s[2] = __builtin_fma(-dz, bn - bo[e], s[2]);
+      if (!isfinite(bn)) s[6] += 1.0;
+    }
   }
   block_sum<7>(s, red);
 
   // ---- phase 4: uniform decisions -------------------------------------------------------------
-  const bool nonfinite = s[6] > 0.0 || !isfinite(s[0]) || !isfinite(s[1]) || !isfinite(a.g[a.ld]);
+  const bool nonfinite = s[6] > 0.0 || !isfinite(s[0]) || !isfinite(s[1]) || !isfinite(loss_z);
   // Curvature guard: ||A dz|| / ||dz|| is a lower bound on lambda_max(A), A = X^T W X / n.  If it
   // exceeds L the step 1/L was too long: raise L, discard the step and restart from beta.
   bool l_bad = false;
@@ -201,39 +244,46 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   const double mom = (t_use - 1.0) / t_new;
   const double resid = sqrt(s[0]), bnorm = sqrt(s[1]);
   const bool conv = !l_bad && (resid <= tol * bnorm);
-  const bool hit_max = (iter + 1 >= ctl->max_iter);
+  const bool hit_max = (iter + 1 >= max_iter);
   const bool finalize = nonfinite || conv || hit_max;
   const bool cold = (flags & SLM_FLAG_COLD_START) != 0;
+  // secant prediction of the next point's start from the last two solutions (see slm_path_point)
+  double extrap = 0.0;
+  if (finalize && !cold && !nonfinite && point >= 1 && point + 1 < n_points)
+    extrap = a.pts[point + 1].extrap;
 
   // ---- phase 5: state update ------------------------------------------------------------------
-  for (int k = tid; k < p; k += TAIL_THREADS) {
-    const int j = a.order[k];
-    const double bn = a.u[k], bo = a.beta[j];
-    a.gprev[j] = a.g[j];
-    a.zprev[j] = a.z[j];
-    if (l_bad && !finalize) {
-      a.z[j] = bo;  // step rejected: beta unchanged, momentum dropped
-    } else if (finalize) {
-      const double out = l_bad ? bo : bn;
-      a.betas_out[(int64_t)point * p + j] = out;
-      const double nxt = cold ? 0.0 : out;
-      a.beta[j] = nxt;
-      a.z[j] = nxt;
-    } else {
-      a.z[j] = bn + mom * (bn - bo);
-      a.beta[j] = bn;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = tid + e * TAIL_THREADS;
+    if (ok[e]) {
+      const double bn = u[e];
+      if (l_bad && !finalize) {
+        a.z[j] = bo[e];  // step rejected: beta unchanged, momentum dropped
+      } else if (finalize) {
+        const double out = l_bad ? bo[e] : bn;
+        u[e] = out;
+        a.betas_out[(int64_t)point * p + j] = out;
+        double nxt = cold ? 0.0 : out;
+        if (extrap != 0.0) nxt = out + extrap * (out - a.betas_out[(int64_t)(point - 1) * p + j]);
+        a.beta[j] = nxt;
+        a.z[j] = nxt;
+      } else {
+        a.z[j] = bn + mom * (bn - bo[e]);
+        a.beta[j] = bn;
+      }
     }
   }
   if (finalize && a.gn_out != nullptr) {
     // group norms of the reported solution (the reference's auxiliaries.group_norms.value,
     // model/_lasso.py:239-255, consumed by the adaptive re-weighting at _adaptive_lasso.py:364-374)
     __syncthreads();
-    if (l_bad) {
-      for (int k = tid; k < p; k += TAIL_THREADS) a.u[k] = a.betas_out[(int64_t)point * p + a.order[k]];
-      __syncthreads();
-    }
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (ok[e]) us[tid + e * TAIL_THREADS] = u[e];
+    __syncthreads();
     double* gn = a.gn_out + (int64_t)point * G;
-    for_each_group_sumsq(a.u, a.gstart, G, a.team, [&](int g, double ss) { gn[g] = sqrt(ss); });
+    for_each_group_sumsq(us, a.order, a.gstart, G, a.team, [&](int g, double ss) { gn[g] = sqrt(ss); });
   }
 
   // ---- phase 6: control block ------------------------------------------------------------------
@@ -248,14 +298,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       info.status = (conv && !nonfinite) ? SLM_OK : (nonfinite ? SLM_ERR_NON_FINITE : SLM_ERR_NOT_CONVERGED);
       info.resid = resid;
       info.beta_norm = bnorm;
-      info.loss = a.g[a.ld];
+      info.loss = loss_z;
       info.L = L_new;
       a.infos[point] = info;
       ctl->iter = 0;
       ctl->t = 1.0;
       ctl->point = point + 1;
       if (nonfinite) ctl->nonfinite = 1;
-      if (point + 1 >= ctl->n_points || nonfinite) ctl->done = 1;
+      if (point + 1 >= n_points || nonfinite) ctl->done = 1;
     } else {
       ctl->iter = iter + 1;
       ctl->t = l_bad ? 1.0 : t_new;

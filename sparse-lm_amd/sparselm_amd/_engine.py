@@ -78,7 +78,7 @@ class _PenaltyStruct(C.Structure):
 
 
 class _PathPoint(C.Structure):
-    _fields_ = [("sa", C.c_double), ("sb", C.c_double), ("sd", C.c_double)]
+    _fields_ = [("sa", C.c_double), ("sb", C.c_double), ("sd", C.c_double), ("extrap", C.c_double)]
 
 
 class _SolveOpts(C.Structure):
@@ -105,6 +105,7 @@ class _PointInfo(C.Structure):
 class _SolveStats(C.Structure):
     _fields_ = [
         ("grad_launches", C.c_int64),
+        ("grad_timed", C.c_int64),
         ("grad_ms_total", C.c_double),
         ("wall_ms", C.c_double),
         ("lipschitz_ms", C.c_double),
@@ -214,6 +215,30 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def path_extrapolation(pts) -> np.ndarray:
+    """Secant factors gamma_k = (s_k - s_{k-1}) / (s_{k-1} - s_{k-2}) for a path whose points are all
+    multiples s_k of one penalty direction (rank-one (K, 3) array); zeros otherwise."""
+    pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
+    K = pts.shape[0]
+    gam = np.zeros(K)
+    if K < 3:
+        return gam
+    ref = pts[np.argmax(np.abs(pts).sum(axis=1))]
+    nrm = float(ref @ ref)
+    if nrm <= 0.0:
+        return gam
+    s = pts @ ref / nrm
+    if not np.allclose(np.outer(s, ref), pts, rtol=1e-12, atol=1e-300):
+        return gam  # the penalty changes shape along the path: prediction would be meaningless
+    for k in range(2, K):
+        den = s[k - 1] - s[k - 2]
+        if den != 0.0:
+            g = (s[k] - s[k - 1]) / den
+            if np.isfinite(g) and abs(g) <= 10.0:
+                gam[k] = g
+    return gam
+
+
 @dataclass
 class PathResult:
     betas: np.ndarray  # (n_points, p)
@@ -225,6 +250,7 @@ class PathResult:
     loss: np.ndarray
     L: float
     grad_launches: int
+    grad_timed: int
     grad_ms_total: float
     wall_ms: float
     lipschitz_ms: float
@@ -416,14 +442,17 @@ class Dataset:
         L: float = 0.0,
         flags: int = 0,
         want_group_norms: bool = False,
+        extrapolate: bool = True,
     ) -> PathResult:
         """Warm-started path; ``points`` is (K, 3) of (sa, sb, sd) scales applied to (a, b, d).
 
         ``a`` (p,), ``b`` (G,), ``d`` (G,): ``None`` means all ones.  K == 1 is the reference's
-        single ``_solve``.
+        single ``_solve``.  ``extrapolate``: when all points are multiples of one penalty direction
+        (an alpha path), start point k from the secant prediction through the two previous solutions.
         """
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         K = pts.shape[0]
+        pts = np.hstack([pts, path_extrapolation(pts)[:, None] if extrapolate else np.zeros((K, 1))])
         G = self.n_groups
         a_ = None if a is None else _f64(np.broadcast_to(a, (self.p,)), "a")
         b_ = None if b is None else _f64(np.broadcast_to(b, (G,)), "b")
@@ -451,6 +480,7 @@ class Dataset:
             loss=np.array([i.loss for i in infos]),
             L=float(infos[K - 1].L),
             grad_launches=int(stats.grad_launches),
+            grad_timed=int(stats.grad_timed),
             grad_ms_total=float(stats.grad_ms_total),
             wall_ms=float(stats.wall_ms),
             lipschitz_ms=float(stats.lipschitz_ms),

@@ -30,10 +30,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     # sizes the C side uses (checked against natural alignment of the header's structs)
-    assert ctypes.sizeof(_engine._PathPoint) == 24
+    assert ctypes.sizeof(_engine._PathPoint) == 32
     assert ctypes.sizeof(_engine._SolveOpts) == 32
     assert ctypes.sizeof(_engine._PointInfo) == 40
-    assert ctypes.sizeof(_engine._SolveStats) == 32
+    assert ctypes.sizeof(_engine._SolveStats) == 40
     assert ctypes.sizeof(_engine._PenaltyStruct) == 24
 
 
@@ -67,3 +67,19 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "fista_ref" not in src, f
+
+
+def test_path_extrapolation_factors():
+    import numpy as np
+
+    a = np.geomspace(1.0, 1e-3, 6)
+    g = _engine.path_extrapolation(np.c_[a, 0 * a, 0 * a])
+    assert g[0] == 0 and g[1] == 0
+    np.testing.assert_allclose(g[2:], (a[2:] - a[1:-1]) / (a[1:-1] - a[:-2]))
+    # sparse-group path: both scales move together -> still one direction
+    g2 = _engine.path_extrapolation(np.c_[0.3 * a, 0.7 * a, 0 * a])
+    np.testing.assert_allclose(g2, g)
+    # penalty changes shape along the path -> no extrapolation
+    assert not _engine.path_extrapolation([(0, 1, 0), (0.3, 0.7, 0), (0, 1, 1)]).any()
+    # repeated point -> zero denominator handled
+    assert np.all(np.isfinite(_engine.path_extrapolation([(1, 0, 0), (1, 0, 0), (0.5, 0, 0)])))
