@@ -140,7 +140,7 @@ def main():
     coef = make_coef(p, 50, seed=0)
     # independent unit per rank: fold/seed differs, law identical
     ds = eng.synthetic_dataset(n, p, seed=1000 + rank, coef=coef, noise_sd=10.0)
-    g0, _ = ds.gradient(None)
+    g0, _, _ = ds.gradient(None, reps=50)  # alpha_max; the extra launches bring the clocks up (setup)
     amax = float(np.max(np.abs(g0)))
     alphas = np.geomspace(amax, 1e-3 * amax, K)
     points = [(a, 0.0, 0.0) for a in alphas]

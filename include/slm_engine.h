@@ -186,6 +186,8 @@ int slm_comm_unique_id(uint8_t id_out[SLM_COMM_ID_BYTES]);
    sum X^T r (and the loss / n) over ranks with RCCL; n_global replaces n in the 1/n scaling. */
 int slm_comm_init(slm_engine* eng, int32_t rank, int32_t n_ranks,
                   const uint8_t id[SLM_COMM_ID_BYTES]);
+/* n_global replaces n in the 1/n (gradient) and 1/(2n) (loss) scaling: the global row count of a
+   row-sharded matrix, or the number of unmasked rows when row weights act as a CV-fold mask. */
 int slm_dataset_set_global_rows(slm_dataset* ds, int64_t n_global);
 int slm_comm_destroy(slm_engine* eng);
 

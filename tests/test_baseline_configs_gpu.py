@@ -1,0 +1,150 @@
+"""BASELINE.json's configurations as parity cases on one GPU.
+
+* configs[1] / configs[2] at their FULL size (n=100k, p=5k): no CPU solver finishes these in
+  seconds, so optimality is certified through a size-independent property -- the KKT residual of the
+  returned coefficients, computed from one more device gradient, bounds the distance to the exact
+  minimiser by kkt/mu (mu = lambda_min(X^T X)/n >= (1 - sqrt(p/n))^2 ~ 0.60 for this Gaussian design;
+  0.5 is used).  North-star bound: 1e-6 rel-inf.
+* configs[3] (SparseGroupLasso CV grid) and configs[4] (row-sharded AdaptiveGroupLasso) at reduced
+  size against the oracle, through the same code paths (stock GridSearchCV; RCCL communicator).
+"""
+
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle
+from sparselm_amd import _engine
+
+pytestmark = pytest.mark.gpu
+
+N, P = 100_000, 5_000
+
+
+def make_coef(p, k, seed, groups=None):
+    rng = np.random.default_rng(seed)
+    coef = np.zeros(p)
+    if groups is None:
+        coef[rng.choice(p, k, replace=False)] = 100.0 * rng.uniform(size=k)
+    else:
+        for g in rng.choice(groups.max() + 1, k, replace=False):
+            m = groups == g
+            coef[m] = 100.0 * rng.uniform(size=m.sum())
+    return coef
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return _engine.get_engine(0)
+
+
+def test_config2_lasso_path_full_size_is_kkt_certified(eng):
+    coef = make_coef(P, 50, 0)
+    with eng.synthetic_dataset(N, P, seed=7, coef=coef, noise_sd=10.0) as ds:
+        g0, _ = ds.gradient(None)
+        amax = float(np.max(np.abs(g0)))
+        alphas = np.geomspace(amax, 1e-3 * amax, 50)
+        res = ds.solve_path([(a, 0.0, 0.0) for a in alphas])
+        assert res.converged
+        assert np.all(res.betas[0] == 0.0)
+        gidx, G = oracle.group_index(None, P)
+        zero = np.zeros(G)
+        for k in (1, 10, 25, 40, 49):
+            beta = res.betas[k]
+            g, _ = ds.gradient(beta)
+            kkt = oracle.kkt_residual(g, beta, alphas[k] * np.ones(P), zero, zero, gidx, G)
+            assert kkt / 0.5 < 1e-6 * np.max(np.abs(beta)), (k, kkt)
+    # the informative features are found and the path gets denser
+    nnz = (res.betas != 0).sum(axis=1)
+    assert nnz[10] >= 40 and nnz[-1] > nnz[10]
+    assert set(np.flatnonzero(coef > 20)) <= set(np.flatnonzero(res.betas[25]))
+
+
+def test_config3_group_lasso_path_full_size_is_kkt_certified(eng):
+    rng = np.random.default_rng(1)
+    groups = rng.permutation(np.repeat(np.arange(500), 10))  # shuffled => non-contiguous labels
+    coef = make_coef(P, 25, 2, groups)
+    gidx, G = oracle.group_index(groups, P)
+    with eng.synthetic_dataset(N, P, seed=11, coef=coef, noise_sd=10.0) as ds:
+        ds.set_groups(gidx, G)
+        g0, _ = ds.gradient(None)
+        bmax = float(np.max(np.sqrt(np.bincount(gidx, weights=g0 * g0, minlength=G))))
+        alphas = np.geomspace(bmax, 1e-3 * bmax, 50)
+        res = ds.solve_path([(0.0, a, 0.0) for a in alphas], want_group_norms=True)
+        assert res.converged
+        assert np.all(res.betas[0] == 0.0)
+        zero_p = np.zeros(P)
+        for k in (1, 12, 30, 49):
+            beta = res.betas[k]
+            g, _ = ds.gradient(beta)
+            kkt = oracle.kkt_residual(g, beta, zero_p, alphas[k] * np.ones(G), np.zeros(G), gidx, G)
+            assert kkt / 0.5 < 1e-6 * np.max(np.abs(beta)), (k, kkt)
+            # group all-or-nothing (reference tests/test_lasso.py:106-111): exact zeros from the prox
+            active = np.bincount(gidx, weights=(beta != 0), minlength=G)
+            assert np.all((active == 0) | (active == 10))
+            np.testing.assert_allclose(res.group_norms[k], np.sqrt(np.bincount(gidx, weights=beta**2, minlength=G)),
+                                       rtol=1e-12, atol=1e-300)
+    informative = np.unique(gidx[coef != 0])
+    assert set(informative) <= set(np.flatnonzero(res.group_norms[20] > 0))
+
+
+def test_config4_sparse_group_lasso_grid_search_reduced(eng):
+    from sklearn.model_selection import GridSearchCV, KFold
+
+    from _oracle_backend import OracleBackend
+    from sparselm_amd import _backend
+    from sparselm_amd.model import SparseGroupLasso
+
+    rng = np.random.default_rng(5)
+    n, p = 1500, 120
+    groups = rng.permutation(np.repeat(np.arange(12), 10))
+    coef = make_coef(p, 3, 6, groups) / 10
+    X = rng.standard_normal((n, p))
+    y = X @ coef + rng.standard_normal(n)
+    grid = {"alpha": list(np.geomspace(2.0, 0.02, 5)), "l1_ratio": [0.05, 0.5, 0.95]}
+    cv = KFold(3, shuffle=True, random_state=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gs = GridSearchCV(SparseGroupLasso(groups=groups), grid, cv=cv).fit(X, y)
+        with _backend.use_backend(OracleBackend()):
+            gs0 = GridSearchCV(SparseGroupLasso(groups=groups), grid, cv=cv).fit(X, y)
+    assert gs.best_params_ == gs0.best_params_
+    np.testing.assert_allclose(gs.cv_results_["mean_test_score"], gs0.cv_results_["mean_test_score"], rtol=1e-6)
+    err = np.max(np.abs(gs.best_estimator_.coef_ - gs0.best_estimator_.coef_)) / np.max(np.abs(gs0.best_estimator_.coef_))
+    assert err < 1e-6
+
+
+def test_config5_adaptive_group_lasso_row_sharded_reduced():
+    # per-rank on-device generation + RCCL all-reduce path with world_size 1 (one GPU per box);
+    # the outer re-weighting loop is the estimator's semantics restated by hand on the dataset API
+    from sparselm_amd import distributed as D
+
+    n, p, G = 30_000, 600, 60
+    groups = np.repeat(np.arange(G), 10)
+    coef = make_coef(p, 6, 3, groups) / 20
+    eng2 = _engine.Engine(0)
+    try:
+        D.init_row_sharding(eng2, rank=0, world_size=1)
+        lo, hi = D.row_range(n, 0, 1)
+        with eng2.synthetic_dataset(hi - lo, p, seed=1000, coef=coef, noise_sd=1.0, row_offset=lo) as ds:
+            ds.set_global_rows(n)
+            ds.set_groups(groups, G)
+            X, y = ds.download()
+            g0, _ = ds.gradient(None)
+            amax = float(np.max(np.sqrt(np.bincount(groups, weights=g0 * g0, minlength=G))))
+            alpha, eps = 0.1 * amax, 1e-6
+            w = alpha * np.ones(G)
+            beta = None
+            for _ in range(3):  # model/_adaptive_lasso.py:206-232 with AdaptiveGroupLasso's update :364-374
+                res = ds.solve_path([(0.0, 1.0, 0.0)], b=w, beta0=beta, tol=1e-10, want_group_norms=True)
+                assert res.converged
+                beta = res.betas[0]
+                w = alpha * (alpha / (res.group_norms[0] + eps))
+        ref = oracle.fit_adaptive_group_lasso(X, y, groups=groups, alpha=alpha, max_iter=3, eps=eps)
+        assert np.max(np.abs(beta - ref["coef"])) / np.max(np.abs(ref["coef"])) < 1e-6
+        big = ref["weights"] < 1e3
+        np.testing.assert_allclose(w[big], ref["weights"][big], rtol=1e-5)
+    finally:
+        eng2.comm_destroy()
+        eng2.close()

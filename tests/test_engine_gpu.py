@@ -281,3 +281,43 @@ def test_non_finite_data_raises(eng):
     with eng.dataset(X, np.ones(10)) as ds:
         with pytest.raises((_engine.NonFiniteError, _engine.EngineError)):
             ds.solve_path([(0.1, 0.0, 0.0)], L=1.0)
+
+
+# ---- row-sharded mode -------------------------------------------------------------------------------
+def test_row_shards_sum_to_full_gradient(eng):
+    # what the in-engine all-reduce adds up: per-shard X_r^T (X_r z - y_r) / n_global
+    rng = np.random.default_rng(8)
+    n, p = 1501, 333
+    X, y, z = rng.standard_normal((n, p)), rng.standard_normal(n), rng.standard_normal(p)
+    from sparselm_amd.distributed import row_range
+
+    total = np.zeros(p)
+    loss = 0.0
+    for r in range(3):
+        lo, hi = row_range(n, r, 3)
+        with eng.dataset(X[lo:hi], y[lo:hi]) as ds:
+            ds.set_global_rows(n)
+            g, l = ds.gradient(z)
+            total += g
+            loss += l
+    g0, l0 = ref_grad(X, y, z)
+    assert rel_inf(total, g0) < 1e-12
+    npt.assert_allclose(loss, l0, rtol=1e-12)
+
+
+def test_rccl_path_with_one_rank(golden):
+    # the RCCL plumbing (dlopen, unique id, communicator, per-iteration all-reduce) on a single GPU
+    from sparselm_amd import distributed as D
+
+    X, y = golden["l1_X"], golden["l1_y"]
+    eng2 = _engine.Engine(0)
+    try:
+        D.init_row_sharding(eng2, rank=0, world_size=1)
+        with eng2.dataset(X, y) as ds:
+            ds.set_global_rows(len(y))
+            res = ds.solve_path([(golden["l1_alpha"][1], 0.0, 0.0)], tol=1e-12, max_iter=100000)
+        assert res.converged
+        assert rel_inf(res.betas[0], golden["l1_coef"][1]) < 1e-9
+    finally:
+        eng2.comm_destroy()
+        eng2.close()
