@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--p", type=int, default=5_000)
     ap.add_argument("--alphas", type=int, default=50)
     ap.add_argument("--tol", type=float, default=1e-8)
+    ap.add_argument("--lanes", type=int, default=1, help="sub-paths advancing together on one pass over X")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     args = ap.parse_args()
 
@@ -147,7 +148,7 @@ def main():
     flags = _engine.FLAG_PROFILE | _engine.FLAG_FRESH_L
 
     for _ in range(args.warmup):
-        ds.solve_path(points, tol=args.tol, flags=flags)
+        ds.solve_path(points, tol=args.tol, flags=flags, lanes=args.lanes)
 
     sync_all()
     t0 = time.perf_counter()
@@ -156,7 +157,7 @@ def main():
     grad_timed = 0
     res = None
     for _ in range(args.steps):
-        res = ds.solve_path(points, tol=args.tol, flags=flags)
+        res = ds.solve_path(points, tol=args.tol, flags=flags, lanes=args.lanes)
         grad_ms += res.grad_ms_total
         grad_launches += res.grad_launches
         grad_timed += res.grad_timed
@@ -191,6 +192,7 @@ def main():
                 "n": n,
                 "p": p,
                 "n_alphas": K,
+                "lanes": args.lanes,
                 "tol": args.tol,
                 "law": "make_regression(n_informative=50, noise=10): X~N(0,1) generated on device",
                 "parallelism": f"grid x{world} (independent paths, no collective)",

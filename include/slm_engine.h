@@ -178,6 +178,30 @@ int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point
                    double* betas_out, double* group_norms_out, slm_point_info* infos,
                    slm_solve_stats* stats);
 
+/*
+ * Several independent problems ("lanes") on ONE pass over X per iteration: lane l has its own
+ * penalty, path, warm start and -- optionally -- its own row weights (a CV-fold mask) and 1/n
+ * scaling.  The fused gradient kernel streams X once and produces all lanes' gradients, so B lanes
+ * cost the HBM traffic of one.  Used for the alpha sub-paths of one long path, for the folds of a
+ * cross-validation, or both.  n_lanes <= SLM_MAX_LANES; SLM_ERR_UNSUPPORTED if no kernel variant
+ * covers (p, n_lanes) -- callers then fall back to fewer lanes.
+ */
+#define SLM_MAX_LANES 4
+typedef struct slm_lane {
+  const slm_penalty* pen;         /* NULL => all-ones base vectors                              */
+  const slm_path_point* points;   /* this lane's warm-started path                              */
+  int32_t n_points;
+  const double* beta0;            /* length p warm start, NULL => 0                             */
+  const double* row_weight;       /* length n, NULL => the dataset's row weights                */
+  int64_t n_eff;                  /* 1/n_eff scaling of loss and gradient; <= 0 => dataset's    */
+  double* betas_out;              /* n_points x p                                               */
+  double* group_norms_out;        /* n_points x G, nullable                                     */
+  slm_point_info* infos;          /* n_points, nullable                                         */
+} slm_lane;
+
+int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes,
+                    const slm_solve_opts* opts, slm_solve_stats* stats);
+
 /* ---- row-sharded mode (very tall X split by rows over ranks; one all-reduce per iteration) ---- */
 #define SLM_COMM_ID_BYTES 128
 /* Rank 0 creates the id and distributes the 128 bytes to the other ranks out of band. */

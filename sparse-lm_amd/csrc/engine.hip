@@ -104,40 +104,50 @@ static int load_rccl() {
 // gradient kernel table
 // ------------------------------------------------------------------------------------------------
 struct GradKernel {
-  int W, C, R;
+  int W, C, R, B;
   void (*fn)(GradArgs);
 };
 
-#define SLM_GK(W, C, R) {W, C, R, grad_fused_kernel<W, C, R>}
-// Default choice per capacity (64*W*C chunks of 16 bytes), ordered by capacity.
+#define SLM_GK(W, C, R, B) {W, C, R, B, grad_fused_kernel<W, C, R, B>}
+// Default choice per (lanes B, capacity 64*W*C chunks of 16 bytes); every list is ordered by
+// capacity.  R (rows held per step) is the largest that keeps the kernel free of (large) spills at
+// 256 VGPRs; measured register counts are in DESIGN.md.
 static const GradKernel kGradDefault[] = {
-    SLM_GK(1, 1, 4), SLM_GK(2, 1, 4), SLM_GK(4, 1, 4), SLM_GK(8, 1, 4), SLM_GK(8, 2, 4),
-    SLM_GK(8, 3, 4), SLM_GK(8, 4, 2), SLM_GK(8, 5, 2), SLM_GK(8, 6, 2), SLM_GK(8, 8, 1),
-    SLM_GK(8, 10, 1),
+    // one lane
+    SLM_GK(1, 1, 4, 1), SLM_GK(2, 1, 4, 1), SLM_GK(4, 1, 4, 1), SLM_GK(8, 1, 4, 1), SLM_GK(8, 2, 4, 1),
+    SLM_GK(8, 3, 4, 1), SLM_GK(8, 4, 2, 1), SLM_GK(8, 5, 2, 1), SLM_GK(8, 6, 2, 1), SLM_GK(8, 8, 2, 1),
+    SLM_GK(8, 10, 1, 1),
+    // two lanes
+    SLM_GK(1, 1, 4, 2), SLM_GK(2, 1, 4, 2), SLM_GK(4, 1, 4, 2), SLM_GK(8, 1, 4, 2), SLM_GK(8, 2, 4, 2),
+    SLM_GK(8, 3, 4, 2), SLM_GK(8, 4, 2, 2), SLM_GK(8, 5, 2, 2), SLM_GK(8, 6, 2, 2), SLM_GK(8, 8, 1, 2),
+    // three lanes
+    SLM_GK(1, 1, 4, 3), SLM_GK(2, 1, 4, 3), SLM_GK(4, 1, 4, 3), SLM_GK(8, 1, 4, 3), SLM_GK(8, 2, 4, 3),
+    SLM_GK(8, 3, 4, 3), SLM_GK(8, 4, 2, 3), SLM_GK(8, 5, 2, 3), SLM_GK(8, 6, 1, 3),
+    // four lanes
+    SLM_GK(1, 1, 4, 4), SLM_GK(2, 1, 4, 4), SLM_GK(4, 1, 4, 4), SLM_GK(8, 1, 4, 4), SLM_GK(8, 2, 4, 4),
+    SLM_GK(8, 3, 2, 4), SLM_GK(8, 4, 2, 4), SLM_GK(8, 5, 1, 4),
 };
 // Extra instantiations reachable through SLM_GRAD_CONFIG=W,C,R (tuning sweeps).
 static const GradKernel kGradExtra[] = {
-    SLM_GK(8, 5, 1), SLM_GK(8, 4, 4), SLM_GK(8, 3, 2), SLM_GK(8, 6, 1), SLM_GK(4, 10, 1),
-    SLM_GK(4, 5, 2), SLM_GK(4, 6, 2), SLM_GK(4, 8, 2),  SLM_GK(4, 10, 2), SLM_GK(4, 5, 4),
-    SLM_GK(2, 10, 2), SLM_GK(1, 2, 4), SLM_GK(2, 2, 4), SLM_GK(4, 2, 4),  SLM_GK(4, 3, 4),
-    SLM_GK(4, 4, 4),
+    SLM_GK(8, 5, 1, 1), SLM_GK(8, 5, 3, 1), SLM_GK(8, 5, 4, 1), SLM_GK(8, 4, 4, 1), SLM_GK(8, 6, 1, 1),
+    SLM_GK(8, 8, 1, 1), SLM_GK(8, 5, 1, 2), SLM_GK(8, 5, 1, 3), SLM_GK(8, 4, 4, 2), SLM_GK(8, 6, 1, 2),
 };
 static const int kProfStride = 4;  // SLM_FLAG_PROFILE times every 4th gradient launch
 static const int64_t kMaxChunks = 64 * 8 * 10;  // largest row the fused kernel covers (p <= 10240)
 
-static const GradKernel* pick_grad_kernel(int64_t p2) {
+static const GradKernel* pick_grad_kernel(int64_t p2, int B) {
   const char* env = getenv("SLM_GRAD_CONFIG");
   if (env) {
     int W = 0, C = 0, R = 0;
     if (sscanf(env, "%d,%d,%d", &W, &C, &R) == 3) {
       for (const auto& k : kGradDefault)
-        if (k.W == W && k.C == C && k.R == R && 64LL * W * C >= p2) return &k;
+        if (k.B == B && k.W == W && k.C == C && k.R == R && 64LL * W * C >= p2) return &k;
       for (const auto& k : kGradExtra)
-        if (k.W == W && k.C == C && k.R == R && 64LL * W * C >= p2) return &k;
+        if (k.B == B && k.W == W && k.C == C && k.R == R && 64LL * W * C >= p2) return &k;
     }
   }
   for (const auto& k : kGradDefault)
-    if (64LL * k.W * k.C >= p2) return &k;
+    if (k.B == B && 64LL * k.W * k.C >= p2) return &k;
   return nullptr;
 }
 
@@ -154,31 +164,46 @@ struct slm_engine {
   int rank = 0, n_ranks = 1;
 };
 
+static const int kMaxLanes = SLM_MAX_LANES;
+
+// Control words shared by all lanes of a solve.
+struct GlobalCtl {
+  int32_t done;        // every lane finished, or abort
+  int32_t lanes_done;
+};
+
+struct HostCtl {  // pinned snapshot the host polls
+  GlobalCtl g;
+  PathCtl lane[SLM_MAX_LANES];
+};
+
 struct slm_dataset {
   slm_engine* eng = nullptr;
   int64_t n = 0, p = 0, ld = 0, n_global = 0;
   double *X = nullptr, *y = nullptr, *rw = nullptr, *yzero = nullptr;
+  double* rw_lanes = nullptr;  // [kMaxLanes][n], allocated when a lane brings its own row weights
   // group structure (group-sorted permutation)
   int G = 0, singleton = 1, team = 1;
   int *order = nullptr, *gid = nullptr, *gstart = nullptr;
-  // gradient launch
-  const GradKernel* gk = nullptr;
-  int nblk = 0;
+  // gradient launch, per lane count B = 1..kMaxLanes (index B-1); gk == nullptr => unsupported
+  const GradKernel* gk[SLM_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  int nblk[SLM_MAX_LANES] = {0, 0, 0, 0};
   double *partial = nullptr, *loss_partial = nullptr;
-  // iteration state
+  // iteration state: kMaxLanes copies, lane stride ld (g: ld + 16)
   double *g = nullptr, *z = nullptr, *beta = nullptr, *zprev = nullptr, *gprev = nullptr;
   double *u = nullptr, *gscale = nullptr, *a0 = nullptr, *b0 = nullptr, *d0 = nullptr;
-  double* lambda = nullptr;
-  PathCtl* ctl = nullptr;
-  PathCtl* hctl = nullptr;  // pinned, 2 slots
+  double* lambda = nullptr;  // [kMaxLanes]
+  PathCtl* ctl = nullptr;    // [kMaxLanes]
+  GlobalCtl* gctl = nullptr;
+  HostCtl* hctl = nullptr;   // pinned, 2 slots
   hipEvent_t ev[2] = {nullptr, nullptr};
-  // path buffers (grown on demand)
-  int cap_points = 0, cap_gn = 0;
+  // path buffers (grown on demand), concatenated over lanes
+  int64_t cap_points = 0, cap_gn = 0;
   slm_path_point* pts = nullptr;
   double *betas_out = nullptr, *gn_out = nullptr;
   slm_point_info* infos = nullptr;
   std::vector<hipEvent_t> prof;
-  // cached Lipschitz constant
+  // cached Lipschitz constant (dataset row weights, dataset n_global)
   double L = 0.0;
   bool L_valid = false;
 };
@@ -291,12 +316,12 @@ extern "C" int slm_engine_device_info(slm_engine* eng, int64_t out[6], char* nam
 // ------------------------------------------------------------------------------------------------
 static void dataset_free(slm_dataset* ds) {
   if (!ds) return;
-  dfree(ds->X); dfree(ds->y); dfree(ds->rw); dfree(ds->yzero);
+  dfree(ds->X); dfree(ds->y); dfree(ds->rw); dfree(ds->yzero); dfree(ds->rw_lanes);
   dfree(ds->order); dfree(ds->gid); dfree(ds->gstart);
   dfree(ds->partial); dfree(ds->loss_partial);
   dfree(ds->g); dfree(ds->z); dfree(ds->beta); dfree(ds->zprev); dfree(ds->gprev);
   dfree(ds->u); dfree(ds->gscale); dfree(ds->a0); dfree(ds->b0); dfree(ds->d0);
-  dfree(ds->lambda); dfree(ds->ctl);
+  dfree(ds->lambda); dfree(ds->ctl); dfree(ds->gctl);
   dfree(ds->pts); dfree(ds->betas_out); dfree(ds->gn_out); dfree(ds->infos);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   for (auto& e : ds->ev)
@@ -314,7 +339,7 @@ static int set_singleton_groups(slm_dataset* ds) {
   SLM_TRY(dalloc(&ds->order, p));
   SLM_TRY(dalloc(&ds->gid, p));
   SLM_TRY(dalloc(&ds->gstart, p + 1));
-  SLM_TRY(dalloc(&ds->gscale, p));
+  SLM_TRY(dalloc(&ds->gscale, (size_t)kMaxLanes * p));
   HIP_TRY(hipMemcpy(ds->order, ident.data(), sizeof(int) * p, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ds->gid, ident.data(), sizeof(int) * p, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ds->gstart, start.data(), sizeof(int) * (p + 1), hipMemcpyHostToDevice));
@@ -339,42 +364,50 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
   ds->n_global = n;
   ds->ld = (p + 15) / 16 * 16;
   const int64_t ld = ds->ld;
-  ds->gk = pick_grad_kernel(ld / 2);
-  if (!ds->gk) {
+  size_t partial_elems = 0, loss_elems = 0;
+  for (int B = 1; B <= kMaxLanes; ++B) {
+    const GradKernel* gk = pick_grad_kernel(ld / 2, B);
+    ds->gk[B - 1] = gk;
+    if (!gk) continue;
+    int occ = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)gk->fn, gk->W * 64, 0);
+    if (e != hipSuccess || occ < 1) occ = 1;
+    int per_cu = occ;
+    if (const char* env = getenv("SLM_GRAD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(env));
+    int64_t nblk = (int64_t)eng->cus * per_cu;
+    const int64_t steps = (n + gk->R - 1) / gk->R;
+    nblk = std::max<int64_t>(1, std::min<int64_t>(nblk, steps));
+    ds->nblk[B - 1] = (int)nblk;
+    partial_elems = std::max(partial_elems, (size_t)nblk * B * (size_t)ld);
+    loss_elems = std::max(loss_elems, (size_t)nblk * B);
+  }
+  if (!ds->gk[0]) {
     delete ds;
     return fail(SLM_ERR_UNSUPPORTED, "no gradient kernel covers p = %lld", (long long)p);
   }
-  int occ = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)ds->gk->fn,
-                                                              ds->gk->W * 64, 0);
-  if (e != hipSuccess || occ < 1) occ = 1;
-  int per_cu = occ;
-  if (const char* env = getenv("SLM_GRAD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(env));
-  int64_t nblk = (int64_t)eng->cus * per_cu;
-  const int64_t steps = (n + ds->gk->R - 1) / ds->gk->R;
-  nblk = std::max<int64_t>(1, std::min<int64_t>(nblk, steps));
-  ds->nblk = (int)nblk;
 
   int rc = SLM_OK;
   auto A = [&](int r) { if (rc == SLM_OK) rc = r; };
+  const size_t ML = kMaxLanes;
   A(dalloc(&ds->X, (size_t)n * ld));
   A(dalloc(&ds->y, n));
   A(dalloc(&ds->yzero, n));
-  A(dalloc(&ds->partial, (size_t)nblk * ld));
-  A(dalloc(&ds->loss_partial, nblk));
-  A(dalloc(&ds->g, ld + 16));
-  A(dalloc(&ds->z, ld));
-  A(dalloc(&ds->beta, ld));
-  A(dalloc(&ds->zprev, ld));
-  A(dalloc(&ds->gprev, ld));
+  A(dalloc(&ds->partial, partial_elems));
+  A(dalloc(&ds->loss_partial, loss_elems));
+  A(dalloc(&ds->g, ML * (ld + 16)));
+  A(dalloc(&ds->z, ML * ld));
+  A(dalloc(&ds->beta, ML * ld));
+  A(dalloc(&ds->zprev, ML * ld));
+  A(dalloc(&ds->gprev, ML * ld));
   A(dalloc(&ds->u, ld));
-  A(dalloc(&ds->a0, ld));
-  A(dalloc(&ds->b0, ld));
-  A(dalloc(&ds->d0, ld));
-  A(dalloc(&ds->lambda, 1));
-  A(dalloc(&ds->ctl, 1));
+  A(dalloc(&ds->a0, ML * ld));
+  A(dalloc(&ds->b0, ML * ld));
+  A(dalloc(&ds->d0, ML * ld));
+  A(dalloc(&ds->lambda, ML));
+  A(dalloc(&ds->ctl, ML));
+  A(dalloc(&ds->gctl, 1));
   if (rc == SLM_OK) {
-    hipError_t e2 = hipHostMalloc((void**)&ds->hctl, 2 * sizeof(PathCtl), hipHostMallocDefault);
+    hipError_t e2 = hipHostMalloc((void**)&ds->hctl, 2 * sizeof(HostCtl), hipHostMallocDefault);
     if (e2 != hipSuccess) rc = fail(SLM_ERR_OOM, "hipHostMalloc: %s", hipGetErrorString(e2));
   }
   for (int k = 0; k < 2 && rc == SLM_OK; ++k) {
@@ -386,11 +419,11 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
     hipStream_t s = eng->stream;
     hipError_t e3 = hipMemsetAsync(ds->X, 0, sizeof(double) * (size_t)n * ld, s);
     if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->yzero, 0, sizeof(double) * n, s);
-    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->z, 0, sizeof(double) * ld, s);
-    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->beta, 0, sizeof(double) * ld, s);
-    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->zprev, 0, sizeof(double) * ld, s);
-    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->gprev, 0, sizeof(double) * ld, s);
-    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->g, 0, sizeof(double) * (ld + 16), s);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->z, 0, sizeof(double) * ML * ld, s);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->beta, 0, sizeof(double) * ML * ld, s);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->zprev, 0, sizeof(double) * ML * ld, s);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->gprev, 0, sizeof(double) * ML * ld, s);
+    if (e3 == hipSuccess) e3 = hipMemsetAsync(ds->g, 0, sizeof(double) * ML * (ld + 16), s);
     if (e3 == hipSuccess) e3 = hipStreamSynchronize(s);
     if (e3 != hipSuccess) rc = fail(SLM_ERR_HIP, "memset: %s", hipGetErrorString(e3));
   }
@@ -590,7 +623,7 @@ extern "C" int slm_dataset_set_groups(slm_dataset* ds, const int32_t* gid, int32
   SLM_TRY(dalloc(&ds->order, p));
   SLM_TRY(dalloc(&ds->gid, p));
   SLM_TRY(dalloc(&ds->gstart, n_groups + 1));
-  SLM_TRY(dalloc(&ds->gscale, n_groups));
+  SLM_TRY(dalloc(&ds->gscale, (size_t)kMaxLanes * n_groups));
   HIP_TRY(hipMemcpy(ds->order, order.data(), sizeof(int) * p, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ds->gid, gid, sizeof(int) * p, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ds->gstart, start.data(), sizeof(int) * (n_groups + 1), hipMemcpyHostToDevice));
@@ -603,60 +636,78 @@ extern "C" int slm_dataset_set_groups(slm_dataset* ds, const int32_t* gid, int32
 // ------------------------------------------------------------------------------------------------
 // launches
 // ------------------------------------------------------------------------------------------------
-static GradArgs make_grad_args(slm_dataset* ds, const double* y, const double* z, const int* done) {
+struct LaneSetup {
+  int B = 1;
+  const double* rw = nullptr;  // device row weights handed to the kernel
+  int64_t rw_stride = 0;
+  double n_eff[SLM_MAX_LANES] = {0, 0, 0, 0};
+};
+
+static LaneSetup default_lanes(slm_dataset* ds, int B) {
+  LaneSetup ls;
+  ls.B = B;
+  ls.rw = ds->rw;
+  ls.rw_stride = 0;
+  for (int l = 0; l < kMaxLanes; ++l) ls.n_eff[l] = (double)ds->n_global;
+  return ls;
+}
+
+// grad -> reduce (-> all-reduce) for B lanes on ONE pass over X:
+// g_l = X^T W_l (X z_l - y) / n_eff_l in ds->g + l*(ld+16), loss_l in g_l[ld].
+static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done,
+                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+  hipStream_t s = ds->eng->stream;
+  const int B = ls.B;
+  const GradKernel* gk = ds->gk[B - 1];
+  const int nblk = ds->nblk[B - 1];
   GradArgs a;
   a.X = ds->X;
   a.y = y;
-  a.rw = ds->rw;
-  a.z = z;
+  a.rw = ls.rw;
+  a.z = ds->z;
   a.partial = ds->partial;
   a.loss_partial = ds->loss_partial;
   a.done = done;
   a.n = ds->n;
   a.ld = ds->ld;
-  a.rows_base = ds->n / ds->nblk;
-  a.rows_rem = ds->n % ds->nblk;
+  a.rows_base = ds->n / nblk;
+  a.rows_rem = ds->n % nblk;
+  a.rw_stride = ls.rw_stride;
   a.p2 = (int)(ds->ld / 2);
-  return a;
-}
-
-static inline void launch_grad(slm_dataset* ds, const GradArgs& a) {
-  hipLaunchKernelGGL(ds->gk->fn, dim3(ds->nblk), dim3(ds->gk->W * 64), 0, ds->eng->stream, a);
-}
-
-// grad -> reduce (-> all-reduce).  g = X^T W (X z - y) / n_global in ds->g, loss in ds->g[ld].
-static int enqueue_gradient(slm_dataset* ds, const double* y, const double* z, const int* done,
-                            hipEvent_t ev_start, hipEvent_t ev_stop) {
-  hipStream_t s = ds->eng->stream;
-  GradArgs ga = make_grad_args(ds, y, z, done);
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
-  launch_grad(ds, ga);
+  hipLaunchKernelGGL(gk->fn, dim3(nblk), dim3(gk->W * 64), 0, s, a);
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
   ReduceArgs ra;
   ra.partial = ds->partial;
   ra.loss_partial = ds->loss_partial;
   ra.g = ds->g;
   ra.done = done;
-  ra.nblk = ds->nblk;
+  ra.nblk = nblk;
+  ra.n_lanes = B;
   ra.ld = ds->ld;
-  ra.scale = 1.0 / (double)ds->n_global;
-  ra.loss_scale = 0.5 / (double)ds->n_global;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(ds->ld / 16 + 1)), dim3(256), 0, s, ra);
+  for (int l = 0; l < kMaxLanes; ++l) {
+    const double ne = ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global;
+    ra.scale[l] = 1.0 / ne;
+    ra.loss_scale[l] = 0.5 / ne;
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(ds->ld / 16 + 1), B), dim3(256), 0, s, ra);
   if (ds->eng->comm) {  // also with one rank: keeps the RCCL path exercised on a single GPU
-    RCCL_TRY(g_rccl.AllReduce(ds->g, ds->g, (size_t)(ds->ld + 16), kNcclFloat64, kNcclSum, ds->eng->comm, s));
+    RCCL_TRY(g_rccl.AllReduce(ds->g, ds->g, (size_t)B * (size_t)(ds->ld + 16), kNcclFloat64, kNcclSum,
+                              ds->eng->comm, s));
   }
   return SLM_OK;
 }
 
-// E = features per thread of the single-workgroup tail kernel (p <= 1024 * E <= 10240)
+// E = features per thread of the one-workgroup-per-lane tail kernel (p <= 1024 * E <= 10240)
 static void launch_tail(const TailArgs& ta, hipStream_t s) {
   const int E = (ta.p + TAIL_THREADS - 1) / TAIL_THREADS;
+  const dim3 grid(ta.n_lanes);
   switch (E) {
 #define SLM_TAIL_CASE(N) \
-  case N: hipLaunchKernelGGL(fista_tail_kernel<N>, dim3(1), dim3(TAIL_THREADS), 0, s, ta); break;
+  case N: hipLaunchKernelGGL(fista_tail_kernel<N>, grid, dim3(TAIL_THREADS), 0, s, ta); break;
     SLM_TAIL_CASE(1) SLM_TAIL_CASE(2) SLM_TAIL_CASE(3) SLM_TAIL_CASE(4) SLM_TAIL_CASE(5)
     SLM_TAIL_CASE(6) SLM_TAIL_CASE(7) SLM_TAIL_CASE(8) SLM_TAIL_CASE(9)
-    default: hipLaunchKernelGGL(fista_tail_kernel<10>, dim3(1), dim3(TAIL_THREADS), 0, s, ta); break;
+    default: hipLaunchKernelGGL(fista_tail_kernel<10>, grid, dim3(TAIL_THREADS), 0, s, ta); break;
 #undef SLM_TAIL_CASE
   }
 }
@@ -668,38 +719,46 @@ static int check_launch() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lipschitz constant
+// Lipschitz constants: lambda_max(X^T W_l X)/n_eff_l for every lane of `ls` in one batched run
 // ------------------------------------------------------------------------------------------------
-static int estimate_lipschitz(slm_dataset* ds, double* L_out) {
-  if (ds->L_valid) {
-    *L_out = ds->L;
-    return SLM_OK;
-  }
+static int power_iteration(slm_dataset* ds, const LaneSetup& ls, double* L_out /*[B]*/) {
   hipStream_t s = ds->eng->stream;
   int iters = 10;
   if (const char* env = getenv("SLM_POWER_ITERS")) iters = std::max(2, atoi(env));
-  hipLaunchKernelGGL(power_init_kernel, dim3(1), dim3(TAIL_THREADS), 0, s, ds->z, (int)ds->p, ds->ld);
+  hipLaunchKernelGGL(power_init_kernel, dim3(ls.B), dim3(TAIL_THREADS), 0, s, ds->z, (int)ds->p, ds->ld);
   for (int k = 0; k < iters; ++k) {
-    SLM_TRY(enqueue_gradient(ds, ds->yzero, ds->z, nullptr, nullptr, nullptr));
+    SLM_TRY(enqueue_gradient(ds, ls, ds->yzero, nullptr, nullptr, nullptr));
     PowerArgs pa;
     pa.g = ds->g;
     pa.v = ds->z;
     pa.lambda = ds->lambda;
     pa.p = (int)ds->p;
-    hipLaunchKernelGGL(power_step_kernel, dim3(1), dim3(TAIL_THREADS), 0, s, pa);
+    pa.ld = ds->ld;
+    hipLaunchKernelGGL(power_step_kernel, dim3(ls.B), dim3(TAIL_THREADS), 0, s, pa);
   }
   SLM_TRY(check_launch());
-  double lam = 0.0;
-  HIP_TRY(hipMemcpyAsync(&lam, ds->lambda, sizeof(double), hipMemcpyDeviceToHost, s));
+  double lam[SLM_MAX_LANES] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(lam, ds->lambda, sizeof(double) * ls.B, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  if (!std::isfinite(lam)) return fail(SLM_ERR_NON_FINITE, "power iteration produced a non-finite value");
-  // ||A v|| after k steps under-estimates lambda_max by a few per cent on flat spectra; the margin
-  // below plus the in-loop curvature guard (fista_tail_kernel) keep the step 1/L safe.
-  double L = lam * 1.08;
-  if (!(L > 0.0)) L = 1.0;  // X == 0
-  ds->L = L;
-  ds->L_valid = true;
-  *L_out = L;
+  for (int l = 0; l < ls.B; ++l) {
+    if (!std::isfinite(lam[l])) return fail(SLM_ERR_NON_FINITE, "power iteration produced a non-finite value");
+    // ||A v|| after k steps under-estimates lambda_max by a few per cent on flat spectra; the margin
+    // below plus the in-loop curvature guard (fista_tail_kernel) keep the step 1/L safe.
+    double L = lam[l] * 1.08;
+    if (!(L > 0.0)) L = 1.0;  // X == 0
+    L_out[l] = L;
+  }
+  return SLM_OK;
+}
+
+static int estimate_lipschitz(slm_dataset* ds, double* L_out) {
+  if (!ds->L_valid) {
+    double L[SLM_MAX_LANES];
+    SLM_TRY(power_iteration(ds, default_lanes(ds, 1), L));
+    ds->L = L[0];
+    ds->L_valid = true;
+  }
+  *L_out = ds->L;
   return SLM_OK;
 }
 
@@ -717,9 +776,10 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
   HIP_TRY(hipSetDevice(ds->eng->device));
   hipStream_t s = ds->eng->stream;
+  const LaneSetup ls = default_lanes(ds, 1);
   HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * ds->ld, s));
   if (z) HIP_TRY(hipMemcpyAsync(ds->z, z, sizeof(double) * ds->p, hipMemcpyHostToDevice, s));
-  SLM_TRY(enqueue_gradient(ds, ds->y, ds->z, nullptr, nullptr, nullptr));
+  SLM_TRY(enqueue_gradient(ds, ls, ds->y, nullptr, nullptr, nullptr));
   SLM_TRY(check_launch());
   HIP_TRY(hipStreamSynchronize(s));
   if (g_out) HIP_TRY(hipMemcpy(g_out, ds->g, sizeof(double) * ds->p, hipMemcpyDeviceToHost));
@@ -727,13 +787,25 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
   if (ms_out) {
     *ms_out = 0.0;
     if (reps < 1) reps = 1;
+    // lanes used by the probe: SLM_PROBE_LANES (tuning), default 1
+    int B = 1;
+    if (const char* env = getenv("SLM_PROBE_LANES")) B = std::min(kMaxLanes, std::max(1, atoi(env)));
+    if (!ds->gk[B - 1]) return fail(SLM_ERR_UNSUPPORTED, "no %d-lane kernel for p = %lld", B, (long long)ds->p);
+    for (int l = 1; l < B; ++l)
+      HIP_TRY(hipMemcpyAsync(ds->z + l * ds->ld, ds->z, sizeof(double) * ds->ld, hipMemcpyDeviceToDevice, s));
+    const LaneSetup lb = default_lanes(ds, B);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    GradArgs ga = make_grad_args(ds, ds->y, ds->z, nullptr);
-    launch_grad(ds, ga);  // warm
+    const GradKernel* gk = ds->gk[B - 1];
+    const int nblk = ds->nblk[B - 1];
+    GradArgs a;
+    a.X = ds->X; a.y = ds->y; a.rw = lb.rw; a.z = ds->z; a.partial = ds->partial;
+    a.loss_partial = ds->loss_partial; a.done = nullptr; a.n = ds->n; a.ld = ds->ld;
+    a.rows_base = ds->n / nblk; a.rows_rem = ds->n % nblk; a.rw_stride = 0; a.p2 = (int)(ds->ld / 2);
+    hipLaunchKernelGGL(gk->fn, dim3(nblk), dim3(gk->W * 64), 0, s, a);  // warm
     HIP_TRY(hipEventRecord(e0, s));
-    for (int r = 0; r < reps; ++r) launch_grad(ds, ga);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(gk->fn, dim3(nblk), dim3(gk->W * 64), 0, s, a);
     HIP_TRY(hipEventRecord(e1, s));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -747,41 +819,52 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
 }
 
 // ------------------------------------------------------------------------------------------------
-// path solve
+// path solves
 // ------------------------------------------------------------------------------------------------
-static int upload_vec_or_const(double* dst, const double* src, int64_t count, double fill, hipStream_t s,
-                               std::vector<double>& scratch) {
+static int upload_vec_or_const(double* dst, const double* src, int64_t count, double fill, hipStream_t s) {
   if (src) {
     for (int64_t i = 0; i < count; ++i)
       if (!(src[i] >= 0.0) || !std::isfinite(src[i]))
         return fail(SLM_ERR_BAD_ARG, "penalty weights must be finite and >= 0 (index %lld)", (long long)i);
     HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
   } else {
-    scratch.assign((size_t)count, fill);
-    HIP_TRY(hipMemcpyAsync(dst, scratch.data(), sizeof(double) * count, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // scratch is reused
+    const int blocks = (int)std::min<int64_t>(1024, (count + 255) / 256);
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, dst, count, fill);
   }
   return SLM_OK;
 }
 
-extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,
-                              int32_t n_points, const slm_solve_opts* opts, const double* beta0,
-                              double* betas_out, double* group_norms_out, slm_point_info* infos,
-                              slm_solve_stats* stats) {
-  if (!ds || !points || !betas_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
-  if (n_points <= 0) return fail(SLM_ERR_BAD_ARG, "n_points must be positive");
-  for (int k = 0; k < n_points; ++k) {
-    const slm_path_point& q = points[k];
-    if (!(q.sa >= 0.0) || !(q.sb >= 0.0) || !(q.sd >= 0.0) || !std::isfinite(q.sa + q.sb + q.sd))
-      return fail(SLM_ERR_BAD_ARG, "path point %d has a negative or non-finite scale", k);
-    if (!std::isfinite(q.extrap) || std::fabs(q.extrap) > 1e3)
-      return fail(SLM_ERR_BAD_ARG, "path point %d has an unreasonable extrapolation factor", k);
+extern "C" int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes,
+                               const slm_solve_opts* opts, slm_solve_stats* stats) {
+  if (!ds || !lanes) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  if (n_lanes < 1 || n_lanes > kMaxLanes)
+    return fail(SLM_ERR_BAD_ARG, "n_lanes must be in [1, %d] (got %d)", kMaxLanes, n_lanes);
+  const int B = n_lanes;
+  if (!ds->gk[B - 1])
+    return fail(SLM_ERR_UNSUPPORTED, "no %d-lane gradient kernel covers p = %lld", B, (long long)ds->p);
+  int64_t total_points = 0;
+  bool any_rw = false, any_gn = false;
+  for (int l = 0; l < B; ++l) {
+    const slm_lane& ln = lanes[l];
+    if (!ln.points || !ln.betas_out) return fail(SLM_ERR_BAD_ARG, "lane %d: NULL points or betas_out", l);
+    if (ln.n_points <= 0) return fail(SLM_ERR_BAD_ARG, "lane %d: n_points must be positive", l);
+    for (int k = 0; k < ln.n_points; ++k) {
+      const slm_path_point& q = ln.points[k];
+      if (!(q.sa >= 0.0) || !(q.sb >= 0.0) || !(q.sd >= 0.0) || !std::isfinite(q.sa + q.sb + q.sd))
+        return fail(SLM_ERR_BAD_ARG, "path point %d has a negative or non-finite scale", k);
+      if (!std::isfinite(q.extrap) || std::fabs(q.extrap) > 1e3)
+        return fail(SLM_ERR_BAD_ARG, "path point %d has an unreasonable extrapolation factor", k);
+    }
+    total_points += ln.n_points;
+    any_rw = any_rw || ln.row_weight != nullptr;
+    any_gn = any_gn || ln.group_norms_out != nullptr;
   }
   slm_engine* eng = ds->eng;
   HIP_TRY(hipSetDevice(eng->device));
   hipStream_t s = eng->stream;
   const auto t_begin = std::chrono::steady_clock::now();
-  const int64_t p = ds->p, ld = ds->ld;
+  const int64_t p = ds->p, ld = ds->ld, n = ds->n;
   const int G = ds->G;
 
   slm_solve_opts o;
@@ -791,62 +874,110 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
   if (o.max_iter <= 0) o.max_iter = 10000;
   const bool profile = (o.flags & SLM_FLAG_PROFILE) != 0;
 
-  // ---- Lipschitz constant ------------------------------------------------------------------
-  double L = o.L;
+  // ---- per-lane row weights / scaling -----------------------------------------------------------
+  LaneSetup ls = default_lanes(ds, B);
+  if (any_rw) {
+    if (!ds->rw_lanes) SLM_TRY(dalloc(&ds->rw_lanes, (size_t)kMaxLanes * n));
+    for (int l = 0; l < B; ++l) {
+      double* dst = ds->rw_lanes + (size_t)l * n;
+      if (lanes[l].row_weight) {
+        const double* w = lanes[l].row_weight;
+        for (int64_t i = 0; i < n; ++i)
+          if (!(w[i] >= 0.0) || !std::isfinite(w[i]))
+            return fail(SLM_ERR_BAD_ARG, "lane %d: row_weight[%lld] is negative or not finite", l, (long long)i);
+        HIP_TRY(hipMemcpyAsync(dst, w, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+      } else if (ds->rw) {
+        HIP_TRY(hipMemcpyAsync(dst, ds->rw, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+      } else {
+        hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, s, dst, n, 1.0);
+      }
+    }
+    ls.rw = ds->rw_lanes;
+    ls.rw_stride = n;
+  }
+  bool custom_scale = false;
+  for (int l = 0; l < B; ++l)
+    if (lanes[l].n_eff > 0) {
+      ls.n_eff[l] = (double)lanes[l].n_eff;
+      custom_scale = true;
+    }
+
+  // ---- Lipschitz constants -----------------------------------------------------------------------
+  double L[SLM_MAX_LANES];
   double lipschitz_ms = 0.0;
-  if (!(L > 0.0)) {
-    if (o.flags & SLM_FLAG_FRESH_L) ds->L_valid = false;
-    const bool cached = ds->L_valid;
+  if (o.L > 0.0) {
+    for (int l = 0; l < B; ++l) L[l] = o.L;
+  } else {
     const auto t0 = std::chrono::steady_clock::now();
-    SLM_TRY(estimate_lipschitz(ds, &L));
-    if (!cached)
+    bool ran = false;
+    if (any_rw || custom_scale) {
+      SLM_TRY(power_iteration(ds, ls, L));  // lane-specific operators: not cached
+      ran = true;
+    } else {
+      if (o.flags & SLM_FLAG_FRESH_L) ds->L_valid = false;
+      ran = !ds->L_valid;
+      double L1 = 0.0;
+      SLM_TRY(estimate_lipschitz(ds, &L1));
+      for (int l = 0; l < B; ++l) L[l] = L1;
+    }
+    if (ran)
       lipschitz_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 
-  // ---- buffers -----------------------------------------------------------------------------
-  if (n_points > ds->cap_points) {
+  // ---- buffers -----------------------------------------------------------------------------------
+  if (total_points > ds->cap_points) {
     dfree(ds->pts); dfree(ds->betas_out); dfree(ds->infos);
     ds->cap_points = 0;
-    SLM_TRY(dalloc(&ds->pts, n_points));
-    SLM_TRY(dalloc(&ds->betas_out, (size_t)n_points * p));
-    SLM_TRY(dalloc(&ds->infos, n_points));
-    ds->cap_points = n_points;
+    SLM_TRY(dalloc(&ds->pts, total_points));
+    SLM_TRY(dalloc(&ds->betas_out, (size_t)total_points * p));
+    SLM_TRY(dalloc(&ds->infos, total_points));
+    ds->cap_points = total_points;
   }
-  if (group_norms_out && (int64_t)n_points * G > ds->cap_gn) {
+  if (any_gn && total_points * G > ds->cap_gn) {
     dfree(ds->gn_out);
     ds->cap_gn = 0;
-    SLM_TRY(dalloc(&ds->gn_out, (size_t)n_points * G));
-    ds->cap_gn = (int)std::min<int64_t>((int64_t)n_points * G, 2147483647);
+    SLM_TRY(dalloc(&ds->gn_out, (size_t)total_points * G));
+    ds->cap_gn = total_points * G;
   }
-  std::vector<double> scratch;
-  SLM_TRY(upload_vec_or_const(ds->a0, pen ? pen->a : nullptr, p, 1.0, s, scratch));
-  SLM_TRY(upload_vec_or_const(ds->b0, pen ? pen->b : nullptr, G, 1.0, s, scratch));
-  SLM_TRY(upload_vec_or_const(ds->d0, pen ? pen->d : nullptr, G, 1.0, s, scratch));
-  HIP_TRY(hipMemcpyAsync(ds->pts, points, sizeof(slm_path_point) * n_points, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(ds->beta, 0, sizeof(double) * ld, s));
-  if (beta0) {
-    for (int64_t j = 0; j < p; ++j)
-      if (!std::isfinite(beta0[j])) return fail(SLM_ERR_BAD_ARG, "beta0[%lld] is not finite", (long long)j);
-    HIP_TRY(hipMemcpyAsync(ds->beta, beta0, sizeof(double) * p, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(ds->beta, 0, sizeof(double) * kMaxLanes * ld, s));
+  HIP_TRY(hipMemsetAsync(ds->zprev, 0, sizeof(double) * kMaxLanes * ld, s));
+  HIP_TRY(hipMemsetAsync(ds->gprev, 0, sizeof(double) * kMaxLanes * ld, s));
+  HIP_TRY(hipMemsetAsync(ds->infos, 0, sizeof(slm_point_info) * total_points, s));
+  PathCtl h[SLM_MAX_LANES];
+  memset(h, 0, sizeof(h));
+  int64_t off = 0;
+  for (int l = 0; l < B; ++l) {
+    const slm_lane& ln = lanes[l];
+    const slm_penalty* pen = ln.pen;
+    SLM_TRY(upload_vec_or_const(ds->a0 + (size_t)l * ld, pen ? pen->a : nullptr, p, 1.0, s));
+    SLM_TRY(upload_vec_or_const(ds->b0 + (size_t)l * ld, pen ? pen->b : nullptr, G, 1.0, s));
+    SLM_TRY(upload_vec_or_const(ds->d0 + (size_t)l * ld, pen ? pen->d : nullptr, G, 1.0, s));
+    HIP_TRY(hipMemcpyAsync(ds->pts + off, ln.points, sizeof(slm_path_point) * ln.n_points,
+                           hipMemcpyHostToDevice, s));
+    if (ln.beta0) {
+      for (int64_t j = 0; j < p; ++j)
+        if (!std::isfinite(ln.beta0[j])) return fail(SLM_ERR_BAD_ARG, "beta0[%lld] is not finite", (long long)j);
+      HIP_TRY(hipMemcpyAsync(ds->beta + (size_t)l * ld, ln.beta0, sizeof(double) * p, hipMemcpyHostToDevice, s));
+    }
+    h[l].n_points = ln.n_points;
+    h[l].max_iter = o.max_iter;
+    h[l].t = 1.0;
+    h[l].L = L[l];
+    h[l].tol = o.tol;
+    h[l].flags = o.flags;
+    h[l].pt_off = (int32_t)off;
+    off += ln.n_points;
   }
-  HIP_TRY(hipMemcpyAsync(ds->z, ds->beta, sizeof(double) * ld, hipMemcpyDeviceToDevice, s));
-  HIP_TRY(hipMemsetAsync(ds->zprev, 0, sizeof(double) * ld, s));
-  HIP_TRY(hipMemsetAsync(ds->gprev, 0, sizeof(double) * ld, s));
-  HIP_TRY(hipMemsetAsync(ds->infos, 0, sizeof(slm_point_info) * n_points, s));
-
-  PathCtl h;
-  memset(&h, 0, sizeof(h));
-  h.n_points = n_points;
-  h.max_iter = o.max_iter;
-  h.t = 1.0;
-  h.L = L;
-  h.tol = o.tol;
-  h.flags = o.flags;
-  HIP_TRY(hipMemcpyAsync(ds->ctl, &h, sizeof(PathCtl), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));  // host staging buffers (h, points, beta0) are free again
+  HIP_TRY(hipMemcpyAsync(ds->z, ds->beta, sizeof(double) * kMaxLanes * ld, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ds->ctl, h, sizeof(PathCtl) * B, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(ds->gctl, 0, sizeof(GlobalCtl), s));
+  HIP_TRY(hipStreamSynchronize(s));  // host staging buffers are free again
 
   TailArgs ta;
   ta.ctl = ds->ctl;
+  ta.gdone = reinterpret_cast<int*>(ds->gctl);
+  ta.n_lanes = B;
   ta.pts = ds->pts;
   ta.p = (int)p;
   ta.G = G;
@@ -866,21 +997,23 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
   ta.gid = ds->gid;
   ta.gstart = ds->gstart;
   ta.betas_out = ds->betas_out;
-  ta.gn_out = group_norms_out ? ds->gn_out : nullptr;
+  ta.gn_out = any_gn ? ds->gn_out : nullptr;
   ta.infos = ds->infos;
 
-  // ---- queue iterations; the device decides when each point (and the path) is finished ---------
+  // ---- queue iterations; the device decides when each point / lane / the solve is finished ------
   int chunk = o.check_every;
   if (chunk <= 0) {
-    const double est_us = std::max(12.0, (double)ds->n * (double)ld * 8.0 / 5.0e6);
+    const double est_us = std::max(12.0, (double)n * (double)ld * 8.0 / 5.0e6);
     chunk = (int)std::min(32.0, std::max(2.0, 400.0 / est_us));
   }
-  const int64_t max_total = (int64_t)n_points * o.max_iter;
+  int max_points = 0;
+  for (int l = 0; l < B; ++l) max_points = std::max(max_points, (int)lanes[l].n_points);
+  const int64_t max_total = (int64_t)max_points * o.max_iter;
   int64_t enq = 0;
   int slot = 0;
   bool pending[2] = {false, false};
   bool done = false;
-  const int* done_flag = &ds->ctl->done;
+  const int* done_flag = &ds->gctl->done;
   while (!done) {
     for (int i = 0; i < chunk; ++i) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -894,19 +1027,19 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
         e0 = ds->prof[2 * slot_id];
         e1 = ds->prof[2 * slot_id + 1];
       }
-      SLM_TRY(enqueue_gradient(ds, ds->y, ds->z, done_flag, e0, e1));
+      SLM_TRY(enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1));
       launch_tail(ta, s);
       ++enq;
     }
     SLM_TRY(check_launch());
-    HIP_TRY(hipMemcpyAsync(&ds->hctl[slot], ds->ctl, sizeof(PathCtl), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&ds->hctl[slot].g, ds->gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(ds->ev[slot], s));
     pending[slot] = true;
     const int other = slot ^ 1;
     if (pending[other]) {
       HIP_TRY(hipEventSynchronize(ds->ev[other]));
       pending[other] = false;
-      if (ds->hctl[other].done) done = true;
+      if (ds->hctl[other].g.done) done = true;
     }
     slot = other;
     if (!done && enq >= max_total + 2 * (int64_t)chunk) {
@@ -915,21 +1048,33 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
     }
   }
   HIP_TRY(hipStreamSynchronize(s));
-  PathCtl fin;
-  HIP_TRY(hipMemcpy(&fin, ds->ctl, sizeof(PathCtl), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(betas_out, ds->betas_out, sizeof(double) * (size_t)n_points * p, hipMemcpyDeviceToHost));
-  if (group_norms_out)
-    HIP_TRY(hipMemcpy(group_norms_out, ds->gn_out, sizeof(double) * (size_t)n_points * G, hipMemcpyDeviceToHost));
-  if (infos) HIP_TRY(hipMemcpy(infos, ds->infos, sizeof(slm_point_info) * n_points, hipMemcpyDeviceToHost));
+  PathCtl fin[SLM_MAX_LANES];
+  HIP_TRY(hipMemcpy(fin, ds->ctl, sizeof(PathCtl) * B, hipMemcpyDeviceToHost));
+  int64_t passes = 0;
+  bool nonfinite = false;
+  off = 0;
+  for (int l = 0; l < B; ++l) {
+    const slm_lane& ln = lanes[l];
+    HIP_TRY(hipMemcpy(ln.betas_out, ds->betas_out + (size_t)off * p, sizeof(double) * (size_t)ln.n_points * p,
+                      hipMemcpyDeviceToHost));
+    if (ln.group_norms_out)
+      HIP_TRY(hipMemcpy(ln.group_norms_out, ds->gn_out + (size_t)off * G,
+                        sizeof(double) * (size_t)ln.n_points * G, hipMemcpyDeviceToHost));
+    if (ln.infos)
+      HIP_TRY(hipMemcpy(ln.infos, ds->infos + off, sizeof(slm_point_info) * ln.n_points, hipMemcpyDeviceToHost));
+    off += ln.n_points;
+    passes = std::max<int64_t>(passes, fin[l].total_iter);
+    nonfinite = nonfinite || fin[l].nonfinite;
+  }
   if (stats) {
-    stats->grad_launches = fin.total_iter;
+    stats->grad_launches = passes;  // launches that did work (every launch serves all lanes)
     stats->grad_ms_total = 0.0;
     stats->grad_timed = 0;
     if (profile) {
       double tot = 0.0;
       int64_t cnt = 0;
-      // iterations 0, kProfStride, 2 kProfStride, ... below total_iter did real work and were timed
-      for (int64_t k = 0; k * kProfStride < fin.total_iter && 2 * k + 1 < (int64_t)ds->prof.size(); ++k) {
+      // iterations 0, kProfStride, 2 kProfStride, ... below `passes` did real work and were timed
+      for (int64_t k = 0; k * kProfStride < passes && 2 * k + 1 < (int64_t)ds->prof.size(); ++k) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ds->prof[2 * k], ds->prof[2 * k + 1]) == hipSuccess) {
           tot += ms;
@@ -943,10 +1088,25 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
     stats->wall_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
-  if (fin.nonfinite)
-    return fail(SLM_ERR_NON_FINITE, "non-finite iterate at path point %d (diverged or non-finite data)",
-                fin.point - 1);
+  if (nonfinite) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
   return SLM_OK;
+}
+
+extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,
+                              int32_t n_points, const slm_solve_opts* opts, const double* beta0,
+                              double* betas_out, double* group_norms_out, slm_point_info* infos,
+                              slm_solve_stats* stats) {
+  if (!ds || !points || !betas_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  slm_lane lane;
+  memset(&lane, 0, sizeof(lane));
+  lane.pen = pen;
+  lane.points = points;
+  lane.n_points = n_points;
+  lane.beta0 = beta0;
+  lane.betas_out = betas_out;
+  lane.group_norms_out = group_norms_out;
+  lane.infos = infos;
+  return slm_solve_lanes(ds, &lane, 1, opts, stats);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -30,15 +30,16 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 struct GradArgs {
   const double* X;       // [n][ld], pad columns are zero
   const double* y;       // [n]
-  const double* rw;      // [n] row weights or nullptr
-  const double* z;       // [ld], pad entries are zero
-  double* partial;       // [gridDim.x][ld]
-  double* loss_partial;  // [gridDim.x]   sum_i w_i (x_i.z - y_i)^2 over the block's rows
+  const double* rw;      // row weights: nullptr, [n] (rw_stride == 0) or [B][rw_stride] per lane
+  const double* z;       // [B][ld], pad entries are zero
+  double* partial;       // [gridDim.x][B][ld]
+  double* loss_partial;  // [gridDim.x][B]   sum_i w_i (x_i.z - y_i)^2 over the block's rows
   const int* done;       // early-exit flag of the path state machine (nullable)
   int64_t n;
   int64_t ld;            // doubles, multiple of 16
   int64_t rows_base;     // n / gridDim.x   (host-computed: no 64-bit division on the device)
   int64_t rows_rem;      // n % gridDim.x
+  int64_t rw_stride;     // 0: all lanes share rw[]; otherwise lane b reads rw[b*rw_stride + row]
   int p2;                // ld / 2: number of 16-byte chunks per row
 };
 
@@ -60,19 +61,68 @@ __device__ __forceinline__ double wave_sum_all(double v) {
   return v;
 }
 
-template <int C, int R>
+// v + (v moved by a DPP pattern); lanes the pattern does not feed (or rows masked off) add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return v + __hiloint2double(hi2, lo2);
+}
+
+// Sum over the 64 lanes with DPP moves only (no LDS round trips, short dependent chain):
+// inclusive scan inside each row of 16 lanes (row_shr 1,2,4,8), then row_bcast15 / row_bcast31
+// carry the row totals forward.  The total ends up in LANE 63 (other lanes hold prefixes).
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+// Sum over aligned groups of W lanes (W = 2, 4, 8), every lane of the group getting the same bits
+// (the pairings are commutative): row_half_mirror, then quad permutes [3,2,1,0] and [1,0,3,2].
+template <int W>
+__device__ __forceinline__ double group_sum_all(double t) {
+  static_assert(W == 1 || W == 2 || W == 4 || W == 8, "W must be 1, 2, 4 or 8");
+  if constexpr (W == 8) {
+    t = dpp_add<0x141, 0xf>(t);  // row_half_mirror: i <-> 7 - i
+    t = dpp_add<0x1B, 0xf>(t);   // quad_perm [3,2,1,0]
+    t = dpp_add<0xB1, 0xf>(t);   // quad_perm [1,0,3,2]
+  } else if constexpr (W == 4) {
+    t = dpp_add<0xB1, 0xf>(t);   // quad_perm [1,0,3,2]
+    t = dpp_add<0x4E, 0xf>(t);   // quad_perm [2,3,0,1]
+  } else if constexpr (W == 2) {
+    t = dpp_add<0xB1, 0xf>(t);
+  }
+  return t;
+}
+
+__device__ __forceinline__ double read_lane63(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+template <int C, int R, int B>
 struct RowSet {
   d2 x[R][C];
   double y[R];
-  double m[R];  // row multiplier: row weight, or 0 for rows past the end of the block's range
+  double m[R][B];  // row multiplier per lane: row weight, or 0 for rows past the block's range
 };
 
-template <int W, int C, int R>
+// B = number of independent problems ("lanes": alpha sub-paths, CV folds) that share ONE pass over
+// X.  Lane b has its own point z_b, row weights and partial gradient; the X registers are shared, so
+// HBM traffic per launch is that of a single gradient while B gradients come out.
+template <int W, int C, int R, int B>
 __global__ __launch_bounds__(W * 64) void grad_fused_kernel(GradArgs a) {
   constexpr int T = W * 64;
   if (a.done != nullptr && *a.done != 0) return;
 
-  __shared__ double red[2][R][W];
+  __shared__ double red[2][R][B][W];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -87,78 +137,95 @@ __global__ __launch_bounds__(W * 64) void grad_fused_kernel(GradArgs a) {
   int cidx[C];
   uint32_t coff[C];  // byte offset of the lane's chunk inside a row (rows are < 4 GiB)
   bool valid[C];
-  d2 zr[C], acc[C];
-  const d2* zv = reinterpret_cast<const d2*>(a.z);
+  d2 zr[B][C], acc[B][C];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const int ci = c * T + tid;
     valid[c] = ci < a.p2;
     cidx[c] = valid[c] ? ci : a.p2 - 1;
     coff[c] = (uint32_t)cidx[c] * 16u;
-    d2 zz = zv[cidx[c]];
-    zr[c] = valid[c] ? zz : d2{0.0, 0.0};  // clamped duplicates contribute nothing to the dots
-    acc[c] = d2{0.0, 0.0};
+#pragma unroll
+    for (int l = 0; l < B; ++l) {
+      const d2 zz = reinterpret_cast<const d2*>(a.z + l * a.ld)[cidx[c]];
+      zr[l][c] = valid[c] ? zz : d2{0.0, 0.0};  // clamped duplicates contribute nothing to the dots
+      acc[l][c] = d2{0.0, 0.0};
+    }
   }
-  double loss = 0.0;
+  double loss[B];
+#pragma unroll
+  for (int l = 0; l < B; ++l) loss[l] = 0.0;
 
-  auto load_rows = [&](RowSet<C, R>& s, int64_t step) {
+  auto load_rows = [&](RowSet<C, R, B>& s, int64_t step) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t i = step * R + r;
       const bool live = i < nrows;
       const int64_t row = r0 + (live ? i : nrows - 1);
       s.y[r] = a.y[row];
-      double m = 1.0;
-      if (a.rw != nullptr) m = a.rw[row];
-      s.m[r] = live ? m : 0.0;
+#pragma unroll
+      for (int l = 0; l < B; ++l) {
+        double m = 1.0;
+        if (a.rw != nullptr) m = a.rw[l * a.rw_stride + row];
+        s.m[r][l] = live ? m : 0.0;
+      }
       const char* rp = reinterpret_cast<const char*>(a.X + row * a.ld);  // wave-uniform base
 #pragma unroll
       for (int c = 0; c < C; ++c) s.x[r][c] = load_x(reinterpret_cast<const d2*>(rp + coff[c]));
     }
   };
 
-  auto process = [&](const RowSet<C, R>& s, int parity) {
-    double dot[R];
+  auto process = [&](const RowSet<C, R, B>& s, int parity) {
+    double dot[R][B];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      double t = 0.0;
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        t = __builtin_fma(s.x[r][c].x, zr[c].x, t);
-        t = __builtin_fma(s.x[r][c].y, zr[c].y, t);
-      }
-      dot[r] = wave_sum_all(t);
-    }
-    if constexpr (W > 1) {
-      if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) red[parity][r][wave] = dot[r];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
+      for (int l = 0; l < B; ++l) {
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < W; ++w) t += red[parity][r][w];
-        dot[r] = t;
+        for (int c = 0; c < C; ++c) {
+          t = __builtin_fma(s.x[r][c].x, zr[l][c].x, t);
+          t = __builtin_fma(s.x[r][c].y, zr[l][c].y, t);
+        }
+        dot[r][l] = wave_sum_lane63(t);
+        if constexpr (W == 1) dot[r][l] = read_lane63(dot[r][l]);
+      }
+    }
+    if constexpr (W > 1) {
+      if (lane == 63) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int l = 0; l < B; ++l) red[parity][r][l][wave] = dot[r][l];
+      }
+      __syncthreads();
+      // lane i picks up wavefront (i mod W)'s partial (ONE LDS read per value) and every aligned
+      // group of W lanes folds them with DPP moves: no LDS round trips after the barrier and the
+      // same bits in every lane
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int l = 0; l < B; ++l) dot[r][l] = group_sum_all<W>(red[parity][r][l][lane & (W - 1)]);
       }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const double e = dot[r] - s.y[r];
-      const double res = e * s.m[r];
-      loss = __builtin_fma(res, e, loss);
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        acc[c].x = __builtin_fma(res, s.x[r][c].x, acc[c].x);
-        acc[c].y = __builtin_fma(res, s.x[r][c].y, acc[c].y);
+      for (int l = 0; l < B; ++l) {
+        const double e = dot[r][l] - s.y[r];
+        const double res = e * s.m[r][l];
+        loss[l] = __builtin_fma(res, e, loss[l]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          acc[l][c].x = __builtin_fma(res, s.x[r][c].x, acc[l][c].x);
+          acc[l][c].y = __builtin_fma(res, s.x[r][c].y, acc[l][c].y);
+        }
       }
     }
   };
 
   if (nrows > 0) {
     const int64_t nsteps = (nrows + R - 1) / R;
-    RowSet<C, R> sa, sb;
+    RowSet<C, R, B> sa, sb;
     load_rows(sa, 0);
     for (int64_t s = 0; s < nsteps; s += 2) {
       const bool has1 = s + 1 < nsteps;
@@ -171,57 +238,64 @@ __global__ __launch_bounds__(W * 64) void grad_fused_kernel(GradArgs a) {
     }
   }
 
-  d2* out = reinterpret_cast<d2*>(a.partial + b * a.ld);
 #pragma unroll
-  for (int c = 0; c < C; ++c)
-    if (valid[c]) out[cidx[c]] = acc[c];
-  if (tid == 0) a.loss_partial[b] = loss;
+  for (int l = 0; l < B; ++l) {
+    d2* out = reinterpret_cast<d2*>(a.partial + (b * B + l) * a.ld);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      if (valid[c]) out[cidx[c]] = acc[l][c];
+    if (tid == 0) a.loss_partial[b * B + l] = loss[l];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Deterministic cross-workgroup reduction:  g[j] = scale * sum_b partial[b][j],  loss likewise.
-// 256 threads = 16 column lanes x 16 row slices; one workgroup per 16 columns (128-byte segments).
-// The loss sum lands in g[ld] so that a single all-reduce covers gradient and loss in the
-// row-sharded mode.
+// Deterministic cross-workgroup reduction per lane:  g_l[j] = scale_l * sum_b partial[b][l][j], loss
+// likewise.  256 threads = 16 column lanes x 16 row slices; one workgroup per 16 columns (128-byte
+// segments).  The loss sum lands in g_l[ld] so that a single all-reduce covers gradient and loss in
+// the row-sharded mode.
 // ---------------------------------------------------------------------------------------------
 struct ReduceArgs {
-  const double* partial;
-  const double* loss_partial;
-  double* g;  // [ld + 16]
+  const double* partial;       // [nblk][B][ld]
+  const double* loss_partial;  // [nblk][B]
+  double* g;                   // [B][ld + 16]
   const int* done;
   int nblk;
+  int n_lanes;
   int64_t ld;
-  double scale;       // 1/n
-  double loss_scale;  // 1/(2n)
+  double scale[4];       // 1/n_eff per lane
+  double loss_scale[4];  // 1/(2 n_eff) per lane
 };
 
+// grid = (ld/16 + 1, n_lanes)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceArgs a) {
   if (a.done != nullptr && *a.done != 0) return;
   __shared__ double lds[16][17];
   const int tid = threadIdx.x;
   const int cl = tid & 15, slice = tid >> 4;
+  const int lane = blockIdx.y, B = a.n_lanes;
   const int64_t col = (int64_t)blockIdx.x * 16 + cl;
   const bool loss_block = (int64_t)blockIdx.x * 16 >= a.ld;  // the extra trailing block
   double s = 0.0;
   if (!loss_block) {
-    for (int b = slice; b < a.nblk; b += 16) s += a.partial[(int64_t)b * a.ld + col];
+    for (int b = slice; b < a.nblk; b += 16) s += a.partial[((int64_t)b * B + lane) * a.ld + col];
   } else {
-    for (int b = tid; b < a.nblk; b += 256) s += a.loss_partial[b];
+    for (int b = tid; b < a.nblk; b += 256) s += a.loss_partial[(int64_t)b * B + lane];
   }
   lds[slice][cl] = s;
   __syncthreads();
+  double* g = a.g + (int64_t)lane * (a.ld + 16);
   if (!loss_block) {
     if (slice == 0) {
       double t = 0.0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) t += lds[k][cl];
-      a.g[col] = t * a.scale;
+      g[col] = t * a.scale[lane];
     }
   } else if (tid == 0) {
     double t = 0.0;
     for (int k = 0; k < 16; ++k)
       for (int c = 0; c < 16; ++c) t += lds[k][c];
-    a.g[a.ld] = t * a.loss_scale;
+    g[a.ld] = t * a.loss_scale[lane];
   }
 }
 

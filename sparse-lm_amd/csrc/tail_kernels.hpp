@@ -39,12 +39,15 @@ struct PathCtl {
   double L;            // Lipschitz constant in use
   double tol;
   uint32_t flags;
-  uint32_t pad;
+  int32_t pt_off;      // index of this lane's first point in the concatenated point/output arrays
 };
 
+// One workgroup per lane (blockIdx.x): vectors of lane l start at l * ld (g: l * (ld + 16)).
 struct TailArgs {
-  PathCtl* ctl;
-  const slm_path_point* pts;  // [n_points]
+  PathCtl* ctl;               // [n_lanes]
+  int* gdone;                 // [0] = every lane finished (or abort), [1] = lanes finished so far
+  int n_lanes;
+  const slm_path_point* pts;  // concatenated over lanes
   int p;
   int G;
   int singleton;     // 1 => every feature its own group (gidx == identity)
@@ -62,9 +65,9 @@ struct TailArgs {
   const int* order;  // [p] feature index of the k-th element in group-sorted order
   const int* gid;    // [p] group of feature j
   const int* gstart; // [G+1]
-  double* betas_out; // [n_points][p]
-  double* gn_out;    // [n_points][G] or nullptr
-  slm_point_info* infos;  // [n_points]
+  double* betas_out; // [total points][p]
+  double* gn_out;    // [total points][G] or nullptr
+  slm_point_info* infos;  // [total points]
 };
 
 __device__ __forceinline__ double soft(double v, double thr) {
@@ -131,10 +134,23 @@ template <int E>
 __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   __shared__ double red[8][TAIL_WAVES];
   __shared__ double us[E * TAIL_THREADS];
-  PathCtl* ctl = a.ctl;
-  if (ctl->done != 0) return;
+  const int lane_id = blockIdx.x;
+  PathCtl* ctl = a.ctl + lane_id;
+  if (ctl->done != 0 || a.gdone[0] != 0) return;
   const int tid = threadIdx.x;
   const int p = a.p, G = a.G;
+  {  // rebase every per-lane pointer
+    const int64_t off = (int64_t)lane_id * a.ld;
+    a.beta += off; a.z += off; a.zprev += off; a.gprev += off;
+    a.a0 += off; a.b0 += off; a.d0 += off;
+    a.g += (int64_t)lane_id * (a.ld + 16);
+    a.gscale += (int64_t)lane_id * G;
+    const int64_t po = ctl->pt_off;
+    a.pts += po;
+    a.betas_out += po * p;
+    a.infos += po;
+    if (a.gn_out != nullptr) a.gn_out += po * G;
+  }
 
   // ---- phase 0: per-feature loads (independent of the control block) ---------------------------
   double zj[E], gj[E], bo[E], a0j[E], gpv[E], zpv[E];
@@ -304,8 +320,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       ctl->iter = 0;
       ctl->t = 1.0;
       ctl->point = point + 1;
-      if (nonfinite) ctl->nonfinite = 1;
-      if (point + 1 >= n_points || nonfinite) ctl->done = 1;
+      if (nonfinite) {
+        ctl->nonfinite = 1;
+        ctl->done = 1;
+        a.gdone[0] = 1;  // abort every lane
+      } else if (point + 1 >= n_points) {
+        ctl->done = 1;
+        if (atomicAdd(&a.gdone[1], 1) + 1 == a.n_lanes) a.gdone[0] = 1;
+      }
     } else {
       ctl->iter = iter + 1;
       ctl->t = l_bad ? 1.0 : t_new;
@@ -318,14 +340,19 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
 // (g = A v comes from the fused gradient kernel run with y = 0).
 // ---------------------------------------------------------------------------------------------
 struct PowerArgs {
-  const double* g;  // [ld]
-  double* v;        // [ld]
-  double* lambda;   // [1]
+  const double* g;  // [n_lanes][ld + 16]
+  double* v;        // [n_lanes][ld]
+  double* lambda;   // [n_lanes]
   int p;
+  int64_t ld;
 };
 
+// one workgroup per lane
 __global__ __launch_bounds__(TAIL_THREADS) void power_step_kernel(PowerArgs a) {
   __shared__ double red[1][TAIL_WAVES];
+  a.g += (int64_t)blockIdx.x * (a.ld + 16);
+  a.v += (int64_t)blockIdx.x * a.ld;
+  a.lambda += blockIdx.x;
   double s[1] = {0.0};
   for (int j = threadIdx.x; j < a.p; j += TAIL_THREADS) s[0] = __builtin_fma(a.g[j], a.g[j], s[0]);
   block_sum<1>(s, red);
@@ -345,6 +372,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 // Deterministic start vector for the power iteration: unit-norm hash noise.
 __global__ __launch_bounds__(TAIL_THREADS) void power_init_kernel(double* v, int p, int64_t ld) {
   __shared__ double red[1][TAIL_WAVES];
+  v += (int64_t)blockIdx.x * ld;  // one workgroup per lane, same start vector
   double s[1] = {0.0};
   for (int j = threadIdx.x; j < p; j += TAIL_THREADS) {
     const uint64_t h = mix64(0x9e3779b97f4a7c15ull * (uint64_t)(j + 1));

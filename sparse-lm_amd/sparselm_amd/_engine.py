@@ -58,6 +58,7 @@ ABI_SYMBOLS = (
     "slm_dataset_lipschitz",
     "slm_gradient",
     "slm_solve_path",
+    "slm_solve_lanes",
     "slm_comm_unique_id",
     "slm_comm_init",
     "slm_dataset_set_global_rows",
@@ -111,6 +112,22 @@ class _SolveStats(C.Structure):
         ("lipschitz_ms", C.c_double),
     ]
 
+
+class _Lane(C.Structure):
+    _fields_ = [
+        ("pen", C.POINTER(_PenaltyStruct)),
+        ("points", C.POINTER(_PathPoint)),
+        ("n_points", C.c_int32),
+        ("beta0", C.c_void_p),
+        ("row_weight", C.c_void_p),
+        ("n_eff", C.c_int64),
+        ("betas_out", C.c_void_p),
+        ("group_norms_out", C.c_void_p),
+        ("infos", C.POINTER(_PointInfo)),
+    ]
+
+
+MAX_LANES = 4
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -169,6 +186,7 @@ def load_library():
                 P(_PointInfo),
                 P(_SolveStats),
             ],
+            "slm_solve_lanes": [vp, P(_Lane), i32, P(_SolveOpts), P(_SolveStats)],
             "slm_comm_unique_id": [vp],
             "slm_comm_init": [vp, i32, i32, vp],
             "slm_dataset_set_global_rows": [vp, i64],
@@ -429,6 +447,82 @@ class Dataset:
         )
         return (g, loss.value, ms.value) if reps > 0 else (g, loss.value)
 
+    def solve_lanes(
+        self,
+        lanes,
+        tol: float = 1e-8,
+        max_iter: int = 10000,
+        check_every: int = 0,
+        L: float = 0.0,
+        flags: int = 0,
+        want_group_norms: bool = False,
+        extrapolate: bool = True,
+    ) -> list:
+        """Solve up to MAX_LANES independent warm-started paths on ONE pass over X per iteration.
+
+        ``lanes``: list of dicts with ``points`` (K_l, 3) and optionally ``a``, ``b``, ``d``,
+        ``beta0``, ``row_weight`` (length n, e.g. a CV-fold mask) and ``n_eff`` (1/n scaling, e.g. the
+        number of training rows).  Returns one ``PathResult`` per lane (shared timing fields).
+        """
+        nl = len(lanes)
+        if not (1 <= nl <= MAX_LANES):
+            raise ValueError(f"between 1 and {MAX_LANES} lanes, got {nl}")
+        G = self.n_groups
+        keep = []  # keep every buffer alive for the duration of the call
+        clanes = (_Lane * nl)()
+        outs = []
+        for l, spec in enumerate(lanes):
+            pts = np.ascontiguousarray(spec["points"], dtype=np.float64).reshape(-1, 3)
+            K = pts.shape[0]
+            gam = path_extrapolation(pts) if extrapolate else np.zeros(K)
+            cpts = (_PathPoint * K)(*[_PathPoint(*row, g) for row, g in zip(pts, gam)])
+
+            def vec(name, size):
+                v = spec.get(name)
+                return None if v is None else _f64(np.broadcast_to(v, (size,)), name)
+
+            a_, b_, d_ = vec("a", self.p), vec("b", G), vec("d", G)
+            pen = _PenaltyStruct(_ptr(a_), _ptr(b_), _ptr(d_))
+            b0 = None if spec.get("beta0") is None else _f64(spec["beta0"], "beta0", (self.p,))
+            rw = None if spec.get("row_weight") is None else _f64(spec["row_weight"], "row_weight", (self.n,))
+            betas = np.empty((K, self.p))
+            gn = np.empty((K, G)) if want_group_norms else None
+            infos = (_PointInfo * K)()
+            keep.append((cpts, a_, b_, d_, pen, b0, rw))
+            clanes[l].pen = C.pointer(pen)
+            clanes[l].points = cpts
+            clanes[l].n_points = K
+            clanes[l].beta0 = _ptr(b0)
+            clanes[l].row_weight = _ptr(rw)
+            clanes[l].n_eff = int(spec.get("n_eff") or 0)
+            clanes[l].betas_out = _ptr(betas)
+            clanes[l].group_norms_out = _ptr(gn)
+            clanes[l].infos = infos
+            outs.append((betas, gn, infos, K))
+        opts = _SolveOpts(float(tol), int(max_iter), int(check_every), float(L), int(flags))
+        stats = _SolveStats()
+        _check(self._lib.slm_solve_lanes(self._h, clanes, nl, C.byref(opts), C.byref(stats)))
+        results = []
+        for betas, gn, infos, K in outs:
+            results.append(
+                PathResult(
+                    betas=betas,
+                    group_norms=gn,
+                    n_iter=np.array([i.n_iter for i in infos]),
+                    status=np.array([i.status for i in infos]),
+                    resid=np.array([i.resid for i in infos]),
+                    beta_norm=np.array([i.beta_norm for i in infos]),
+                    loss=np.array([i.loss for i in infos]),
+                    L=float(infos[K - 1].L),
+                    grad_launches=int(stats.grad_launches),
+                    grad_timed=int(stats.grad_timed),
+                    grad_ms_total=float(stats.grad_ms_total),
+                    wall_ms=float(stats.wall_ms),
+                    lipschitz_ms=float(stats.lipschitz_ms),
+                )
+            )
+        return results
+
     def solve_path(
         self,
         points,
@@ -443,48 +537,74 @@ class Dataset:
         flags: int = 0,
         want_group_norms: bool = False,
         extrapolate: bool = True,
+        lanes: int = 1,
     ) -> PathResult:
         """Warm-started path; ``points`` is (K, 3) of (sa, sb, sd) scales applied to (a, b, d).
 
         ``a`` (p,), ``b`` (G,), ``d`` (G,): ``None`` means all ones.  K == 1 is the reference's
         single ``_solve``.  ``extrapolate``: when all points are multiples of one penalty direction
         (an alpha path), start point k from the secant prediction through the two previous solutions.
+        ``lanes`` > 1 cuts the path into that many contiguous sub-paths that advance together, one
+        pass over X serving all of them (the first point of every later sub-path starts cold).
         """
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         K = pts.shape[0]
-        pts = np.hstack([pts, path_extrapolation(pts)[:, None] if extrapolate else np.zeros((K, 1))])
-        G = self.n_groups
-        a_ = None if a is None else _f64(np.broadcast_to(a, (self.p,)), "a")
-        b_ = None if b is None else _f64(np.broadcast_to(b, (G,)), "b")
-        d_ = None if d is None else _f64(np.broadcast_to(d, (G,)), "d")
-        b0 = None if beta0 is None else _f64(beta0, "beta0", (self.p,))
-        pen = _PenaltyStruct(_ptr(a_), _ptr(b_), _ptr(d_))
-        cpts = (_PathPoint * K)(*[_PathPoint(*row) for row in pts])
-        opts = _SolveOpts(float(tol), int(max_iter), int(check_every), float(L), int(flags))
-        betas = np.empty((K, self.p))
-        gn = np.empty((K, G)) if want_group_norms else None
-        infos = (_PointInfo * K)()
-        stats = _SolveStats()
-        _check(
-            self._lib.slm_solve_path(
-                self._h, C.byref(pen), cpts, K, C.byref(opts), _ptr(b0), _ptr(betas), _ptr(gn), infos, C.byref(stats)
-            )
-        )
+        lanes = max(1, min(int(lanes), MAX_LANES, K))
+        common = dict(a=a, b=b, d=d)
+        kw = dict(tol=tol, max_iter=max_iter, check_every=check_every, L=L, flags=flags,
+                  want_group_norms=want_group_norms, extrapolate=extrapolate)
+        if lanes == 1:
+            return self.solve_lanes([dict(points=pts, beta0=beta0, **common)], **kw)[0]
+        bounds = split_path(K, lanes)
+        specs = [dict(points=pts[lo:hi], beta0=beta0 if lo == 0 else None, **common) for lo, hi in bounds]
+        try:
+            parts = self.solve_lanes(specs, **kw)
+        except NotImplementedError:  # no kernel variant for (p, lanes): fall back to fewer lanes
+            return self.solve_path(points, a=a, b=b, d=d, beta0=beta0, lanes=lanes - 1, **kw)
+        gn = None if not want_group_norms else np.vstack([r.group_norms for r in parts])
+        cat = lambda f: np.concatenate([getattr(r, f) for r in parts])  # noqa: E731
+        r0 = parts[0]
         return PathResult(
-            betas=betas,
+            betas=np.vstack([r.betas for r in parts]),
             group_norms=gn,
-            n_iter=np.array([i.n_iter for i in infos]),
-            status=np.array([i.status for i in infos]),
-            resid=np.array([i.resid for i in infos]),
-            beta_norm=np.array([i.beta_norm for i in infos]),
-            loss=np.array([i.loss for i in infos]),
-            L=float(infos[K - 1].L),
-            grad_launches=int(stats.grad_launches),
-            grad_timed=int(stats.grad_timed),
-            grad_ms_total=float(stats.grad_ms_total),
-            wall_ms=float(stats.wall_ms),
-            lipschitz_ms=float(stats.lipschitz_ms),
+            n_iter=cat("n_iter"),
+            status=cat("status"),
+            resid=cat("resid"),
+            beta_norm=cat("beta_norm"),
+            loss=cat("loss"),
+            L=r0.L,
+            grad_launches=r0.grad_launches,
+            grad_timed=r0.grad_timed,
+            grad_ms_total=r0.grad_ms_total,
+            wall_ms=r0.wall_ms,
+            lipschitz_ms=r0.lipschitz_ms,
         )
+
+
+def split_path(n_points: int, lanes: int, cold_cost: float = 3.0) -> list:
+    """Contiguous [lo, hi) blocks of a K-point path for ``lanes`` sub-paths of about equal cost.
+
+    Every sub-path but the first starts cold, which costs about ``cold_cost`` warm points, so the
+    first block gets that many more points.
+    """
+    lanes = max(1, min(lanes, n_points))
+    if lanes == 1:
+        return [(0, n_points)]
+    per = (n_points + cold_cost * (lanes - 1)) / lanes  # cost budget per lane, in warm points
+    sizes = [max(1, int(round(per)))] + [max(1, int(round(per - cold_cost)))] * (lanes - 1)
+    # fix rounding so the sizes add up
+    i = 0
+    while sum(sizes) > n_points:
+        j = max(range(lanes), key=lambda k: sizes[k])
+        sizes[j] -= 1
+    while sum(sizes) < n_points:
+        sizes[i % lanes] += 1
+        i += 1
+    bounds, lo = [], 0
+    for sz in sizes:
+        bounds.append((lo, lo + sz))
+        lo += sz
+    return bounds
 
 
 # -- default engine per process / device ------------------------------------------------------------

@@ -283,6 +283,73 @@ def test_non_finite_data_raises(eng):
             ds.solve_path([(0.1, 0.0, 0.0)], L=1.0)
 
 
+# ---- lanes: several problems on one pass over X ---------------------------------------------------------
+@pytest.mark.parametrize("p", [300, 1100, 2600, 5000])
+def test_path_split_into_lanes_matches_single_lane(eng, p):
+    n = 1500 if p <= 1100 else 800
+    rng = np.random.default_rng(p)
+    X = rng.standard_normal((n, p))
+    beta = np.zeros(p)
+    beta[rng.choice(p, 15, replace=False)] = rng.uniform(1, 5, 15)
+    y = X @ beta + rng.standard_normal(n)
+    amax = np.max(np.abs(X.T @ y)) / n
+    pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 0.05 * amax, 13)]
+    with eng.dataset(X, y) as ds:
+        r1 = ds.solve_path(pts, tol=1e-12, max_iter=200000)
+        assert r1.converged
+        for lanes in (2, 3, 4):
+            rl = ds.solve_path(pts, tol=1e-12, max_iter=200000, lanes=lanes)
+            assert rl.converged
+            assert rl.betas.shape == r1.betas.shape
+            for k in range(1, len(pts)):
+                assert rel_inf(rl.betas[k], r1.betas[k]) < 1e-8, (lanes, k)
+            assert rl.grad_launches < r1.grad_launches  # fewer passes over X
+
+
+def test_lanes_as_cv_folds_match_oracle_on_training_rows(eng, golden):
+    # each lane = one CV fold: its own row mask (test rows weigh 0) and 1/n_train scaling
+    X, y, groups, gw = golden["grp_X"], golden["grp_y"], golden["grp_groups"], golden["grp_gw"]
+    n, p = X.shape
+    gidx, G = oracle.group_index(groups, p)
+    folds = np.arange(n) % 4
+    alpha = float(golden["grp_alpha"])
+    pts = [(0.3 * a, 0.7 * a, 0.0) for a in (2 * alpha, alpha, 0.5 * alpha)]
+    with eng.dataset(X, y) as ds:
+        ds.set_groups(gidx, G)
+        specs = [dict(points=pts, b=gw, row_weight=(folds != f).astype(float), n_eff=int(np.sum(folds != f)))
+                 for f in range(4)]
+        res = ds.solve_lanes(specs, tol=1e-12, max_iter=200000, want_group_norms=True)
+    for f, r in enumerate(res):
+        assert r.converged
+        tr = folds != f
+        b = None
+        for k, (sa, sb, _) in enumerate(pts):
+            b, info = oracle.fista(X[tr], y[tr], sa, sb * gw, 0.0, gidx, G, beta0=b, tol=1e-13)
+            assert rel_inf(r.betas[k], b) < 1e-8, (f, k)
+        npt.assert_allclose(r.group_norms[-1], np.sqrt(np.bincount(gidx, weights=r.betas[-1] ** 2, minlength=G)),
+                            rtol=1e-12, atol=1e-300)
+
+
+def test_lanes_with_different_penalties_and_lengths(eng, golden):
+    X, y = golden["l1_X"], golden["l1_y"]
+    p = X.shape[1]
+    al = golden["l1_alpha"]
+    w = golden["wl1_w"]
+    specs = [
+        dict(points=[(al[3], 0, 0), (al[1], 0, 0), (al[0], 0, 0)]),  # plain lasso path
+        dict(points=[(1.0, 0, 0)], a=w),  # weighted l1, single point
+        dict(points=[(al[2], 0, 0), (al[2], 0, 0)], beta0=golden["l1_coef"][2]),  # warm start at the answer
+    ]
+    with eng.dataset(X, y) as ds:
+        res = ds.solve_lanes(specs, tol=1e-12, max_iter=200000)
+    assert all(r.converged for r in res)
+    for k, j in enumerate((3, 1, 0)):
+        assert rel_inf(res[0].betas[k], golden["l1_coef"][j]) < 1e-9
+    assert rel_inf(res[1].betas[0], golden["wl1_coef"]) < 1e-9
+    assert rel_inf(res[2].betas[1], golden["l1_coef"][2]) < 1e-9
+    assert res[2].n_iter[0] <= 3
+
+
 # ---- row-sharded mode -------------------------------------------------------------------------------
 def test_row_shards_sum_to_full_gradient(eng):
     # what the in-engine all-reduce adds up: per-shard X_r^T (X_r z - y_r) / n_global

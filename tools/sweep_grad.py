@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "sparse-lm_amd"))
 from sparselm_amd import _engine  # noqa: E402
 
 CONFIGS = {
-    5000: ["8,5,2", "8,5,1", "8,6,2", "8,6,1", "4,10,1", "4,10,2", "8,8,1", "8,10,1", "2,10,2"],
+    5000: ["8,5,2", "8,5,1", "8,5,3", "8,5,4", "8,6,2"],
     10000: ["8,10,1"],
     2048: ["8,2,4", "8,3,4", "8,3,2", "4,4,4", "8,4,2", "8,4,4", "4,5,2", "4,5,4"],
     512: ["4,1,4", "8,1,4", "2,2,4", "4,2,4", "1,2,4", "2,1,4"],
@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--p", type=int, default=5000)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--blocks", type=str, default="0,1,2")
+    ap.add_argument("--lanes", type=str, default="1")
     args = ap.parse_args()
     eng = _engine.get_engine(0)
     print(eng.device_info(), flush=True)
@@ -54,9 +55,15 @@ def main():
             except Exception as exc:  # config does not cover p
                 print(f"cfg={cfg} blocks/CU={blocks}: skipped ({exc})", flush=True)
                 continue
-            g, loss, ms = ds.gradient(z, reps=args.reps)
-            print(f"cfg={cfg} blocks/CU={blocks or 'occ'}: {ms:8.4f} ms  {nbytes / ms / 1e6:8.1f} GB/s  "
-                  f"frac_of_8TB/s={nbytes / ms / 1e6 / 8000:.3f}  |g|={np.linalg.norm(g):.6e}", flush=True)
+            for lanes in args.lanes.split(","):
+                os.environ["SLM_PROBE_LANES"] = lanes
+                try:
+                    g, loss, ms = ds.gradient(z, reps=args.reps)
+                except NotImplementedError as exc:
+                    print(f"cfg={cfg} lanes={lanes}: unsupported ({exc})", flush=True)
+                    continue
+                print(f"cfg={cfg} lanes={lanes} blocks/CU={blocks or 'occ'}: {ms:8.4f} ms  {nbytes / ms / 1e6:8.1f} GB/s  "
+                      f"frac_of_8TB/s={nbytes / ms / 1e6 / 8000:.3f}  |g|={np.linalg.norm(g):.6e}", flush=True)
             ds.close()
 
 
