@@ -139,6 +139,7 @@ typedef struct slm_path_point {
 #define SLM_FLAG_PROFILE 2u      /* bracket every 4th gradient launch with HIP events     */
 #define SLM_FLAG_COLD_START 4u   /* do not warm-start point k+1 from point k             */
 #define SLM_FLAG_FRESH_L 8u      /* re-estimate the Lipschitz constant even if cached     */
+#define SLM_FLAG_FISTA_ONLY 16u  /* never use spectral steps (plain FISTA with restart)  */
 
 typedef struct slm_solve_opts {
   double tol;          /* stop when ||beta+ - z||_2 <= tol * ||beta+||_2; <= 0 => 1e-8   */
@@ -154,7 +155,9 @@ typedef struct slm_point_info {
   double resid;      /* ||beta+ - z||_2 at exit                                          */
   double beta_norm;  /* ||beta||_2                                                       */
   double loss;       /* 1/(2n)||X z - y||_W^2 at the last gradient point                 */
-  double L;          /* Lipschitz constant in use at exit                                */
+  double L;          /* inverse step in use at exit (Lipschitz constant in FISTA mode)   */
+  int32_t mode;      /* 1 = spectral (Barzilai-Borwein) steps, 0 = FISTA (after fallback) */
+  int32_t rejects;   /* spectral candidates rejected so far in this solve                */
 } slm_point_info;
 
 typedef struct slm_solve_stats {

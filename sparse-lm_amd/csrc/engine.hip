@@ -967,6 +967,9 @@ extern "C" int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n
     h[l].tol = o.tol;
     h[l].flags = o.flags;
     h[l].pt_off = (int32_t)off;
+    h[l].mode = (o.flags & SLM_FLAG_FISTA_ONLY) ? 0 : 1;
+    h[l].ak = L[l];
+    h[l].Lhat = 0.5 * L[l];  // a sure lower bound of lambda_max for the residual scaling
     off += ln.n_points;
   }
   HIP_TRY(hipMemcpyAsync(ds->z, ds->beta, sizeof(double) * kMaxLanes * ld, hipMemcpyDeviceToDevice, s));

@@ -40,7 +40,21 @@ struct PathCtl {
   double tol;
   uint32_t flags;
   int32_t pt_off;      // index of this lane's first point in the concatenated point/output arrays
+  // spectral (Barzilai-Borwein) mode, see fista_tail_kernel
+  int32_t mode;        // 1 = spectral steps with non-monotone acceptance, 0 = FISTA
+  int32_t have_base;   // the gradient at the base point beta is known (gprev)
+  int32_t rejects;     // candidates rejected so far in this solve (fallback trigger)
+  int32_t n_hist;      // valid entries of hist[]
+  double ak;           // current inverse step (curvature estimate along the last step)
+  double Lhat;         // largest curvature ||dg||/||dz|| seen (lower bound of lambda_max)
+  double pen_z;        // penalty value at the candidate z
+  double hist[5];      // last accepted objective values (non-monotone reference)
 };
+
+constexpr int BB_HIST = 5;
+constexpr int BB_REJECT_LIMIT = 3;    // rejected candidates before a lane falls back to FISTA
+constexpr int BB_POINT_LIMIT = 60;    // spectral iterations on one point before falling back
+constexpr double BB_SIGMA = 1e-4;
 
 // One workgroup per lane (blockIdx.x): vectors of lane l start at l * ld (g: l * (ld + 16)).
 struct TailArgs {
@@ -130,6 +144,22 @@ __device__ __forceinline__ void for_each_group_sumsq(const double* src, const in
 // once into registers (independent loads: one L2 round trip), the group phase goes through LDS, the
 // only other global round trips are the control block and -- for real group penalties -- the group
 // tables.
+//
+// Two iteration schemes share this kernel (per lane, chosen by ctl->mode):
+//
+//  * mode 1, spectral proximal gradient (SpaRSA: Barzilai-Borwein step + non-monotone acceptance).
+//    State: base point beta with its gradient (gprev), candidate z = prox(beta - gprev/ak).  Each
+//    call receives grad/loss at z: the candidate is accepted when F(z) <= max(last 5 F) -
+//    sigma/2 ak ||z-beta||^2 (then ak <- <dz,dg>/<dz,dz>, the curvature along the step) or rejected
+//    (ak <- 2 ak, same base); a new candidate is produced either way.  On well-conditioned sparse
+//    problems (the BASELINE shapes) the local curvature is far below lambda_max and this needs about
+//    half the gradient evaluations of FISTA.
+//  * mode 0, FISTA with gradient-scheme restart and the curvature guard on L.  A lane falls back to
+//    it for good after BB_REJECT_LIMIT rejections or BB_POINT_LIMIT spectral iterations on one point
+//    (ill-conditioned / p > n problems, where FISTA's worst-case rate wins).
+//
+// Both stop on the prox-gradient residual ||prox step||_2 <= tol ||beta||_2 measured with a step no
+// longer than 1/Lhat, so the meaning of `tol` does not depend on the mode.
 template <int E>
 __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   __shared__ double red[8][TAIL_WAVES];
@@ -153,21 +183,16 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   }
 
   // ---- phase 0: per-feature loads (independent of the control block) ---------------------------
-  double zj[E], gj[E], bo[E], a0j[E], gpv[E], zpv[E];
-  int gi[E];
-  bool ok[E];
+  // (kept to the minimum that must live across the reductions: 1024 threads => 128 VGPRs)
+  double zj[E], gj[E], bo[E], gpv[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int j = tid + e * TAIL_THREADS;
-    ok[e] = j < p;
-    const int jj = ok[e] ? j : 0;
+    const int jj = j < p ? j : 0;
     zj[e] = a.z[jj];
     gj[e] = a.g[jj];
     bo[e] = a.beta[jj];
-    a0j[e] = a.a0[jj];
     gpv[e] = a.gprev[jj];
-    zpv[e] = a.zprev[jj];
-    gi[e] = a.singleton ? jj : a.gid[jj];
   }
 
   // uniform snapshot of the control block (read-only until the final single-thread update)
@@ -180,113 +205,296 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   const int64_t total_iter = ctl->total_iter;
   const int n_points = ctl->n_points;
   const int max_iter = ctl->max_iter;
+  const int mode = ctl->mode;
+  const int have_base = ctl->have_base;
+  const int rejects = ctl->rejects;
+  const int n_hist = ctl->n_hist;
+  const double ak_old = ctl->ak;
+  const double Lhat_old = ctl->Lhat;
+  const double pen_z = ctl->pen_z;
+  double hist[BB_HIST];
+#pragma unroll
+  for (int k = 0; k < BB_HIST; ++k) hist[k] = ctl->hist[k];
   const slm_path_point pt = a.pts[point];
   const double loss_z = a.g[a.ld];
-  const double step = 1.0 / L;
   const bool group_pen = (pt.sb != 0.0) || (pt.sd != 0.0);
-
-  // ---- phase 1: gradient step, soft threshold, curvature-guard sums -----------------------------
-  //  s[0] = ||b+ - z||^2   s[1] = ||b+||^2   s[2] = (z - b+).(b+ - b)   s[3] = ||g - gprev||^2
-  //  s[4] = ||z - zprev||^2   s[5] = ||z||^2   s[6] = #non-finite
-  double s[7] = {0, 0, 0, 0, 0, 0, 0};
-  double u[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int j = tid + e * TAIL_THREADS;
-    u[e] = 0.0;
-    if (ok[e]) {
-      const double dg = gj[e] - gpv[e], dzz = zj[e] - zpv[e];
-      s[3] = __builtin_fma(dg, dg, s[3]);
-      s[4] = __builtin_fma(dzz, dzz, s[4]);
-      s[5] = __builtin_fma(zj[e], zj[e], s[5]);
-      a.gprev[j] = gj[e];
-      a.zprev[j] = zj[e];
-      double uu = soft(zj[e] - step * gj[e], step * pt.sa * a0j[e]);
-      if (group_pen && a.singleton) {
-        const double nrm = fabs(uu);
-        const double sc = nrm > 0.0 ? fmax(0.0, 1.0 - step * pt.sb * a.b0[j] / nrm) : 0.0;
-        uu *= sc / (1.0 + step * pt.sd * a.d0[j]);
-      }
-      u[e] = uu;
-    }
-  }
-  // ---- phase 2: block soft threshold + ridge shrink per group (teams gather through LDS) --------
-  if (group_pen && !a.singleton) {
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-      if (ok[e]) us[tid + e * TAIL_THREADS] = u[e];
-    __syncthreads();
-    for_each_group_sumsq(us, a.order, a.gstart, G, a.team, [&](int g, double ss) {
-      const double nrm = sqrt(ss);
-      const double sc = nrm > 0.0 ? fmax(0.0, 1.0 - step * pt.sb * a.b0[g] / nrm) : 0.0;
-      a.gscale[g] = sc / (1.0 + step * pt.sd * a.d0[g]);
-    });
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-      if (ok[e]) u[e] *= a.gscale[gi[e]];
-  }
-
-  // ---- phase 3: reductions --------------------------------------------------------------------
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    if (ok[e]) {
-      const double bn = u[e];
-      const double dz = bn - zj[e];
-      s[0] = __builtin_fma(dz, dz, s[0]);
-      s[1] = __builtin_fma(bn, bn, s[1]);
-      s[2] = __builtin_fma(-dz, bn - bo[e], s[2]);
-      if (!isfinite(bn)) s[6] += 1.0;
-    }
-  }
-  block_sum<7>(s, red);
-
-  // ---- phase 4: uniform decisions -------------------------------------------------------------
-  const bool nonfinite = s[6] > 0.0 || !isfinite(s[0]) || !isfinite(s[1]) || !isfinite(loss_z);
-  // Curvature guard: ||A dz|| / ||dz|| is a lower bound on lambda_max(A), A = X^T W X / n.  If it
-  // exceeds L the step 1/L was too long: raise L, discard the step and restart from beta.
-  bool l_bad = false;
-  double L_new = L;
-  if (total_iter > 0 && s[4] > 1e-12 * s[5] && s[4] > 0.0) {
-    const double curv = sqrt(s[3] / s[4]);
-    if (curv > L * (1.0 + 1e-9)) {
-      l_bad = true;
-      L_new = 1.02 * curv;
-    }
-  }
-  const bool restart = !(flags & SLM_FLAG_NO_RESTART) && s[2] > 0.0;
-  const double t_use = restart ? 1.0 : t_old;
-  const double t_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t_use * t_use));
-  const double mom = (t_use - 1.0) / t_new;
-  const double resid = sqrt(s[0]), bnorm = sqrt(s[1]);
-  const bool conv = !l_bad && (resid <= tol * bnorm);
-  const bool hit_max = (iter + 1 >= max_iter);
-  const bool finalize = nonfinite || conv || hit_max;
   const bool cold = (flags & SLM_FLAG_COLD_START) != 0;
+  const bool hit_max = (iter + 1 >= max_iter);
+
+  // prox_{step * penalty} of the per-thread vector v[] (in place), optionally accumulating the
+  // penalty value of the result into pen (thread-partial; the caller block-sums it).
+  auto prox_inplace = [&](double (&v)[E], double step, double* pen) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = tid + e * TAIL_THREADS;
+      if (j < p) {
+        double uu = soft(v[e], step * pt.sa * a.a0[j]);
+        if (group_pen && a.singleton) {
+          const double nrm = fabs(uu);
+          const double sc = nrm > 0.0 ? fmax(0.0, 1.0 - step * pt.sb * a.b0[j] / nrm) : 0.0;
+          uu *= sc / (1.0 + step * pt.sd * a.d0[j]);
+          if (pen) *pen += pt.sb * a.b0[j] * fabs(uu) + 0.5 * pt.sd * a.d0[j] * uu * uu;
+        }
+        v[e] = uu;
+      } else {
+        v[e] = 0.0;
+      }
+    }
+    if (group_pen && !a.singleton) {
+      __syncthreads();  // us may still be read by an earlier phase
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = tid + e * TAIL_THREADS;
+        if (j < p) us[j] = v[e];
+      }
+      __syncthreads();
+      for_each_group_sumsq(us, a.order, a.gstart, G, a.team, [&](int g, double ss) {
+        const double nrm = sqrt(ss);
+        const double sc = (nrm > 0.0 ? fmax(0.0, 1.0 - step * pt.sb * a.b0[g] / nrm) : 0.0) /
+                          (1.0 + step * pt.sd * a.d0[g]);
+        a.gscale[g] = sc;
+        if (pen) {
+          const double nc = nrm * sc;
+          *pen += pt.sb * a.b0[g] * nc + 0.5 * pt.sd * a.d0[g] * nc * nc;
+        }
+      });
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = tid + e * TAIL_THREADS;
+        if (j < p) v[e] *= a.gscale[a.gid[j]];
+      }
+    }
+    if (pen && pt.sa != 0.0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = tid + e * TAIL_THREADS;
+        if (j < p) *pen += pt.sa * a.a0[j] * fabs(v[e]);
+      }
+    }
+  };
+
+  // outcome of this call, filled by either scheme
+  double u[E];   // next point z (candidate / extrapolated point), or the reported solution when finalize
+  double nb[E];  // new beta when !finalize
+  bool finalize = false, conv = false, nonfinite = false;
+  double resid = 0.0, bnorm = 0.0;
+  // control-block updates
+  int new_mode = mode, new_have_base = have_base, new_rejects = rejects, new_n_hist = n_hist;
+  double new_t = t_old, new_L = L, new_ak = ak_old, new_Lhat = Lhat_old, new_pen_z = pen_z;
+  bool did_restart = false, l_bad = false;
+
+  if (mode == 1) {
+    // ================= spectral (BB) scheme =====================================================
+    //  s[0] = ||z - beta||^2   s[1] = <z - beta, g - gbase>   s[2] = ||g - gbase||^2   s[3] = #non-finite g
+    //  s[4] = penalty value at z (only computed at the start of a path point, when no candidate
+    //         carried it over)
+    double s[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if (tid + e * TAIL_THREADS < p) {
+        const double dz = zj[e] - bo[e], dg = gj[e] - gpv[e];
+        s[0] = __builtin_fma(dz, dz, s[0]);
+        s[1] = __builtin_fma(dz, dg, s[1]);
+        s[2] = __builtin_fma(dg, dg, s[2]);
+        if (!isfinite(gj[e])) s[3] += 1.0;
+      }
+    }
+    if (!have_base) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = tid + e * TAIL_THREADS;
+        if (j < p) {
+          const double az = fabs(zj[e]);
+          s[4] += pt.sa * a.a0[j] * az;
+          if (group_pen && a.singleton) s[4] += pt.sb * a.b0[j] * az + 0.5 * pt.sd * a.d0[j] * az * az;
+        }
+      }
+      if (group_pen && !a.singleton) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int j = tid + e * TAIL_THREADS;
+          if (j < p) us[j] = zj[e];
+        }
+        __syncthreads();
+        for_each_group_sumsq(us, a.order, a.gstart, G, a.team, [&](int g, double ss) {
+          s[4] += pt.sb * a.b0[g] * sqrt(ss) + 0.5 * pt.sd * a.d0[g] * ss;
+        });
+      }
+    }
+    block_sum<5>(s, red);
+    const double Fz = loss_z + (have_base ? pen_z : s[4]);
+    nonfinite = s[3] > 0.0 || !isfinite(Fz);
+    bool accept;
+    if (!have_base) {
+      accept = true;  // z is the start point of this path point: it becomes the base
+      new_n_hist = 0;
+    } else {
+      double fmax_hist = hist[0];
+#pragma unroll
+      for (int k = 1; k < BB_HIST; ++k)
+        if (k < n_hist) fmax_hist = fmax(fmax_hist, hist[k]);
+      accept = Fz <= fmax_hist - 0.5 * BB_SIGMA * ak_old * s[0];
+      if (accept) {
+        if (s[0] > 0.0) {
+          new_Lhat = fmax(Lhat_old, sqrt(s[2] / s[0]));
+          new_ak = s[1] > 0.0 ? s[1] / s[0] : new_Lhat;
+        }
+        new_ak = fmin(fmax(new_ak, 1e-6 * new_Lhat), 1e6 * new_Lhat);
+      } else {
+        new_ak = fmin(2.0 * ak_old, 1e6 * Lhat_old);
+        new_rejects = rejects + 1;
+      }
+    }
+    if (accept) {  // push F(z) into the ring of the last BB_HIST accepted values
+      if (new_n_hist < BB_HIST) {
+#pragma unroll
+        for (int k = 0; k < BB_HIST; ++k)
+          if (k == new_n_hist) hist[k] = Fz;
+        new_n_hist += 1;
+      } else {
+#pragma unroll
+        for (int k = 0; k + 1 < BB_HIST; ++k) hist[k] = hist[k + 1];
+        hist[BB_HIST - 1] = Fz;
+      }
+      new_have_base = 1;
+    }
+    // base point and its gradient after the decision; (zprev, gprev) = (base, its gradient) stays a
+    // consistent pair for the FISTA curvature guard should this lane fall back
+    const double step = 1.0 / new_ak;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = tid + e * TAIL_THREADS;
+      nb[e] = accept ? zj[e] : bo[e];
+      const double gb = accept ? gj[e] : gpv[e];
+      if (j < p) {
+        if (accept) a.gprev[j] = gb;
+        a.zprev[j] = nb[e];
+      }
+      u[e] = nb[e] - step * gb;
+    }
+    const bool fallback = !nonfinite && (new_rejects >= BB_REJECT_LIMIT || iter + 1 > BB_POINT_LIMIT);
+    if (fallback) {
+      new_mode = 0;
+      new_t = 1.0;
+      new_L = fmax(L, new_Lhat);
+#pragma unroll
+      for (int e = 0; e < E; ++e) u[e] = nb[e];  // FISTA restarts from the base point
+      finalize = hit_max;
+      if (finalize) {
+        double q[1] = {0.0};
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          if (tid + e * TAIL_THREADS < p) q[0] = __builtin_fma(u[e], u[e], q[0]);
+        block_sum<1>(q, red);
+        bnorm = sqrt(q[0]);
+        resid = sqrt(s[0]);
+      }
+    } else {
+      double pen_c = 0.0;
+      prox_inplace(u, step, &pen_c);
+      //  q[0] = ||c - base||^2   q[1] = ||c||^2   q[2] = pen(c)   q[3] = #non-finite
+      double q[4] = {0, 0, pen_c, 0};
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (tid + e * TAIL_THREADS < p) {
+          const double dc = u[e] - nb[e];
+          q[0] = __builtin_fma(dc, dc, q[0]);
+          q[1] = __builtin_fma(u[e], u[e], q[1]);
+          if (!isfinite(u[e])) q[3] += 1.0;
+        }
+      }
+      block_sum<4>(q, red);
+      nonfinite = nonfinite || q[3] > 0.0 || !isfinite(q[0]) || !isfinite(q[1]);
+      new_pen_z = q[2];
+      resid = sqrt(q[0]) * fmax(1.0, new_ak / new_Lhat);
+      bnorm = sqrt(q[1]);
+      conv = resid <= tol * bnorm;
+      finalize = nonfinite || conv || hit_max;
+    }
+  } else {
+    // ================= FISTA scheme =================================================================
+    //  s[0] = ||b+ - z||^2   s[1] = ||b+||^2   s[2] = (z - b+).(b+ - b)   s[3] = ||g - gprev||^2
+    //  s[4] = ||z - zprev||^2   s[5] = ||z||^2   s[6] = #non-finite
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    const double step = 1.0 / L;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = tid + e * TAIL_THREADS;
+      if (j < p) {
+        const double dg = gj[e] - gpv[e], dzz = zj[e] - a.zprev[j];
+        s[3] = __builtin_fma(dg, dg, s[3]);
+        s[4] = __builtin_fma(dzz, dzz, s[4]);
+        s[5] = __builtin_fma(zj[e], zj[e], s[5]);
+        a.gprev[j] = gj[e];
+        a.zprev[j] = zj[e];
+      }
+      u[e] = zj[e] - step * gj[e];
+    }
+    prox_inplace(u, step, nullptr);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if (tid + e * TAIL_THREADS < p) {
+        const double bn = u[e];
+        const double dz = bn - zj[e];
+        s[0] = __builtin_fma(dz, dz, s[0]);
+        s[1] = __builtin_fma(bn, bn, s[1]);
+        s[2] = __builtin_fma(-dz, bn - bo[e], s[2]);
+        if (!isfinite(bn)) s[6] += 1.0;
+      }
+    }
+    block_sum<7>(s, red);
+    nonfinite = s[6] > 0.0 || !isfinite(s[0]) || !isfinite(s[1]) || !isfinite(loss_z);
+    // Curvature guard: ||A dz|| / ||dz|| is a lower bound on lambda_max(A), A = X^T W X / n.  If it
+    // exceeds L the step 1/L was too long: raise L, discard the step and restart from beta.
+    if (total_iter > 0 && s[4] > 1e-12 * s[5] && s[4] > 0.0) {
+      const double curv = sqrt(s[3] / s[4]);
+      if (curv > L * (1.0 + 1e-9)) {
+        l_bad = true;
+        new_L = 1.02 * curv;
+      }
+    }
+    did_restart = !(flags & SLM_FLAG_NO_RESTART) && s[2] > 0.0;
+    const double t_use = did_restart ? 1.0 : t_old;
+    const double t_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t_use * t_use));
+    const double mom = (t_use - 1.0) / t_new;
+    resid = sqrt(s[0]);
+    bnorm = sqrt(s[1]);
+    conv = !l_bad && (resid <= tol * bnorm);
+    finalize = nonfinite || conv || hit_max;
+    new_t = l_bad ? 1.0 : t_new;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const double bn = u[e];
+      if (l_bad) {
+        nb[e] = bo[e];  // step rejected: beta unchanged, momentum dropped
+        u[e] = bo[e];
+      } else {
+        nb[e] = bn;
+        if (!finalize) u[e] = bn + mom * (bn - bo[e]);  // next extrapolated point
+      }
+    }
+  }
+
+  // ---- state update --------------------------------------------------------------------------
   // secant prediction of the next point's start from the last two solutions (see slm_path_point)
   double extrap = 0.0;
   if (finalize && !cold && !nonfinite && point >= 1 && point + 1 < n_points)
     extrap = a.pts[point + 1].extrap;
-
-  // ---- phase 5: state update ------------------------------------------------------------------
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int j = tid + e * TAIL_THREADS;
-    if (ok[e]) {
-      const double bn = u[e];
-      if (l_bad && !finalize) {
-        a.z[j] = bo[e];  // step rejected: beta unchanged, momentum dropped
-      } else if (finalize) {
-        const double out = l_bad ? bo[e] : bn;
-        u[e] = out;
+    if (j < p) {
+      if (finalize) {
+        const double out = u[e];
         a.betas_out[(int64_t)point * p + j] = out;
         double nxt = cold ? 0.0 : out;
         if (extrap != 0.0) nxt = out + extrap * (out - a.betas_out[(int64_t)(point - 1) * p + j]);
         a.beta[j] = nxt;
         a.z[j] = nxt;
       } else {
-        a.z[j] = bn + mom * (bn - bo[e]);
-        a.beta[j] = bn;
+        a.beta[j] = nb[e];
+        a.z[j] = u[e];
       }
     }
   }
@@ -295,19 +503,25 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     // model/_lasso.py:239-255, consumed by the adaptive re-weighting at _adaptive_lasso.py:364-374)
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-      if (ok[e]) us[tid + e * TAIL_THREADS] = u[e];
+    for (int e = 0; e < E; ++e) {
+      const int j = tid + e * TAIL_THREADS;
+      if (j < p) us[j] = u[e];
+    }
     __syncthreads();
     double* gn = a.gn_out + (int64_t)point * G;
     for_each_group_sumsq(us, a.order, a.gstart, G, a.team, [&](int g, double ss) { gn[g] = sqrt(ss); });
   }
 
-  // ---- phase 6: control block ------------------------------------------------------------------
+  // ---- control block ----------------------------------------------------------------------------
   if (tid == 0) {
     ctl->total_iter = total_iter + 1;
-    ctl->L = L_new;
+    ctl->L = new_L;
+    ctl->mode = new_mode;
+    ctl->rejects = new_rejects;
+    ctl->ak = new_ak;
+    ctl->Lhat = new_Lhat;
     if (l_bad) ctl->l_bumps += 1;
-    if (restart) ctl->restarts += 1;
+    if (did_restart) ctl->restarts += 1;
     if (finalize) {
       slm_point_info info;
       info.n_iter = iter + 1;
@@ -315,10 +529,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       info.resid = resid;
       info.beta_norm = bnorm;
       info.loss = loss_z;
-      info.L = L_new;
+      info.L = new_mode == 1 ? new_ak : new_L;
+      info.mode = new_mode;
+      info.rejects = new_rejects;
       a.infos[point] = info;
       ctl->iter = 0;
       ctl->t = 1.0;
+      ctl->have_base = 0;  // the next point's objective differs: start its history afresh
+      ctl->n_hist = 0;
+      ctl->pen_z = 0.0;
       ctl->point = point + 1;
       if (nonfinite) {
         ctl->nonfinite = 1;
@@ -330,7 +549,12 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       }
     } else {
       ctl->iter = iter + 1;
-      ctl->t = l_bad ? 1.0 : t_new;
+      ctl->t = new_t;
+      ctl->have_base = new_have_base;
+      ctl->n_hist = new_n_hist;
+      ctl->pen_z = new_pen_z;
+#pragma unroll
+      for (int k = 0; k < BB_HIST; ++k) ctl->hist[k] = hist[k];
     }
   }
 }

@@ -35,6 +35,7 @@ FLAG_NO_RESTART = 1
 FLAG_PROFILE = 2
 FLAG_COLD_START = 4
 FLAG_FRESH_L = 8
+FLAG_FISTA_ONLY = 16
 
 COMM_ID_BYTES = 128
 
@@ -100,6 +101,8 @@ class _PointInfo(C.Structure):
         ("beta_norm", C.c_double),
         ("loss", C.c_double),
         ("L", C.c_double),
+        ("mode", C.c_int32),
+        ("rejects", C.c_int32),
     ]
 
 
@@ -266,6 +269,7 @@ class PathResult:
     resid: np.ndarray
     beta_norm: np.ndarray
     loss: np.ndarray
+    mode: np.ndarray  # per point: 1 = spectral steps, 0 = FISTA
     L: float
     grad_launches: int
     grad_timed: int
@@ -513,6 +517,7 @@ class Dataset:
                     resid=np.array([i.resid for i in infos]),
                     beta_norm=np.array([i.beta_norm for i in infos]),
                     loss=np.array([i.loss for i in infos]),
+                    mode=np.array([i.mode for i in infos]),
                     L=float(infos[K - 1].L),
                     grad_launches=int(stats.grad_launches),
                     grad_timed=int(stats.grad_timed),
@@ -572,6 +577,7 @@ class Dataset:
             resid=cat("resid"),
             beta_norm=cat("beta_norm"),
             loss=cat("loss"),
+            mode=cat("mode"),
             L=r0.L,
             grad_launches=r0.grad_launches,
             grad_timed=r0.grad_timed,

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     # sizes the C side uses (checked against natural alignment of the header's structs)
     assert ctypes.sizeof(_engine._PathPoint) == 32
     assert ctypes.sizeof(_engine._SolveOpts) == 32
-    assert ctypes.sizeof(_engine._PointInfo) == 40
+    assert ctypes.sizeof(_engine._PointInfo) == 48
     assert ctypes.sizeof(_engine._SolveStats) == 40
     assert ctypes.sizeof(_engine._PenaltyStruct) == 24
 
