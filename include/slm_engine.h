@@ -205,6 +205,17 @@ typedef struct slm_lane {
 int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes,
                     const slm_solve_opts* opts, slm_solve_stats* stats);
 
+/*
+ * ONE warm-started path walked by n_lanes lanes that share each pass over X: the path is cut into
+ * n_lanes contiguous ranges (the first warm-started from beta0, the others cold); a lane that runs
+ * out of points takes over the upper half of what the busiest lane has left, so the lanes finish
+ * together whatever the per-point cost profile is.  Same outputs as slm_solve_path.
+ */
+int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,
+                         int32_t n_points, int32_t n_lanes, const slm_solve_opts* opts,
+                         const double* beta0, double* betas_out, double* group_norms_out,
+                         slm_point_info* infos, slm_solve_stats* stats);
+
 /* ---- row-sharded mode (very tall X split by rows over ranks; one all-reduce per iteration) ---- */
 #define SLM_COMM_ID_BYTES 128
 /* Rank 0 creates the id and distributes the 128 bytes to the other ranks out of band. */

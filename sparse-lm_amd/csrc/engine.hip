@@ -205,6 +205,7 @@ struct slm_dataset {
   std::vector<hipEvent_t> prof;
   // cached Lipschitz constant (dataset row weights, dataset n_global)
   double L = 0.0;
+  int L_iters = 0;
   bool L_valid = false;
 };
 
@@ -721,9 +722,14 @@ static int check_launch() {
 // ------------------------------------------------------------------------------------------------
 // Lipschitz constants: lambda_max(X^T W_l X)/n_eff_l for every lane of `ls` in one batched run
 // ------------------------------------------------------------------------------------------------
-static int power_iteration(slm_dataset* ds, const LaneSetup& ls, double* L_out /*[B]*/) {
+// Power steps used for the seed L of a solve.  The spectral scheme only needs the right order of
+// magnitude (it measures curvature along its own steps) and FISTA's curvature guard repairs an
+// under-estimate, so a handful of passes is enough; slm_dataset_lipschitz() asks for more.
+static const int kPowerItersSolve = 4;
+static const int kPowerItersQuery = 16;
+
+static int power_iteration(slm_dataset* ds, const LaneSetup& ls, double* L_out /*[B]*/, int iters) {
   hipStream_t s = ds->eng->stream;
-  int iters = 10;
   if (const char* env = getenv("SLM_POWER_ITERS")) iters = std::max(2, atoi(env));
   hipLaunchKernelGGL(power_init_kernel, dim3(ls.B), dim3(TAIL_THREADS), 0, s, ds->z, (int)ds->p, ds->ld);
   for (int k = 0; k < iters; ++k) {
@@ -751,11 +757,12 @@ static int power_iteration(slm_dataset* ds, const LaneSetup& ls, double* L_out /
   return SLM_OK;
 }
 
-static int estimate_lipschitz(slm_dataset* ds, double* L_out) {
-  if (!ds->L_valid) {
+static int estimate_lipschitz(slm_dataset* ds, double* L_out, int iters) {
+  if (!ds->L_valid || ds->L_iters < iters) {
     double L[SLM_MAX_LANES];
-    SLM_TRY(power_iteration(ds, default_lanes(ds, 1), L));
+    SLM_TRY(power_iteration(ds, default_lanes(ds, 1), L, iters));
     ds->L = L[0];
+    ds->L_iters = iters;
     ds->L_valid = true;
   }
   *L_out = ds->L;
@@ -765,7 +772,7 @@ static int estimate_lipschitz(slm_dataset* ds, double* L_out) {
 extern "C" int slm_dataset_lipschitz(slm_dataset* ds, double* L_out) {
   if (!ds || !L_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
   HIP_TRY(hipSetDevice(ds->eng->device));
-  return estimate_lipschitz(ds, L_out);
+  return estimate_lipschitz(ds, L_out, kPowerItersQuery);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -835,8 +842,10 @@ static int upload_vec_or_const(double* dst, const double* src, int64_t count, do
   return SLM_OK;
 }
 
-extern "C" int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes,
-                               const slm_solve_opts* opts, slm_solve_stats* stats) {
+// shared_path: the lanes are contiguous, ordered ranges of ONE path (slm_solve_path_lanes): global
+// point indices on the device and work stealing between lanes.
+static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, const slm_solve_opts* opts,
+                      slm_solve_stats* stats, bool shared_path) {
   if (!ds || !lanes) return fail(SLM_ERR_BAD_ARG, "NULL argument");
   if (n_lanes < 1 || n_lanes > kMaxLanes)
     return fail(SLM_ERR_BAD_ARG, "n_lanes must be in [1, %d] (got %d)", kMaxLanes, n_lanes);
@@ -912,13 +921,13 @@ extern "C" int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n
     const auto t0 = std::chrono::steady_clock::now();
     bool ran = false;
     if (any_rw || custom_scale) {
-      SLM_TRY(power_iteration(ds, ls, L));  // lane-specific operators: not cached
+      SLM_TRY(power_iteration(ds, ls, L, kPowerItersSolve));  // lane-specific operators: not cached
       ran = true;
     } else {
       if (o.flags & SLM_FLAG_FRESH_L) ds->L_valid = false;
       ran = !ds->L_valid;
       double L1 = 0.0;
-      SLM_TRY(estimate_lipschitz(ds, &L1));
+      SLM_TRY(estimate_lipschitz(ds, &L1, kPowerItersSolve));
       for (int l = 0; l < B; ++l) L[l] = L1;
     }
     if (ran)
@@ -966,9 +975,14 @@ extern "C" int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n
     h[l].L = L[l];
     h[l].tol = o.tol;
     h[l].flags = o.flags;
-    h[l].pt_off = (int32_t)off;
+    h[l].pt_off = shared_path ? 0 : (int32_t)off;
+    if (shared_path) {  // global indices: [off, off + n_points)
+      h[l].point = (int32_t)off;
+      h[l].pt_lo = (int32_t)off;
+      h[l].n_points = (int32_t)(off + ln.n_points);
+    }
     h[l].mode = (o.flags & SLM_FLAG_FISTA_ONLY) ? 0 : 1;
-    h[l].ak = L[l];
+    h[l].ak = 1.25 * L[l];  // a slightly short first step; the scheme measures its own curvature after it
     h[l].Lhat = 0.5 * L[l];  // a sure lower bound of lambda_max for the residual scaling
     off += ln.n_points;
   }
@@ -981,6 +995,7 @@ extern "C" int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n
   ta.ctl = ds->ctl;
   ta.gdone = reinterpret_cast<int*>(ds->gctl);
   ta.n_lanes = B;
+  ta.steal = shared_path ? 1 : 0;
   ta.pts = ds->pts;
   ta.p = (int)p;
   ta.G = G;
@@ -1011,6 +1026,7 @@ extern "C" int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n
   }
   int max_points = 0;
   for (int l = 0; l < B; ++l) max_points = std::max(max_points, (int)lanes[l].n_points);
+  if (shared_path) max_points = (int)total_points;  // a lane may end up walking most of the path
   const int64_t max_total = (int64_t)max_points * o.max_iter;
   int64_t enq = 0;
   int slot = 0;
@@ -1093,6 +1109,36 @@ extern "C" int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n
   }
   if (nonfinite) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
   return SLM_OK;
+}
+
+extern "C" int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes,
+                               const slm_solve_opts* opts, slm_solve_stats* stats) {
+  return solve_core(ds, lanes, n_lanes, opts, stats, false);
+}
+
+extern "C" int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,
+                                    int32_t n_points, int32_t n_lanes, const slm_solve_opts* opts,
+                                    const double* beta0, double* betas_out, double* group_norms_out,
+                                    slm_point_info* infos, slm_solve_stats* stats) {
+  if (!ds || !points || !betas_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  if (n_points <= 0) return fail(SLM_ERR_BAD_ARG, "n_points must be positive");
+  int B = std::max(1, std::min<int>(std::min<int>(n_lanes, kMaxLanes), n_points));
+  while (B > 1 && !ds->gk[B - 1]) --B;  // no kernel variant for (p, B): fewer lanes
+  slm_lane lanes[SLM_MAX_LANES];
+  memset(lanes, 0, sizeof(lanes));
+  int64_t lo = 0;
+  for (int l = 0; l < B; ++l) {
+    const int64_t hi = (int64_t)n_points * (l + 1) / B;
+    lanes[l].pen = pen;
+    lanes[l].points = points + lo;
+    lanes[l].n_points = (int32_t)(hi - lo);
+    lanes[l].beta0 = (l == 0) ? beta0 : nullptr;
+    lanes[l].betas_out = betas_out + lo * ds->p;
+    lanes[l].group_norms_out = group_norms_out ? group_norms_out + lo * ds->G : nullptr;
+    lanes[l].infos = infos ? infos + lo : nullptr;
+    lo = hi;
+  }
+  return solve_core(ds, lanes, B, opts, stats, B > 1);
 }
 
 extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,

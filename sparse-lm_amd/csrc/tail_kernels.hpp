@@ -27,7 +27,7 @@ constexpr int TAIL_WAVES = TAIL_THREADS / 64;
 // Device-resident control block of a path solve.  The host only ever reads copies of it.
 struct PathCtl {
   int32_t point;       // current path point
-  int32_t n_points;
+  int32_t n_points;    // end (exclusive) of the range of points this lane is walking
   int32_t iter;        // iterations spent on the current point
   int32_t max_iter;
   int32_t done;        // 1 => every later kernel of the queue returns immediately
@@ -49,6 +49,8 @@ struct PathCtl {
   double Lhat;         // largest curvature ||dg||/||dz|| seen (lower bound of lambda_max)
   double pen_z;        // penalty value at the candidate z
   double hist[5];      // last accepted objective values (non-monotone reference)
+  int32_t pt_lo;       // first point of the range being walked (secant starts need two solved points in it)
+  int32_t steals;      // ranges this lane took over from busier lanes
 };
 
 constexpr int BB_HIST = 5;
@@ -61,6 +63,8 @@ struct TailArgs {
   PathCtl* ctl;               // [n_lanes]
   int* gdone;                 // [0] = every lane finished (or abort), [1] = lanes finished so far
   int n_lanes;
+  int steal;                  // 1 => all lanes walk ONE path: an idle lane takes over the upper half of
+                              //      the points the busiest lane has not reached yet (cold start)
   const slm_path_point* pts;  // concatenated over lanes
   int p;
   int G;
@@ -204,6 +208,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   const uint32_t flags = ctl->flags;
   const int64_t total_iter = ctl->total_iter;
   const int n_points = ctl->n_points;
+  const int pt_lo = ctl->pt_lo;
   const int max_iter = ctl->max_iter;
   const int mode = ctl->mode;
   const int have_base = ctl->have_base;
@@ -479,8 +484,44 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   // ---- state update --------------------------------------------------------------------------
   // secant prediction of the next point's start from the last two solutions (see slm_path_point)
   double extrap = 0.0;
-  if (finalize && !cold && !nonfinite && point >= 1 && point + 1 < n_points)
+  if (finalize && !cold && !nonfinite && point - pt_lo >= 1 && point + 1 < n_points)
     extrap = a.pts[point + 1].extrap;
+  // End of this lane's range: in shared-path mode try to take over work from the busiest lane.
+  // A thief only takes points >= victim.point + 2 (the victim may advance by one point during this
+  // very launch) and claims them with a compare-and-swap on the victim's range end, so two thieves
+  // can never own the same points; the victim sees its shorter range at its next launch.
+  __shared__ int steal_lo, steal_hi;
+  const bool range_end = finalize && !nonfinite && (point + 1 >= n_points);
+  if (range_end && a.steal) {
+    if (tid == 0) {
+      steal_lo = -1;
+      steal_hi = -1;
+      for (int attempt = 0; attempt < a.n_lanes && steal_lo < 0; ++attempt) {
+        int best = -1, best_rem = 1, best_end = 0;
+        for (int v = 0; v < a.n_lanes; ++v) {
+          if (v == lane_id) continue;
+          PathCtl* cv = a.ctl + v;
+          const int dv = __hip_atomic_load(&cv->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int pv = __hip_atomic_load(&cv->point, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int ev = __hip_atomic_load(&cv->n_points, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int rem = ev - (pv + 2);  // points that can be taken safely
+          if (!dv && rem > best_rem) {
+            best = v;
+            best_rem = rem;
+            best_end = ev;
+          }
+        }
+        if (best < 0) break;
+        const int mid = best_end - best_rem / 2;  // upper half of the stealable points
+        if (atomicCAS(&a.ctl[best].n_points, best_end, mid) == best_end) {
+          steal_lo = mid;
+          steal_hi = best_end;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const bool stolen = range_end && a.steal && steal_lo >= 0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int j = tid + e * TAIL_THREADS;
@@ -488,7 +529,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       if (finalize) {
         const double out = u[e];
         a.betas_out[(int64_t)point * p + j] = out;
-        double nxt = cold ? 0.0 : out;
+        double nxt = (cold || stolen) ? 0.0 : out;  // a stolen range starts cold
         if (extrap != 0.0) nxt = out + extrap * (out - a.betas_out[(int64_t)(point - 1) * p + j]);
         a.beta[j] = nxt;
         a.z[j] = nxt;
@@ -543,7 +584,12 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
         ctl->nonfinite = 1;
         ctl->done = 1;
         a.gdone[0] = 1;  // abort every lane
-      } else if (point + 1 >= n_points) {
+      } else if (stolen) {
+        ctl->point = steal_lo;
+        ctl->pt_lo = steal_lo;
+        ctl->n_points = steal_hi;
+        ctl->steals += 1;
+      } else if (range_end) {
         ctl->done = 1;
         if (atomicAdd(&a.gdone[1], 1) + 1 == a.n_lanes) a.gdone[0] = 1;
       }

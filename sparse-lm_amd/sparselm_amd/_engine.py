@@ -60,6 +60,7 @@ ABI_SYMBOLS = (
     "slm_gradient",
     "slm_solve_path",
     "slm_solve_lanes",
+    "slm_solve_path_lanes",
     "slm_comm_unique_id",
     "slm_comm_init",
     "slm_dataset_set_global_rows",
@@ -190,6 +191,9 @@ def load_library():
                 P(_SolveStats),
             ],
             "slm_solve_lanes": [vp, P(_Lane), i32, P(_SolveOpts), P(_SolveStats)],
+            "slm_solve_path_lanes": [
+                vp, P(_PenaltyStruct), P(_PathPoint), i32, i32, P(_SolveOpts), vp, vp, vp, P(_PointInfo), P(_SolveStats),
+            ],
             "slm_comm_unique_id": [vp],
             "slm_comm_init": [vp, i32, i32, vp],
             "slm_dataset_set_global_rows": [vp, i64],
@@ -560,57 +564,42 @@ class Dataset:
                   want_group_norms=want_group_norms, extrapolate=extrapolate)
         if lanes == 1:
             return self.solve_lanes([dict(points=pts, beta0=beta0, **common)], **kw)[0]
-        bounds = split_path(K, lanes)
-        specs = [dict(points=pts[lo:hi], beta0=beta0 if lo == 0 else None, **common) for lo, hi in bounds]
-        try:
-            parts = self.solve_lanes(specs, **kw)
-        except NotImplementedError:  # no kernel variant for (p, lanes): fall back to fewer lanes
-            return self.solve_path(points, a=a, b=b, d=d, beta0=beta0, lanes=lanes - 1, **kw)
-        gn = None if not want_group_norms else np.vstack([r.group_norms for r in parts])
-        cat = lambda f: np.concatenate([getattr(r, f) for r in parts])  # noqa: E731
-        r0 = parts[0]
-        return PathResult(
-            betas=np.vstack([r.betas for r in parts]),
-            group_norms=gn,
-            n_iter=cat("n_iter"),
-            status=cat("status"),
-            resid=cat("resid"),
-            beta_norm=cat("beta_norm"),
-            loss=cat("loss"),
-            mode=cat("mode"),
-            L=r0.L,
-            grad_launches=r0.grad_launches,
-            grad_timed=r0.grad_timed,
-            grad_ms_total=r0.grad_ms_total,
-            wall_ms=r0.wall_ms,
-            lipschitz_ms=r0.lipschitz_ms,
+        # shared path: the engine splits it into `lanes` ranges and balances them by work stealing
+        G = self.n_groups
+        gam = path_extrapolation(pts) if extrapolate else np.zeros(K)
+        cpts = (_PathPoint * K)(*[_PathPoint(*row, g) for row, g in zip(pts, gam)])
+        a_ = None if a is None else _f64(np.broadcast_to(a, (self.p,)), "a")
+        b_ = None if b is None else _f64(np.broadcast_to(b, (G,)), "b")
+        d_ = None if d is None else _f64(np.broadcast_to(d, (G,)), "d")
+        pen = _PenaltyStruct(_ptr(a_), _ptr(b_), _ptr(d_))
+        b0 = None if beta0 is None else _f64(beta0, "beta0", (self.p,))
+        opts = _SolveOpts(float(tol), int(max_iter), int(check_every), float(L), int(flags))
+        betas = np.empty((K, self.p))
+        gn = np.empty((K, G)) if want_group_norms else None
+        infos = (_PointInfo * K)()
+        stats = _SolveStats()
+        _check(
+            self._lib.slm_solve_path_lanes(
+                self._h, C.byref(pen), cpts, K, lanes, C.byref(opts), _ptr(b0), _ptr(betas), _ptr(gn), infos,
+                C.byref(stats),
+            )
         )
-
-
-def split_path(n_points: int, lanes: int, cold_cost: float = 3.0) -> list:
-    """Contiguous [lo, hi) blocks of a K-point path for ``lanes`` sub-paths of about equal cost.
-
-    Every sub-path but the first starts cold, which costs about ``cold_cost`` warm points, so the
-    first block gets that many more points.
-    """
-    lanes = max(1, min(lanes, n_points))
-    if lanes == 1:
-        return [(0, n_points)]
-    per = (n_points + cold_cost * (lanes - 1)) / lanes  # cost budget per lane, in warm points
-    sizes = [max(1, int(round(per)))] + [max(1, int(round(per - cold_cost)))] * (lanes - 1)
-    # fix rounding so the sizes add up
-    i = 0
-    while sum(sizes) > n_points:
-        j = max(range(lanes), key=lambda k: sizes[k])
-        sizes[j] -= 1
-    while sum(sizes) < n_points:
-        sizes[i % lanes] += 1
-        i += 1
-    bounds, lo = [], 0
-    for sz in sizes:
-        bounds.append((lo, lo + sz))
-        lo += sz
-    return bounds
+        return PathResult(
+            betas=betas,
+            group_norms=gn,
+            n_iter=np.array([i.n_iter for i in infos]),
+            status=np.array([i.status for i in infos]),
+            resid=np.array([i.resid for i in infos]),
+            beta_norm=np.array([i.beta_norm for i in infos]),
+            loss=np.array([i.loss for i in infos]),
+            mode=np.array([i.mode for i in infos]),
+            L=float(infos[K - 1].L),
+            grad_launches=int(stats.grad_launches),
+            grad_timed=int(stats.grad_timed),
+            grad_ms_total=float(stats.grad_ms_total),
+            wall_ms=float(stats.wall_ms),
+            lipschitz_ms=float(stats.lipschitz_ms),
+        )
 
 
 # -- default engine per process / device ------------------------------------------------------------

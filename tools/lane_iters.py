@@ -12,5 +12,5 @@ amax = np.max(np.abs(g0)); alphas = np.geomspace(amax, 1e-3 * amax, 50)
 pts = [(a, 0, 0) for a in alphas]
 for lanes in (1, 2, 3, 4):
     r = ds.solve_path(pts, lanes=lanes)
-    print("lanes", lanes, "passes", r.grad_launches, "split", _engine.split_path(50, lanes))
+    print("lanes", lanes, "passes", r.grad_launches)
     print("  n_iter", list(r.n_iter))
