@@ -138,7 +138,8 @@ def main():
             torch.cuda.synchronize()
         eng.synchronize()
 
-    eng = _engine.get_engine(local_rank)
+    # one rank per GPU; on a box with fewer GPUs than ranks (tests) ranks share devices
+    eng = _engine.get_engine(local_rank % max(1, _engine.device_count()))
     n, p, K = args.n, args.p, args.alphas
     coef = make_coef(p, 50, seed=0)
     # independent unit per rank: fold/seed differs, law identical
