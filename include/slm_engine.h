@@ -119,6 +119,15 @@ int slm_dataset_lipschitz(slm_dataset* ds, double* L_out);
 int slm_gradient(slm_dataset* ds, const double* z, double* g_out, double* loss_out, int32_t reps,
                  double* ms_out);
 
+/*
+ * Weighted squared error of m coefficient vectors in ceil(m / SLM_MAX_LANES) passes over X:
+ *   sse_out[k] = sum_i w_i (x_i . Z[k] - y_i)^2        (Z: m x p, C-order, host)
+ * row_weight (length n, host, nullable => the dataset's) is typically the TEST mask of a CV fold, so
+ * that hold-out scores come from the resident X instead of a host GEMM (the reference scores with
+ * estimator.predict on X[test], model_selection.py:305-315).
+ */
+int slm_eval_sse(slm_dataset* ds, const double* Z, int32_t m, const double* row_weight, double* sse_out);
+
 /* ---- solve ----------------------------------------------------------------------------------- */
 typedef struct slm_penalty {
   const double* a; /* length p, per-coefficient l1 weight; NULL => all ones            */

@@ -826,6 +826,51 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
 }
 
 // ------------------------------------------------------------------------------------------------
+// hold-out scoring: weighted SSE of m coefficient vectors, SLM_MAX_LANES per pass over X
+// ------------------------------------------------------------------------------------------------
+extern "C" int slm_eval_sse(slm_dataset* ds, const double* Z, int32_t m, const double* row_weight,
+                            double* sse_out) {
+  if (!ds || !Z || !sse_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  if (m <= 0) return fail(SLM_ERR_BAD_ARG, "m must be positive");
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  hipStream_t s = ds->eng->stream;
+  const int64_t n = ds->n, p = ds->p, ld = ds->ld;
+  for (int64_t k = 0; k < (int64_t)m * p; ++k)
+    if (!std::isfinite(Z[k])) return fail(SLM_ERR_BAD_ARG, "Z contains a non-finite value");
+  LaneSetup ls = default_lanes(ds, 1);
+  if (row_weight) {
+    for (int64_t i = 0; i < n; ++i)
+      if (!(row_weight[i] >= 0.0) || !std::isfinite(row_weight[i]))
+        return fail(SLM_ERR_BAD_ARG, "row_weight[%lld] is negative or not finite", (long long)i);
+    if (!ds->rw_lanes) SLM_TRY(dalloc(&ds->rw_lanes, (size_t)kMaxLanes * n));
+    HIP_TRY(hipMemcpyAsync(ds->rw_lanes, row_weight, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    ls.rw = ds->rw_lanes;
+    ls.rw_stride = 0;  // every lane reads the same mask
+  }
+  for (int l = 0; l < kMaxLanes; ++l) ls.n_eff[l] = 0.5;  // loss_scale = 1/(2 n_eff) = 1  =>  g[ld] = SSE
+  int maxB = kMaxLanes;
+  while (maxB > 1 && !ds->gk[maxB - 1]) --maxB;
+  std::vector<double> losses(kMaxLanes);
+  for (int32_t k0 = 0; k0 < m; k0 += maxB) {
+    const int B = std::min<int32_t>(maxB, m - k0);  // kernel variants exist for every B <= maxB
+    ls.B = B;
+    HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * kMaxLanes * ld, s));
+    for (int l = 0; l < B; ++l)
+      HIP_TRY(hipMemcpyAsync(ds->z + (size_t)l * ld, Z + (size_t)(k0 + l) * p, sizeof(double) * p,
+                             hipMemcpyHostToDevice, s));
+    SLM_TRY(enqueue_gradient(ds, ls, ds->y, nullptr, nullptr, nullptr));
+    SLM_TRY(check_launch());
+    for (int l = 0; l < B; ++l)
+      HIP_TRY(hipMemcpyAsync(&losses[l], ds->g + (size_t)l * (ld + 16) + ld, sizeof(double),
+                             hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int l = 0; l < B; ++l) sse_out[k0 + l] = losses[l];
+  }
+  return SLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // path solves
 // ------------------------------------------------------------------------------------------------
 static int upload_vec_or_const(double* dst, const double* src, int64_t count, double fill, hipStream_t s) {

@@ -58,6 +58,7 @@ ABI_SYMBOLS = (
     "slm_dataset_set_groups",
     "slm_dataset_lipschitz",
     "slm_gradient",
+    "slm_eval_sse",
     "slm_solve_path",
     "slm_solve_lanes",
     "slm_solve_path_lanes",
@@ -178,6 +179,7 @@ def load_library():
             "slm_dataset_set_groups": [vp, vp, i32],
             "slm_dataset_lipschitz": [vp, P(dbl)],
             "slm_gradient": [vp, vp, vp, P(dbl), i32, P(dbl)],
+            "slm_eval_sse": [vp, vp, i32, vp, vp],
             "slm_solve_path": [
                 vp,
                 P(_PenaltyStruct),
@@ -454,6 +456,17 @@ class Dataset:
             )
         )
         return (g, loss.value, ms.value) if reps > 0 else (g, loss.value)
+
+    def eval_sse(self, Z, row_weight=None) -> np.ndarray:
+        """sum_i w_i (x_i . Z[k] - y_i)^2 for every row Z[k] of ``Z`` (m, p); ``row_weight`` is e.g. the
+        test mask of a CV fold.  ceil(m/4) passes over the resident X."""
+        Z = _f64(np.atleast_2d(Z), "Z")
+        if Z.shape[1] != self.p:
+            raise ValueError(f"Z must have {self.p} columns")
+        rw = None if row_weight is None else _f64(row_weight, "row_weight", (self.n,))
+        out = np.empty(Z.shape[0])
+        _check(self._lib.slm_eval_sse(self._h, _ptr(Z), Z.shape[0], _ptr(rw), _ptr(out)))
+        return out
 
     def solve_lanes(
         self,

@@ -1,0 +1,334 @@
+"""Grid search with the one-standard-error rule, grid-aware on the GPU.
+
+Counterpart of ``sparselm.model_selection.GridSearchCV`` (reference
+src/sparselm/model_selection.py:30-424): same constructor (``opt_selection_method`` in
+{"max_score", "one_std_score"}, default scoring ``neg_root_mean_squared_error`` :166), same
+selection rule (:190-223), same fitted attributes (``cv_results_``, ``best_index_``,
+``best_params_``, ``best_score_``, ``best_score_std_`` :396-398, ``best_estimator_``).
+
+What differs is how the (candidate x fold) grid is evaluated.  The reference dispatches
+``clone(estimator).fit(X[train], y[train])`` per cell through joblib (:273, :304-323), re-indexing X
+every time.  Here, for the non-adaptive Lasso-family estimators with a grid over ``alpha`` (and any
+other penalty hyper-parameter, e.g. ``l1_ratio``), X is uploaded ONCE and
+
+  * every fold is a row mask (test rows weigh 0) with its own 1/n_train scaling -- a *lane*;
+  * every (fold, other-params) pair is one warm-started alpha path solved on the device;
+  * up to four lanes share each pass over X (``slm_solve_lanes``);
+  * hold-out scores come from the resident X as well (``slm_eval_sse`` with the test mask);
+  * across processes (``torch.distributed`` launched one rank per GPU) the (fold, params) units are
+    dealt to ranks with ``distributed.shard_units`` and gathered -- no data-path collective.
+
+Anything else (adaptive estimators, ``fit_intercept=True``, sample weights, custom scorers, grids
+without ``alpha``) runs through scikit-learn's generic loop, still with the one-std rule.
+"""
+
+from __future__ import annotations
+
+import numbers
+import re
+import time
+from collections import defaultdict
+
+import numpy as np
+from sklearn.base import clone, is_classifier
+from sklearn.model_selection import GridSearchCV as _GridSearchCV
+from sklearn.model_selection import ParameterGrid, check_cv
+from sklearn.utils.validation import check_is_fitted, indexable
+
+from . import _engine
+from . import distributed as D
+from .model._adaptive_lasso import AdaptiveLasso
+from .model._base import ProxRegressor
+
+__all__ = ["GridSearchCV"]
+
+_FAST_SCORINGS = ("neg_root_mean_squared_error", "neg_mean_squared_error", "r2")
+
+
+def select_best_index_onestd(results, refit_metric="score"):
+    """One-standard-error rule (reference model_selection.py:190-223): among the candidates whose
+    summed non-negative numerical hyper-parameters are at least those of the best-scoring one,
+    take the one whose mean score is closest to (best mean - its std)."""
+    opt_index = results[f"rank_test_{refit_metric}"].argmin()
+    m = results[f"mean_test_{refit_metric}"][opt_index]
+    sig = results[f"std_test_{refit_metric}"][opt_index]
+    metrics = results[f"mean_test_{refit_metric}"]
+    params = []
+    for name in (key for key in results if re.match(r"^param_(\w+)", key)):
+        if all(isinstance(val, numbers.Number) for val in results[name]):
+            p = np.array(results[name], dtype=float)
+            if np.all(p > -1e-9):
+                params.append(p)
+    params_sum = np.sum(params, axis=0)
+    one_std_dists = np.abs(metrics - m + sig)
+    candidates = np.arange(len(metrics))[params_sum >= params_sum[opt_index]]
+    return int(candidates[np.argmin(one_std_dists[candidates])])
+
+
+class GridSearchCV(_GridSearchCV):
+    """Exhaustive search over a parameter grid with optional one-standard-error selection.
+
+    Args:
+        estimator: estimator object (any scikit-learn estimator; the sparselm_amd Lasso family
+            gets the device-resident fast path described in the module docstring).
+        param_grid (dict | list[dict]): as in scikit-learn.
+        opt_selection_method (str): "max_score" (default) or "one_std_score".
+        scoring: default "neg_root_mean_squared_error" (reference :166).
+        n_jobs, refit, cv, verbose, pre_dispatch, error_score, return_train_score: as scikit-learn.
+        lanes (int): folds solved per pass over X on the fast path (1..4, default 4).
+    """
+
+    def __init__(
+        self,
+        estimator,
+        param_grid,
+        *,
+        opt_selection_method="max_score",
+        scoring="neg_root_mean_squared_error",
+        n_jobs=None,
+        refit=True,
+        cv=None,
+        verbose=0,
+        pre_dispatch="2*n_jobs",
+        error_score=np.nan,
+        return_train_score=False,
+        lanes=4,
+    ):
+        super().__init__(
+            estimator=estimator,
+            param_grid=param_grid,
+            scoring=scoring,
+            n_jobs=n_jobs,
+            refit=refit,
+            cv=cv,
+            verbose=verbose,
+            pre_dispatch=pre_dispatch,
+            error_score=error_score,
+            return_train_score=return_train_score,
+        )
+        self.opt_selection_method = opt_selection_method
+        self.lanes = lanes
+
+    # ------------------------------------------------------------------------------------------
+    def _fast_path_ok(self, fit_params) -> bool:
+        est = self.estimator
+        if not isinstance(est, ProxRegressor) or isinstance(est, AdaptiveLasso):
+            return False
+        if est.fit_intercept or getattr(est, "standardize", False) or fit_params:
+            return False
+        if self.scoring not in _FAST_SCORINGS or self.return_train_score:
+            return False
+        if self.refit not in (True, False):
+            return False
+        grids = self.param_grid if isinstance(self.param_grid, (list, tuple)) else [self.param_grid]
+        return all(isinstance(g, dict) and "alpha" in g for g in grids)
+
+    def fit(self, X, y=None, *, groups=None, **fit_params):
+        """Run the search (reference model_selection.py:226-424)."""
+        if self.opt_selection_method not in ("max_score", "one_std_score"):
+            raise ValueError(f"opt_selection_method {self.opt_selection_method!r} is not supported")
+        if self._fast_path_ok(fit_params):
+            return self._fit_device(X, y, groups)
+        return self._fit_generic(X, y, groups, fit_params)
+
+    # ---- generic: scikit-learn's loop + selection rule ------------------------------------------
+    def _fit_generic(self, X, y, groups, fit_params):
+        user_refit = self.refit
+        if self.opt_selection_method == "one_std_score" and user_refit is True:
+            self.refit = lambda results: select_best_index_onestd(results)
+        try:
+            super().fit(X, y, groups=groups, **fit_params)
+        finally:
+            self.refit = user_refit
+        if hasattr(self, "best_index_"):
+            self.best_score_ = self.cv_results_["mean_test_score"][self.best_index_]
+            self.best_score_std_ = self.cv_results_["std_test_score"][self.best_index_]
+        return self
+
+    # ---- device-resident fast path ------------------------------------------------------------------
+    def _fit_device(self, X, y, groups):
+        est = self.estimator
+        X, y, groups = indexable(X, y, groups)
+        X = np.asarray(X, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        n, p = X.shape
+        cv = check_cv(self.cv, y, classifier=is_classifier(est))
+        splits = list(cv.split(X, y, groups))
+        n_splits = len(splits)
+        candidates = list(ParameterGrid(self.param_grid))
+        # validate every candidate the way fit() would (same error classes)
+        for params in candidates:
+            clone(est).set_params(**params)._validate_params(X, y)
+
+        # units: (non-alpha params, fold) -> one warm-started alpha path
+        by_combo = defaultdict(list)
+        for ci, params in enumerate(candidates):
+            key = tuple(sorted((k, repr(v)) for k, v in params.items() if k != "alpha"))
+            by_combo[key].append(ci)
+        combos = list(by_combo.values())
+        units = [(c, f) for c in range(len(combos)) for f in range(n_splits)]
+
+        rank, world, local_rank = D.world()
+        eng = _engine.get_engine()
+        t0 = time.perf_counter()
+        scores = np.full((len(candidates), n_splits), np.nan)
+        fit_time = np.zeros((len(candidates), n_splits))
+        with eng.dataset(X, y) as ds:
+            base = clone(est).set_params(alpha=1.0)
+            a1, b1, d1, gidx, G = base._penalty(X)
+            if gidx is not None:
+                ds.set_groups(gidx, G)
+            my_units = [units[i] for i in D.shard_units(len(units), rank, world)]
+            lanes = max(1, min(int(self.lanes), _engine.MAX_LANES))
+            opts = _solver_options(est)
+            local = {}
+            for k0 in range(0, len(my_units), lanes):
+                batch = my_units[k0 : k0 + lanes]
+                specs, metas = [], []
+                for c, f in batch:
+                    cis = sorted(combos[c], key=lambda ci: -candidates[ci]["alpha"])
+                    e = clone(est).set_params(**{k: v for k, v in candidates[cis[0]].items() if k != "alpha"})
+                    e.set_params(alpha=1.0)
+                    a, b, d, _, _ = e._penalty(X)
+                    alphas = np.array([candidates[ci]["alpha"] for ci in cis], dtype=float)
+                    pts = np.c_[
+                        alphas if a is not None else 0 * alphas,
+                        alphas if b is not None else 0 * alphas,
+                        np.ones_like(alphas) if d is not None else 0 * alphas,
+                    ]
+                    train, test = splits[f]
+                    mask = np.zeros(n)
+                    mask[train] = 1.0
+                    specs.append(dict(points=pts, a=a, b=b, d=d, row_weight=mask, n_eff=len(train)))
+                    metas.append((cis, test))
+                t_batch = time.perf_counter()
+                results = _solve_lanes_with_fallback(ds, specs, opts)
+                dt = (time.perf_counter() - t_batch) / max(1, sum(len(m[0]) for m in metas))
+                for (c, f), (cis, test), res in zip(batch, metas, results):
+                    tmask = np.zeros(n)
+                    tmask[test] = 1.0
+                    sse = ds.eval_sse(res.betas, tmask)
+                    local[(c, f)] = (cis, self._score_from_sse(sse, y[test]), dt)
+            merged = _gather(local, units)
+            for (c, f), (cis, sc, dt) in merged.items():
+                scores[cis, f] = sc
+                fit_time[cis, f] = dt
+
+            self.cv_results_ = _format_results(candidates, scores, fit_time)
+            self.n_splits_ = n_splits
+            self.multimetric_ = False
+            self.scorer_ = self.scoring
+            if self.opt_selection_method == "one_std_score":
+                self.best_index_ = select_best_index_onestd(self.cv_results_)
+            else:
+                self.best_index_ = int(self.cv_results_["rank_test_score"].argmin())
+            self.best_params_ = candidates[self.best_index_]
+            self.best_score_ = self.cv_results_["mean_test_score"][self.best_index_]
+            self.best_score_std_ = self.cv_results_["std_test_score"][self.best_index_]
+            if self.refit:
+                t1 = time.perf_counter()
+                best = clone(est).set_params(**self.best_params_)
+                a, b, d, _, _ = best._penalty(X)
+                res = ds.solve_path(
+                    [(1.0, 1.0, 1.0)],
+                    a=np.zeros(p) if a is None else a,
+                    b=np.zeros(ds.n_groups) if b is None else b,
+                    d=np.zeros(ds.n_groups) if d is None else d,
+                    **opts,
+                )
+                best.coef_ = res.betas[0]
+                best.intercept_ = 0.0
+                best.n_features_in_ = p
+                best.solver_info_ = {"n_iter": int(res.n_iter[0]), "converged": res.converged}
+                self.best_estimator_ = best
+                self.refit_time_ = time.perf_counter() - t1
+        self.search_time_ = time.perf_counter() - t0
+        return self
+
+    def _score_from_sse(self, sse, y_test):
+        mse = sse / len(y_test)
+        if self.scoring == "neg_mean_squared_error":
+            return -mse
+        if self.scoring == "neg_root_mean_squared_error":
+            return -np.sqrt(mse)
+        sst = float(np.sum((y_test - np.mean(y_test)) ** 2))
+        return 1.0 - sse / sst if sst > 0 else np.where(sse == 0, 1.0, 0.0)
+
+    def predict(self, X):
+        check_is_fitted(self, "best_estimator_")
+        return self.best_estimator_.predict(X)
+
+
+def _solver_options(est) -> dict:
+    from ._backend import normalise_options
+
+    o = normalise_options(est.solver_options)
+    out = {}
+    if "tol" in o:
+        out["tol"] = float(o["tol"])
+    if "max_iter" in o:
+        out["max_iter"] = int(o["max_iter"])
+    return out
+
+
+def _solve_lanes_with_fallback(ds, specs, opts):
+    """Four lanes when the kernel table has a variant for this p, otherwise fewer per call."""
+    try:
+        return ds.solve_lanes(specs, **opts)
+    except NotImplementedError:
+        if len(specs) == 1:
+            raise
+        half = len(specs) // 2
+        return _solve_lanes_with_fallback(ds, specs[:half], opts) + _solve_lanes_with_fallback(ds, specs[half:], opts)
+
+
+def _gather(local: dict, units) -> dict:
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, local)
+    merged = {}
+    for part in parts:
+        merged.update(part)
+    missing = [u for u in units if u not in merged]
+    if missing:
+        raise RuntimeError(f"grid units {missing[:4]} were not solved by any rank")
+    return merged
+
+
+def _format_results(candidates, scores, fit_time) -> dict:
+    """cv_results_ in scikit-learn's layout (BaseSearchCV._format_results)."""
+    from scipy.stats import rankdata
+
+    n_cand, n_splits = scores.shape
+    results = {}
+    results["mean_fit_time"] = fit_time.mean(axis=1)
+    results["std_fit_time"] = fit_time.std(axis=1)
+    results["mean_score_time"] = np.zeros(n_cand)
+    results["std_score_time"] = np.zeros(n_cand)
+    names = sorted({k for c in candidates for k in c})
+    for name in names:
+        vals = np.ma.MaskedArray(np.empty(n_cand, dtype=object), mask=True)
+        for i, c in enumerate(candidates):
+            if name in c:
+                vals[i] = c[name]
+        try:
+            if not vals.mask.any():
+                vals = np.ma.MaskedArray(np.array([c[name] for c in candidates]), mask=False)
+        except (ValueError, TypeError):
+            pass
+        results[f"param_{name}"] = vals
+    results["params"] = candidates
+    for f in range(n_splits):
+        results[f"split{f}_test_score"] = scores[:, f]
+    mean = scores.mean(axis=1)
+    results["mean_test_score"] = mean
+    results["std_test_score"] = scores.std(axis=1)
+    if np.isnan(mean).all():
+        results["rank_test_score"] = np.ones(n_cand, dtype=np.int32)
+    else:
+        min_score = np.nanmin(mean) - 1
+        results["rank_test_score"] = rankdata(-np.nan_to_num(mean, nan=min_score), method="min").astype(np.int32)
+    return results

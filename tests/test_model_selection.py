@@ -1,0 +1,113 @@
+"""Grid search with the one-standard-error rule (mirrors /root/reference/tests/test_model_selection.py).
+
+CPU: the selection rule and the generic path with scikit-learn's own Lasso (the reference's test_onestd
+needs nothing else) and with the oracle behind our estimators.  GPU: the device-resident fast path
+against the generic path, cell by cell.
+"""
+
+import warnings
+
+import numpy as np
+import pytest
+from sklearn.datasets import make_regression
+from sklearn.linear_model import Lasso as SkLasso
+from sklearn.model_selection import GridSearchCV as SkGridSearchCV
+from sklearn.model_selection import KFold, train_test_split
+
+from _oracle_backend import OracleBackend
+from sparselm_amd import _backend
+from sparselm_amd.model import AdaptiveLasso, GroupLasso, Lasso, SparseGroupLasso
+from sparselm_amd.model_selection import GridSearchCV, _format_results, select_best_index_onestd
+
+
+def test_onestd_with_sklearn_lasso():
+    # /root/reference/tests/test_model_selection.py:122-167 (deterministic: one repetition suffices)
+    X, y = make_regression(n_samples=200, n_features=100, n_informative=10, noise=40.0, bias=-15.0, random_state=0)
+    X_train, _, y_train, _ = train_test_split(X, y, test_size=0.25, random_state=0)
+    cv5 = KFold(n_splits=5, shuffle=True, random_state=0)
+    params = {"alpha": np.logspace(-1, 1, 10)}
+    std = GridSearchCV(SkLasso(fit_intercept=True), params, opt_selection_method="one_std_score", cv=cv5).fit(X_train, y_train)
+    opt = GridSearchCV(SkLasso(fit_intercept=True), params, opt_selection_method="max_score", cv=cv5).fit(X_train, y_train)
+    assert opt.best_params_["alpha"] <= std.best_params_["alpha"]
+    assert np.sum(np.abs(opt.best_estimator_.coef_) >= 1e-6) >= np.sum(np.abs(std.best_estimator_.coef_) >= 1e-6)
+    # max_score agrees with scikit-learn's own search under the same default scoring
+    sk = SkGridSearchCV(SkLasso(fit_intercept=True), params, scoring="neg_root_mean_squared_error", cv=cv5).fit(X_train, y_train)
+    assert opt.best_params_ == sk.best_params_
+    np.testing.assert_allclose(opt.cv_results_["mean_test_score"], sk.cv_results_["mean_test_score"])
+    assert opt.best_score_ == pytest.approx(sk.best_score_)
+    assert std.best_score_std_ == pytest.approx(std.cv_results_["std_test_score"][std.best_index_])
+    with pytest.raises(ValueError):
+        GridSearchCV(SkLasso(), params, opt_selection_method="median").fit(X_train, y_train)
+
+
+def test_one_std_rule_on_synthetic_results():
+    cands = [{"alpha": a} for a in (0.01, 0.1, 1.0, 10.0)]
+    scores = np.array([[-1.0, -1.2], [-0.9, -1.1], [-1.06, -1.16], [-3.0, -3.2]])
+    res = _format_results(cands, scores, np.zeros_like(scores))
+    assert list(res["rank_test_score"]) == [2, 1, 3, 4]
+    # best = alpha 0.1 (mean -1.0, std 0.1): closest to -1.1 among alpha >= 0.1 is alpha = 1.0
+    assert select_best_index_onestd(res) == 2
+
+
+def test_generic_path_with_oracle_backend(golden):
+    X, y = golden["l1_X"], golden["l1_y"]
+    grid = {"alpha": [0.05, 0.5, 2.0, 10.0]}
+    cv = KFold(4, shuffle=True, random_state=1)
+    with _backend.use_backend(OracleBackend()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # fit_intercept=True keeps this on the generic (scikit-learn loop) path
+        gs = GridSearchCV(Lasso(fit_intercept=True), grid, cv=cv, opt_selection_method="one_std_score").fit(X, y)
+        sk = SkGridSearchCV(Lasso(fit_intercept=True), grid, cv=cv, scoring="neg_root_mean_squared_error").fit(X, y)
+    np.testing.assert_allclose(gs.cv_results_["mean_test_score"], sk.cv_results_["mean_test_score"], rtol=1e-9)
+    assert gs.best_params_["alpha"] >= sk.best_params_["alpha"]
+    assert gs.predict(X).shape == y.shape
+
+
+# ---- device-resident fast path ---------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("scoring", ["neg_root_mean_squared_error", "r2"])
+def test_fast_path_matches_generic_path(golden, scoring):
+    X, y, groups, gw = golden["grp_X"], golden["grp_y"], golden["grp_groups"], golden["grp_gw"]
+    cv = KFold(5, shuffle=True, random_state=0)
+    cases = [
+        (Lasso(), {"alpha": list(np.geomspace(20, 0.05, 7))}),
+        (GroupLasso(groups=groups, group_weights=gw), {"alpha": list(np.geomspace(20, 0.1, 6))}),
+        (SparseGroupLasso(groups=groups), {"alpha": list(np.geomspace(10, 0.1, 5)), "l1_ratio": [0.1, 0.5, 0.9]}),
+    ]
+    for est, grid in cases:
+        est.set_params(solver_options={"tol": 1e-11})
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fast = GridSearchCV(est, grid, cv=cv, scoring=scoring).fit(X, y)
+            slow = SkGridSearchCV(est, grid, cv=cv, scoring=scoring).fit(X, y)
+        assert fast.cv_results_["params"] == slow.cv_results_["params"]
+        for f in range(5):
+            np.testing.assert_allclose(fast.cv_results_[f"split{f}_test_score"], slow.cv_results_[f"split{f}_test_score"],
+                                       rtol=1e-7, atol=1e-9)
+        assert fast.best_params_ == slow.best_params_
+        assert fast.best_score_ == pytest.approx(slow.best_score_, rel=1e-7)
+        np.testing.assert_allclose(fast.best_estimator_.coef_, slow.best_estimator_.coef_, rtol=0,
+                                   atol=1e-7 * np.max(np.abs(slow.best_estimator_.coef_)))
+        np.testing.assert_allclose(fast.predict(X), slow.predict(X), rtol=1e-6, atol=1e-6)
+        assert hasattr(fast, "search_time_")  # marks the device path
+
+
+@pytest.mark.gpu
+def test_fast_path_one_std_and_fallbacks(golden):
+    X, y = golden["l1_X"], golden["l1_y"]
+    grid = {"alpha": list(np.logspace(-1, 1.5, 8))}
+    cv = KFold(5, shuffle=True, random_state=0)
+    opt = GridSearchCV(Lasso(), grid, cv=cv).fit(X, y)
+    std = GridSearchCV(Lasso(), grid, cv=cv, opt_selection_method="one_std_score").fit(X, y)
+    assert std.best_params_["alpha"] >= opt.best_params_["alpha"]
+    assert std.best_score_std_ > 0
+    # adaptive estimators and fit_intercept=True go through the generic loop (no search_time_)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ada = GridSearchCV(AdaptiveLasso(), {"alpha": [0.5, 2.0]}, cv=3).fit(X, y)
+        icpt = GridSearchCV(Lasso(fit_intercept=True), {"alpha": [0.5, 2.0]}, cv=3).fit(X, y)
+    assert not hasattr(ada, "search_time_") and not hasattr(icpt, "search_time_")
+    assert ada.best_estimator_.n_iter_ >= 1
+    # invalid candidates raise the estimator's own error class before anything is solved
+    with pytest.raises(ValueError):
+        GridSearchCV(Lasso(), {"alpha": [1.0, -1.0]}, cv=3).fit(X, y)
