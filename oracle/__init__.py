@@ -38,10 +38,13 @@ from .fista import fista, lipschitz  # noqa: F401
 from .estimators import (  # noqa: F401
     fit_adaptive_group_lasso,
     fit_adaptive_lasso,
+    fit_adaptive_overlap_group_lasso,
     fit_adaptive_ridged_group_lasso,
     fit_adaptive_sparse_group_lasso,
     fit_group_lasso,
     fit_lasso,
+    fit_overlap_group_lasso,
+    overlap_extension,
     fit_ridged_group_lasso,
     fit_sparse_group_lasso,
     preprocess,

@@ -55,6 +55,25 @@ def _group_weights(group_weights, G):
     return np.ones(G) if group_weights is None else np.asarray(group_weights, dtype=np.float64)
 
 
+def _whiten_groups(X, gidx, G):
+    """standardize=True (model/_lasso.py:249-252 penalises ||X_g beta_g||): per-group SVD
+    X_g = U S V^T, gamma_g = S V^T beta_g  =>  ||X_g beta_g|| = ||gamma_g|| on the design U.
+    (The product uses QR; a different factorisation here keeps the cross-check independent.)"""
+    U = np.empty_like(X)
+    maps = []
+    for g in range(G):
+        cols = np.flatnonzero(gidx == g)
+        u, sv, vt = np.linalg.svd(X[:, cols], full_matrices=False)
+        U[:, cols] = u
+        maps.append((cols, vt.T / sv))
+    def back(gamma):
+        beta = np.empty_like(gamma)
+        for cols, m in maps:
+            beta[cols] = m @ gamma[cols]
+        return beta
+    return U, back
+
+
 def _delta(delta, G):
     # model/_lasso.py:744-765: delta of length 1 is broadcast to all groups
     delta = np.asarray(delta, dtype=np.float64).reshape(-1)
@@ -74,14 +93,20 @@ def fit_lasso(X, y, alpha=1.0, fit_intercept=False, sample_weight=None, **kw):
 
 
 def fit_group_lasso(
-    X, y, groups=None, alpha=1.0, group_weights=None, fit_intercept=False, sample_weight=None, **kw
+    X, y, groups=None, alpha=1.0, group_weights=None, fit_intercept=False, sample_weight=None,
+    standardize=False, **kw
 ):
     """GroupLasso: model/_lasso.py:124-275 (group norms :239-255, regulariser :267-275)."""
     Xp, yp, xo, yo = preprocess(X, y, sample_weight, fit_intercept)
     p = Xp.shape[1]
     gidx, G = group_index(groups, p)
     w = _group_weights(group_weights, G)
+    back = None
+    if standardize:
+        Xp, back = _whiten_groups(Xp, gidx, G)
     beta, info = _solve(Xp, yp, np.zeros(p), alpha * w, np.zeros(G), gidx, G, **kw)
+    if back is not None:
+        beta = back(beta)
     return {"coef": beta, "intercept": _intercept(beta, xo, yo, fit_intercept), "info": info}
 
 
@@ -124,6 +149,51 @@ def fit_ridged_group_lasso(
     w = _group_weights(group_weights, G)
     beta, info = _solve(Xp, yp, np.zeros(p), alpha * w, _delta(delta, G), gidx, G, **kw)
     return {"coef": beta, "intercept": _intercept(beta, xo, yo, fit_intercept), "info": info}
+
+
+def overlap_extension(group_list, n_features):
+    """Column duplication that makes overlapping groups disjoint (model/_lasso.py:440-461):
+    group ids sorted; for every group the features that list it; returns (beta_indices,
+    extended_groups).  ``group_list=None`` means singleton groups (:446-448)."""
+    if group_list is None:
+        group_list = [[i] for i in range(n_features)]
+    group_ids = np.sort(np.unique([gid for grp in group_list for gid in grp]))
+    inds = [[i for i, grp in enumerate(group_list) if gid in grp] for gid in group_ids]
+    extended_groups = np.concatenate([len(g) * [i] for i, g in enumerate(inds)])
+    return np.concatenate(inds).astype(np.int64), extended_groups.astype(np.int64)
+
+
+def fit_overlap_group_lasso(
+    X, y, group_list=None, alpha=1.0, group_weights=None, fit_intercept=False, sample_weight=None, **kw
+):
+    """OverlapGroupLasso: group lasso on the column-duplicated design, coefficients of duplicated
+    columns summed back (model/_lasso.py:279-502, fold-back :486-502)."""
+    Xp, yp, xo, yo = preprocess(X, y, sample_weight, fit_intercept)
+    p = Xp.shape[1]
+    bidx, ext = overlap_extension(group_list, p)
+    G = int(ext.max()) + 1
+    w = _group_weights(group_weights, G)
+    beta_ext, info = _solve(Xp[:, bidx], yp, np.zeros(len(bidx)), alpha * w, np.zeros(G), ext, G, **kw)
+    beta = np.bincount(bidx, weights=beta_ext, minlength=p)
+    return {"coef": beta, "intercept": _intercept(beta, xo, yo, fit_intercept), "info": info}
+
+
+def fit_adaptive_overlap_group_lasso(
+    X, y, group_list=None, alpha=1.0, group_weights=None, max_iter=3, eps=1e-6, tol=1e-10,
+    update_function=None, fit_intercept=False, sample_weight=None, **kw
+):
+    """AdaptiveOverlapGroupLasso: AdaptiveGroupLasso on the extended design, folded back
+    (model/_adaptive_lasso.py:377-524)."""
+    Xp, yp, xo, yo = preprocess(X, y, sample_weight, fit_intercept)
+    p = Xp.shape[1]
+    bidx, ext = overlap_extension(group_list, p)
+    r = fit_adaptive_group_lasso(
+        Xp[:, bidx], yp, groups=ext, alpha=alpha, group_weights=group_weights, max_iter=max_iter, eps=eps,
+        tol=tol, update_function=update_function, fit_intercept=False, **kw
+    )
+    beta = np.bincount(bidx, weights=r["coef"], minlength=p)
+    return {"coef": beta, "intercept": _intercept(beta, xo, yo, fit_intercept), "n_iter": r["n_iter"],
+            "weights": r["weights"]}
 
 
 # --------------------------------------------------------------------------------------------
@@ -206,6 +276,7 @@ def fit_adaptive_group_lasso(
     fit_intercept=False,
     sample_weight=None,
     delta=None,
+    standardize=False,
     **kw,
 ):
     """AdaptiveGroupLasso: first solve uses alpha*ones(G) WITHOUT group_weights (:343-352, :354-362);
@@ -218,6 +289,9 @@ def fit_adaptive_group_lasso(
     dvec = np.zeros(G) if delta is None else _delta(delta, G)
     update = _default_update(alpha) if update_function is None else update_function
     zeros_p = np.zeros(p)
+    back = None
+    if standardize:  # group_norms.value is ||X_g beta_g|| then (:372-374): loop in whitened coordinates
+        Xp, back = _whiten_groups(Xp, gidx, G)
 
     def solve_with(w, beta_prev):
         return _solve(Xp, yp, zeros_p, w, dvec, gidx, G, beta0=beta_prev, **kw)[0]
@@ -227,6 +301,8 @@ def fit_adaptive_group_lasso(
         return (alpha * gw) * np.asarray(update(norms, eps), dtype=np.float64)
 
     beta, n_iter, w = _adaptive_loop(solve_with, update_weights, alpha * np.ones(G), max_iter, tol)
+    if back is not None:
+        beta = back(beta)
     return {
         "coef": beta,
         "intercept": _intercept(beta, xo, yo, fit_intercept),

@@ -7,18 +7,21 @@ branch-and-bound MIQP solver and are out of scope for a proximal-gradient engine
 from ._adaptive_lasso import (
     AdaptiveGroupLasso,
     AdaptiveLasso,
+    AdaptiveOverlapGroupLasso,
     AdaptiveRidgedGroupLasso,
     AdaptiveSparseGroupLasso,
 )
-from ._lasso import GroupLasso, Lasso, RidgedGroupLasso, SparseGroupLasso
+from ._lasso import GroupLasso, Lasso, OverlapGroupLasso, RidgedGroupLasso, SparseGroupLasso
 
 __all__ = [
     "Lasso",
     "GroupLasso",
+    "OverlapGroupLasso",
     "SparseGroupLasso",
     "RidgedGroupLasso",
     "AdaptiveLasso",
     "AdaptiveGroupLasso",
+    "AdaptiveOverlapGroupLasso",
     "AdaptiveSparseGroupLasso",
     "AdaptiveRidgedGroupLasso",
 ]

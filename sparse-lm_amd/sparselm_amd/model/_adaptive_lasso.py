@@ -28,11 +28,12 @@ import numpy as np
 from sklearn.utils._param_validation import Interval
 
 from .._backend import get_backend
-from ._lasso import GroupLasso, Lasso, RidgedGroupLasso, SparseGroupLasso
+from ._lasso import GroupLasso, Lasso, OverlapGroupLasso, RidgedGroupLasso, SparseGroupLasso
 
 __all__ = [
     "AdaptiveLasso",
     "AdaptiveGroupLasso",
+    "AdaptiveOverlapGroupLasso",
     "AdaptiveSparseGroupLasso",
     "AdaptiveRidgedGroupLasso",
 ]
@@ -129,9 +130,12 @@ class AdaptiveLasso(Lasso):
         p = X.shape[1]
         gidx, G, weights = self._adaptive_setup(X)
         previous_weights = weights.copy()
-        problem = get_backend().problem(X, y, gidx, G, solver_options)
+        # standardize=True: the loop runs in the per-group QR coordinates, where the engine's group norms
+        # are ||X_g b_g|| -- what the reference feeds to the weight update (_adaptive_lasso.py:364-374)
+        Xu, back = self._design_transform(X)
+        problem = get_backend().problem(Xu, y, gidx, G, solver_options)
         beta = None
-        warm = self._warm_beta(p) if hasattr(self, "coef_") else None
+        warm = self._warm_beta(p) if (hasattr(self, "coef_") and back is None) else None
         infos = []
         self.n_iter_ = 0
         try:
@@ -154,7 +158,7 @@ class AdaptiveLasso(Lasso):
             raise ValueError("max_iter=0 performs no solve; coef_ would be undefined")
         self.adaptive_weights_ = weights
         self.solver_info_ = {"solves": infos}
-        return beta
+        return beta if back is None else back(beta)
 
 
 class AdaptiveGroupLasso(AdaptiveLasso, GroupLasso):
@@ -206,6 +210,72 @@ class AdaptiveGroupLasso(AdaptiveLasso, GroupLasso):
     def _updated_weights(self, beta, group_norms):
         update = self._get_update_function()
         return (self.alpha * self._gw) * np.asarray(update(group_norms, self.eps), dtype=np.float64)
+
+
+class AdaptiveOverlapGroupLasso(AdaptiveGroupLasso, OverlapGroupLasso):
+    r"""Adaptive Overlap Group Lasso (reference _adaptive_lasso.py:377-524): the AdaptiveGroupLasso
+    re-weighting loop on the column-duplicated design, coefficients folded back (:515-524)."""
+
+    def __init__(
+        self,
+        group_list=None,
+        alpha=1.0,
+        group_weights=None,
+        max_iter=3,
+        eps=1e-6,
+        tol=1e-10,
+        update_function=None,
+        standardize=False,
+        fit_intercept=False,
+        copy_X=True,
+        warm_start=True,
+        solver=None,
+        solver_options=None,
+    ):
+        OverlapGroupLasso.__init__(
+            self,
+            group_list=group_list,
+            alpha=alpha,
+            group_weights=group_weights,
+            standardize=standardize,
+            fit_intercept=fit_intercept,
+            copy_X=copy_X,
+            warm_start=warm_start,
+            solver=solver,
+            solver_options=solver_options,
+        )
+        self._init_adaptive(max_iter, eps, tol, update_function)
+
+    def _validate_params(self, X, y) -> None:
+        OverlapGroupLasso._validate_params(self, X, y)
+        if self.max_iter == 1:
+            warnings.warn(
+                "max_iter is set to 1. It should ideally be set > 1, otherwise consider "
+                "using a non-adaptive Regressor",
+                UserWarning,
+            )
+
+    def _solve(self, X, y, solver_options, *args, **kwargs):
+        p = X.shape[1]
+        bidx, ext, G = self._extended(X)
+        self._ext_groups = ext
+        beta_ext = AdaptiveLasso._solve(self, np.ascontiguousarray(X[:, bidx]), y, solver_options)
+        return np.bincount(bidx, weights=beta_ext, minlength=p)
+
+    def _design_transform(self, X_ext):
+        if not self.standardize:
+            return X_ext, None
+        from ._lasso import standardize_groups
+
+        return standardize_groups(X_ext, self._ext_groups, int(self._ext_groups.max()) + 1)
+
+    def _adaptive_setup(self, X_ext):
+        G = int(self._ext_groups.max()) + 1
+        self._gw = np.ones(G) if self.group_weights is None else np.asarray(self.group_weights, dtype=np.float64)
+        return self._ext_groups, G, self.alpha * np.ones(G)
+
+    def _warm_beta(self, n_features):
+        return None  # coef_ lives in the folded space; the extended problem starts cold
 
 
 class AdaptiveSparseGroupLasso(AdaptiveLasso, SparseGroupLasso):

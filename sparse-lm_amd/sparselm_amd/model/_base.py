@@ -127,6 +127,11 @@ class ProxRegressor(RegressorMixin, BaseEstimator):
         """Return (a, b, d, gidx, n_groups); a: (p,) or None (=0), b/d: (G,) or None (=0)."""
         raise NotImplementedError
 
+    def _design_transform(self, X):
+        """Hook: return (X_used, back) where ``back`` maps the solution on X_used to coefficients of X
+        (None = identity).  Used by ``standardize=True``."""
+        return X, None
+
     def _warm_beta(self, n_features):
         if self.warm_start and hasattr(self, "coef_") and np.shape(self.coef_) == (n_features,):
             if np.all(np.isfinite(self.coef_)):
@@ -137,18 +142,19 @@ class ProxRegressor(RegressorMixin, BaseEstimator):
         """Counterpart of CVXRegressor._solve (reference _base.py:512-519): one minimisation."""
         a, b, d, gidx, G = self._penalty(X)
         p = X.shape[1]
-        problem = get_backend().problem(X, y, gidx, G, solver_options)
+        Xu, back = self._design_transform(X)
+        problem = get_backend().problem(Xu, y, gidx, G, solver_options)
         try:
             beta, _, info = problem.solve(
                 np.zeros(p) if a is None else a,
                 np.zeros(G) if b is None else b,
                 np.zeros(G) if d is None else d,
-                beta0=self._warm_beta(p),
+                beta0=self._warm_beta(p) if back is None else None,
             )
         finally:
             problem.close()
         self.solver_info_ = info
-        return beta
+        return beta if back is None else back(beta)
 
     def __sklearn_tags__(self):
         tags = super().__sklearn_tags__()

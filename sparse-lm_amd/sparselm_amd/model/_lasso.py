@@ -19,7 +19,7 @@ from sklearn.utils.validation import check_scalar
 from .._utils.validation import check_group_weights, check_groups, dense_group_index
 from ._base import ProxRegressor
 
-__all__ = ["Lasso", "GroupLasso", "SparseGroupLasso", "RidgedGroupLasso"]
+__all__ = ["Lasso", "GroupLasso", "OverlapGroupLasso", "SparseGroupLasso", "RidgedGroupLasso"]
 
 
 class Lasso(ProxRegressor):
@@ -103,10 +103,21 @@ class GroupLasso(Lasso):
             n_groups = len(np.unique(self.groups))
         check_groups(self.groups, X.shape[1])
         check_group_weights(self.group_weights, n_groups)
-        if self.standardize:
+        if self.standardize and not self._supports_standardize:
             raise NotImplementedError(
-                "standardize=True (penalty on ||X_g b_g||) is not implemented by the HIP engine yet"
+                f"standardize=True is not implemented for {self.__class__.__name__}: its penalty mixes "
+                "||X_g b_g|| with terms on b itself, which the per-group QR change of variables does not keep separable"
             )
+
+    # standardize=True is a per-group change of variables (see standardize_groups); it only keeps the
+    # problem inside the prox family for pure group penalties
+    _supports_standardize = True
+
+    def _design_transform(self, X):
+        if not self.standardize:
+            return X, None
+        gidx, G = dense_group_index(self.groups, X.shape[1])
+        return standardize_groups(X, gidx, G)
 
     def _group_setup(self, X):
         gidx, G = dense_group_index(self.groups, X.shape[1])
@@ -118,9 +129,138 @@ class GroupLasso(Lasso):
         return None, self.alpha * w, None, gidx, G
 
 
+def standardize_groups(X, gidx, n_groups):
+    """Per-group thin QR, ``X_g = Q_g R_g``: with ``gamma_g = R_g beta_g`` the standardised penalty
+    ``||X_g beta_g||_2`` (reference _lasso.py:249-252) is the ordinary ``||gamma_g||_2`` on the design
+    ``Q`` and the loss is unchanged (``X beta = Q gamma``).  Returns (Q, back) with
+    ``back(gamma) = beta``.  Needs every group to have full column rank."""
+    from scipy.linalg import solve_triangular
+
+    X = np.asarray(X, dtype=np.float64)
+    gidx = np.arange(X.shape[1]) if gidx is None else np.asarray(gidx)
+    Q = np.empty_like(X)
+    factors = []
+    for g in range(n_groups):
+        cols = np.flatnonzero(gidx == g)
+        if len(cols) > X.shape[0]:
+            raise ValueError(f"standardize=True: group {g} has more features than there are samples")
+        q, r = np.linalg.qr(X[:, cols])
+        diag = np.abs(np.diag(r))
+        if len(cols) and diag.min() <= 1e-12 * max(diag.max(), 1e-300):
+            raise ValueError(f"standardize=True: the columns of group {g} are linearly dependent")
+        Q[:, cols] = q
+        factors.append((cols, r))
+
+    def back(gamma):
+        beta = np.empty_like(gamma)
+        for cols, r in factors:
+            beta[cols] = solve_triangular(r, gamma[cols], lower=False)
+        return beta
+
+    return Q, back
+
+
+def overlap_extension(group_list, n_features):
+    """Column duplication that makes overlapping groups disjoint (reference _lasso.py:440-461):
+    returns (beta_indices, extended_groups); ``None`` means singleton groups (:446-448)."""
+    if group_list is None:
+        group_list = [[i] for i in range(n_features)]
+    group_ids = np.sort(np.unique([gid for grp in group_list for gid in grp]))
+    inds = [[i for i, grp in enumerate(group_list) if gid in grp] for gid in group_ids]
+    extended_groups = np.concatenate([len(g) * [i] for i, g in enumerate(inds)])
+    return np.concatenate(inds).astype(np.int64), extended_groups.astype(np.int32)
+
+
+class OverlapGroupLasso(GroupLasso):
+    r"""Overlap Group Lasso: ``alpha sum_G w_G ||b_G||_2`` where a coefficient may belong to several
+    groups (reference _lasso.py:279-502).  Solved, as in the reference, as an ordinary group lasso on
+    the design with duplicated columns ``X[:, beta_indices]`` (:440-461); the coefficients of the
+    copies are summed back (:486-502).
+
+    Args:
+        group_list (list[list[int]] | None): for every feature the ids of the groups it belongs to;
+            ``None`` warns and reduces to a Lasso (:398-404).
+    """
+
+    def __init__(
+        self,
+        group_list=None,
+        alpha=1.0,
+        group_weights=None,
+        standardize=False,
+        fit_intercept=False,
+        copy_X=True,
+        warm_start=False,
+        solver=None,
+        solver_options=None,
+    ):
+        self.group_list = group_list
+        GroupLasso.__init__(
+            self,
+            groups=None,
+            alpha=alpha,
+            group_weights=group_weights,
+            standardize=standardize,
+            fit_intercept=fit_intercept,
+            copy_X=copy_X,
+            warm_start=warm_start,
+            solver=solver,
+            solver_options=solver_options,
+        )
+
+    @classmethod
+    def _get_param_names(cls):
+        # `groups` is fixed to None by the constructor and is not a hyper-parameter of this class
+        return sorted(n for n in super()._get_param_names() if n != "groups")
+
+    def _n_groups(self, n_features):
+        if self.group_list is None:
+            return n_features
+        return len(np.unique([gid for grp in self.group_list for gid in grp]))
+
+    def _validate_params(self, X, y) -> None:
+        """Reference _lasso.py:384-406 (skips GroupLasso's own group checks)."""
+        Lasso._validate_params(self, X, y)
+        if self.group_list is not None:
+            if len(self.group_list) != X.shape[1]:
+                raise ValueError("The length of the group list must be the same as the number of features.")
+        else:
+            warnings.warn(
+                "No group list has been supplied such that the problem reduces to"
+                " a simple Lasso. You should consider using that instead.",
+                UserWarning,
+            )
+        check_group_weights(self.group_weights, self._n_groups(X.shape[1]))
+
+    def _extended(self, X):
+        bidx, ext = overlap_extension(self.group_list, X.shape[1])
+        return bidx, ext, int(ext.max()) + 1
+
+    def _solve(self, X, y, solver_options, *args, **kwargs):
+        from .._backend import get_backend
+
+        p = X.shape[1]
+        bidx, ext, G = self._extended(X)
+        w = np.ones(G) if self.group_weights is None else np.asarray(self.group_weights, dtype=np.float64)
+        X_ext, back = np.ascontiguousarray(X[:, bidx]), None
+        if self.standardize:
+            X_ext, back = standardize_groups(X_ext, ext, G)
+        problem = get_backend().problem(X_ext, y, ext, G, solver_options)
+        try:
+            beta_ext, _, info = problem.solve(np.zeros(len(bidx)), self.alpha * w, np.zeros(G))
+        finally:
+            problem.close()
+        self.solver_info_ = info
+        if back is not None:
+            beta_ext = back(beta_ext)
+        return np.bincount(bidx, weights=beta_ext, minlength=p)
+
+
 class SparseGroupLasso(GroupLasso):
     r"""Sparse Group Lasso: ``lambda1 ||b||_1 + lambda2 sum_g w_g ||b_g||_2`` with
     ``lambda1 = l1_ratio * alpha`` and ``lambda2 = (1 - l1_ratio) * alpha`` (reference _lasso.py:505-639)."""
+
+    _supports_standardize = False
 
     def __init__(
         self,
@@ -180,6 +320,8 @@ class RidgedGroupLasso(GroupLasso):
     Args:
         delta (ndarray | tuple): ridge weight, length 1 (shared) or one per group (:744-765).
     """
+
+    _supports_standardize = False
 
     _hyper_parameter_constraints: dict = {
         "alpha": [Interval(type=Real, left=0.0, right=None, closed="left")],
