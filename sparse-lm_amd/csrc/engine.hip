@@ -105,10 +105,20 @@ static int load_rccl() {
 // ------------------------------------------------------------------------------------------------
 struct GradKernel {
   int W, C, R, B;
+  int D;  // 0: rows wait in VGPRs (grad_fused_kernel); > 0: LDS ring, D rows in flight (grad_ring_kernel)
   void (*fn)(GradArgs);
 };
 
-#define SLM_GK(W, C, R, B) {W, C, R, B, grad_fused_kernel<W, C, R, B>}
+#define SLM_GK(W, C, R, B) {W, C, R, B, 0, grad_fused_kernel<W, C, R, B>}
+#define SLM_RK(W, C, B, D) {W, C, 1, B, D, grad_ring_kernel<W, C, B, D>}
+// LDS-ring variants, preferred where they exist (512-thread workgroups, rows of up to 5120 columns);
+// ordered by capacity within each lane count.
+static const GradKernel kGradRing[] = {
+    SLM_RK(8, 1, 1, 3), SLM_RK(8, 2, 1, 3), SLM_RK(8, 3, 1, 3), SLM_RK(8, 4, 1, 3), SLM_RK(8, 5, 1, 2),
+    SLM_RK(8, 1, 2, 3), SLM_RK(8, 2, 2, 3), SLM_RK(8, 3, 2, 3), SLM_RK(8, 4, 2, 3), SLM_RK(8, 5, 2, 2),
+    SLM_RK(8, 1, 3, 3), SLM_RK(8, 2, 3, 3), SLM_RK(8, 3, 3, 3), SLM_RK(8, 4, 3, 3), SLM_RK(8, 5, 3, 2),
+    SLM_RK(8, 1, 4, 3), SLM_RK(8, 2, 4, 3), SLM_RK(8, 3, 4, 3), SLM_RK(8, 4, 4, 3), SLM_RK(8, 5, 4, 2),
+};
 // Default choice per (lanes B, capacity 64*W*C chunks of 16 bytes); every list is ordered by
 // capacity.  R (rows held per step) is the largest that keeps the kernel free of (large) spills at
 // 256 VGPRs; measured register counts are in DESIGN.md.
@@ -136,6 +146,15 @@ static const int kProfStride = 4;  // SLM_FLAG_PROFILE times every 4th gradient 
 static const int64_t kMaxChunks = 64 * 8 * 10;  // largest row the fused kernel covers (p <= 10240)
 
 static const GradKernel* pick_grad_kernel(int64_t p2, int B) {
+  // LDS-ring variants: measured flat in B (0.60-0.61 ms for B = 1..4 at p = 5000) where the register
+  // variants grow (0.598 / 0.599 / 0.615 / 0.733 ms on the same box), so they take over from B = 3.
+  // SLM_GRAD_RING=0 disables them, =1 forces them for every B.
+  const char* ring = getenv("SLM_GRAD_RING");
+  const bool ring_off = ring && ring[0] == '0', ring_all = ring && ring[0] == '1';
+  if (!ring_off && p2 > 256 && (B >= 3 || ring_all)) {
+    for (const auto& k : kGradRing)
+      if (k.B == B && 64LL * k.W * k.C >= p2) return &k;
+  }
   const char* env = getenv("SLM_GRAD_CONFIG");
   if (env) {
     int W = 0, C = 0, R = 0;
@@ -725,7 +744,7 @@ static int check_launch() {
 // Power steps used for the seed L of a solve.  The spectral scheme only needs the right order of
 // magnitude (it measures curvature along its own steps) and FISTA's curvature guard repairs an
 // under-estimate, so a handful of passes is enough; slm_dataset_lipschitz() asks for more.
-static const int kPowerItersSolve = 4;
+static const int kPowerItersSolve = 2;
 static const int kPowerItersQuery = 16;
 
 static int power_iteration(slm_dataset* ds, const LaneSetup& ls, double* L_out /*[B]*/, int iters) {

@@ -249,6 +249,176 @@ __global__ __launch_bounds__(W * 64) void grad_fused_kernel(GradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-ring variant: the same single pass, but the rows in flight wait in LDS instead of VGPRs.
+//
+// Each wavefront streams ITS OWN 16-byte chunks of the next D rows straight into LDS with
+// `global_load_lds_dwordx4` (no VGPR destination) and later reads exactly those chunks back, so the
+// ring needs no cross-wave synchronisation: the only ordering is the wave's own counted
+// `s_waitcnt vmcnt(D*C)`.  With the prefetch depth decoupled from the register budget, the register
+// file holds only one row (4C VGPRs) next to the per-lane z and accumulators (8C VGPRs per lane),
+// which is what lets four and more lanes keep two to three rows (80-120 KB per CU) in flight.
+// Rules followed (cdna_hip_programming.md, "Pipelining across barriers"): all LDS in ONE array, raw
+// `s_barrier` + `lgkmcnt(0)` for the dot exchange (a `__syncthreads()` would drain the DMA queue),
+// counted `vmcnt`, no VGPR-destination global loads inside the loop (y / row weights are scalar loads).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Scalar (SMEM) load of one double through a wave-uniform pointer.  Written in asm because, next to
+// LDS-DMA traffic, hipcc turns `y[row]` into a VGPR load and then waits `vmcnt(0)` on it, draining
+// the ring every row.  The caller must `s_waitcnt lgkmcnt(0)` before using the value.
+__device__ __forceinline__ uint64_t smem_load_u64(const double* p) {
+  uint64_t v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int W, int C, int B, int D>
+__global__ __launch_bounds__(W * 64) void grad_ring_kernel(GradArgs a) {
+  constexpr int T = W * 64;
+  constexpr int SLOT = T * C * 16;             // bytes of one ring slot (one padded row)
+  constexpr int RING = (D + 1) * SLOT;
+  constexpr int RED = 2 * B * W * 8;
+  static_assert(RING + RED <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  static_assert(D * C < 64, "too many DMA loads in flight for vmcnt");
+  if (a.done != nullptr && *a.done != 0) return;
+
+  __shared__ __attribute__((aligned(16))) char smem[RING + RED];
+  double* red = reinterpret_cast<double*>(smem + RING);  // [2][B][W]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int64_t b = blockIdx.x;
+  const int64_t base = a.rows_base, rem = a.rows_rem;
+  const int64_t r0 = b * base + (b < rem ? b : rem);
+  const int64_t nrows = base + (b < rem ? 1 : 0);
+
+  uint32_t coff[C];  // byte offset of the lane's chunk inside a global row (clamped)
+  bool valid[C];
+  d2 zr[B][C], acc[B][C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int ci = c * T + tid;
+    valid[c] = ci < a.p2;
+    const int cc = valid[c] ? ci : a.p2 - 1;
+    coff[c] = (uint32_t)cc * 16u;
+#pragma unroll
+    for (int l = 0; l < B; ++l) {
+      const d2 zz = reinterpret_cast<const d2*>(a.z + l * a.ld)[cc];
+      zr[l][c] = valid[c] ? zz : d2{0.0, 0.0};
+      acc[l][c] = d2{0.0, 0.0};
+    }
+  }
+  double loss[B];
+#pragma unroll
+  for (int l = 0; l < B; ++l) loss[l] = 0.0;
+
+  // DMA one row into ring slot `slot`: C wave-instructions of 1 KiB each
+  auto issue_row = [&](int64_t i, int slot) {
+    const char* rp = reinterpret_cast<const char*>(a.X + (r0 + i) * a.ld);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      char* dst = smem + slot * SLOT + (c * T + wave * 64) * 16;  // wave-uniform; hardware adds lane*16
+      __builtin_amdgcn_global_load_lds((gptr_t)(rp + coff[c]), (lptr_t)dst, 16, 0, SLM_NT_LOADS ? 2 : 0);
+    }
+  };
+
+  if (nrows > 0) {
+    // prologue: D rows in flight
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      if (k < nrows) issue_row(k, k);
+    int slot = 0;        // slot of row i
+    int slot_in = D;     // slot row i + D goes into
+    for (int64_t i = 0; i < nrows; ++i) {
+      const int64_t left = nrows - 1 - i;  // rows after i
+      if (left >= D) {
+        issue_row(i + D, slot_in);
+        wait_vmcnt<D * C>();
+      } else {
+        // tail: fewer than D rows remain in flight behind row i
+        if (D >= 3 && left == 2) wait_vmcnt<(D >= 3 ? 2 : 0) * C>();
+        else if (D >= 2 && left == 1) wait_vmcnt<(D >= 2 ? 1 : 0) * C>();
+        else wait_vmcnt<0>();
+      }
+      // scalar operands of this row (SMEM loads; waited for together with the LDS reads below)
+      const int64_t row = r0 + i;
+      const uint64_t yi_bits = smem_load_u64(a.y + row);
+      uint64_t m_bits[B];
+      const bool has_rw = a.rw != nullptr;
+      if (has_rw) {
+#pragma unroll
+        for (int l = 0; l < B; ++l) m_bits[l] = smem_load_u64(a.rw + l * a.rw_stride + row);
+      }
+
+      d2 x[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        x[c] = *reinterpret_cast<const d2*>(smem + slot * SLOT + (c * T + tid) * 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const double yi = __longlong_as_double((long long)yi_bits);
+      double m[B];
+#pragma unroll
+      for (int l = 0; l < B; ++l) m[l] = has_rw ? __longlong_as_double((long long)m_bits[l]) : 1.0;
+
+      double dot[B];
+#pragma unroll
+      for (int l = 0; l < B; ++l) {
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          t = __builtin_fma(x[c].x, zr[l][c].x, t);
+          t = __builtin_fma(x[c].y, zr[l][c].y, t);
+        }
+        dot[l] = wave_sum_lane63(t);
+        if constexpr (W == 1) dot[l] = read_lane63(dot[l]);
+      }
+      if constexpr (W > 1) {
+        const int parity = (int)(i & 1);
+        if (lane == 63) {
+#pragma unroll
+          for (int l = 0; l < B; ++l) red[(parity * B + l) * W + wave] = dot[l];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int l = 0; l < B; ++l) dot[l] = group_sum_all<W>(red[(parity * B + l) * W + (lane & (W - 1))]);
+      }
+#pragma unroll
+      for (int l = 0; l < B; ++l) {
+        const double e = dot[l] - yi;
+        const double res = e * m[l];
+        loss[l] = __builtin_fma(res, e, loss[l]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          acc[l][c].x = __builtin_fma(res, x[c].x, acc[l][c].x);
+          acc[l][c].y = __builtin_fma(res, x[c].y, acc[l][c].y);
+        }
+      }
+      slot = (slot == D) ? 0 : slot + 1;
+      slot_in = (slot_in == D) ? 0 : slot_in + 1;
+    }
+  }
+
+#pragma unroll
+  for (int l = 0; l < B; ++l) {
+    d2* out = reinterpret_cast<d2*>(a.partial + (b * B + l) * a.ld);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      if (valid[c]) out[c * T + tid] = acc[l][c];
+    if (tid == 0) a.loss_partial[b * B + l] = loss[l];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Deterministic cross-workgroup reduction per lane:  g_l[j] = scale_l * sum_b partial[b][l][j], loss
 // likewise.  256 threads = 16 column lanes x 16 row slices; one workgroup per 16 columns (128-byte
 // segments).  The loss sum lands in g_l[ld] so that a single all-reduce covers gradient and loss in

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--blocks", type=str, default="0,1,2")
     ap.add_argument("--lanes", type=str, default="1")
+    ap.add_argument("--ring", type=str, default="0", help="comma list of SLM_GRAD_RING values to sweep (0 = register kernel, 1 = LDS ring)")
     args = ap.parse_args()
     eng = _engine.get_engine(0)
     print(eng.device_info(), flush=True)
@@ -40,31 +41,33 @@ def main():
     cfgs = CONFIGS.get(p)
     if cfgs is None:
         cfgs = [None]
-    for cfg in cfgs:
-        for blocks in args.blocks.split(","):
-            if cfg is None:
-                os.environ.pop("SLM_GRAD_CONFIG", None)
-            else:
-                os.environ["SLM_GRAD_CONFIG"] = cfg
-            if blocks == "0":
-                os.environ.pop("SLM_GRAD_BLOCKS_PER_CU", None)
-            else:
-                os.environ["SLM_GRAD_BLOCKS_PER_CU"] = blocks
-            try:
-                ds = eng.synthetic_dataset(n, p, seed=1, coef=coef, noise_sd=1.0)
-            except Exception as exc:  # config does not cover p
-                print(f"cfg={cfg} blocks/CU={blocks}: skipped ({exc})", flush=True)
-                continue
-            for lanes in args.lanes.split(","):
-                os.environ["SLM_PROBE_LANES"] = lanes
+    for ring in args.ring.split(","):
+        os.environ["SLM_GRAD_RING"] = ring
+        for cfg in (cfgs if ring == "0" else ["ring"]):
+            for blocks in args.blocks.split(","):
+                if cfg is None or cfg == "ring":
+                    os.environ.pop("SLM_GRAD_CONFIG", None)
+                else:
+                    os.environ["SLM_GRAD_CONFIG"] = cfg
+                if blocks == "0":
+                    os.environ.pop("SLM_GRAD_BLOCKS_PER_CU", None)
+                else:
+                    os.environ["SLM_GRAD_BLOCKS_PER_CU"] = blocks
                 try:
-                    g, loss, ms = ds.gradient(z, reps=args.reps)
-                except NotImplementedError as exc:
-                    print(f"cfg={cfg} lanes={lanes}: unsupported ({exc})", flush=True)
+                    ds = eng.synthetic_dataset(n, p, seed=1, coef=coef, noise_sd=1.0)
+                except Exception as exc:  # config does not cover p
+                    print(f"cfg={cfg} blocks/CU={blocks}: skipped ({exc})", flush=True)
                     continue
-                print(f"cfg={cfg} lanes={lanes} blocks/CU={blocks or 'occ'}: {ms:8.4f} ms  {nbytes / ms / 1e6:8.1f} GB/s  "
-                      f"frac_of_8TB/s={nbytes / ms / 1e6 / 8000:.3f}  |g|={np.linalg.norm(g):.6e}", flush=True)
-            ds.close()
+                for lanes in args.lanes.split(","):
+                    os.environ["SLM_PROBE_LANES"] = lanes
+                    try:
+                        g, loss, ms = ds.gradient(z, reps=args.reps)
+                    except NotImplementedError as exc:
+                        print(f"cfg={cfg} lanes={lanes}: unsupported ({exc})", flush=True)
+                        continue
+                    print(f"cfg={cfg} lanes={lanes} blocks/CU={blocks or 'occ'}: {ms:8.4f} ms  {nbytes / ms / 1e6:8.1f} GB/s  "
+                          f"frac_of_8TB/s={nbytes / ms / 1e6 / 8000:.3f}  |g|={np.linalg.norm(g):.6e}", flush=True)
+                ds.close()
 
 
 if __name__ == "__main__":
