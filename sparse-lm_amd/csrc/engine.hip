@@ -142,10 +142,16 @@ static const GradKernel kGradExtra[] = {
     SLM_GK(8, 5, 1, 1), SLM_GK(8, 5, 3, 1), SLM_GK(8, 5, 4, 1), SLM_GK(8, 4, 4, 1), SLM_GK(8, 6, 1, 1),
     SLM_GK(8, 8, 1, 1), SLM_GK(8, 5, 1, 2), SLM_GK(8, 5, 1, 3), SLM_GK(8, 4, 4, 2), SLM_GK(8, 6, 1, 2),
 };
+static const int kMaxTailE = 64;  // tail kernel instantiations cover p <= 1024 * 64
 static const int kProfStride = 4;  // SLM_FLAG_PROFILE times every 4th gradient launch
 static const int64_t kMaxChunks = 64 * 8 * 10;  // largest row the fused kernel covers (p <= 10240)
 
+// Rows longer than the fused kernels cover: two-pass fallback (D = -1), one lane, any p.
+static const GradKernel kGradTwoPass = {8, 4, 2, 1, -1, nullptr};
+static const int kTwoPassC = 4;  // column tile of xtr_kernel: 512 * 4 chunks = 4096 columns
+
 static const GradKernel* pick_grad_kernel(int64_t p2, int B) {
+  if (p2 > kMaxChunks) return B == 1 ? &kGradTwoPass : nullptr;
   // LDS-ring variants: measured flat in B (0.60-0.61 ms for B = 1..4 at p = 5000) where the register
   // variants grow (0.598 / 0.599 / 0.615 / 0.733 ms on the same box), so they take over from B = 3.
   // SLM_GRAD_RING=0 disables them, =1 forces them for every B.
@@ -201,6 +207,7 @@ struct slm_dataset {
   int64_t n = 0, p = 0, ld = 0, n_global = 0;
   double *X = nullptr, *y = nullptr, *rw = nullptr, *yzero = nullptr;
   double* rw_lanes = nullptr;  // [kMaxLanes][n], allocated when a lane brings its own row weights
+  double* rvec = nullptr;      // [n] residuals of the two-pass fallback
   // group structure (group-sorted permutation)
   int G = 0, singleton = 1, team = 1;
   int *order = nullptr, *gid = nullptr, *gstart = nullptr;
@@ -336,7 +343,7 @@ extern "C" int slm_engine_device_info(slm_engine* eng, int64_t out[6], char* nam
 // ------------------------------------------------------------------------------------------------
 static void dataset_free(slm_dataset* ds) {
   if (!ds) return;
-  dfree(ds->X); dfree(ds->y); dfree(ds->rw); dfree(ds->yzero); dfree(ds->rw_lanes);
+  dfree(ds->X); dfree(ds->y); dfree(ds->rw); dfree(ds->yzero); dfree(ds->rw_lanes); dfree(ds->rvec);
   dfree(ds->order); dfree(ds->gid); dfree(ds->gstart);
   dfree(ds->partial); dfree(ds->loss_partial);
   dfree(ds->g); dfree(ds->z); dfree(ds->beta); dfree(ds->zprev); dfree(ds->gprev);
@@ -373,9 +380,9 @@ static int set_singleton_groups(slm_dataset* ds) {
 static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** out) {
   if (n <= 0 || p <= 0) return fail(SLM_ERR_BAD_ARG, "n and p must be positive (got %lld x %lld)",
                                     (long long)n, (long long)p);
-  if (p > 2 * kMaxChunks)
-    return fail(SLM_ERR_UNSUPPORTED, "p = %lld exceeds the fused kernel's row capacity (%lld columns)",
-                (long long)p, (long long)(2 * kMaxChunks));
+  if (p > (int64_t)TAIL_THREADS * kMaxTailE)
+    return fail(SLM_ERR_UNSUPPORTED, "p = %lld exceeds the supported %d columns", (long long)p,
+                TAIL_THREADS * kMaxTailE);
   if (n > (int64_t)2000000000) return fail(SLM_ERR_UNSUPPORTED, "n too large");
   slm_dataset* ds = new slm_dataset();
   ds->eng = eng;
@@ -389,9 +396,11 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
     const GradKernel* gk = pick_grad_kernel(ld / 2, B);
     ds->gk[B - 1] = gk;
     if (!gk) continue;
-    int occ = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)gk->fn, gk->W * 64, 0);
-    if (e != hipSuccess || occ < 1) occ = 1;
+    int occ = 2;
+    if (gk->D >= 0) {
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)gk->fn, gk->W * 64, 0);
+      if (e != hipSuccess || occ < 1) occ = 1;
+    }
     int per_cu = occ;
     if (const char* env = getenv("SLM_GRAD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(env));
     int64_t nblk = (int64_t)eng->cus * per_cu;
@@ -412,6 +421,7 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
   A(dalloc(&ds->X, (size_t)n * ld));
   A(dalloc(&ds->y, n));
   A(dalloc(&ds->yzero, n));
+  if (ds->gk[0]->D < 0) A(dalloc(&ds->rvec, n));
   A(dalloc(&ds->partial, partial_elems));
   A(dalloc(&ds->loss_partial, loss_elems));
   A(dalloc(&ds->g, ML * (ld + 16)));
@@ -419,7 +429,7 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
   A(dalloc(&ds->beta, ML * ld));
   A(dalloc(&ds->zprev, ML * ld));
   A(dalloc(&ds->gprev, ML * ld));
-  A(dalloc(&ds->u, ld));
+  A(dalloc(&ds->u, ML * ld));
   A(dalloc(&ds->a0, ML * ld));
   A(dalloc(&ds->b0, ML * ld));
   A(dalloc(&ds->d0, ML * ld));
@@ -695,7 +705,17 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
   a.rw_stride = ls.rw_stride;
   a.p2 = (int)(ds->ld / 2);
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
-  hipLaunchKernelGGL(gk->fn, dim3(nblk), dim3(gk->W * 64), 0, s, a);
+  if (gk->D >= 0) {
+    hipLaunchKernelGGL(gk->fn, dim3(nblk), dim3(gk->W * 64), 0, s, a);
+  } else {  // two-pass fallback (one lane; row weights shared)
+    TwoPassArgs t;
+    t.X = ds->X; t.y = y; t.rw = ls.rw; t.z = ds->z; t.r = ds->rvec; t.partial = ds->partial;
+    t.loss_partial = ds->loss_partial; t.done = done; t.n = ds->n; t.ld = ds->ld;
+    t.rows_base = a.rows_base; t.rows_rem = a.rows_rem; t.p2 = a.p2;
+    hipLaunchKernelGGL(rowdot_kernel, dim3(nblk), dim3(256), 0, s, t);
+    const unsigned tiles = (unsigned)((a.p2 + 512 * kTwoPassC - 1) / (512 * kTwoPassC));
+    hipLaunchKernelGGL(xtr_kernel<kTwoPassC>, dim3(nblk, tiles), dim3(512), 0, s, t);
+  }
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
   ReduceArgs ra;
   ra.partial = ds->partial;
@@ -718,18 +738,30 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
   return SLM_OK;
 }
 
-// E = features per thread of the one-workgroup-per-lane tail kernel (p <= 1024 * E <= 10240)
+// E = features per thread of the one-workgroup-per-lane tail kernel (p <= 1024 * E).  Up to E = 8
+// everything stays in registers; the larger instantiations (long-row fallback) spill to scratch,
+// which is irrelevant next to a two-pass gradient over a matrix that wide.
 static void launch_tail(const TailArgs& ta, hipStream_t s) {
   const int E = (ta.p + TAIL_THREADS - 1) / TAIL_THREADS;
   const dim3 grid(ta.n_lanes);
+#define SLM_TAIL_LAUNCH(N) hipLaunchKernelGGL(fista_tail_kernel<N>, grid, dim3(TAIL_THREADS), 0, s, ta)
   switch (E) {
-#define SLM_TAIL_CASE(N) \
-  case N: hipLaunchKernelGGL(fista_tail_kernel<N>, grid, dim3(TAIL_THREADS), 0, s, ta); break;
-    SLM_TAIL_CASE(1) SLM_TAIL_CASE(2) SLM_TAIL_CASE(3) SLM_TAIL_CASE(4) SLM_TAIL_CASE(5)
-    SLM_TAIL_CASE(6) SLM_TAIL_CASE(7) SLM_TAIL_CASE(8) SLM_TAIL_CASE(9)
-    default: hipLaunchKernelGGL(fista_tail_kernel<10>, grid, dim3(TAIL_THREADS), 0, s, ta); break;
-#undef SLM_TAIL_CASE
+    case 1: SLM_TAIL_LAUNCH(1); break;
+    case 2: SLM_TAIL_LAUNCH(2); break;
+    case 3: SLM_TAIL_LAUNCH(3); break;
+    case 4: SLM_TAIL_LAUNCH(4); break;
+    case 5: SLM_TAIL_LAUNCH(5); break;
+    case 6: SLM_TAIL_LAUNCH(6); break;
+    case 7: SLM_TAIL_LAUNCH(7); break;
+    case 8: SLM_TAIL_LAUNCH(8); break;
+    case 9: SLM_TAIL_LAUNCH(9); break;
+    case 10: SLM_TAIL_LAUNCH(10); break;
+    default:
+      if (E <= 16) SLM_TAIL_LAUNCH(16);
+      else if (E <= 32) SLM_TAIL_LAUNCH(32);
+      else SLM_TAIL_LAUNCH(64);
   }
+#undef SLM_TAIL_LAUNCH
 }
 
 static int check_launch() {
@@ -825,6 +857,21 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
     HIP_TRY(hipEventCreate(&e1));
     const GradKernel* gk = ds->gk[B - 1];
     const int nblk = ds->nblk[B - 1];
+    if (gk->D < 0) {  // two-pass fallback: time the pair of kernels through the common path
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, s));
+      for (int r = 0; r < reps; ++r) SLM_TRY(enqueue_gradient(ds, lb, ds->y, nullptr, nullptr, nullptr));
+      HIP_TRY(hipEventRecord(e1, s));
+      HIP_TRY(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+      *ms_out = (double)ms / reps;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      return check_launch();
+    }
     GradArgs a;
     a.X = ds->X; a.y = ds->y; a.rw = lb.rw; a.z = ds->z; a.partial = ds->partial;
     a.loss_partial = ds->loss_partial; a.done = nullptr; a.n = ds->n; a.ld = ds->ld;
@@ -1072,6 +1119,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   ta.zprev = ds->zprev;
   ta.gprev = ds->gprev;
   ta.gscale = ds->gscale;
+  ta.uscratch = ds->u;
   ta.a0 = ds->a0;
   ta.b0 = ds->b0;
   ta.d0 = ds->d0;

@@ -419,6 +419,120 @@ __global__ __launch_bounds__(W * 64) void grad_ring_kernel(GradArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two-pass fallback for rows too long for the fused kernels (p > 10 240): X is read twice, so it
+// tops out near half the fused kernels' rate, but it has no limit on p.  One lane only.
+//   pass A  rowdot_kernel:  r_i = w_i (x_i . z - y_i)   (one wavefront per row, z re-read from L2)
+//   pass B  xtr_kernel<C>:  partial[blk][tile] = sum_{i in blk} r_i x_i[tile]
+// Both use the same contiguous row blocks, so the reduce kernel sees the layout of the fused path.
+// ---------------------------------------------------------------------------------------------
+struct TwoPassArgs {
+  const double* X;
+  const double* y;
+  const double* rw;  // nullptr or [n]
+  const double* z;   // [ld]
+  double* r;         // [n] weighted residuals
+  double* partial;   // [gridDim.x][ld]
+  double* loss_partial;
+  const int* done;
+  int64_t n, ld, rows_base, rows_rem;
+  int p2;
+};
+
+__global__ __launch_bounds__(256) void rowdot_kernel(TwoPassArgs a) {
+  if (a.done != nullptr && *a.done != 0) return;
+  __shared__ double lsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b = blockIdx.x;
+  const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
+  const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
+  const d2* zv = reinterpret_cast<const d2*>(a.z);
+  double loss = 0.0;
+  for (int64_t i = wave; i < nrows; i += 4) {
+    const int64_t row = r0 + i;
+    const d2* xv = reinterpret_cast<const d2*>(a.X + row * a.ld);
+    double t0 = 0.0, t1 = 0.0;
+    int ci = lane;
+    for (; ci + 64 < a.p2; ci += 128) {  // two independent chains
+      const d2 xa = load_x(xv + ci), xb = load_x(xv + ci + 64);
+      const d2 za = zv[ci], zb = zv[ci + 64];
+      t0 = __builtin_fma(xa.x, za.x, t0);
+      t0 = __builtin_fma(xa.y, za.y, t0);
+      t1 = __builtin_fma(xb.x, zb.x, t1);
+      t1 = __builtin_fma(xb.y, zb.y, t1);
+    }
+    if (ci < a.p2) {
+      const d2 xa = load_x(xv + ci), za = zv[ci];
+      t0 = __builtin_fma(xa.x, za.x, t0);
+      t0 = __builtin_fma(xa.y, za.y, t0);
+    }
+    const double dot = wave_sum_lane63(t0 + t1);
+    if (lane == 63) {
+      const double e = dot - a.y[row];
+      const double res = e * (a.rw != nullptr ? a.rw[row] : 1.0);
+      a.r[row] = res;
+      loss = __builtin_fma(res, e, loss);
+    }
+  }
+  if (lane == 63) lsum[wave] = loss;
+  __syncthreads();
+  if (threadIdx.x == 0) a.loss_partial[b] = (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+}
+
+// grid = (row blocks, column tiles of 512*C chunks)
+template <int C>
+__global__ __launch_bounds__(512) void xtr_kernel(TwoPassArgs a) {
+  if (a.done != nullptr && *a.done != 0) return;
+  constexpr int T = 512;
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
+  const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
+  const int tile0 = blockIdx.y * (T * C);
+  int cidx[C];
+  bool valid[C];
+  d2 acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int ci = tile0 + c * T + tid;
+    valid[c] = ci < a.p2;
+    cidx[c] = valid[c] ? ci : a.p2 - 1;
+    acc[c] = d2{0.0, 0.0};
+  }
+  int64_t i = 0;
+  for (; i + 1 < nrows; i += 2) {  // two rows in flight
+    const double ra = a.r[r0 + i], rb = a.r[r0 + i + 1];
+    const d2* xa = reinterpret_cast<const d2*>(a.X + (r0 + i) * a.ld);
+    const d2* xb = reinterpret_cast<const d2*>(a.X + (r0 + i + 1) * a.ld);
+    d2 va[C], vb[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) va[c] = load_x(xa + cidx[c]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) vb[c] = load_x(xb + cidx[c]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      acc[c].x = __builtin_fma(ra, va[c].x, acc[c].x);
+      acc[c].y = __builtin_fma(ra, va[c].y, acc[c].y);
+      acc[c].x = __builtin_fma(rb, vb[c].x, acc[c].x);
+      acc[c].y = __builtin_fma(rb, vb[c].y, acc[c].y);
+    }
+  }
+  if (i < nrows) {
+    const double ra = a.r[r0 + i];
+    const d2* xa = reinterpret_cast<const d2*>(a.X + (r0 + i) * a.ld);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const d2 v = load_x(xa + cidx[c]);
+      acc[c].x = __builtin_fma(ra, v.x, acc[c].x);
+      acc[c].y = __builtin_fma(ra, v.y, acc[c].y);
+    }
+  }
+  d2* out = reinterpret_cast<d2*>(a.partial + b * a.ld);
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+    if (valid[c]) out[cidx[c]] = acc[c];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Deterministic cross-workgroup reduction per lane:  g_l[j] = scale_l * sum_b partial[b][l][j], loss
 // likewise.  256 threads = 16 column lanes x 16 row slices; one workgroup per 16 columns (128-byte
 // segments).  The loss sum lands in g_l[ld] so that a single all-reduce covers gradient and loss in

@@ -77,6 +77,7 @@ struct TailArgs {
   double* zprev;     // [ld]
   double* gprev;     // [ld]
   double* gscale;    // [G] scratch
+  double* uscratch;  // [ld] scratch per lane (only used when p > 16384)
   const double* a0;  // [p]
   const double* b0;  // [G]
   const double* d0;  // [G]
@@ -167,7 +168,10 @@ __device__ __forceinline__ void for_each_group_sumsq(const double* src, const in
 template <int E>
 __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   __shared__ double red[8][TAIL_WAVES];
-  __shared__ double us[E * TAIL_THREADS];
+  // image of the thresholded vector for the group gathers: LDS up to 16K features, the per-lane
+  // global scratch beyond (long-row fallback; the tail is negligible next to a two-pass gradient)
+  constexpr bool US_IN_LDS = E <= 16;
+  __shared__ double us_lds[US_IN_LDS ? E * TAIL_THREADS : 1];
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
   if (ctl->done != 0 || a.gdone[0] != 0) return;
@@ -179,12 +183,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     a.a0 += off; a.b0 += off; a.d0 += off;
     a.g += (int64_t)lane_id * (a.ld + 16);
     a.gscale += (int64_t)lane_id * G;
+    a.uscratch += off;
     const int64_t po = ctl->pt_off;
     a.pts += po;
     a.betas_out += po * p;
     a.infos += po;
     if (a.gn_out != nullptr) a.gn_out += po * G;
   }
+
+  double* us = US_IN_LDS ? us_lds : a.uscratch;
 
   // ---- phase 0: per-feature loads (independent of the control block) ---------------------------
   // (kept to the minimum that must live across the reductions: 1024 threads => 128 VGPRs)

@@ -55,6 +55,45 @@ def test_gradient_matches_numpy(eng, n, p):
         npt.assert_array_equal(yd, y)
 
 
+@pytest.mark.parametrize("n,p", [(300, 10241), (257, 12345), (130, 20000), (64, 40001)])
+def test_long_rows_use_the_two_pass_fallback(eng, n, p):
+    # rows beyond the fused kernels' 10 240 columns: two-pass gradient + spilled tail, same answers
+    rng = np.random.default_rng(p)
+    X = rng.standard_normal((n, p))
+    y = rng.standard_normal(n)
+    z = rng.standard_normal(p)
+    w = rng.uniform(0.0, 2.0, n)
+    with eng.dataset(X, y, row_weight=w) as ds:
+        g, loss = ds.gradient(z)
+        g0, loss0 = ref_grad(X, y, z, w)
+        assert rel_inf(g, g0) < 1e-12
+        npt.assert_allclose(loss, loss0, rtol=1e-12)
+
+
+def test_long_row_solve_matches_oracle(eng):
+    rng = np.random.default_rng(3)
+    n, p = 400, 11000
+    X = rng.standard_normal((n, p))
+    beta = np.zeros(p)
+    beta[rng.choice(p, 8, replace=False)] = rng.uniform(2, 5, 8)
+    y = X @ beta + 0.5 * rng.standard_normal(n)
+    groups = rng.permutation(np.repeat(np.arange(p // 10), 10))
+    gidx, G = oracle.group_index(groups, p)
+    amax = np.max(np.abs(X.T @ y)) / n
+    L = oracle.lipschitz(X)
+    with eng.dataset(X, y) as ds:
+        ds.set_groups(gidx, G)
+        pts = [(0.5 * amax, 0.3 * amax, 0.0), (0.3 * amax, 0.2 * amax, 0.0)]
+        res = ds.solve_path(pts, tol=1e-10, max_iter=20000, lanes=4, want_group_norms=True)  # lanes fall back to 1
+    assert res.converged
+    b = None
+    for k, (sa, sb, _) in enumerate(pts):
+        b, info = oracle.fista(X, y, sa, sb, 0.0, gidx, G, beta0=b, L=L, tol=1e-12, max_iter=200000)
+        assert rel_inf(res.betas[k], b) < 1e-6
+    npt.assert_allclose(res.group_norms[-1], np.sqrt(np.bincount(gidx, weights=res.betas[-1] ** 2, minlength=G)),
+                        rtol=1e-12, atol=1e-300)
+
+
 def test_gradient_is_bitwise_reproducible(eng):
     rng = np.random.default_rng(5)
     X, y, z = rng.standard_normal((4000, 700)), rng.standard_normal(4000), rng.standard_normal(700)
