@@ -27,7 +27,8 @@ def counters(tag):
     if not files:
         return out
     per = {}
-    for r in csv.DictReader(open(files[0])):
+    files.sort(key=os.path.getmtime)
+    for r in csv.DictReader(open(files[-1])):  # newest run
         per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
     for k, v in per.items():
         # launches that early-exit (path already finished) move ~0 bytes: keep the working ones
@@ -40,8 +41,9 @@ def main():
     tag = sys.argv[1]
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_stats", "**", "*_kernel_stats.csv"), recursive=True)
+    stats.sort(key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+        shutil.copy(stats[-1], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
     fetch, write = counters("fetch"), counters("write")
     summary = {"units": "KiB per dispatch as reported by rocprofv3; *_bytes fields are corrected bytes", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
