@@ -111,3 +111,51 @@ def test_fast_path_one_std_and_fallbacks(golden):
     # invalid candidates raise the estimator's own error class before anything is solved
     with pytest.raises(ValueError):
         GridSearchCV(Lasso(), {"alpha": [1.0, -1.0]}, cv=3).fit(X, y)
+
+
+def _grid_rank(rank, world_size, port, out_dir):
+    import os
+    import sys
+
+    import torch.distributed as dist
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for path in (root, os.path.join(root, "sparse-lm_amd"), os.path.join(root, "tests")):
+        if path not in sys.path:
+            sys.path.insert(0, path)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world_size), LOCAL_RANK="0")  # one GPU on the test box: both ranks share it
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    from sparselm_amd.model import SparseGroupLasso
+    from sparselm_amd.model_selection import GridSearchCV as GS
+
+    with np.load(os.path.join(root, "tests", "golden", "lasso_family_golden.npz")) as f:
+        X, y, groups = f["grp_X"], f["grp_y"], f["grp_groups"]
+    grid = {"alpha": list(np.geomspace(10, 0.1, 5)), "l1_ratio": [0.1, 0.5, 0.9]}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gs = GS(SparseGroupLasso(groups=groups, solver_options={"tol": 1e-11}), grid,
+                cv=KFold(5, shuffle=True, random_state=0)).fit(X, y)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), mean=gs.cv_results_["mean_test_score"],
+             coef=gs.best_estimator_.coef_, best=gs.best_index_)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_fast_path_two_ranks_share_the_grid(golden, tmp_path):
+    # N > 1 path of the grid-aware search: (l1_ratio, fold) units dealt to ranks, results gathered
+    import torch.multiprocessing as mp
+
+    mp.spawn(_grid_rank, args=(2, 29641, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["mean"], r1["mean"])  # every rank ends with the full table
+    assert int(r0["best"]) == int(r1["best"])
+    X, y, groups = golden["grp_X"], golden["grp_y"], golden["grp_groups"]
+    grid = {"alpha": list(np.geomspace(10, 0.1, 5)), "l1_ratio": [0.1, 0.5, 0.9]}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        one = GridSearchCV(SparseGroupLasso(groups=groups, solver_options={"tol": 1e-11}), grid,
+                           cv=KFold(5, shuffle=True, random_state=0)).fit(X, y)
+    np.testing.assert_allclose(r0["mean"], one.cv_results_["mean_test_score"], rtol=1e-9)
+    np.testing.assert_allclose(r0["coef"], one.best_estimator_.coef_, rtol=0, atol=1e-9 * np.max(np.abs(one.best_estimator_.coef_)))
