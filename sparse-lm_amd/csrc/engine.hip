@@ -1145,25 +1145,79 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   bool pending[2] = {false, false};
   bool done = false;
   const int* done_flag = &ds->gctl->done;
-  while (!done) {
-    for (int i = 0; i < chunk; ++i) {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (profile && enq % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time
-        const int64_t slot_id = enq / kProfStride;
-        while ((int64_t)ds->prof.size() < 2 * (slot_id + 1)) {
-          hipEvent_t ev;
-          HIP_TRY(hipEventCreate(&ev));
-          ds->prof.push_back(ev);
+
+  // Optional hipGraph replay of a chunk (SLM_GRAPH=1): the chunk of iterations + the status copy is
+  // captured once per solve into two graphs (one per status slot).  OFF by default: measured on
+  // MI355X (tools/small_fit_timing.py) the small-problem loop is bound by the ~1.5 us dependent-kernel
+  // boundaries on the device (17 us per 3-kernel iteration), not by host launches, so replay gives
+  // 18.7 vs 16.9 us per iteration and adds ~0.6 ms of instantiation per solve.
+  hipGraphExec_t gexec[2] = {nullptr, nullptr};
+  bool use_graph = false;
+  {
+    const char* env = getenv("SLM_GRAPH");
+    if (env && env[0] == '1' && !profile && !eng->comm && chunk >= 4) {
+      use_graph = true;
+      for (int k = 0; k < 2 && use_graph; ++k) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+          use_graph = false;
+          break;
         }
-        e0 = ds->prof[2 * slot_id];
-        e1 = ds->prof[2 * slot_id + 1];
+        int rc = SLM_OK;
+        for (int i = 0; i < chunk && rc == SLM_OK; ++i) {
+          rc = enqueue_gradient(ds, ls, ds->y, done_flag, nullptr, nullptr);
+          launch_tail(ta, s);
+        }
+        hipError_t e1 = hipMemcpyAsync(&ds->hctl[k].g, ds->gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, s);
+        hipError_t e2 = hipStreamEndCapture(s, &graph);
+        if (rc != SLM_OK || e1 != hipSuccess || e2 != hipSuccess || !graph ||
+            hipGraphInstantiate(&gexec[k], graph, nullptr, nullptr, 0) != hipSuccess) {
+          use_graph = false;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
       }
-      SLM_TRY(enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1));
-      launch_tail(ta, s);
-      ++enq;
+      if (!use_graph) {
+        (void)hipGetLastError();  // clear; fall back to eager launches
+        for (auto& ge : gexec)
+          if (ge) {
+            (void)hipGraphExecDestroy(ge);
+            ge = nullptr;
+          }
+      }
     }
-    SLM_TRY(check_launch());
-    HIP_TRY(hipMemcpyAsync(&ds->hctl[slot].g, ds->gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, s));
+  }
+  struct GraphGuard {
+    hipGraphExec_t* g;
+    ~GraphGuard() {
+      for (int k = 0; k < 2; ++k)
+        if (g[k]) (void)hipGraphExecDestroy(g[k]);
+    }
+  } graph_guard{gexec};
+
+  while (!done) {
+    if (use_graph) {
+      HIP_TRY(hipGraphLaunch(gexec[slot], s));
+      enq += chunk;
+    } else {
+      for (int i = 0; i < chunk; ++i) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile && enq % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time
+          const int64_t slot_id = enq / kProfStride;
+          while ((int64_t)ds->prof.size() < 2 * (slot_id + 1)) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreate(&ev));
+            ds->prof.push_back(ev);
+          }
+          e0 = ds->prof[2 * slot_id];
+          e1 = ds->prof[2 * slot_id + 1];
+        }
+        SLM_TRY(enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1));
+        launch_tail(ta, s);
+        ++enq;
+      }
+      SLM_TRY(check_launch());
+      HIP_TRY(hipMemcpyAsync(&ds->hctl[slot].g, ds->gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipEventRecord(ds->ev[slot], s));
     pending[slot] = true;
     const int other = slot ^ 1;
