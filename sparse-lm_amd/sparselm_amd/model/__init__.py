@@ -11,9 +11,17 @@ from ._adaptive_lasso import (
     AdaptiveRidgedGroupLasso,
     AdaptiveSparseGroupLasso,
 )
-from ._lasso import GroupLasso, Lasso, OverlapGroupLasso, RidgedGroupLasso, SparseGroupLasso
+from ._lasso import (
+    GroupLasso,
+    Lasso,
+    OrdinaryLeastSquares,
+    OverlapGroupLasso,
+    RidgedGroupLasso,
+    SparseGroupLasso,
+)
 
 __all__ = [
+    "OrdinaryLeastSquares",
     "Lasso",
     "GroupLasso",
     "OverlapGroupLasso",

@@ -19,7 +19,15 @@ from sklearn.utils.validation import check_scalar
 from .._utils.validation import check_group_weights, check_groups, dense_group_index
 from ._base import ProxRegressor
 
-__all__ = ["Lasso", "GroupLasso", "OverlapGroupLasso", "SparseGroupLasso", "RidgedGroupLasso"]
+__all__ = ["OrdinaryLeastSquares", "Lasso", "GroupLasso", "OverlapGroupLasso", "SparseGroupLasso", "RidgedGroupLasso"]
+
+
+class OrdinaryLeastSquares(ProxRegressor):
+    r"""Ordinary least squares ``1/(2n)||X b - y||^2`` (reference model/_ols.py:16-65): the penalty-free
+    member of the family, solved by the same engine."""
+
+    def _penalty(self, X):
+        return None, None, None, None, X.shape[1]
 
 
 class Lasso(ProxRegressor):

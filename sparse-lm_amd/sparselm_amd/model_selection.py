@@ -28,11 +28,13 @@ import numbers
 import re
 import time
 from collections import defaultdict
+from copy import deepcopy
 
 import numpy as np
 from sklearn.base import clone, is_classifier
 from sklearn.model_selection import GridSearchCV as _GridSearchCV
 from sklearn.model_selection import ParameterGrid, check_cv
+from sklearn.model_selection._search import BaseSearchCV
 from sklearn.utils.validation import check_is_fitted, indexable
 
 from . import _engine
@@ -40,7 +42,7 @@ from . import distributed as D
 from .model._adaptive_lasso import AdaptiveLasso
 from .model._base import ProxRegressor
 
-__all__ = ["GridSearchCV"]
+__all__ = ["GridSearchCV", "LineSearchCV"]
 
 _FAST_SCORINGS = ("neg_root_mean_squared_error", "neg_mean_squared_error", "r2")
 
@@ -257,6 +259,109 @@ class GridSearchCV(_GridSearchCV):
     def predict(self, X):
         check_is_fitted(self, "best_estimator_")
         return self.best_estimator_.predict(X)
+
+
+class LineSearchCV(BaseSearchCV):
+    """Cyclic one-dimensional grid searches (reference model_selection.py:427-707).
+
+    ``param_grid`` is a list of ``(name, values)`` pairs; iteration i searches parameter
+    ``i % n_params`` over its values with every other parameter fixed at its current best (initially
+    the first value of its list); ``n_iter`` defaults to ``2 * n_params`` (:650-654).  Every line is a
+    ``GridSearchCV`` of this module, so alpha lines of the Lasso family run on the device-resident
+    fast path.  After ``fit`` the fitted attributes of the last line search are exposed (:695-703) and
+    ``history_`` holds all of them.
+    """
+
+    def __init__(
+        self,
+        estimator,
+        param_grid,
+        *,
+        opt_selection_method="max_score",
+        n_iter=None,
+        scoring="neg_root_mean_squared_error",
+        n_jobs=None,
+        refit=True,
+        cv=None,
+        verbose=0,
+        pre_dispatch="2*n_jobs",
+        error_score=np.nan,
+        return_train_score=False,
+    ):
+        super().__init__(
+            estimator=estimator,
+            scoring=scoring,
+            n_jobs=n_jobs,
+            refit=refit,
+            cv=cv,
+            verbose=verbose,
+            pre_dispatch=pre_dispatch,
+            error_score=error_score,
+            return_train_score=return_train_score,
+        )
+        self.param_grid = param_grid
+        self.opt_selection_method = opt_selection_method
+        self.n_iter = n_iter
+
+    def fit(self, X, y=None, *, groups=None, **fit_params):
+        if not (
+            isinstance(self.param_grid, (list, tuple))
+            and len(self.param_grid) > 0
+            and isinstance(self.param_grid[0], (tuple, list))
+            and isinstance(self.param_grid[0][0], str)
+        ):
+            raise ValueError("Parameter grid is not given in the correct format!")
+        n_params = len(self.param_grid)
+        if self.opt_selection_method is None:
+            methods = ["max_score"] * n_params
+        elif isinstance(self.opt_selection_method, str):
+            methods = [self.opt_selection_method] * n_params
+        elif (
+            isinstance(self.opt_selection_method, (list, tuple))
+            and all(isinstance(m, str) for m in self.opt_selection_method)
+            and len(self.opt_selection_method) == n_params
+        ):
+            methods = list(self.opt_selection_method)
+        else:
+            raise ValueError(
+                "Optimal hyperparams selection methods should be given as a"
+                " single string, or as a list of strings with the same"
+                " amount of parameters!"
+            )
+        n_iter = self.n_iter if (self.n_iter is not None and self.n_iter > 0) else 2 * n_params
+        history = []
+        best = None
+        for i in range(n_iter):
+            pid = i % n_params
+            last = [values[0] if best is None else best[name] for name, values in self.param_grid]
+            line = {
+                name: (list(values) if k == pid else [lv])
+                for k, ((name, values), lv) in enumerate(zip(self.param_grid, last))
+            }
+            search = GridSearchCV(
+                estimator=self.estimator,
+                param_grid=line,
+                opt_selection_method=methods[pid],
+                scoring=self.scoring,
+                n_jobs=self.n_jobs,
+                refit=self.refit,
+                cv=self.cv,
+                verbose=self.verbose,
+                pre_dispatch=self.pre_dispatch,
+                error_score=self.error_score,
+                return_train_score=self.return_train_score,
+            )
+            search.fit(X, y, groups=groups, **fit_params)
+            best = deepcopy(search.best_params_)
+            history.append(search)
+        self.history_ = history
+        for attr in (v for v in vars(history[-1]) if v.endswith("_") and not v.startswith("__")):
+            setattr(self, attr, getattr(history[-1], attr))
+        return self
+
+    def _run_search(self, evaluate_candidates):
+        """Unused: every line is its own GridSearchCV."""
+        return
 
 
 def _solver_options(est) -> dict:

@@ -159,3 +159,56 @@ def test_fast_path_two_ranks_share_the_grid(golden, tmp_path):
                            cv=KFold(5, shuffle=True, random_state=0)).fit(X, y)
     np.testing.assert_allclose(r0["mean"], one.cv_results_["mean_test_score"], rtol=1e-9)
     np.testing.assert_allclose(r0["coef"], one.best_estimator_.coef_, rtol=0, atol=1e-9 * np.max(np.abs(one.best_estimator_.coef_)))
+
+
+def test_line_search_with_sklearn_estimator():
+    # /root/reference/tests/test_model_selection.py:170-187 pattern, with an estimator that needs no GPU
+    from sklearn.linear_model import ElasticNet
+
+    from sparselm_amd.model_selection import LineSearchCV
+
+    X, y = make_regression(n_samples=120, n_features=30, n_informative=6, noise=5.0, random_state=2)
+    grid = [("alpha", [0.01, 0.1, 1.0, 10.0]), ("l1_ratio", [0.2, 0.5, 0.9])]
+    ls = LineSearchCV(ElasticNet(max_iter=10000), grid, opt_selection_method=["one_std_score", "max_score"], cv=4, n_iter=3)
+    ls.fit(X, y)
+    assert len(ls.history_) == 3
+    assert set(ls.best_params_) == {"alpha", "l1_ratio"}
+    assert ls.best_params_["alpha"] in grid[0][1] and ls.best_params_["l1_ratio"] in grid[1][1]
+    assert ls.predict(X).shape == y.shape
+    assert ls.best_score_ <= 0
+    with pytest.raises(ValueError):
+        LineSearchCV(ElasticNet(), {"alpha": [1.0]}).fit(X, y)
+    with pytest.raises(ValueError):
+        LineSearchCV(ElasticNet(), grid, opt_selection_method=["max_score"]).fit(X, y)
+
+
+def test_make_group_regression_shapes():
+    # /root/reference/tests/test_dataset.py:13-61
+    from sparselm_amd.dataset import make_group_regression
+
+    X, y, groups, coef = make_group_regression(n_samples=50, n_groups=6, n_features_per_group=[2, 3, 4, 2, 5, 1],
+                                               n_informative_groups=2, frac_informative_in_group=0.5, noise=1.0,
+                                               coef=True, random_state=0)
+    assert X.shape == (50, 17) and y.shape == (50,) and groups.shape == (17,) and coef.shape == (17,)
+    assert len(np.unique(groups)) == 6
+    assert len(np.unique(groups[coef != 0])) == 2
+    X2, y2, g2 = make_group_regression(random_state=0)
+    assert X2.shape == (100, 200) and len(np.unique(g2)) == 20
+
+
+@pytest.mark.gpu
+def test_line_search_fast_path_and_ols(golden):
+    from sparselm_amd.model import OrdinaryLeastSquares
+    from sparselm_amd.model_selection import LineSearchCV
+
+    X, y, groups = golden["grp_X"], golden["grp_y"], golden["grp_groups"]
+    grid = [("alpha", list(np.geomspace(10, 0.1, 5))), ("l1_ratio", [0.1, 0.5, 0.9])]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ls = LineSearchCV(SparseGroupLasso(groups=groups), grid, cv=3).fit(X, y)
+    assert all(hasattr(h, "search_time_") for h in ls.history_)  # every line ran on the device path
+    assert ls.best_params_["alpha"] in grid[0][1]
+    Xo, yo, sw = golden["ols_X"], golden["ols_y"], golden["ols_sw"]
+    ols = OrdinaryLeastSquares(fit_intercept=True, solver_options={"tol": 1e-12, "max_iter": 200000}).fit(Xo, yo, sample_weight=sw)
+    np.testing.assert_allclose(ols.coef_, golden["ols_coef_icpt"], rtol=1e-7)  # reference tests/test_ols.py:35-66
+    np.testing.assert_allclose(ols.intercept_, golden["ols_icpt"], rtol=1e-7)
