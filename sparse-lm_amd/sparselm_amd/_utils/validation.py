@@ -1,43 +1,50 @@
-"""Input contract of ``groups=`` / ``group_weights=``.
+"""Input contract of ``groups=`` / ``group_weights=`` for the group estimators.
 
-Same checks, in the same order, raising the same exception classes as the reference
-(src/sparselm/_utils/validation.py:9-35 and :38-59; pinned by tests/test_lasso.py:203-260).
+What must hold, and which exception class reports a violation, is pinned by the reference's tests
+(/root/reference/tests/test_lasso.py:203-260; implementation src/sparselm/_utils/validation.py):
+a non-sequence is a ``TypeError``; a wrong shape or length is a ``ValueError``; ``None`` is accepted
+everywhere (each feature its own group, unit weights).
 """
 
 from __future__ import annotations
 
 import numpy as np
 
+_SEQUENCE_TYPES = (list, np.ndarray)
+
+
+def _require_sequence(value, what: str) -> np.ndarray:
+    if not isinstance(value, _SEQUENCE_TYPES):
+        raise TypeError(f"{what} must be a list or ndarray")
+    return np.asarray(value)
+
 
 def check_groups(groups, n_features: int) -> None:
-    """``groups`` must be a list/ndarray (TypeError), 1-D and of length n_features (ValueError)."""
+    """One integer-like label per feature, as a flat list/array."""
     if groups is None:
         return
-    if not isinstance(groups, (list, np.ndarray)):
-        raise TypeError("groups must be a list or ndarray")
-    arr = np.asarray(groups).astype(int)
-    if arr.ndim != 1:
+    labels = _require_sequence(groups, "groups").astype(int)
+    if labels.ndim != 1:
         raise ValueError("groups must be a 1D array")
-    if len(arr) != n_features:
+    if labels.shape[0] != n_features:
         raise ValueError(f"groups must be the same length as the number of features {n_features}")
 
 
 def check_group_weights(group_weights, n_groups: int) -> None:
-    """``group_weights`` must be a list/ndarray (TypeError) with one entry per group (ValueError)."""
+    """One weight per group (in sorted-label order)."""
     if group_weights is None:
         return
-    if not isinstance(group_weights, (list, np.ndarray)):
-        raise TypeError("group_weights must be a list or ndarray")
-    arr = np.asarray(group_weights)
-    if len(arr) != n_groups:
+    weights = _require_sequence(group_weights, "group_weights")
+    if len(weights) != n_groups:
         raise ValueError(
-            f"group_weights must be the same length as the number of groups {len(arr)} != {n_groups}"
+            f"group_weights must be the same length as the number of groups {len(weights)} != {n_groups}"
         )
 
 
 def dense_group_index(groups, n_features: int):
-    """Dense index 0..G-1 per feature in sorted-unique label order (model/_lasso.py:248)."""
+    """(index per feature in 0..G-1, G): the i-th sorted unique label is group i, the pairing the
+    reference uses for ``group_weights`` / ``delta`` (src/sparselm/model/_lasso.py:248)."""
     if groups is None:
         return None, n_features
-    uniq, inv = np.unique(np.asarray(groups), return_inverse=True)
-    return inv.astype(np.int32).reshape(-1), len(uniq)
+    uniq, inverse = np.unique(np.asarray(groups), return_inverse=True)
+    return inverse.astype(np.int32).reshape(-1), len(uniq)

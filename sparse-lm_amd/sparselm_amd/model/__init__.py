@@ -1,35 +1,13 @@
-"""Estimators with the reference's public names (src/sparselm/model/__init__.py:1-43), Lasso family only.
+"""Lasso-family estimators under the reference's public names.
 
-The mixed-integer estimators (BestSubsetSelection, RegularizedL0, L1L0, L2L0, ...) need a
-branch-and-bound MIQP solver and are out of scope for a proximal-gradient engine.
+The reference exports 16 estimators from ``sparselm.model``; the ten below (plus OLS) are the ones a
+proximal-gradient engine can serve.  The mixed-integer ones (BestSubsetSelection, RegularizedL0,
+L1L0, L2L0, ...) need a branch-and-bound MIQP solver and are out of scope.
 """
 
-from ._adaptive_lasso import (
-    AdaptiveGroupLasso,
-    AdaptiveLasso,
-    AdaptiveOverlapGroupLasso,
-    AdaptiveRidgedGroupLasso,
-    AdaptiveSparseGroupLasso,
-)
-from ._lasso import (
-    GroupLasso,
-    Lasso,
-    OrdinaryLeastSquares,
-    OverlapGroupLasso,
-    RidgedGroupLasso,
-    SparseGroupLasso,
-)
+from . import _adaptive_lasso as _adaptive
+from . import _lasso as _plain
 
-__all__ = [
-    "OrdinaryLeastSquares",
-    "Lasso",
-    "GroupLasso",
-    "OverlapGroupLasso",
-    "SparseGroupLasso",
-    "RidgedGroupLasso",
-    "AdaptiveLasso",
-    "AdaptiveGroupLasso",
-    "AdaptiveOverlapGroupLasso",
-    "AdaptiveSparseGroupLasso",
-    "AdaptiveRidgedGroupLasso",
-]
+__all__ = list(_plain.__all__) + list(_adaptive.__all__)
+globals().update({name: getattr(_plain, name) for name in _plain.__all__})
+globals().update({name: getattr(_adaptive, name) for name in _adaptive.__all__})
