@@ -1167,6 +1167,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         for (int i = 0; i < chunk && rc == SLM_OK; ++i) {
           rc = enqueue_gradient(ds, ls, ds->y, done_flag, nullptr, nullptr);
           launch_tail(ta, s);
+          if (shared_path) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
         }
         hipError_t e1 = hipMemcpyAsync(&ds->hctl[k].g, ds->gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, s);
         hipError_t e2 = hipStreamEndCapture(s, &graph);
@@ -1213,6 +1214,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         }
         SLM_TRY(enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1));
         launch_tail(ta, s);
+        if (shared_path) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
         ++enq;
       }
       SLM_TRY(check_launch());

@@ -51,6 +51,8 @@ struct PathCtl {
   double hist[5];      // last accepted objective values (non-monotone reference)
   int32_t pt_lo;       // first point of the range being walked (secant starts need two solved points in it)
   int32_t steals;      // ranges this lane took over from busier lanes
+  int32_t idle;        // shared-path mode: finished its range, waiting for steal_kernel to hand out work
+  int32_t pad_;
 };
 
 constexpr int BB_HIST = 5;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   __shared__ double us_lds[US_IN_LDS ? E * TAIL_THREADS : 1];
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
-  if (ctl->done != 0 || a.gdone[0] != 0) return;
+  if (ctl->done != 0 || ctl->idle != 0 || a.gdone[0] != 0) return;
   const int tid = threadIdx.x;
   const int p = a.p, G = a.G;
   {  // rebase every per-lane pointer
@@ -493,42 +495,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   double extrap = 0.0;
   if (finalize && !cold && !nonfinite && point - pt_lo >= 1 && point + 1 < n_points)
     extrap = a.pts[point + 1].extrap;
-  // End of this lane's range: in shared-path mode try to take over work from the busiest lane.
-  // A thief only takes points >= victim.point + 2 (the victim may advance by one point during this
-  // very launch) and claims them with a compare-and-swap on the victim's range end, so two thieves
-  // can never own the same points; the victim sees its shorter range at its next launch.
-  __shared__ int steal_lo, steal_hi;
+  // End of this lane's range: in shared-path mode the lane goes idle and steal_kernel (launched
+  // right after this kernel, when every lane's state is at rest) hands it new work or retires it.
   const bool range_end = finalize && !nonfinite && (point + 1 >= n_points);
-  if (range_end && a.steal) {
-    if (tid == 0) {
-      steal_lo = -1;
-      steal_hi = -1;
-      for (int attempt = 0; attempt < a.n_lanes && steal_lo < 0; ++attempt) {
-        int best = -1, best_rem = 1, best_end = 0;
-        for (int v = 0; v < a.n_lanes; ++v) {
-          if (v == lane_id) continue;
-          PathCtl* cv = a.ctl + v;
-          const int dv = __hip_atomic_load(&cv->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int pv = __hip_atomic_load(&cv->point, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int ev = __hip_atomic_load(&cv->n_points, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const int rem = ev - (pv + 2);  // points that can be taken safely
-          if (!dv && rem > best_rem) {
-            best = v;
-            best_rem = rem;
-            best_end = ev;
-          }
-        }
-        if (best < 0) break;
-        const int mid = best_end - best_rem / 2;  // upper half of the stealable points
-        if (atomicCAS(&a.ctl[best].n_points, best_end, mid) == best_end) {
-          steal_lo = mid;
-          steal_hi = best_end;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  const bool stolen = range_end && a.steal && steal_lo >= 0;
+  const bool goes_idle = range_end && a.steal;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int j = tid + e * TAIL_THREADS;
@@ -536,7 +506,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       if (finalize) {
         const double out = u[e];
         a.betas_out[(int64_t)point * p + j] = out;
-        double nxt = (cold || stolen) ? 0.0 : out;  // a stolen range starts cold
+        double nxt = (cold || goes_idle) ? 0.0 : out;  // a taken-over range starts cold
         if (extrap != 0.0) nxt = out + extrap * (out - a.betas_out[(int64_t)(point - 1) * p + j]);
         a.beta[j] = nxt;
         a.z[j] = nxt;
@@ -591,11 +561,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
         ctl->nonfinite = 1;
         ctl->done = 1;
         a.gdone[0] = 1;  // abort every lane
-      } else if (stolen) {
-        ctl->point = steal_lo;
-        ctl->pt_lo = steal_lo;
-        ctl->n_points = steal_hi;
-        ctl->steals += 1;
+      } else if (goes_idle) {
+        ctl->idle = 1;
       } else if (range_end) {
         ctl->done = 1;
         if (atomicAdd(&a.gdone[1], 1) + 1 == a.n_lanes) a.gdone[0] = 1;
@@ -610,6 +577,53 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       for (int k = 0; k < BB_HIST; ++k) ctl->hist[k] = hist[k];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shared-path work distribution.  Runs as ONE small workgroup after the tail kernel, when no lane is
+// touching its control block, so the hand-out is sequential and reproducible: idle lanes are served
+// in index order; each takes the upper half of the points the busiest lane has not started
+// (keeping at least one for the victim) and starts cold; with nothing left to take it retires.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void steal_kernel(TailArgs a) {
+  if (a.gdone[0] != 0) return;
+  __shared__ int took[SLM_MAX_LANES];
+  if (threadIdx.x == 0) {
+    for (int l = 0; l < a.n_lanes; ++l) {
+      took[l] = 0;
+      PathCtl* me = a.ctl + l;
+      if (!me->idle || me->done) continue;
+      int best = -1, best_rem = 0;
+      for (int v = 0; v < a.n_lanes; ++v) {
+        const PathCtl* cv = a.ctl + v;
+        if (v == l || cv->done || cv->idle) continue;
+        const int rem = cv->n_points - (cv->point + 1);  // points the victim has not started
+        if (rem > best_rem) {
+          best = v;
+          best_rem = rem;
+        }
+      }
+      if (best >= 0 && best_rem >= 1) {
+        PathCtl* cv = a.ctl + best;
+        const int hi = cv->n_points;
+        const int mid = hi - (best_rem + 1) / 2;
+        cv->n_points = mid;
+        me->point = mid;
+        me->pt_lo = mid;
+        me->n_points = hi;
+        me->steals += 1;
+        me->idle = 0;
+        took[l] = 1;
+      } else {
+        me->idle = 0;
+        me->done = 1;
+        if (atomicAdd(&a.gdone[1], 1) + 1 == a.n_lanes) a.gdone[0] = 1;
+      }
+    }
+  }
+  __syncthreads();
+  // (the tail kernel already zeroed beta and z of a lane that went idle: cold start is in place)
+  (void)took;
 }
 
 // ---------------------------------------------------------------------------------------------
