@@ -3,7 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "tail_kernels.hpp"  // mix64
+#include "grad_kernel.hpp"   // d2
+#include "tail_kernels.hpp"  // mix64, block_sum
 
 namespace slm {
 
@@ -41,6 +42,43 @@ __global__ __launch_bounds__(256) void fill_kernel(double* dst, int64_t count, d
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;
        e += (int64_t)gridDim.x * blockDim.x)
     dst[e] = value;
+}
+
+// sums[0] = sum_i w_i, sums[1] = sum_i w_i y_i   (one workgroup; w == nullptr => ones)
+__global__ __launch_bounds__(1024) void weighted_sums_kernel(const double* __restrict__ y,
+                                                             const double* __restrict__ w, int64_t n,
+                                                             double* __restrict__ sums) {
+  __shared__ double red[2][TAIL_WAVES];
+  double s[2] = {0.0, 0.0};
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double wi = w ? w[i] : 1.0;
+    s[0] += wi;
+    s[1] = __builtin_fma(wi, y[i], s[1]);
+  }
+  block_sum<2>(s, red);
+  if (threadIdx.x == 0) {
+    sums[0] = s[0];
+    sums[1] = s[1];
+  }
+}
+
+// X[i][j] -= xmean[j] (j < p only: pad columns stay zero), y[i] -= ymean
+__global__ __launch_bounds__(256) void center_kernel(double* __restrict__ X, double* __restrict__ y, int64_t n,
+                                                     int64_t p, int64_t ld, const double* __restrict__ xmean,
+                                                     double ymean) {
+  const int64_t chunks = ld / 2;
+  const int64_t total = n * chunks;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / chunks, c = e - i * chunks;
+    d2* px = reinterpret_cast<d2*>(X + i * ld) + c;
+    d2 v = *px;
+    const int64_t j = 2 * c;
+    if (j < p) v.x -= xmean[j];
+    if (j + 1 < p) v.y -= xmean[j + 1];
+    *px = v;
+    if (c == 0) y[i] -= ymean;
+  }
 }
 
 // Two independent N(0,1) draws from a 64-bit counter (Box-Muller on two 53-bit uniforms).

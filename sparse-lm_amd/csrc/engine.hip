@@ -610,6 +610,8 @@ extern "C" int slm_dataset_download(slm_dataset* ds, double* X_out, double* y_ou
   return SLM_OK;
 }
 
+extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y_mean_out);
+
 extern "C" int slm_dataset_set_row_weights(slm_dataset* ds, const double* row_weight) {
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
   HIP_TRY(hipSetDevice(ds->eng->device));
@@ -824,6 +826,41 @@ extern "C" int slm_dataset_lipschitz(slm_dataset* ds, double* L_out) {
   if (!ds || !L_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
   HIP_TRY(hipSetDevice(ds->eng->device));
   return estimate_lipschitz(ds, L_out, kPowerItersQuery);
+}
+
+// ------------------------------------------------------------------------------------------------
+// in-place centring by the row-weighted means
+// ------------------------------------------------------------------------------------------------
+extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y_mean_out) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  if (ds->eng->comm) return fail(SLM_ERR_UNSUPPORTED, "centring a row-sharded dataset is not implemented");
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  hipStream_t s = ds->eng->stream;
+  const int64_t n = ds->n, p = ds->p, ld = ds->ld;
+  // sum w, sum w y
+  hipLaunchKernelGGL(weighted_sums_kernel, dim3(1), dim3(1024), 0, s, ds->y, ds->rw, n, ds->lambda);
+  double sums[2] = {0.0, 0.0};
+  HIP_TRY(hipMemcpyAsync(sums, ds->lambda, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (!(sums[0] > 0.0)) return fail(SLM_ERR_BAD_ARG, "row weights sum to zero");
+  const double ymean = sums[1] / sums[0];
+  // x_mean = X^T w / sum w: the gradient kernel with z = 0 and y = -1 (borrowing yzero)
+  const int blocks = (int)std::min<int64_t>(4096, (n + 255) / 256);
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, ds->yzero, n, -1.0);
+  HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * ld, s));
+  LaneSetup ls = default_lanes(ds, 1);
+  ls.n_eff[0] = sums[0];
+  SLM_TRY(enqueue_gradient(ds, ls, ds->yzero, nullptr, nullptr, nullptr));
+  HIP_TRY(hipMemsetAsync(ds->yzero, 0, sizeof(double) * n, s));
+  // subtract (g holds x_mean; pad entries are exactly zero)
+  const int cblocks = ds->eng->cus * 8;
+  hipLaunchKernelGGL(center_kernel, dim3(cblocks), dim3(256), 0, s, ds->X, ds->y, n, p, ld, ds->g, ymean);
+  SLM_TRY(check_launch());
+  if (x_mean_out) HIP_TRY(hipMemcpyAsync(x_mean_out, ds->g, sizeof(double) * p, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (y_mean_out) *y_mean_out = ymean;
+  ds->L_valid = false;
+  return SLM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

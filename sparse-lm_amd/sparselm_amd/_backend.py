@@ -22,13 +22,15 @@ _KNOWN_OPTIONS = {"tol", "max_iter", "L", "restart", "check_every", "device"}
 class SolveProblem:
     """Device-resident problem: upload once, solve many penalties (adaptive loops, paths)."""
 
-    def __init__(self, backend, X, y, gidx, n_groups, options):
+    def __init__(self, backend, X, y, gidx, n_groups, options, row_weight=None, center=False):
         self.backend = backend
         self.options = options
         self.p = X.shape[1]
         self.n_groups = n_groups
         eng = _engine.get_engine(options.get("device"))
-        self.ds = eng.dataset(X, y)
+        self.ds = eng.dataset(X, y, row_weight=row_weight)
+        # fit_intercept: centre the device copy in place (no centred host copy of X is ever made)
+        self.x_mean, self.y_mean = self.ds.center() if center else (None, None)
         if gidx is not None:
             self.ds.set_groups(gidx, n_groups)
 
@@ -74,9 +76,12 @@ class SolveProblem:
 
 class HipBackend:
     name = "hip"
+    # sample weights and centring are applied on the device (row weights in the fused kernel,
+    # slm_dataset_center): the estimator hands over the raw validated arrays
+    native_preprocessing = True
 
-    def problem(self, X, y, gidx, n_groups, options) -> SolveProblem:
-        return SolveProblem(self, X, y, gidx, n_groups, options)
+    def problem(self, X, y, gidx, n_groups, options, row_weight=None, center=False) -> SolveProblem:
+        return SolveProblem(self, X, y, gidx, n_groups, options, row_weight=row_weight, center=center)
 
 
 _backend = HipBackend()

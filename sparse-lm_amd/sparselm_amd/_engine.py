@@ -54,6 +54,7 @@ ABI_SYMBOLS = (
     "slm_dataset_destroy",
     "slm_dataset_shape",
     "slm_dataset_download",
+    "slm_dataset_center",
     "slm_dataset_set_row_weights",
     "slm_dataset_set_groups",
     "slm_dataset_lipschitz",
@@ -175,6 +176,7 @@ def load_library():
             "slm_dataset_destroy": [vp],
             "slm_dataset_shape": [vp, P(i64), P(i64), P(i64)],
             "slm_dataset_download": [vp, vp, vp],
+            "slm_dataset_center": [vp, vp, P(dbl)],
             "slm_dataset_set_row_weights": [vp, vp],
             "slm_dataset_set_groups": [vp, vp, i32],
             "slm_dataset_lipschitz": [vp, P(dbl)],
@@ -418,6 +420,13 @@ class Dataset:
         y = np.empty(self.n) if want_y else None
         _check(self._lib.slm_dataset_download(self._h, _ptr(X), _ptr(y)))
         return X, y
+
+    def center(self):
+        """Centre the device copy of (X, y) in place by the row-weighted means; returns (x_mean, y_mean)."""
+        xm = np.empty(self.p)
+        ym = C.c_double()
+        _check(self._lib.slm_dataset_center(self._h, _ptr(xm), C.byref(ym)))
+        return xm, ym.value
 
     def set_row_weights(self, row_weight):
         rw = None if row_weight is None else _f64(row_weight, "row_weight", (self.n,))

@@ -133,7 +133,7 @@ class AdaptiveLasso(Lasso):
         # standardize=True: the loop runs in the per-group QR coordinates, where the engine's group norms
         # are ||X_g b_g|| -- what the reference feeds to the weight update (_adaptive_lasso.py:364-374)
         Xu, back = self._design_transform(X)
-        problem = get_backend().problem(Xu, y, gidx, G, solver_options)
+        problem = self._open_problem(Xu, y, gidx, G, solver_options)
         beta = None
         warm = self._warm_beta(p) if (hasattr(self, "coef_") and back is None) else None
         infos = []

@@ -62,7 +62,21 @@ class ProxRegressor(RegressorMixin, BaseEstimator):
     def fit(self, X, y, sample_weight=None, *args, **kwargs):
         """Fit the coefficients (reference flow: _base.py:142-205)."""
         X, y = validate_data(self, X, y, accept_sparse=False, y_numeric=True, multi_output=False)
-        X, y, X_offset, y_offset = self._preprocess_data(X, y, sample_weight)
+        # Preprocessing (reference _base.py:207-227).  With the HIP backend the same arithmetic runs
+        # on the device: normalised sample weights become row weights of the fused kernel, centring is
+        # done in place on the engine's copy -- the host never builds a second X.
+        self._native = None
+        if getattr(get_backend(), "native_preprocessing", False) and not self._needs_host_preprocessing():
+            X = np.asarray(X, dtype=np.float64)
+            y = np.asarray(y, dtype=np.float64)
+            w = None
+            if sample_weight is not None:
+                w = _check_sample_weight(sample_weight, X, dtype=X.dtype)
+                w = w * (X.shape[0] / np.sum(w))
+            self._native = {"row_weight": w, "center": bool(self.fit_intercept)}
+            X_offset, y_offset = np.zeros(X.shape[1]), 0.0
+        else:
+            X, y, X_offset, y_offset = self._preprocess_data(X, y, sample_weight)
         self._validate_params(X, y)
 
         solver_options = self.solver_options if self.solver_options is not None else {}
@@ -74,7 +88,13 @@ class ProxRegressor(RegressorMixin, BaseEstimator):
                 "FISTA engine and ignores it.",
                 UserWarning,
             )
-        self.coef_ = self._solve(X, y, normalise_options(solver_options), *args, **kwargs)
+        try:
+            self.coef_ = self._solve(X, y, normalise_options(solver_options), *args, **kwargs)
+            if self._native is not None and self._native.get("offsets") is not None:
+                X_offset, y_offset = self._native["offsets"]
+        finally:
+            native, self._native = self._native, None
+        del native
         self._set_intercept(X_offset, y_offset)
         return self
 
@@ -127,6 +147,23 @@ class ProxRegressor(RegressorMixin, BaseEstimator):
         """Return (a, b, d, gidx, n_groups); a: (p,) or None (=0), b/d: (G,) or None (=0)."""
         raise NotImplementedError
 
+    def _needs_host_preprocessing(self) -> bool:
+        """True when ``_solve`` manipulates the preprocessed design on the host (column duplication,
+        per-group QR) and therefore needs the centred / re-weighted X itself."""
+        return False
+
+    def _open_problem(self, X, y, gidx, G, solver_options):
+        """Upload (X, y) to the backend; in native mode with device-side weights and centring."""
+        native = getattr(self, "_native", None)
+        if native is None:
+            return get_backend().problem(X, y, gidx, G, solver_options)
+        problem = get_backend().problem(
+            X, y, gidx, G, solver_options, row_weight=native["row_weight"], center=native["center"]
+        )
+        if native["center"]:
+            native["offsets"] = (problem.x_mean, problem.y_mean)
+        return problem
+
     def _design_transform(self, X):
         """Hook: return (X_used, back) where ``back`` maps the solution on X_used to coefficients of X
         (None = identity).  Used by ``standardize=True``."""
@@ -143,7 +180,7 @@ class ProxRegressor(RegressorMixin, BaseEstimator):
         a, b, d, gidx, G = self._penalty(X)
         p = X.shape[1]
         Xu, back = self._design_transform(X)
-        problem = get_backend().problem(Xu, y, gidx, G, solver_options)
+        problem = self._open_problem(Xu, y, gidx, G, solver_options)
         try:
             beta, _, info = problem.solve(
                 np.zeros(p) if a is None else a,

@@ -121,6 +121,9 @@ class GroupLasso(Lasso):
     # problem inside the prox family for pure group penalties
     _supports_standardize = True
 
+    def _needs_host_preprocessing(self) -> bool:
+        return bool(self.standardize)  # the per-group QR works on the centred design
+
     def _design_transform(self, X):
         if not self.standardize:
             return X, None
@@ -221,6 +224,9 @@ class OverlapGroupLasso(GroupLasso):
         # `groups` is fixed to None by the constructor and is not a hyper-parameter of this class
         return sorted(n for n in super()._get_param_names() if n != "groups")
 
+    def _needs_host_preprocessing(self) -> bool:
+        return True  # the duplicated-column design is assembled on the host
+
     def _n_groups(self, n_features):
         if self.group_list is None:
             return n_features
@@ -253,7 +259,7 @@ class OverlapGroupLasso(GroupLasso):
         X_ext, back = np.ascontiguousarray(X[:, bidx]), None
         if self.standardize:
             X_ext, back = standardize_groups(X_ext, ext, G)
-        problem = get_backend().problem(X_ext, y, ext, G, solver_options)
+        problem = self._open_problem(X_ext, y, ext, G, solver_options)
         try:
             beta_ext, _, info = problem.solve(np.zeros(len(bidx)), self.alpha * w, np.zeros(G))
         finally:

@@ -120,6 +120,27 @@ def test_gradient_fortran_order_and_row_weights(eng):
         assert rel_inf(g, ref_grad(X, y, z)[0]) < 1e-12
 
 
+def test_in_place_centering_matches_numpy(eng):
+    rng = np.random.default_rng(12)
+    n, p = 700, 131
+    X = rng.standard_normal((n, p)) + rng.uniform(-3, 3, p)
+    y = rng.standard_normal(n) + 5.0
+    w = rng.uniform(0.0, 2.0, n)
+    w[::9] = 0.0
+    for weights in (None, w):
+        with eng.dataset(X, y, row_weight=weights) as ds:
+            xm, ym = ds.center()
+            npt.assert_allclose(xm, np.average(X, axis=0, weights=weights), rtol=1e-13)
+            npt.assert_allclose(ym, np.average(y, weights=weights), rtol=1e-13)
+            Xc, yc = ds.download()
+            npt.assert_allclose(Xc, X - xm, rtol=0, atol=1e-14)
+            npt.assert_allclose(yc, y - ym, rtol=0, atol=1e-14)
+            z = rng.standard_normal(p)
+            g, loss = ds.gradient(z)
+            g0, loss0 = ref_grad(X - xm, y - ym, z, weights)
+            assert rel_inf(g, g0) < 1e-12  # pad columns stayed zero, row weights still apply
+
+
 def test_gradient_linearity_at_scale(eng):
     # size-independent property at a size the oracle would not finish quickly:
     # grad(z1 + z2) + grad(0) == grad(z1) + grad(z2)   (affine map), and a checksum against the loss
