@@ -370,3 +370,35 @@ def test_sklearn_compatible(backend, estimator_cls):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         check_estimator(estimator_cls(fit_intercept=True))
+
+
+def test_stepwise_estimator(backend, golden):
+    # behaviours of /root/reference/tests/test_stepwise.py on the re-implemented composite
+    from sklearn.base import clone
+    from sklearn.utils._param_validation import InvalidParameterError
+
+    from sparselm_amd.stepwise import StepwiseEstimator
+
+    X, y = golden["l1_X"], golden["l1_y"]
+    p = X.shape[1]
+    scopes = (tuple(range(0, 10)), tuple(range(10, p)))
+    step = StepwiseEstimator(
+        [("head", Lasso(alpha=0.5, fit_intercept=True, solver_options=TIGHT)), ("tail", Lasso(alpha=2.0, solver_options=TIGHT))],
+        scopes,
+    ).fit(X, y)
+    first = Lasso(alpha=0.5, fit_intercept=True, solver_options=TIGHT).fit(X[:, :10], y)
+    resid = y - first.predict(X[:, :10])
+    second = Lasso(alpha=2.0, solver_options=TIGHT).fit(X[:, 10:], resid)
+    npt.assert_allclose(step.coef_[:10], first.coef_, rtol=0, atol=1e-9)
+    npt.assert_allclose(step.coef_[10:], second.coef_, rtol=0, atol=1e-9)
+    npt.assert_allclose(step.intercept_, first.intercept_, rtol=1e-9)
+    npt.assert_allclose(step.predict(X), first.predict(X[:, :10]) + second.predict(X[:, 10:]), rtol=1e-9, atol=1e-9)
+    # parameters are routed through the step names and survive clone()
+    c = clone(step).set_params(tail__alpha=7.0)
+    assert c.get_params()["tail__alpha"] == 7.0 and step.get_params()["tail__alpha"] == 2.0
+    with pytest.raises(InvalidParameterError):  # blocks must partition range(p)
+        StepwiseEstimator(step.steps, ((0, 1), (1, 2))).fit(X[:, :3], y)
+    with pytest.raises(InvalidParameterError):  # only the first step may fit an intercept
+        StepwiseEstimator([("a", Lasso()), ("b", Lasso(fit_intercept=True))], scopes).fit(X, y)
+    with pytest.raises(InvalidParameterError):  # no nesting
+        StepwiseEstimator([("a", Lasso()), ("b", step)], scopes).fit(X, y)
