@@ -174,7 +174,7 @@ def main():
     if rank == 0:
         assert res is not None and res.converged, "path did not converge"
         # algorithmic bytes of one launch: X once, y once, per lane z read and g written
-        lanes_used = max(1, min(args.lanes, 4))
+        lanes_used = max(1, min(args.lanes, 4))  # p = 5000: the kernel table stops at four lanes
         bytes_per_grad = 8.0 * (n * p + 2 * n + 2 * p * lanes_used)
         t_grad_ms = grad_ms / max(1, grad_timed)
         achieved = bytes_per_grad / (t_grad_ms * 1e-3) / 1e9 if t_grad_ms > 0 else 0.0

@@ -118,6 +118,10 @@ static const GradKernel kGradRing[] = {
     SLM_RK(8, 1, 2, 3), SLM_RK(8, 2, 2, 3), SLM_RK(8, 3, 2, 3), SLM_RK(8, 4, 2, 3), SLM_RK(8, 5, 2, 2),
     SLM_RK(8, 1, 3, 3), SLM_RK(8, 2, 3, 3), SLM_RK(8, 3, 3, 3), SLM_RK(8, 4, 3, 3), SLM_RK(8, 5, 3, 2),
     SLM_RK(8, 1, 4, 3), SLM_RK(8, 2, 4, 3), SLM_RK(8, 3, 4, 3), SLM_RK(8, 4, 4, 3), SLM_RK(8, 5, 4, 2),
+    // five and six lanes only where the 8C VGPRs per lane leave the kernel spill-free: a variant with
+    // 12 spilled registers in the row loop (B = 5 at C = 5) measured 1.62 ms against 0.59 ms
+    SLM_RK(8, 1, 5, 3), SLM_RK(8, 2, 5, 3), SLM_RK(8, 3, 5, 3), SLM_RK(8, 4, 5, 3),
+    SLM_RK(8, 1, 6, 3), SLM_RK(8, 2, 6, 3), SLM_RK(8, 3, 6, 3),
 };
 // Default choice per (lanes B, capacity 64*W*C chunks of 16 bytes); every list is ordered by
 // capacity.  R (rows held per step) is the largest that keeps the kernel free of (large) spills at
@@ -212,8 +216,8 @@ struct slm_dataset {
   int G = 0, singleton = 1, team = 1;
   int *order = nullptr, *gid = nullptr, *gstart = nullptr;
   // gradient launch, per lane count B = 1..kMaxLanes (index B-1); gk == nullptr => unsupported
-  const GradKernel* gk[SLM_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
-  int nblk[SLM_MAX_LANES] = {0, 0, 0, 0};
+  const GradKernel* gk[SLM_MAX_LANES] = {};
+  int nblk[SLM_MAX_LANES] = {};
   double *partial = nullptr, *loss_partial = nullptr;
   // iteration state: kMaxLanes copies, lane stride ld (g: ld + 16)
   double *g = nullptr, *z = nullptr, *beta = nullptr, *zprev = nullptr, *gprev = nullptr;
@@ -672,7 +676,7 @@ struct LaneSetup {
   int B = 1;
   const double* rw = nullptr;  // device row weights handed to the kernel
   int64_t rw_stride = 0;
-  double n_eff[SLM_MAX_LANES] = {0, 0, 0, 0};
+  double n_eff[SLM_MAX_LANES] = {};
 };
 
 static LaneSetup default_lanes(slm_dataset* ds, int B) {
@@ -796,7 +800,7 @@ static int power_iteration(slm_dataset* ds, const LaneSetup& ls, double* L_out /
     hipLaunchKernelGGL(power_step_kernel, dim3(ls.B), dim3(TAIL_THREADS), 0, s, pa);
   }
   SLM_TRY(check_launch());
-  double lam[SLM_MAX_LANES] = {0, 0, 0, 0};
+  double lam[SLM_MAX_LANES] = {};
   HIP_TRY(hipMemcpyAsync(lam, ds->lambda, sizeof(double) * ls.B, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (int l = 0; l < ls.B; ++l) {

@@ -546,8 +546,8 @@ struct ReduceArgs {
   int nblk;
   int n_lanes;
   int64_t ld;
-  double scale[4];       // 1/n_eff per lane
-  double loss_scale[4];  // 1/(2 n_eff) per lane
+  double scale[8];       // 1/n_eff per lane
+  double loss_scale[8];  // 1/(2 n_eff) per lane
 };
 
 // grid = (ld/16 + 1, n_lanes)

@@ -133,7 +133,7 @@ class _Lane(C.Structure):
     ]
 
 
-MAX_LANES = 4
+MAX_LANES = 6
 
 _lib = None
 _lib_lock = threading.Lock()
