@@ -21,7 +21,7 @@ def build(force: bool = False) -> str:
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= os.path.getmtime(src):
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", src, "-o", OUT, "-lm"]
+    cmd = ["gcc", "-O3", "-march=x86-64-v3", "-fopenmp", "-shared", "-fPIC", src, "-o", OUT, "-lm"]
     subprocess.run(cmd, check=True)
     return OUT
 

@@ -9,7 +9,7 @@
  *   sum_j a_j|b_j| + sum_g b_g||b_g||_2 + 1/2 sum_g d_g||b_g||_2^2
  * (model/_lasso.py:99-107, 267-275, 627-639, 795-811).
  *
- * Build: gcc -O3 -march=native -fopenmp -shared -fPIC fista_ref.c -o _build/libfista_ref.so -lm
+ * Build: gcc -O3 -march=x86-64-v3 -fopenmp -shared -fPIC fista_ref.c -o _build/libfista_ref.so -lm
  */
 #include <math.h>
 #include <stdint.h>
