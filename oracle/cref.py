@@ -22,6 +22,10 @@ def _load():
         lib.oracle_gradient.restype = dbl
         lib.oracle_fista.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, i32, dbl, dbl, i64, C.c_int, vp]
         lib.oracle_fista.restype = i64
+        lib.oracle_numa_copy.argtypes = [vp, i64, i64]
+        lib.oracle_numa_copy.restype = vp
+        lib.oracle_free.argtypes = [vp]
+        lib.oracle_free.restype = None
         _lib = lib
     return _lib
 
@@ -64,6 +68,29 @@ def fista(X, y, a, b, d, gidx, n_groups, beta0=None, L=None, tol=1e-13, max_iter
         1 if restart else 0, _p(beta),
     )
     return beta, int(it)
+
+
+class NumaMatrix:
+    """Row-major copy of X whose pages were first touched in parallel (see oracle_numa_copy); use as
+    ``with NumaMatrix(X) as Xn:`` and pass ``Xn`` wherever these wrappers take ``X``."""
+
+    def __init__(self, X):
+        lib = _load()
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self.shape = X.shape
+        self._ptr = lib.oracle_numa_copy(_p(X), X.shape[0], X.shape[1])
+        if not self._ptr:
+            raise MemoryError("oracle_numa_copy failed")
+        buf = (C.c_double * (X.shape[0] * X.shape[1])).from_address(self._ptr)
+        self.array = np.frombuffer(buf, dtype=np.float64).reshape(X.shape)
+
+    def __enter__(self):
+        return self.array
+
+    def __exit__(self, *exc):
+        self.array = None
+        _load().oracle_free(self._ptr)
+        self._ptr = None
 
 
 def num_threads() -> int:

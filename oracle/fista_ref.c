@@ -62,6 +62,20 @@ double oracle_gradient(const double* X, int64_t n, int64_t p, int64_t ld, const 
   return 0.5 * loss * inv_n;
 }
 
+/* NUMA-friendly copy of a row-major matrix: pages are first touched by the thread that will stream
+ * them in oracle_gradient (same static row schedule), so a multi-socket host reads X from all of its
+ * memory controllers instead of the one node a single-threaded allocation landed on.  Free with
+ * oracle_free. */
+double* oracle_numa_copy(const double* src, int64_t n, int64_t p) {
+  double* dst = (double*)malloc(sizeof(double) * (size_t)n * (size_t)p);
+  if (!dst) return 0;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i) memcpy(dst + i * p, src + i * p, sizeof(double) * (size_t)p);
+  return dst;
+}
+
+void oracle_free(double* ptr) { free(ptr); }
+
 static double soft(double v, double thr) {
   const double m = fabs(v) - thr;
   return m <= 0.0 ? 0.0 : copysign(m, v);
