@@ -14,6 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -299,9 +300,12 @@ class Engine:
         _check(self._lib.slm_engine_create(int(device_id), C.byref(h)))
         self._h = h
         self.device_id = int(device_id)
+        self._datasets = weakref.WeakSet()  # closed before the engine goes (their handles point at it)
 
     def close(self):
         if getattr(self, "_h", None):
+            for ds in list(getattr(self, "_datasets", ())):
+                ds.close()
             self._lib.slm_engine_destroy(self._h)
             self._h = None
 
@@ -391,6 +395,7 @@ class Dataset:
         self._h = handle
         self.n, self.p = int(n), int(p)
         self.n_groups = self.p
+        engine._datasets.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
