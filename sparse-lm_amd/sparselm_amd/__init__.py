@@ -8,4 +8,4 @@ cvxpy).  There is no CPU fallback.
 
 __version__ = "0.1.0"
 
-from . import model  # noqa: F401,E402
+from . import model, tools  # noqa: F401,E402
