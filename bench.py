@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--alphas", type=int, default=50)
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--lanes", type=int, default=4, help="ranges of the path advancing together on one pass over X")
+    ap.add_argument("--no-ws", action="store_true", help="disable the working-set refinement (A/B runs)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     args = ap.parse_args()
 
@@ -153,6 +154,8 @@ def main():
     alphas = np.geomspace(amax, 1e-3 * amax, K)
     points = [(a, 0.0, 0.0) for a in alphas]
     flags = _engine.FLAG_PROFILE | _engine.FLAG_FRESH_L
+    if args.no_ws:
+        flags |= _engine.FLAG_NO_WORKING_SET
 
     for _ in range(args.warmup):
         ds.solve_path(points, tol=args.tol, flags=flags, lanes=args.lanes)
@@ -207,6 +210,7 @@ def main():
                 "parallelism": f"grid x{world} (independent paths, no collective)",
                 "grad_evals_per_path": grad_launches / args.steps,
                 "lipschitz_ms_per_path": res.lipschitz_ms,
+                "working_set": {"builds": res.ws_builds, "appends": res.ws_appends, "refined": res.ws_refined, "misses": res.ws_misses},
             },
             "roofline": {
                 "bound": "hbm",

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 1
+#define SLM_ABI_VERSION 2
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -157,6 +157,10 @@ typedef struct slm_path_point {
 #define SLM_FLAG_COLD_START 4u   /* do not warm-start point k+1 from point k             */
 #define SLM_FLAG_FRESH_L 8u      /* re-estimate the Lipschitz constant even if cached     */
 #define SLM_FLAG_FISTA_ONLY 16u  /* never use spectral steps (plain FISTA with restart)  */
+#define SLM_FLAG_WORKING_SET 32u     /* Gram-assisted working-set refinement between passes even for
+                                        small X (default: only when one pass over X costs more than
+                                        the refinement, n*ld >= 2^26)                              */
+#define SLM_FLAG_NO_WORKING_SET 64u  /* never refine: every iterate comes from a pass over X        */
 
 typedef struct slm_solve_opts {
   double tol;          /* stop when ||beta+ - z||_2 <= tol * ||beta+||_2; <= 0 => 1e-8   */
@@ -183,6 +187,10 @@ typedef struct slm_solve_stats {
   double grad_ms_total;   /* sum of the device durations of the timed ones               */
   double wall_ms;         /* host wall clock of the call                                 */
   double lipschitz_ms;    /* part of wall_ms spent estimating L (0 if cached / given)    */
+  int64_t ws_builds;      /* working sets selected and their Grams built from scratch       */
+  int64_t ws_appends;     /* times columns were appended to the working set instead        */
+  int64_t ws_refined;     /* iterates moved by the working-set refinement, all lanes       */
+  int64_t ws_misses;      /* times an iterate left the working set (forces a rebuild)      */
 } slm_solve_stats;
 
 /*

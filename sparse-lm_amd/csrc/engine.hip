@@ -23,6 +23,7 @@
 #include "data_kernels.hpp"
 #include "grad_kernel.hpp"
 #include "tail_kernels.hpp"
+#include "ws_kernels.hpp"
 
 using namespace slm;
 
@@ -213,8 +214,13 @@ struct slm_dataset {
   double* rw_lanes = nullptr;  // [kMaxLanes][n], allocated when a lane brings its own row weights
   double* rvec = nullptr;      // [n] residuals of the two-pass fallback
   // group structure (group-sorted permutation)
-  int G = 0, singleton = 1, team = 1;
+  int G = 0, singleton = 1, team = 1, max_group = 1;
   int *order = nullptr, *gid = nullptr, *gstart = nullptr;
+  // working-set refinement (ws_kernels.hpp), allocated on first use
+  WsCtl* ws_ctl = nullptr;
+  int32_t *ws_idx = nullptr, *ws_pos = nullptr, *ws_gs = nullptr, *ws_gl = nullptr;
+  double *ws_score = nullptr, *ws_XW = nullptr, *ws_part = nullptr, *ws_G = nullptr;
+  int ws_sets = 0;  // Gram copies allocated
   // gradient launch, per lane count B = 1..kMaxLanes (index B-1); gk == nullptr => unsupported
   const GradKernel* gk[SLM_MAX_LANES] = {};
   int nblk[SLM_MAX_LANES] = {};
@@ -354,6 +360,8 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->u); dfree(ds->gscale); dfree(ds->a0); dfree(ds->b0); dfree(ds->d0);
   dfree(ds->lambda); dfree(ds->ctl); dfree(ds->gctl);
   dfree(ds->pts); dfree(ds->betas_out); dfree(ds->gn_out); dfree(ds->infos);
+  dfree(ds->ws_ctl); dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
+  dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   for (auto& e : ds->ev)
     if (e) (void)hipEventDestroy(e);
@@ -377,6 +385,7 @@ static int set_singleton_groups(slm_dataset* ds) {
   ds->G = p;
   ds->singleton = 1;
   ds->team = 1;
+  ds->max_group = 1;
   return SLM_OK;
 }
 
@@ -666,6 +675,7 @@ extern "C" int slm_dataset_set_groups(slm_dataset* ds, const int32_t* gid, int32
   ds->G = n_groups;
   ds->singleton = 0;
   ds->team = team;
+  ds->max_group = max_size;
   return SLM_OK;
 }
 
@@ -1171,6 +1181,76 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   ta.gn_out = any_gn ? ds->gn_out : nullptr;
   ta.infos = ds->infos;
 
+  // ---- working-set refinement (ws_kernels.hpp) -----------------------------------------------------
+  // Worth it when a pass over X costs more than the one-workgroup model solve that replaces several
+  // of them; row-sharded datasets would need the Gram all-reduced (not built).
+  bool use_ws = false;
+  WsArgs wa;
+  memset(&wa, 0, sizeof(wa));
+  {
+    const char* env = getenv("SLM_WS");
+    const bool big = (double)n * (double)ld >= 67108864.0;  // 2^26 doubles = 512 MiB
+    use_ws = big || (o.flags & SLM_FLAG_WORKING_SET);
+    if (env && env[0] == '1') use_ws = true;
+    if ((env && env[0] == '0') || (o.flags & SLM_FLAG_NO_WORKING_SET)) use_ws = false;
+    if (eng->comm || ds->max_group > 64 || n < 4) use_ws = false;
+  }
+  if (use_ws) {
+    const int n_sets = (any_rw || custom_scale) ? B : 1;
+    const int ws_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n / 64));
+    if (!ds->ws_ctl) {
+      SLM_TRY(dalloc(&ds->ws_ctl, 1));
+      SLM_TRY(dalloc(&ds->ws_idx, WS_KCAP));
+      SLM_TRY(dalloc(&ds->ws_gs, WS_KCAP));
+      SLM_TRY(dalloc(&ds->ws_gl, WS_KCAP));
+      SLM_TRY(dalloc(&ds->ws_pos, (size_t)ld));
+      SLM_TRY(dalloc(&ds->ws_score, (size_t)ld));
+      SLM_TRY(dalloc(&ds->ws_XW, (size_t)n * WS_KCAP));
+    }
+    if (ds->ws_sets < n_sets) {
+      dfree(ds->ws_part); dfree(ds->ws_G);
+      ds->ws_sets = 0;
+      SLM_TRY(dalloc(&ds->ws_part, (size_t)eng->cus * n_sets * WS_KCAP * WS_KCAP));
+      SLM_TRY(dalloc(&ds->ws_G, (size_t)n_sets * WS_KCAP * WS_KCAP));
+      ds->ws_sets = n_sets;
+    }
+    WsCtl wc;
+    memset(&wc, 0, sizeof(wc));
+    wc.request = 1;
+    for (int l = 0; l < kMaxLanes; ++l) wc.last_point[l] = -1;
+    wc.max_builds = 24;
+    HIP_TRY(hipMemcpyAsync(ds->ws_ctl, &wc, sizeof(wc), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    wa.ws = ds->ws_ctl;
+    wa.idx = ds->ws_idx; wa.pos = ds->ws_pos; wa.gs = ds->ws_gs; wa.gl = ds->ws_gl;
+    wa.score = ds->ws_score; wa.XW = ds->ws_XW; wa.part = ds->ws_part; wa.Gm = ds->ws_G;
+    wa.X = ds->X; wa.n = n; wa.ld = ld;
+    wa.rw = ls.rw; wa.rw_stride = ls.rw_stride;
+    for (int l = 0; l < kMaxLanes; ++l)
+      wa.inv_n[l] = 1.0 / (ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global);
+    wa.n_sets = n_sets;
+    wa.nblk = ws_nblk;
+    wa.theta = 0.7;
+    if (const char* th = getenv("SLM_WS_THETA")) {
+      const double v = atof(th);
+      if (v > 0.0 && v <= 1.0) wa.theta = v;
+    }
+  }
+  // everything that follows the gradient of one pass
+  auto enqueue_after_gradient = [&]() {
+    launch_tail(ta, s);
+    if (shared_path) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
+    if (use_ws) {
+      hipLaunchKernelGGL(ws_select_kernel, dim3(1), dim3(WS_THREADS), 0, s, ta, wa);
+      hipLaunchKernelGGL(ws_gather_kernel, dim3((unsigned)(eng->cus * 8)), dim3(256), 0, s, wa);
+      hipLaunchKernelGGL(ws_gram_kernel, dim3((unsigned)wa.nblk, (unsigned)wa.n_sets, 2), dim3(WS_GRAM_THREADS), 0, s,
+                         wa);
+      hipLaunchKernelGGL(ws_gram_reduce_kernel, dim3(WS_KCAP * WS_KCAP / 256, (unsigned)wa.n_sets), dim3(256),
+                         0, s, wa);
+      hipLaunchKernelGGL(ws_solve_kernel, dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
+    }
+  };
+
   // ---- queue iterations; the device decides when each point / lane / the solve is finished ------
   int chunk = o.check_every;
   if (chunk <= 0) {
@@ -1207,8 +1287,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         int rc = SLM_OK;
         for (int i = 0; i < chunk && rc == SLM_OK; ++i) {
           rc = enqueue_gradient(ds, ls, ds->y, done_flag, nullptr, nullptr);
-          launch_tail(ta, s);
-          if (shared_path) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
+          enqueue_after_gradient();
         }
         hipError_t e1 = hipMemcpyAsync(&ds->hctl[k].g, ds->gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, s);
         hipError_t e2 = hipStreamEndCapture(s, &graph);
@@ -1254,8 +1333,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
           e1 = ds->prof[2 * slot_id + 1];
         }
         SLM_TRY(enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1));
-        launch_tail(ta, s);
-        if (shared_path) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
+        enqueue_after_gradient();
         ++enq;
       }
       SLM_TRY(check_launch());
@@ -1313,6 +1391,15 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       stats->grad_timed = cnt;
     }
     stats->lipschitz_ms = lipschitz_ms;
+    stats->ws_builds = stats->ws_appends = stats->ws_refined = stats->ws_misses = 0;
+    if (use_ws) {
+      WsCtl wc;
+      HIP_TRY(hipMemcpy(&wc, ds->ws_ctl, sizeof(wc), hipMemcpyDeviceToHost));
+      stats->ws_builds = wc.builds;
+      stats->ws_appends = wc.appends;
+      stats->ws_refined = wc.refined;
+      stats->ws_misses = wc.misses;
+    }
     stats->wall_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }

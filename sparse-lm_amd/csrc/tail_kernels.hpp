@@ -234,6 +234,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   const bool group_pen = (pt.sb != 0.0) || (pt.sd != 0.0);
   const bool cold = (flags & SLM_FLAG_COLD_START) != 0;
   const bool hit_max = (iter + 1 >= max_iter);
+  // ||beta|| in the stopping rule never drops below 1e-10 of the scale the data give a coefficient
+  // vector (rms residual / sqrt(L)): at alpha ~ alpha_max the minimiser is a rounding-level number
+  // (~1e-16) and "tol relative to it" would ask for more digits than fp64 has.
+  const double bnorm_floor = 1e-10 * sqrt(2.0 * fmax(loss_z, 0.0) / fmax(L, Lhat_old));
 
   // prox_{step * penalty} of the per-thread vector v[] (in place), optionally accumulating the
   // penalty value of the result into pen (thread-partial; the caller block-sums it).
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       new_pen_z = q[2];
       resid = sqrt(q[0]) * fmax(1.0, new_ak / new_Lhat);
       bnorm = sqrt(q[1]);
-      conv = resid <= tol * bnorm;
+      conv = resid <= tol * fmax(bnorm, bnorm_floor);
       finalize = nonfinite || conv || hit_max;
     }
   } else {
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     const double mom = (t_use - 1.0) / t_new;
     resid = sqrt(s[0]);
     bnorm = sqrt(s[1]);
-    conv = !l_bad && (resid <= tol * bnorm);
+    conv = !l_bad && (resid <= tol * fmax(bnorm, bnorm_floor));
     finalize = nonfinite || conv || hit_max;
     new_t = l_bad ? 1.0 : t_new;
 #pragma unroll

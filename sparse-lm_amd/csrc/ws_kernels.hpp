@@ -1,0 +1,707 @@
+// Working-set refinement: Gram-assisted prediction of the next iterate between two passes over X.
+//
+// f(b) = 1/(2n) ||X b - y||^2_W is quadratic, so once the gradient g0 = grad f(z0) at ONE point is
+// known (the fused pass just delivered it), the gradient at any b that differs from z0 only on a
+// small column set W is exact without touching X again:
+//
+//     grad f(b)_W = g0_W + G_WW (b - z0)_W,        G_WW = X_W^T diag(w) X_W / n     (K x K, K <= 256)
+//
+// The kernels below (i) pick W on the device (every coefficient that is non-zero in any lane plus the
+// features / groups whose gradient is within a factor theta of entering at the loosest penalty of
+// the lane's range), (ii) gather the K columns into a compact n x K matrix, (iii) build G_WW with
+// f64 MFMA (the one GEMM-shaped piece of this path: 2 n K^2 flop), and (iv) after every pass let one
+// workgroup per lane minimise the penalised quadratic model over W (FISTA on K unknowns, the matrix
+// stays in L2) and move the lane's next evaluation point there.  The next pass over X then VERIFIES
+// that point with the true gradient under the unchanged stopping rule of fista_tail_kernel, so the
+// meaning of `tol` and every reported solution are exactly those of the plain iteration; a point of
+// a path costs one pass instead of three to seven.  Coordinates outside W are never touched: if a
+// lane's iterate moves there (a feature outside W wants to enter) the refinement is skipped for
+// that lane and W is rebuilt.
+//
+// Counterpart in the reference: none (cvxpy hands the whole problem to an interior-point solver,
+// src/sparselm/model/_base.py:512-519); the idea is the covariance-update / working-set strategy
+// of coordinate-descent Lasso solvers, restated for the proximal-gradient state machine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tail_kernels.hpp"
+
+namespace slm {
+
+constexpr int WS_KCAP = 256;        // capacity of the working set (leading dimension of G and XW)
+constexpr int WS_KINIT = 128;       // size a selection is cut down to when more than WS_KCAP qualify
+constexpr int WS_KLDS = 128;        // up to this many columns the Gram lives in LDS during the model solve
+constexpr int WS_THREADS = 1024;
+constexpr int WS_INNER_MAX = 400;   // inner iterations per refinement
+constexpr double WS_INNER_TOL = 0.05;  // inner stop: residual <= WS_INNER_TOL * tol * ||b||
+constexpr int WS_LOOKAHEAD = 4;     // path points ahead whose penalty decides what enters W now
+constexpr int WS_MAX_REPEATS = 6;   // refinements of one path point before the lane iterates plainly
+
+struct WsCtl {
+  int32_t request;    // (re)build W at the next opportunity
+  int32_t building;   // select changed W in this pass: gather / gram / reduce must run
+  int32_t valid;      // G matches idx
+  int32_t K;          // columns in use, padded to a multiple of 16 (padding entries have idx = -1)
+  int32_t Kreal;      // columns in use without the padding
+  int32_t k_new;      // first position whose column / Gram rows this build has to produce (0 = all)
+  int32_t builds;     // full selections built
+  int32_t appends;    // builds that only appended columns to the existing W
+  int32_t max_builds;
+  int32_t disabled;   // the non-zero coefficients alone kept exceeding WS_KCAP
+  int32_t misses;     // times a lane's plain step left W
+  int32_t refined;    // refinements applied (all lanes)
+  int32_t counter;    // last-workgroup detection of the reduce kernel
+  int32_t stale;      // a lane left W and the build budget is spent: such lanes iterate plainly
+  int32_t overflows;  // builds skipped because the non-zero coefficients alone exceed WS_KCAP
+  int32_t pad_;
+  int32_t last_point[SLM_MAX_LANES];  // path point of each lane's last refinement ...
+  int32_t repeats[SLM_MAX_LANES];     // ... and how many times in a row it was that point
+  double Lw[SLM_MAX_LANES];  // lambda_max estimate per Gram (0 = not yet computed)
+};
+
+struct WsArgs {
+  WsCtl* ws;
+  int32_t* idx;    // [WS_KCAP] feature of working-set position k, or -1
+  int32_t* pos;    // [ld] position of feature j in W, or -1
+  int32_t* gs;     // [WS_KCAP] first position of k's group
+  int32_t* gl;     // [WS_KCAP] members of k's group
+  double* score;   // [ld] scratch: entry score per item
+  double* XW;      // [n][WS_KCAP] gathered columns
+  double* part;    // [nblk][n_sets][WS_KCAP * WS_KCAP] partial Grams
+  double* Gm;      // [n_sets][WS_KCAP * WS_KCAP]
+  const double* X;
+  int64_t n, ld;
+  const double* rw;   // row weights per set, or nullptr (all ones)
+  int64_t rw_stride;
+  double inv_n[SLM_MAX_LANES];
+  int32_t n_sets;     // 1 (every lane shares the row weights) or n_lanes
+  int32_t nblk;
+  double theta;
+};
+
+// exclusive prefix sum of one int per thread over the 1024-thread workgroup
+__device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[16]*/, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < TAIL_WAVES; ++w) {
+    const int t = wave_tot[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// (i) choose W.  One workgroup.  Runs after tail/steal in every pass; returns at once unless a build
+// was requested or a lane's plain step left the current W.  With a valid W the newcomers are
+// APPENDED (their columns and Gram rows are all that has to be produced); a fresh selection is made
+// at the start of a solve and when the appended set would exceed WS_KCAP.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArgs w) {
+  __shared__ double red[2][TAIL_WAVES];
+  __shared__ int wave_tot[TAIL_WAVES];
+  WsCtl* ws = w.ws;
+  if (a.gdone[0] != 0 || ws->disabled) return;
+  const int tid = threadIdx.x;
+  const int p = a.p, G = a.G;
+  const bool singleton = a.singleton != 0;
+  const int nitems = singleton ? p : G;
+  const bool had_w = ws->valid != 0;
+
+  // ---- did the plain step of any live lane move a coordinate outside the current W? --------------
+  // (z = candidate / extrapolated point just produced by the tail kernel, zprev = the point it was
+  // produced from: they differ outside W exactly when a feature outside W wants to enter)
+  const bool requested = ws->request != 0;
+  if (!requested && !had_w) return;
+  bool miss = false;
+  if (!requested) {
+    double out[1] = {0.0};
+    for (int l = 0; l < a.n_lanes; ++l) {
+      const PathCtl* c = a.ctl + l;
+      if (c->done || c->idle) continue;
+      const double* z = a.z + (int64_t)l * a.ld;
+      const double* zp = a.zprev + (int64_t)l * a.ld;
+      for (int j = tid; j < p; j += WS_THREADS)
+        if (w.pos[j] < 0 && z[j] != zp[j]) out[0] += 1.0;
+    }
+    block_sum<1>(out, red);
+    miss = out[0] != 0.0;
+    if (miss && tid == 0) ws->misses += 1;
+  }
+  if (ws->builds >= ws->max_builds || ws->appends >= 8 * ws->max_builds) {
+    // budget spent: keep the W we have for lanes that stay inside it, the others iterate plainly
+    if (tid == 0) {
+      ws->request = 0;
+      if (miss) ws->stale = 1;
+    }
+    return;
+  }
+
+  // ---- entry score per item (max over lanes); +inf marks items that are non-zero at a lane's
+  //      expansion point, -1 items that are already in W -----------------------------------------
+  const double inf = __builtin_huge_val();
+  int path_end = 0;  // shared-path mode: ranges move between lanes, the end of the path does not
+  for (int l = 0; l < a.n_lanes; ++l) path_end = max(path_end, a.ctl[l].n_points);
+  for (int it = tid; it < nitems; it += WS_THREADS) {
+    double sc = 0.0;
+    for (int l = 0; l < a.n_lanes; ++l) {
+      const PathCtl* c = a.ctl + l;
+      if (c->done || c->idle) continue;
+      const int64_t off = (int64_t)l * a.ld;
+      const double* g = a.g + (int64_t)l * (a.ld + 16);
+      // the penalty this lane will have reached WS_LOOKAHEAD points from now (ranges may move between
+      // lanes in shared-path mode, so the look-ahead runs to the end of the path there): features that
+      // would enter by then are taken now; later ones are appended when their time comes
+      const int end = a.steal ? path_end : c->pt_off + c->n_points;
+      const int look = min(c->pt_off + c->point + WS_LOOKAHEAD, end - 1);
+      const slm_path_point pe = a.pts[look < 0 ? 0 : look];
+      if (singleton) {
+        const int j = it;
+        if (a.zprev[off + j] != 0.0) {
+          sc = inf;
+        } else {
+          const double thr = pe.sa * a.a0[off + j] + pe.sb * a.b0[off + j];
+          const double r = thr > 0.0 ? fabs(g[j]) / thr : inf;
+          sc = fmax(sc, r);
+        }
+      } else {
+        const int k0 = a.gstart[it], k1 = a.gstart[it + 1];
+        double num = 0.0, rmax = 0.0;
+        bool act = false;
+        for (int k = k0; k < k1; ++k) {
+          const int j = a.order[k];
+          act = act || a.zprev[off + j] != 0.0;
+          const double thr = pe.sa * a.a0[off + j];
+          const double m = fmax(fabs(g[j]) - thr, 0.0);
+          num = __builtin_fma(m, m, num);
+          rmax = fmax(rmax, thr > 0.0 ? fabs(g[j]) / thr : inf);
+        }
+        const double den = pe.sb * a.b0[off + it];
+        const double r = den > 0.0 ? sqrt(num) / den : rmax;
+        sc = act ? inf : fmax(sc, r);
+      }
+    }
+    w.score[it] = sc;
+  }
+  __syncthreads();
+
+  // feature count of the items with score >= thr (optionally only those not yet in W), and the
+  // largest finite score
+  auto count_at = [&](double thr, bool only_new, double* n_sel, double* smax) {
+    double v[2] = {0.0, 0.0};
+    for (int it = tid; it < nitems; it += WS_THREADS) {
+      const double sc = w.score[it];
+      const int first = singleton ? it : a.order[a.gstart[it]];
+      const int size = singleton ? 1 : a.gstart[it + 1] - a.gstart[it];
+      if (sc >= thr && !(only_new && w.pos[first] >= 0)) v[0] += (double)size;
+      if (sc < inf) v[1] = fmax(v[1], sc);
+    }
+    double s[1] = {v[0]};
+    block_sum<1>(s, red);
+    *n_sel = s[0];
+    double m = v[1];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[1][tid >> 6] = m;
+    __syncthreads();
+    double mm = 0.0;
+#pragma unroll
+    for (int k = 0; k < TAIL_WAVES; ++k) mm = fmax(mm, red[1][k]);
+    *smax = mm;
+  };
+
+  double n_sel, smax, thr = w.theta;
+  const int k_old = had_w ? ws->Kreal : 0;
+  bool append = had_w;
+  if (append) {
+    count_at(thr, true, &n_sel, &smax);
+    if (n_sel == 0.0) {  // no newcomer (the usual case); a lane that left W anyway cannot be helped
+      if (miss && tid == 0) ws->stale = 1;
+      return;
+    }
+    if ((double)k_old + n_sel > (double)WS_KCAP) append = false;  // does not fit: select afresh
+  }
+  if (!append) {
+    count_at(inf, false, &n_sel, &smax);
+    if (n_sel > (double)WS_KCAP) {
+      // the non-zero coefficients of the expansion points alone do not fit (dense early iterates of
+      // a cold start, or a dense solution): try again after the next pass, give up after 50 tries
+      if (tid == 0) {
+        ws->request = 1;
+        ws->valid = 0;
+        ws->overflows += 1;
+        if (ws->overflows >= 50) ws->disabled = 1;
+      }
+      return;
+    }
+    count_at(thr, false, &n_sel, &smax);
+    if (n_sel > (double)WS_KCAP) {
+      double lo = thr, hi = fmax(smax, thr) * (1.0 + 1e-12) + 1e-300;  // count(hi) = non-zeros only
+      for (int k = 0; k < 24; ++k) {
+        const double mid = 0.5 * (lo + hi);
+        count_at(mid, false, &n_sel, &smax);
+        if (n_sel > (double)WS_KINIT) lo = mid; else hi = mid;
+      }
+      thr = hi;
+    }
+    for (int j = tid; j < p; j += WS_THREADS) w.pos[j] = -1;
+  }
+  for (int k = k_old * (append ? 1 : 0) + tid; k < WS_KCAP; k += WS_THREADS) {
+    w.idx[k] = -1;
+    w.gs[k] = k;
+    w.gl[k] = 1;
+  }
+  __syncthreads();
+
+  // ---- positions: items in index order, members of a group contiguous -----------------------------
+  const int per = (nitems + WS_THREADS - 1) / WS_THREADS;
+  const int i0 = tid * per, i1 = min(i0 + per, nitems);
+  auto chosen = [&](int it) {
+    if (!(w.score[it] >= thr)) return false;
+    return !(append && w.pos[singleton ? it : a.order[a.gstart[it]]] >= 0);
+  };
+  int mine = 0;
+  for (int it = i0; it < i1; ++it)
+    if (chosen(it)) mine += singleton ? 1 : a.gstart[it + 1] - a.gstart[it];
+  int total = 0;
+  int at = (append ? k_old : 0) + block_excl_scan(mine, wave_tot, &total);
+  // (chosen() reads pos[], the loop below writes it: decide first, then write)
+  unsigned long long pick = 0ull;
+  for (int it = i0; it < i1 && it - i0 < 64; ++it)
+    if (chosen(it)) pick |= 1ull << (it - i0);
+  __syncthreads();
+  for (int it = i0; it < i1 && it - i0 < 64; ++it) {
+    if (!((pick >> (it - i0)) & 1ull)) continue;
+    if (singleton) {
+      w.idx[at] = it;
+      w.pos[it] = at;
+      at += 1;
+    } else {
+      const int k0 = a.gstart[it], len = a.gstart[it + 1] - k0;
+      for (int m = 0; m < len; ++m) {
+        const int j = a.order[k0 + m];
+        w.idx[at + m] = j;
+        w.pos[j] = at + m;
+        w.gs[at + m] = at;
+        w.gl[at + m] = len;
+      }
+      at += len;
+    }
+  }
+  if (tid == 0) {
+    const int Kreal = (append ? k_old : 0) + total;
+    ws->Kreal = Kreal;
+    ws->K = max(16, (Kreal + 15) & ~15);
+    ws->k_new = append ? k_old : 0;
+    ws->building = 1;
+    ws->valid = 0;
+    ws->stale = 0;
+    ws->counter = 0;
+    if (append) {
+      ws->appends += 1;
+    } else {
+      ws->builds += 1;
+      for (int l = 0; l < SLM_MAX_LANES; ++l) ws->Lw[l] = 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (ii) gather the new columns: XW[i][k] = X[i][idx[k]] for k >= k_new (0 for padding positions)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
+  if (!w.ws->building) return;
+  const int k0 = w.ws->k_new;
+  const int Kn = w.ws->K - k0;
+  const int64_t total = w.n * Kn;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / Kn;
+    const int k = k0 + (int)(e - i * Kn);
+    const int j = w.idx[k];
+    w.XW[i * WS_KCAP + k] = j >= 0 ? w.X[i * w.ld + j] : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (iii) partial Grams with v_mfma_f64_16x16x4_f64.  Grid (nblk, n_sets, 2); 8 wavefronts per
+// workgroup laid out 4 x 2, wavefront (wi, wj) owning the 4 x 4 block of 16x16 output tiles
+// I = 4 wi + ti, J = 8 h + 4 wj + tj (h = blockIdx.z: a workgroup covers 256 x 128; 16 accumulator
+// tiles = 128 registers per lane, which is why it is not one 1024-thread workgroup).  Only the tile
+// rows that hold new positions (I >= k_new / 16) are computed; the reduce kernel mirrors them into
+// the columns.  Operand maps (guide "Fragment layout"): lane l holds A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15]; result register r of lane l is D[row (l >> 4) + 4 r][col l & 15].  Here
+// k runs over 4 consecutive rows of XW, A[i][k] = w_k XW[row_k][16 I + i], B[k][j] = XW[row_k][16 J + j].
+// ---------------------------------------------------------------------------------------------
+typedef double ws_d4 __attribute__((ext_vector_type(4)));
+constexpr int WS_GRAM_THREADS = 512;
+
+__global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
+  if (!w.ws->building) return;
+  const int K = w.ws->K;
+  const int tile_lo = w.ws->k_new >> 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, wj = 2 * (int)blockIdx.z + (wave & 1);
+  const int tiles = K >> 4;
+  const int ti_lo = max(0, tile_lo - 4 * wi);                       // first tile row of this wave to do
+  const int nti = min(4, max(0, tiles - 4 * wi)), ntj = min(4, max(0, tiles - 4 * wj));
+  if (ti_lo >= nti || ntj == 0) return;
+  const int set = blockIdx.y;
+  const int64_t b = blockIdx.x;
+  const int64_t base = w.n / w.nblk, rem = w.n % w.nblk;
+  const int64_t r0 = b * base + (b < rem ? b : rem);
+  const int64_t nrows = base + (b < rem ? 1 : 0);
+  const double* rw = w.rw ? w.rw + (int64_t)set * w.rw_stride : nullptr;
+
+  ws_d4 acc[4][4];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = ws_d4{0.0, 0.0, 0.0, 0.0};
+
+  const int kk = lane >> 4, c = lane & 15;
+  for (int64_t s = 0; s < nrows; s += 4) {
+    const int64_t i = s + kk;
+    const bool ok = i < nrows;
+    const int64_t row = r0 + (ok ? i : 0);
+    const double wgt = ok ? (rw ? rw[row] : 1.0) : 0.0;
+    const double* xr = w.XW + row * WS_KCAP + c;
+    double av[4], bv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      av[t] = (t >= ti_lo && t < nti) ? xr[16 * (4 * wi + t)] * wgt : 0.0;
+      bv[t] = t < ntj ? xr[16 * (4 * wj + t)] : 0.0;
+    }
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      if (ti >= ti_lo && ti < nti) {
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          if (tj < ntj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
+      }
+    }
+  }
+  double* out = w.part + ((int64_t)b * w.n_sets + set) * (WS_KCAP * WS_KCAP);
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    if (ti < ti_lo || ti >= nti) continue;
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+      if (tj >= ntj) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = 16 * (4 * wi + ti) + kk + 4 * r, gj = 16 * (4 * wj + tj) + c;
+        out[gi * WS_KCAP + gj] = acc[ti][tj][r];
+      }
+    }
+  }
+}
+
+// fixed-order sum of the partial Grams, scaled by 1/n_set: the new tile rows and, mirrored, the
+// matching columns of the old part; the last workgroup publishes the Gram
+__global__ __launch_bounds__(256) void ws_gram_reduce_kernel(WsArgs w) {
+  WsCtl* ws = w.ws;
+  if (!ws->building) return;
+  const int K = ws->K;
+  const int row_lo = (ws->k_new >> 4) << 4;
+  const int set = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;  // element of the KCAP x KCAP matrix
+  const int i = e / WS_KCAP, j = e % WS_KCAP;
+  if (i >= row_lo && i < K && j < K) {
+    double s = 0.0;
+    for (int b = 0; b < w.nblk; ++b) s += w.part[((int64_t)b * w.n_sets + set) * (WS_KCAP * WS_KCAP) + e];
+    s *= w.inv_n[set];
+    double* Gs = w.Gm + (int64_t)set * (WS_KCAP * WS_KCAP);
+    Gs[e] = s;
+    if (j < row_lo) Gs[j * WS_KCAP + i] = s;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = gridDim.x * gridDim.y;
+    if (atomicAdd(&ws->counter, 1) + 1 == total) {
+      ws->counter = 0;
+      ws->request = 0;
+      ws->valid = 1;
+      __threadfence();
+      ws->building = 0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (iv) refinement: one workgroup per lane minimises the penalised quadratic model over W.
+// Thread 4k + q works on working-set position k (q = 0..3 split the matrix-vector product).  Up to
+// WS_KLDS columns the Gram is copied into LDS first, so an inner iteration never leaves the CU.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs w) {
+  __shared__ double red[8][TAIL_WAVES];
+  __shared__ double delta[WS_KCAP];
+  __shared__ double uim[WS_KCAP];
+  __shared__ int nz[WS_KCAP];
+  __shared__ int nnz_s;
+  __shared__ double Gl[WS_KLDS * WS_KLDS];
+  const int lane_id = blockIdx.x;
+  PathCtl* ctl = a.ctl + lane_id;
+  WsCtl* ws = w.ws;
+  if (ctl->done != 0 || ctl->idle != 0 || a.gdone[0] != 0) return;
+  if (!ws->valid || ws->building || ws->disabled) return;
+  const int tid = threadIdx.x;
+  const int p = a.p;
+  const int K = ws->K;
+  const int set = w.n_sets == 1 ? 0 : lane_id;
+  const double* Gm = w.Gm + (int64_t)set * (WS_KCAP * WS_KCAP);
+  {
+    const int64_t off = (int64_t)lane_id * a.ld;
+    a.beta += off; a.z += off; a.zprev += off; a.gprev += off;
+    a.a0 += off; a.b0 += off; a.d0 += off;
+    a.pts += ctl->pt_off;
+  }
+  // A lane whose plain step left W (and W could not be extended) is not refined: resetting those
+  // coordinates below would undo its progress.  Neither is a lane that keeps being sent back to the
+  // same path point (the model solve did not reach the tolerance, e.g. a near-singular Gram): it
+  // finishes the point with plain steps.
+  if (ws->stale) {
+    double out[1] = {0.0};
+    for (int j = tid; j < p; j += WS_THREADS)
+      if (w.pos[j] < 0 && a.z[j] != a.zprev[j]) out[0] += 1.0;
+    block_sum<1>(out, red);
+    if (out[0] != 0.0) return;
+  }
+  const int point_now = ctl->point + ctl->pt_off;
+  const int reps = ws->last_point[lane_id] == point_now ? ws->repeats[lane_id] : 0;
+  if (reps >= WS_MAX_REPEATS) return;
+
+  const slm_path_point pt = a.pts[ctl->point];
+  const int mode = ctl->mode;
+  const double tol = ctl->tol;
+  const bool group_pen = (pt.sb != 0.0) || (pt.sd != 0.0);
+  const bool g_lds = K <= WS_KLDS;
+  if (g_lds) {
+    for (int e = tid; e < K * K; e += WS_THREADS) {
+      const int r = e / K, c = e - r * K;
+      Gl[e] = Gm[r * WS_KCAP + c];
+    }
+  }
+
+  const int k = tid >> 2, q = tid & 3;
+  const int j = k < K ? w.idx[k] : -1;
+  const bool live = j >= 0;
+  const bool mine = live && q == 0;  // the thread that accounts for position k in reductions
+  const int jj = live ? j : 0;
+  const double z0 = live ? a.zprev[jj] : 0.0;
+  const double g0 = live ? a.gprev[jj] : 0.0;
+  const double x_start = live ? a.z[jj] : 0.0;
+  const double pa = live ? pt.sa * a.a0[jj] : 0.0;
+  const int gsk = live ? w.gs[k] : 0, glk = live ? w.gl[k] : 1;
+  const int gix = a.singleton ? jj : a.gid[jj];
+  const double pb = live ? pt.sb * a.b0[gix] : 0.0;
+  const double pd = live ? pt.sd * a.d0[gix] : 0.0;
+  __syncthreads();  // Gl complete
+
+  // G (val - z0) for the vector held as `val` at every position.  Every call is followed by a
+  // block_sum before the next one, so delta is never overwritten while it is being read.
+  auto matvec = [&](double val, bool dense) -> double {
+    if (q == 0) delta[k] = (k < K) ? val - z0 : 0.0;
+    __syncthreads();
+    double acc = 0.0;
+    if (g_lds) {
+      if (k < K) {
+#pragma unroll 4
+        for (int c = q; c < K; c += 4) acc = __builtin_fma(Gl[c * K + k], delta[c], acc);
+      }
+    } else if (dense) {
+      if (k < K) {
+#pragma unroll 4
+        for (int c = q; c < K; c += 4) acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
+      }
+    } else {
+      if (tid < 64) {  // compact list of the non-zero entries (wave 0, ballots)
+        int basep = 0;
+        for (int c0 = 0; c0 < K; c0 += 64) {
+          const int kk = c0 + tid;
+          const bool nzq = kk < K && delta[kk] != 0.0;
+          const uint64_t m = __ballot(nzq);
+          if (nzq) nz[basep + __popcll(m & ((1ull << tid) - 1ull))] = kk;
+          basep += __popcll(m);
+        }
+        if (tid == 0) nnz_s = basep;
+      }
+      __syncthreads();
+      const int nnz = nnz_s;
+      if (k < K) {
+#pragma unroll 4
+        for (int m = q; m < nnz; m += 4) {
+          const int c = nz[m];
+          acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
+        }
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    return acc;
+  };
+  // prox of the lane's penalty at the current path point, step s, on the W coordinates
+  auto prox_w = [&](double v, double s) -> double {
+    double u = live ? soft(v, s * pa) : 0.0;
+    if (group_pen) {
+      if (a.singleton) {
+        const double nrm = fabs(u);
+        const double sc = nrm > 0.0 ? fmax(0.0, 1.0 - s * pb / nrm) : 0.0;
+        u *= sc / (1.0 + s * pd);
+      } else {
+        __syncthreads();
+        if (q == 0) uim[k] = u;
+        __syncthreads();
+        double ss = 0.0;
+        for (int m = 0; m < glk; ++m) {
+          const double t = uim[gsk + m];
+          ss = __builtin_fma(t, t, ss);
+        }
+        const double nrm = sqrt(ss);
+        const double sc = (nrm > 0.0 ? fmax(0.0, 1.0 - s * pb / nrm) : 0.0) / (1.0 + s * pd);
+        u *= sc;
+      }
+    }
+    return u;
+  };
+  // penalty value of the vector held as `val` (thread-partial: counted once per position / group)
+  auto pen_part = [&](double val) -> double {
+    double pv = 0.0;
+    if (mine) {
+      pv = pa * fabs(val);
+      if (group_pen && a.singleton) pv += pb * fabs(val) + 0.5 * pd * val * val;
+    }
+    if (group_pen && !a.singleton) {
+      __syncthreads();
+      if (q == 0) uim[k] = live ? val : 0.0;
+      __syncthreads();
+      if (mine && gsk == k) {  // first member of the group
+        double ss = 0.0;
+        for (int m = 0; m < glk; ++m) ss = __builtin_fma(uim[k + m], uim[k + m], ss);
+        pv += pb * sqrt(ss) + 0.5 * pd * ss;
+      }
+    }
+    return pv;
+  };
+
+  // ---- lambda_max of this Gram (once per selection): power iteration from a fixed start ---------
+  double Lw = ws->Lw[set];
+  if (!(Lw > 0.0)) {
+    double vec = (k < K) ? 1.0 + 0.37 * (double)(((k * 2654435761u) >> 24) & 0xffu) / 255.0 : 0.0;
+    double lam = 0.0;
+    for (int itp = 0; itp < 10; ++itp) {
+      const double y = matvec(vec + z0, true);  // matvec works on (val - z0)
+      double s[1] = {q == 0 && k < K ? y * y : 0.0};
+      block_sum<1>(s, red);
+      lam = sqrt(s[0]);
+      vec = lam > 0.0 ? y / lam : 0.0;
+    }
+    Lw = lam * 1.1;  // from below; the curvature guard in the loop covers the rest
+    if (!(Lw > 0.0)) return;  // empty / zero Gram: nothing to refine
+  }
+
+  // ---- FISTA on the model ------------------------------------------------------------------------
+  double L = Lw;
+  double x = x_start, v = x_start, t = 1.0;
+  double v_prev = 0.0, gv_prev = 0.0;
+  bool have_prev = false;
+  double m_start;  // model value at the start (relative to the expansion point)
+  {
+    const double gd = matvec(x_start, false);
+    const double d = x_start - z0;
+    double s[2] = {mine ? d * (g0 + 0.5 * gd) : 0.0, 0.0};
+    s[1] = pen_part(x_start);
+    block_sum<2>(s, red);
+    m_start = s[0] + s[1];
+  }
+  bool ok = true;
+  for (int it = 0; it < WS_INNER_MAX; ++it) {
+    const double gv = g0 + matvec(v, false);
+    const double u = prox_w(v - gv / L, 1.0 / L);
+    //  s[0] = ||u - v||^2  s[1] = ||u||^2  s[2] = (v - u).(u - x)  s[3] = #non-finite
+    //  s[4] = ||v - v_prev||^2  s[5] = ||gv - gv_prev||^2   (curvature along the last move of v)
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    if (mine) {
+      const double r = u - v;
+      s[0] = r * r;
+      s[1] = u * u;
+      s[2] = -r * (u - x);
+      if (!isfinite(u)) s[3] = 1.0;
+      if (have_prev) {
+        const double dv = v - v_prev, dg = gv - gv_prev;
+        s[4] = dv * dv;
+        s[5] = dg * dg;
+      }
+    }
+    block_sum<6>(s, red);
+    if (s[3] > 0.0 || !isfinite(s[0])) {
+      ok = false;
+      break;
+    }
+    v_prev = v;
+    gv_prev = gv;
+    have_prev = true;
+    if (s[4] > 0.0 && sqrt(s[5] / s[4]) > L) {  // the step 1/L was too long: redo it from x
+      L = 1.05 * sqrt(s[5] / s[4]);
+      v = x;
+      t = 1.0;
+      continue;
+    }
+    const bool restart = s[2] > 0.0;
+    const double t_use = restart ? 1.0 : t;
+    const double t_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t_use * t_use));
+    const double mom = (t_use - 1.0) / t_new;
+    v = u + mom * (u - x);
+    x = u;
+    t = t_new;
+    if (sqrt(s[0]) <= WS_INNER_TOL * tol * sqrt(s[1])) break;
+  }
+  if (!ok) return;
+  // accept only if the model says the refined point is no worse than the start
+  {
+    const double gd = matvec(x, false);
+    const double d = x - z0;
+    double s[3] = {mine ? d * (g0 + 0.5 * gd) : 0.0, 0.0, mine && !isfinite(x) ? 1.0 : 0.0};
+    s[1] = pen_part(x);
+    block_sum<3>(s, red);
+    const double m_end = s[0] + s[1];
+    if (s[2] > 0.0 || !(m_end <= m_start)) return;
+  }
+  // the refined point: model minimiser on W, the expansion point elsewhere
+  for (int f = tid; f < p; f += WS_THREADS) {
+    if (w.pos[f] < 0) {
+      const double zo = a.zprev[f];
+      a.z[f] = zo;
+      if (mode == 0) a.beta[f] = zo;
+    }
+  }
+  if (mine) {
+    a.z[jj] = x;
+    if (mode == 0) a.beta[jj] = x;
+  }
+  if (tid == 0) {
+    if (mode == 1) ctl->have_base = 0;  // the refined point becomes the base of the spectral scheme
+    else ctl->t = 1.0;
+    ws->last_point[lane_id] = point_now;
+    ws->repeats[lane_id] = reps + 1;
+    if (L > ws->Lw[set]) ws->Lw[set] = L;
+    atomicAdd(&ws->refined, 1);
+  }
+}
+
+}  // namespace slm

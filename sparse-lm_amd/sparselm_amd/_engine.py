@@ -37,8 +37,11 @@ FLAG_PROFILE = 2
 FLAG_COLD_START = 4
 FLAG_FRESH_L = 8
 FLAG_FISTA_ONLY = 16
+FLAG_WORKING_SET = 32  # force the Gram-assisted refinement even for small X
+FLAG_NO_WORKING_SET = 64
 
 COMM_ID_BYTES = 128
+ABI_VERSION = 2  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -117,6 +120,10 @@ class _SolveStats(C.Structure):
         ("grad_ms_total", C.c_double),
         ("wall_ms", C.c_double),
         ("lipschitz_ms", C.c_double),
+        ("ws_builds", C.c_int64),
+        ("ws_appends", C.c_int64),
+        ("ws_refined", C.c_int64),
+        ("ws_misses", C.c_int64),
     ]
 
 
@@ -165,6 +172,11 @@ def load_library():
         P = C.POINTER
         lib.slm_abi_version.restype = C.c_int
         lib.slm_last_error.restype = C.c_char_p
+        if lib.slm_abi_version() != ABI_VERSION:
+            raise EngineError(
+                f"{path} has ABI version {lib.slm_abi_version()}, this binding needs {ABI_VERSION}: "
+                "rebuild it with `python sparse-lm_amd/build.py --force`"
+            )
         sigs = {
             "slm_device_count": [P(C.c_int)],
             "slm_engine_create": [C.c_int, P(vp)],
@@ -285,6 +297,10 @@ class PathResult:
     grad_ms_total: float
     wall_ms: float
     lipschitz_ms: float
+    ws_builds: int = 0  # working sets selected from scratch during the solve (0: refinement not used)
+    ws_appends: int = 0  # times columns were appended to the working set
+    ws_refined: int = 0
+    ws_misses: int = 0
 
     @property
     def converged(self) -> bool:
@@ -555,6 +571,10 @@ class Dataset:
                     grad_ms_total=float(stats.grad_ms_total),
                     wall_ms=float(stats.wall_ms),
                     lipschitz_ms=float(stats.lipschitz_ms),
+                    ws_builds=int(stats.ws_builds),
+                    ws_appends=int(stats.ws_appends),
+                    ws_refined=int(stats.ws_refined),
+                    ws_misses=int(stats.ws_misses),
                 )
             )
         return results
@@ -626,6 +646,10 @@ class Dataset:
             grad_ms_total=float(stats.grad_ms_total),
             wall_ms=float(stats.wall_ms),
             lipschitz_ms=float(stats.lipschitz_ms),
+            ws_builds=int(stats.ws_builds),
+            ws_appends=int(stats.ws_appends),
+            ws_refined=int(stats.ws_refined),
+            ws_misses=int(stats.ws_misses),
         )
 
 

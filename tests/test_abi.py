@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _engine.load_library()
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert lib.slm_abi_version() == 1
+    assert lib.slm_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_engine._PathPoint) == 32
     assert ctypes.sizeof(_engine._SolveOpts) == 32
     assert ctypes.sizeof(_engine._PointInfo) == 48
-    assert ctypes.sizeof(_engine._SolveStats) == 40
+    assert ctypes.sizeof(_engine._SolveStats) == 72
     assert ctypes.sizeof(_engine._PenaltyStruct) == 24
 
 

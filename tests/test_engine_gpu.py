@@ -14,6 +14,7 @@ import oracle
 from sparselm_amd import _engine
 
 pytestmark = pytest.mark.gpu
+PLAIN = _engine.FLAG_NO_WORKING_SET  # tests of the plain iteration's mechanics pin it
 
 
 @pytest.fixture(scope="module")
@@ -240,8 +241,9 @@ def test_path_extrapolation_only_moves_the_start(eng):
     amax = np.max(np.abs(X.T @ y)) / n
     pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-3 * amax, 25)]
     with eng.dataset(X, y) as ds:
-        r0 = ds.solve_path(pts, tol=1e-12, extrapolate=False)
-        r1 = ds.solve_path(pts, tol=1e-12, extrapolate=True)
+        # (plain iteration: with the working-set refinement every point costs one pass either way)
+        r0 = ds.solve_path(pts, tol=1e-12, extrapolate=False, flags=PLAIN)
+        r1 = ds.solve_path(pts, tol=1e-12, extrapolate=True, flags=PLAIN)
     assert r0.converged and r1.converged
     for k in range(1, len(pts)):
         assert rel_inf(r1.betas[k], r0.betas[k]) < 1e-9
@@ -303,7 +305,7 @@ def test_curvature_guard_recovers_from_too_small_L(eng):
     gidx, G = oracle.group_index(None, p)
     ref, _ = oracle.fista(X, y, alpha, 0.0, 0.0, gidx, G, tol=1e-13)
     with eng.dataset(X, y) as ds:
-        res = ds.solve_path([(alpha, 0.0, 0.0)], L=0.05 * L0, tol=1e-11, max_iter=100000)
+        res = ds.solve_path([(alpha, 0.0, 0.0)], L=0.05 * L0, tol=1e-11, max_iter=100000, flags=PLAIN)
     assert res.converged
     # the guard raises L to the largest curvature it has seen (a lower bound of lambda_max): far above
     # the bad start, not necessarily all the way to lambda_max
@@ -314,7 +316,7 @@ def test_curvature_guard_recovers_from_too_small_L(eng):
 def test_max_iter_reports_not_converged(eng, golden):
     X, y = golden["l1_X"], golden["l1_y"]
     with eng.dataset(X, y) as ds:
-        res = ds.solve_path([(0.5, 0.0, 0.0), (0.05, 0.0, 0.0)], tol=1e-15, max_iter=3)
+        res = ds.solve_path([(0.5, 0.0, 0.0), (0.05, 0.0, 0.0)], tol=1e-15, max_iter=3, flags=PLAIN)
     assert not res.converged
     assert list(res.n_iter) == [3, 3]
     assert list(res.status) == [_engine.SLM_ERR_NOT_CONVERGED] * 2
@@ -386,10 +388,10 @@ def test_path_split_into_lanes_matches_single_lane(eng, p):
     amax = np.max(np.abs(X.T @ y)) / n
     pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 0.05 * amax, 13)]
     with eng.dataset(X, y) as ds:
-        r1 = ds.solve_path(pts, tol=1e-12, max_iter=200000)
+        r1 = ds.solve_path(pts, tol=1e-12, max_iter=200000, flags=PLAIN)
         assert r1.converged
         for lanes in (2, 3, 4, 6):  # six lanes exist up to 3072 columns; beyond, the engine uses what it has
-            rl = ds.solve_path(pts, tol=1e-12, max_iter=200000, lanes=lanes)
+            rl = ds.solve_path(pts, tol=1e-12, max_iter=200000, lanes=lanes, flags=PLAIN)
             assert rl.converged
             assert rl.betas.shape == r1.betas.shape
             for k in range(1, len(pts)):

@@ -1,0 +1,200 @@
+"""Working-set (Gram-assisted) refinement, sparse-lm_amd/csrc/ws_kernels.hpp.
+
+The refinement only moves the point the next pass over X evaluates; every reported solution is
+still verified by a true gradient under the unchanged stopping rule.  So with it (FLAG_WORKING_SET)
+and without it (FLAG_NO_WORKING_SET) the engine must agree with the oracle and with itself to the
+solver tolerance, on every penalty of the family, while spending fewer passes over X.
+"""
+
+import numpy as np
+import pytest
+
+import oracle
+from sparselm_amd import _engine
+
+pytestmark = pytest.mark.gpu
+WS, NO_WS = _engine.FLAG_WORKING_SET, _engine.FLAG_NO_WORKING_SET
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return _engine.get_engine(0)
+
+
+def rel_inf(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def ofista(X, y, a, b=None, d=None, groups=None, G=None):
+    """Oracle minimiser at tight tolerance (singleton groups when none are given)."""
+    p = X.shape[1]
+    if groups is None:
+        groups, G = np.arange(p), p
+    b = np.zeros(G) if b is None else b
+    d = np.zeros(G) if d is None else d
+    return oracle.fista(X, y, a, b, d, np.asarray(groups), G, tol=1e-13, max_iter=200000)[0]
+
+
+def problem(n, p, n_inf, seed, groups=None, noise=1.0):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, p))
+    beta = np.zeros(p)
+    if groups is None:
+        beta[rng.choice(p, n_inf, replace=False)] = rng.uniform(1, 5, n_inf) * rng.choice([-1, 1], n_inf)
+    else:
+        for g in rng.choice(groups.max() + 1, n_inf, replace=False):
+            beta[groups == g] = rng.uniform(1, 3, int(np.sum(groups == g))) * rng.choice([-1, 1])
+    y = X @ beta + noise * rng.standard_normal(n)
+    return X, y
+
+
+def alpha_path(X, y, k=12, lo=1e-2, groups=None, G=None):
+    c = X.T @ y / X.shape[0]
+    amax = np.max(np.abs(c)) if groups is None else np.max(np.sqrt(np.bincount(groups, weights=c * c, minlength=G)))
+    return np.geomspace(amax, lo * amax, k)
+
+
+@pytest.mark.parametrize("n,p,lanes", [(3000, 700, 1), (3000, 700, 4), (2500, 333, 3), (900, 61, 2), (400, 9, 1)])
+def test_lasso_path_with_and_without_refinement(eng, n, p, lanes):
+    X, y = problem(n, p, min(12, p // 2), seed=n + p)
+    alphas = alpha_path(X, y)
+    pts = [(a, 0, 0) for a in alphas]
+    with eng.dataset(X, y) as ds:
+        r1 = ds.solve_path(pts, tol=1e-11, lanes=lanes, flags=WS)
+        r0 = ds.solve_path(pts, tol=1e-11, lanes=lanes, flags=NO_WS)
+    assert r1.converged and r0.converged
+    assert r1.ws_builds >= 1 and r1.ws_refined > 0 and r0.ws_builds == 0
+    assert rel_inf(r1.betas, r0.betas) < 1e-8
+    for k in (3, 7, 11):
+        ref = ofista(X, y, alphas[k] * np.ones(p))
+        assert rel_inf(r1.betas[k], ref) < 1e-8
+    assert r1.grad_launches < r0.grad_launches  # that is the point
+
+
+def test_refinement_takes_about_one_pass_per_point(eng):
+    X, y = problem(6000, 900, 15, seed=1)
+    alphas = alpha_path(X, y, k=24, lo=1e-2)
+    pts = [(a, 0, 0) for a in alphas]
+    with eng.dataset(X, y) as ds:
+        r1 = ds.solve_path(pts, tol=1e-8, flags=WS)
+        r0 = ds.solve_path(pts, tol=1e-8, flags=NO_WS)
+    assert r1.converged
+    assert r1.grad_launches <= 2 * len(alphas) + 4 * max(1, r1.ws_builds)
+    assert r1.grad_launches < 0.7 * r0.grad_launches
+    assert rel_inf(r1.betas, r0.betas) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["group", "sparse_group", "ridged", "shuffled_sgl"])
+def test_group_penalties_match_oracle_with_refinement(eng, kind):
+    n, G, size = 2500, 40, 6
+    p = G * size
+    groups = np.repeat(np.arange(G), size)
+    if kind == "shuffled_sgl":
+        groups = np.random.default_rng(5).permutation(groups)
+    X, y = problem(n, p, 5, seed=11, groups=groups)
+    w = np.random.default_rng(2).uniform(0.5, 2.0, G)
+    alphas = alpha_path(X, y, k=8, lo=3e-2, groups=groups, G=G)
+    if kind == "group":
+        sa, sb, sd = 0.0, 1.0, 0.0
+    elif kind in ("sparse_group", "shuffled_sgl"):
+        sa, sb, sd = 0.3, 0.7, 0.0
+    else:
+        sa, sb, sd = 0.0, 1.0, 1.0
+    pts = [(sa * a, sb * a, sd * 0.2) for a in alphas]
+    with eng.dataset(X, y) as ds:
+        ds.set_groups(groups, G)
+        r1 = ds.solve_path(pts, b=w, tol=1e-11, flags=WS, want_group_norms=True)
+        r0 = ds.solve_path(pts, b=w, tol=1e-11, flags=NO_WS, want_group_norms=True)
+    assert r1.converged and r1.ws_refined > 0
+    assert rel_inf(r1.betas, r0.betas) < 1e-8
+    np.testing.assert_allclose(r1.group_norms, r0.group_norms, rtol=0, atol=1e-8 * np.max(r0.group_norms))
+    for k in (2, 7):
+        ref = ofista(X, y, pts[k][0] * np.ones(p), pts[k][1] * w, pts[k][2] * np.ones(G), groups, G)
+        assert rel_inf(r1.betas[k], ref) < 1e-8
+
+
+def test_lanes_with_their_own_row_masks_get_their_own_gram(eng):
+    # CV folds as lanes: each lane's Gram is X^T diag(mask) X / n_train
+    n, p = 3000, 300
+    X, y = problem(n, p, 10, seed=21)
+    rng = np.random.default_rng(0)
+    fold = rng.integers(0, 3, n)
+    alphas = alpha_path(X, y, k=6, lo=5e-2)
+    lanes = []
+    for f in range(3):
+        m = (fold != f).astype(float)
+        lanes.append(dict(points=[(a, 0, 0) for a in alphas], row_weight=m, n_eff=int(m.sum())))
+    with eng.dataset(X, y) as ds:
+        res = ds.solve_lanes(lanes, tol=1e-11, flags=WS)
+        res0 = ds.solve_lanes(lanes, tol=1e-11, flags=NO_WS)
+    assert res[0].ws_builds >= 1 and res[0].ws_refined > 0
+    for f in range(3):
+        tr = fold != f
+        assert res[f].converged
+        assert rel_inf(res[f].betas, res0[f].betas) < 1e-8
+        ref = ofista(X[tr], y[tr], alphas[-1] * np.ones(p))
+        assert rel_inf(res[f].betas[-1], ref) < 1e-8
+
+
+def test_weighted_l1_and_warm_start(eng):
+    # the adaptive estimators' inner solves: per-coefficient weights, one point, warm start
+    n, p = 2000, 400
+    X, y = problem(n, p, 8, seed=31)
+    a = np.random.default_rng(3).uniform(0.05, 2.0, p)
+    with eng.dataset(X, y) as ds:
+        cold = ds.solve_path([(0.1, 0, 0)], a=a, tol=1e-11, flags=WS)
+        warm = ds.solve_path([(0.08, 0, 0)], a=a, beta0=cold.betas[0], tol=1e-11, flags=WS)
+        plain = ds.solve_path([(0.08, 0, 0)], a=a, tol=1e-11, flags=NO_WS)
+    assert warm.converged and rel_inf(warm.betas, plain.betas) < 1e-8
+    assert warm.grad_launches <= plain.grad_launches
+    ref = ofista(X, y, 0.08 * a)
+    assert rel_inf(warm.betas[0], ref) < 1e-8
+
+
+def test_dense_solutions_overflow_the_working_set_gracefully(eng):
+    # more active coefficients than the 256 columns a working set holds: refinement switches itself
+    # off and the plain iteration finishes the job
+    n, p = 1500, 600
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((n, p))
+    y = X @ rng.standard_normal(p) + 0.1 * rng.standard_normal(n)
+    with eng.dataset(X, y) as ds:
+        r1 = ds.solve_path([(1e-4, 0, 0)], tol=1e-10, flags=WS)
+        r0 = ds.solve_path([(1e-4, 0, 0)], tol=1e-10, flags=NO_WS)
+    assert r1.converged and np.count_nonzero(r1.betas[0]) > 256
+    assert rel_inf(r1.betas, r0.betas) < 1e-7
+
+
+def test_ols_limit_inside_the_working_set(eng):
+    # alpha = 0 with p <= 256: every column is in W, the model IS the problem
+    n, p = 800, 40
+    X, y = problem(n, p, 40, seed=41)
+    with eng.dataset(X, y) as ds:
+        r1 = ds.solve_path([(0, 0, 0)], tol=1e-12, flags=WS)
+    assert r1.converged
+    ref = np.linalg.lstsq(X, y, rcond=None)[0]
+    assert rel_inf(r1.betas[0], ref) < 1e-8
+
+
+def test_ill_conditioned_problem_is_solved_to_kkt(eng):
+    # p > n with strongly correlated columns: FISTA alone needs tens of thousands of passes here; the
+    # model solve on the Gram does the same iterations without touching X.  Check optimality directly.
+    rng = np.random.default_rng(6)
+    n, p = 60, 200
+    Z = rng.standard_normal((n, 8))
+    X = Z @ rng.standard_normal((8, p)) + 0.05 * rng.standard_normal((n, p))
+    y = X[:, :5] @ np.ones(5) + 0.01 * rng.standard_normal(n)
+    alphas = alpha_path(X, y, k=6, lo=1e-2)
+    pts = [(a, 0, 0) for a in alphas]
+    with eng.dataset(X, y) as ds:
+        r1 = ds.solve_path(pts, tol=1e-10, max_iter=100000, flags=WS)
+        r0 = ds.solve_path(pts, tol=1e-10, max_iter=100000, flags=NO_WS)
+    assert r1.converged
+    assert r1.grad_launches < r0.grad_launches
+    for a, b, b0 in zip(alphas, r1.betas, r0.betas):
+        g = X.T @ (X @ b - y) / n
+        assert np.max(np.abs(g)) <= a * (1 + 1e-6)  # dual feasibility
+        on = b != 0
+        np.testing.assert_allclose(g[on], -a * np.sign(b[on]), rtol=1e-6)  # stationarity on the support
+        obj = lambda v: 0.5 * np.sum((X @ v - y) ** 2) / n + a * np.abs(v).sum()
+        assert obj(b) <= obj(b0) * (1 + 1e-9)
