@@ -210,7 +210,7 @@ def main():
                 "parallelism": f"grid x{world} (independent paths, no collective)",
                 "grad_evals_per_path": grad_launches / args.steps,
                 "lipschitz_ms_per_path": res.lipschitz_ms,
-                "working_set": {"builds": res.ws_builds, "appends": res.ws_appends, "refined": res.ws_refined, "misses": res.ws_misses},
+                "working_set": {"builds": res.ws_builds, "appends": res.ws_appends, "refined": res.ws_refined, "misses": res.ws_misses, "columns": res.ws_columns},
             },
             "roofline": {
                 "bound": "hbm",

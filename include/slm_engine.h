@@ -190,7 +190,8 @@ typedef struct slm_solve_stats {
   int64_t ws_builds;      /* working sets selected and their Grams built from scratch       */
   int64_t ws_appends;     /* times columns were appended to the working set instead        */
   int64_t ws_refined;     /* iterates moved by the working-set refinement, all lanes       */
-  int64_t ws_misses;      /* times an iterate left the working set (forces a rebuild)      */
+  int64_t ws_misses;      /* times an iterate left the working set (columns get appended)  */
+  int64_t ws_columns;     /* columns in the working set at the end of the solve            */
 } slm_solve_stats;
 
 /*

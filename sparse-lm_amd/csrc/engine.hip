@@ -1230,11 +1230,20 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       wa.inv_n[l] = 1.0 / (ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global);
     wa.n_sets = n_sets;
     wa.nblk = ws_nblk;
-    wa.theta = 0.7;
+    wa.theta = 0.85;
+    // measured on the headline path (tools/ws_sweep.py, 24 combinations within 8 % of each other):
+    // theta 0.85 / look-ahead 2 / 16 newcomers per pass / 112 initial columns was the fastest
+    wa.lookahead = 2;
+    wa.append_max = 16;
+    wa.k_init = 112;
+    // tuning knobs (tools/ws_sweep.py)
     if (const char* th = getenv("SLM_WS_THETA")) {
       const double v = atof(th);
       if (v > 0.0 && v <= 1.0) wa.theta = v;
     }
+    if (const char* e = getenv("SLM_WS_LOOKAHEAD")) wa.lookahead = std::max(0, std::min(64, atoi(e)));
+    if (const char* e = getenv("SLM_WS_APPEND")) wa.append_max = std::max(1, std::min(WS_KCAP, atoi(e)));
+    if (const char* e = getenv("SLM_WS_KINIT")) wa.k_init = std::max(16, std::min(WS_KCAP, atoi(e)));
   }
   // everything that follows the gradient of one pass
   auto enqueue_after_gradient = [&]() {
@@ -1391,7 +1400,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       stats->grad_timed = cnt;
     }
     stats->lipschitz_ms = lipschitz_ms;
-    stats->ws_builds = stats->ws_appends = stats->ws_refined = stats->ws_misses = 0;
+    stats->ws_builds = stats->ws_appends = stats->ws_refined = stats->ws_misses = stats->ws_columns = 0;
     if (use_ws) {
       WsCtl wc;
       HIP_TRY(hipMemcpy(&wc, ds->ws_ctl, sizeof(wc), hipMemcpyDeviceToHost));
@@ -1399,6 +1408,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       stats->ws_appends = wc.appends;
       stats->ws_refined = wc.refined;
       stats->ws_misses = wc.misses;
+      stats->ws_columns = wc.Kreal;
     }
     stats->wall_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

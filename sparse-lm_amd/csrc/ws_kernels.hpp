@@ -30,12 +30,10 @@
 namespace slm {
 
 constexpr int WS_KCAP = 256;        // capacity of the working set (leading dimension of G and XW)
-constexpr int WS_KINIT = 128;       // size a selection is cut down to when more than WS_KCAP qualify
 constexpr int WS_KLDS = 128;        // up to this many columns the Gram lives in LDS during the model solve
 constexpr int WS_THREADS = 1024;
 constexpr int WS_INNER_MAX = 400;   // inner iterations per refinement
 constexpr double WS_INNER_TOL = 0.05;  // inner stop: residual <= WS_INNER_TOL * tol * ||b||
-constexpr int WS_LOOKAHEAD = 4;     // path points ahead whose penalty decides what enters W now
 constexpr int WS_MAX_REPEATS = 6;   // refinements of one path point before the lane iterates plainly
 
 struct WsCtl {
@@ -78,6 +76,10 @@ struct WsArgs {
   int32_t n_sets;     // 1 (every lane shares the row weights) or n_lanes
   int32_t nblk;
   double theta;
+  int32_t lookahead;   // path points ahead whose penalty decides what enters W now
+  int32_t append_max;  // newcomers appended per pass (the likeliest first)
+  int32_t k_init;      // a fresh selection is cut down to this size (or to its non-zeros)
+  int32_t pad_;
 };
 
 // exclusive prefix sum of one int per thread over the 1024-thread workgroup
@@ -120,82 +122,107 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
   const int nitems = singleton ? p : G;
   const bool had_w = ws->valid != 0;
 
-  // ---- did the plain step of any live lane move a coordinate outside the current W? --------------
-  // (z = candidate / extrapolated point just produced by the tail kernel, zprev = the point it was
-  // produced from: they differ outside W exactly when a feature outside W wants to enter)
   const bool requested = ws->request != 0;
   if (!requested && !had_w) return;
-  bool miss = false;
-  if (!requested) {
-    double out[1] = {0.0};
-    for (int l = 0; l < a.n_lanes; ++l) {
-      const PathCtl* c = a.ctl + l;
-      if (c->done || c->idle) continue;
-      const double* z = a.z + (int64_t)l * a.ld;
-      const double* zp = a.zprev + (int64_t)l * a.ld;
-      for (int j = tid; j < p; j += WS_THREADS)
-        if (w.pos[j] < 0 && z[j] != zp[j]) out[0] += 1.0;
-    }
-    block_sum<1>(out, red);
-    miss = out[0] != 0.0;
-    if (miss && tid == 0) ws->misses += 1;
-  }
   if (ws->builds >= ws->max_builds || ws->appends >= 8 * ws->max_builds) {
-    // budget spent: keep the W we have for lanes that stay inside it, the others iterate plainly
+    // budget spent: keep the W we have; lanes whose plain step leaves it iterate plainly (ws_solve_kernel
+    // checks that per lane once `stale` is set)
     if (tid == 0) {
       ws->request = 0;
-      if (miss) ws->stale = 1;
+      ws->stale = 1;
     }
     return;
   }
 
-  // ---- entry score per item (max over lanes); +inf marks items that are non-zero at a lane's
-  //      expansion point, -1 items that are already in W -----------------------------------------
+  // per-lane constants: is the lane walking a path, and the penalty scales w.lookahead points ahead
+  // of where it is (ranges may move between lanes in shared-path mode, so the look-ahead runs to the
+  // end of the path there).  Features that would enter by then are taken now; later ones are
+  // appended when their time comes.
+  __shared__ int lane_live[SLM_MAX_LANES];
+  __shared__ double lane_sa[SLM_MAX_LANES], lane_sb[SLM_MAX_LANES];
+  if (tid < SLM_MAX_LANES) {
+    int live = 0;
+    double sa = 0.0, sb = 0.0;
+    if (tid < a.n_lanes) {
+      const PathCtl* c = a.ctl + tid;
+      live = !(c->done || c->idle);
+      int path_end = 0;
+      for (int l = 0; l < a.n_lanes; ++l) path_end = max(path_end, a.ctl[l].n_points);
+      const int end = a.steal ? path_end : c->pt_off + c->n_points;
+      const int look = min(c->pt_off + c->point + w.lookahead, end - 1);
+      const slm_path_point pe = a.pts[look < 0 ? 0 : look];
+      sa = pe.sa;
+      sb = pe.sb;
+    }
+    lane_live[tid] = live;
+    lane_sa[tid] = sa;
+    lane_sb[tid] = sb;
+  }
+  __syncthreads();
+
+  // ---- one sweep: entry score per item (max over lanes; +inf marks items that are non-zero at a
+  //      lane's expansion point), newcomers at the default threshold, and whether the plain step of
+  //      any lane moved a coordinate outside W (z = candidate / extrapolated point just produced by
+  //      the tail kernel, zprev = the point it was produced from: they differ outside W exactly when
+  //      a feature outside W wants to enter) ---------------------------------------------------------
   const double inf = __builtin_huge_val();
-  int path_end = 0;  // shared-path mode: ranges move between lanes, the end of the path does not
-  for (int l = 0; l < a.n_lanes; ++l) path_end = max(path_end, a.ctl[l].n_points);
+  double sweep[2] = {0.0, 0.0};  // [0] features of newcomers at theta, [1] coordinates that left W
   for (int it = tid; it < nitems; it += WS_THREADS) {
     double sc = 0.0;
-    for (int l = 0; l < a.n_lanes; ++l) {
-      const PathCtl* c = a.ctl + l;
-      if (c->done || c->idle) continue;
-      const int64_t off = (int64_t)l * a.ld;
-      const double* g = a.g + (int64_t)l * (a.ld + 16);
-      // the penalty this lane will have reached WS_LOOKAHEAD points from now (ranges may move between
-      // lanes in shared-path mode, so the look-ahead runs to the end of the path there): features that
-      // would enter by then are taken now; later ones are appended when their time comes
-      const int end = a.steal ? path_end : c->pt_off + c->n_points;
-      const int look = min(c->pt_off + c->point + WS_LOOKAHEAD, end - 1);
-      const slm_path_point pe = a.pts[look < 0 ? 0 : look];
-      if (singleton) {
-        const int j = it;
-        if (a.zprev[off + j] != 0.0) {
+    bool in_w = false;
+    if (singleton) {
+      const int j = it;
+      in_w = had_w && w.pos[j] >= 0;
+#pragma unroll
+      for (int l = 0; l < SLM_MAX_LANES; ++l) {
+        if (l >= a.n_lanes || !lane_live[l]) continue;
+        const int64_t off = (int64_t)l * a.ld;
+        const double zp = a.zprev[off + j];
+        if (!in_w && had_w && a.z[off + j] != zp) sweep[1] += 1.0;
+        if (zp != 0.0) {
           sc = inf;
         } else {
-          const double thr = pe.sa * a.a0[off + j] + pe.sb * a.b0[off + j];
-          const double r = thr > 0.0 ? fabs(g[j]) / thr : inf;
-          sc = fmax(sc, r);
+          const double thr = lane_sa[l] * a.a0[off + j] + lane_sb[l] * a.b0[off + j];
+          const double gj = a.g[(int64_t)l * (a.ld + 16) + j];
+          sc = fmax(sc, thr > 0.0 ? fabs(gj) / thr : inf);
         }
-      } else {
-        const int k0 = a.gstart[it], k1 = a.gstart[it + 1];
+      }
+      if (sc >= w.theta && !in_w) sweep[0] += 1.0;
+    } else {
+      const int k0 = a.gstart[it], k1 = a.gstart[it + 1];
+      in_w = had_w && w.pos[a.order[k0]] >= 0;
+      for (int l = 0; l < a.n_lanes; ++l) {
+        if (!lane_live[l]) continue;
+        const int64_t off = (int64_t)l * a.ld;
+        const double* g = a.g + (int64_t)l * (a.ld + 16);
         double num = 0.0, rmax = 0.0;
         bool act = false;
         for (int k = k0; k < k1; ++k) {
           const int j = a.order[k];
-          act = act || a.zprev[off + j] != 0.0;
-          const double thr = pe.sa * a.a0[off + j];
+          const double zp = a.zprev[off + j];
+          if (!in_w && had_w && a.z[off + j] != zp) sweep[1] += 1.0;
+          act = act || zp != 0.0;
+          const double thr = lane_sa[l] * a.a0[off + j];
           const double m = fmax(fabs(g[j]) - thr, 0.0);
           num = __builtin_fma(m, m, num);
           rmax = fmax(rmax, thr > 0.0 ? fabs(g[j]) / thr : inf);
         }
-        const double den = pe.sb * a.b0[off + it];
+        const double den = lane_sb[l] * a.b0[off + it];
         const double r = den > 0.0 ? sqrt(num) / den : rmax;
         sc = act ? inf : fmax(sc, r);
       }
+      if (sc >= w.theta && !in_w) sweep[0] += (double)(k1 - k0);
     }
     w.score[it] = sc;
   }
-  __syncthreads();
+  block_sum<2>(sweep, red);  // (its barriers also publish score[])
+  const bool miss = had_w && sweep[1] != 0.0;
+  if (miss && tid == 0) ws->misses += 1;
+  if (had_w && !requested && sweep[0] == 0.0) {
+    // no newcomer (the usual pass).  A lane that left W anyway cannot be helped: it iterates plainly.
+    if (miss && tid == 0) ws->stale = 1;
+    return;
+  }
 
   // feature count of the items with score >= thr (optionally only those not yet in W), and the
   // largest finite score
@@ -223,16 +250,51 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
     *smax = mm;
   };
 
+  // smallest threshold >= thr0 whose selection has at most `cap` features (scores >= it are kept)
+  auto fit_threshold = [&](double thr0, bool only_new, double cap, double* n_out) -> double {
+    double n_sel, smax;
+    count_at(thr0, only_new, &n_sel, &smax);
+    if (n_sel <= cap) {
+      *n_out = n_sel;
+      return thr0;
+    }
+    double lo = thr0, hi = fmax(smax, thr0) * (1.0 + 1e-12) + 1e-300;  // count(hi) = non-zeros only
+    double n_hi = 0.0;
+    for (int k = 0; k < 14; ++k) {
+      const double mid = 0.5 * (lo + hi);
+      count_at(mid, only_new, &n_sel, &smax);
+      if (n_sel > cap) {
+        lo = mid;
+      } else {
+        hi = mid;
+        n_hi = n_sel;
+        if (n_sel >= 0.5 * cap) break;  // close enough to the cap
+      }
+    }
+    if (n_hi == 0.0) count_at(hi, only_new, &n_hi, &smax);
+    *n_out = n_hi;
+    return hi;
+  };
+
   double n_sel, smax, thr = w.theta;
   const int k_old = had_w ? ws->Kreal : 0;
   bool append = had_w;
   if (append) {
-    count_at(thr, true, &n_sel, &smax);
-    if (n_sel == 0.0) {  // no newcomer (the usual case); a lane that left W anyway cannot be helped
-      if (miss && tid == 0) ws->stale = 1;
+    // newcomers: at most w.append_max per pass, the likeliest first (a feature left out that enters
+    // anyway shows up as a miss and is appended then)
+    if (sweep[0] <= (double)w.append_max) {
+      n_sel = sweep[0];
+    } else {
+      thr = fit_threshold(w.theta, true, (double)w.append_max, &n_sel);
+    }
+    if (n_sel == 0.0) {  // (requested with a valid W and nothing to add)
+      if (tid == 0) ws->request = 0;
       return;
     }
-    if ((double)k_old + n_sel > (double)WS_KCAP) append = false;  // does not fit: select afresh
+    if ((double)k_old + n_sel > (double)WS_KCAP) {  // does not fit: select afresh
+      append = false;
+      thr = w.theta;
+    }
   }
   if (!append) {
     count_at(inf, false, &n_sel, &smax);
@@ -247,16 +309,8 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
       }
       return;
     }
-    count_at(thr, false, &n_sel, &smax);
-    if (n_sel > (double)WS_KCAP) {
-      double lo = thr, hi = fmax(smax, thr) * (1.0 + 1e-12) + 1e-300;  // count(hi) = non-zeros only
-      for (int k = 0; k < 24; ++k) {
-        const double mid = 0.5 * (lo + hi);
-        count_at(mid, false, &n_sel, &smax);
-        if (n_sel > (double)WS_KINIT) lo = mid; else hi = mid;
-      }
-      thr = hi;
-    }
+    const double nonzeros = n_sel;
+    thr = fit_threshold(w.theta, false, fmax((double)w.k_init, nonzeros), &n_sel);
     for (int j = tid; j < p; j += WS_THREADS) w.pos[j] = -1;
   }
   for (int k = k_old * (append ? 1 : 0) + tid; k < WS_KCAP; k += WS_THREADS) {
@@ -423,6 +477,7 @@ __global__ __launch_bounds__(256) void ws_gram_reduce_kernel(WsArgs w) {
   const int i = e / WS_KCAP, j = e % WS_KCAP;
   if (i >= row_lo && i < K && j < K) {
     double s = 0.0;
+#pragma unroll 8
     for (int b = 0; b < w.nblk; ++b) s += w.part[((int64_t)b * w.n_sets + set) * (WS_KCAP * WS_KCAP) + e];
     s *= w.inv_n[set];
     double* Gs = w.Gm + (int64_t)set * (WS_KCAP * WS_KCAP);

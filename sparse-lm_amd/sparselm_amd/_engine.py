@@ -124,6 +124,7 @@ class _SolveStats(C.Structure):
         ("ws_appends", C.c_int64),
         ("ws_refined", C.c_int64),
         ("ws_misses", C.c_int64),
+        ("ws_columns", C.c_int64),
     ]
 
 
@@ -301,6 +302,7 @@ class PathResult:
     ws_appends: int = 0  # times columns were appended to the working set
     ws_refined: int = 0
     ws_misses: int = 0
+    ws_columns: int = 0  # columns in the working set at the end
 
     @property
     def converged(self) -> bool:
@@ -575,6 +577,7 @@ class Dataset:
                     ws_appends=int(stats.ws_appends),
                     ws_refined=int(stats.ws_refined),
                     ws_misses=int(stats.ws_misses),
+                    ws_columns=int(stats.ws_columns),
                 )
             )
         return results
@@ -650,6 +653,7 @@ class Dataset:
             ws_appends=int(stats.ws_appends),
             ws_refined=int(stats.ws_refined),
             ws_misses=int(stats.ws_misses),
+            ws_columns=int(stats.ws_columns),
         )
 
 

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_engine._PathPoint) == 32
     assert ctypes.sizeof(_engine._SolveOpts) == 32
     assert ctypes.sizeof(_engine._PointInfo) == 48
-    assert ctypes.sizeof(_engine._SolveStats) == 72
+    assert ctypes.sizeof(_engine._SolveStats) == 80
     assert ctypes.sizeof(_engine._PenaltyStruct) == 24
 
 

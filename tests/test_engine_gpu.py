@@ -352,8 +352,8 @@ def test_spectral_mode_matches_fista_and_saves_gradients(eng):
     amax = np.max(np.abs(X.T @ y)) / n
     pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-3 * amax, 30)]
     with eng.dataset(X, y) as ds:
-        rf = ds.solve_path(pts, tol=1e-11, flags=_engine.FLAG_FISTA_ONLY)
-        rb = ds.solve_path(pts, tol=1e-11)
+        rf = ds.solve_path(pts, tol=1e-11, flags=_engine.FLAG_FISTA_ONLY | PLAIN)
+        rb = ds.solve_path(pts, tol=1e-11, flags=PLAIN)
     assert rf.converged and rb.converged
     assert np.all(rf.mode == 0) and np.all(rb.mode == 1)  # well conditioned: no fallback
     for k in range(1, len(pts)):
