@@ -200,7 +200,10 @@ static const int kMaxLanes = SLM_MAX_LANES;
 struct GlobalCtl {
   int32_t done;        // every lane finished, or abort
   int32_t lanes_done;
+  int32_t hard;        // most passes any lane has spent on one path point so far (TailArgs::gdone[2])
+  int32_t pad_;
 };
+static const int kWsLateIters = 48;  // passes on one point after which a small problem gets the working set
 
 struct HostCtl {  // pinned snapshot the host polls
   GlobalCtl g;
@@ -1035,6 +1038,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   HIP_TRY(hipSetDevice(eng->device));
   hipStream_t s = eng->stream;
   const auto t_begin = std::chrono::steady_clock::now();
+  auto t_mark = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+  double tr[6] = {0, 0, 0, 0, 0, 0};
   const int64_t p = ds->p, ld = ds->ld, n = ds->n;
   const int G = ds->G;
 
@@ -1151,7 +1156,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   HIP_TRY(hipMemcpyAsync(ds->z, ds->beta, sizeof(double) * kMaxLanes * ld, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(ds->ctl, h, sizeof(PathCtl) * B, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(ds->gctl, 0, sizeof(GlobalCtl), s));
+  tr[0] = t_mark();
   HIP_TRY(hipStreamSynchronize(s));  // host staging buffers are free again
+  tr[1] = t_mark();
 
   TailArgs ta;
   ta.ctl = ds->ctl;
@@ -1184,18 +1191,21 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // ---- working-set refinement (ws_kernels.hpp) -----------------------------------------------------
   // Worth it when a pass over X costs more than the one-workgroup model solve that replaces several
   // of them; row-sharded datasets would need the Gram all-reduced (not built).
-  bool use_ws = false;
+  // Small problems start with plain steps (their passes cost less than a model solve) and switch the
+  // refinement on when a path point turns out to be hard (ws_late: more than kWsLateIters passes on
+  // one point -- ill-conditioned designs, where FISTA needs thousands).
+  bool use_ws = false, ws_late = false;
   WsArgs wa;
   memset(&wa, 0, sizeof(wa));
   {
     const char* env = getenv("SLM_WS");
     const bool big = (double)n * (double)ld >= 67108864.0;  // 2^26 doubles = 512 MiB
-    use_ws = big || (o.flags & SLM_FLAG_WORKING_SET);
-    if (env && env[0] == '1') use_ws = true;
-    if ((env && env[0] == '0') || (o.flags & SLM_FLAG_NO_WORKING_SET)) use_ws = false;
-    if (eng->comm || ds->max_group > 64 || n < 4) use_ws = false;
+    const bool possible = !(eng->comm || ds->max_group > 64 || n < 4) &&
+                          !((env && env[0] == '0') || (o.flags & SLM_FLAG_NO_WORKING_SET));
+    use_ws = possible && (big || (o.flags & SLM_FLAG_WORKING_SET) || (env && env[0] == '1'));
+    ws_late = possible && !use_ws;
   }
-  if (use_ws) {
+  auto ws_setup = [&]() -> int {
     const int n_sets = (any_rw || custom_scale) ? B : 1;
     const int ws_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n / 64));
     if (!ds->ws_ctl) {
@@ -1244,7 +1254,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (const char* e = getenv("SLM_WS_LOOKAHEAD")) wa.lookahead = std::max(0, std::min(64, atoi(e)));
     if (const char* e = getenv("SLM_WS_APPEND")) wa.append_max = std::max(1, std::min(WS_KCAP, atoi(e)));
     if (const char* e = getenv("SLM_WS_KINIT")) wa.k_init = std::max(16, std::min(WS_KCAP, atoi(e)));
-  }
+    return SLM_OK;
+  };
+  if (use_ws) SLM_TRY(ws_setup());
   // everything that follows the gradient of one pass
   auto enqueue_after_gradient = [&]() {
     launch_tail(ta, s);
@@ -1266,6 +1278,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     const double est_us = std::max(12.0, (double)n * (double)ld * 8.0 / 5.0e6);
     chunk = (int)std::min(32.0, std::max(2.0, 400.0 / est_us));
   }
+  if (use_ws) chunk = std::min(chunk, 8);  // a queued pass is nine launches even when it returns at once
   int max_points = 0;
   for (int l = 0; l < B; ++l) max_points = std::max(max_points, (int)lanes[l].n_points);
   if (shared_path) max_points = (int)total_points;  // a lane may end up walking most of the path
@@ -1324,6 +1337,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
   } graph_guard{gexec};
 
+  tr[2] = t_mark();
   while (!done) {
     if (use_graph) {
       HIP_TRY(hipGraphLaunch(gexec[slot], s));
@@ -1355,6 +1369,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       HIP_TRY(hipEventSynchronize(ds->ev[other]));
       pending[other] = false;
       if (ds->hctl[other].g.done) done = true;
+      if (!done && ws_late && !use_graph && ds->hctl[other].g.hard >= kWsLateIters) {
+        SLM_TRY(ws_setup());  // (waits for the stream: the queued passes simply finish first)
+        use_ws = true;
+        ws_late = false;
+        chunk = std::min(chunk, 8);
+      }
     }
     slot = other;
     if (!done && enq >= max_total + 2 * (int64_t)chunk) {
@@ -1363,6 +1383,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
   }
   HIP_TRY(hipStreamSynchronize(s));
+  tr[3] = t_mark();
   PathCtl fin[SLM_MAX_LANES];
   HIP_TRY(hipMemcpy(fin, ds->ctl, sizeof(PathCtl) * B, hipMemcpyDeviceToHost));
   int64_t passes = 0;
@@ -1413,6 +1434,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     stats->wall_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
+  tr[4] = t_mark();
+  if (getenv("SLM_TRACE") && tr[4] > 15.0)
+    fprintf(stderr, "[slm] slow solve: setup %.2f sync %.2f prequeue %.2f loop %.2f end %.2f ms\n", tr[0], tr[1], tr[2], tr[3], tr[4]);
   if (nonfinite) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
   return SLM_OK;
 }

@@ -63,7 +63,8 @@ constexpr double BB_SIGMA = 1e-4;
 // One workgroup per lane (blockIdx.x): vectors of lane l start at l * ld (g: l * (ld + 16)).
 struct TailArgs {
   PathCtl* ctl;               // [n_lanes]
-  int* gdone;                 // [0] = every lane finished (or abort), [1] = lanes finished so far
+  int* gdone;                 // [0] = every lane finished (or abort), [1] = lanes finished so far,
+                              // [2] = most passes spent on one point so far
   int n_lanes;
   int steal;                  // 1 => all lanes walk ONE path: an idle lane takes over the upper half of
                               //      the points the busiest lane has not reached yet (cold start)
@@ -573,6 +574,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       }
     } else {
       ctl->iter = iter + 1;
+      atomicMax(&a.gdone[2], iter + 1);  // GlobalCtl::hard: lets the host give a hard problem the working set
       ctl->t = new_t;
       ctl->have_base = new_have_base;
       ctl->n_hist = new_n_hist;

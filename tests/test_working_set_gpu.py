@@ -198,3 +198,30 @@ def test_ill_conditioned_problem_is_solved_to_kkt(eng):
         np.testing.assert_allclose(g[on], -a * np.sign(b[on]), rtol=1e-6)  # stationarity on the support
         obj = lambda v: 0.5 * np.sum((X @ v - y) ** 2) / n + a * np.abs(v).sum()
         assert obj(b) <= obj(b0) * (1 + 1e-9)
+
+
+def test_small_hard_problem_gets_the_working_set_late(eng):
+    # default flags on a small problem: plain steps first; once a point has cost 48 passes the host
+    # switches the refinement on and the path finishes in a handful of passes instead of > 100 000
+    rng = np.random.default_rng(6)
+    n, p = 60, 200
+    Z = rng.standard_normal((n, 8))
+    X = Z @ rng.standard_normal((8, p)) + 0.05 * rng.standard_normal((n, p))
+    y = X[:, :5] @ np.ones(5) + 0.01 * rng.standard_normal(n)
+    alphas = alpha_path(X, y, k=6, lo=1e-2)
+    pts = [(a, 0, 0) for a in alphas]
+    with eng.dataset(X, y) as ds:
+        r = ds.solve_path(pts, tol=1e-10, max_iter=100000)
+        easy = ds.solve_path([(alphas[1], 0, 0)], tol=1e-6, max_iter=100000, flags=0)
+    assert r.converged and r.ws_builds >= 1 and r.grad_launches < 2000
+    for a, b in zip(alphas, r.betas):
+        g = X.T @ (X @ b - y) / n
+        assert np.max(np.abs(g)) <= a * (1 + 1e-6)
+    assert easy.converged
+
+
+def test_easy_small_problem_stays_plain(eng):
+    X, y = problem(400, 100, 10, seed=51)
+    with eng.dataset(X, y) as ds:
+        r = ds.solve_path([(0.1, 0, 0)], tol=1e-8)
+    assert r.converged and r.ws_builds == 0 and r.grad_launches < 48
