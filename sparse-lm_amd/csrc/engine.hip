@@ -24,6 +24,7 @@
 #include "grad_kernel.hpp"
 #include "tail_kernels.hpp"
 #include "ws_kernels.hpp"
+#include "split_kernels.hpp"
 
 using namespace slm;
 
@@ -155,6 +156,24 @@ static const int64_t kMaxChunks = 64 * 8 * 10;  // largest row the fused kernel 
 static const GradKernel kGradTwoPass = {8, 4, 2, 1, -1, nullptr};
 static const int kTwoPassC = 4;  // column tile of xtr_kernel: 512 * 4 chunks = 4096 columns
 
+// Split pass (split_kernels.hpp) for working-set solves: eight lanes per read of X, rows of up to
+// 5120 columns (40 accumulator doubles per thread).  D rows in flight as for the fused ring kernel.
+struct SplitKernel {
+  int W, C, B, D;
+  void (*xtr)(SplitArgs);
+  void (*rowdot)(SplitArgs);
+  void (*resid)(SplitArgs);
+};
+#define SLM_SK(C, D) {8, C, 8, D, xtr_ring_kernel<8, C, 8, D>, rowdot_ring_kernel<8, C, 8, D>, resid_ws_kernel<8>}
+static const SplitKernel kSplit[] = {SLM_SK(1, 3), SLM_SK(2, 3), SLM_SK(3, 3), SLM_SK(4, 3), SLM_SK(5, 2)};
+static const SplitKernel* pick_split_kernel(int64_t p2) {
+  const char* env = getenv("SLM_SPLIT");
+  if (env && env[0] == '0') return nullptr;
+  for (const auto& k : kSplit)
+    if (64LL * k.W * k.C >= p2) return &k;
+  return nullptr;
+}
+
 static const GradKernel* pick_grad_kernel(int64_t p2, int B) {
   if (p2 > kMaxChunks) return B == 1 ? &kGradTwoPass : nullptr;
   // LDS-ring variants: measured flat in B (0.60-0.61 ms for B = 1..4 at p = 5000) where the register
@@ -227,6 +246,9 @@ struct slm_dataset {
   // gradient launch, per lane count B = 1..kMaxLanes (index B-1); gk == nullptr => unsupported
   const GradKernel* gk[SLM_MAX_LANES] = {};
   int nblk[SLM_MAX_LANES] = {};
+  const SplitKernel* sk = nullptr;  // split pass for working-set solves (nullptr: rows too long)
+  int split_nblk = 0;
+  double* R = nullptr;              // [n][SPLIT_LANES] residuals of the split pass, allocated on first use
   double *partial = nullptr, *loss_partial = nullptr;
   // iteration state: kMaxLanes copies, lane stride ld (g: ld + 16)
   double *g = nullptr, *z = nullptr, *beta = nullptr, *zprev = nullptr, *gprev = nullptr;
@@ -358,7 +380,7 @@ static void dataset_free(slm_dataset* ds) {
   if (!ds) return;
   dfree(ds->X); dfree(ds->y); dfree(ds->rw); dfree(ds->yzero); dfree(ds->rw_lanes); dfree(ds->rvec);
   dfree(ds->order); dfree(ds->gid); dfree(ds->gstart);
-  dfree(ds->partial); dfree(ds->loss_partial);
+  dfree(ds->partial); dfree(ds->loss_partial); dfree(ds->R);
   dfree(ds->g); dfree(ds->z); dfree(ds->beta); dfree(ds->zprev); dfree(ds->gprev);
   dfree(ds->u); dfree(ds->gscale); dfree(ds->a0); dfree(ds->b0); dfree(ds->d0);
   dfree(ds->lambda); dfree(ds->ctl); dfree(ds->gctl);
@@ -429,6 +451,12 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
   if (!ds->gk[0]) {
     delete ds;
     return fail(SLM_ERR_UNSUPPORTED, "no gradient kernel covers p = %lld", (long long)p);
+  }
+  ds->sk = pick_split_kernel(ld / 2);
+  if (ds->sk) {
+    ds->split_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n));  // one ring workgroup per CU
+    partial_elems = std::max(partial_elems, (size_t)ds->split_nblk * SPLIT_LANES * (size_t)ld);
+    loss_elems = std::max(loss_elems, (size_t)ds->split_nblk * SPLIT_LANES);
   }
 
   int rc = SLM_OK;
@@ -708,6 +736,7 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
   hipStream_t s = ds->eng->stream;
   const int B = ls.B;
   const GradKernel* gk = ds->gk[B - 1];
+  if (!gk) return fail(SLM_ERR_UNSUPPORTED, "no %d-lane gradient kernel covers p = %lld", B, (long long)ds->p);
   const int nblk = ds->nblk[B - 1];
   GradArgs a;
   a.X = ds->X;
@@ -757,6 +786,49 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
   return SLM_OK;
 }
 
+// The same for working-set solves through the split pass: residuals (from the gathered columns where a
+// lane's point is supported on W, from X otherwise), then X^T r for all eight lane slots on one read
+// of X.  ctl == nullptr: every lane takes its residual from X (slm_gradient with SLM_GRAD_SPLIT=1).
+static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done,
+                                  const PathCtl* ctl, const WsArgs* wa, hipEvent_t ev_start,
+                                  hipEvent_t ev_stop) {
+  hipStream_t s = ds->eng->stream;
+  const SplitKernel* sk = ds->sk;
+  const int nblk = ds->split_nblk;
+  if (!ds->R) {
+    SLM_TRY(dalloc(&ds->R, (size_t)ds->n * SPLIT_LANES));
+    HIP_TRY(hipMemsetAsync(ds->R, 0, sizeof(double) * (size_t)ds->n * SPLIT_LANES, s));
+  }
+  SplitArgs a;
+  memset(&a, 0, sizeof(a));
+  a.X = ds->X; a.y = y; a.rw = ls.rw; a.rw_stride = ls.rw_stride; a.z = ds->z; a.R = ds->R;
+  a.partial = ds->partial; a.loss_partial = ds->loss_partial; a.done = done; a.ctl = ctl;
+  if (wa) { a.XW = wa->XW; a.idx = wa->idx; a.ws = wa->ws; }
+  a.n = ds->n; a.ld = ds->ld; a.rows_base = ds->n / nblk; a.rows_rem = ds->n % nblk;
+  a.p2 = (int)(ds->ld / 2);
+  a.n_lanes = ls.B;
+  if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
+  hipLaunchKernelGGL(sk->rowdot, dim3(nblk), dim3(sk->W * 64), 0, s, a);
+  if (wa && ctl) hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(sk->xtr, dim3(nblk), dim3(sk->W * 64), 0, s, a);
+  if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
+  ReduceArgs ra;
+  ra.partial = ds->partial;
+  ra.loss_partial = ds->loss_partial;
+  ra.g = ds->g;
+  ra.done = done;
+  ra.nblk = nblk;
+  ra.n_lanes = SPLIT_LANES;  // partial rows are laid out for eight lane slots
+  ra.ld = ds->ld;
+  for (int l = 0; l < kMaxLanes; ++l) {
+    const double ne = ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global;
+    ra.scale[l] = 1.0 / ne;
+    ra.loss_scale[l] = 0.5 / ne;
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(ds->ld / 16 + 1), ls.B), dim3(256), 0, s, ra);
+  return SLM_OK;
+}
+
 // E = features per thread of the one-workgroup-per-lane tail kernel (p <= 1024 * E).  Up to E = 8
 // everything stays in registers; the larger instantiations (long-row fallback) spill to scratch,
 // which is irrelevant next to a two-pass gradient over a matrix that wide.
@@ -803,7 +875,12 @@ static int power_iteration(slm_dataset* ds, const LaneSetup& ls, double* L_out /
   if (const char* env = getenv("SLM_POWER_ITERS")) iters = std::max(2, atoi(env));
   hipLaunchKernelGGL(power_init_kernel, dim3(ls.B), dim3(TAIL_THREADS), 0, s, ds->z, (int)ds->p, ds->ld);
   for (int k = 0; k < iters; ++k) {
-    SLM_TRY(enqueue_gradient(ds, ls, ds->yzero, nullptr, nullptr, nullptr));
+    if (ds->gk[ls.B - 1]) {
+      SLM_TRY(enqueue_gradient(ds, ls, ds->yzero, nullptr, nullptr, nullptr));
+    } else {  // more lanes than the fused kernels serve (working-set solves): the split pass has eight
+      if (!ds->sk) return fail(SLM_ERR_UNSUPPORTED, "no %d-lane kernel for p = %lld", ls.B, (long long)ds->p);
+      SLM_TRY(enqueue_gradient_split(ds, ls, ds->yzero, nullptr, nullptr, nullptr, nullptr, nullptr));
+    }
     PowerArgs pa;
     pa.g = ds->g;
     pa.v = ds->z;
@@ -891,7 +968,10 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
   const LaneSetup ls = default_lanes(ds, 1);
   HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * ds->ld, s));
   if (z) HIP_TRY(hipMemcpyAsync(ds->z, z, sizeof(double) * ds->p, hipMemcpyHostToDevice, s));
-  SLM_TRY(enqueue_gradient(ds, ls, ds->y, nullptr, nullptr, nullptr));
+  const char* split_env = getenv("SLM_GRAD_SPLIT");  // tests: take the split pass (residuals from X)
+  const bool use_split = split_env && split_env[0] == '1' && ds->sk != nullptr;
+  if (use_split) SLM_TRY(enqueue_gradient_split(ds, ls, ds->y, nullptr, nullptr, nullptr, nullptr, nullptr));
+  else SLM_TRY(enqueue_gradient(ds, ls, ds->y, nullptr, nullptr, nullptr));
   SLM_TRY(check_launch());
   HIP_TRY(hipStreamSynchronize(s));
   if (g_out) HIP_TRY(hipMemcpy(g_out, ds->g, sizeof(double) * ds->p, hipMemcpyDeviceToHost));
@@ -902,6 +982,35 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
     // lanes used by the probe: SLM_PROBE_LANES (tuning), default 1
     int B = 1;
     if (const char* env = getenv("SLM_PROBE_LANES")) B = std::min(kMaxLanes, std::max(1, atoi(env)));
+    if (use_split) {  // time the split pass (rowdot + xtr, or xtr alone with SLM_GRAD_SPLIT_XTR_ONLY=1)
+      for (int l = 1; l < B; ++l)
+        HIP_TRY(hipMemcpyAsync(ds->z + l * ds->ld, ds->z, sizeof(double) * ds->ld, hipMemcpyDeviceToDevice, s));
+      const LaneSetup lb = default_lanes(ds, B);
+      const bool xtr_only = getenv("SLM_GRAD_SPLIT_XTR_ONLY") != nullptr;
+      SLM_TRY(enqueue_gradient_split(ds, lb, ds->y, nullptr, nullptr, nullptr, nullptr, nullptr));  // warm; allocates R
+      SplitArgs a;
+      memset(&a, 0, sizeof(a));
+      a.X = ds->X; a.y = ds->y; a.rw = lb.rw; a.rw_stride = 0; a.z = ds->z; a.R = ds->R;
+      a.partial = ds->partial; a.loss_partial = ds->loss_partial;
+      a.n = ds->n; a.ld = ds->ld; a.rows_base = ds->n / ds->split_nblk; a.rows_rem = ds->n % ds->split_nblk;
+      a.p2 = (int)(ds->ld / 2); a.n_lanes = B;
+      hipEvent_t e0, e1;
+      HIP_TRY(hipEventCreate(&e0));
+      HIP_TRY(hipEventCreate(&e1));
+      HIP_TRY(hipEventRecord(e0, s));
+      for (int r = 0; r < reps; ++r) {
+        if (!xtr_only) hipLaunchKernelGGL(ds->sk->rowdot, dim3(ds->split_nblk), dim3(ds->sk->W * 64), 0, s, a);
+        hipLaunchKernelGGL(ds->sk->xtr, dim3(ds->split_nblk), dim3(ds->sk->W * 64), 0, s, a);
+      }
+      HIP_TRY(hipEventRecord(e1, s));
+      HIP_TRY(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+      *ms_out = (double)ms / reps;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      return check_launch();
+    }
     if (!ds->gk[B - 1]) return fail(SLM_ERR_UNSUPPORTED, "no %d-lane kernel for p = %lld", B, (long long)ds->p);
     for (int l = 1; l < B; ++l)
       HIP_TRY(hipMemcpyAsync(ds->z + l * ds->ld, ds->z, sizeof(double) * ds->ld, hipMemcpyDeviceToDevice, s));
@@ -1009,13 +1118,32 @@ static int upload_vec_or_const(double* dst, const double* src, int64_t count, do
 
 // shared_path: the lanes are contiguous, ordered ranges of ONE path (slm_solve_path_lanes): global
 // point indices on the device and work stealing between lanes.
+// Working-set refinement policy (see solve_core): 0 = never, 1 = when a path point turns out hard
+// (small problems), 2 = from the first pass.
+static int ws_policy(const slm_dataset* ds, uint32_t flags) {
+  const char* env = getenv("SLM_WS");
+  if (ds->eng->comm || ds->max_group > 64 || ds->n < 4) return 0;
+  if ((env && env[0] == '0') || (flags & SLM_FLAG_NO_WORKING_SET)) return 0;
+  const bool big = (double)ds->n * (double)ds->ld >= 67108864.0;  // 2^26 doubles = 512 MiB
+  return (big || (flags & SLM_FLAG_WORKING_SET) || (env && env[0] == '1')) ? 2 : 1;
+}
+// most lanes one solve can run: the fused kernels' table, or the split pass's eight when the working
+// set is on from the start
+static int max_lanes_for(const slm_dataset* ds, uint32_t flags) {
+  if (ws_policy(ds, flags) == 2 && ds->sk) return SPLIT_LANES;
+  int B = kMaxLanes;
+  while (B > 1 && !ds->gk[B - 1]) --B;
+  return B;
+}
+
 static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, const slm_solve_opts* opts,
                       slm_solve_stats* stats, bool shared_path) {
   if (!ds || !lanes) return fail(SLM_ERR_BAD_ARG, "NULL argument");
   if (n_lanes < 1 || n_lanes > kMaxLanes)
     return fail(SLM_ERR_BAD_ARG, "n_lanes must be in [1, %d] (got %d)", kMaxLanes, n_lanes);
   const int B = n_lanes;
-  if (!ds->gk[B - 1])
+  const bool split = ws_policy(ds, opts ? opts->flags : 0u) == 2 && ds->sk != nullptr;
+  if (!split && !ds->gk[B - 1])
     return fail(SLM_ERR_UNSUPPORTED, "no %d-lane gradient kernel covers p = %lld", B, (long long)ds->p);
   int64_t total_points = 0;
   bool any_rw = false, any_gn = false;
@@ -1148,6 +1276,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       h[l].pt_lo = (int32_t)off;
       h[l].n_points = (int32_t)(off + ln.n_points);
     }
+    h[l].zzero = ln.beta0 ? 0 : 1;
     h[l].mode = (o.flags & SLM_FLAG_FISTA_ONLY) ? 0 : 1;
     h[l].ak = 1.25 * L[l];  // a slightly short first step; the scheme measures its own curvature after it
     h[l].Lhat = 0.5 * L[l];  // a sure lower bound of lambda_max for the residual scaling
@@ -1198,12 +1327,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   WsArgs wa;
   memset(&wa, 0, sizeof(wa));
   {
-    const char* env = getenv("SLM_WS");
-    const bool big = (double)n * (double)ld >= 67108864.0;  // 2^26 doubles = 512 MiB
-    const bool possible = !(eng->comm || ds->max_group > 64 || n < 4) &&
-                          !((env && env[0] == '0') || (o.flags & SLM_FLAG_NO_WORKING_SET));
-    use_ws = possible && (big || (o.flags & SLM_FLAG_WORKING_SET) || (env && env[0] == '1'));
-    ws_late = possible && !use_ws;
+    const int pol = ws_policy(ds, o.flags);
+    use_ws = pol == 2;
+    ws_late = pol == 1;
   }
   auto ws_setup = [&]() -> int {
     const int n_sets = (any_rw || custom_scale) ? B : 1;
@@ -1257,6 +1383,13 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     return SLM_OK;
   };
   if (use_ws) SLM_TRY(ws_setup());
+  const int* done_flag = &ds->gctl->done;
+  // the gradient of one pass: split pass (eight lane slots, residuals from the gathered columns where
+  // possible) when the working set runs from the start, the fused kernel otherwise
+  auto enqueue_pass_gradient = [&](hipEvent_t e0, hipEvent_t e1) -> int {
+    if (split) return enqueue_gradient_split(ds, ls, ds->y, done_flag, ds->ctl, &wa, e0, e1);
+    return enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1);
+  };
   // everything that follows the gradient of one pass
   auto enqueue_after_gradient = [&]() {
     launch_tail(ta, s);
@@ -1287,7 +1420,6 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   int slot = 0;
   bool pending[2] = {false, false};
   bool done = false;
-  const int* done_flag = &ds->gctl->done;
 
   // Optional hipGraph replay of a chunk (SLM_GRAPH=1): the chunk of iterations + the status copy is
   // captured once per solve into two graphs (one per status slot).  OFF by default: measured on
@@ -1308,7 +1440,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         }
         int rc = SLM_OK;
         for (int i = 0; i < chunk && rc == SLM_OK; ++i) {
-          rc = enqueue_gradient(ds, ls, ds->y, done_flag, nullptr, nullptr);
+          rc = enqueue_pass_gradient(nullptr, nullptr);
           enqueue_after_gradient();
         }
         hipError_t e1 = hipMemcpyAsync(&ds->hctl[k].g, ds->gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, s);
@@ -1355,7 +1487,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
           e0 = ds->prof[2 * slot_id];
           e1 = ds->prof[2 * slot_id + 1];
         }
-        SLM_TRY(enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1));
+        SLM_TRY(enqueue_pass_gradient(e0, e1));
         enqueue_after_gradient();
         ++enq;
       }
@@ -1453,7 +1585,7 @@ extern "C" int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, con
   if (!ds || !points || !betas_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
   if (n_points <= 0) return fail(SLM_ERR_BAD_ARG, "n_points must be positive");
   int B = std::max(1, std::min<int>(std::min<int>(n_lanes, kMaxLanes), n_points));
-  while (B > 1 && !ds->gk[B - 1]) --B;  // no kernel variant for (p, B): fewer lanes
+  B = std::min(B, max_lanes_for(ds, opts ? opts->flags : 0u));  // no kernel variant for (p, B): fewer lanes
   slm_lane lanes[SLM_MAX_LANES];
   memset(lanes, 0, sizeof(lanes));
   int64_t lo = 0;

@@ -1,0 +1,396 @@
+// Split gradient pass for working-set solves: residuals first, then ONE stream over X for X^T r.
+//
+// With the working-set refinement (ws_kernels.hpp) nearly every point a lane asks the gradient at is
+// supported on W, the <= 256 columns already gathered into the compact matrix XW.  Its residual
+// r = W (X z - y) then needs only XW (n x K, a few tens of MB), and the pass over X reduces to the
+// second half of the fused kernel, g = X^T r / n.  That half keeps only the accumulators in
+// registers (4C VGPRs per lane instead of the fused kernel's 8C for z + accumulators), so EIGHT lanes
+// share one read of X where the fused kernel tops out at four, and its row loop has no dot product,
+// no cross-wave exchange and no barrier at all.
+//
+//   resid_ws_kernel      R[i][l] = w_l,i (XW_i . zW_l - y_i)      lanes whose z is supported on W
+//   rowdot_ring_kernel   R[i][l] = w_l,i (x_i . z_l - y_i)        the others (reads X; returns at once
+//                                                                 when there are none)
+//   xtr_ring_kernel      partial[blk][l][:] = sum_{i in blk} R[i][l] x_i     (reads X once)
+//
+// All three use the same contiguous row blocks as the fused kernels, so reduce_partials_kernel and
+// everything after it are unchanged.  R is lane-minor ([n][8]) so a row's eight residuals are one
+// 64-byte scalar load.  Reference counterpart: the `X @ beta` inside the cvxpy objective
+// (src/sparselm/model/_lasso.py:109-121), as for the fused kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "grad_kernel.hpp"
+#include "tail_kernels.hpp"
+#include "ws_kernels.hpp"
+
+namespace slm {
+
+constexpr int SPLIT_LANES = 8;  // lane-minor stride of R
+
+struct SplitArgs {
+  const double* X;
+  const double* y;
+  const double* rw;      // row weights (nullptr = ones); lane l uses rw + l * rw_stride
+  int64_t rw_stride;
+  const double* z;       // [n_lanes][ld]
+  double* R;             // [n][SPLIT_LANES] weighted residuals
+  double* partial;       // [nblk][B][ld]
+  double* loss_partial;  // [nblk][B]   sum_i w e^2 of the block
+  const int* done;
+  const PathCtl* ctl;    // nullptr => every lane takes its residual from X (slm_gradient, tests)
+  const double* XW;      // [n][WS_KCAP]
+  const int32_t* idx;    // [WS_KCAP]
+  const WsCtl* ws;
+  int64_t n, ld, rows_base, rows_rem;
+  int p2;
+  int n_lanes;
+};
+
+// which lanes take their residual from XW: live, flagged by ws_solve_kernel, and W still published
+__device__ __forceinline__ unsigned split_ws_mask(const SplitArgs& a) {
+  if (a.ctl == nullptr || a.ws == nullptr || !a.ws->valid || a.ws->building) return 0u;
+  unsigned m = 0u;
+  for (int l = 0; l < a.n_lanes; ++l)
+    if (!a.ctl[l].done && !a.ctl[l].idle && a.ctl[l].zsup) m |= 1u << l;
+  return m;
+}
+__device__ __forceinline__ unsigned split_live_mask(const SplitArgs& a) {
+  unsigned m = 0u;
+  for (int l = 0; l < a.n_lanes; ++l)
+    if (a.ctl == nullptr || (!a.ctl[l].done && !a.ctl[l].idle)) m |= 1u << l;
+  return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// residuals from the gathered columns: one THREAD per row.  A thread walks its row of XW (K
+// contiguous doubles) while all threads of the workgroup read the same zW[k][0..7] from an LDS image
+// (broadcast reads), so a row costs K/2 16-byte loads + 8K FMAs and no cross-lane reduction.  (One
+// wavefront per row with eight DPP reductions per row measured 149 us; the rows of a wavefront are
+// 2 KiB apart here, but XW is small and the lines are fully used over the k loop.)
+// ---------------------------------------------------------------------------------------------
+template <int B>
+__global__ __launch_bounds__(256) void resid_ws_kernel(SplitArgs a) {
+  if (a.done != nullptr && *a.done != 0) return;
+  const unsigned mask = split_ws_mask(a);
+  if (mask == 0u) return;
+  __shared__ double zw[WS_KCAP][B];  // 16 KiB
+  __shared__ double lsum[4][B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.ws->K;  // multiple of 16; positions >= Kreal hold zero columns
+  const int64_t b = blockIdx.x;
+  const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
+  const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
+  for (int e = tid; e < K * B; e += 256) {
+    const int k = e / B, l = e - k * B;
+    const int j = a.idx[k];
+    zw[k][l] = (j >= 0 && l < a.n_lanes) ? a.z[(int64_t)l * a.ld + j] : 0.0;
+  }
+  __syncthreads();
+  double loss[B];
+#pragma unroll
+  for (int l = 0; l < B; ++l) loss[l] = 0.0;
+  for (int64_t i = tid; i < nrows; i += 256) {
+    const int64_t row = r0 + i;
+    const d2* xr = reinterpret_cast<const d2*>(a.XW + row * WS_KCAP);
+    double dot[B];
+#pragma unroll
+    for (int l = 0; l < B; ++l) dot[l] = 0.0;
+    for (int k = 0; k < K; k += 2) {
+      const d2 x = xr[k >> 1];
+#pragma unroll
+      for (int l = 0; l < B; ++l) {
+        dot[l] = __builtin_fma(x.x, zw[k][l], dot[l]);
+        dot[l] = __builtin_fma(x.y, zw[k + 1][l], dot[l]);
+      }
+    }
+    const double yi = a.y[row];
+    double res[B];
+#pragma unroll
+    for (int l = 0; l < B; ++l) {
+      const double m = a.rw ? a.rw[(int64_t)l * a.rw_stride + row] : 1.0;
+      const double e = dot[l] - yi;
+      res[l] = e * m;
+      loss[l] = __builtin_fma(res[l], e, loss[l]);
+    }
+    // only the lanes served here own their slot of R (the others belong to rowdot_ring_kernel)
+    if (mask == (1u << B) - 1u) {
+      d2* out = reinterpret_cast<d2*>(a.R + row * SPLIT_LANES);
+#pragma unroll
+      for (int l = 0; l < B; l += 2) out[l >> 1] = d2{res[l], res[l + 1]};
+    } else {
+#pragma unroll
+      for (int l = 0; l < B; ++l)
+        if ((mask >> l) & 1u) a.R[row * SPLIT_LANES + l] = res[l];
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < B; ++l) {
+    double t = loss[l];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (lane == 0) lsum[wave][l] = t;
+  }
+  __syncthreads();
+  if (tid < B && ((mask >> tid) & 1u))
+    a.loss_partial[b * B + tid] = lsum[0][tid] + lsum[1][tid] + lsum[2][tid] + lsum[3][tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+// residuals from X for the lanes the kernel above does not serve: the first half of grad_ring_kernel
+// (same ring, same DPP reductions, one barrier per row for the cross-wave exchange)
+// ---------------------------------------------------------------------------------------------
+template <int W, int C, int B, int D>
+__global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
+  constexpr int T = W * 64;
+  constexpr int SLOT = T * C * 16;
+  constexpr int RING = (D + 1) * SLOT;
+  constexpr int RED = 2 * B * W * 8;
+  static_assert(RING + RED <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  static_assert(D * C < 64, "too many DMA loads in flight for vmcnt");
+  if (a.done != nullptr && *a.done != 0) return;
+  const unsigned mask = split_live_mask(a) & ~split_ws_mask(a);  // lanes served here
+  if (mask == 0u) return;
+
+  __shared__ __attribute__((aligned(16))) char smem[RING + RED];
+  double* red = reinterpret_cast<double*>(smem + RING);  // [2][B][W]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t b = blockIdx.x;
+  const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
+  const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
+
+  // Cold start: every lane served here still sits at z = 0 (PathCtl::zzero), so e = -y and X is
+  // not needed at all -- the first pass of a path costs one read of X, not two.
+  bool all_zero = a.ctl != nullptr;
+  if (all_zero) {
+    for (int l = 0; l < a.n_lanes; ++l)
+      if (((mask >> l) & 1u) && !a.ctl[l].zzero) all_zero = false;
+  }
+  if (all_zero) {
+    double ls[B];
+#pragma unroll
+    for (int l = 0; l < B; ++l) ls[l] = 0.0;
+    for (int64_t i = tid; i < nrows; i += T) {
+      const int64_t row = r0 + i;
+      const double e = -a.y[row];
+#pragma unroll
+      for (int l = 0; l < B; ++l) {
+        if ((mask >> l) & 1u) {
+          const double m = a.rw ? a.rw[(int64_t)l * a.rw_stride + row] : 1.0;
+          a.R[row * SPLIT_LANES + l] = e * m;
+          ls[l] = __builtin_fma(e * m, e, ls[l]);
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < B; ++l) {
+      double t = ls[l];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+      if (lane == 0) red[l * W + wave] = t;
+    }
+    __syncthreads();
+    if (tid < B && ((mask >> tid) & 1u)) {
+      double t = 0.0;
+      for (int w2 = 0; w2 < W; ++w2) t += red[tid * W + w2];
+      a.loss_partial[b * B + tid] = t;
+    }
+    return;
+  }
+
+  uint32_t coff[C];
+  d2 zr[B][C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int ci = c * T + tid;
+    const bool valid = ci < a.p2;
+    const int cc = valid ? ci : a.p2 - 1;
+    coff[c] = (uint32_t)cc * 16u;
+#pragma unroll
+    for (int l = 0; l < B; ++l) {
+      const d2 zz = l < a.n_lanes ? reinterpret_cast<const d2*>(a.z + (int64_t)l * a.ld)[cc] : d2{0.0, 0.0};
+      zr[l][c] = valid ? zz : d2{0.0, 0.0};
+    }
+  }
+  double loss[B];
+#pragma unroll
+  for (int l = 0; l < B; ++l) loss[l] = 0.0;
+
+  auto issue_row = [&](int64_t i, int slot) {
+    const char* rp = reinterpret_cast<const char*>(a.X + (r0 + i) * a.ld);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      char* dst = smem + slot * SLOT + (c * T + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)(rp + coff[c]), (lptr_t)dst, 16, 0, SLM_NT_LOADS ? 2 : 0);
+    }
+  };
+
+  if (nrows > 0) {
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      if (k < nrows) issue_row(k, k);
+    int slot = 0, slot_in = D;
+    for (int64_t i = 0; i < nrows; ++i) {
+      const int64_t left = nrows - 1 - i;
+      if (left >= D) {
+        issue_row(i + D, slot_in);
+        wait_vmcnt<D * C>();
+      } else {
+        if (D >= 3 && left == 2) wait_vmcnt<(D >= 3 ? 2 : 0) * C>();
+        else if (D >= 2 && left == 1) wait_vmcnt<(D >= 2 ? 1 : 0) * C>();
+        else wait_vmcnt<0>();
+      }
+      const int64_t row = r0 + i;
+      const uint64_t yi_bits = smem_load_u64(a.y + row);
+      d2 x[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        x[c] = *reinterpret_cast<const d2*>(smem + slot * SLOT + (c * T + tid) * 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const double yi = __longlong_as_double((long long)yi_bits);
+      double dot[B];
+#pragma unroll
+      for (int l = 0; l < B; ++l) {
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          t = __builtin_fma(x[c].x, zr[l][c].x, t);
+          t = __builtin_fma(x[c].y, zr[l][c].y, t);
+        }
+        dot[l] = wave_sum_lane63(t);
+        if constexpr (W == 1) dot[l] = read_lane63(dot[l]);
+      }
+      if constexpr (W > 1) {
+        const int parity = (int)(i & 1);
+        if (lane == 63) {
+#pragma unroll
+          for (int l = 0; l < B; ++l) red[(parity * B + l) * W + wave] = dot[l];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int l = 0; l < B; ++l) dot[l] = group_sum_all<W>(red[(parity * B + l) * W + (lane & (W - 1))]);
+      }
+      if (tid == 0) {
+#pragma unroll
+        for (int l = 0; l < B; ++l) {
+          if ((mask >> l) & 1u) {
+            const double m = a.rw ? a.rw[(int64_t)l * a.rw_stride + row] : 1.0;
+            const double e = dot[l] - yi;
+            const double res = e * m;
+            a.R[row * SPLIT_LANES + l] = res;
+            loss[l] = __builtin_fma(res, e, loss[l]);
+          }
+        }
+      }
+      slot = (slot == D) ? 0 : slot + 1;
+      slot_in = (slot_in == D) ? 0 : slot_in + 1;
+    }
+  }
+  if (tid == 0) {
+#pragma unroll
+    for (int l = 0; l < B; ++l)
+      if ((mask >> l) & 1u) a.loss_partial[b * B + l] = loss[l];
+  }
+}
+
+// 64-byte scalar load: the eight residuals of one row.  Caller waits lgkmcnt(0) before use.
+typedef uint32_t slm_u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ slm_u32x16 smem_load_64B(const double* p) {
+  slm_u32x16 v;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// g partials: acc[l][:] += R[row][l] * x_row.  Every wavefront streams its own chunks through the
+// LDS ring and reads only those back: no cross-wave traffic, no barrier in the row loop.  Measured at
+// n=100k, p=5k, 8 lanes: 0.614 ms (6.5 TB/s); a barrier per row (0.625 ms) or a third row in flight
+// (all 160 KiB of LDS, 0.653 ms) are slower; loading the residuals before the DMA wait gained 2 %.
+// ---------------------------------------------------------------------------------------------
+template <int W, int C, int B, int D>
+__global__ __launch_bounds__(W * 64) void xtr_ring_kernel(SplitArgs a) {
+  constexpr int T = W * 64;
+  constexpr int SLOT = T * C * 16;
+  constexpr int RING = (D + 1) * SLOT;
+  static_assert(RING <= 160 * 1024, "ring does not fit the 160 KiB LDS");
+  static_assert(D * C < 64, "too many DMA loads in flight for vmcnt");
+  static_assert(B <= SPLIT_LANES, "R holds eight lanes per row");
+  if (a.done != nullptr && *a.done != 0) return;
+
+  __shared__ __attribute__((aligned(16))) char smem[RING];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t b = blockIdx.x;
+  const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
+  const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
+
+  uint32_t coff[C];
+  bool valid[C];
+  d2 acc[B][C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int ci = c * T + tid;
+    valid[c] = ci < a.p2;
+    coff[c] = (uint32_t)(valid[c] ? ci : a.p2 - 1) * 16u;
+#pragma unroll
+    for (int l = 0; l < B; ++l) acc[l][c] = d2{0.0, 0.0};
+  }
+
+  auto issue_row = [&](int64_t i, int slot) {
+    const char* rp = reinterpret_cast<const char*>(a.X + (r0 + i) * a.ld);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      char* dst = smem + slot * SLOT + (c * T + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)(rp + coff[c]), (lptr_t)dst, 16, 0, SLM_NT_LOADS ? 2 : 0);
+    }
+  };
+
+  if (nrows > 0) {
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      if (k < nrows) issue_row(k, k);
+    int slot = 0, slot_in = D;
+    for (int64_t i = 0; i < nrows; ++i) {
+      // the row's residuals first: the scalar load then flies while the wave waits for its DMA chunks
+      const slm_u32x16 rb = smem_load_64B(a.R + (r0 + i) * SPLIT_LANES);
+      const int64_t left = nrows - 1 - i;
+      if (left >= D) {
+        issue_row(i + D, slot_in);
+        wait_vmcnt<D * C>();
+      } else {
+        if (D >= 3 && left == 2) wait_vmcnt<(D >= 3 ? 2 : 0) * C>();
+        else if (D >= 2 && left == 1) wait_vmcnt<(D >= 2 ? 1 : 0) * C>();
+        else wait_vmcnt<0>();
+      }
+      d2 x[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        x[c] = *reinterpret_cast<const d2*>(smem + slot * SLOT + (c * T + tid) * 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int l = 0; l < B; ++l) {
+        const double res = __hiloint2double((int)rb[2 * l + 1], (int)rb[2 * l]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          acc[l][c].x = __builtin_fma(res, x[c].x, acc[l][c].x);
+          acc[l][c].y = __builtin_fma(res, x[c].y, acc[l][c].y);
+        }
+      }
+      slot = (slot == D) ? 0 : slot + 1;
+      slot_in = (slot_in == D) ? 0 : slot_in + 1;
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < B; ++l) {
+    d2* out = reinterpret_cast<d2*>(a.partial + (b * B + l) * a.ld);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      if (valid[c]) out[c * T + tid] = acc[l][c];
+  }
+}
+
+}  // namespace slm

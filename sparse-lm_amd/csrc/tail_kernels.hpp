@@ -52,13 +52,20 @@ struct PathCtl {
   int32_t pt_lo;       // first point of the range being walked (secant starts need two solved points in it)
   int32_t steals;      // ranges this lane took over from busier lanes
   int32_t idle;        // shared-path mode: finished its range, waiting for steal_kernel to hand out work
-  int32_t pad_;
+  int32_t zzero;       // z has not moved from the all-zero start (split pass: residual = -y, no read of X)
+  int32_t pad2_;
+  int32_t zsup;        // z is zero outside the working set: its residual can come from the gathered
+                       // columns (split_kernels.hpp); maintained by ws_solve_kernel
 };
 
 constexpr int BB_HIST = 5;
 constexpr int BB_REJECT_LIMIT = 3;    // rejected candidates before a lane falls back to FISTA
 constexpr int BB_POINT_LIMIT = 60;    // spectral iterations on one point before falling back
 constexpr double BB_SIGMA = 1e-4;
+// Stopping rule floor: ||prox step|| <= kRoundFloor * ||g|| / curvature is the rounding noise of the
+// step itself (16 ulp of the gradient); below it `tol * ||beta||` cannot be met in fp64 when the
+// minimiser is itself a rounding-level number (alpha ~ alpha_max).
+constexpr double kRoundFloor = 16.0 * 2.220446049250313e-16;
 
 // One workgroup per lane (blockIdx.x): vectors of lane l start at l * ld (g: l * (ld + 16)).
 struct TailArgs {
@@ -308,7 +315,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     //  s[0] = ||z - beta||^2   s[1] = <z - beta, g - gbase>   s[2] = ||g - gbase||^2   s[3] = #non-finite g
     //  s[4] = penalty value at z (only computed at the start of a path point, when no candidate
     //         carried it over)
-    double s[5] = {0, 0, 0, 0, 0};
+    //  s[5] = ||g||^2 (rounding floor of the stopping rule)
+    double s[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       if (tid + e * TAIL_THREADS < p) {
@@ -317,6 +325,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
         s[1] = __builtin_fma(dz, dg, s[1]);
         s[2] = __builtin_fma(dg, dg, s[2]);
         if (!isfinite(gj[e])) s[3] += 1.0;
+        s[5] = __builtin_fma(gj[e], gj[e], s[5]);
       }
     }
     if (!have_base) {
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
         });
       }
     }
-    block_sum<5>(s, red);
+    block_sum<6>(s, red);
     const double Fz = loss_z + (have_base ? pen_z : s[4]);
     nonfinite = s[3] > 0.0 || !isfinite(Fz);
     bool accept;
@@ -428,14 +437,16 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       new_pen_z = q[2];
       resid = sqrt(q[0]) * fmax(1.0, new_ak / new_Lhat);
       bnorm = sqrt(q[1]);
-      conv = resid <= tol * fmax(bnorm, bnorm_floor);
+      // (second term: a prox step at the rounding level of the gradient itself cannot be improved)
+      conv = resid <= fmax(tol * fmax(bnorm, bnorm_floor), kRoundFloor * sqrt(s[5]) / fmin(new_ak, new_Lhat));
       finalize = nonfinite || conv || hit_max;
     }
   } else {
     // ================= FISTA scheme =================================================================
     //  s[0] = ||b+ - z||^2   s[1] = ||b+||^2   s[2] = (z - b+).(b+ - b)   s[3] = ||g - gprev||^2
     //  s[4] = ||z - zprev||^2   s[5] = ||z||^2   s[6] = #non-finite
-    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    //  s[7] = ||g||^2
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const double step = 1.0 / L;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -445,6 +456,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
         s[3] = __builtin_fma(dg, dg, s[3]);
         s[4] = __builtin_fma(dzz, dzz, s[4]);
         s[5] = __builtin_fma(zj[e], zj[e], s[5]);
+        s[7] = __builtin_fma(gj[e], gj[e], s[7]);
         a.gprev[j] = gj[e];
         a.zprev[j] = zj[e];
       }
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
         if (!isfinite(bn)) s[6] += 1.0;
       }
     }
-    block_sum<7>(s, red);
+    block_sum<8>(s, red);
     nonfinite = s[6] > 0.0 || !isfinite(s[0]) || !isfinite(s[1]) || !isfinite(loss_z);
     // Curvature guard: ||A dz|| / ||dz|| is a lower bound on lambda_max(A), A = X^T W X / n.  If it
     // exceeds L the step 1/L was too long: raise L, discard the step and restart from beta.
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     const double mom = (t_use - 1.0) / t_new;
     resid = sqrt(s[0]);
     bnorm = sqrt(s[1]);
-    conv = !l_bad && (resid <= tol * fmax(bnorm, bnorm_floor));
+    conv = !l_bad && (resid <= fmax(tol * fmax(bnorm, bnorm_floor), kRoundFloor * sqrt(s[7]) / L));
     finalize = nonfinite || conv || hit_max;
     new_t = l_bad ? 1.0 : t_new;
 #pragma unroll
@@ -537,6 +549,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
 
   // ---- control block ----------------------------------------------------------------------------
   if (tid == 0) {
+    ctl->zzero = 0;  // (z was just rewritten)
     ctl->total_iter = total_iter + 1;
     ctl->L = new_L;
     ctl->mode = new_mode;
@@ -619,6 +632,7 @@ __global__ __launch_bounds__(256) void steal_kernel(TailArgs a) {
         me->n_points = hi;
         me->steals += 1;
         me->idle = 0;
+        me->zzero = 1;  // cold start: the tail kernel zeroed z when the lane went idle
         took[l] = 1;
       } else {
         me->idle = 0;

@@ -503,8 +503,7 @@ __global__ __launch_bounds__(256) void ws_gram_reduce_kernel(WsArgs w) {
 // Thread 4k + q works on working-set position k (q = 0..3 split the matrix-vector product).  Up to
 // WS_KLDS columns the Gram is copied into LDS first, so an inner iteration never leaves the CU.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs w) {
-  __shared__ double red[8][TAIL_WAVES];
+__device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, double (*red)[TAIL_WAVES]) {
   __shared__ double delta[WS_KCAP];
   __shared__ double uim[WS_KCAP];
   __shared__ int nz[WS_KCAP];
@@ -513,7 +512,6 @@ __global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
   WsCtl* ws = w.ws;
-  if (ctl->done != 0 || ctl->idle != 0 || a.gdone[0] != 0) return;
   if (!ws->valid || ws->building || ws->disabled) return;
   const int tid = threadIdx.x;
   const int p = a.p;
@@ -752,11 +750,33 @@ __global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs
   if (tid == 0) {
     if (mode == 1) ctl->have_base = 0;  // the refined point becomes the base of the spectral scheme
     else ctl->t = 1.0;
+    ctl->zzero = 0;
     ws->last_point[lane_id] = point_now;
     ws->repeats[lane_id] = reps + 1;
     if (L > ws->Lw[set]) ws->Lw[set] = L;
     atomicAdd(&ws->refined, 1);
   }
+}
+
+__global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs w) {
+  __shared__ double red[8][TAIL_WAVES];
+  const int lane_id = blockIdx.x;
+  PathCtl* ctl = a.ctl + lane_id;
+  if (ctl->done != 0 || ctl->idle != 0 || a.gdone[0] != 0) return;
+  ws_refine_lane(a, w, red);  // (every return inside is taken by the whole workgroup)
+  __syncthreads();
+  // Is the point the next pass evaluates zero outside W?  Then its residual needs only the gathered
+  // columns (resid_ws_kernel) and the pass over X is the accumulate-only xtr_ring_kernel.
+  const WsCtl* ws = w.ws;
+  const bool w_ok = ws->valid && !ws->building && !ws->disabled;
+  double out[1] = {0.0};
+  if (w_ok) {
+    const double* z = a.z + (int64_t)lane_id * a.ld;
+    for (int j = threadIdx.x; j < a.p; j += WS_THREADS)
+      if (w.pos[j] < 0 && z[j] != 0.0) out[0] += 1.0;
+  }
+  block_sum<1>(out, red);
+  if (threadIdx.x == 0) ctl->zsup = (w_ok && out[0] == 0.0) ? 1 : 0;
 }
 
 }  // namespace slm

@@ -225,3 +225,46 @@ def test_easy_small_problem_stays_plain(eng):
     with eng.dataset(X, y) as ds:
         r = ds.solve_path([(0.1, 0, 0)], tol=1e-8)
     assert r.converged and r.ws_builds == 0 and r.grad_launches < 48
+
+
+@pytest.mark.parametrize("lanes", [5, 8])
+def test_eight_lane_split_pass_path_matches_oracle(eng, lanes):
+    # working set from the first pass => the split pass with eight lane slots (residuals from the
+    # gathered columns, accumulate-only stream over X)
+    n, p = 4000, 900
+    X, y = problem(n, p, 14, seed=77)
+    alphas = alpha_path(X, y, k=24, lo=1e-2)
+    pts = [(a, 0, 0) for a in alphas]
+    with eng.dataset(X, y) as ds:
+        r8 = ds.solve_path(pts, tol=1e-11, lanes=lanes, flags=WS)
+        r1 = ds.solve_path(pts, tol=1e-11, lanes=1, flags=NO_WS)
+    assert r8.converged and r8.ws_refined > 0
+    assert rel_inf(r8.betas, r1.betas) < 1e-8
+    for k in (5, 23):
+        assert rel_inf(r8.betas[k], ofista(X, y, alphas[k] * np.ones(p))) < 1e-8
+    assert r8.grad_launches <= len(alphas) // lanes + 8
+
+
+def test_split_pass_with_fold_masks_and_groups(eng):
+    # six CV-fold lanes with their own row masks and Grams, sparse-group penalty, shuffled groups
+    n, G, size = 3000, 30, 5
+    p = G * size
+    groups = np.random.default_rng(9).permutation(np.repeat(np.arange(G), size))
+    X, y = problem(n, p, 4, seed=13, groups=groups)
+    fold = np.random.default_rng(1).integers(0, 6, n)
+    alphas = alpha_path(X, y, k=6, lo=5e-2, groups=groups, G=G)
+    lanes = []
+    for f in range(6):
+        m = (fold != f).astype(float)
+        lanes.append(dict(points=[(0.3 * a, 0.7 * a, 0) for a in alphas], row_weight=m, n_eff=int(m.sum())))
+    with eng.dataset(X, y) as ds:
+        ds.set_groups(groups, G)
+        res = ds.solve_lanes(lanes, tol=1e-11, flags=WS)
+        res0 = ds.solve_lanes(lanes[:4], tol=1e-11, flags=NO_WS)
+    for f in range(6):
+        assert res[f].converged
+        tr = fold != f
+        ref = ofista(X[tr], y[tr], 0.3 * alphas[-1] * np.ones(p), 0.7 * alphas[-1] * np.ones(G), None, groups, G)
+        assert rel_inf(res[f].betas[-1], ref) < 1e-8
+    for f in range(4):
+        assert rel_inf(res[f].betas, res0[f].betas) < 1e-8
