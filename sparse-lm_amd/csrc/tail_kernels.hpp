@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "../../include/slm_engine.h"
+#include "grad_kernel.hpp"  // DPP reductions
 
 namespace slm {
 
@@ -105,19 +106,18 @@ __device__ __forceinline__ double soft(double v, double thr) {
 }
 
 // Sum NV values over the 1024-thread workgroup; every thread gets bit-identical totals.
-// Stage 1: 64-wide xor butterfly per wavefront.  Stage 2: the 16 wavefront partials go through LDS
-// and every 16-lane group folds them with a 16-wide xor butterfly (commutative pairing => the same
-// bits in every lane).
+// Stage 1: DPP scan per wavefront (wave_sum_lane63: no LDS round trips).  Stage 2: the 16 wavefront
+// totals go through LDS, every wavefront scans them in its first row of 16 lanes with the same DPP
+// pattern and broadcasts lane 15 (v_readlane), so all threads hold the same bits.  (The first version used 64- and 16-wide xor butterflies of
+// ds_bpermute: ten dependent LDS round trips per value; this one took the tail kernel from 24 us to
+// the figure in DESIGN.md.)
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double (*lds)[TAIL_WAVES]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < NV; ++k) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
-  }
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum_lane63(v[k]);
   __syncthreads();  // protect lds from the previous use
-  if (lane == 0) {
+  if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) lds[k][wave] = v[k];
   }
@@ -125,9 +125,13 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double (*lds)[TAIL_WA
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     double t = lds[k][lane & (TAIL_WAVES - 1)];
-#pragma unroll
-    for (int off = TAIL_WAVES / 2; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-    v[k] = t;
+    t = dpp_add<0x111, 0xf>(t);  // inclusive scan inside the row of 16 lanes: lane 15 gets the total
+    t = dpp_add<0x112, 0xf>(t);
+    t = dpp_add<0x114, 0xf>(t);
+    t = dpp_add<0x118, 0xf>(t);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(t), 15);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(t), 15);
+    v[k] = __hiloint2double(hi, lo);
   }
 }
 

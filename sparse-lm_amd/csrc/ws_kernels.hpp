@@ -428,6 +428,7 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
     for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = ws_d4{0.0, 0.0, 0.0, 0.0};
 
   const int kk = lane >> 4, c = lane & 15;
+#pragma unroll 4
   for (int64_t s = 0; s < nrows; s += 4) {
     const int64_t i = s + kk;
     const bool ok = i < nrows;
