@@ -732,7 +732,7 @@ static LaneSetup default_lanes(slm_dataset* ds, int B) {
 // grad -> reduce (-> all-reduce) for B lanes on ONE pass over X:
 // g_l = X^T W_l (X z_l - y) / n_eff_l in ds->g + l*(ld+16), loss_l in g_l[ld].
 static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done,
-                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+                            hipEvent_t ev_start, hipEvent_t ev_stop, int64_t n_rows = 0) {
   hipStream_t s = ds->eng->stream;
   const int B = ls.B;
   const GradKernel* gk = ds->gk[B - 1];
@@ -746,10 +746,11 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
   a.partial = ds->partial;
   a.loss_partial = ds->loss_partial;
   a.done = done;
-  a.n = ds->n;
+  const int64_t nr = n_rows > 0 ? n_rows : ds->n;  // n_rows: only the first rows (sketched Lipschitz bound)
+  a.n = nr;
   a.ld = ds->ld;
-  a.rows_base = ds->n / nblk;
-  a.rows_rem = ds->n % nblk;
+  a.rows_base = nr / nblk;
+  a.rows_rem = nr % nblk;
   a.rw_stride = ls.rw_stride;
   a.p2 = (int)(ds->ld / 2);
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
@@ -758,7 +759,7 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
   } else {  // two-pass fallback (one lane; row weights shared)
     TwoPassArgs t;
     t.X = ds->X; t.y = y; t.rw = ls.rw; t.z = ds->z; t.r = ds->rvec; t.partial = ds->partial;
-    t.loss_partial = ds->loss_partial; t.done = done; t.n = ds->n; t.ld = ds->ld;
+    t.loss_partial = ds->loss_partial; t.done = done; t.n = nr; t.ld = ds->ld;
     t.rows_base = a.rows_base; t.rows_rem = a.rows_rem; t.p2 = a.p2;
     hipLaunchKernelGGL(rowdot_kernel, dim3(nblk), dim3(256), 0, s, t);
     const unsigned tiles = (unsigned)((a.p2 + 512 * kTwoPassC - 1) / (512 * kTwoPassC));
@@ -791,7 +792,7 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
 // of X.  ctl == nullptr: every lane takes its residual from X (slm_gradient with SLM_GRAD_SPLIT=1).
 static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done,
                                   const PathCtl* ctl, const WsArgs* wa, hipEvent_t ev_start,
-                                  hipEvent_t ev_stop) {
+                                  hipEvent_t ev_stop, int64_t n_rows = 0) {
   hipStream_t s = ds->eng->stream;
   const SplitKernel* sk = ds->sk;
   const int nblk = ds->split_nblk;
@@ -804,7 +805,8 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
   a.X = ds->X; a.y = y; a.rw = ls.rw; a.rw_stride = ls.rw_stride; a.z = ds->z; a.R = ds->R;
   a.partial = ds->partial; a.loss_partial = ds->loss_partial; a.done = done; a.ctl = ctl;
   if (wa) { a.XW = wa->XW; a.idx = wa->idx; a.ws = wa->ws; }
-  a.n = ds->n; a.ld = ds->ld; a.rows_base = ds->n / nblk; a.rows_rem = ds->n % nblk;
+  const int64_t nr = n_rows > 0 ? n_rows : ds->n;
+  a.n = nr; a.ld = ds->ld; a.rows_base = nr / nblk; a.rows_rem = nr % nblk;
   a.p2 = (int)(ds->ld / 2);
   a.n_lanes = ls.B;
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
@@ -868,18 +870,31 @@ static int check_launch() {
 // magnitude (it measures curvature along its own steps) and FISTA's curvature guard repairs an
 // under-estimate, so a handful of passes is enough; slm_dataset_lipschitz() asks for more.
 static const int kPowerItersSolve = 2;
+static const int kPowerItersSketch = 4;  // on an eighth of the rows (working-set solves)
 static const int kPowerItersQuery = 16;
 
-static int power_iteration(slm_dataset* ds, const LaneSetup& ls, double* L_out /*[B]*/, int iters) {
+// n_rows > 0: the operator of the first n_rows rows only, X_S^T W X_S / (n_eff n_rows / n).  Its largest
+// eigenvalue is, in expectation, no smaller than that of the full operator (Jensen: lambda_max is
+// convex and E G_S = G for exchangeable rows), so it serves as a cheap step-size bound where the
+// iteration does not depend on a tight one (working-set solves); the curvature guards cover the rest.
+static int power_iteration(slm_dataset* ds, const LaneSetup& ls_in, double* L_out /*[B]*/, int iters,
+                           int64_t n_rows = 0) {
+  LaneSetup ls = ls_in;
+  if (n_rows > 0) {
+    for (int l = 0; l < kMaxLanes; ++l) {
+      const double ne = ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global;
+      ls.n_eff[l] = ne * (double)n_rows / (double)ds->n;
+    }
+  }
   hipStream_t s = ds->eng->stream;
   if (const char* env = getenv("SLM_POWER_ITERS")) iters = std::max(2, atoi(env));
   hipLaunchKernelGGL(power_init_kernel, dim3(ls.B), dim3(TAIL_THREADS), 0, s, ds->z, (int)ds->p, ds->ld);
   for (int k = 0; k < iters; ++k) {
     if (ds->gk[ls.B - 1]) {
-      SLM_TRY(enqueue_gradient(ds, ls, ds->yzero, nullptr, nullptr, nullptr));
+      SLM_TRY(enqueue_gradient(ds, ls, ds->yzero, nullptr, nullptr, nullptr, n_rows));
     } else {  // more lanes than the fused kernels serve (working-set solves): the split pass has eight
       if (!ds->sk) return fail(SLM_ERR_UNSUPPORTED, "no %d-lane kernel for p = %lld", ls.B, (long long)ds->p);
-      SLM_TRY(enqueue_gradient_split(ds, ls, ds->yzero, nullptr, nullptr, nullptr, nullptr, nullptr));
+      SLM_TRY(enqueue_gradient_split(ds, ls, ds->yzero, nullptr, nullptr, nullptr, nullptr, nullptr, n_rows));
     }
     PowerArgs pa;
     pa.g = ds->g;
@@ -1215,7 +1230,15 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   } else {
     const auto t0 = std::chrono::steady_clock::now();
     bool ran = false;
-    if (any_rw || custom_scale) {
+    // working-set solves barely use L (first candidate, fallback steps): a bound from the first eighth
+    // of the rows, four power steps, costs a quarter of the two full passes
+    const bool sketch = ws_policy(ds, o.flags) == 2 && n >= 65536 && !getenv("SLM_NO_L_SKETCH");
+    if (sketch && !(ds->L_valid && !(o.flags & SLM_FLAG_FRESH_L) && !any_rw && !custom_scale)) {
+      SLM_TRY(power_iteration(ds, (any_rw || custom_scale) ? ls : default_lanes(ds, 1), L, kPowerItersSketch, n / 8));
+      if (!(any_rw || custom_scale))
+        for (int l = 1; l < B; ++l) L[l] = L[0];
+      ran = true;
+    } else if (any_rw || custom_scale) {
       SLM_TRY(power_iteration(ds, ls, L, kPowerItersSolve));  // lane-specific operators: not cached
       ran = true;
     } else {
@@ -1333,7 +1356,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   }
   auto ws_setup = [&]() -> int {
     const int n_sets = (any_rw || custom_scale) ? B : 1;
-    const int ws_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n / 64));
+    const int ws_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n / 64));  // (2 MiB of partials each)
     if (!ds->ws_ctl) {
       SLM_TRY(dalloc(&ds->ws_ctl, 1));
       SLM_TRY(dalloc(&ds->ws_idx, WS_KCAP));
@@ -1371,7 +1394,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     // theta 0.85 / look-ahead 2 / 16 newcomers per pass / 112 initial columns was the fastest
     wa.lookahead = 2;
     wa.append_max = 16;
-    wa.k_init = 112;
+    wa.k_init = ds->singleton ? 112 : 256;  // groups bring their features in blocks (config 3: 12.4 vs 29.6 ms per path)
     // tuning knobs (tools/ws_sweep.py)
     if (const char* th = getenv("SLM_WS_THETA")) {
       const double v = atof(th);
@@ -1397,9 +1420,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (use_ws) {
       hipLaunchKernelGGL(ws_select_kernel, dim3(1), dim3(WS_THREADS), 0, s, ta, wa);
       hipLaunchKernelGGL(ws_gather_kernel, dim3((unsigned)(eng->cus * 8)), dim3(256), 0, s, wa);
-      hipLaunchKernelGGL(ws_gram_kernel, dim3((unsigned)wa.nblk, (unsigned)wa.n_sets, 2), dim3(WS_GRAM_THREADS), 0, s,
+      hipLaunchKernelGGL(ws_gram_kernel, dim3((unsigned)wa.nblk, (unsigned)wa.n_sets, 8), dim3(WS_GRAM_THREADS), 0, s,
                          wa);
-      hipLaunchKernelGGL(ws_gram_reduce_kernel, dim3(WS_KCAP * WS_KCAP / 256, (unsigned)wa.n_sets), dim3(256),
+      hipLaunchKernelGGL(ws_gram_reduce_kernel, dim3(WS_TILES * WS_TILES, (unsigned)wa.n_sets), dim3(256),
                          0, s, wa);
       hipLaunchKernelGGL(ws_solve_kernel, dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
     }

@@ -4,7 +4,7 @@
 // known (the fused pass just delivered it), the gradient at any b that differs from z0 only on a
 // small column set W is exact without touching X again:
 //
-//     grad f(b)_W = g0_W + G_WW (b - z0)_W,        G_WW = X_W^T diag(w) X_W / n     (K x K, K <= 256)
+//     grad f(b)_W = g0_W + G_WW (b - z0)_W,        G_WW = X_W^T diag(w) X_W / n     (K x K, K <= 512)
 //
 // The kernels below (i) pick W on the device (every coefficient that is non-zero in any lane plus the
 // features / groups whose gradient is within a factor theta of entering at the loosest penalty of
@@ -29,8 +29,9 @@
 
 namespace slm {
 
-constexpr int WS_KCAP = 256;        // capacity of the working set (leading dimension of G and XW)
+constexpr int WS_KCAP = 512;        // capacity of the working set (leading dimension of G and XW)
 constexpr int WS_KLDS = 128;        // up to this many columns the Gram lives in LDS during the model solve
+constexpr int WS_TILES = WS_KCAP / 16; // 16x16 tiles per side of the Gram
 constexpr int WS_THREADS = 1024;
 constexpr int WS_INNER_MAX = 400;   // inner iterations per refinement
 constexpr double WS_INNER_TOL = 0.05;  // inner stop: residual <= WS_INNER_TOL * tol * ||b||
@@ -66,7 +67,7 @@ struct WsArgs {
   int32_t* gl;     // [WS_KCAP] members of k's group
   double* score;   // [ld] scratch: entry score per item
   double* XW;      // [n][WS_KCAP] gathered columns
-  double* part;    // [nblk][n_sets][WS_KCAP * WS_KCAP] partial Grams
+  double* part;    // [n_sets][tile][nblk][16 x 16] partial Grams
   double* Gm;      // [n_sets][WS_KCAP * WS_KCAP]
   const double* X;
   int64_t n, ld;
@@ -282,10 +283,11 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
   if (append) {
     // newcomers: at most w.append_max per pass, the likeliest first (a feature left out that enters
     // anyway shows up as a miss and is appended then)
-    if (sweep[0] <= (double)w.append_max) {
+    const double cap = (double)(miss ? 4 * w.append_max : w.append_max);  // a lane is stuck: be generous
+    if (sweep[0] <= cap) {
       n_sel = sweep[0];
     } else {
-      thr = fit_threshold(w.theta, true, (double)w.append_max, &n_sel);
+      thr = fit_threshold(w.theta, true, cap, &n_sel);
     }
     if (n_sel == 0.0) {  // (requested with a valid W and nothing to add)
       if (tid == 0) ws->request = 0;
@@ -391,10 +393,11 @@ __global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// (iii) partial Grams with v_mfma_f64_16x16x4_f64.  Grid (nblk, n_sets, 2); 8 wavefronts per
-// workgroup laid out 4 x 2, wavefront (wi, wj) owning the 4 x 4 block of 16x16 output tiles
-// I = 4 wi + ti, J = 8 h + 4 wj + tj (h = blockIdx.z: a workgroup covers 256 x 128; 16 accumulator
-// tiles = 128 registers per lane, which is why it is not one 1024-thread workgroup).  Only the tile
+// (iii) partial Grams with v_mfma_f64_16x16x4_f64.  Grid (nblk, n_sets, 8); 8 wavefronts per
+// workgroup laid out 4 x 2, each owning a 4 x 4 block of 16x16 output tiles, so a workgroup covers
+// 256 x 128 of the 512 x 512 capacity and blockIdx.z picks which (2 row halves x 4 column quarters;
+// workgroups beyond K return at once).  16 accumulator tiles = 128 registers per lane, which is why
+// it is not one 1024-thread workgroup.  Only the tile
 // rows that hold new positions (I >= k_new / 16) are computed; the reduce kernel mirrors them into
 // the columns.  Operand maps (guide "Fragment layout"): lane l holds A[i = l & 15][k = l >> 4] and
 // B[k = l >> 4][j = l & 15]; result register r of lane l is D[row (l >> 4) + 4 r][col l & 15].  Here
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
   const int tile_lo = w.ws->k_new >> 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wi = wave >> 1, wj = 2 * (int)blockIdx.z + (wave & 1);
+  const int wi = 4 * ((int)blockIdx.z >> 2) + (wave >> 1), wj = 2 * ((int)blockIdx.z & 3) + (wave & 1);
   const int tiles = K >> 4;
   const int ti_lo = max(0, tile_lo - 4 * wi);                       // first tile row of this wave to do
   const int nti = min(4, max(0, tiles - 4 * wi)), ntj = min(4, max(0, tiles - 4 * wj));
@@ -450,45 +453,58 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
       }
     }
   }
-  double* out = w.part + ((int64_t)b * w.n_sets + set) * (WS_KCAP * WS_KCAP);
+  // partials are stored tile by tile, the row blocks of one tile next to each other:
+  // part[set][tile (I, J)][b][16 x 16] -- the reduce kernel then walks 2 KiB strides, not 2 MiB ones
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti) {
     if (ti < ti_lo || ti >= nti) continue;
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj) {
       if (tj >= ntj) continue;
+      const int64_t tile = (int64_t)(4 * wi + ti) * WS_TILES + (4 * wj + tj);
+      double* out = w.part + (((int64_t)set * (WS_TILES * WS_TILES) + tile) * w.nblk + b) * 256;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gi = 16 * (4 * wi + ti) + kk + 4 * r, gj = 16 * (4 * wj + tj) + c;
-        out[gi * WS_KCAP + gj] = acc[ti][tj][r];
-      }
+      for (int r = 0; r < 4; ++r) out[(kk + 4 * r) * 16 + c] = acc[ti][tj][r];
     }
   }
 }
 
 // fixed-order sum of the partial Grams, scaled by 1/n_set: the new tile rows and, mirrored, the
-// matching columns of the old part; the last workgroup publishes the Gram
+// matching columns of the old part.  One workgroup per 16x16 tile (grid (WS_TILES^2, n_sets)); the
+// last workgroup publishes the Gram.
 __global__ __launch_bounds__(256) void ws_gram_reduce_kernel(WsArgs w) {
   WsCtl* ws = w.ws;
   if (!ws->building) return;
   const int K = ws->K;
   const int row_lo = (ws->k_new >> 4) << 4;
   const int set = blockIdx.y;
-  const int e = blockIdx.x * 256 + threadIdx.x;  // element of the KCAP x KCAP matrix
-  const int i = e / WS_KCAP, j = e % WS_KCAP;
-  if (i >= row_lo && i < K && j < K) {
-    double s = 0.0;
-#pragma unroll 8
-    for (int b = 0; b < w.nblk; ++b) s += w.part[((int64_t)b * w.n_sets + set) * (WS_KCAP * WS_KCAP) + e];
-    s *= w.inv_n[set];
+  const int tile = blockIdx.x, I = tile / WS_TILES, J = tile % WS_TILES;
+  const int tiles = K >> 4, I_lo = row_lo >> 4;
+  if (I < I_lo || I >= tiles || J >= tiles) return;  // (only the working tiles take part in the count below)
+  const int i = 16 * I + (threadIdx.x >> 4), j = 16 * J + (threadIdx.x & 15);
+  {
+    const double* src = w.part + (((int64_t)set * (WS_TILES * WS_TILES) + tile) * w.nblk) * 256 + threadIdx.x;
+    // four interleaved chains, 32 loads in flight per thread (the loop is latency-bound); the order
+    // of additions is fixed, so the result is reproducible
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    int b = 0;
+    for (; b + 32 <= w.nblk; b += 32) {
+      double v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v[u] = src[(int64_t)(b + u) * 256];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) s4[u & 3] += v[u];
+    }
+    for (; b < w.nblk; ++b) s4[b & 3] += src[(int64_t)b * 256];
+    double s = ((s4[0] + s4[1]) + (s4[2] + s4[3])) * w.inv_n[set];
     double* Gs = w.Gm + (int64_t)set * (WS_KCAP * WS_KCAP);
-    Gs[e] = s;
+    Gs[i * WS_KCAP + j] = s;
     if (j < row_lo) Gs[j * WS_KCAP + i] = s;
   }
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int total = gridDim.x * gridDim.y;
+    const int total = (tiles - I_lo) * tiles * (int)gridDim.y;
     if (atomicAdd(&ws->counter, 1) + 1 == total) {
       ws->counter = 0;
       ws->request = 0;
@@ -501,7 +517,8 @@ __global__ __launch_bounds__(256) void ws_gram_reduce_kernel(WsArgs w) {
 
 // ---------------------------------------------------------------------------------------------
 // (iv) refinement: one workgroup per lane minimises the penalised quadratic model over W.
-// Thread 4k + q works on working-set position k (q = 0..3 split the matrix-vector product).  Up to
+// Threads TPC k + q work on working-set position k (q splits the matrix-vector product; TPC = 4, or 2
+// beyond 256 positions).  Up to
 // WS_KLDS columns the Gram is copied into LDS first, so an inner iteration never leaves the CU.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, double (*red)[TAIL_WAVES]) {
@@ -552,7 +569,10 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     }
   }
 
-  const int k = tid >> 2, q = tid & 3;
+  // 4 threads per position up to 256 positions, 2 beyond (1024 threads, WS_KCAP = 512)
+  const int tsh = K <= 256 ? 2 : 1;
+  const int TPC = 1 << tsh;
+  const int k = tid >> tsh, q = tid & (TPC - 1);
   const int j = k < K ? w.idx[k] : -1;
   const bool live = j >= 0;
   const bool mine = live && q == 0;  // the thread that accounts for position k in reductions
@@ -576,12 +596,12 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     if (g_lds) {
       if (k < K) {
 #pragma unroll 4
-        for (int c = q; c < K; c += 4) acc = __builtin_fma(Gl[c * K + k], delta[c], acc);
+        for (int c = q; c < K; c += TPC) acc = __builtin_fma(Gl[c * K + k], delta[c], acc);
       }
     } else if (dense) {
       if (k < K) {
 #pragma unroll 4
-        for (int c = q; c < K; c += 4) acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
+        for (int c = q; c < K; c += TPC) acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
       }
     } else {
       if (tid < 64) {  // compact list of the non-zero entries (wave 0, ballots)
@@ -599,14 +619,14 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
       const int nnz = nnz_s;
       if (k < K) {
 #pragma unroll 4
-        for (int m = q; m < nnz; m += 4) {
+        for (int m = q; m < nnz; m += TPC) {
           const int c = nz[m];
           acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
         }
       }
     }
     acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
+    if (TPC == 4) acc += __shfl_xor(acc, 2, 64);
     return acc;
   };
   // prox of the lane's penalty at the current path point, step s, on the W coordinates
