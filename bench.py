@@ -184,7 +184,10 @@ def main():
         # p = 5000: the fused kernels stop at four lanes; the split pass of working-set solves has eight
         split = not args.no_ws and res.ws_builds > 0
         lanes_used = max(1, min(args.lanes, 8 if split else 4))
-        bytes_per_grad = 8.0 * (n * p + 2 * n + 2 * p * lanes_used)
+        if split:  # xtr_ring_kernel: X once, the row residuals of eight lane slots, eight gradient rows out
+            bytes_per_grad = 8.0 * (n * p + 8 * n + 8 * p)
+        else:
+            bytes_per_grad = 8.0 * (n * p + 2 * n + 2 * p * lanes_used)
         t_grad_ms = grad_ms / max(1, grad_timed)
         achieved = bytes_per_grad / (t_grad_ms * 1e-3) / 1e9 if t_grad_ms > 0 else 0.0
         out = {
@@ -222,7 +225,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(n, p, lanes_used),
                 "traffic_unit": "HBM bytes per launch (PMC, profiles/roofline_traffic.json)",
-                "kernel": (f"split gradient pass: resid_ws_kernel + xtr_ring_kernel (lanes={lanes_used})" if split
+                "kernel": (f"xtr_ring_kernel (X^T r of the split pass, lanes={lanes_used})" if split
                            else f"grad_fused_kernel (lanes={lanes_used})"),
                 "avg_kernel_ms": t_grad_ms,
                 "launches": grad_launches,
