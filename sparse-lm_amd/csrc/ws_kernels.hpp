@@ -408,21 +408,36 @@ constexpr int WS_GRAM_THREADS = 512;
 
 __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
   if (!w.ws->building) return;
+  __shared__ ws_d4 comb[2][16][64];  // 64 KiB: row-split appends fold their four parts through here
   const int K = w.ws->K;
   const int tile_lo = w.ws->k_new >> 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wi = 4 * ((int)blockIdx.z >> 2) + (wave >> 1), wj = 2 * ((int)blockIdx.z & 3) + (wave & 1);
   const int tiles = K >> 4;
-  const int ti_lo = max(0, tile_lo - 4 * wi);                       // first tile row of this wave to do
-  const int nti = min(4, max(0, tiles - 4 * wi)), ntj = min(4, max(0, tiles - 4 * wj));
-  if (ti_lo >= nti || ntj == 0) return;
+  const int wj = 2 * ((int)blockIdx.z & 3) + (wave & 1);
+  const int ntj = min(4, max(0, tiles - 4 * wj));
+  // An append touches at most four tile rows.  With the usual mapping only the wavefronts whose tile
+  // rows those are would work (2 of 8, 98 dependent steps each: 0.13 ms of latency); instead the four
+  // wavefront pairs split the ROWS of the block between them, all on the new tile rows, and fold
+  // their accumulators through LDS in a fixed order.
+  const bool row_split = tile_lo > 0 && tiles - tile_lo <= 4;
+  if (row_split && ((int)blockIdx.z >> 2)) return;
+  const int part = row_split ? (wave >> 1) : 0;
+  const int ibase = row_split ? tile_lo : 4 * (4 * ((int)blockIdx.z >> 2) + (wave >> 1));
+  const int ti_lo = row_split ? 0 : max(0, tile_lo - ibase);  // first tile row of this wave to do
+  const int nti = min(4, max(0, tiles - ibase));
+  const bool active = ti_lo < nti && ntj > 0;
+  if (!row_split && !active) return;
   const int set = blockIdx.y;
   const int64_t b = blockIdx.x;
   const int64_t base = w.n / w.nblk, rem = w.n % w.nblk;
   const int64_t r0 = b * base + (b < rem ? b : rem);
   const int64_t nrows = base + (b < rem ? 1 : 0);
   const double* rw = w.rw ? w.rw + (int64_t)set * w.rw_stride : nullptr;
+  // rows of this wavefront: everything, or the part-th quarter (in steps of four rows)
+  const int64_t steps = (nrows + 3) >> 2;
+  const int64_t s_begin = row_split ? 4 * (steps * part / 4) : 0;
+  const int64_t s_end = row_split ? min(nrows, 4 * (steps * (part + 1) / 4)) : nrows;
 
   ws_d4 acc[4][4];
 #pragma unroll
@@ -431,27 +446,46 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
     for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = ws_d4{0.0, 0.0, 0.0, 0.0};
 
   const int kk = lane >> 4, c = lane & 15;
+  if (active) {
 #pragma unroll 4
-  for (int64_t s = 0; s < nrows; s += 4) {
-    const int64_t i = s + kk;
-    const bool ok = i < nrows;
-    const int64_t row = r0 + (ok ? i : 0);
-    const double wgt = ok ? (rw ? rw[row] : 1.0) : 0.0;
-    const double* xr = w.XW + row * WS_KCAP + c;
-    double av[4], bv[4];
+    for (int64_t s = s_begin; s < s_end; s += 4) {
+      const int64_t i = s + kk;
+      const bool ok = i < s_end;
+      const int64_t row = r0 + (ok ? i : 0);
+      const double wgt = ok ? (rw ? rw[row] : 1.0) : 0.0;
+      const double* xr = w.XW + row * WS_KCAP + c;
+      double av[4], bv[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      av[t] = (t >= ti_lo && t < nti) ? xr[16 * (4 * wi + t)] * wgt : 0.0;
-      bv[t] = t < ntj ? xr[16 * (4 * wj + t)] : 0.0;
-    }
+      for (int t = 0; t < 4; ++t) {
+        av[t] = (t >= ti_lo && t < nti) ? xr[16 * (ibase + t)] * wgt : 0.0;
+        bv[t] = t < ntj ? xr[16 * (4 * wj + t)] : 0.0;
+      }
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      if (ti >= ti_lo && ti < nti) {
+      for (int ti = 0; ti < 4; ++ti) {
+        if (ti >= ti_lo && ti < nti) {
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-          if (tj < ntj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
+          for (int tj = 0; tj < 4; ++tj)
+            if (tj < ntj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
+        }
       }
     }
+  }
+  if (row_split) {  // parts 0..3 in order: store, add + store, add + store, add (and write below)
+    for (int round = 0; round < 4; ++round) {
+      if (part == round && active) {
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 4; ++tj) {
+            if (ti < nti && tj < ntj) {
+              if (round > 0) acc[ti][tj] += comb[wave & 1][ti * 4 + tj][lane];
+              if (round < 3) comb[wave & 1][ti * 4 + tj][lane] = acc[ti][tj];
+            }
+          }
+      }
+      __syncthreads();
+    }
+    if (part != 3 || !active) return;
   }
   // partials are stored tile by tile, the row blocks of one tile next to each other:
   // part[set][tile (I, J)][b][16 x 16] -- the reduce kernel then walks 2 KiB strides, not 2 MiB ones
@@ -461,7 +495,7 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj) {
       if (tj >= ntj) continue;
-      const int64_t tile = (int64_t)(4 * wi + ti) * WS_TILES + (4 * wj + tj);
+      const int64_t tile = (int64_t)(ibase + ti) * WS_TILES + (4 * wj + tj);
       double* out = w.part + (((int64_t)set * (WS_TILES * WS_TILES) + tile) * w.nblk + b) * 256;
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[(kk + 4 * r) * 16 + c] = acc[ti][tj][r];

@@ -13,7 +13,8 @@ other penalty hyper-parameter, e.g. ``l1_ratio``), X is uploaded ONCE and
 
   * every fold is a row mask (test rows weigh 0) with its own 1/n_train scaling -- a *lane*;
   * every (fold, other-params) pair is one warm-started alpha path solved on the device;
-  * up to four lanes share each pass over X (``slm_solve_lanes``);
+  * up to eight lanes share each pass over X (``slm_solve_lanes``; eight in working-set solves on
+    large X, otherwise as many as the fused kernel table has for this p);
   * hold-out scores come from the resident X as well (``slm_eval_sse`` with the test mask);
   * across processes (``torch.distributed`` launched one rank per GPU) the (fold, params) units are
     dealt to ranks with ``distributed.shard_units`` and gathered -- no data-path collective.
@@ -77,7 +78,8 @@ class GridSearchCV(_GridSearchCV):
         opt_selection_method (str): "max_score" (default) or "one_std_score".
         scoring: default "neg_root_mean_squared_error" (reference :166).
         n_jobs, refit, cv, verbose, pre_dispatch, error_score, return_train_score: as scikit-learn.
-        lanes (int): folds solved per pass over X on the fast path (1..4, default 4).
+        lanes (int): (fold, grid-row) units solved per pass over X on the fast path (1..8, default 8;
+            the engine falls back to fewer where no kernel variant serves that many).
     """
 
     def __init__(
@@ -94,7 +96,7 @@ class GridSearchCV(_GridSearchCV):
         pre_dispatch="2*n_jobs",
         error_score=np.nan,
         return_train_score=False,
-        lanes=4,
+        lanes=8,
     ):
         super().__init__(
             estimator=estimator,
@@ -377,7 +379,7 @@ def _solver_options(est) -> dict:
 
 
 def _solve_lanes_with_fallback(ds, specs, opts):
-    """Four lanes when the kernel table has a variant for this p, otherwise fewer per call."""
+    """As many lanes as asked for when a kernel variant serves them for this p, otherwise halves."""
     try:
         return ds.solve_lanes(specs, **opts)
     except NotImplementedError:

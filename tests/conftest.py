@@ -8,6 +8,11 @@ reference's own.
 import os
 import sys
 
+# The CPU oracle leans on multi-threaded BLAS; on a many-core host whose cores are shared or
+# throttled, 256 BLAS threads turn a two-second oracle fit into minutes.  (Set before numpy loads.)
+for _var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_var, "16")
+
 import numpy as np
 import pytest
 from sklearn.datasets import make_regression
