@@ -215,7 +215,7 @@ int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point
  * cross-validation, or both.  n_lanes <= SLM_MAX_LANES; SLM_ERR_UNSUPPORTED if no kernel variant
  * covers (p, n_lanes) -- callers then fall back to fewer lanes.
  */
-#define SLM_MAX_LANES 8
+#define SLM_MAX_LANES 10
 typedef struct slm_lane {
   const slm_penalty* pen;         /* NULL => all-ones base vectors                              */
   const slm_path_point* points;   /* this lane's warm-started path                              */

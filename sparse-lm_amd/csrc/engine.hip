@@ -156,15 +156,17 @@ static const int64_t kMaxChunks = 64 * 8 * 10;  // largest row the fused kernel 
 static const GradKernel kGradTwoPass = {8, 4, 2, 1, -1, nullptr};
 static const int kTwoPassC = 4;  // column tile of xtr_kernel: 512 * 4 chunks = 4096 columns
 
-// Split pass (split_kernels.hpp) for working-set solves: eight lanes per read of X, rows of up to
-// 5120 columns (40 accumulator doubles per thread).  D rows in flight as for the fused ring kernel.
+// Split pass (split_kernels.hpp) for working-set solves: ten lanes per read of X, rows of up to
+// 5120 columns (40 accumulator doubles per thread and lane).  D rows in flight as for the fused ring kernel.
 struct SplitKernel {
   int W, C, B, D;
   void (*xtr)(SplitArgs);
   void (*rowdot)(SplitArgs);
   void (*resid)(SplitArgs);
 };
-#define SLM_SK(C, D) {8, C, 8, D, xtr_ring_kernel<8, C, 8, D>, rowdot_ring_kernel<8, C, 8, D>, resid_ws_kernel<8>}
+#define SLM_SK(C, D)                                                                                   \
+  {8, C, SPLIT_LANES, D, xtr_ring_kernel<8, C, SPLIT_LANES, D>, rowdot_ring_kernel<8, C, ROWDOT_LANES, D>, \
+   resid_ws_kernel<SPLIT_LANES>}
 static const SplitKernel kSplit[] = {SLM_SK(1, 3), SLM_SK(2, 3), SLM_SK(3, 3), SLM_SK(4, 3), SLM_SK(5, 2)};
 static const SplitKernel* pick_split_kernel(int64_t p2) {
   const char* env = getenv("SLM_SPLIT");
@@ -248,7 +250,7 @@ struct slm_dataset {
   int nblk[SLM_MAX_LANES] = {};
   const SplitKernel* sk = nullptr;  // split pass for working-set solves (nullptr: rows too long)
   int split_nblk = 0;
-  double* R = nullptr;              // [n][SPLIT_LANES] residuals of the split pass, allocated on first use
+  double* R = nullptr;              // [n][SPLIT_RSTRIDE] residuals of the split pass, allocated on first use
   double *partial = nullptr, *loss_partial = nullptr;
   // iteration state: kMaxLanes copies, lane stride ld (g: ld + 16)
   double *g = nullptr, *z = nullptr, *beta = nullptr, *zprev = nullptr, *gprev = nullptr;
@@ -797,8 +799,8 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
   const SplitKernel* sk = ds->sk;
   const int nblk = ds->split_nblk;
   if (!ds->R) {
-    SLM_TRY(dalloc(&ds->R, (size_t)ds->n * SPLIT_LANES));
-    HIP_TRY(hipMemsetAsync(ds->R, 0, sizeof(double) * (size_t)ds->n * SPLIT_LANES, s));
+    SLM_TRY(dalloc(&ds->R, (size_t)ds->n * SPLIT_RSTRIDE));
+    HIP_TRY(hipMemsetAsync(ds->R, 0, sizeof(double) * (size_t)ds->n * SPLIT_RSTRIDE, s));
   }
   SplitArgs a;
   memset(&a, 0, sizeof(a));
@@ -809,7 +811,10 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
   a.n = nr; a.ld = ds->ld; a.rows_base = nr / nblk; a.rows_rem = nr % nblk;
   a.p2 = (int)(ds->ld / 2);
   a.n_lanes = ls.B;
-  hipLaunchKernelGGL(sk->rowdot, dim3(nblk), dim3(sk->W * 64), 0, s, a);
+  for (int l0 = 0; l0 < ls.B; l0 += ROWDOT_LANES) {  // (each launch returns at once unless a lane of its window needs X)
+    a.lane0 = l0;
+    hipLaunchKernelGGL(sk->rowdot, dim3(nblk), dim3(sk->W * 64), 0, s, a);
+  }
   if (wa && ctl) hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
   // (SLM_FLAG_PROFILE brackets the kernel that streams X, the one the roofline is quoted on)
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
@@ -1015,7 +1020,12 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
       HIP_TRY(hipEventCreate(&e1));
       HIP_TRY(hipEventRecord(e0, s));
       for (int r = 0; r < reps; ++r) {
-        if (!xtr_only) hipLaunchKernelGGL(ds->sk->rowdot, dim3(ds->split_nblk), dim3(ds->sk->W * 64), 0, s, a);
+        if (!xtr_only) {
+          for (int l0 = 0; l0 < B; l0 += ROWDOT_LANES) {
+            a.lane0 = l0;
+            hipLaunchKernelGGL(ds->sk->rowdot, dim3(ds->split_nblk), dim3(ds->sk->W * 64), 0, s, a);
+          }
+        }
         hipLaunchKernelGGL(ds->sk->xtr, dim3(ds->split_nblk), dim3(ds->sk->W * 64), 0, s, a);
       }
       HIP_TRY(hipEventRecord(e1, s));

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(W * 64) void grad_ring_kernel(GradArgs a) {
       }
       // scalar operands of this row (SMEM loads; waited for together with the LDS reads below)
       const int64_t row = r0 + i;
-      const uint64_t yi_bits = smem_load_u64(a.y + row);
+      uint64_t yi_bits = smem_load_u64(a.y + row);
       uint64_t m_bits[B];
       const bool has_rw = a.rw != nullptr;
       if (has_rw) {
@@ -363,7 +363,13 @@ __global__ __launch_bounds__(W * 64) void grad_ring_kernel(GradArgs a) {
 #pragma unroll
       for (int c = 0; c < C; ++c)
         x[c] = *reinterpret_cast<const d2*>(smem + slot * SLOT + (c * T + tid) * 16);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // (the "+s" operands make the loaded SGPRs outputs of the wait: the compiler, which believes the
+      // load asm delivered them at once, can neither read nor recycle them before this point)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(yi_bits) : : "memory");
+      if (has_rw) {
+#pragma unroll
+        for (int l = 0; l < B; ++l) asm volatile("" : "+s"(m_bits[l]));
+      }
       const double yi = __longlong_as_double((long long)yi_bits);
       double m[B];
 #pragma unroll
@@ -546,8 +552,8 @@ struct ReduceArgs {
   int nblk;
   int n_lanes;
   int64_t ld;
-  double scale[8];       // 1/n_eff per lane
-  double loss_scale[8];  // 1/(2 n_eff) per lane
+  double scale[10];       // 1/n_eff per lane (SLM_MAX_LANES)
+  double loss_scale[10];  // 1/(2 n_eff) per lane
 };
 
 // grid = (ld/16 + 1, n_lanes)

@@ -4,7 +4,7 @@
 // supported on W, the <= 256 columns already gathered into the compact matrix XW.  Its residual
 // r = W (X z - y) then needs only XW (n x K, a few tens of MB), and the pass over X reduces to the
 // second half of the fused kernel, g = X^T r / n.  That half keeps only the accumulators in
-// registers (4C VGPRs per lane instead of the fused kernel's 8C for z + accumulators), so EIGHT lanes
+// registers (4C VGPRs per lane instead of the fused kernel's 8C for z + accumulators), so TEN lanes
 // share one read of X where the fused kernel tops out at four, and its row loop has no dot product,
 // no cross-wave exchange and no barrier at all.
 //
@@ -14,8 +14,8 @@
 //   xtr_ring_kernel      partial[blk][l][:] = sum_{i in blk} R[i][l] x_i     (reads X once)
 //
 // All three use the same contiguous row blocks as the fused kernels, so reduce_partials_kernel and
-// everything after it are unchanged.  R is lane-minor ([n][8]) so a row's eight residuals are one
-// 64-byte scalar load.  Reference counterpart: the `X @ beta` inside the cvxpy objective
+// everything after it are unchanged.  R is lane-minor ([n][16], ten used) so a row's residuals are
+// two 64-byte scalar loads.  Reference counterpart: the `X @ beta` inside the cvxpy objective
 // (src/sparselm/model/_lasso.py:109-121), as for the fused kernel.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,7 +27,9 @@
 
 namespace slm {
 
-constexpr int SPLIT_LANES = 8;  // lane-minor stride of R
+constexpr int SPLIT_LANES = 10;    // lane slots of the split pass (40 accumulator doubles x 10 = 236 VGPRs at C = 5)
+constexpr int SPLIT_RSTRIDE = 16;  // doubles per row of R (two 64-byte scalar loads)
+constexpr int ROWDOT_LANES = 5;    // lanes per launch of rowdot_ring_kernel (z + row in registers: 162 VGPRs)
 
 struct SplitArgs {
   const double* X;
@@ -35,9 +37,9 @@ struct SplitArgs {
   const double* rw;      // row weights (nullptr = ones); lane l uses rw + l * rw_stride
   int64_t rw_stride;
   const double* z;       // [n_lanes][ld]
-  double* R;             // [n][SPLIT_LANES] weighted residuals
-  double* partial;       // [nblk][B][ld]
-  double* loss_partial;  // [nblk][B]   sum_i w e^2 of the block
+  double* R;             // [n][SPLIT_RSTRIDE] weighted residuals (SPLIT_LANES used)
+  double* partial;       // [nblk][SPLIT_LANES][ld]
+  double* loss_partial;  // [nblk][SPLIT_LANES]   sum_i w e^2 of the block
   const int* done;
   const PathCtl* ctl;    // nullptr => every lane takes its residual from X (slm_gradient, tests)
   const double* XW;      // [n][WS_KCAP]
@@ -46,6 +48,7 @@ struct SplitArgs {
   int64_t n, ld, rows_base, rows_rem;
   int p2;
   int n_lanes;
+  int lane0;  // rowdot_ring_kernel: first lane of this launch
 };
 
 // which lanes take their residual from XW: live, flagged by ws_solve_kernel, and W still published
@@ -72,6 +75,7 @@ __device__ __forceinline__ unsigned split_live_mask(const SplitArgs& a) {
 // ---------------------------------------------------------------------------------------------
 template <int B>
 __global__ __launch_bounds__(256) void resid_ws_kernel(SplitArgs a) {
+  static_assert(B == SPLIT_LANES && B % 2 == 0, "one launch serves every lane slot");
   if (a.done != nullptr && *a.done != 0) return;
   const unsigned mask = split_ws_mask(a);
   if (mask == 0u) return;
@@ -116,13 +120,13 @@ __global__ __launch_bounds__(256) void resid_ws_kernel(SplitArgs a) {
     }
     // only the lanes served here own their slot of R (the others belong to rowdot_ring_kernel)
     if (mask == (1u << B) - 1u) {
-      d2* out = reinterpret_cast<d2*>(a.R + row * SPLIT_LANES);
+      d2* out = reinterpret_cast<d2*>(a.R + row * SPLIT_RSTRIDE);
 #pragma unroll
       for (int l = 0; l < B; l += 2) out[l >> 1] = d2{res[l], res[l + 1]};
     } else {
 #pragma unroll
       for (int l = 0; l < B; ++l)
-        if ((mask >> l) & 1u) a.R[row * SPLIT_LANES + l] = res[l];
+        if ((mask >> l) & 1u) a.R[row * SPLIT_RSTRIDE + l] = res[l];
     }
   }
 #pragma unroll
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void resid_ws_kernel(SplitArgs a) {
   }
   __syncthreads();
   if (tid < B && ((mask >> tid) & 1u))
-    a.loss_partial[b * B + tid] = lsum[0][tid] + lsum[1][tid] + lsum[2][tid] + lsum[3][tid];
+    a.loss_partial[b * SPLIT_LANES + tid] = lsum[0][tid] + lsum[1][tid] + lsum[2][tid] + lsum[3][tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -150,7 +154,9 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
   static_assert(RING + RED <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   static_assert(D * C < 64, "too many DMA loads in flight for vmcnt");
   if (a.done != nullptr && *a.done != 0) return;
-  const unsigned mask = split_live_mask(a) & ~split_ws_mask(a);  // lanes served here
+  // lanes served here: live, not served by resid_ws_kernel, inside this launch's window of B lanes
+  const int lane0 = a.lane0;
+  const unsigned mask = ((split_live_mask(a) & ~split_ws_mask(a)) >> lane0) & ((1u << B) - 1u);
   if (mask == 0u) return;
 
   __shared__ __attribute__((aligned(16))) char smem[RING + RED];
@@ -166,8 +172,8 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
   // not needed at all -- the first pass of a path costs one read of X, not two.
   bool all_zero = a.ctl != nullptr;
   if (all_zero) {
-    for (int l = 0; l < a.n_lanes; ++l)
-      if (((mask >> l) & 1u) && !a.ctl[l].zzero) all_zero = false;
+    for (int l = 0; l < B; ++l)
+      if (((mask >> l) & 1u) && !a.ctl[lane0 + l].zzero) all_zero = false;
   }
   if (all_zero) {
     double ls[B];
@@ -179,8 +185,8 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
 #pragma unroll
       for (int l = 0; l < B; ++l) {
         if ((mask >> l) & 1u) {
-          const double m = a.rw ? a.rw[(int64_t)l * a.rw_stride + row] : 1.0;
-          a.R[row * SPLIT_LANES + l] = e * m;
+          const double m = a.rw ? a.rw[(int64_t)(lane0 + l) * a.rw_stride + row] : 1.0;
+          a.R[row * SPLIT_RSTRIDE + lane0 + l] = e * m;
           ls[l] = __builtin_fma(e * m, e, ls[l]);
         }
       }
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
     if (tid < B && ((mask >> tid) & 1u)) {
       double t = 0.0;
       for (int w2 = 0; w2 < W; ++w2) t += red[tid * W + w2];
-      a.loss_partial[b * B + tid] = t;
+      a.loss_partial[b * SPLIT_LANES + lane0 + tid] = t;
     }
     return;
   }
@@ -211,7 +217,8 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
     coff[c] = (uint32_t)cc * 16u;
 #pragma unroll
     for (int l = 0; l < B; ++l) {
-      const d2 zz = l < a.n_lanes ? reinterpret_cast<const d2*>(a.z + (int64_t)l * a.ld)[cc] : d2{0.0, 0.0};
+      const d2 zz = lane0 + l < a.n_lanes ? reinterpret_cast<const d2*>(a.z + (int64_t)(lane0 + l) * a.ld)[cc]
+                                          : d2{0.0, 0.0};
       zr[l][c] = valid ? zz : d2{0.0, 0.0};
     }
   }
@@ -244,12 +251,12 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
         else wait_vmcnt<0>();
       }
       const int64_t row = r0 + i;
-      const uint64_t yi_bits = smem_load_u64(a.y + row);
+      uint64_t yi_bits = smem_load_u64(a.y + row);
       d2 x[C];
 #pragma unroll
       for (int c = 0; c < C; ++c)
         x[c] = *reinterpret_cast<const d2*>(smem + slot * SLOT + (c * T + tid) * 16);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(yi_bits) : : "memory");
       const double yi = __longlong_as_double((long long)yi_bits);
       double dot[B];
 #pragma unroll
@@ -278,10 +285,10 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
 #pragma unroll
         for (int l = 0; l < B; ++l) {
           if ((mask >> l) & 1u) {
-            const double m = a.rw ? a.rw[(int64_t)l * a.rw_stride + row] : 1.0;
+            const double m = a.rw ? a.rw[(int64_t)(lane0 + l) * a.rw_stride + row] : 1.0;
             const double e = dot[l] - yi;
             const double res = e * m;
-            a.R[row * SPLIT_LANES + l] = res;
+            a.R[row * SPLIT_RSTRIDE + lane0 + l] = res;
             loss[l] = __builtin_fma(res, e, loss[l]);
           }
         }
@@ -293,15 +300,25 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
   if (tid == 0) {
 #pragma unroll
     for (int l = 0; l < B; ++l)
-      if ((mask >> l) & 1u) a.loss_partial[b * B + l] = loss[l];
+      if ((mask >> l) & 1u) a.loss_partial[b * SPLIT_LANES + lane0 + l] = loss[l];
   }
 }
 
-// 64-byte scalar load: the eight residuals of one row.  Caller waits lgkmcnt(0) before use.
+// 64-byte / 16-byte scalar loads: eight / two of the residuals of one row.  The caller waits
+// lgkmcnt(0) before use.  EVERY element of the result must be used: the compiler treats the asm output
+// as available at once and recycles registers of the tuple it considers dead while the load is still
+// in flight (a 64-byte load for lanes 8-9 had its upper SGPRs reused for the LDS ring address: the
+// DMA then went to whatever the load wrote there).
 typedef uint32_t slm_u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t slm_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ slm_u32x16 smem_load_64B(const double* p) {
   slm_u32x16 v;
   asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ slm_u32x4 smem_load_16B(const double* p) {
+  slm_u32x4 v;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
   return v;
 }
 
@@ -318,7 +335,7 @@ __global__ __launch_bounds__(W * 64) void xtr_ring_kernel(SplitArgs a) {
   constexpr int RING = (D + 1) * SLOT;
   static_assert(RING <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   static_assert(D * C < 64, "too many DMA loads in flight for vmcnt");
-  static_assert(B <= SPLIT_LANES, "R holds eight lanes per row");
+  static_assert(B == SPLIT_LANES && B == 10, "a row of R is one 64-byte and one 16-byte scalar load");
   if (a.done != nullptr && *a.done != 0) return;
 
   __shared__ __attribute__((aligned(16))) char smem[RING];
@@ -356,7 +373,8 @@ __global__ __launch_bounds__(W * 64) void xtr_ring_kernel(SplitArgs a) {
     int slot = 0, slot_in = D;
     for (int64_t i = 0; i < nrows; ++i) {
       // the row's residuals first: the scalar load then flies while the wave waits for its DMA chunks
-      const slm_u32x16 rb = smem_load_64B(a.R + (r0 + i) * SPLIT_LANES);
+      slm_u32x16 ra = smem_load_64B(a.R + (r0 + i) * SPLIT_RSTRIDE);
+      slm_u32x4 rb = smem_load_16B(a.R + (r0 + i) * SPLIT_RSTRIDE + 8);
       const int64_t left = nrows - 1 - i;
       if (left >= D) {
         issue_row(i + D, slot_in);
@@ -370,10 +388,12 @@ __global__ __launch_bounds__(W * 64) void xtr_ring_kernel(SplitArgs a) {
 #pragma unroll
       for (int c = 0; c < C; ++c)
         x[c] = *reinterpret_cast<const d2*>(smem + slot * SLOT + (c * T + tid) * 16);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // the loaded SGPRs are outputs of the wait (see smem_load_64B): live and unread until here
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(rb) : : "memory");
 #pragma unroll
       for (int l = 0; l < B; ++l) {
-        const double res = __hiloint2double((int)rb[2 * l + 1], (int)rb[2 * l]);
+        const double res = l < 8 ? __hiloint2double((int)ra[2 * (l & 7) + 1], (int)ra[2 * (l & 7)])
+                                 : __hiloint2double((int)rb[2 * (l & 7) + 1], (int)rb[2 * (l & 7)]);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           acc[l][c].x = __builtin_fma(res, x[c].x, acc[l][c].x);

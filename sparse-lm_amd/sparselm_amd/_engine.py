@@ -142,7 +142,7 @@ class _Lane(C.Structure):
     ]
 
 
-MAX_LANES = 8
+MAX_LANES = 10
 
 _lib = None
 _lib_lock = threading.Lock()

@@ -227,8 +227,8 @@ def test_easy_small_problem_stays_plain(eng):
     assert r.converged and r.ws_builds == 0 and r.grad_launches < 48
 
 
-@pytest.mark.parametrize("lanes", [5, 8])
-def test_eight_lane_split_pass_path_matches_oracle(eng, lanes):
+@pytest.mark.parametrize("lanes", [5, 8, 10])
+def test_many_lane_split_pass_path_matches_oracle(eng, lanes):
     # working set from the first pass => the split pass with eight lane slots (residuals from the
     # gathered columns, accumulate-only stream over X)
     n, p = 4000, 900
