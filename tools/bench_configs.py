@@ -42,12 +42,12 @@ def main():
     bmax = float(gnorm.max())
     alphas = np.geomspace(bmax, 1e-3 * bmax, 50)
     pts = [(0.0, a, 0.0) for a in alphas]
-    ds.solve_path(pts, lanes=8)
+    ds.solve_path(pts, lanes=10)
     t0 = time.perf_counter()
     for _ in range(args.reps):
-        res = ds.solve_path(pts, lanes=8, flags=_engine.FLAG_FRESH_L)
+        res = ds.solve_path(pts, lanes=10, flags=_engine.FLAG_FRESH_L)
     dt = (time.perf_counter() - t0) / args.reps
-    print(json.dumps({"config": "3: GroupLasso 500x10 groups, 50-alpha path, 1 GPU, 8 lanes", "fits_per_s": 50 / dt,
+    print(json.dumps({"config": "3: GroupLasso 500x10 groups, 50-alpha path, 1 GPU, 10 lanes", "fits_per_s": 50 / dt,
                       "ms_per_path": 1e3 * dt, "passes": res.grad_launches, "converged": res.converged, "ws": [res.ws_builds, res.ws_appends, res.ws_refined, res.ws_misses, res.ws_columns],
                       "nnz_groups_last": int(np.sum(res.betas[-1].reshape(-1) != 0) // 10)}), flush=True)
 
@@ -59,9 +59,9 @@ def main():
 
     def run_grid():
         total_passes = 0
-        for k0 in range(0, len(units), 8):
+        for k0 in range(0, len(units), 10):
             specs = []
-            for f, r in units[k0 : k0 + 8]:
+            for f, r in units[k0 : k0 + 10]:
                 # alpha_max for this l1_ratio (upper bound: group part alone or l1 part alone)
                 amax = min(bmax / (1 - r), float(np.max(np.abs(g0))) / r)
                 al = np.geomspace(amax, 1e-3 * amax, 50)
