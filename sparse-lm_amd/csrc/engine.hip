@@ -826,7 +826,7 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
   ra.g = ds->g;
   ra.done = done;
   ra.nblk = nblk;
-  ra.n_lanes = SPLIT_LANES;  // partial rows are laid out for eight lane slots
+  ra.n_lanes = SPLIT_LANES;  // partial rows are laid out for all lane slots of the split pass
   ra.ld = ds->ld;
   for (int l = 0; l < kMaxLanes; ++l) {
     const double ne = ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global;
@@ -898,7 +898,7 @@ static int power_iteration(slm_dataset* ds, const LaneSetup& ls_in, double* L_ou
   for (int k = 0; k < iters; ++k) {
     if (ds->gk[ls.B - 1]) {
       SLM_TRY(enqueue_gradient(ds, ls, ds->yzero, nullptr, nullptr, nullptr, n_rows));
-    } else {  // more lanes than the fused kernels serve (working-set solves): the split pass has eight
+    } else {  // more lanes than the fused kernels serve (working-set solves): the split pass has ten
       if (!ds->sk) return fail(SLM_ERR_UNSUPPORTED, "no %d-lane kernel for p = %lld", ls.B, (long long)ds->p);
       SLM_TRY(enqueue_gradient_split(ds, ls, ds->yzero, nullptr, nullptr, nullptr, nullptr, nullptr, n_rows));
     }
@@ -1153,7 +1153,7 @@ static int ws_policy(const slm_dataset* ds, uint32_t flags) {
   const bool big = (double)ds->n * (double)ds->ld >= 67108864.0;  // 2^26 doubles = 512 MiB
   return (big || (flags & SLM_FLAG_WORKING_SET) || (env && env[0] == '1')) ? 2 : 1;
 }
-// most lanes one solve can run: the fused kernels' table, or the split pass's eight when the working
+// most lanes one solve can run: the fused kernels' table, or the split pass's ten when the working
 // set is on from the start
 static int max_lanes_for(const slm_dataset* ds, uint32_t flags) {
   if (ws_policy(ds, flags) == 2 && ds->sk) return SPLIT_LANES;
@@ -1418,7 +1418,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   };
   if (use_ws) SLM_TRY(ws_setup());
   const int* done_flag = &ds->gctl->done;
-  // the gradient of one pass: split pass (eight lane slots, residuals from the gathered columns where
+  // the gradient of one pass: split pass (ten lane slots, residuals from the gathered columns where
   // possible) when the working set runs from the start, the fused kernel otherwise
   auto enqueue_pass_gradient = [&](hipEvent_t e0, hipEvent_t e1) -> int {
     if (split) return enqueue_gradient_split(ds, ls, ds->y, done_flag, ds->ctl, &wa, e0, e1);

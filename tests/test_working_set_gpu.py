@@ -268,3 +268,19 @@ def test_split_pass_with_fold_masks_and_groups(eng):
         assert rel_inf(res[f].betas[-1], ref) < 1e-8
     for f in range(4):
         assert rel_inf(res[f].betas, res0[f].betas) < 1e-8
+
+
+def test_plain_steps_inside_the_split_pass_use_both_rowdot_windows(eng):
+    # seven lanes, a dense problem: the refinement gives up (> 512 non-zeros), every lane takes plain
+    # steps whose residuals come from X (rowdot_ring_kernel, two launches of five lanes)
+    n, p = 1500, 700
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((n, p))
+    y = X @ rng.standard_normal(p) + 0.1 * rng.standard_normal(n)
+    lanes = [dict(points=[(a, 0, 0)]) for a in np.geomspace(3e-4, 1e-4, 7)]
+    with eng.dataset(X, y) as ds:
+        res = ds.solve_lanes(lanes, tol=1e-10, flags=WS)
+        ref = [ds.solve_path(l["points"], tol=1e-10, flags=NO_WS) for l in lanes]
+    for r, r0 in zip(res, ref):
+        assert r.converged and np.count_nonzero(r.betas[0]) > 512
+        assert rel_inf(r.betas, r0.betas) < 1e-7

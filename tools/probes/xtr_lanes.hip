@@ -1,0 +1,120 @@
+// How does the accumulate-only pass scale with the number of lane slots?  (standalone probe)
+#include "../../sparse-lm_amd/csrc/split_kernels.hpp"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+using namespace slm;
+
+// same loop as xtr_ring_kernel, any B <= 10 (the residual row is always loaded in full)
+template <int W, int C, int B, int D>
+__global__ __launch_bounds__(W * 64) void xtr_probe_kernel(SplitArgs a) {
+  constexpr int T = W * 64;
+  constexpr int SLOT = T * C * 16;
+  constexpr int RING = (D + 1) * SLOT;
+  __shared__ __attribute__((aligned(16))) char smem[RING];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t b = blockIdx.x;
+  const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
+  const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
+  uint32_t coff[C];
+  d2 acc[B][C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int ci = c * T + tid;
+    coff[c] = (uint32_t)(ci < a.p2 ? ci : a.p2 - 1) * 16u;
+#pragma unroll
+    for (int l = 0; l < B; ++l) acc[l][c] = d2{0.0, 0.0};
+  }
+  auto issue_row = [&](int64_t i, int slot) {
+    const char* rp = reinterpret_cast<const char*>(a.X + (r0 + i) * a.ld);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      char* dst = smem + slot * SLOT + (c * T + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((gptr_t)(rp + coff[c]), (lptr_t)dst, 16, 0, 2);
+    }
+  };
+  for (int k = 0; k < D; ++k) if (k < nrows) issue_row(k, k);
+  int slot = 0, slot_in = D;
+  for (int64_t i = 0; i < nrows; ++i) {
+    slm_u32x16 ra = smem_load_64B(a.R + (r0 + i) * SPLIT_RSTRIDE);
+    slm_u32x4 rb = smem_load_16B(a.R + (r0 + i) * SPLIT_RSTRIDE + 8);
+    const int64_t left = nrows - 1 - i;
+    if (left >= D) { issue_row(i + D, slot_in); wait_vmcnt<D * C>(); } else wait_vmcnt<0>();
+    d2 x[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) x[c] = *reinterpret_cast<const d2*>(smem + slot * SLOT + (c * T + tid) * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(rb) : : "memory");
+#pragma unroll
+    for (int l = 0; l < B; ++l) {
+      const double res = l < 8 ? __hiloint2double((int)ra[2 * (l & 7) + 1], (int)ra[2 * (l & 7)])
+                               : __hiloint2double((int)rb[2 * (l & 7) + 1], (int)rb[2 * (l & 7)]);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        acc[l][c].x = __builtin_fma(res, x[c].x, acc[l][c].x);
+        acc[l][c].y = __builtin_fma(res, x[c].y, acc[l][c].y);
+      }
+    }
+    slot = (slot == D) ? 0 : slot + 1;
+    slot_in = (slot_in == D) ? 0 : slot_in + 1;
+  }
+#pragma unroll
+  for (int l = 0; l < B; ++l) {
+    d2* out = reinterpret_cast<d2*>(a.partial + (b * B + l) * a.ld);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      if (c * T + tid < a.p2) out[c * T + tid] = acc[l][c];
+  }
+}
+
+template <int W, int C, int B, int D>
+static void runw(const SplitArgs& a, int nblk, const char* tag) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((xtr_probe_kernel<W, C, B, D>), dim3(nblk), dim3(W * 64), 0, 0, a);
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < 30; ++r) hipLaunchKernelGGL((xtr_probe_kernel<W, C, B, D>), dim3(nblk), dim3(W * 64), 0, 0, a);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  printf("%s W=%d C=%d B=%d D=%d: %.4f ms  %.0f GB/s\n", tag, W, C, B, D, ms / 30, 8.0 * a.n * (a.ld) / (ms / 30) / 1e6);
+}
+
+template <int B, int D>
+static void run(const SplitArgs& a, int nblk, const char* tag) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((xtr_probe_kernel<8, 5, B, D>), dim3(nblk), dim3(512), 0, 0, a);
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < 30; ++r) hipLaunchKernelGGL((xtr_probe_kernel<8, 5, B, D>), dim3(nblk), dim3(512), 0, 0, a);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  printf("%s B=%d D=%d: %.4f ms  %.0f GB/s\n", tag, B, D, ms / 30, 8.0 * a.n * (a.ld) / (ms / 30) / 1e6);
+}
+
+int main() {
+  const int64_t n = 100000, ld = 5008;
+  double *X, *R, *P;
+  (void)hipMalloc(&X, n * ld * 8); (void)hipMalloc(&R, n * 16 * 8); (void)hipMalloc(&P, (size_t)512 * 10 * ld * 8);  // largest grid x most lanes
+  (void)hipMemset(X, 0, n * ld * 8); (void)hipMemset(R, 0, n * 16 * 8);
+  SplitArgs a; memset(&a, 0, sizeof(a));
+  a.X = X; a.R = R; a.partial = P; a.n = n; a.ld = ld; a.p2 = (int)(ld / 2);
+  for (int nblk : {256}) {
+    a.rows_base = n / nblk; a.rows_rem = n % nblk;
+    printf("nblk=%d\n", nblk);
+    run<1, 2>(a, nblk, "xtr"); run<10, 2>(a, nblk, "xtr");
+    runw<16, 3, 1, 2>(a, nblk, "xtr"); runw<16, 3, 8, 2>(a, nblk, "xtr");
+    runw<4, 10, 1, 2>(a, nblk, "xtr"); runw<4, 10, 1, 1>(a, nblk, "xtr");
+  }
+  {
+    const int nblk = 512;  // two 256-thread workgroups per CU (ring 2 x 80 KB... D = 1: 80 KB each)
+    a.rows_base = n / nblk; a.rows_rem = n % nblk;
+    printf("nblk=%d\n", nblk);
+    runw<4, 10, 1, 1>(a, nblk, "xtr");
+    runw<4, 10, 4, 1>(a, nblk, "xtr");
+  }
+  return 0;
+}

@@ -14,16 +14,16 @@ ds = eng.synthetic_dataset(n, p, seed=1000, coef=make_coef(p, 50, seed=0), noise
 g0, _, _ = ds.gradient(None, reps=50)
 amax = float(np.max(np.abs(g0)))
 pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-3 * amax, K)]
-grid = dict(SLM_WS_THETA=["0.7", "0.85"], SLM_WS_LOOKAHEAD=["2", "4"], SLM_WS_APPEND=["16", "32", "64"], SLM_WS_KINIT=["64", "112"])
+grid = dict(SLM_WS_THETA=["0.7", "0.85"], SLM_WS_LOOKAHEAD=["1", "2", "3"], SLM_WS_APPEND=["16", "32"], SLM_WS_KINIT=["112", "160"])
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     grid = dict(SLM_WS_THETA=["0.7"], SLM_WS_LOOKAHEAD=["4"], SLM_WS_APPEND=["32"], SLM_WS_KINIT=["112"])
 for combo in itertools.product(*grid.values()):
     for k, v in zip(grid.keys(), combo):
         os.environ[k] = v
-    ds.solve_path(pts, tol=1e-8, lanes=4, flags=_engine.FLAG_FRESH_L)
+    ds.solve_path(pts, tol=1e-8, lanes=10, flags=_engine.FLAG_FRESH_L)
     t0 = time.perf_counter()
     for _ in range(4):
-        r = ds.solve_path(pts, tol=1e-8, lanes=4, flags=_engine.FLAG_FRESH_L)
+        r = ds.solve_path(pts, tol=1e-8, lanes=10, flags=_engine.FLAG_FRESH_L)
     dt = (time.perf_counter() - t0) / 4
     print(dict(zip(grid.keys(), combo)), f"{1e3*dt:7.2f} ms/path {K/dt:7.0f} fits/s passes={r.grad_launches} builds={r.ws_builds} "
           f"appends={r.ws_appends} misses={r.ws_misses} cols={r.ws_columns} conv={r.converged}", flush=True)
