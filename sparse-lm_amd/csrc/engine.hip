@@ -224,7 +224,7 @@ struct GlobalCtl {
   int32_t hard;        // most passes any lane has spent on one path point so far (TailArgs::gdone[2])
   int32_t pad_;
 };
-static const int kWsLateIters = 48;  // passes on one point after which a small problem gets the working set
+static const int kWsLateIters = 24;  // passes on one point after which a small problem gets the working set
 
 struct HostCtl {  // pinned snapshot the host polls
   GlobalCtl g;
@@ -1442,8 +1442,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // ---- queue iterations; the device decides when each point / lane / the solve is finished ------
   int chunk = o.check_every;
   if (chunk <= 0) {
+    // passes queued per status poll.  The host learns of the stop one chunk late, so up to two chunks
+    // of launches return at once at the end of a solve (4.5 us each): small chunks win even for tiny
+    // problems (measured, tools/chunk_probe.py: 19-pass fit 0.63 ms at 32, 0.44 ms at 4).
     const double est_us = std::max(12.0, (double)n * (double)ld * 8.0 / 5.0e6);
-    chunk = (int)std::min(32.0, std::max(2.0, 400.0 / est_us));
+    chunk = est_us > 150.0 ? 2 : 4;
   }
   if (use_ws) chunk = std::min(chunk, 8);  // a queued pass is nine launches even when it returns at once
   int max_points = 0;

@@ -201,7 +201,7 @@ def test_ill_conditioned_problem_is_solved_to_kkt(eng):
 
 
 def test_small_hard_problem_gets_the_working_set_late(eng):
-    # default flags on a small problem: plain steps first; once a point has cost 48 passes the host
+    # default flags on a small problem: plain steps first; once a point has cost 24 passes the host
     # switches the refinement on and the path finishes in a handful of passes instead of > 100 000
     rng = np.random.default_rng(6)
     n, p = 60, 200
@@ -224,7 +224,7 @@ def test_easy_small_problem_stays_plain(eng):
     X, y = problem(400, 100, 10, seed=51)
     with eng.dataset(X, y) as ds:
         r = ds.solve_path([(0.1, 0, 0)], tol=1e-8)
-    assert r.converged and r.ws_builds == 0 and r.grad_launches < 48
+    assert r.converged and r.ws_builds == 0 and r.grad_launches < 24
 
 
 @pytest.mark.parametrize("lanes", [5, 8, 10])
