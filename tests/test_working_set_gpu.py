@@ -6,6 +6,8 @@ and without it (FLAG_NO_WORKING_SET) the engine must agree with the oracle and w
 solver tolerance, on every penalty of the family, while spending fewer passes over X.
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -221,6 +223,8 @@ def test_small_hard_problem_gets_the_working_set_late(eng):
 
 
 def test_easy_small_problem_stays_plain(eng):
+    if os.environ.get("SLM_WS") == "1":
+        pytest.skip("working set forced on by SLM_WS=1")
     X, y = problem(400, 100, 10, seed=51)
     with eng.dataset(X, y) as ds:
         r = ds.solve_path([(0.1, 0, 0)], tol=1e-8)
