@@ -38,6 +38,15 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const double* __restrict
   }
 }
 
+// lane 0's copy of a per-lane vector -> lanes 1 .. n_lanes-1 (stride ld)
+__global__ __launch_bounds__(256) void broadcast_lanes_kernel(double* v, int64_t count, int64_t ld, int n_lanes) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const double x = v[e];
+    for (int l = 1; l < n_lanes; ++l) v[(int64_t)l * ld + e] = x;
+  }
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(double* dst, int64_t count, double value) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;
        e += (int64_t)gridDim.x * blockDim.x)

@@ -1285,12 +1285,18 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   PathCtl h[SLM_MAX_LANES];
   memset(h, 0, sizeof(h));
   int64_t off = 0;
+  bool same_pen = B > 1;
+  for (int l = 1; l < B; ++l) same_pen = same_pen && lanes[l].pen == lanes[0].pen;
   for (int l = 0; l < B; ++l) {
     const slm_lane& ln = lanes[l];
     const slm_penalty* pen = ln.pen;
-    SLM_TRY(upload_vec_or_const(ds->a0 + (size_t)l * ld, pen ? pen->a : nullptr, p, 1.0, s));
-    SLM_TRY(upload_vec_or_const(ds->b0 + (size_t)l * ld, pen ? pen->b : nullptr, G, 1.0, s));
-    SLM_TRY(upload_vec_or_const(ds->d0 + (size_t)l * ld, pen ? pen->d : nullptr, G, 1.0, s));
+    // lanes that share one penalty (the ranges of a shared path) get lane 0's copy from a device-side
+    // broadcast below instead of thirty small uploads
+    if (!same_pen || l == 0) {
+      SLM_TRY(upload_vec_or_const(ds->a0 + (size_t)l * ld, pen ? pen->a : nullptr, p, 1.0, s));
+      SLM_TRY(upload_vec_or_const(ds->b0 + (size_t)l * ld, pen ? pen->b : nullptr, G, 1.0, s));
+      SLM_TRY(upload_vec_or_const(ds->d0 + (size_t)l * ld, pen ? pen->d : nullptr, G, 1.0, s));
+    }
     HIP_TRY(hipMemcpyAsync(ds->pts + off, ln.points, sizeof(slm_path_point) * ln.n_points,
                            hipMemcpyHostToDevice, s));
     if (ln.beta0) {
@@ -1315,6 +1321,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     h[l].ak = 1.25 * L[l];  // a slightly short first step; the scheme measures its own curvature after it
     h[l].Lhat = 0.5 * L[l];  // a sure lower bound of lambda_max for the residual scaling
     off += ln.n_points;
+  }
+  if (same_pen) {
+    hipLaunchKernelGGL(broadcast_lanes_kernel, dim3(32), dim3(256), 0, s, ds->a0, p, ld, B);
+    hipLaunchKernelGGL(broadcast_lanes_kernel, dim3(32), dim3(256), 0, s, ds->b0, (int64_t)G, ld, B);
+    hipLaunchKernelGGL(broadcast_lanes_kernel, dim3(32), dim3(256), 0, s, ds->d0, (int64_t)G, ld, B);
   }
   HIP_TRY(hipMemcpyAsync(ds->z, ds->beta, sizeof(double) * kMaxLanes * ld, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemcpyAsync(ds->ctl, h, sizeof(PathCtl) * B, hipMemcpyHostToDevice, s));
@@ -1429,6 +1440,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     launch_tail(ta, s);
     if (shared_path) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
     if (use_ws) {
+      hipLaunchKernelGGL(ws_score_kernel, dim3((unsigned)(((ds->singleton ? p : G) + 255) / 256)), dim3(256), 0, s, ta, wa);
       hipLaunchKernelGGL(ws_select_kernel, dim3(1), dim3(WS_THREADS), 0, s, ta, wa);
       hipLaunchKernelGGL(ws_gather_kernel, dim3((unsigned)(eng->cus * 8)), dim3(256), 0, s, wa);
       hipLaunchKernelGGL(ws_gram_kernel, dim3((unsigned)wa.nblk, (unsigned)wa.n_sets, 8), dim3(WS_GRAM_THREADS), 0, s,

@@ -53,6 +53,8 @@ struct WsCtl {
   int32_t counter;    // last-workgroup detection of the reduce kernel
   int32_t stale;      // a lane left W and the build budget is spent: such lanes iterate plainly
   int32_t overflows;  // builds skipped because the non-zero coefficients alone exceed WS_KCAP
+  int32_t sweep_new;  // ws_score_kernel -> ws_select_kernel: features of newcomers at theta ...
+  int32_t sweep_miss; // ... and coordinates a plain step moved outside W (both reset by ws_select_kernel)
   int32_t pad_;
   int32_t last_point[SLM_MAX_LANES];  // path point of each lane's last refinement ...
   int32_t repeats[SLM_MAX_LANES];     // ... and how many times in a row it was that point
@@ -107,8 +109,113 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[16]*/, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// (i) choose W.  One workgroup.  Runs after tail/steal in every pass; returns at once unless a build
-// was requested or a lane's plain step left the current W.  With a valid W the newcomers are
+// (i-a) one sweep over the items (features, or groups), one thread each: entry score (max over lanes;
+// +inf marks items that are non-zero at a lane's expansion point), the feature count of newcomers at
+// the default threshold, and whether the plain step of any lane moved a coordinate outside W
+// (z = candidate / extrapolated point just produced by the tail kernel, zprev = the point it was
+// produced from: they differ outside W exactly when a feature outside W wants to enter).
+// Per-lane constants: is the lane walking a path, and the penalty scales w.lookahead points ahead of
+// where it is (ranges may move between lanes in shared-path mode, so the look-ahead runs to the end of
+// the path there).  Features that would enter by then are taken now; later ones are appended when
+// their time comes.  (Inside the one-workgroup select kernel this sweep cost 45-60 us per pass.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
+  WsCtl* ws = w.ws;
+  if (a.gdone[0] != 0 || ws->disabled) return;
+  const bool had_w = ws->valid != 0;
+  if (!ws->request && !had_w) return;
+  if (ws->builds >= ws->max_builds || ws->appends >= 8 * ws->max_builds) return;
+  const int tid = threadIdx.x;
+  const bool singleton = a.singleton != 0;
+  const int nitems = singleton ? a.p : a.G;
+  __shared__ int lane_live[SLM_MAX_LANES];
+  __shared__ double lane_sa[SLM_MAX_LANES], lane_sb[SLM_MAX_LANES];
+  __shared__ int cnt[2];
+  if (tid < SLM_MAX_LANES) {
+    int live = 0;
+    double sa = 0.0, sb = 0.0;
+    if (tid < a.n_lanes) {
+      const PathCtl* c = a.ctl + tid;
+      live = !(c->done || c->idle);
+      int path_end = 0;
+      for (int l = 0; l < a.n_lanes; ++l) path_end = max(path_end, a.ctl[l].n_points);
+      const int end = a.steal ? path_end : c->pt_off + c->n_points;
+      const int look = min(c->pt_off + c->point + w.lookahead, end - 1);
+      const slm_path_point pe = a.pts[look < 0 ? 0 : look];
+      sa = pe.sa;
+      sb = pe.sb;
+    }
+    lane_live[tid] = live;
+    lane_sa[tid] = sa;
+    lane_sb[tid] = sb;
+  }
+  if (tid == 0) cnt[0] = cnt[1] = 0;
+  __syncthreads();
+
+  const double inf = __builtin_huge_val();
+  int n_new = 0, n_miss = 0;
+  const int it = blockIdx.x * 256 + tid;
+  if (it < nitems) {
+    double sc = 0.0;
+    bool in_w = false;
+    if (singleton) {
+      const int j = it;
+      in_w = had_w && w.pos[j] >= 0;
+#pragma unroll
+      for (int l = 0; l < SLM_MAX_LANES; ++l) {
+        if (l >= a.n_lanes || !lane_live[l]) continue;
+        const int64_t off = (int64_t)l * a.ld;
+        const double zp = a.zprev[off + j];
+        if (!in_w && had_w && a.z[off + j] != zp) n_miss += 1;
+        if (zp != 0.0) {
+          sc = inf;
+        } else {
+          const double thr = lane_sa[l] * a.a0[off + j] + lane_sb[l] * a.b0[off + j];
+          const double gj = a.g[(int64_t)l * (a.ld + 16) + j];
+          sc = fmax(sc, thr > 0.0 ? fabs(gj) / thr : inf);
+        }
+      }
+      if (sc >= w.theta && !in_w) n_new += 1;
+    } else {
+      const int k0 = a.gstart[it], k1 = a.gstart[it + 1];
+      in_w = had_w && w.pos[a.order[k0]] >= 0;
+      for (int l = 0; l < a.n_lanes; ++l) {
+        if (!lane_live[l]) continue;
+        const int64_t off = (int64_t)l * a.ld;
+        const double* g = a.g + (int64_t)l * (a.ld + 16);
+        double num = 0.0, rmax = 0.0;
+        bool act = false;
+        for (int k = k0; k < k1; ++k) {
+          const int j = a.order[k];
+          const double zp = a.zprev[off + j];
+          if (!in_w && had_w && a.z[off + j] != zp) n_miss += 1;
+          act = act || zp != 0.0;
+          const double thr = lane_sa[l] * a.a0[off + j];
+          const double m = fmax(fabs(g[j]) - thr, 0.0);
+          num = __builtin_fma(m, m, num);
+          rmax = fmax(rmax, thr > 0.0 ? fabs(g[j]) / thr : inf);
+        }
+        const double den = lane_sb[l] * a.b0[off + it];
+        const double r = den > 0.0 ? sqrt(num) / den : rmax;
+        sc = act ? inf : fmax(sc, r);
+      }
+      if (sc >= w.theta && !in_w) n_new += k1 - k0;
+    }
+    w.score[it] = sc;
+  }
+  // integer counts: the order of the atomic additions does not matter
+  if (n_new) atomicAdd(&cnt[0], n_new);
+  if (n_miss) atomicAdd(&cnt[1], n_miss);
+  __syncthreads();
+  if (tid == 0) {
+    if (cnt[0]) atomicAdd(&ws->sweep_new, cnt[0]);
+    if (cnt[1]) atomicAdd(&ws->sweep_miss, cnt[1]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (i-b) choose W.  One workgroup.  Runs after ws_score_kernel in every pass; returns at once unless a
+// build was requested, a lane's plain step left the current W, or there are newcomers.  With a valid W the newcomers are
 // APPENDED (their columns and Gram rows are all that has to be produced); a fresh selection is made
 // at the start of a solve and when the appended set would exceed WS_KCAP.
 // ---------------------------------------------------------------------------------------------
@@ -135,88 +242,14 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
     return;
   }
 
-  // per-lane constants: is the lane walking a path, and the penalty scales w.lookahead points ahead
-  // of where it is (ranges may move between lanes in shared-path mode, so the look-ahead runs to the
-  // end of the path there).  Features that would enter by then are taken now; later ones are
-  // appended when their time comes.
-  __shared__ int lane_live[SLM_MAX_LANES];
-  __shared__ double lane_sa[SLM_MAX_LANES], lane_sb[SLM_MAX_LANES];
-  if (tid < SLM_MAX_LANES) {
-    int live = 0;
-    double sa = 0.0, sb = 0.0;
-    if (tid < a.n_lanes) {
-      const PathCtl* c = a.ctl + tid;
-      live = !(c->done || c->idle);
-      int path_end = 0;
-      for (int l = 0; l < a.n_lanes; ++l) path_end = max(path_end, a.ctl[l].n_points);
-      const int end = a.steal ? path_end : c->pt_off + c->n_points;
-      const int look = min(c->pt_off + c->point + w.lookahead, end - 1);
-      const slm_path_point pe = a.pts[look < 0 ? 0 : look];
-      sa = pe.sa;
-      sb = pe.sb;
-    }
-    lane_live[tid] = live;
-    lane_sa[tid] = sa;
-    lane_sb[tid] = sb;
-  }
+  // scores and the two counts come from ws_score_kernel (many workgroups, launched just before)
+  double sweep[2] = {(double)ws->sweep_new, (double)ws->sweep_miss};
   __syncthreads();
-
-  // ---- one sweep: entry score per item (max over lanes; +inf marks items that are non-zero at a
-  //      lane's expansion point), newcomers at the default threshold, and whether the plain step of
-  //      any lane moved a coordinate outside W (z = candidate / extrapolated point just produced by
-  //      the tail kernel, zprev = the point it was produced from: they differ outside W exactly when
-  //      a feature outside W wants to enter) ---------------------------------------------------------
-  const double inf = __builtin_huge_val();
-  double sweep[2] = {0.0, 0.0};  // [0] features of newcomers at theta, [1] coordinates that left W
-  for (int it = tid; it < nitems; it += WS_THREADS) {
-    double sc = 0.0;
-    bool in_w = false;
-    if (singleton) {
-      const int j = it;
-      in_w = had_w && w.pos[j] >= 0;
-#pragma unroll
-      for (int l = 0; l < SLM_MAX_LANES; ++l) {
-        if (l >= a.n_lanes || !lane_live[l]) continue;
-        const int64_t off = (int64_t)l * a.ld;
-        const double zp = a.zprev[off + j];
-        if (!in_w && had_w && a.z[off + j] != zp) sweep[1] += 1.0;
-        if (zp != 0.0) {
-          sc = inf;
-        } else {
-          const double thr = lane_sa[l] * a.a0[off + j] + lane_sb[l] * a.b0[off + j];
-          const double gj = a.g[(int64_t)l * (a.ld + 16) + j];
-          sc = fmax(sc, thr > 0.0 ? fabs(gj) / thr : inf);
-        }
-      }
-      if (sc >= w.theta && !in_w) sweep[0] += 1.0;
-    } else {
-      const int k0 = a.gstart[it], k1 = a.gstart[it + 1];
-      in_w = had_w && w.pos[a.order[k0]] >= 0;
-      for (int l = 0; l < a.n_lanes; ++l) {
-        if (!lane_live[l]) continue;
-        const int64_t off = (int64_t)l * a.ld;
-        const double* g = a.g + (int64_t)l * (a.ld + 16);
-        double num = 0.0, rmax = 0.0;
-        bool act = false;
-        for (int k = k0; k < k1; ++k) {
-          const int j = a.order[k];
-          const double zp = a.zprev[off + j];
-          if (!in_w && had_w && a.z[off + j] != zp) sweep[1] += 1.0;
-          act = act || zp != 0.0;
-          const double thr = lane_sa[l] * a.a0[off + j];
-          const double m = fmax(fabs(g[j]) - thr, 0.0);
-          num = __builtin_fma(m, m, num);
-          rmax = fmax(rmax, thr > 0.0 ? fabs(g[j]) / thr : inf);
-        }
-        const double den = lane_sb[l] * a.b0[off + it];
-        const double r = den > 0.0 ? sqrt(num) / den : rmax;
-        sc = act ? inf : fmax(sc, r);
-      }
-      if (sc >= w.theta && !in_w) sweep[0] += (double)(k1 - k0);
-    }
-    w.score[it] = sc;
+  if (tid == 0) {
+    ws->sweep_new = 0;
+    ws->sweep_miss = 0;
   }
-  block_sum<2>(sweep, red);  // (its barriers also publish score[])
+  const double inf = __builtin_huge_val();
   const bool miss = had_w && sweep[1] != 0.0;
   if (miss && tid == 0) ws->misses += 1;
   if (had_w && !requested && sweep[0] == 0.0) {
