@@ -288,3 +288,36 @@ def test_plain_steps_inside_the_split_pass_use_both_rowdot_windows(eng):
     for r, r0 in zip(res, ref):
         assert r.converged and np.count_nonzero(r.betas[0]) > 512
         assert rel_inf(r.betas, r0.betas) < 1e-7
+
+
+def test_estimators_on_large_X_take_the_working_set_path(monkeypatch):
+    # n * ld >= 2^26: the engine's default policy switches the refinement and the split pass on; the
+    # estimator surface (sample weights, intercept, groups, adaptive re-weighting) must give the same
+    # coefficients as with the plain iteration (SLM_WS=0)
+    import warnings
+
+    from sparselm_amd.model import AdaptiveLasso, Lasso, SparseGroupLasso
+
+    rng = np.random.default_rng(12)
+    n, p = 70_000, 960  # 67.2M doubles
+    X = rng.standard_normal((n, p))
+    beta = np.zeros(p)
+    beta[rng.choice(p, 20, replace=False)] = rng.uniform(1, 4, 20) * rng.choice([-1, 1], 20)
+    y = X @ beta + 3.0 + rng.standard_normal(n)
+    w = rng.uniform(0.5, 1.5, n)
+    groups = np.repeat(np.arange(p // 8), 8)
+    cases = [
+        (lambda: Lasso(alpha=0.05, fit_intercept=True), dict(sample_weight=w)),
+        (lambda: SparseGroupLasso(groups=groups, alpha=0.05, l1_ratio=0.4), {}),
+        (lambda: AdaptiveLasso(alpha=0.05, max_iter=3), {}),
+    ]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for make, kw in cases:
+            monkeypatch.delenv("SLM_WS", raising=False)
+            a = make().fit(X, y, **kw)
+            monkeypatch.setenv("SLM_WS", "0")
+            b = make().fit(X, y, **kw)
+            assert rel_inf(a.coef_, b.coef_) < 1e-6, type(a).__name__
+            assert abs(a.intercept_ - b.intercept_) <= 1e-6 * max(1.0, abs(b.intercept_))
+            assert np.count_nonzero(a.coef_) >= 20
