@@ -243,7 +243,7 @@ struct slm_dataset {
   // working-set refinement (ws_kernels.hpp), allocated on first use
   WsCtl* ws_ctl = nullptr;
   int32_t *ws_idx = nullptr, *ws_pos = nullptr, *ws_gs = nullptr, *ws_gl = nullptr;
-  double *ws_score = nullptr, *ws_XW = nullptr, *ws_part = nullptr, *ws_G = nullptr;
+  double *ws_score = nullptr, *ws_XW = nullptr, *ws_part = nullptr, *ws_G = nullptr, *ws_Gx = nullptr;
   int ws_sets = 0;  // Gram copies allocated
   // gradient launch, per lane count B = 1..kMaxLanes (index B-1); gk == nullptr => unsupported
   const GradKernel* gk[SLM_MAX_LANES] = {};
@@ -388,7 +388,7 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->lambda); dfree(ds->ctl); dfree(ds->gctl);
   dfree(ds->pts); dfree(ds->betas_out); dfree(ds->gn_out); dfree(ds->infos);
   dfree(ds->ws_ctl); dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
-  dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G);
+  dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   for (auto& e : ds->ev)
     if (e) (void)hipEventDestroy(e);
@@ -834,6 +834,10 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
     ra.loss_scale[l] = 0.5 / ne;
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(ds->ld / 16 + 1), ls.B), dim3(256), 0, s, ra);
+  if (ds->eng->comm) {  // row-sharded: sum the gradients (and losses) of the row blocks over ranks
+    RCCL_TRY(g_rccl.AllReduce(ds->g, ds->g, (size_t)ls.B * (size_t)(ds->ld + 16), kNcclFloat64, kNcclSum,
+                              ds->eng->comm, s));
+  }
   return SLM_OK;
 }
 
@@ -1148,7 +1152,7 @@ static int upload_vec_or_const(double* dst, const double* src, int64_t count, do
 // (small problems), 2 = from the first pass.
 static int ws_policy(const slm_dataset* ds, uint32_t flags) {
   const char* env = getenv("SLM_WS");
-  if (ds->eng->comm || ds->max_group > 64 || ds->n < 4) return 0;
+  if (ds->max_group > 64 || ds->n < 4) return 0;
   if ((env && env[0] == '0') || (flags & SLM_FLAG_NO_WORKING_SET)) return 0;
   const bool big = (double)ds->n * (double)ds->ld >= 67108864.0;  // 2^26 doubles = 512 MiB
   return (big || (flags & SLM_FLAG_WORKING_SET) || (env && env[0] == '1')) ? 2 : 1;
@@ -1389,8 +1393,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       SLM_TRY(dalloc(&ds->ws_XW, (size_t)n * WS_KCAP));
     }
     if (ds->ws_sets < n_sets) {
-      dfree(ds->ws_part); dfree(ds->ws_G);
+      dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
       ds->ws_sets = 0;
+      if (eng->comm) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)n_sets * WS_KCAP * WS_KCAP));
       SLM_TRY(dalloc(&ds->ws_part, (size_t)eng->cus * n_sets * WS_KCAP * WS_KCAP));
       SLM_TRY(dalloc(&ds->ws_G, (size_t)n_sets * WS_KCAP * WS_KCAP));
       ds->ws_sets = n_sets;
@@ -1405,6 +1410,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     wa.ws = ds->ws_ctl;
     wa.idx = ds->ws_idx; wa.pos = ds->ws_pos; wa.gs = ds->ws_gs; wa.gl = ds->ws_gl;
     wa.score = ds->ws_score; wa.XW = ds->ws_XW; wa.part = ds->ws_part; wa.Gm = ds->ws_G;
+    if (eng->comm && !ds->ws_Gx) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)ds->ws_sets * WS_KCAP * WS_KCAP));
+    wa.Gx = eng->comm ? ds->ws_Gx : nullptr;  // row-sharded: Gram parts are summed over ranks before use
     wa.X = ds->X; wa.n = n; wa.ld = ld;
     wa.rw = ls.rw; wa.rw_stride = ls.rw_stride;
     for (int l = 0; l < kMaxLanes; ++l)
@@ -1435,6 +1442,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (split) return enqueue_gradient_split(ds, ls, ds->y, done_flag, ds->ctl, &wa, e0, e1);
     return enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1);
   };
+  int ws_comm_rc = 0;  // first RCCL error of the per-pass Gram all-reduce (checked after each chunk)
   // everything that follows the gradient of one pass
   auto enqueue_after_gradient = [&]() {
     launch_tail(ta, s);
@@ -1445,8 +1453,18 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       hipLaunchKernelGGL(ws_gather_kernel, dim3((unsigned)(eng->cus * 8)), dim3(256), 0, s, wa);
       hipLaunchKernelGGL(ws_gram_kernel, dim3((unsigned)wa.nblk, (unsigned)wa.n_sets, 8), dim3(WS_GRAM_THREADS), 0, s,
                          wa);
+      if (wa.Gx)  // (zero where this pass builds nothing, so the unconditional all-reduce below is harmless)
+        (void)hipMemsetAsync(wa.Gx, 0, sizeof(double) * (size_t)wa.n_sets * WS_KCAP * WS_KCAP, s);
       hipLaunchKernelGGL(ws_gram_reduce_kernel, dim3(WS_TILES * WS_TILES, (unsigned)wa.n_sets), dim3(256),
                          0, s, wa);
+      if (wa.Gx) {
+        // one collective per pass on every rank whether or not a build is under way: the ranks run the
+        // same state machine on the same all-reduced gradients, so they agree on when that is
+        ws_comm_rc = g_rccl.AllReduce(wa.Gx, wa.Gx, (size_t)wa.n_sets * WS_KCAP * WS_KCAP, kNcclFloat64, kNcclSum,
+                                      eng->comm, s);
+        hipLaunchKernelGGL(ws_publish_kernel, dim3(WS_KCAP * WS_KCAP / 256, (unsigned)wa.n_sets), dim3(256), 0, s,
+                           wa);
+      }
       hipLaunchKernelGGL(ws_solve_kernel, dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
     }
   };
@@ -1541,6 +1559,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         ++enq;
       }
       SLM_TRY(check_launch());
+      if (ws_comm_rc != 0) return fail(SLM_ERR_COMM, "ncclAllReduce of the working-set Gram failed (%d)", ws_comm_rc);
       HIP_TRY(hipMemcpyAsync(&ds->hctl[slot].g, ds->gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipEventRecord(ds->ev[slot], s));

@@ -55,7 +55,8 @@ struct WsCtl {
   int32_t overflows;  // builds skipped because the non-zero coefficients alone exceed WS_KCAP
   int32_t sweep_new;  // ws_score_kernel -> ws_select_kernel: features of newcomers at theta ...
   int32_t sweep_miss; // ... and coordinates a plain step moved outside W (both reset by ws_select_kernel)
-  int32_t pad_;
+  int32_t staged;     // row-sharded mode: the local Gram parts sit in the staging matrix, waiting for the
+                      // all-reduce and ws_publish_kernel
   int32_t last_point[SLM_MAX_LANES];  // path point of each lane's last refinement ...
   int32_t repeats[SLM_MAX_LANES];     // ... and how many times in a row it was that point
   double Lw[SLM_MAX_LANES];  // lambda_max estimate per Gram (0 = not yet computed)
@@ -71,6 +72,8 @@ struct WsArgs {
   double* XW;      // [n][WS_KCAP] gathered columns
   double* part;    // [n_sets][tile][nblk][16 x 16] partial Grams
   double* Gm;      // [n_sets][WS_KCAP * WS_KCAP]
+  double* Gx;      // row-sharded mode: [n_sets][WS_KCAP * WS_KCAP] staging, zeroed every pass, summed over
+                   // ranks between ws_gram_reduce_kernel and ws_publish_kernel (nullptr otherwise)
   const double* X;
   int64_t n, ld;
   const double* rw;   // row weights per set, or nullptr (all ones)
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(256) void ws_gram_reduce_kernel(WsArgs w) {
     }
     for (; b < w.nblk; ++b) s4[b & 3] += src[(int64_t)b * 256];
     double s = ((s4[0] + s4[1]) + (s4[2] + s4[3])) * w.inv_n[set];
-    double* Gs = w.Gm + (int64_t)set * (WS_KCAP * WS_KCAP);
+    double* Gs = (w.Gx ? w.Gx : w.Gm) + (int64_t)set * (WS_KCAP * WS_KCAP);
     Gs[i * WS_KCAP + j] = s;
     if (j < row_lo) Gs[j * WS_KCAP + i] = s;
   }
@@ -574,6 +577,39 @@ __global__ __launch_bounds__(256) void ws_gram_reduce_kernel(WsArgs w) {
     const int total = (tiles - I_lo) * tiles * (int)gridDim.y;
     if (atomicAdd(&ws->counter, 1) + 1 == total) {
       ws->counter = 0;
+      if (w.Gx) {
+        ws->staged = 1;  // this rank's rows only: all-reduce, then ws_publish_kernel
+      } else {
+        ws->request = 0;
+        ws->valid = 1;
+        __threadfence();
+        ws->building = 0;
+      }
+    }
+  }
+}
+
+// Row-sharded mode: after the all-reduce of the staging matrix, move the new rows / columns into the
+// Gram and publish it.  grid (WS_KCAP * WS_KCAP / 256, n_sets).
+__global__ __launch_bounds__(256) void ws_publish_kernel(WsArgs w) {
+  WsCtl* ws = w.ws;
+  if (!ws->building || !ws->staged) return;
+  const int K = ws->K;
+  const int row_lo = (ws->k_new >> 4) << 4;
+  const int set = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int i = e / WS_KCAP, j = e % WS_KCAP;
+  if (i < K && j < K && (i >= row_lo || j >= row_lo)) {
+    const int64_t at = (int64_t)set * (WS_KCAP * WS_KCAP) + e;
+    w.Gm[at] = w.Gx[at];
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = gridDim.x * gridDim.y;
+    if (atomicAdd(&ws->counter, 1) + 1 == total) {
+      ws->counter = 0;
+      ws->staged = 0;
       ws->request = 0;
       ws->valid = 1;
       __threadfence();

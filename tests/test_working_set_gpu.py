@@ -321,3 +321,32 @@ def test_estimators_on_large_X_take_the_working_set_path(monkeypatch):
             assert rel_inf(a.coef_, b.coef_) < 1e-6, type(a).__name__
             assert abs(a.intercept_ - b.intercept_) <= 1e-6 * max(1.0, abs(b.intercept_))
             assert np.count_nonzero(a.coef_) >= 20
+
+
+def test_working_set_in_row_sharded_mode_with_one_rank():
+    # RCCL communicator with a single rank: the Gram parts go through the staging matrix, the
+    # all-reduce and ws_publish_kernel; the gradient of the split pass is all-reduced too
+    from sparselm_amd import distributed as D
+
+    n, G, size = 6000, 40, 5
+    p = G * size
+    groups = np.random.default_rng(3).permutation(np.repeat(np.arange(G), size))
+    X, y = problem(n, p, 5, seed=23, groups=groups)
+    alphas = alpha_path(X, y, k=10, lo=3e-2, groups=groups, G=G)
+    pts = [(0.3 * a, 0.7 * a, 0) for a in alphas]
+    eng2 = _engine.Engine(0)
+    try:
+        D.init_row_sharding(eng2, rank=0, world_size=1)
+        with eng2.dataset(X, y) as ds:
+            ds.set_global_rows(n)
+            ds.set_groups(groups, G)
+            r1 = ds.solve_path(pts, tol=1e-11, lanes=4, flags=WS)
+            r0 = ds.solve_path(pts, tol=1e-11, lanes=1, flags=NO_WS)
+    finally:
+        eng2.comm_destroy()
+        eng2.close()
+    assert r1.converged and r1.ws_builds >= 1 and r1.ws_refined > 0
+    assert rel_inf(r1.betas, r0.betas) < 1e-8
+    assert r1.grad_launches < r0.grad_launches
+    ref = ofista(X, y, pts[-1][0] * np.ones(p), pts[-1][1] * np.ones(G), None, groups, G)
+    assert rel_inf(r1.betas[-1], ref) < 1e-8
