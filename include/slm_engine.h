@@ -128,7 +128,8 @@ int slm_gradient(slm_dataset* ds, const double* z, double* g_out, double* loss_o
                  double* ms_out);
 
 /*
- * Weighted squared error of m coefficient vectors in ceil(m / SLM_MAX_LANES) passes over X:
+ * Weighted squared error of m coefficient vectors, as many per pass over X as the fused kernel
+ * table has lanes for this p:
  *   sse_out[k] = sum_i w_i (x_i . Z[k] - y_i)^2        (Z: m x p, C-order, host)
  * row_weight (length n, host, nullable => the dataset's) is typically the TEST mask of a CV fold, so
  * that hold-out scores come from the resident X instead of a host GEMM (the reference scores with
@@ -213,7 +214,10 @@ int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point
  * scaling.  The fused gradient kernel streams X once and produces all lanes' gradients, so B lanes
  * cost the HBM traffic of one.  Used for the alpha sub-paths of one long path, for the folds of a
  * cross-validation, or both.  n_lanes <= SLM_MAX_LANES; SLM_ERR_UNSUPPORTED if no kernel variant
- * covers (p, n_lanes) -- callers then fall back to fewer lanes.
+ * covers (p, n_lanes) -- callers then fall back to fewer lanes.  How many lanes a pass can serve:
+ * the fused kernels go up to 4 at p = 5000 (6 up to 3072 columns: z and the accumulators of every
+ * lane live in registers); working-set solves on rows of up to 5120 columns use the split pass, whose
+ * accumulate-only stream over X serves SLM_MAX_LANES.
  */
 #define SLM_MAX_LANES 10
 typedef struct slm_lane {
