@@ -1173,6 +1173,16 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     return fail(SLM_ERR_BAD_ARG, "n_lanes must be in [1, %d] (got %d)", kMaxLanes, n_lanes);
   const int B = n_lanes;
   const bool split = ws_policy(ds, opts ? opts->flags : 0u) == 2 && ds->sk != nullptr;
+  // Shared path with the working set on from the start: the lanes take the points of the path in turn
+  // (lane l: l, l + B, ...) instead of contiguous ranges.  Every lane then starts near alpha_max, where
+  // the first working set (chosen from the gradient at zero) is enough, and all lanes move down the
+  // path together, so W only ever has to cover one band of alphas; a contiguous split starts some lanes
+  // cold at small alpha, whose first refinement misses features W could not know about (one extra pass).
+  // (Only for per-feature penalties.  With group penalties the cold starts do not miss -- config 3: no
+  // miss either way -- while looking a whole stride ahead pulls noise groups into W: 380 columns and
+  // 10.9 ms per path against 250 columns and 10.3 ms with contiguous ranges.)
+  const bool interleave = shared_path && ds->singleton && ws_policy(ds, opts ? opts->flags : 0u) == 2 &&
+                          !getenv("SLM_NO_INTERLEAVE");
   if (!split && !ds->gk[B - 1])
     return fail(SLM_ERR_UNSUPPORTED, "no %d-lane gradient kernel covers p = %lld", B, (long long)ds->p);
   int64_t total_points = 0;
@@ -1315,7 +1325,13 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     h[l].tol = o.tol;
     h[l].flags = o.flags;
     h[l].pt_off = shared_path ? 0 : (int32_t)off;
-    if (shared_path) {  // global indices: [off, off + n_points)
+    h[l].stride = 1;
+    if (shared_path && interleave) {  // lane l takes points l, l + B, l + 2B, ... of the whole path
+      h[l].point = l;
+      h[l].pt_lo = l;
+      h[l].n_points = (int32_t)total_points;
+      h[l].stride = B;
+    } else if (shared_path) {  // global indices: [off, off + n_points)
       h[l].point = (int32_t)off;
       h[l].pt_lo = (int32_t)off;
       h[l].n_points = (int32_t)(off + ln.n_points);
@@ -1342,7 +1358,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   ta.ctl = ds->ctl;
   ta.gdone = reinterpret_cast<int*>(ds->gctl);
   ta.n_lanes = B;
-  ta.steal = shared_path ? 1 : 0;
+  ta.steal = (shared_path && !interleave) ? 1 : 0;  // interleaved lanes are balanced by construction
   ta.pts = ds->pts;
   ta.p = (int)p;
   ta.G = G;
@@ -1422,7 +1438,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     // measured on the headline path (tools/ws_sweep.py, 24 combinations within 8 % of each other):
     // theta 0.85 / look-ahead 2 / 16 newcomers per pass / 112 initial columns was the fastest
     wa.lookahead = 2;
-    wa.append_max = 16;
+    wa.append_max = interleave ? 48 : 16;  // interleaved lanes need the next band of the path at once
     wa.k_init = ds->singleton ? 112 : 256;  // groups bring their features in blocks (config 3: 12.4 vs 29.6 ms per path)
     // tuning knobs (tools/ws_sweep.py)
     if (const char* th = getenv("SLM_WS_THETA")) {
@@ -1446,7 +1462,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // everything that follows the gradient of one pass
   auto enqueue_after_gradient = [&]() {
     launch_tail(ta, s);
-    if (shared_path) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
+    if (shared_path && !interleave) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
     if (use_ws) {
       hipLaunchKernelGGL(ws_score_kernel, dim3((unsigned)(((ds->singleton ? p : G) + 255) / 256)), dim3(256), 0, s, ta, wa);
       hipLaunchKernelGGL(ws_select_kernel, dim3(1), dim3(WS_THREADS), 0, s, ta, wa);

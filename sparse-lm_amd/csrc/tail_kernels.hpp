@@ -54,7 +54,8 @@ struct PathCtl {
   int32_t steals;      // ranges this lane took over from busier lanes
   int32_t idle;        // shared-path mode: finished its range, waiting for steal_kernel to hand out work
   int32_t zzero;       // z has not moved from the all-zero start (split pass: residual = -y, no read of X)
-  int32_t pad2_;
+  int32_t stride;      // points between this lane's consecutive path points: 1 (a contiguous range), or the
+                       // number of lanes when the lanes of a shared path take its points in turn
   int32_t zsup;        // z is zero outside the working set: its residual can come from the gathered
                        // columns (split_kernels.hpp); maintained by ws_solve_kernel
 };
@@ -514,11 +515,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   // ---- state update --------------------------------------------------------------------------
   // secant prediction of the next point's start from the last two solutions (see slm_path_point)
   double extrap = 0.0;
-  if (finalize && !cold && !nonfinite && point - pt_lo >= 1 && point + 1 < n_points)
+  const int stride = ctl->stride > 1 ? ctl->stride : 1;
+  // (interleaved lanes: the neighbouring points belong to other lanes and finish in this same launch,
+  //  so there is no secant through them -- the next point starts from this lane's last solution)
+  if (finalize && !cold && !nonfinite && stride == 1 && point - pt_lo >= 1 && point + 1 < n_points)
     extrap = a.pts[point + 1].extrap;
   // End of this lane's range: in shared-path mode the lane goes idle and steal_kernel (launched
   // right after this kernel, when every lane's state is at rest) hands it new work or retires it.
-  const bool range_end = finalize && !nonfinite && (point + 1 >= n_points);
+  const bool range_end = finalize && !nonfinite && (point + stride >= n_points);
   const bool goes_idle = range_end && a.steal;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       ctl->have_base = 0;  // the next point's objective differs: start its history afresh
       ctl->n_hist = 0;
       ctl->pen_z = 0.0;
-      ctl->point = point + 1;
+      ctl->point = point + stride;
       if (nonfinite) {
         ctl->nonfinite = 1;
         ctl->done = 1;

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
       int path_end = 0;
       for (int l = 0; l < a.n_lanes; ++l) path_end = max(path_end, a.ctl[l].n_points);
       const int end = a.steal ? path_end : c->pt_off + c->n_points;
-      const int look = min(c->pt_off + c->point + w.lookahead, end - 1);
+      // (interleaved lanes jump `stride` points at a time: look at least as far as the next one)
+      const int look = min(c->pt_off + c->point + max(w.lookahead, c->stride), end - 1);
       const slm_path_point pe = a.pts[look < 0 ? 0 : look];
       sa = pe.sa;
       sb = pe.sb;

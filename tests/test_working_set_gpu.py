@@ -350,3 +350,22 @@ def test_working_set_in_row_sharded_mode_with_one_rank():
     assert r1.grad_launches < r0.grad_launches
     ref = ofista(X, y, pts[-1][0] * np.ones(p), pts[-1][1] * np.ones(G), None, groups, G)
     assert rel_inf(r1.betas[-1], ref) < 1e-8
+
+
+def test_interleaved_lanes_of_a_shared_path(eng, monkeypatch):
+    # working set from the start + per-feature penalty: the lanes of a shared path take its points in
+    # turn (lane l: l, l + B, ...); same coefficients as contiguous ranges, never more passes
+    n, p = 5000, 800
+    X, y = problem(n, p, 16, seed=91)
+    alphas = alpha_path(X, y, k=23, lo=5e-3)  # 23 points over 5 lanes: ragged last round
+    pts = [(a, 0, 0) for a in alphas]
+    with eng.dataset(X, y) as ds:
+        ri = ds.solve_path(pts, tol=1e-11, lanes=5, flags=WS)
+        monkeypatch.setenv("SLM_NO_INTERLEAVE", "1")
+        rc = ds.solve_path(pts, tol=1e-11, lanes=5, flags=WS)
+        monkeypatch.delenv("SLM_NO_INTERLEAVE")
+        r1 = ds.solve_path(pts, tol=1e-11, lanes=1, flags=NO_WS)
+    assert ri.converged and rc.converged
+    assert rel_inf(ri.betas, r1.betas) < 1e-8 and rel_inf(rc.betas, r1.betas) < 1e-8
+    assert ri.grad_launches <= rc.grad_launches
+    assert ri.grad_launches <= 1 + -(-len(alphas) // 5) + 2
