@@ -14,7 +14,7 @@ ds = eng.synthetic_dataset(n, p, seed=1000, coef=make_coef(p, 50, seed=0), noise
 g0, _, _ = ds.gradient(None, reps=50)
 amax = float(np.max(np.abs(g0)))
 pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-3 * amax, K)]
-grid = dict(SLM_WS_THETA=["0.7", "0.85"], SLM_WS_LOOKAHEAD=["1", "2", "3"], SLM_WS_APPEND=["16", "32"], SLM_WS_KINIT=["112", "160"])
+grid = dict(SLM_WS_THETA=["0.85", "0.95"], SLM_WS_LOOKAHEAD=["2"], SLM_WS_APPEND=["24", "48", "96"], SLM_WS_KINIT=["64", "112"])
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     grid = dict(SLM_WS_THETA=["0.7"], SLM_WS_LOOKAHEAD=["4"], SLM_WS_APPEND=["32"], SLM_WS_KINIT=["112"])
 for combo in itertools.product(*grid.values()):
