@@ -1172,7 +1172,10 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   if (n_lanes < 1 || n_lanes > kMaxLanes)
     return fail(SLM_ERR_BAD_ARG, "n_lanes must be in [1, %d] (got %d)", kMaxLanes, n_lanes);
   const int B = n_lanes;
-  const bool split = ws_policy(ds, opts ? opts->flags : 0u) == 2 && ds->sk != nullptr;
+  // the split pass costs four launches where the fused kernel costs one: take it when X is large (the
+  // accumulate-only stream is then all that matters) or when only it has enough lanes
+  const bool split = ws_policy(ds, opts ? opts->flags : 0u) == 2 && ds->sk != nullptr &&
+                     ((double)ds->n * (double)ds->ld >= 67108864.0 || !ds->gk[B - 1]);
   // Shared path with the working set on from the start: the lanes take the points of the path in turn
   // (lane l: l, l + B, ...) instead of contiguous ranges.  Every lane then starts near alpha_max, where
   // the first working set (chosen from the gradient at zero) is enough, and all lanes move down the
@@ -1412,7 +1415,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
       ds->ws_sets = 0;
       if (eng->comm) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)n_sets * WS_KCAP * WS_KCAP));
-      SLM_TRY(dalloc(&ds->ws_part, (size_t)eng->cus * n_sets * WS_KCAP * WS_KCAP));
+      SLM_TRY(dalloc(&ds->ws_part, (size_t)ws_nblk * n_sets * WS_KCAP * WS_KCAP));  // (ws_nblk depends on n only)
       SLM_TRY(dalloc(&ds->ws_G, (size_t)n_sets * WS_KCAP * WS_KCAP));
       ds->ws_sets = n_sets;
     }
