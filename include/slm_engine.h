@@ -154,7 +154,7 @@ typedef struct slm_path_point {
 } slm_path_point;
 
 #define SLM_FLAG_NO_RESTART 1u   /* disable the gradient-scheme momentum restart        */
-#define SLM_FLAG_PROFILE 2u      /* bracket every 4th gradient launch with HIP events     */
+#define SLM_FLAG_PROFILE 2u      /* bracket every 2nd gradient launch with HIP events     */
 #define SLM_FLAG_COLD_START 4u   /* do not warm-start point k+1 from point k             */
 #define SLM_FLAG_FRESH_L 8u      /* re-estimate the Lipschitz constant even if cached     */
 #define SLM_FLAG_FISTA_ONLY 16u  /* never use spectral steps (plain FISTA with restart)  */

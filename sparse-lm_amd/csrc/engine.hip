@@ -149,7 +149,7 @@ static const GradKernel kGradExtra[] = {
     SLM_GK(8, 8, 1, 1), SLM_GK(8, 5, 1, 2), SLM_GK(8, 5, 1, 3), SLM_GK(8, 4, 4, 2), SLM_GK(8, 6, 1, 2),
 };
 static const int kMaxTailE = 64;  // tail kernel instantiations cover p <= 1024 * 64
-static const int kProfStride = 4;  // SLM_FLAG_PROFILE times every 4th gradient launch
+static const int kProfStride = 2;  // SLM_FLAG_PROFILE times every 2nd gradient launch (a working-set path has ~6)
 static const int64_t kMaxChunks = 64 * 8 * 10;  // largest row the fused kernel covers (p <= 10240)
 
 // Rows longer than the fused kernels cover: two-pass fallback (D = -1), one lane, any p.
