@@ -8,6 +8,7 @@ reference's random stream, so labels for a given seed differ from the reference'
 
 from __future__ import annotations
 
+import warnings
 from collections.abc import Sequence
 
 import numpy as np
@@ -50,10 +51,20 @@ def make_group_regression(
     groups = np.repeat(np.arange(n_groups), sizes)
     beta = np.zeros(p)
     start = np.concatenate(([0], np.cumsum(sizes)))
-    for g in rng.choice(n_groups, size=n_informative_groups, replace=False):
-        k = max(1, int(round(frac_informative_in_group * sizes[g])))
-        idx = start[g] + rng.choice(sizes[g], size=k, replace=False)
-        beta[idx] = 100.0 * rng.uniform(size=k)
+    # as in the reference (dataset.py:66-95) the informative groups are the first n_informative_groups
+    # (labels are shuffled over the columns below), each with round(frac * size) informative features
+    counts = [round(frac_informative_in_group * sizes[g]) for g in range(n_informative_groups)]
+    if any(k < 1 for k in counts):
+        warnings.warn(
+            "The number of features and fraction of informative features per group resulted in "
+            "informative groups having no informative features.",
+            UserWarning,
+        )
+    for g, k in enumerate(counts):
+        if k < 1:
+            continue
+        idx = start[g] + rng.choice(sizes[g], size=min(k, sizes[g]), replace=False)
+        beta[idx] = 100.0 * rng.uniform(size=len(idx))
     y = X @ beta + bias
     if noise > 0.0:
         y = y + rng.normal(scale=noise, size=n_samples)
