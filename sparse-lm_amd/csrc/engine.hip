@@ -244,6 +244,8 @@ struct slm_dataset {
   WsCtl* ws_ctl = nullptr;
   int32_t *ws_idx = nullptr, *ws_pos = nullptr, *ws_gs = nullptr, *ws_gl = nullptr;
   double *ws_score = nullptr, *ws_XW = nullptr, *ws_part = nullptr, *ws_G = nullptr, *ws_Gx = nullptr;
+  double* XT = nullptr;  // column-major copy of X for the column gathers ([p][ldt]), built on first use
+  int64_t ldt = 0;
   int ws_sets = 0;  // Gram copies allocated
   // gradient launch, per lane count B = 1..kMaxLanes (index B-1); gk == nullptr => unsupported
   const GradKernel* gk[SLM_MAX_LANES] = {};
@@ -388,7 +390,7 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->lambda); dfree(ds->ctl); dfree(ds->gctl);
   dfree(ds->pts); dfree(ds->betas_out); dfree(ds->gn_out); dfree(ds->infos);
   dfree(ds->ws_ctl); dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
-  dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
+  dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   for (auto& e : ds->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1419,6 +1421,16 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       SLM_TRY(dalloc(&ds->ws_G, (size_t)n_sets * WS_KCAP * WS_KCAP));
       ds->ws_sets = n_sets;
     }
+    if (!ds->XT) {
+      // column-major copy of X (a layout of the data like the padded row-major one: depends on nothing
+      // but X, kept for the life of the dataset; 2 ms for 4 GB)
+      ds->ldt = (n + 15) / 16 * 16;
+      SLM_TRY(dalloc(&ds->XT, (size_t)ld * ds->ldt));  // (ld rows: the transpose also writes the pad columns)
+      const dim3 grid((unsigned)((ld + 31) / 32), (unsigned)((n + 31) / 32));
+      // X seen as an F-order (ld x n) matrix with leading dimension ld -> row-major [ld][ldt]; rows >= p
+      // of the result are the pad columns and are not written
+      hipLaunchKernelGGL(transpose_f2c_kernel, grid, dim3(256), 0, s, (const double*)ds->X, ld, n, ds->XT, ds->ldt);
+    }
     WsCtl wc;
     memset(&wc, 0, sizeof(wc));
     wc.request = 1;
@@ -1431,7 +1443,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     wa.score = ds->ws_score; wa.XW = ds->ws_XW; wa.part = ds->ws_part; wa.Gm = ds->ws_G;
     if (eng->comm && !ds->ws_Gx) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)ds->ws_sets * WS_KCAP * WS_KCAP));
     wa.Gx = eng->comm ? ds->ws_Gx : nullptr;  // row-sharded: Gram parts are summed over ranks before use
-    wa.X = ds->X; wa.n = n; wa.ld = ld;
+    wa.X = ds->X; wa.XT = ds->XT; wa.ldt = ds->ldt; wa.n = n; wa.ld = ld;
     wa.rw = ls.rw; wa.rw_stride = ls.rw_stride;
     for (int l = 0; l < kMaxLanes; ++l)
       wa.inv_n[l] = 1.0 / (ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global);
@@ -1469,7 +1481,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (use_ws) {
       hipLaunchKernelGGL(ws_score_kernel, dim3((unsigned)(((ds->singleton ? p : G) + 255) / 256)), dim3(256), 0, s, ta, wa);
       hipLaunchKernelGGL(ws_select_kernel, dim3(1), dim3(WS_THREADS), 0, s, ta, wa);
-      hipLaunchKernelGGL(ws_gather_kernel, dim3((unsigned)(eng->cus * 8)), dim3(256), 0, s, wa);
+      hipLaunchKernelGGL(ws_gather_kernel, dim3((unsigned)std::min<int64_t>((n + 31) / 32, 1024), WS_KCAP / 32), dim3(256), 0, s, wa);
       hipLaunchKernelGGL(ws_gram_kernel, dim3((unsigned)wa.nblk, (unsigned)wa.n_sets, 8), dim3(WS_GRAM_THREADS), 0, s,
                          wa);
       if (wa.Gx)  // (zero where this pass builds nothing, so the unconditional all-reduce below is harmless)

@@ -75,6 +75,8 @@ struct WsArgs {
   double* Gx;      // row-sharded mode: [n_sets][WS_KCAP * WS_KCAP] staging, zeroed every pass, summed over
                    // ranks between ws_gram_reduce_kernel and ws_publish_kernel (nullptr otherwise)
   const double* X;
+  const double* XT;   // column-major copy of X ([p][ldt], built once per dataset): columns are contiguous
+  int64_t ldt;
   int64_t n, ld;
   const double* rw;   // row weights per set, or nullptr (all ones)
   int64_t rw_stride;
@@ -413,19 +415,35 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
 }
 
 // ---------------------------------------------------------------------------------------------
-// (ii) gather the new columns: XW[i][k] = X[i][idx[k]] for k >= k_new (0 for padding positions)
+// (ii) gather the new columns: XW[i][k] = X[i][idx[k]] for k >= k_new (0 for padding positions).
+// Read from the column-major copy XT, where a column is contiguous, through a 32 x 32 LDS tile, so
+// reads and writes both move 256-byte segments.  (Gathering from the row-major X touches one 64-byte
+// sector per element: 0.2 ms for 112 columns, 0.5 ms per 50-alpha path.)  grid (row tiles, 16 column
+// tiles of 32 starting at k_new); tiles beyond K return at once.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
   if (!w.ws->building) return;
-  const int k0 = w.ws->k_new;
-  const int Kn = w.ws->K - k0;
-  const int64_t total = w.n * Kn;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = e / Kn;
-    const int k = k0 + (int)(e - i * Kn);
-    const int j = w.idx[k];
-    w.XW[i * WS_KCAP + k] = j >= 0 ? w.X[i * w.ld + j] : 0.0;
+  const int K = w.ws->K;
+  const int k0 = w.ws->k_new + 32 * (int)blockIdx.y;
+  if (k0 >= K) return;
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t row_tiles = (w.n + 31) / 32;
+  for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
+    const int64_t i0 = rt * 32;
+    __syncthreads();  // the tile of the previous round has been written out
+    for (int kk = ty; kk < 32; kk += 8) {  // read: lanes walk rows i (contiguous in XT)
+      const int k = k0 + kk;
+      const int j = k < K ? w.idx[k] : -1;
+      const int64_t i = i0 + tx;
+      tile[kk][tx] = (j >= 0 && i < w.n) ? w.XT[(int64_t)j * w.ldt + i] : 0.0;
+    }
+    __syncthreads();
+    for (int ii = ty; ii < 32; ii += 8) {  // write: lanes walk positions k (contiguous in XW)
+      const int64_t i = i0 + ii;
+      const int k = k0 + tx;
+      if (i < w.n && k < K) w.XW[i * WS_KCAP + k] = tile[tx][ii];
+    }
   }
 }
 
