@@ -244,8 +244,9 @@ struct slm_dataset {
   WsCtl* ws_ctl = nullptr;
   int32_t *ws_idx = nullptr, *ws_pos = nullptr, *ws_gs = nullptr, *ws_gl = nullptr;
   double *ws_score = nullptr, *ws_XW = nullptr, *ws_part = nullptr, *ws_G = nullptr, *ws_Gx = nullptr;
-  double* XT = nullptr;  // column-major copy of X for the column gathers ([p][ldt]), built on first use
+  double* XT = nullptr;  // column-major copy of X for the column gathers ([ld][ldt]), built on first use
   int64_t ldt = 0;
+  bool XT_ready = false, XT_failed = false;
   int ws_sets = 0;  // Gram copies allocated
   // gradient launch, per lane count B = 1..kMaxLanes (index B-1); gk == nullptr => unsupported
   const GradKernel* gk[SLM_MAX_LANES] = {};
@@ -981,6 +982,7 @@ extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y
   HIP_TRY(hipStreamSynchronize(s));
   if (y_mean_out) *y_mean_out = ymean;
   ds->L_valid = false;
+  ds->XT_ready = false;  // X changed in place: the column-major copy is rebuilt on next use
   return SLM_OK;
 }
 
@@ -1421,11 +1423,19 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       SLM_TRY(dalloc(&ds->ws_G, (size_t)n_sets * WS_KCAP * WS_KCAP));
       ds->ws_sets = n_sets;
     }
-    if (!ds->XT) {
+    if (!ds->XT && !ds->XT_failed) {
       // column-major copy of X (a layout of the data like the padded row-major one: depends on nothing
-      // but X, kept for the life of the dataset; 2 ms for 4 GB)
+      // but X, kept for the life of the dataset; 2 ms for 4 GB).  Optional: without the memory for it
+      // the gathers read the row-major X, one 64-byte sector per element.
       ds->ldt = (n + 15) / 16 * 16;
-      SLM_TRY(dalloc(&ds->XT, (size_t)ld * ds->ldt));  // (ld rows: the transpose also writes the pad columns)
+      if (hipMalloc((void**)&ds->XT, sizeof(double) * (size_t)ld * ds->ldt) != hipSuccess) {  // (ld rows: pad columns too)
+        (void)hipGetLastError();
+        ds->XT = nullptr;
+        ds->XT_failed = true;
+      }
+    }
+    if (ds->XT && !ds->XT_ready) {
+      ds->XT_ready = true;
       const dim3 grid((unsigned)((ld + 31) / 32), (unsigned)((n + 31) / 32));
       // X seen as an F-order (ld x n) matrix with leading dimension ld -> row-major [ld][ldt]; rows >= p
       // of the result are the pad columns and are not written

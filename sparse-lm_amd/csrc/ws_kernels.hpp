@@ -436,7 +436,8 @@ __global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
       const int k = k0 + kk;
       const int j = k < K ? w.idx[k] : -1;
       const int64_t i = i0 + tx;
-      tile[kk][tx] = (j >= 0 && i < w.n) ? w.XT[(int64_t)j * w.ldt + i] : 0.0;
+      // (XT == nullptr: no memory for the column-major copy -- same tile, sector-granular reads from X)
+      tile[kk][tx] = (j >= 0 && i < w.n) ? (w.XT ? w.XT[(int64_t)j * w.ldt + i] : w.X[i * w.ld + j]) : 0.0;
     }
     __syncthreads();
     for (int ii = ty; ii < 32; ii += 8) {  // write: lanes walk positions k (contiguous in XW)
