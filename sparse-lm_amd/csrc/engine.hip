@@ -1475,7 +1475,23 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (const char* e = getenv("SLM_WS_KINIT")) wa.k_init = std::max(16, std::min(WS_KCAP, atoi(e)));
     return SLM_OK;
   };
-  if (use_ws) SLM_TRY(ws_setup());
+  // no memory for the working-set buffers: the plain iteration still works (unless this solve runs
+  // more lanes than the fused kernels serve, which only the split pass can do)
+  auto ws_release = [&]() {
+    dfree(ds->ws_ctl); dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
+    dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
+    ds->ws_sets = 0;
+    (void)hipGetLastError();
+  };
+  if (use_ws) {
+    const int rc = ws_setup();
+    if (rc == SLM_ERR_OOM && !split) {
+      ws_release();
+      use_ws = false;
+    } else if (rc != SLM_OK) {
+      return rc;
+    }
+  }
   const int* done_flag = &ds->gctl->done;
   // the gradient of one pass: split pass (ten lane slots, residuals from the gathered columns where
   // possible) when the working set runs from the start, the fused kernel otherwise
@@ -1611,10 +1627,16 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       pending[other] = false;
       if (ds->hctl[other].g.done) done = true;
       if (!done && ws_late && !use_graph && ds->hctl[other].g.hard >= kWsLateIters) {
-        SLM_TRY(ws_setup());  // (waits for the stream: the queued passes simply finish first)
-        use_ws = true;
+        const int rc = ws_setup();  // (waits for the stream: the queued passes simply finish first)
         ws_late = false;
-        chunk = std::min(chunk, 8);
+        if (rc == SLM_OK) {
+          use_ws = true;
+          chunk = std::min(chunk, 8);
+        } else if (rc == SLM_ERR_OOM) {
+          ws_release();  // carry on with plain steps
+        } else {
+          return rc;
+        }
       }
     }
     slot = other;
