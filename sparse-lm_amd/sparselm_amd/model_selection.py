@@ -78,8 +78,8 @@ class GridSearchCV(_GridSearchCV):
         opt_selection_method (str): "max_score" (default) or "one_std_score".
         scoring: default "neg_root_mean_squared_error" (reference :166).
         n_jobs, refit, cv, verbose, pre_dispatch, error_score, return_train_score: as scikit-learn.
-        lanes (int): (fold, grid-row) units solved per pass over X on the fast path (1..8, default 8;
-            the engine falls back to fewer where no kernel variant serves that many).
+        lanes (int): (fold, grid-row) units solved per pass over X on the fast path (1..10, default
+            10; the engine falls back to fewer where no kernel variant serves that many).
     """
 
     def __init__(
@@ -96,7 +96,7 @@ class GridSearchCV(_GridSearchCV):
         pre_dispatch="2*n_jobs",
         error_score=np.nan,
         return_train_score=False,
-        lanes=8,
+        lanes=10,
     ):
         super().__init__(
             estimator=estimator,
