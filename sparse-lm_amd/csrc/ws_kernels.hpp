@@ -503,7 +503,6 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
 
   const int kk = lane >> 4, c = lane & 15;
   if (active) {
-#pragma unroll 4
     for (int64_t s = s_begin; s < s_end; s += 4) {
       const int64_t i = s + kk;
       const bool ok = i < s_end;
