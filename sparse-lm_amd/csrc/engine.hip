@@ -1404,7 +1404,20 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     ws_late = pol == 1;
   }
   auto ws_setup = [&]() -> int {
-    const int n_sets = (any_rw || custom_scale) ? B : 1;
+    // lanes with the same row weights (same host pointer: the folds of a CV grid) and the same 1/n
+    // scaling share one Gram
+    int set_of[SLM_MAX_LANES] = {}, set_lane[SLM_MAX_LANES] = {};
+    int n_sets = 0;
+    for (int l = 0; l < B; ++l) {
+      int found = -1;
+      for (int m = 0; m < l && found < 0; ++m)
+        if (lanes[m].row_weight == lanes[l].row_weight && lanes[m].n_eff == lanes[l].n_eff) found = set_of[m];
+      if (found < 0) {
+        found = n_sets;
+        set_lane[n_sets++] = l;
+      }
+      set_of[l] = found;
+    }
     const int ws_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n / 64));  // (2 MiB of partials each)
     if (!ds->ws_ctl) {
       SLM_TRY(dalloc(&ds->ws_ctl, 1));
@@ -1455,8 +1468,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     wa.Gx = eng->comm ? ds->ws_Gx : nullptr;  // row-sharded: Gram parts are summed over ranks before use
     wa.X = ds->X; wa.XT = ds->XT; wa.ldt = ds->ldt; wa.n = n; wa.ld = ld;
     wa.rw = ls.rw; wa.rw_stride = ls.rw_stride;
-    for (int l = 0; l < kMaxLanes; ++l)
-      wa.inv_n[l] = 1.0 / (ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global);
+    for (int l = 0; l < kMaxLanes; ++l) {
+      wa.set_of[l] = l < B ? set_of[l] : 0;
+      wa.set_lane[l] = l < n_sets ? set_lane[l] : 0;
+      const int rep = wa.set_lane[l];
+      wa.inv_n[l] = 1.0 / (ls.n_eff[rep] > 0 ? ls.n_eff[rep] : (double)ds->n_global);
+    }
     wa.n_sets = n_sets;
     wa.nblk = ws_nblk;
     wa.theta = 0.85;
@@ -1505,7 +1522,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     launch_tail(ta, s);
     if (shared_path && !interleave) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
     if (use_ws) {
-      hipLaunchKernelGGL(ws_score_kernel, dim3((unsigned)(((ds->singleton ? p : G) + 255) / 256)), dim3(256), 0, s, ta, wa);
+      {
+        const int bs = ds->singleton ? 256 : 64;
+        const int64_t items = ds->singleton ? p : G;
+        hipLaunchKernelGGL(ws_score_kernel, dim3((unsigned)((items + bs - 1) / bs)), dim3(bs), 0, s, ta, wa);
+      }
       hipLaunchKernelGGL(ws_select_kernel, dim3(1), dim3(WS_THREADS), 0, s, ta, wa);
       hipLaunchKernelGGL(ws_gather_kernel, dim3((unsigned)std::min<int64_t>((n + 31) / 32, 1024), WS_KCAP / 32), dim3(256), 0, s, wa);
       hipLaunchKernelGGL(ws_gram_kernel, dim3((unsigned)wa.nblk, (unsigned)wa.n_sets, 8), dim3(WS_GRAM_THREADS), 0, s,

@@ -80,8 +80,10 @@ struct WsArgs {
   int64_t n, ld;
   const double* rw;   // row weights per set, or nullptr (all ones)
   int64_t rw_stride;
-  double inv_n[SLM_MAX_LANES];
-  int32_t n_sets;     // 1 (every lane shares the row weights) or n_lanes
+  double inv_n[SLM_MAX_LANES];        // per SET: 1 / n_eff
+  int32_t set_of[SLM_MAX_LANES];      // Gram of lane l (lanes with the same row weights and scaling share one)
+  int32_t set_lane[SLM_MAX_LANES];    // a lane of set s (whose row weights the Gram kernel reads)
+  int32_t n_sets;     // distinct (row weights, 1/n scaling) among the lanes
   int32_t nblk;
   double theta;
   int32_t lookahead;   // path points ahead whose penalty decides what enters W now
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
 
   const double inf = __builtin_huge_val();
   int n_new = 0, n_miss = 0;
-  const int it = blockIdx.x * 256 + tid;
+  const int it = blockIdx.x * blockDim.x + tid;  // (64-thread workgroups for groups: more CUs on few, heavier items)
   if (it < nitems) {
     double sc = 0.0;
     bool in_w = false;
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
   const int64_t base = w.n / w.nblk, rem = w.n % w.nblk;
   const int64_t r0 = b * base + (b < rem ? b : rem);
   const int64_t nrows = base + (b < rem ? 1 : 0);
-  const double* rw = w.rw ? w.rw + (int64_t)set * w.rw_stride : nullptr;
+  const double* rw = w.rw ? w.rw + (int64_t)w.set_lane[set] * w.rw_stride : nullptr;
   // rows of this wavefront: everything, or the part-th quarter (in steps of four rows)
   const int64_t steps = (nrows + 3) >> 2;
   const int64_t s_begin = row_split ? 4 * (steps * part / 4) : 0;
@@ -656,7 +658,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   const int tid = threadIdx.x;
   const int p = a.p;
   const int K = ws->K;
-  const int set = w.n_sets == 1 ? 0 : lane_id;
+  const int set = w.set_of[lane_id];
   const double* Gm = w.Gm + (int64_t)set * (WS_KCAP * WS_KCAP);
   {
     const int64_t off = (int64_t)lane_id * a.ld;

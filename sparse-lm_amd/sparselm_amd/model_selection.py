@@ -172,7 +172,17 @@ class GridSearchCV(_GridSearchCV):
             key = tuple(sorted((k, repr(v)) for k, v in params.items() if k != "alpha"))
             by_combo[key].append(ci)
         combos = list(by_combo.values())
-        units = [(c, f) for c in range(len(combos)) for f in range(n_splits)]
+        # fold-major: the units of one batch then mostly share a fold, i.e. one row mask, and the
+        # engine builds ONE working-set Gram for all lanes with the same mask (same host array)
+        units = [(c, f) for f in range(n_splits) for c in range(len(combos))]
+        train_masks, test_masks = [], []
+        for train, test in splits:
+            m = np.zeros(n)
+            m[train] = 1.0
+            train_masks.append(m)
+            t = np.zeros(n)
+            t[test] = 1.0
+            test_masks.append(t)
 
         rank, world, local_rank = D.world()
         eng = _engine.get_engine()
@@ -203,17 +213,13 @@ class GridSearchCV(_GridSearchCV):
                         np.ones_like(alphas) if d is not None else 0 * alphas,
                     ]
                     train, test = splits[f]
-                    mask = np.zeros(n)
-                    mask[train] = 1.0
-                    specs.append(dict(points=pts, a=a, b=b, d=d, row_weight=mask, n_eff=len(train)))
+                    specs.append(dict(points=pts, a=a, b=b, d=d, row_weight=train_masks[f], n_eff=len(train)))
                     metas.append((cis, test))
                 t_batch = time.perf_counter()
                 results = _solve_lanes_with_fallback(ds, specs, opts)
                 dt = (time.perf_counter() - t_batch) / max(1, sum(len(m[0]) for m in metas))
                 for (c, f), (cis, test), res in zip(batch, metas, results):
-                    tmask = np.zeros(n)
-                    tmask[test] = 1.0
-                    sse = ds.eval_sse(res.betas, tmask)
+                    sse = ds.eval_sse(res.betas, test_masks[f])
                     local[(c, f)] = (cis, self._score_from_sse(sse, y[test]), dt)
             merged = _gather(local, units)
             for (c, f), (cis, sc, dt) in merged.items():

@@ -55,7 +55,7 @@ def main():
     l1_ratios = np.linspace(0.05, 0.95, 10)
     folds = np.random.default_rng(0).permutation(n) % 5  # KFold(5, shuffle=True)
     masks = [(folds != f).astype(float) for f in range(5)]
-    units = [(f, r) for r in l1_ratios for f in range(5)]
+    units = [(f, r) for f in range(5) for r in l1_ratios]  # fold-major: a batch shares one row mask, one Gram
 
     def run_grid():
         total_passes = 0
