@@ -137,6 +137,15 @@ int slm_gradient(slm_dataset* ds, const double* z, double* g_out, double* loss_o
  */
 int slm_eval_sse(slm_dataset* ds, const double* Z, int32_t m, const double* row_weight, double* sse_out);
 
+/*
+ * The same for coefficient vectors that are zero outside n_cols <= 512 columns (the solutions of a
+ * regularisation path): cols[n_cols] are those columns, Zs is m x n_cols (C-order, host).  The columns
+ * are gathered once on the device and every vector then costs n x n_cols doubles instead of a share of
+ * a pass over X.  SLM_ERR_UNSUPPORTED if n_cols > 512 (callers then use slm_eval_sse).
+ */
+int slm_eval_sse_sparse(slm_dataset* ds, const int32_t* cols, int32_t n_cols, const double* Zs, int32_t m,
+                        const double* row_weight, double* sse_out);
+
 /* ---- solve ----------------------------------------------------------------------------------- */
 typedef struct slm_penalty {
   const double* a; /* length p, per-coefficient l1 weight; NULL => all ones            */

@@ -1133,6 +1133,90 @@ extern "C" int slm_eval_sse(slm_dataset* ds, const double* Z, int32_t m, const d
   return SLM_OK;
 }
 
+// column-major copy of X for column gathers (see solve_core / ws_setup); optional (no memory: nullptr)
+static int ensure_xt(slm_dataset* ds) {
+  hipStream_t s = ds->eng->stream;
+  const int64_t n = ds->n, ld = ds->ld;
+  if (!ds->XT && !ds->XT_failed) {
+    ds->ldt = (n + 15) / 16 * 16;
+    if (hipMalloc((void**)&ds->XT, sizeof(double) * (size_t)ld * ds->ldt) != hipSuccess) {
+      (void)hipGetLastError();
+      ds->XT = nullptr;
+      ds->XT_failed = true;
+    }
+  }
+  if (ds->XT && !ds->XT_ready) {
+    ds->XT_ready = true;
+    const dim3 grid((unsigned)((ld + 31) / 32), (unsigned)((n + 31) / 32));
+    hipLaunchKernelGGL(transpose_f2c_kernel, grid, dim3(256), 0, s, (const double*)ds->X, ld, n, ds->XT, ds->ldt);
+  }
+  return SLM_OK;
+}
+
+extern "C" int slm_eval_sse_sparse(slm_dataset* ds, const int32_t* cols, int32_t n_cols, const double* Zs,
+                                   int32_t m, const double* row_weight, double* sse_out) {
+  if (!ds || !cols || !Zs || !sse_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  if (m <= 0 || n_cols <= 0) return fail(SLM_ERR_BAD_ARG, "m and n_cols must be positive");
+  if (n_cols > WS_KCAP) return fail(SLM_ERR_UNSUPPORTED, "more than %d columns: use slm_eval_sse", WS_KCAP);
+  for (int k = 0; k < n_cols; ++k)
+    if (cols[k] < 0 || cols[k] >= ds->p) return fail(SLM_ERR_BAD_ARG, "cols[%d] = %d outside [0, p)", k, cols[k]);
+  slm_engine* eng = ds->eng;
+  HIP_TRY(hipSetDevice(eng->device));
+  hipStream_t s = eng->stream;
+  const int64_t n = ds->n;
+  if (row_weight) {
+    for (int64_t i = 0; i < n; ++i)
+      if (!(row_weight[i] >= 0.0) || !std::isfinite(row_weight[i]))
+        return fail(SLM_ERR_BAD_ARG, "row_weight[%lld] is negative or not finite", (long long)i);
+    if (!ds->rw_lanes) SLM_TRY(dalloc(&ds->rw_lanes, (size_t)kMaxLanes * n));
+    HIP_TRY(hipMemcpyAsync(ds->rw_lanes, row_weight, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  }
+  // scratch shared with the working set (every solve re-initialises that state)
+  if (!ds->ws_idx) SLM_TRY(dalloc(&ds->ws_idx, WS_KCAP));
+  if (!ds->ws_XW) SLM_TRY(dalloc(&ds->ws_XW, (size_t)n * WS_KCAP));
+  SLM_TRY(ensure_xt(ds));
+  const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus * 4, (n + 255) / 256));
+  double *dZ = nullptr, *dpart = nullptr;
+  SLM_TRY(dalloc(&dZ, (size_t)m * n_cols));
+  if (dalloc(&dpart, (size_t)nblk * SSE_M) != SLM_OK) {
+    dfree(dZ);
+    return SLM_ERR_OOM;
+  }
+  int rc = SLM_OK;
+  auto bail = [&](hipError_t e) {
+    if (e != hipSuccess && rc == SLM_OK) rc = fail(SLM_ERR_HIP, "slm_eval_sse_sparse: %s", hipGetErrorString(e));
+  };
+  bail(hipMemcpyAsync(ds->ws_idx, cols, sizeof(int32_t) * n_cols, hipMemcpyHostToDevice, s));
+  bail(hipMemcpyAsync(dZ, Zs, sizeof(double) * (size_t)m * n_cols, hipMemcpyHostToDevice, s));
+  if (rc == SLM_OK) {
+    GatherArgs ga;
+    ga.X = ds->X; ga.XT = ds->XT; ga.n = n; ga.ld = ds->ld; ga.ldt = ds->ldt;
+    ga.idx = ds->ws_idx; ga.K = n_cols; ga.XW = ds->ws_XW;
+    hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)std::min<int64_t>((n + 31) / 32, 1024), (unsigned)((n_cols + 31) / 32)),
+                       dim3(256), 0, s, ga);
+    std::vector<double> part((size_t)nblk * SSE_M);
+    for (int v0 = 0; v0 < m && rc == SLM_OK; v0 += SSE_M) {
+      SseArgs sa;
+      sa.XW = ds->ws_XW; sa.y = ds->y; sa.rw = row_weight ? ds->rw_lanes : ds->rw;
+      sa.Zs = dZ + (size_t)v0 * n_cols; sa.partial = dpart; sa.n = n; sa.K = n_cols;
+      sa.m = std::min<int>(SSE_M, m - v0);
+      (void)hipFuncSetAttribute((const void*)sse_sparse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      hipLaunchKernelGGL(sse_sparse_kernel, dim3(nblk), dim3(256), sizeof(double) * (size_t)n_cols * SSE_M, s, sa);
+      bail(hipMemcpyAsync(part.data(), dpart, sizeof(double) * part.size(), hipMemcpyDeviceToHost, s));
+      bail(hipStreamSynchronize(s));
+      for (int v = 0; v < sa.m; ++v) {
+        double t = 0.0;
+        for (int b = 0; b < nblk; ++b) t += part[(size_t)b * SSE_M + v];
+        sse_out[v0 + v] = t;
+      }
+    }
+  }
+  bail(hipStreamSynchronize(s));
+  dfree(dZ); dfree(dpart);
+  if (rc == SLM_OK) rc = check_launch();
+  return rc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // path solves
 // ------------------------------------------------------------------------------------------------
@@ -1436,24 +1520,10 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       SLM_TRY(dalloc(&ds->ws_G, (size_t)n_sets * WS_KCAP * WS_KCAP));
       ds->ws_sets = n_sets;
     }
-    if (!ds->XT && !ds->XT_failed) {
-      // column-major copy of X (a layout of the data like the padded row-major one: depends on nothing
-      // but X, kept for the life of the dataset; 2 ms for 4 GB).  Optional: without the memory for it
-      // the gathers read the row-major X, one 64-byte sector per element.
-      ds->ldt = (n + 15) / 16 * 16;
-      if (hipMalloc((void**)&ds->XT, sizeof(double) * (size_t)ld * ds->ldt) != hipSuccess) {  // (ld rows: pad columns too)
-        (void)hipGetLastError();
-        ds->XT = nullptr;
-        ds->XT_failed = true;
-      }
-    }
-    if (ds->XT && !ds->XT_ready) {
-      ds->XT_ready = true;
-      const dim3 grid((unsigned)((ld + 31) / 32), (unsigned)((n + 31) / 32));
-      // X seen as an F-order (ld x n) matrix with leading dimension ld -> row-major [ld][ldt]; rows >= p
-      // of the result are the pad columns and are not written
-      hipLaunchKernelGGL(transpose_f2c_kernel, grid, dim3(256), 0, s, (const double*)ds->X, ld, n, ds->XT, ds->ldt);
-    }
+    // column-major copy of X (a layout of the data like the padded row-major one: depends on nothing
+    // but X, kept for the life of the dataset; 2 ms for 4 GB).  Optional: without the memory for it
+    // the gathers read the row-major X, one 64-byte sector per element.
+    SLM_TRY(ensure_xt(ds));
     WsCtl wc;
     memset(&wc, 0, sizeof(wc));
     wc.request = 1;

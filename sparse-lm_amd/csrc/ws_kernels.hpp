@@ -924,4 +924,97 @@ __global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs
   if (threadIdx.x == 0) ctl->zsup = (w_ok && out[0] == 0.0) ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hold-out scoring of sparse coefficient vectors (grid searches): gather the union of their supports
+// once (<= WS_KCAP columns, same tiled gather as above, explicit arguments), then one thread per row
+// computes up to SSE_M residuals from K contiguous doubles.  A dense evaluation costs a pass over X
+// per four vectors; this costs n x K doubles per sixteen.
+// ---------------------------------------------------------------------------------------------
+constexpr int SSE_M = 16;
+
+struct GatherArgs {
+  const double* X;
+  const double* XT;  // nullptr: read the row-major X
+  int64_t n, ld, ldt;
+  const int32_t* idx;  // [K] columns (all >= 0)
+  int K;               // multiple of 16 is not required
+  double* XW;          // [n][WS_KCAP]
+};
+
+__global__ __launch_bounds__(256) void gather_cols_kernel(GatherArgs w) {
+  const int k0 = 32 * (int)blockIdx.y;
+  if (k0 >= w.K) return;
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t row_tiles = (w.n + 31) / 32;
+  for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
+    const int64_t i0 = rt * 32;
+    __syncthreads();
+    for (int kk = ty; kk < 32; kk += 8) {
+      const int k = k0 + kk;
+      const int j = k < w.K ? w.idx[k] : -1;
+      const int64_t i = i0 + tx;
+      tile[kk][tx] = (j >= 0 && i < w.n) ? (w.XT ? w.XT[(int64_t)j * w.ldt + i] : w.X[i * w.ld + j]) : 0.0;
+    }
+    __syncthreads();
+    for (int ii = ty; ii < 32; ii += 8) {
+      const int64_t i = i0 + ii;
+      const int k = k0 + tx;
+      if (i < w.n && k < w.K) w.XW[i * WS_KCAP + k] = tile[tx][ii];
+    }
+  }
+}
+
+struct SseArgs {
+  const double* XW;  // [n][WS_KCAP]
+  const double* y;
+  const double* rw;  // nullptr: ones
+  const double* Zs;  // [m][K] coefficients on the gathered columns
+  double* partial;   // [gridDim.x][SSE_M]
+  int64_t n;
+  int K, m;          // m <= SSE_M vectors in this launch
+};
+
+__global__ __launch_bounds__(256) void sse_sparse_kernel(SseArgs a) {
+  extern __shared__ double zs[];  // [K][SSE_M]
+  __shared__ double wsum[4][SSE_M];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < a.K * SSE_M; e += 256) {
+    const int k = e / SSE_M, v = e - k * SSE_M;
+    zs[e] = v < a.m ? a.Zs[(int64_t)v * a.K + k] : 0.0;
+  }
+  __syncthreads();
+  double sse[SSE_M];
+#pragma unroll
+  for (int v = 0; v < SSE_M; ++v) sse[v] = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * 256 + tid; row < a.n; row += (int64_t)gridDim.x * 256) {
+    const double w = a.rw ? a.rw[row] : 1.0;
+    if (w == 0.0) continue;  // (a fold mask: four fifths of the rows)
+    const double* xr = a.XW + row * WS_KCAP;
+    double dot[SSE_M];
+#pragma unroll
+    for (int v = 0; v < SSE_M; ++v) dot[v] = 0.0;
+    for (int k = 0; k < a.K; ++k) {
+      const double x = xr[k];
+#pragma unroll
+      for (int v = 0; v < SSE_M; ++v) dot[v] = __builtin_fma(x, zs[k * SSE_M + v], dot[v]);
+    }
+    const double yi = a.y[row];
+#pragma unroll
+    for (int v = 0; v < SSE_M; ++v) {
+      const double e = dot[v] - yi;
+      sse[v] = __builtin_fma(w * e, e, sse[v]);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < SSE_M; ++v) {
+    double t = sse[v];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (lane == 0) wsum[wave][v] = t;
+  }
+  __syncthreads();
+  if (tid < SSE_M) a.partial[(int64_t)blockIdx.x * SSE_M + tid] = wsum[0][tid] + wsum[1][tid] + wsum[2][tid] + wsum[3][tid];
+}
+
 }  // namespace slm

@@ -64,6 +64,7 @@ ABI_SYMBOLS = (
     "slm_dataset_lipschitz",
     "slm_gradient",
     "slm_eval_sse",
+    "slm_eval_sse_sparse",
     "slm_solve_path",
     "slm_solve_lanes",
     "slm_solve_path_lanes",
@@ -143,6 +144,7 @@ class _Lane(C.Structure):
 
 
 MAX_LANES = 10
+WS_COLUMNS = 512  # WS_KCAP of the engine: columns a working set / a sparse scoring call can hold
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -196,6 +198,7 @@ def load_library():
             "slm_dataset_lipschitz": [vp, P(dbl)],
             "slm_gradient": [vp, vp, vp, P(dbl), i32, P(dbl)],
             "slm_eval_sse": [vp, vp, i32, vp, vp],
+            "slm_eval_sse_sparse": [vp, vp, i32, vp, i32, vp, vp],
             "slm_solve_path": [
                 vp,
                 P(_PenaltyStruct),
@@ -489,14 +492,25 @@ class Dataset:
         )
         return (g, loss.value, ms.value) if reps > 0 else (g, loss.value)
 
-    def eval_sse(self, Z, row_weight=None) -> np.ndarray:
+    def eval_sse(self, Z, row_weight=None, sparse=None) -> np.ndarray:
         """sum_i w_i (x_i . Z[k] - y_i)^2 for every row Z[k] of ``Z`` (m, p); ``row_weight`` is e.g. the
-        test mask of a CV fold.  ceil(m/4) passes over the resident X."""
+        test mask of a CV fold.  Rows with a joint support of at most 512 columns are scored from those
+        columns (``sparse=False`` forces the dense route: ceil(m/4) passes over the resident X)."""
         Z = _f64(np.atleast_2d(Z), "Z")
         if Z.shape[1] != self.p:
             raise ValueError(f"Z must have {self.p} columns")
         rw = None if row_weight is None else _f64(row_weight, "row_weight", (self.n,))
         out = np.empty(Z.shape[0])
+        # sparse rows (the solutions of a path): gather the union of their supports once on the device
+        # and score from those columns instead of passes over X
+        cols = np.flatnonzero(np.any(Z != 0.0, axis=0)).astype(np.int32)
+        if cols.size == 0:
+            cols = np.zeros(1, dtype=np.int32)
+        if cols.size <= WS_COLUMNS and sparse is not False:
+            Zs = np.ascontiguousarray(Z[:, cols])
+            _check(self._lib.slm_eval_sse_sparse(self._h, _ptr(cols), int(cols.size), _ptr(Zs), Z.shape[0], _ptr(rw),
+                                                 _ptr(out)))
+            return out
         _check(self._lib.slm_eval_sse(self._h, _ptr(Z), Z.shape[0], _ptr(rw), _ptr(out)))
         return out
 

@@ -503,3 +503,30 @@ def test_split_gradient_matches_numpy(eng, n, p, monkeypatch):
         g0, loss0 = ref_grad(X, y, z, w)
         assert rel_inf(g, g0) < 1e-12
         npt.assert_allclose(loss, loss0, rtol=1e-12)
+
+
+def test_sparse_hold_out_scoring_matches_dense_and_numpy(eng):
+    # slm_eval_sse_sparse: gather the union of the supports once, score from those columns
+    rng = np.random.default_rng(8)
+    n, p, m = 3000, 700, 37
+    X = rng.standard_normal((n, p))
+    y = rng.standard_normal(n)
+    Z = np.zeros((m, p))
+    for k in range(m):
+        idx = rng.choice(p, rng.integers(0, 40), replace=False)
+        Z[k, idx] = rng.standard_normal(len(idx))
+    mask = (rng.random(n) < 0.2).astype(float)
+    w = rng.uniform(0.0, 2.0, n)
+    with eng.dataset(X, y) as ds:
+        for rw in (None, mask, w):
+            ref = np.array([np.sum((1.0 if rw is None else rw) * (X @ z - y) ** 2) for z in Z])
+            s_sparse = ds.eval_sse(Z, rw)
+            s_dense = ds.eval_sse(Z, rw, sparse=False)
+            npt.assert_allclose(s_sparse, ref, rtol=1e-12)
+            npt.assert_allclose(s_dense, ref, rtol=1e-12)
+        # more than 512 columns in the joint support: falls back to the passes over X
+        Zd = rng.standard_normal((3, p))
+        npt.assert_allclose(ds.eval_sse(Zd, mask), [np.sum(mask * (X @ z - y) ** 2) for z in Zd], rtol=1e-12)
+        # a solve afterwards still works (the scratch is shared with the working set)
+        r = ds.solve_path([(0.1, 0, 0)], tol=1e-10, flags=_engine.FLAG_WORKING_SET)
+        assert r.converged
