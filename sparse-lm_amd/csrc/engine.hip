@@ -1503,15 +1503,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       set_of[l] = found;
     }
     const int ws_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n / 64));  // (2 MiB of partials each)
-    if (!ds->ws_ctl) {
-      SLM_TRY(dalloc(&ds->ws_ctl, 1));
-      SLM_TRY(dalloc(&ds->ws_idx, WS_KCAP));
-      SLM_TRY(dalloc(&ds->ws_gs, WS_KCAP));
-      SLM_TRY(dalloc(&ds->ws_gl, WS_KCAP));
-      SLM_TRY(dalloc(&ds->ws_pos, (size_t)ld));
-      SLM_TRY(dalloc(&ds->ws_score, (size_t)ld));
-      SLM_TRY(dalloc(&ds->ws_XW, (size_t)n * WS_KCAP));
-    }
+    // (each on its own: slm_eval_sse_sparse may already have brought idx and XW in)
+    if (!ds->ws_ctl) SLM_TRY(dalloc(&ds->ws_ctl, 1));
+    if (!ds->ws_idx) SLM_TRY(dalloc(&ds->ws_idx, WS_KCAP));
+    if (!ds->ws_gs) SLM_TRY(dalloc(&ds->ws_gs, WS_KCAP));
+    if (!ds->ws_gl) SLM_TRY(dalloc(&ds->ws_gl, WS_KCAP));
+    if (!ds->ws_pos) SLM_TRY(dalloc(&ds->ws_pos, (size_t)ld));
+    if (!ds->ws_score) SLM_TRY(dalloc(&ds->ws_score, (size_t)ld));
+    if (!ds->ws_XW) SLM_TRY(dalloc(&ds->ws_XW, (size_t)n * WS_KCAP));
     if (ds->ws_sets < n_sets) {
       dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
       ds->ws_sets = 0;
