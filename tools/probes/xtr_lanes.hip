@@ -6,7 +6,7 @@
 using namespace slm;
 
 // same loop as xtr_ring_kernel, any B <= 10 (the residual row is always loaded in full)
-template <int W, int C, int B, int D>
+template <int W, int C, int B, int D, int AUX = 2>
 __global__ __launch_bounds__(W * 64) void xtr_probe_kernel(SplitArgs a) {
   constexpr int T = W * 64;
   constexpr int SLOT = T * C * 16;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(W * 64) void xtr_probe_kernel(SplitArgs a) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       char* dst = smem + slot * SLOT + (c * T + wave * 64) * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)(rp + coff[c]), (lptr_t)dst, 16, 0, 2);
+      __builtin_amdgcn_global_load_lds((gptr_t)(rp + coff[c]), (lptr_t)dst, 16, 0, AUX);
     }
   };
   for (int k = 0; k < D; ++k) if (k < nrows) issue_row(k, k);
@@ -81,6 +81,20 @@ static void runw(const SplitArgs& a, int nblk, const char* tag) {
   printf("%s W=%d C=%d B=%d D=%d: %.4f ms  %.0f GB/s\n", tag, W, C, B, D, ms / 30, 8.0 * a.n * (a.ld) / (ms / 30) / 1e6);
 }
 
+template <int AUX>
+static void runaux(const SplitArgs& a, int nblk) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((xtr_probe_kernel<8, 5, 10, 2, AUX>), dim3(nblk), dim3(512), 0, 0, a);
+  (void)hipEventRecord(e0, 0);
+  for (int r = 0; r < 30; ++r) hipLaunchKernelGGL((xtr_probe_kernel<8, 5, 10, 2, AUX>), dim3(nblk), dim3(512), 0, 0, a);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  printf("aux=%d B=10 D=2: %.4f ms  %.0f GB/s\n", AUX, ms / 30, 8.0 * a.n * (a.ld) / (ms / 30) / 1e6);
+}
+
 template <int B, int D>
 static void run(const SplitArgs& a, int nblk, const char* tag) {
   hipEvent_t e0, e1;
@@ -105,16 +119,8 @@ int main() {
   for (int nblk : {256}) {
     a.rows_base = n / nblk; a.rows_rem = n % nblk;
     printf("nblk=%d\n", nblk);
-    run<1, 2>(a, nblk, "xtr"); run<10, 2>(a, nblk, "xtr");
-    runw<16, 3, 1, 2>(a, nblk, "xtr"); runw<16, 3, 8, 2>(a, nblk, "xtr");
-    runw<4, 10, 1, 2>(a, nblk, "xtr"); runw<4, 10, 1, 1>(a, nblk, "xtr");
-  }
-  {
-    const int nblk = 512;  // two 256-thread workgroups per CU (ring 2 x 80 KB... D = 1: 80 KB each)
-    a.rows_base = n / nblk; a.rows_rem = n % nblk;
-    printf("nblk=%d\n", nblk);
-    runw<4, 10, 1, 1>(a, nblk, "xtr");
-    runw<4, 10, 4, 1>(a, nblk, "xtr");
+    runaux<0>(a, nblk); runaux<1>(a, nblk); runaux<2>(a, nblk); runaux<3>(a, nblk);
+    runaux<0>(a, nblk); runaux<2>(a, nblk);
   }
   return 0;
 }
