@@ -326,7 +326,9 @@ __device__ __forceinline__ slm_u32x4 smem_load_16B(const double* p) {
 // g partials: acc[l][:] += R[row][l] * x_row.  Every wavefront streams its own chunks through the
 // LDS ring and reads only those back: no cross-wave traffic, no barrier in the row loop.  Measured at
 // n=100k, p=5k, 8 lanes: 0.614 ms (6.5 TB/s); a barrier per row (0.625 ms) or a third row in flight
-// (all 160 KiB of LDS, 0.653 ms) are slower; loading the residuals before the DMA wait gained 2 %.
+// (all 160 KiB of LDS, 0.653 ms) are slower; loading the residuals before the DMA wait gained 2 %;
+// the `nt` policy on the DMA loads matters (0.626 ms against 0.723 ms without, tools/probes/xtr_lanes.hip);
+// the lane count hardly does (one lane: 0.620 ms, ten: 0.649 ms on the same box).
 // ---------------------------------------------------------------------------------------------
 template <int W, int C, int B, int D>
 __global__ __launch_bounds__(W * 64) void xtr_ring_kernel(SplitArgs a) {
