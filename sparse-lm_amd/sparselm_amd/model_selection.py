@@ -120,7 +120,7 @@ class GridSearchCV(_GridSearchCV):
             return False
         if getattr(_backend.get_backend(), "name", None) != "hip":  # (tests may inject another backend)
             return False
-        if est.fit_intercept or getattr(est, "standardize", False) or fit_params:
+        if getattr(est, "standardize", False) or fit_params:
             return False
         if self.scoring not in _FAST_SCORINGS or self.return_train_score:
             return False
@@ -189,11 +189,27 @@ class GridSearchCV(_GridSearchCV):
         t0 = time.perf_counter()
         scores = np.full((len(candidates), n_splits), np.nan)
         fit_time = np.zeros((len(candidates), n_splits))
-        with eng.dataset(X, y) as ds:
+        # fit_intercept=True: the intercept is an unpenalised coefficient on a column of ones appended to
+        # the device copy (its own group, zero weights).  Minimising over it jointly is what centring X and
+        # y by their training-fold means does (reference _base.py:207-227), fold by fold, without a
+        # centred copy per fold.
+        intercept = bool(est.fit_intercept)
+        Xd = np.hstack([X, np.ones((n, 1))]) if intercept else X
+
+        def with_intercept(a, b, d, G):
+            """penalty vectors of the augmented problem (None stays None: that term is off)"""
+            if not intercept:
+                return a, b, d
+            a = None if a is None else np.append(np.broadcast_to(a, (p,)), 0.0)
+            b = None if b is None else np.append(np.broadcast_to(b, (G,)), 0.0)
+            d = None if d is None else np.append(np.broadcast_to(d, (G,)), 0.0)
+            return a, b, d
+
+        with eng.dataset(Xd, y) as ds:
             base = clone(est).set_params(alpha=1.0)
             a1, b1, d1, gidx, G = base._penalty(X)
             if gidx is not None:
-                ds.set_groups(gidx, G)
+                ds.set_groups(np.append(gidx, G) if intercept else gidx, G + 1 if intercept else G)
             my_units = [units[i] for i in D.shard_units(len(units), rank, world)]
             lanes = max(1, min(int(self.lanes), _engine.MAX_LANES))
             opts = _solver_options(est)
@@ -205,7 +221,8 @@ class GridSearchCV(_GridSearchCV):
                     cis = sorted(combos[c], key=lambda ci: -candidates[ci]["alpha"])
                     e = clone(est).set_params(**{k: v for k, v in candidates[cis[0]].items() if k != "alpha"})
                     e.set_params(alpha=1.0)
-                    a, b, d, _, _ = e._penalty(X)
+                    a, b, d, _, G_e = e._penalty(X)
+                    a, b, d = with_intercept(a, b, d, G_e if G_e is not None else p)
                     alphas = np.array([candidates[ci]["alpha"] for ci in cis], dtype=float)
                     pts = np.c_[
                         alphas if a is not None else 0 * alphas,
@@ -240,16 +257,17 @@ class GridSearchCV(_GridSearchCV):
             if self.refit:
                 t1 = time.perf_counter()
                 best = clone(est).set_params(**self.best_params_)
-                a, b, d, _, _ = best._penalty(X)
+                a, b, d, _, G_b = best._penalty(X)
+                a, b, d = with_intercept(a, b, d, G_b if G_b is not None else p)
                 res = ds.solve_path(
                     [(1.0, 1.0, 1.0)],
-                    a=np.zeros(p) if a is None else a,
+                    a=np.zeros(ds.p) if a is None else a,
                     b=np.zeros(ds.n_groups) if b is None else b,
                     d=np.zeros(ds.n_groups) if d is None else d,
                     **opts,
                 )
-                best.coef_ = res.betas[0]
-                best.intercept_ = 0.0
+                best.coef_ = res.betas[0][:p].copy()
+                best.intercept_ = float(res.betas[0][p]) if intercept else 0.0
                 best.n_features_in_ = p
                 best.solver_info_ = {"n_iter": int(res.n_iter[0]), "converged": res.converged}
                 self.best_estimator_ = best

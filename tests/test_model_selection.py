@@ -101,13 +101,14 @@ def test_fast_path_one_std_and_fallbacks(golden):
     std = GridSearchCV(Lasso(), grid, cv=cv, opt_selection_method="one_std_score").fit(X, y)
     assert std.best_params_["alpha"] >= opt.best_params_["alpha"]
     assert std.best_score_std_ > 0
-    # adaptive estimators and fit_intercept=True go through the generic loop (no search_time_)
+    # adaptive estimators go through the generic loop (no search_time_); fit_intercept=True stays on the
+    # device path (unpenalised column of ones)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ada = GridSearchCV(AdaptiveLasso(), {"alpha": [0.5, 2.0]}, cv=3).fit(X, y)
         icpt = GridSearchCV(Lasso(fit_intercept=True), {"alpha": [0.5, 2.0]}, cv=3).fit(X, y)
-    assert not hasattr(ada, "search_time_") and not hasattr(icpt, "search_time_")
-    assert ada.best_estimator_.n_iter_ >= 1
+    assert not hasattr(ada, "search_time_") and hasattr(icpt, "search_time_")
+    assert ada.best_estimator_.n_iter_ >= 1 and icpt.best_estimator_.intercept_ != 0.0
     # invalid candidates raise the estimator's own error class before anything is solved
     with pytest.raises(ValueError):
         GridSearchCV(Lasso(), {"alpha": [1.0, -1.0]}, cv=3).fit(X, y)
@@ -212,3 +213,31 @@ def test_line_search_fast_path_and_ols(golden):
     ols = OrdinaryLeastSquares(fit_intercept=True, solver_options={"tol": 1e-12, "max_iter": 200000}).fit(Xo, yo, sample_weight=sw)
     np.testing.assert_allclose(ols.coef_, golden["ols_coef_icpt"], rtol=1e-7)  # reference tests/test_ols.py:35-66
     np.testing.assert_allclose(ols.intercept_, golden["ols_icpt"], rtol=1e-7)
+
+
+@pytest.mark.gpu
+def test_fast_path_with_intercept_matches_generic_path(golden):
+    # fit_intercept=True on the device path: an unpenalised column of ones, fold by fold equivalent to
+    # centring by the training-fold means
+    X, y, groups, gw = golden["grp_X"], golden["grp_y"], golden["grp_groups"], golden["grp_gw"]
+    X = X + 3.0 * np.arange(X.shape[1]) / X.shape[1]  # non-zero column means
+    y = y + 25.0
+    cv = KFold(5, shuffle=True, random_state=0)
+    cases = [
+        (Lasso(fit_intercept=True), {"alpha": list(np.geomspace(20, 0.05, 6))}),
+        (GroupLasso(groups=groups, group_weights=gw, fit_intercept=True), {"alpha": list(np.geomspace(20, 0.1, 5))}),
+        (SparseGroupLasso(groups=groups, fit_intercept=True), {"alpha": list(np.geomspace(10, 0.1, 4)), "l1_ratio": [0.2, 0.8]}),
+    ]
+    for est, grid in cases:
+        est.set_params(solver_options={"tol": 1e-12, "max_iter": 200000})
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fast = GridSearchCV(est, grid, cv=cv).fit(X, y)
+            slow = SkGridSearchCV(est, grid, cv=cv, scoring="neg_root_mean_squared_error").fit(X, y)
+        assert hasattr(fast, "search_time_")  # the device path ran
+        np.testing.assert_allclose(fast.cv_results_["mean_test_score"], slow.cv_results_["mean_test_score"], rtol=1e-6)
+        assert fast.best_params_ == slow.best_params_
+        np.testing.assert_allclose(fast.best_estimator_.coef_, slow.best_estimator_.coef_, rtol=0,
+                                   atol=1e-6 * np.max(np.abs(slow.best_estimator_.coef_)))
+        assert fast.best_estimator_.intercept_ == pytest.approx(slow.best_estimator_.intercept_, rel=1e-6)
+        np.testing.assert_allclose(fast.predict(X), slow.predict(X), rtol=1e-6, atol=1e-6)
