@@ -13,13 +13,17 @@ other penalty hyper-parameter, e.g. ``l1_ratio``), X is uploaded ONCE and
 
   * every fold is a row mask (test rows weigh 0) with its own 1/n_train scaling -- a *lane*;
   * every (fold, other-params) pair is one warm-started alpha path solved on the device;
-  * up to eight lanes share each pass over X (``slm_solve_lanes``; eight in working-set solves on
-    large X, otherwise as many as the fused kernel table has for this p);
-  * hold-out scores come from the resident X as well (``slm_eval_sse`` with the test mask);
+  * up to ten lanes share each pass over X (``slm_solve_lanes``; ten in working-set solves on large
+    X, otherwise as many as the fused kernel table has for this p); units are dealt fold-major so the
+    lanes of a batch share one row mask and one working-set Gram;
+  * ``fit_intercept=True`` is an unpenalised column of ones appended to the device copy (jointly
+    minimising over it is per-fold centring);
+  * hold-out scores come from the device as well (``slm_eval_sse_sparse`` on the gathered support
+    columns of a unit's solutions, ``slm_eval_sse`` otherwise, with the test mask);
   * across processes (``torch.distributed`` launched one rank per GPU) the (fold, params) units are
     dealt to ranks with ``distributed.shard_units`` and gathered -- no data-path collective.
 
-Anything else (adaptive estimators, ``fit_intercept=True``, sample weights, custom scorers, grids
+Anything else (adaptive estimators, ``standardize=True``, sample weights, custom scorers, grids
 without ``alpha``) runs through scikit-learn's generic loop, still with the one-std rule.
 """
 
