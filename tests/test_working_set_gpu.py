@@ -369,3 +369,16 @@ def test_interleaved_lanes_of_a_shared_path(eng, monkeypatch):
     assert rel_inf(ri.betas, r1.betas) < 1e-8 and rel_inf(rc.betas, r1.betas) < 1e-8
     assert ri.grad_launches <= rc.grad_launches
     assert ri.grad_launches <= 1 + -(-len(alphas) // 5) + 2
+
+
+def test_randomised_cross_check_against_plain_iteration():
+    """tools/ws_fuzz.py: random penalty kinds, group sizes, lane counts, fold masks and p > n; the working-set
+    answer must match the plain iteration to 1e-6 or, where the minimiser is not unique, reach the same objective."""
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "ws_fuzz.py"), "120", "7"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "FUZZ cases 120" in out.stdout and "flagged 0" in out.stdout
