@@ -8,14 +8,17 @@ selection rule (:190-223), same fitted attributes (``cv_results_``, ``best_index
 
 What differs is how the (candidate x fold) grid is evaluated.  The reference dispatches
 ``clone(estimator).fit(X[train], y[train])`` per cell through joblib (:273, :304-323), re-indexing X
-every time.  Here, for the non-adaptive Lasso-family estimators with a grid over ``alpha`` (and any
-other penalty hyper-parameter, e.g. ``l1_ratio``), X is uploaded ONCE and
+every time.  Here, for the Lasso-family estimators with a grid over ``alpha`` (and any other penalty
+hyper-parameter, e.g. ``l1_ratio``), X is uploaded ONCE and
 
   * every fold is a row mask (test rows weigh 0) with its own 1/n_train scaling -- a *lane*;
   * every (fold, other-params) pair is one warm-started alpha path solved on the device;
   * up to ten lanes share each pass over X (``slm_solve_lanes``; ten in working-set solves on large
     X, otherwise as many as the fused kernel table has for this p); units are dealt fold-major so the
     lanes of a batch share one row mask and one working-set Gram;
+  * for the ``Adaptive*`` estimators every (candidate, fold) re-weighting loop is a lane instead: outer
+    iteration k of up to ten loops is one call, each lane with its own weight vectors, row mask and warm
+    start (``_adaptive_lanes``; loop semantics of reference _adaptive_lasso.py:206-232);
   * ``fit_intercept=True`` is an unpenalised column of ones appended to the device copy (jointly
     minimising over it is per-fold centring);
   * hold-out scores come from the device as well (``slm_eval_sse_sparse`` on the gathered support
@@ -23,8 +26,8 @@ other penalty hyper-parameter, e.g. ``l1_ratio``), X is uploaded ONCE and
   * across processes (``torch.distributed`` launched one rank per GPU) the (fold, params) units are
     dealt to ranks with ``distributed.shard_units`` and gathered -- no data-path collective.
 
-Anything else (adaptive estimators, ``standardize=True``, sample weights, custom scorers, grids
-without ``alpha``) runs through scikit-learn's generic loop, still with the one-std rule.
+Anything else (``standardize=True`` and the overlap classes, which assemble another design matrix per
+fit; sample weights, custom scorers, grids without ``alpha``) runs through scikit-learn's generic loop, still with the one-std rule.
 """
 
 from __future__ import annotations
@@ -120,11 +123,12 @@ class GridSearchCV(_GridSearchCV):
     # ------------------------------------------------------------------------------------------
     def _fast_path_ok(self, fit_params) -> bool:
         est = self.estimator
-        if not isinstance(est, ProxRegressor) or isinstance(est, AdaptiveLasso):
+        if not isinstance(est, ProxRegressor):
             return False
         if getattr(_backend.get_backend(), "name", None) != "hip":  # (tests may inject another backend)
             return False
-        if getattr(est, "standardize", False) or fit_params:
+        # standardize=True and the overlap classes assemble another design matrix on the host per fit
+        if est._needs_host_preprocessing() or fit_params:
             return False
         if self.scoring not in _FAST_SCORINGS or self.return_train_score:
             return False
@@ -175,6 +179,9 @@ class GridSearchCV(_GridSearchCV):
         for ci, params in enumerate(candidates):
             key = tuple(sorted((k, repr(v)) for k, v in params.items() if k != "alpha"))
             by_combo[key].append(ci)
+        adaptive = isinstance(est, AdaptiveLasso)
+        if adaptive:  # every (candidate, fold) is its own re-weighting loop: no shared alpha path
+            by_combo = {ci: [ci] for ci in range(len(candidates))}
         combos = list(by_combo.values())
         # fold-major: the units of one batch then mostly share a fold, i.e. one row mask, and the
         # engine builds ONE working-set Gram for all lanes with the same mask (same host array)
@@ -220,6 +227,16 @@ class GridSearchCV(_GridSearchCV):
             local = {}
             for k0 in range(0, len(my_units), lanes):
                 batch = my_units[k0 : k0 + lanes]
+                if adaptive:
+                    ests = [clone(est).set_params(**candidates[combos[c][0]]) for c, _ in batch]
+                    t_batch = time.perf_counter()
+                    fits = _adaptive_lanes(ds, ests, X, [train_masks[f] for _, f in batch],
+                                           [len(splits[f][0]) for _, f in batch], opts, with_intercept)
+                    dt = (time.perf_counter() - t_batch) / len(batch)
+                    for (c, f), fit in zip(batch, fits):
+                        sse = ds.eval_sse(fit["beta"][None, :], test_masks[f])
+                        local[(c, f)] = (combos[c], self._score_from_sse(sse, y[splits[f][1]]), dt)
+                    continue
                 specs, metas = [], []
                 for c, f in batch:
                     cis = sorted(combos[c], key=lambda ci: -candidates[ci]["alpha"])
@@ -261,19 +278,27 @@ class GridSearchCV(_GridSearchCV):
             if self.refit:
                 t1 = time.perf_counter()
                 best = clone(est).set_params(**self.best_params_)
-                a, b, d, _, G_b = best._penalty(X)
-                a, b, d = with_intercept(a, b, d, G_b if G_b is not None else p)
-                res = ds.solve_path(
-                    [(1.0, 1.0, 1.0)],
-                    a=np.zeros(ds.p) if a is None else a,
-                    b=np.zeros(ds.n_groups) if b is None else b,
-                    d=np.zeros(ds.n_groups) if d is None else d,
-                    **opts,
-                )
-                best.coef_ = res.betas[0][:p].copy()
-                best.intercept_ = float(res.betas[0][p]) if intercept else 0.0
+                if adaptive:
+                    fit = _adaptive_lanes(ds, [best], X, [None], [n], opts, with_intercept)[0]
+                    beta_aug = fit["beta"]
+                    best.n_iter_ = fit["n_iter"]
+                    best.adaptive_weights_ = fit["weights"]
+                    best.solver_info_ = {"solves": fit["infos"]}
+                else:
+                    a, b, d, _, G_b = best._penalty(X)
+                    a, b, d = with_intercept(a, b, d, G_b if G_b is not None else p)
+                    res = ds.solve_path(
+                        [(1.0, 1.0, 1.0)],
+                        a=np.zeros(ds.p) if a is None else a,
+                        b=np.zeros(ds.n_groups) if b is None else b,
+                        d=np.zeros(ds.n_groups) if d is None else d,
+                        **opts,
+                    )
+                    beta_aug = res.betas[0]
+                    best.solver_info_ = {"n_iter": int(res.n_iter[0]), "converged": res.converged}
+                best.coef_ = beta_aug[:p].copy()
+                best.intercept_ = float(beta_aug[p]) if intercept else 0.0
                 best.n_features_in_ = p
-                best.solver_info_ = {"n_iter": int(res.n_iter[0]), "converged": res.converged}
                 self.best_estimator_ = best
                 self.refit_time_ = time.perf_counter() - t1
         self.search_time_ = time.perf_counter() - t0
@@ -417,6 +442,45 @@ def _solve_lanes_with_fallback(ds, specs, opts):
             raise
         half = len(specs) // 2
         return _solve_lanes_with_fallback(ds, specs[:half], opts) + _solve_lanes_with_fallback(ds, specs[half:], opts)
+
+
+def _adaptive_lanes(ds, ests, X, row_weights, n_effs, opts, with_intercept):
+    """The re-weighting loops of several Adaptive* estimators side by side: outer iteration k of every
+    estimator is ONE call with one lane per estimator (each lane its own weight vectors, row mask and warm
+    start), so X is read once per inner iteration for all of them.  Same loop semantics as
+    AdaptiveLasso._solve (reference _adaptive_lasso.py:206-232): weights updated after every solve, early
+    stop per estimator on ``||w_new - w_prev|| <= tol``, coefficients of the last solve returned.
+
+    Returns one dict per estimator: ``beta`` (augmented with the intercept coefficient when the dataset has
+    the column of ones), ``n_iter``, ``weights``, ``infos``.
+    """
+    p = X.shape[1]
+    st = []
+    for e in ests:
+        if e.max_iter < 1:
+            raise ValueError("max_iter=0 performs no solve; coef_ would be undefined")
+        _, G, w = e._adaptive_setup(X)
+        st.append(dict(G=G, w=w, prev=w.copy(), beta=None, n_iter=0, done=False, infos=[]))
+    for it in range(max(e.max_iter for e in ests)):
+        live = [i for i, e in enumerate(ests) if not st[i]["done"] and it < e.max_iter]
+        if not live:
+            break
+        specs = []
+        for i in live:
+            a, b, d = with_intercept(*ests[i]._weights_to_penalty(st[i]["w"], p, st[i]["G"]), st[i]["G"])
+            specs.append(dict(points=[(1.0, 1.0, 1.0)], a=a, b=b, d=d,
+                              beta0=st[i]["beta"] if ests[i].warm_start else None,
+                              row_weight=row_weights[i], n_eff=n_effs[i]))
+        results = _solve_lanes_with_fallback(ds, specs, dict(opts, want_group_norms=True))
+        for i, res in zip(live, results):
+            s = st[i]
+            s["beta"] = res.betas[0].copy()
+            s["n_iter"] += 1
+            s["infos"].append({"n_iter": int(res.n_iter[0]), "converged": res.converged})
+            w = ests[i]._updated_weights(s["beta"][:p], res.group_norms[0][: s["G"]])
+            s["done"] = bool(np.linalg.norm(w - s["prev"]) <= ests[i].tol)
+            s["prev"], s["w"] = w.copy(), w
+    return [dict(beta=s["beta"], n_iter=s["n_iter"], weights=s["w"], infos=s["infos"]) for s in st]
 
 
 def _gather(local: dict, units) -> dict:

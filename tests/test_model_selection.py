@@ -101,13 +101,14 @@ def test_fast_path_one_std_and_fallbacks(golden):
     std = GridSearchCV(Lasso(), grid, cv=cv, opt_selection_method="one_std_score").fit(X, y)
     assert std.best_params_["alpha"] >= opt.best_params_["alpha"]
     assert std.best_score_std_ > 0
-    # adaptive estimators go through the generic loop (no search_time_); fit_intercept=True stays on the
-    # device path (unpenalised column of ones)
+    # custom scorers go through the generic loop (no search_time_); adaptive estimators and
+    # fit_intercept=True stay on the device path
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
+        r2 = GridSearchCV(Lasso(), {"alpha": [0.5, 2.0]}, cv=3, scoring="neg_mean_absolute_error").fit(X, y)
         ada = GridSearchCV(AdaptiveLasso(), {"alpha": [0.5, 2.0]}, cv=3).fit(X, y)
         icpt = GridSearchCV(Lasso(fit_intercept=True), {"alpha": [0.5, 2.0]}, cv=3).fit(X, y)
-    assert not hasattr(ada, "search_time_") and hasattr(icpt, "search_time_")
+    assert not hasattr(r2, "search_time_") and hasattr(ada, "search_time_") and hasattr(icpt, "search_time_")
     assert ada.best_estimator_.n_iter_ >= 1 and icpt.best_estimator_.intercept_ != 0.0
     # invalid candidates raise the estimator's own error class before anything is solved
     with pytest.raises(ValueError):
@@ -241,3 +242,55 @@ def test_fast_path_with_intercept_matches_generic_path(golden):
                                    atol=1e-6 * np.max(np.abs(slow.best_estimator_.coef_)))
         assert fast.best_estimator_.intercept_ == pytest.approx(slow.best_estimator_.intercept_, rel=1e-6)
         np.testing.assert_allclose(fast.predict(X), slow.predict(X), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_fast_path_adaptive_estimators_match_generic_path(golden):
+    # Adaptive* in the grid: every (candidate, fold) re-weighting loop is a lane; outer iteration k of up to
+    # ten of them is one engine call.  Same scores, selection and refit as scikit-learn's loop of fits.
+    from sklearn.datasets import make_regression
+
+    from sparselm_amd.model import AdaptiveGroupLasso, AdaptiveLasso, AdaptiveRidgedGroupLasso, AdaptiveSparseGroupLasso
+
+    X, y, groups, gw = golden["grp_X"], golden["grp_y"], golden["grp_groups"], golden["grp_gw"]
+    Xr, yr = make_regression(n_samples=100, n_features=80, n_informative=10, random_state=0)  # README example
+    cv = KFold(5, shuffle=True, random_state=0)
+    so = {"tol": 1e-12, "max_iter": 400000}
+    cases = [
+        (AdaptiveLasso(fit_intercept=True, solver_options=so), {"alpha": list(np.logspace(-2, 2, 6))}, Xr, yr),
+        (AdaptiveLasso(max_iter=5, warm_start=False, solver_options=so), {"alpha": [8.0, 2.0, 0.5]}, X, y),
+        (AdaptiveGroupLasso(groups=groups, group_weights=gw, solver_options=so), {"alpha": list(np.geomspace(10, 0.3, 4))}, X, y),
+        (AdaptiveSparseGroupLasso(groups=groups, fit_intercept=True, solver_options=so),
+         {"alpha": [5.0, 1.0], "l1_ratio": [0.3, 0.7]}, X, y + 10.0),
+        (AdaptiveRidgedGroupLasso(groups=groups, delta=(0.5,), solver_options=so), {"alpha": [6.0, 1.5]}, X, y),
+    ]
+    for est, grid, Xc, yc in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fast = GridSearchCV(est, grid, cv=cv).fit(Xc, yc)
+            slow = SkGridSearchCV(est, grid, cv=cv, scoring="neg_root_mean_squared_error").fit(Xc, yc)
+        assert hasattr(fast, "search_time_"), type(est).__name__  # the device path ran
+        np.testing.assert_allclose(fast.cv_results_["mean_test_score"], slow.cv_results_["mean_test_score"],
+                                   rtol=1e-5, err_msg=type(est).__name__)
+        assert fast.best_params_ == slow.best_params_
+        be, bs = fast.best_estimator_, slow.best_estimator_
+        np.testing.assert_allclose(be.coef_, bs.coef_, rtol=0, atol=1e-5 * np.max(np.abs(bs.coef_)))
+        assert be.intercept_ == pytest.approx(bs.intercept_, rel=1e-5, abs=1e-9)
+        assert be.n_iter_ == bs.n_iter_
+        np.testing.assert_allclose(be.adaptive_weights_, bs.adaptive_weights_, rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_overlap_and_standardized_searches_take_the_generic_path(golden):
+    from sparselm_amd.model import OverlapGroupLasso
+
+    X, y = golden["grp_X"][:, :24], golden["grp_y"]
+    group_list = [[j // 4] + ([j // 4 + 1] if j % 4 == 3 and j // 4 + 1 < 6 else []) for j in range(24)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gs = GridSearchCV(OverlapGroupLasso(group_list=group_list), {"alpha": [5.0, 1.0, 0.2]}, cv=3).fit(X, y)
+        ref = SkGridSearchCV(OverlapGroupLasso(group_list=group_list), {"alpha": [5.0, 1.0, 0.2]}, cv=3,
+                             scoring="neg_root_mean_squared_error").fit(X, y)
+    assert not hasattr(gs, "search_time_")
+    np.testing.assert_allclose(gs.cv_results_["mean_test_score"], ref.cv_results_["mean_test_score"], rtol=1e-8)
+    np.testing.assert_allclose(gs.best_estimator_.coef_, ref.best_estimator_.coef_, atol=1e-8)
