@@ -176,6 +176,32 @@ static const SplitKernel* pick_split_kernel(int64_t p2) {
   return nullptr;
 }
 
+// X^T R of the split pass on the matrix cores (xtr_mfma_kernel): grid = (column blocks of 512, row blocks),
+// about two workgroups per CU; rows per block a multiple of 8.  SLM_XTR_RING=1 keeps the LDS-ring kernel.
+static int xtr_max_row_blocks(int cus, int64_t ld) {
+  const int xb = (int)((ld + XTR_CB - 1) / XTR_CB);
+  return std::max(1, 2 * cus / xb);
+}
+static bool xtr_use_ring() {
+  static const bool ring = [] { const char* e = getenv("SLM_XTR_RING"); return e && e[0] == '1'; }();
+  return ring;
+}
+// sets a.xrows; returns the number of row blocks (= blocks of `partial` to reduce)
+static int launch_xtr(const SplitKernel* sk, int split_nblk, int cus, SplitArgs& a, hipStream_t s) {
+  if (xtr_use_ring()) {
+    hipLaunchKernelGGL(sk->xtr, dim3(split_nblk), dim3(sk->W * 64), 0, s, a);
+    return split_nblk;
+  }
+  const int xb = (int)((a.ld + XTR_CB - 1) / XTR_CB);
+  const int64_t want = xtr_max_row_blocks(cus, a.ld);
+  int64_t rows = (a.n + want - 1) / want;
+  rows = (rows + 7) / 8 * 8;
+  const int yb = (int)((a.n + rows - 1) / rows);  // <= want
+  a.xrows = (int)rows;
+  hipLaunchKernelGGL(xtr_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+  return yb;
+}
+
 static const GradKernel* pick_grad_kernel(int64_t p2, int B) {
   if (p2 > kMaxChunks) return B == 1 ? &kGradTwoPass : nullptr;
   // LDS-ring variants: measured flat in B (0.60-0.61 ms for B = 1..4 at p = 5000) where the register
@@ -461,6 +487,7 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
   if (ds->sk) {
     ds->split_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n));  // one ring workgroup per CU
     partial_elems = std::max(partial_elems, (size_t)ds->split_nblk * SPLIT_LANES * (size_t)ld);
+    partial_elems = std::max(partial_elems, (size_t)xtr_max_row_blocks(eng->cus, ld) * SPLIT_LANES * (size_t)ld);
     loss_elems = std::max(loss_elems, (size_t)ds->split_nblk * SPLIT_LANES);
   }
 
@@ -777,6 +804,7 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
   ra.g = ds->g;
   ra.done = done;
   ra.nblk = nblk;
+  ra.nblk_loss = nblk;
   ra.n_lanes = B;
   ra.ld = ds->ld;
   for (int l = 0; l < kMaxLanes; ++l) {
@@ -821,14 +849,15 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
   if (wa && ctl) hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
   // (SLM_FLAG_PROFILE brackets the kernel that streams X, the one the roofline is quoted on)
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
-  hipLaunchKernelGGL(sk->xtr, dim3(nblk), dim3(sk->W * 64), 0, s, a);
+  const int xblk = launch_xtr(sk, nblk, ds->eng->cus, a, s);
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
   ReduceArgs ra;
   ra.partial = ds->partial;
   ra.loss_partial = ds->loss_partial;
   ra.g = ds->g;
   ra.done = done;
-  ra.nblk = nblk;
+  ra.nblk = xblk;
+  ra.nblk_loss = nblk;
   ra.n_lanes = SPLIT_LANES;  // partial rows are laid out for all lane slots of the split pass
   ra.ld = ds->ld;
   for (int l = 0; l < kMaxLanes; ++l) {
@@ -1034,7 +1063,7 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
             hipLaunchKernelGGL(ds->sk->rowdot, dim3(ds->split_nblk), dim3(ds->sk->W * 64), 0, s, a);
           }
         }
-        hipLaunchKernelGGL(ds->sk->xtr, dim3(ds->split_nblk), dim3(ds->sk->W * 64), 0, s, a);
+        (void)launch_xtr(ds->sk, ds->split_nblk, ds->eng->cus, a, s);
       }
       HIP_TRY(hipEventRecord(e1, s));
       HIP_TRY(hipEventSynchronize(e1));

@@ -550,6 +550,7 @@ struct ReduceArgs {
   double* g;                   // [B][ld + 16]
   const int* done;
   int nblk;
+  int nblk_loss;  // row blocks of loss_partial (the split pass's residual kernels keep their own blocks)
   int n_lanes;
   int64_t ld;
   double scale[10];       // 1/n_eff per lane (SLM_MAX_LANES)
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceArgs a) {
   if (!loss_block) {
     for (int b = slice; b < a.nblk; b += 16) s += a.partial[((int64_t)b * B + lane) * a.ld + col];
   } else {
-    for (int b = tid; b < a.nblk; b += 256) s += a.loss_partial[(int64_t)b * B + lane];
+    for (int b = tid; b < a.nblk_loss; b += 256) s += a.loss_partial[(int64_t)b * B + lane];
   }
   lds[slice][cl] = s;
   __syncthreads();

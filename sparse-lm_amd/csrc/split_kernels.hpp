@@ -49,6 +49,7 @@ struct SplitArgs {
   int p2;
   int n_lanes;
   int lane0;  // rowdot_ring_kernel: first lane of this launch
+  int xrows;  // xtr_mfma_kernel: rows per workgroup row (multiple of 8); partial is then [gridDim.y][SPLIT_LANES][ld]
 };
 
 // which lanes take their residual from XW: live, flagged by ws_solve_kernel, and W still published
@@ -412,6 +413,107 @@ __global__ __launch_bounds__(W * 64) void xtr_ring_kernel(SplitArgs a) {
 #pragma unroll
     for (int c = 0; c < C; ++c)
       if (valid[c]) out[c * T + tid] = acc[l][c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same sums on the matrix cores: partial[by][l][col] = sum_{row in block by} R[row][l] X[row][col]
+// as v_mfma_f64_16x16x4_f64 products, D[i][j] += sum_k A[i][k] B[k][j] with k = 4 consecutive rows,
+// A[i][k] = X[row_k][col_i] (16 columns) and B[k][j] = R[row_k][j] -- R's 16-double rows ARE the B
+// operand (lane l of the wavefront holds B[k = l >> 4][j = l & 15]: one coalesced 512-byte load per four
+// rows; slots 10..15 are zero padding).  Lane l holds A[i = l & 15][k = l >> 4], so ONE 16-byte load per
+// lane brings four rows x 32 consecutive columns (256 contiguous bytes per row) and its two doubles feed
+// two MFMAs (even and odd columns).  A wavefront owns 128 columns (8 result tiles = 64 registers), a
+// workgroup 512, grid.y splits the rows; two 8-row batches are in flight per wavefront (plain register
+// double buffering, no LDS, no barrier).  The vector units only move data: 27 TFLOP/s of the 2 n p 16
+// products run on the MFMA pipe at a third of its fp64 rate, so the kernel is bound by HBM alone.
+// Measured at n = 100k, p = 5k on one box (tools/probes/xtr_mfma.hip): 0.60 ms (6.8 TB/s) against 0.63 ms
+// for xtr_ring_kernel; 32 residual columns cost 0.70 ms, 48 cost 1.0 ms.
+// Result register r of lane l is D[i = (l >> 4) + 4 r][j = l & 15] (guide "Fragment layout").
+// ---------------------------------------------------------------------------------------------
+typedef double slm_d4 __attribute__((ext_vector_type(4)));
+constexpr int XTR_WAVES = 4;                   // wavefronts per workgroup
+constexpr int XTR_CW = 128;                    // columns per wavefront
+constexpr int XTR_CB = XTR_WAVES * XTR_CW;     // columns per workgroup
+constexpr int XTR_U = 2;                       // 4-row steps per batch
+
+__global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a) {
+  static_assert(SPLIT_RSTRIDE == 16 && SPLIT_LANES <= 16, "a row of R is the 16-wide B operand");
+  if (a.done != nullptr && *a.done != 0) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int col0 = ((int)blockIdx.x * XTR_WAVES + wave) * XTR_CW;
+  const int ld = (int)a.ld;
+  if (col0 >= ld) return;  // (no barrier below)
+  const int64_t r0 = (int64_t)blockIdx.y * a.xrows;
+  const int64_t r1 = r0 + a.xrows < a.n ? r0 + a.xrows : a.n;
+  const int kq = lane >> 4, i16 = lane & 15;
+  int coff[4];  // columns past the row (ld is a multiple of 16, not of 32) re-read its last pair; not stored
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = col0 + 32 * c + 2 * i16;
+    coff[c] = col < ld - 2 ? col : ld - 2;
+  }
+  slm_d4 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = slm_d4{0.0, 0.0, 0.0, 0.0};
+  const int nb = (int)((r1 - r0) / (4 * XTR_U));  // full batches
+  const double* xp = a.X + (r0 + kq) * a.ld;
+  const double* rp = a.R + (r0 + kq) * SPLIT_RSTRIDE + i16;
+  d2 xa[XTR_U][4], xb[XTR_U][4];
+  double ra[XTR_U], rb[XTR_U];
+  auto load = [&](d2(&xv)[XTR_U][4], double(&rv)[XTR_U], int b) {
+    const double* xq = xp + (int64_t)b * (4 * XTR_U) * a.ld;
+    const double* rq = rp + (int64_t)b * (4 * XTR_U) * SPLIT_RSTRIDE;
+#pragma unroll
+    for (int u = 0; u < XTR_U; ++u) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const d2* src = reinterpret_cast<const d2*>(xq + (int64_t)u * 4 * a.ld + coff[c]);
+        xv[u][c] = SLM_NT_LOADS ? __builtin_nontemporal_load(src) : *src;
+      }
+      rv[u] = rq[u * 4 * SPLIT_RSTRIDE];
+    }
+  };
+  auto compute = [&](d2(&xv)[XTR_U][4], double(&rv)[XTR_U]) {
+#pragma unroll
+    for (int u = 0; u < XTR_U; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].x, rv[u], acc[2 * c], 0, 0, 0);
+        acc[2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].y, rv[u], acc[2 * c + 1], 0, 0, 0);
+      }
+  };
+  if (nb > 0) load(xa, ra, 0);
+  for (int b = 0; b < nb; b += 2) {
+    if (b + 1 < nb) load(xb, rb, b + 1);
+    compute(xa, ra);
+    if (b + 2 < nb) load(xa, ra, b + 2);
+    if (b + 1 < nb) compute(xb, rb);
+  }
+  // the last rows of the block (fewer than 8): 4-row steps, rows past the end contribute R = 0
+  for (int64_t row = r0 + (int64_t)nb * (4 * XTR_U); row < r1; row += 4) {
+    const bool ok = row + kq < r1;
+    const int64_t rr = ok ? row + kq : r1 - 1;
+    const double rv = ok ? a.R[rr * SPLIT_RSTRIDE + i16] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const d2 x = *reinterpret_cast<const d2*>(a.X + rr * a.ld + coff[c]);
+      acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, rv, acc[2 * c], 0, 0, 0);
+      acc[2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, rv, acc[2 * c + 1], 0, 0, 0);
+    }
+  }
+  if (i16 < SPLIT_LANES) {  // tile 2c+e holds columns col0 + 32 c + 2 i + e
+    double* out = a.partial + ((int64_t)blockIdx.y * SPLIT_LANES + i16) * a.ld;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = col0 + 32 * c + 2 * (kq + 4 * r) + e;
+          if (col < ld) out[col] = acc[2 * c + e][r];
+        }
   }
 }
 
