@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--p", type=int, default=5_000)
     ap.add_argument("--alphas", type=int, default=50)
     ap.add_argument("--tol", type=float, default=1e-8)
-    ap.add_argument("--lanes", type=int, default=10, help="ranges of the path advancing together on one pass over X")
+    ap.add_argument("--lanes", type=int, default=16, help="ranges of the path advancing together on one pass over X")
     ap.add_argument("--no-ws", action="store_true", help="disable the working-set refinement (A/B runs)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     args = ap.parse_args()
@@ -210,11 +210,11 @@ def main():
     if rank == 0:
         assert res is not None and res.converged, "path did not converge"
         # algorithmic bytes of one launch: X once, y once, per lane z read and g written
-        # p = 5000: the fused kernels stop at four lanes; the split pass of working-set solves has ten
+        # p = 5000: the fused kernels stop at four lanes; the split pass of working-set solves has sixteen
         split = not args.no_ws and res.ws_builds > 0
-        lanes_used = max(1, min(args.lanes, 10 if split else 4))
-        if split:  # xtr_ring_kernel: X once, the row residuals of ten lane slots, ten gradient rows out
-            bytes_per_grad = 8.0 * (n * p + 10 * n + 10 * p)
+        lanes_used = max(1, min(args.lanes, 16 if split else 4))
+        if split:  # xtr_mfma_kernel: X once, the row residuals of 16 lane slots, 16 gradient rows out
+            bytes_per_grad = 8.0 * (n * p + 16 * n + 16 * p)
         else:
             bytes_per_grad = 8.0 * (n * p + 2 * n + 2 * p * lanes_used)
         t_grad_ms = grad_ms / max(1, grad_timed)
@@ -254,7 +254,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(n, p, lanes_used),
                 "traffic_unit": "HBM bytes per launch (PMC, profiles/roofline_traffic.json)",
-                "kernel": (f"xtr_ring_kernel (X^T r of the split pass, lanes={lanes_used})" if split
+                "kernel": (f"xtr_mfma_kernel (X^T R of the split pass on the matrix cores, lanes={lanes_used})" if split
                            else f"grad_fused_kernel (lanes={lanes_used})"),
                 "avg_kernel_ms": t_grad_ms,
                 "launches": grad_launches,

@@ -228,7 +228,7 @@ int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point
  * lane live in registers); working-set solves on rows of up to 5120 columns use the split pass, whose
  * accumulate-only stream over X serves SLM_MAX_LANES.
  */
-#define SLM_MAX_LANES 10
+#define SLM_MAX_LANES 16
 typedef struct slm_lane {
   const slm_penalty* pen;         /* NULL => all-ones base vectors                              */
   const slm_path_point* points;   /* this lane's warm-started path                              */

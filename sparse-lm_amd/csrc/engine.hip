@@ -156,17 +156,15 @@ static const int64_t kMaxChunks = 64 * 8 * 10;  // largest row the fused kernel 
 static const GradKernel kGradTwoPass = {8, 4, 2, 1, -1, nullptr};
 static const int kTwoPassC = 4;  // column tile of xtr_kernel: 512 * 4 chunks = 4096 columns
 
-// Split pass (split_kernels.hpp) for working-set solves: ten lanes per read of X, rows of up to
-// 5120 columns (40 accumulator doubles per thread and lane).  D rows in flight as for the fused ring kernel.
+// Split pass (split_kernels.hpp) for working-set solves: sixteen lanes per read of X.  The table is for
+// rowdot_ring_kernel (rows of up to 5120 columns, D rows in flight as for the fused ring kernel).
 struct SplitKernel {
   int W, C, B, D;
-  void (*xtr)(SplitArgs);
   void (*rowdot)(SplitArgs);
   void (*resid)(SplitArgs);
 };
 #define SLM_SK(C, D)                                                                                   \
-  {8, C, SPLIT_LANES, D, xtr_ring_kernel<8, C, SPLIT_LANES, D>, rowdot_ring_kernel<8, C, ROWDOT_LANES, D>, \
-   resid_ws_kernel<SPLIT_LANES>}
+  {8, C, SPLIT_LANES, D, rowdot_ring_kernel<8, C, ROWDOT_LANES, D>, resid_ws_kernel<SPLIT_LANES>}
 static const SplitKernel kSplit[] = {SLM_SK(1, 3), SLM_SK(2, 3), SLM_SK(3, 3), SLM_SK(4, 3), SLM_SK(5, 2)};
 static const SplitKernel* pick_split_kernel(int64_t p2) {
   const char* env = getenv("SLM_SPLIT");
@@ -177,21 +175,13 @@ static const SplitKernel* pick_split_kernel(int64_t p2) {
 }
 
 // X^T R of the split pass on the matrix cores (xtr_mfma_kernel): grid = (column blocks of 512, row blocks),
-// about two workgroups per CU; rows per block a multiple of 8.  SLM_XTR_RING=1 keeps the LDS-ring kernel.
+// about two workgroups per CU; rows per block a multiple of 8.
 static int xtr_max_row_blocks(int cus, int64_t ld) {
   const int xb = (int)((ld + XTR_CB - 1) / XTR_CB);
   return std::max(1, 2 * cus / xb);
 }
-static bool xtr_use_ring() {
-  static const bool ring = [] { const char* e = getenv("SLM_XTR_RING"); return e && e[0] == '1'; }();
-  return ring;
-}
 // sets a.xrows; returns the number of row blocks (= blocks of `partial` to reduce)
-static int launch_xtr(const SplitKernel* sk, int split_nblk, int cus, SplitArgs& a, hipStream_t s) {
-  if (xtr_use_ring()) {
-    hipLaunchKernelGGL(sk->xtr, dim3(split_nblk), dim3(sk->W * 64), 0, s, a);
-    return split_nblk;
-  }
+static int launch_xtr(int cus, SplitArgs& a, hipStream_t s) {
   const int xb = (int)((a.ld + XTR_CB - 1) / XTR_CB);
   const int64_t want = xtr_max_row_blocks(cus, a.ld);
   int64_t rows = (a.n + want - 1) / want;
@@ -849,7 +839,7 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
   if (wa && ctl) hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
   // (SLM_FLAG_PROFILE brackets the kernel that streams X, the one the roofline is quoted on)
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
-  const int xblk = launch_xtr(sk, nblk, ds->eng->cus, a, s);
+  const int xblk = launch_xtr(ds->eng->cus, a, s);
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
   ReduceArgs ra;
   ra.partial = ds->partial;
@@ -1063,7 +1053,7 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
             hipLaunchKernelGGL(ds->sk->rowdot, dim3(ds->split_nblk), dim3(ds->sk->W * 64), 0, s, a);
           }
         }
-        (void)launch_xtr(ds->sk, ds->split_nblk, ds->eng->cus, a, s);
+        (void)launch_xtr(ds->eng->cus, a, s);
       }
       HIP_TRY(hipEventRecord(e1, s));
       HIP_TRY(hipEventSynchronize(e1));
@@ -1274,7 +1264,7 @@ static int ws_policy(const slm_dataset* ds, uint32_t flags) {
   const bool big = (double)ds->n * (double)ds->ld >= 67108864.0;  // 2^26 doubles = 512 MiB
   return (big || (flags & SLM_FLAG_WORKING_SET) || (env && env[0] == '1')) ? 2 : 1;
 }
-// most lanes one solve can run: the fused kernels' table, or the split pass's ten when the working
+// most lanes one solve can run: the fused kernels' table, or the split pass's sixteen when the working
 // set is on from the start
 static int max_lanes_for(const slm_dataset* ds, uint32_t flags) {
   if (ws_policy(ds, flags) == 2 && ds->sk) return SPLIT_LANES;
@@ -1608,7 +1598,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
   }
   const int* done_flag = &ds->gctl->done;
-  // the gradient of one pass: split pass (ten lane slots, residuals from the gathered columns where
+  // the gradient of one pass: split pass (sixteen lane slots, residuals from the gathered columns where
   // possible) when the working set runs from the start, the fused kernel otherwise
   auto enqueue_pass_gradient = [&](hipEvent_t e0, hipEvent_t e1) -> int {
     if (split) return enqueue_gradient_split(ds, ls, ds->y, done_flag, ds->ctl, &wa, e0, e1);

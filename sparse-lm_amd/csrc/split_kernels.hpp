@@ -3,19 +3,18 @@
 // With the working-set refinement (ws_kernels.hpp) nearly every point a lane asks the gradient at is
 // supported on W, the <= 256 columns already gathered into the compact matrix XW.  Its residual
 // r = W (X z - y) then needs only XW (n x K, a few tens of MB), and the pass over X reduces to the
-// second half of the fused kernel, g = X^T r / n.  That half keeps only the accumulators in
-// registers (4C VGPRs per lane instead of the fused kernel's 8C for z + accumulators), so TEN lanes
-// share one read of X where the fused kernel tops out at four, and its row loop has no dot product,
-// no cross-wave exchange and no barrier at all.
+// second half of the fused kernel, G = X^T R / n with R the n x 16 matrix of the lanes' residuals: a
+// skinny GEMM, run on the matrix cores, so SIXTEEN lanes share one read of X where the fused kernel tops
+// out at four, and its row loop has no dot product, no cross-wave exchange and no barrier at all.
 //
 //   resid_ws_kernel      R[i][l] = w_l,i (XW_i . zW_l - y_i)      lanes whose z is supported on W
 //   rowdot_ring_kernel   R[i][l] = w_l,i (x_i . z_l - y_i)        the others (reads X; returns at once
 //                                                                 when there are none)
-//   xtr_ring_kernel      partial[blk][l][:] = sum_{i in blk} R[i][l] x_i     (reads X once)
+//   xtr_mfma_kernel      partial[blk][l][:] = sum_{i in blk} R[i][l] x_i     (reads X once)
 //
-// All three use the same contiguous row blocks as the fused kernels, so reduce_partials_kernel and
-// everything after it are unchanged.  R is lane-minor ([n][16], ten used) so a row's residuals are
-// two 64-byte scalar loads.  Reference counterpart: the `X @ beta` inside the cvxpy objective
+// The residual kernels use the same contiguous row blocks as the fused kernels; xtr_mfma_kernel has its
+// own (column block, row block) grid; reduce_partials_kernel and everything after it are unchanged.  R is
+// lane-minor ([n][16]): a row of R is a row of the MFMA B operand.  Reference counterpart: the `X @ beta` inside the cvxpy objective
 // (src/sparselm/model/_lasso.py:109-121), as for the fused kernel.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,7 +26,7 @@
 
 namespace slm {
 
-constexpr int SPLIT_LANES = 10;    // lane slots of the split pass (40 accumulator doubles x 10 = 236 VGPRs at C = 5)
+constexpr int SPLIT_LANES = 16;    // lane slots of the split pass: the 16 columns of the MFMA B operand
 constexpr int SPLIT_RSTRIDE = 16;  // doubles per row of R (two 64-byte scalar loads)
 constexpr int ROWDOT_LANES = 5;    // lanes per launch of rowdot_ring_kernel (z + row in registers: 162 VGPRs)
 
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(256) void resid_ws_kernel(SplitArgs a) {
   if (a.done != nullptr && *a.done != 0) return;
   const unsigned mask = split_ws_mask(a);
   if (mask == 0u) return;
-  __shared__ double zw[WS_KCAP][B];  // 16 KiB
+  __shared__ double zw[WS_KCAP][B];  // 64 KiB
   __shared__ double lsum[4][B];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.ws->K;  // multiple of 16; positions >= Kreal hold zero columns
@@ -305,119 +304,8 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
   }
 }
 
-// 64-byte / 16-byte scalar loads: eight / two of the residuals of one row.  The caller waits
-// lgkmcnt(0) before use.  EVERY element of the result must be used: the compiler treats the asm output
-// as available at once and recycles registers of the tuple it considers dead while the load is still
-// in flight (a 64-byte load for lanes 8-9 had its upper SGPRs reused for the LDS ring address: the
-// DMA then went to whatever the load wrote there).
-typedef uint32_t slm_u32x16 __attribute__((ext_vector_type(16)));
-typedef uint32_t slm_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ slm_u32x16 smem_load_64B(const double* p) {
-  slm_u32x16 v;
-  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ slm_u32x4 smem_load_16B(const double* p) {
-  slm_u32x4 v;
-  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
-  return v;
-}
-
 // ---------------------------------------------------------------------------------------------
-// g partials: acc[l][:] += R[row][l] * x_row.  Every wavefront streams its own chunks through the
-// LDS ring and reads only those back: no cross-wave traffic, no barrier in the row loop.  Measured at
-// n=100k, p=5k, 8 lanes: 0.614 ms (6.5 TB/s); a barrier per row (0.625 ms) or a third row in flight
-// (all 160 KiB of LDS, 0.653 ms) are slower; loading the residuals before the DMA wait gained 2 %;
-// the `nt` policy on the DMA loads matters (0.626 ms against 0.723 ms without, tools/probes/xtr_lanes.hip);
-// the lane count hardly does (one lane: 0.620 ms, ten: 0.649 ms on the same box).
-// ---------------------------------------------------------------------------------------------
-template <int W, int C, int B, int D>
-__global__ __launch_bounds__(W * 64) void xtr_ring_kernel(SplitArgs a) {
-  constexpr int T = W * 64;
-  constexpr int SLOT = T * C * 16;
-  constexpr int RING = (D + 1) * SLOT;
-  static_assert(RING <= 160 * 1024, "ring does not fit the 160 KiB LDS");
-  static_assert(D * C < 64, "too many DMA loads in flight for vmcnt");
-  static_assert(B == SPLIT_LANES && B == 10, "a row of R is one 64-byte and one 16-byte scalar load");
-  if (a.done != nullptr && *a.done != 0) return;
-
-  __shared__ __attribute__((aligned(16))) char smem[RING];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t b = blockIdx.x;
-  const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
-  const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
-
-  uint32_t coff[C];
-  bool valid[C];
-  d2 acc[B][C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const int ci = c * T + tid;
-    valid[c] = ci < a.p2;
-    coff[c] = (uint32_t)(valid[c] ? ci : a.p2 - 1) * 16u;
-#pragma unroll
-    for (int l = 0; l < B; ++l) acc[l][c] = d2{0.0, 0.0};
-  }
-
-  auto issue_row = [&](int64_t i, int slot) {
-    const char* rp = reinterpret_cast<const char*>(a.X + (r0 + i) * a.ld);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      char* dst = smem + slot * SLOT + (c * T + wave * 64) * 16;
-      __builtin_amdgcn_global_load_lds((gptr_t)(rp + coff[c]), (lptr_t)dst, 16, 0, SLM_NT_LOADS ? 2 : 0);
-    }
-  };
-
-  if (nrows > 0) {
-#pragma unroll
-    for (int k = 0; k < D; ++k)
-      if (k < nrows) issue_row(k, k);
-    int slot = 0, slot_in = D;
-    for (int64_t i = 0; i < nrows; ++i) {
-      // the row's residuals first: the scalar load then flies while the wave waits for its DMA chunks
-      slm_u32x16 ra = smem_load_64B(a.R + (r0 + i) * SPLIT_RSTRIDE);
-      slm_u32x4 rb = smem_load_16B(a.R + (r0 + i) * SPLIT_RSTRIDE + 8);
-      const int64_t left = nrows - 1 - i;
-      if (left >= D) {
-        issue_row(i + D, slot_in);
-        wait_vmcnt<D * C>();
-      } else {
-        if (D >= 3 && left == 2) wait_vmcnt<(D >= 3 ? 2 : 0) * C>();
-        else if (D >= 2 && left == 1) wait_vmcnt<(D >= 2 ? 1 : 0) * C>();
-        else wait_vmcnt<0>();
-      }
-      d2 x[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c)
-        x[c] = *reinterpret_cast<const d2*>(smem + slot * SLOT + (c * T + tid) * 16);
-      // the loaded SGPRs are outputs of the wait (see smem_load_64B): live and unread until here
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(rb) : : "memory");
-#pragma unroll
-      for (int l = 0; l < B; ++l) {
-        const double res = l < 8 ? __hiloint2double((int)ra[2 * (l & 7) + 1], (int)ra[2 * (l & 7)])
-                                 : __hiloint2double((int)rb[2 * (l & 7) + 1], (int)rb[2 * (l & 7)]);
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          acc[l][c].x = __builtin_fma(res, x[c].x, acc[l][c].x);
-          acc[l][c].y = __builtin_fma(res, x[c].y, acc[l][c].y);
-        }
-      }
-      slot = (slot == D) ? 0 : slot + 1;
-      slot_in = (slot_in == D) ? 0 : slot_in + 1;
-    }
-  }
-#pragma unroll
-  for (int l = 0; l < B; ++l) {
-    d2* out = reinterpret_cast<d2*>(a.partial + (b * B + l) * a.ld);
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-      if (valid[c]) out[c * T + tid] = acc[l][c];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same sums on the matrix cores: partial[by][l][col] = sum_{row in block by} R[row][l] X[row][col]
+// X^T R on the matrix cores: partial[by][l][col] = sum_{row in block by} R[row][l] X[row][col]
 // as v_mfma_f64_16x16x4_f64 products, D[i][j] += sum_k A[i][k] B[k][j] with k = 4 consecutive rows,
 // A[i][k] = X[row_k][col_i] (16 columns) and B[k][j] = R[row_k][j] -- R's 16-double rows ARE the B
 // operand (lane l of the wavefront holds B[k = l >> 4][j = l & 15]: one coalesced 512-byte load per four
@@ -428,7 +316,8 @@ __global__ __launch_bounds__(W * 64) void xtr_ring_kernel(SplitArgs a) {
 // double buffering, no LDS, no barrier).  The vector units only move data: 27 TFLOP/s of the 2 n p 16
 // products run on the MFMA pipe at a third of its fp64 rate, so the kernel is bound by HBM alone.
 // Measured at n = 100k, p = 5k on one box (tools/probes/xtr_mfma.hip): 0.60 ms (6.8 TB/s) against 0.63 ms
-// for xtr_ring_kernel; 32 residual columns cost 0.70 ms, 48 cost 1.0 ms.
+// for the vector-FMA kernel it replaced (rows DMA'd through an LDS ring, residuals by scalar loads, ten
+// lanes at most: tools/probes/xtr_lanes.hip keeps that loop); 32 residual columns cost 0.70 ms, 48 cost 1.0 ms.
 // Result register r of lane l is D[i = (l >> 4) + 4 r][j = l & 15] (guide "Fragment layout").
 // ---------------------------------------------------------------------------------------------
 typedef double slm_d4 __attribute__((ext_vector_type(4)));

@@ -143,7 +143,7 @@ class _Lane(C.Structure):
     ]
 
 
-MAX_LANES = 10
+MAX_LANES = 16
 WS_COLUMNS = 512  # WS_KCAP of the engine: columns a working set / a sparse scoring call can hold
 
 _lib = None

@@ -13,11 +13,11 @@ hyper-parameter, e.g. ``l1_ratio``), X is uploaded ONCE and
 
   * every fold is a row mask (test rows weigh 0) with its own 1/n_train scaling -- a *lane*;
   * every (fold, other-params) pair is one warm-started alpha path solved on the device;
-  * up to ten lanes share each pass over X (``slm_solve_lanes``; ten in working-set solves on large
+  * up to sixteen lanes share each pass over X (``slm_solve_lanes``; sixteen in working-set solves on large
     X, otherwise as many as the fused kernel table has for this p); units are dealt fold-major so the
     lanes of a batch share one row mask and one working-set Gram;
   * for the ``Adaptive*`` estimators every (candidate, fold) re-weighting loop is a lane instead: outer
-    iteration k of up to ten loops is one call, each lane with its own weight vectors, row mask and warm
+    iteration k of up to sixteen loops is one call, each lane with its own weight vectors, row mask and warm
     start (``_adaptive_lanes``; loop semantics of reference _adaptive_lasso.py:206-232);
   * ``fit_intercept=True`` is an unpenalised column of ones appended to the device copy (jointly
     minimising over it is per-fold centring);
@@ -103,7 +103,7 @@ class GridSearchCV(_GridSearchCV):
         pre_dispatch="2*n_jobs",
         error_score=np.nan,
         return_train_score=False,
-        lanes=10,
+        lanes=16,
     ):
         super().__init__(
             estimator=estimator,

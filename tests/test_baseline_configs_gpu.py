@@ -47,7 +47,9 @@ def test_config2_lasso_path_full_size_is_kkt_certified(eng):
         alphas = np.geomspace(amax, 1e-3 * amax, 50)
         res = ds.solve_path([(a, 0.0, 0.0) for a in alphas])
         assert res.converged
-        assert np.all(res.betas[0] == 0.0)
+        # alpha_max comes from another kernel's gradient (different summation order): the first point is zero
+        # up to that rounding
+        assert np.max(np.abs(res.betas[0])) <= 1e-12 * np.max(np.abs(res.betas[-1]))
         gidx, G = oracle.group_index(None, P)
         zero = np.zeros(G)
         for k in (1, 10, 25, 40, 49):
@@ -73,7 +75,9 @@ def test_config3_group_lasso_path_full_size_is_kkt_certified(eng):
         alphas = np.geomspace(bmax, 1e-3 * bmax, 50)
         res = ds.solve_path([(0.0, a, 0.0) for a in alphas], want_group_norms=True)
         assert res.converged
-        assert np.all(res.betas[0] == 0.0)
+        # alpha_max comes from another kernel's gradient (different summation order): the first point is zero
+        # up to that rounding
+        assert np.max(np.abs(res.betas[0])) <= 1e-12 * np.max(np.abs(res.betas[-1]))
         zero_p = np.zeros(P)
         for k in (1, 12, 30, 49):
             beta = res.betas[k]

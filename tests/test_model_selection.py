@@ -247,7 +247,7 @@ def test_fast_path_with_intercept_matches_generic_path(golden):
 @pytest.mark.gpu
 def test_fast_path_adaptive_estimators_match_generic_path(golden):
     # Adaptive* in the grid: every (candidate, fold) re-weighting loop is a lane; outer iteration k of up to
-    # ten of them is one engine call.  Same scores, selection and refit as scikit-learn's loop of fits.
+    # sixteen of them is one engine call.  Same scores, selection and refit as scikit-learn's loop of fits.
     from sklearn.datasets import make_regression
 
     from sparselm_amd.model import AdaptiveGroupLasso, AdaptiveLasso, AdaptiveRidgedGroupLasso, AdaptiveSparseGroupLasso

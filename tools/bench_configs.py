@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--n", type=int, default=100_000)
     ap.add_argument("--p", type=int, default=5_000)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--lanes", type=int, default=_engine.MAX_LANES)
     args = ap.parse_args()
     n, p = args.n, args.p
     G = p // 10
@@ -42,12 +43,12 @@ def main():
     bmax = float(gnorm.max())
     alphas = np.geomspace(bmax, 1e-3 * bmax, 50)
     pts = [(0.0, a, 0.0) for a in alphas]
-    ds.solve_path(pts, lanes=10)
+    ds.solve_path(pts, lanes=args.lanes)
     t0 = time.perf_counter()
     for _ in range(args.reps):
-        res = ds.solve_path(pts, lanes=10, flags=_engine.FLAG_FRESH_L)
+        res = ds.solve_path(pts, lanes=args.lanes, flags=_engine.FLAG_FRESH_L)
     dt = (time.perf_counter() - t0) / args.reps
-    print(json.dumps({"config": "3: GroupLasso 500x10 groups, 50-alpha path, 1 GPU, 10 lanes", "fits_per_s": 50 / dt,
+    print(json.dumps({"config": f"3: GroupLasso 500x10 groups, 50-alpha path, 1 GPU, {args.lanes} lanes", "fits_per_s": 50 / dt,
                       "ms_per_path": 1e3 * dt, "passes": res.grad_launches, "converged": res.converged, "ws": [res.ws_builds, res.ws_appends, res.ws_refined, res.ws_misses, res.ws_columns],
                       "nnz_groups_last": int(np.sum(res.betas[-1].reshape(-1) != 0) // 10)}), flush=True)
 
@@ -59,9 +60,9 @@ def main():
 
     def run_grid():
         total_passes = 0
-        for k0 in range(0, len(units), 10):
+        for k0 in range(0, len(units), args.lanes):
             specs = []
-            for f, r in units[k0 : k0 + 10]:
+            for f, r in units[k0 : k0 + args.lanes]:
                 # alpha_max for this l1_ratio (upper bound: group part alone or l1 part alone)
                 amax = min(bmax / (1 - r), float(np.max(np.abs(g0))) / r)
                 al = np.geomspace(amax, 1e-3 * amax, 50)
@@ -76,7 +77,7 @@ def main():
     t0 = time.perf_counter()
     passes = run_grid()
     dt = time.perf_counter() - t0
-    print(json.dumps({"config": "4: SparseGroupLasso 5-fold x 10 l1_ratio x 50 alpha = 2500 fits, 1 GPU, folds as lanes",
+    print(json.dumps({"config": f"4: SparseGroupLasso 5-fold x 10 l1_ratio x 50 alpha = 2500 fits, 1 GPU, {args.lanes} (fold, l1_ratio) units per call",
                       "fits_per_s": 2500 / dt, "seconds_per_grid": dt, "passes": passes}), flush=True)
     ds.close()
 

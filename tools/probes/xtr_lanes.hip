@@ -1,9 +1,31 @@
-// How does the accumulate-only pass scale with the number of lane slots?  (standalone probe)
+// How does the accumulate-only pass scale with the number of lane slots?  (standalone probe of the
+// vector-FMA kernel the library used before xtr_mfma_kernel: rows DMA'd through an LDS ring, residuals
+// by scalar loads)
 #include "../../sparse-lm_amd/csrc/split_kernels.hpp"
 #include <cstdio>
 #include <cstring>
 #include <vector>
 using namespace slm;
+
+// 64-byte / 16-byte scalar loads: eight / two of the residuals of one row.  The caller waits
+// lgkmcnt(0) before use.  EVERY element of the result must be used: the compiler treats the asm output
+// as available at once and recycles registers of the tuple it considers dead while the load is still
+// in flight (a 64-byte load for lanes 8-9 had its upper SGPRs reused for the LDS ring address: the
+// DMA then went to whatever the load wrote there).
+typedef uint32_t slm_u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t slm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ slm_u32x16 smem_load_64B(const double* p) {
+  slm_u32x16 v;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ slm_u32x4 smem_load_16B(const double* p) {
+  slm_u32x4 v;
+  asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
+
 
 // same loop as xtr_ring_kernel, any B <= 10 (the residual row is always loaded in full)
 template <int W, int C, int B, int D, int AUX = 2>
