@@ -1421,8 +1421,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       SLM_TRY(upload_vec_or_const(ds->b0 + (size_t)l * ld, pen ? pen->b : nullptr, G, 1.0, s));
       SLM_TRY(upload_vec_or_const(ds->d0 + (size_t)l * ld, pen ? pen->d : nullptr, G, 1.0, s));
     }
-    HIP_TRY(hipMemcpyAsync(ds->pts + off, ln.points, sizeof(slm_path_point) * ln.n_points,
-                           hipMemcpyHostToDevice, s));
+    if (l == 0 || ln.points != lanes[l - 1].points + lanes[l - 1].n_points) {  // (one copy per contiguous run)
+      int64_t run = ln.n_points;
+      for (int m = l + 1; m < B && lanes[m].points == lanes[m - 1].points + lanes[m - 1].n_points; ++m)
+        run += lanes[m].n_points;
+      HIP_TRY(hipMemcpyAsync(ds->pts + off, ln.points, sizeof(slm_path_point) * run, hipMemcpyHostToDevice, s));
+    }
     if (ln.beta0) {
       for (int64_t j = 0; j < p; ++j)
         if (!std::isfinite(ln.beta0[j])) return fail(SLM_ERR_BAD_ARG, "beta0[%lld] is not finite", (long long)j);
@@ -1760,17 +1764,31 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   HIP_TRY(hipMemcpy(fin, ds->ctl, sizeof(PathCtl) * B, hipMemcpyDeviceToHost));
   int64_t passes = 0;
   bool nonfinite = false;
+  // results: lanes whose host buffers follow each other (the ranges of one shared path do) travel in one
+  // copy -- a device-to-host copy into pageable memory costs ~40 us before the first byte moves
   off = 0;
-  for (int l = 0; l < B; ++l) {
-    const slm_lane& ln = lanes[l];
-    HIP_TRY(hipMemcpy(ln.betas_out, ds->betas_out + (size_t)off * p, sizeof(double) * (size_t)ln.n_points * p,
+  for (int l = 0; l < B;) {
+    int l1 = l + 1;
+    int64_t pts = lanes[l].n_points;
+    const bool gn = lanes[l].group_norms_out != nullptr, inf = lanes[l].infos != nullptr;
+    while (l1 < B && lanes[l1].betas_out == lanes[l].betas_out + (size_t)pts * p &&
+           (lanes[l1].group_norms_out != nullptr) == gn && (lanes[l1].infos != nullptr) == inf &&
+           (!gn || lanes[l1].group_norms_out == lanes[l].group_norms_out + (size_t)pts * G) &&
+           (!inf || lanes[l1].infos == lanes[l].infos + pts)) {
+      pts += lanes[l1].n_points;
+      ++l1;
+    }
+    HIP_TRY(hipMemcpy(lanes[l].betas_out, ds->betas_out + (size_t)off * p, sizeof(double) * (size_t)pts * p,
                       hipMemcpyDeviceToHost));
-    if (ln.group_norms_out)
-      HIP_TRY(hipMemcpy(ln.group_norms_out, ds->gn_out + (size_t)off * G,
-                        sizeof(double) * (size_t)ln.n_points * G, hipMemcpyDeviceToHost));
-    if (ln.infos)
-      HIP_TRY(hipMemcpy(ln.infos, ds->infos + off, sizeof(slm_point_info) * ln.n_points, hipMemcpyDeviceToHost));
-    off += ln.n_points;
+    if (gn)
+      HIP_TRY(hipMemcpy(lanes[l].group_norms_out, ds->gn_out + (size_t)off * G, sizeof(double) * (size_t)pts * G,
+                        hipMemcpyDeviceToHost));
+    if (inf)
+      HIP_TRY(hipMemcpy(lanes[l].infos, ds->infos + off, sizeof(slm_point_info) * (size_t)pts, hipMemcpyDeviceToHost));
+    off += pts;
+    l = l1;
+  }
+  for (int l = 0; l < B; ++l) {
     passes = std::max<int64_t>(passes, fin[l].total_iter);
     nonfinite = nonfinite || fin[l].nonfinite;
   }

@@ -505,26 +505,39 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
 
   const int kk = lane >> 4, c = lane & 15;
   if (active) {
-    for (int64_t s = s_begin; s < s_end; s += 4) {
+    // two steps in flight: the loads of step s + 4 are issued before the 16 MFMAs of step s (the loop is
+    // otherwise one load latency per 4 rows: ~100 dependent steps per wavefront)
+    // (the row weight is applied in mma(), not at the load, so nothing waits on a load before the MFMAs)
+    auto load = [&](int64_t s, double(&av)[4], double(&bv)[4], double& wgt) {
       const int64_t i = s + kk;
       const bool ok = i < s_end;
       const int64_t row = r0 + (ok ? i : 0);
-      const double wgt = ok ? (rw ? rw[row] : 1.0) : 0.0;
+      wgt = ok ? (rw ? rw[row] : 1.0) : 0.0;
       const double* xr = w.XW + row * WS_KCAP + c;
-      double av[4], bv[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        av[t] = (t >= ti_lo && t < nti) ? xr[16 * (ibase + t)] * wgt : 0.0;
+        av[t] = (t >= ti_lo && t < nti) ? xr[16 * (ibase + t)] : 0.0;
         bv[t] = t < ntj ? xr[16 * (4 * wj + t)] : 0.0;
       }
+    };
+    auto mma = [&](const double(&av)[4], const double(&bv)[4], double wgt) {
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
         if (ti >= ti_lo && ti < nti) {
+          const double a = av[ti] * wgt;
 #pragma unroll
           for (int tj = 0; tj < 4; ++tj)
-            if (tj < ntj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti], bv[tj], acc[ti][tj], 0, 0, 0);
+            if (tj < ntj) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[tj], acc[ti][tj], 0, 0, 0);
         }
       }
+    };
+    double a0[4], b0[4], a1[4], b1[4], w0 = 0.0, w1 = 0.0;
+    if (s_begin < s_end) load(s_begin, a0, b0, w0);
+    for (int64_t s = s_begin; s < s_end; s += 8) {
+      if (s + 4 < s_end) load(s + 4, a1, b1, w1);
+      mma(a0, b0, w0);
+      if (s + 8 < s_end) load(s + 8, a0, b0, w0);
+      if (s + 4 < s_end) mma(a1, b1, w1);
     }
   }
   if (row_split) {  // parts 0..3 in order: store, add + store, add + store, add (and write below)
