@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// (iii) partial Grams with v_mfma_f64_16x16x4_f64.  Grid (nblk, n_sets, 8); 8 wavefronts per
+// (iii) partial Grams with v_mfma_f64_16x16x4_f64.  Grid (nblk, n_sets, 4 WS_GRAM_ZCHUNKS); 8 wavefronts per
 // workgroup laid out 4 x 2, each owning a 4 x 4 block of 16x16 output tiles, so a workgroup covers
 // 256 x 128 of the 512 x 512 capacity and blockIdx.z picks which (2 row halves x 4 column quarters;
 // workgroups beyond K return at once).  16 accumulator tiles = 128 registers per lane, which is why
@@ -463,6 +463,7 @@ __global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
 // ---------------------------------------------------------------------------------------------
 typedef double ws_d4 __attribute__((ext_vector_type(4)));
 constexpr int WS_GRAM_THREADS = 512;
+constexpr int WS_GRAM_ZCHUNKS = 4;  // grid.z = 4 column quarters x this many row chunks
 
 __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
   if (!w.ws->building) return;
@@ -478,10 +479,14 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
   // rows those are would work (2 of 8, 98 dependent steps each: 0.13 ms of latency); instead the four
   // wavefront pairs split the ROWS of the block between them, all on the new tile rows, and fold
   // their accumulators through LDS in a fixed order.
-  const bool row_split = tile_lo > 0 && tiles - tile_lo <= 4;
-  if (row_split && ((int)blockIdx.z >> 2)) return;
+  // Larger appends (a miss quadruples the cap) are cut into chunks of four tile rows, one per value of
+  // blockIdx.z >> 2, each handled the same way (up to 16 new tile rows = 256 columns; the generic
+  // mapping left most wavefronts idle on them: 0.44 ms for 170 new columns).
+  const bool row_split = tile_lo > 0 && tiles - tile_lo <= 4 * WS_GRAM_ZCHUNKS;
+  const int zhi = (int)blockIdx.z >> 2;
+  if (row_split ? (tile_lo + 4 * zhi >= tiles) : (zhi >= 2)) return;
   const int part = row_split ? (wave >> 1) : 0;
-  const int ibase = row_split ? tile_lo : 4 * (4 * ((int)blockIdx.z >> 2) + (wave >> 1));
+  const int ibase = row_split ? tile_lo + 4 * zhi : 4 * (4 * zhi + (wave >> 1));
   const int ti_lo = row_split ? 0 : max(0, tile_lo - ibase);  // first tile row of this wave to do
   const int nti = min(4, max(0, tiles - ibase));
   const bool active = ti_lo < nti && ntj > 0;
