@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 2
+#define SLM_ABI_VERSION 3
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -243,6 +243,9 @@ typedef struct slm_lane {
 
 int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes,
                     const slm_solve_opts* opts, slm_solve_stats* stats);
+/* How many lanes one slm_solve_lanes call on this dataset can take with these solve flags (callers
+ * size their batches of CV folds / grid rows with it instead of probing for SLM_ERR_UNSUPPORTED). */
+int slm_dataset_max_lanes(slm_dataset* ds, uint32_t flags, int32_t* max_lanes_out);
 
 /*
  * ONE warm-started path walked by n_lanes lanes that share each pass over X: the path is cut into

@@ -1831,6 +1831,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   return SLM_OK;
 }
 
+extern "C" int slm_dataset_max_lanes(slm_dataset* ds, uint32_t flags, int32_t* max_lanes_out) {
+  if (!ds || !max_lanes_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  *max_lanes_out = max_lanes_for(ds, flags);
+  return SLM_OK;
+}
+
 extern "C" int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes,
                                const slm_solve_opts* opts, slm_solve_stats* stats) {
   return solve_core(ds, lanes, n_lanes, opts, stats, false);

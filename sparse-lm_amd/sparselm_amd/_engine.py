@@ -41,7 +41,7 @@ FLAG_WORKING_SET = 32  # force the Gram-assisted refinement even for small X
 FLAG_NO_WORKING_SET = 64
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 2  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 3  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -62,6 +62,7 @@ ABI_SYMBOLS = (
     "slm_dataset_set_row_weights",
     "slm_dataset_set_groups",
     "slm_dataset_lipschitz",
+    "slm_dataset_max_lanes",
     "slm_gradient",
     "slm_eval_sse",
     "slm_eval_sse_sparse",
@@ -196,6 +197,7 @@ def load_library():
             "slm_dataset_set_row_weights": [vp, vp],
             "slm_dataset_set_groups": [vp, vp, i32],
             "slm_dataset_lipschitz": [vp, P(dbl)],
+            "slm_dataset_max_lanes": [vp, C.c_uint32, P(i32)],
             "slm_gradient": [vp, vp, vp, P(dbl), i32, P(dbl)],
             "slm_eval_sse": [vp, vp, i32, vp, vp],
             "slm_eval_sse_sparse": [vp, vp, i32, vp, i32, vp, vp],
@@ -473,6 +475,13 @@ class Dataset:
         G = int(g.max()) + 1 if n_groups is None else int(n_groups)
         _check(self._lib.slm_dataset_set_groups(self._h, _ptr(g), G))
         self.n_groups = G
+
+    def max_lanes(self, flags: int = 0) -> int:
+        """Lanes one ``solve_lanes`` call can take here (16 in working-set solves on large X, else what the
+        fused kernel table has for this p)."""
+        out = C.c_int32()
+        _check(self._lib.slm_dataset_max_lanes(self._h, int(flags), C.byref(out)))
+        return int(out.value)
 
     def lipschitz(self) -> float:
         L = C.c_double()

@@ -222,7 +222,7 @@ class GridSearchCV(_GridSearchCV):
             if gidx is not None:
                 ds.set_groups(np.append(gidx, G) if intercept else gidx, G + 1 if intercept else G)
             my_units = [units[i] for i in D.shard_units(len(units), rank, world)]
-            lanes = max(1, min(int(self.lanes), _engine.MAX_LANES))
+            lanes = max(1, min(int(self.lanes), _engine.MAX_LANES, ds.max_lanes()))
             opts = _solver_options(est)
             local = {}
             for k0 in range(0, len(my_units), lanes):
@@ -237,6 +237,9 @@ class GridSearchCV(_GridSearchCV):
                         sse = ds.eval_sse(fit["beta"][None, :], test_masks[f])
                         local[(c, f)] = (combos[c], self._score_from_sse(sse, y[splits[f][1]]), dt)
                     continue
+                # a batch with spare lane slots (the last one; every one when there are fewer units than
+                # lanes, e.g. a grid dealt over 8 GPUs) cuts each unit's path into contiguous ranges, one
+                # lane each: a pass advances every lane by one point, so the call needs K / split passes
                 specs, metas = [], []
                 for c, f in batch:
                     cis = sorted(combos[c], key=lambda ci: -candidates[ci]["alpha"])
@@ -251,13 +254,18 @@ class GridSearchCV(_GridSearchCV):
                         np.ones_like(alphas) if d is not None else 0 * alphas,
                     ]
                     train, test = splits[f]
-                    specs.append(dict(points=pts, a=a, b=b, d=d, row_weight=train_masks[f], n_eff=len(train)))
-                    metas.append((cis, test))
+                    split = max(1, min(lanes // len(batch), len(cis) // 4)) if lanes >= 8 else 1
+                    for part in np.array_split(np.arange(len(cis)), split):
+                        specs.append(dict(points=pts[part], a=a, b=b, d=d, row_weight=train_masks[f], n_eff=len(train)))
+                    metas.append((cis, test, split))
                 t_batch = time.perf_counter()
                 results = _solve_lanes_with_fallback(ds, specs, opts)
                 dt = (time.perf_counter() - t_batch) / max(1, sum(len(m[0]) for m in metas))
-                for (c, f), (cis, test), res in zip(batch, metas, results):
-                    sse = ds.eval_sse(res.betas, test_masks[f])
+                at = 0
+                for (c, f), (cis, test, split) in zip(batch, metas):
+                    betas = np.vstack([r.betas for r in results[at : at + split]])
+                    at += split
+                    sse = ds.eval_sse(betas, test_masks[f])
                     local[(c, f)] = (cis, self._score_from_sse(sse, y[test]), dt)
             merged = _gather(local, units)
             for (c, f), (cis, sc, dt) in merged.items():

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = _engine.load_library()
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert lib.slm_abi_version() == 2
+    assert lib.slm_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

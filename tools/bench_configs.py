@@ -62,12 +62,15 @@ def main():
         total_passes = 0
         for k0 in range(0, len(units), args.lanes):
             specs = []
-            for f, r in units[k0 : k0 + args.lanes]:
+            batch = units[k0 : k0 + args.lanes]
+            split = max(1, args.lanes // len(batch))  # spare lane slots: cut each path into contiguous ranges
+            for f, r in batch:
                 # alpha_max for this l1_ratio (upper bound: group part alone or l1 part alone)
                 amax = min(bmax / (1 - r), float(np.max(np.abs(g0))) / r)
                 al = np.geomspace(amax, 1e-3 * amax, 50)
-                specs.append(dict(points=np.c_[r * al, (1 - r) * al, 0 * al], row_weight=masks[f],
-                                  n_eff=int(masks[f].sum())))
+                pts = np.c_[r * al, (1 - r) * al, 0 * al]
+                for part in np.array_split(np.arange(50), split):
+                    specs.append(dict(points=pts[part], row_weight=masks[f], n_eff=int(masks[f].sum())))
             out = ds.solve_lanes(specs)
             total_passes += out[0].grad_launches
             assert all(o.converged for o in out)
