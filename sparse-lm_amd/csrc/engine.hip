@@ -832,10 +832,9 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
   a.n = nr; a.ld = ds->ld; a.rows_base = nr / nblk; a.rows_rem = nr % nblk;
   a.p2 = (int)(ds->ld / 2);
   a.n_lanes = ls.B;
-  for (int l0 = 0; l0 < ls.B; l0 += ROWDOT_LANES) {  // (each launch returns at once unless a lane of its window needs X)
-    a.lane0 = l0;
-    hipLaunchKernelGGL(sk->rowdot, dim3(nblk), dim3(sk->W * 64), 0, s, a);
-  }
+  // (one window of ROWDOT_LANES lanes per grid row; a window returns at once unless one of its lanes needs X)
+  a.lane0 = 0;
+  hipLaunchKernelGGL(sk->rowdot, dim3(nblk, (ls.B + ROWDOT_LANES - 1) / ROWDOT_LANES), dim3(sk->W * 64), 0, s, a);
   if (wa && ctl) hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
   // (SLM_FLAG_PROFILE brackets the kernel that streams X, the one the roofline is quoted on)
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
@@ -902,7 +901,7 @@ static int check_launch() {
 // magnitude (it measures curvature along its own steps) and FISTA's curvature guard repairs an
 // under-estimate, so a handful of passes is enough; slm_dataset_lipschitz() asks for more.
 static const int kPowerItersSolve = 2;
-static const int kPowerItersSketch = 4;  // on an eighth of the rows (working-set solves)
+static const int kPowerItersSketch = 3;  // on a sixteenth of the rows (working-set solves)
 static const int kPowerItersQuery = 16;
 
 // n_rows > 0: the operator of the first n_rows rows only, X_S^T W X_S / (n_eff n_rows / n).  Its largest
@@ -1048,10 +1047,9 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
       HIP_TRY(hipEventRecord(e0, s));
       for (int r = 0; r < reps; ++r) {
         if (!xtr_only) {
-          for (int l0 = 0; l0 < B; l0 += ROWDOT_LANES) {
-            a.lane0 = l0;
-            hipLaunchKernelGGL(ds->sk->rowdot, dim3(ds->split_nblk), dim3(ds->sk->W * 64), 0, s, a);
-          }
+          a.lane0 = 0;
+          hipLaunchKernelGGL(ds->sk->rowdot, dim3(ds->split_nblk, (B + ROWDOT_LANES - 1) / ROWDOT_LANES),
+                             dim3(ds->sk->W * 64), 0, s, a);
         }
         (void)launch_xtr(ds->eng->cus, a, s);
       }
@@ -1369,7 +1367,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     // of the rows, four power steps, costs a quarter of the two full passes
     const bool sketch = ws_policy(ds, o.flags) == 2 && n >= 65536 && !getenv("SLM_NO_L_SKETCH");
     if (sketch && !(ds->L_valid && !(o.flags & SLM_FLAG_FRESH_L) && !any_rw && !custom_scale)) {
-      SLM_TRY(power_iteration(ds, (any_rw || custom_scale) ? ls : default_lanes(ds, 1), L, kPowerItersSketch, n / 8));
+      SLM_TRY(power_iteration(ds, (any_rw || custom_scale) ? ls : default_lanes(ds, 1), L, kPowerItersSketch, n / 16));
       if (!(any_rw || custom_scale))
         for (int l = 1; l < B; ++l) L[l] = L[0];
       ran = true;
@@ -1387,6 +1385,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       lipschitz_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
 
+  tr[5] = t_mark();
   // ---- buffers -----------------------------------------------------------------------------------
   if (total_points > ds->cap_points) {
     dfree(ds->pts); dfree(ds->betas_out); dfree(ds->infos);
@@ -1825,8 +1824,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
   tr[4] = t_mark();
-  if (getenv("SLM_TRACE") && tr[4] > 15.0)
-    fprintf(stderr, "[slm] slow solve: setup %.2f sync %.2f prequeue %.2f loop %.2f end %.2f ms\n", tr[0], tr[1], tr[2], tr[3], tr[4]);
+  if (const char* trc = getenv("SLM_TRACE"))  // 1: slow solves only, 2: every solve (cumulative ms since entry)
+    if (tr[4] > 15.0 || trc[0] == '2')
+      fprintf(stderr, "[slm] solve: L+buffers %.3f setup %.3f sync %.3f prequeue %.3f loop %.3f end %.3f ms\n", tr[5], tr[0], tr[1], tr[2], tr[3], tr[4]);
   if (nonfinite) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
   return SLM_OK;
 }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
   static_assert(D * C < 64, "too many DMA loads in flight for vmcnt");
   if (a.done != nullptr && *a.done != 0) return;
   // lanes served here: live, not served by resid_ws_kernel, inside this launch's window of B lanes
-  const int lane0 = a.lane0;
+  const int lane0 = a.lane0 + (int)blockIdx.y * B;  // grid.y = windows of B lanes (one launch for all of them)
   const unsigned mask = ((split_live_mask(a) & ~split_ws_mask(a)) >> lane0) & ((1u << B) - 1u);
   if (mask == 0u) return;
 
