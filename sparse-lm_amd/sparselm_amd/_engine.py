@@ -145,6 +145,26 @@ class _Lane(C.Structure):
 
 
 MAX_LANES = 16
+
+# numpy views of the two per-point structs (no per-point Python objects on the way in or out)
+_INFO_DTYPE = np.dtype(
+    [("n_iter", "<i4"), ("status", "<i4"), ("resid", "<f8"), ("beta_norm", "<f8"), ("loss", "<f8"), ("L", "<f8"),
+     ("mode", "<i4"), ("rejects", "<i4")]
+)
+assert _INFO_DTYPE.itemsize == C.sizeof(_PointInfo) and C.sizeof(_PathPoint) == 32
+
+
+def _points_block(pts, gam):
+    """(K, 4) float64 rows (sa, sb, sd, extrap) == slm_path_point[K]"""
+    out = np.empty((pts.shape[0], 4))
+    out[:, :3] = pts
+    out[:, 3] = gam
+    return out
+
+
+def _as(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
 WS_COLUMNS = 512  # WS_KCAP of the engine: columns a working set / a sparse scoring call can hold
 
 _lib = None
@@ -551,7 +571,7 @@ class Dataset:
             pts = np.ascontiguousarray(spec["points"], dtype=np.float64).reshape(-1, 3)
             K = pts.shape[0]
             gam = path_extrapolation(pts) if extrapolate else np.zeros(K)
-            cpts = (_PathPoint * K)(*[_PathPoint(*row, g) for row, g in zip(pts, gam)])
+            cpts = _points_block(pts, gam)
 
             def vec(name, size):
                 v = spec.get(name)
@@ -563,17 +583,17 @@ class Dataset:
             rw = None if spec.get("row_weight") is None else _f64(spec["row_weight"], "row_weight", (self.n,))
             betas = np.empty((K, self.p))
             gn = np.empty((K, G)) if want_group_norms else None
-            infos = (_PointInfo * K)()
+            infos = np.zeros(K, dtype=_INFO_DTYPE)
             keep.append((cpts, a_, b_, d_, pen, b0, rw))
             clanes[l].pen = C.pointer(pen)
-            clanes[l].points = cpts
+            clanes[l].points = _as(cpts, _PathPoint)
             clanes[l].n_points = K
             clanes[l].beta0 = _ptr(b0)
             clanes[l].row_weight = _ptr(rw)
             clanes[l].n_eff = int(spec.get("n_eff") or 0)
             clanes[l].betas_out = _ptr(betas)
             clanes[l].group_norms_out = _ptr(gn)
-            clanes[l].infos = infos
+            clanes[l].infos = _as(infos, _PointInfo)
             outs.append((betas, gn, infos, K))
         opts = _SolveOpts(float(tol), int(max_iter), int(check_every), float(L), int(flags))
         stats = _SolveStats()
@@ -584,13 +604,13 @@ class Dataset:
                 PathResult(
                     betas=betas,
                     group_norms=gn,
-                    n_iter=np.array([i.n_iter for i in infos]),
-                    status=np.array([i.status for i in infos]),
-                    resid=np.array([i.resid for i in infos]),
-                    beta_norm=np.array([i.beta_norm for i in infos]),
-                    loss=np.array([i.loss for i in infos]),
-                    mode=np.array([i.mode for i in infos]),
-                    L=float(infos[K - 1].L),
+                    n_iter=infos["n_iter"].astype(np.int64),
+                    status=infos["status"].astype(np.int64),
+                    resid=infos["resid"].copy(),
+                    beta_norm=infos["beta_norm"].copy(),
+                    loss=infos["loss"].copy(),
+                    mode=infos["mode"].astype(np.int64),
+                    L=float(infos["L"][K - 1]),
                     grad_launches=int(stats.grad_launches),
                     grad_timed=int(stats.grad_timed),
                     grad_ms_total=float(stats.grad_ms_total),
@@ -640,7 +660,7 @@ class Dataset:
         # shared path: the engine splits it into `lanes` ranges and balances them by work stealing
         G = self.n_groups
         gam = path_extrapolation(pts) if extrapolate else np.zeros(K)
-        cpts = (_PathPoint * K)(*[_PathPoint(*row, g) for row, g in zip(pts, gam)])
+        cpts = _points_block(pts, gam)
         a_ = None if a is None else _f64(np.broadcast_to(a, (self.p,)), "a")
         b_ = None if b is None else _f64(np.broadcast_to(b, (G,)), "b")
         d_ = None if d is None else _f64(np.broadcast_to(d, (G,)), "d")
@@ -649,24 +669,24 @@ class Dataset:
         opts = _SolveOpts(float(tol), int(max_iter), int(check_every), float(L), int(flags))
         betas = np.empty((K, self.p))
         gn = np.empty((K, G)) if want_group_norms else None
-        infos = (_PointInfo * K)()
+        infos = np.zeros(K, dtype=_INFO_DTYPE)
         stats = _SolveStats()
         _check(
             self._lib.slm_solve_path_lanes(
-                self._h, C.byref(pen), cpts, K, lanes, C.byref(opts), _ptr(b0), _ptr(betas), _ptr(gn), infos,
-                C.byref(stats),
+                self._h, C.byref(pen), _as(cpts, _PathPoint), K, lanes, C.byref(opts), _ptr(b0), _ptr(betas), _ptr(gn),
+                _as(infos, _PointInfo), C.byref(stats),
             )
         )
         return PathResult(
             betas=betas,
             group_norms=gn,
-            n_iter=np.array([i.n_iter for i in infos]),
-            status=np.array([i.status for i in infos]),
-            resid=np.array([i.resid for i in infos]),
-            beta_norm=np.array([i.beta_norm for i in infos]),
-            loss=np.array([i.loss for i in infos]),
-            mode=np.array([i.mode for i in infos]),
-            L=float(infos[K - 1].L),
+            n_iter=infos["n_iter"].astype(np.int64),
+            status=infos["status"].astype(np.int64),
+            resid=infos["resid"].copy(),
+            beta_norm=infos["beta_norm"].copy(),
+            loss=infos["loss"].copy(),
+            mode=infos["mode"].astype(np.int64),
+            L=float(infos["L"][K - 1]),
             grad_launches=int(stats.grad_launches),
             grad_timed=int(stats.grad_timed),
             grad_ms_total=float(stats.grad_ms_total),
