@@ -1706,12 +1706,22 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   } graph_guard{gexec};
 
   tr[2] = t_mark();
+  // Working-set solves from the start verify one point per lane and pass, after the pass at zero: the
+  // queue is cut to end exactly there, and polls go pass by pass after it (a miss adds a pass or two).
+  // Without this a 5-pass path drags three queued no-op passes behind it (12 launches each).
+  int64_t expected = 0;
+  if (use_ws && !ws_late && !use_graph && o.check_every <= 0) {
+    int64_t most = 0;
+    for (int l = 0; l < B; ++l) most = std::max<int64_t>(most, shared_path && interleave ? (total_points - l + B - 1) / B : lanes[l].n_points);
+    expected = 1 + most;
+  }
   while (!done) {
     if (use_graph) {
       HIP_TRY(hipGraphLaunch(gexec[slot], s));
       enq += chunk;
     } else {
-      for (int i = 0; i < chunk; ++i) {
+      const int this_chunk = expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(chunk, expected - enq) : 1);
+      for (int i = 0; i < this_chunk; ++i) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && enq % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time
           const int64_t slot_id = enq / kProfStride;

@@ -16,8 +16,9 @@ amax = float(np.max(np.abs(g0)))
 pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-3 * amax, 50)]
 for _ in range(2):
     ds.solve_path(pts, lanes=16, flags=_engine.FLAG_FRESH_L)
-for _ in range(4):
+for rep in range(8):
+    ce = 0 if rep % 2 == 0 else 2  # check_every=2: fixed chunks of two passes (the schedule before the expected-pass cut)
     t = time.perf_counter()
-    r = ds.solve_path(pts, lanes=16, flags=_engine.FLAG_FRESH_L)
+    r = ds.solve_path(pts, lanes=16, flags=_engine.FLAG_FRESH_L, check_every=ce)
     dt = (time.perf_counter() - t) * 1e3
-    print(f"python wall {dt:.3f} ms   C wall {r.wall_ms:.3f} ms   lipschitz {r.lipschitz_ms:.3f} ms  passes {r.grad_launches}", flush=True)
+    print(f"check_every={ce} python wall {dt:.3f} ms   C wall {r.wall_ms:.3f} ms   lipschitz {r.lipschitz_ms:.3f} ms  passes {r.grad_launches}", flush=True)
