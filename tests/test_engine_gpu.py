@@ -483,10 +483,12 @@ def test_rccl_path_with_one_rank(golden):
         eng2.close()
 
 
-# ---- split pass (residuals, then X^T r for eight lane slots) -------------------------------------------
-@pytest.mark.parametrize("n,p", [(1, 1), (25, 30), (257, 129), (1000, 1000), (333, 1537), (700, 5000), (513, 5120)])
+# ---- split pass (residuals, then X^T R for sixteen lane slots on the matrix cores) ----------------------
+@pytest.mark.parametrize("n,p", [(1, 1), (7, 40), (25, 30), (257, 129), (1000, 1000), (333, 1537), (4099, 48),
+                                 (20011, 600), (700, 5000), (513, 5120)])
 def test_split_gradient_matches_numpy(eng, n, p, monkeypatch):
-    # SLM_GRAD_SPLIT=1 routes slm_gradient through rowdot_ring_kernel + xtr_ring_kernel
+    # SLM_GRAD_SPLIT=1 routes slm_gradient through rowdot_ring_kernel + xtr_mfma_kernel (row blocks with
+    # fewer than 8 rows, a last block cut short, rows that end inside a 32-column chunk)
     monkeypatch.setenv("SLM_GRAD_SPLIT", "1")
     rng = np.random.default_rng(n * 31 + p)
     X = rng.standard_normal((n, p))

@@ -33,7 +33,7 @@ for case in range(n_cases):
     elif kind == "group": pts = [(0, al, 0) for al in alphas]
     elif kind == "sgl": pts = [(0.4 * al, 0.6 * al, 0) for al in alphas]
     else: pts = [(0, al, 0.3) for al in alphas]
-    lanes = int(rng.integers(1, 11))
+    lanes = int(rng.integers(1, 17))
     tol = 1e-10
     with eng.dataset(X, y) as ds:
         if groups is not None: ds.set_groups(groups, G)
@@ -42,7 +42,7 @@ for case in range(n_cases):
             r0 = ds.solve_path(pts, a=a, b=b, tol=tol, max_iter=300000, lanes=1, flags=PLAIN)
             B1, B0, ok = r1.betas, r0.betas, r1.converged and r0.converged
         else:  # independent lanes with fold masks
-            nl = min(lanes, 6)
+            nl = min(lanes, 12)
             fold = rng.integers(0, max(2, nl), n)
             specs = [dict(points=pts, a=a, b=b, row_weight=(fold != f).astype(float), n_eff=int(np.sum(fold != f))) for f in range(nl)]
             R1 = ds.solve_lanes(specs, tol=tol, max_iter=300000, flags=WS)
