@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE config 3 alone (GroupLasso 500x10, 50-alpha path, 8 lanes) for profiling."""
+"""BASELINE config 3 alone (GroupLasso 500x10, 50-alpha path, 16 lanes) for profiling and knob sweeps."""
 import os, sys, time, json
 import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -25,9 +25,9 @@ if len(sys.argv) > 1:
 for combo in itertools.product(*grid.values()):
     for k, v in zip(grid.keys(), combo):
         os.environ[k] = v
-    ds.solve_path(pts, lanes=8)
+    ds.solve_path(pts, lanes=16)
     t0 = time.perf_counter()
     for _ in range(3):
-        res = ds.solve_path(pts, lanes=8, flags=_engine.FLAG_FRESH_L)
+        res = ds.solve_path(pts, lanes=16, flags=_engine.FLAG_FRESH_L)
     dt = (time.perf_counter() - t0) / 3
     print(json.dumps({"knobs": combo, "ms_per_path": round(1e3 * dt, 2), "passes": res.grad_launches, "ws": [res.ws_builds, res.ws_appends, res.ws_refined, res.ws_misses, res.ws_columns], "max_iter": int(max(res.n_iter))}), flush=True)
