@@ -813,6 +813,25 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
 // The same for working-set solves through the split pass: residuals (from the gathered columns where a
 // lane's point is supported on W, from X otherwise), then X^T r for all eight lane slots on one read
 // of X.  ctl == nullptr: every lane takes its residual from X (slm_gradient with SLM_GRAD_SPLIT=1).
+// Residuals from X for the lanes the working set does not serve: all sixteen lane slots in one read of
+// the column-major copy on the matrix cores when that copy exists (working-set solves make it), otherwise
+// the vector kernel, five lanes per read of X (one window per grid row; a window returns at once unless
+// one of its lanes needs X) -- also the choice for calls of up to five lanes.  SLM_ROWDOT_RING=1/0 forces one.
+static void launch_rowdot(slm_dataset* ds, const SplitKernel* sk, int nblk, int B, SplitArgs& a, hipStream_t s) {
+  // Measured at n = 100k, p = 5k (tools/rowdot_probe.py): matrix cores 0.75-0.80 ms whatever the lane count;
+  // vector kernel 0.62 ms for one lane, 0.81 ms for five, 3.1 ms for sixteen (four reads of X).
+  const char* env = getenv("SLM_ROWDOT_RING");
+  const bool ring = env ? env[0] == '1' : B <= ROWDOT_LANES;
+  a.lane0 = 0;
+  if (!ring && ds->XT && ds->XT_ready) {
+    a.XT = ds->XT;
+    a.ldt = ds->ldt;
+    hipLaunchKernelGGL(rowdot_mfma_kernel, dim3(nblk), dim3(XZ_WAVES * 64), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(sk->rowdot, dim3(nblk, (B + ROWDOT_LANES - 1) / ROWDOT_LANES), dim3(sk->W * 64), 0, s, a);
+  }
+}
+
 static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done,
                                   const PathCtl* ctl, const WsArgs* wa, hipEvent_t ev_start,
                                   hipEvent_t ev_stop, int64_t n_rows = 0) {
@@ -832,9 +851,7 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
   a.n = nr; a.ld = ds->ld; a.rows_base = nr / nblk; a.rows_rem = nr % nblk;
   a.p2 = (int)(ds->ld / 2);
   a.n_lanes = ls.B;
-  // (one window of ROWDOT_LANES lanes per grid row; a window returns at once unless one of its lanes needs X)
-  a.lane0 = 0;
-  hipLaunchKernelGGL(sk->rowdot, dim3(nblk, (ls.B + ROWDOT_LANES - 1) / ROWDOT_LANES), dim3(sk->W * 64), 0, s, a);
+  launch_rowdot(ds, sk, nblk, ls.B, a, s);
   if (wa && ctl) hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
   // (SLM_FLAG_PROFILE brackets the kernel that streams X, the one the roofline is quoted on)
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
@@ -1007,6 +1024,8 @@ extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y
 // ------------------------------------------------------------------------------------------------
 // single gradient evaluation (tests, alpha_max, roofline probe)
 // ------------------------------------------------------------------------------------------------
+static int ensure_xt(slm_dataset* ds);
+
 extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, double* loss_out,
                             int32_t reps, double* ms_out) {
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
@@ -1017,6 +1036,7 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
   if (z) HIP_TRY(hipMemcpyAsync(ds->z, z, sizeof(double) * ds->p, hipMemcpyHostToDevice, s));
   const char* split_env = getenv("SLM_GRAD_SPLIT");  // tests: take the split pass (residuals from X)
   const bool use_split = split_env && split_env[0] == '1' && ds->sk != nullptr;
+  if (use_split) SLM_TRY(ensure_xt(ds));  // (so that tests and probes reach rowdot_mfma_kernel; optional copy)
   if (use_split) SLM_TRY(enqueue_gradient_split(ds, ls, ds->y, nullptr, nullptr, nullptr, nullptr, nullptr));
   else SLM_TRY(enqueue_gradient(ds, ls, ds->y, nullptr, nullptr, nullptr));
   SLM_TRY(check_launch());
@@ -1047,9 +1067,7 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
       HIP_TRY(hipEventRecord(e0, s));
       for (int r = 0; r < reps; ++r) {
         if (!xtr_only) {
-          a.lane0 = 0;
-          hipLaunchKernelGGL(ds->sk->rowdot, dim3(ds->split_nblk, (B + ROWDOT_LANES - 1) / ROWDOT_LANES),
-                             dim3(ds->sk->W * 64), 0, s, a);
+          launch_rowdot(ds, ds->sk, ds->split_nblk, B, a, s);
         }
         (void)launch_xtr(ds->eng->cus, a, s);
       }

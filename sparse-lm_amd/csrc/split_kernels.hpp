@@ -49,6 +49,8 @@ struct SplitArgs {
   int n_lanes;
   int lane0;  // rowdot_ring_kernel: first lane of this launch
   int xrows;  // xtr_mfma_kernel: rows per workgroup row (multiple of 8); partial is then [gridDim.y][SPLIT_LANES][ld]
+  const double* XT;  // rowdot_mfma_kernel: column-major copy of X, [ld][ldt]
+  int64_t ldt;
 };
 
 // which lanes take their residual from XW: live, flagged by ws_solve_kernel, and W still published
@@ -403,6 +405,158 @@ __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a
           const int col = col0 + 32 * c + 2 * (kq + 4 * r) + e;
           if (col < ld) out[col] = acc[2 * c + e][r];
         }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The first half on the matrix cores as well: R[row][l] = w_l,row (x_row . z_l - y_row) for ALL sixteen lane
+// slots in one read of X (rowdot_ring_kernel serves five per read).  The contraction runs over columns,
+// which MFMA spreads over the four lane groups of a wavefront, so the operand that is contiguous along
+// ROWS is needed: the column-major copy XT the working set keeps for its gathers.  D[i][j] += sum_k
+// A[i][k] B[k][j] with i = lane slot, j = row, k = column: lane l = (j = l & 15, q = l >> 4) loads
+// z[l & 15][c0 + 4q .. 4q + 3] once per 16 columns (32 bytes, rows of z are contiguous) and, for step
+// m = 0..3, XT[c0 + 4q + m][rows 2j, 2j + 1] (16 bytes: 4 columns x 256 contiguous bytes per
+// instruction); the two doubles feed two MFMAs (even / odd rows of a 32-row tile).  A wavefront carries
+// XZ_T tiles at once so they share the loads of z; 8 wavefronts cover 512 rows per round of the
+// workgroup's row block (the same blocks as resid_ws_kernel: both write loss_partial[block][lane]).
+// Two 16-column batches in flight per wavefront (register double buffering).
+// ---------------------------------------------------------------------------------------------
+constexpr int XZ_WAVES = 8;
+constexpr int XZ_T = 2;
+
+__global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a) {
+  static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 rows of the MFMA A operand");
+  if (a.done != nullptr && *a.done != 0) return;
+  const unsigned mask = split_live_mask(a) & ~split_ws_mask(a);
+  if (mask == 0u) return;
+  __shared__ double red[XZ_WAVES][SPLIT_LANES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t b = blockIdx.x;
+  const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
+  const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
+
+  bool all_zero = a.ctl != nullptr;  // cold start: e = -y without reading X (as rowdot_ring_kernel)
+  if (all_zero) {
+    for (int l = 0; l < a.n_lanes; ++l)
+      if (((mask >> l) & 1u) && !a.ctl[l].zzero) all_zero = false;
+  }
+  if (all_zero) {
+    double ls[SPLIT_LANES];
+#pragma unroll
+    for (int l = 0; l < SPLIT_LANES; ++l) ls[l] = 0.0;
+    for (int64_t i = tid; i < nrows; i += XZ_WAVES * 64) {
+      const int64_t row = r0 + i;
+      const double e = -a.y[row];
+#pragma unroll
+      for (int l = 0; l < SPLIT_LANES; ++l) {
+        if ((mask >> l) & 1u) {
+          const double m = a.rw ? a.rw[(int64_t)l * a.rw_stride + row] : 1.0;
+          a.R[row * SPLIT_RSTRIDE + l] = e * m;
+          ls[l] = __builtin_fma(e * m, e, ls[l]);
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < SPLIT_LANES; ++l) {
+      double t = ls[l];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+      if (lane == 0) red[wave][l] = t;
+    }
+    __syncthreads();
+    if (tid < SPLIT_LANES && ((mask >> tid) & 1u)) {
+      double t = 0.0;
+      for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2][tid];
+      a.loss_partial[b * SPLIT_LANES + tid] = t;
+    }
+    return;
+  }
+
+  const int j = lane & 15, q = lane >> 4;
+  const int64_t rbase = r0 & ~(int64_t)1;  // even: the 16-byte loads of XT stay aligned
+  const int64_t rend = r0 + nrows;
+  const int ntiles = (int)((rend - rbase + 31) >> 5);
+  const int ngroups = (int)(a.ld >> 4);
+  const double* zp = a.z + (int64_t)(j < a.n_lanes ? j : a.n_lanes - 1) * a.ld + 4 * q;
+  double loss[4] = {0.0, 0.0, 0.0, 0.0};  // of lane slots q, q + 4, q + 8, q + 12 over this lane's rows
+  for (int t0 = wave * XZ_T; t0 < ntiles; t0 += XZ_WAVES * XZ_T) {
+    const int nt = __builtin_amdgcn_readfirstlane(ntiles - t0 < XZ_T ? ntiles - t0 : XZ_T);
+    const double* xp[XZ_T];
+#pragma unroll
+    for (int t = 0; t < XZ_T; ++t) {
+      int64_t rp = rbase + 32 * (int64_t)(t0 + t) + 2 * j;
+      if (rp > a.ldt - 2) rp = a.ldt - 2;  // (rows past the block are computed and dropped)
+      xp[t] = a.XT + (int64_t)(4 * q) * a.ldt + rp;
+    }
+    slm_d4 acc[XZ_T][2];
+#pragma unroll
+    for (int t = 0; t < XZ_T; ++t) acc[t][0] = acc[t][1] = slm_d4{0.0, 0.0, 0.0, 0.0};
+    slm_d4 za, zb;
+    d2 xa[4][XZ_T], xb[4][XZ_T];
+    auto load = [&](slm_d4& zv, d2(&xv)[4][XZ_T], int g) {
+      zv = *reinterpret_cast<const slm_d4*>(zp + 16 * g);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int t = 0; t < XZ_T; ++t)
+          if (t < nt) {
+            const d2* src = reinterpret_cast<const d2*>(xp[t] + (int64_t)(16 * g + m) * a.ldt);
+            xv[m][t] = SLM_NT_LOADS ? __builtin_nontemporal_load(src) : *src;
+          }
+    };
+    auto compute = [&](const slm_d4& zv, d2(&xv)[4][XZ_T]) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int t = 0; t < XZ_T; ++t)
+          if (t < nt) {
+            acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[m], xv[m][t].x, acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[m], xv[m][t].y, acc[t][1], 0, 0, 0);
+          }
+    };
+    load(za, xa, 0);
+    for (int g = 0; g < ngroups; g += 2) {
+      if (g + 1 < ngroups) load(zb, xb, g + 1);
+      compute(za, xa);
+      if (g + 2 < ngroups) load(za, xa, g + 2);
+      if (g + 1 < ngroups) compute(zb, xb);
+    }
+    // result register r of lane l: lane slot (l >> 4) + 4 r, row 2 (l & 15) + e of the tile
+#pragma unroll
+    for (int t = 0; t < XZ_T; ++t) {
+      if (t >= nt) continue;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int64_t row = rbase + 32 * (int64_t)(t0 + t) + 2 * j + e;
+        if (row < r0 || row >= rend) continue;
+        const double yi = a.y[row];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int l = q + 4 * r;
+          if ((mask >> l) & 1u) {
+            const double m = a.rw ? a.rw[(int64_t)l * a.rw_stride + row] : 1.0;
+            const double err = acc[t][e][r] - yi;
+            const double res = err * m;
+            a.R[row * SPLIT_RSTRIDE + l] = res;
+            loss[r] = __builtin_fma(res, err, loss[r]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double t = loss[r];
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (j == 0) red[wave][q + 4 * r] = t;
+  }
+  __syncthreads();
+  if (tid < SPLIT_LANES && ((mask >> tid) & 1u)) {
+    double t = 0.0;
+    for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2][tid];
+    a.loss_partial[b * SPLIT_LANES + tid] = t;
   }
 }
 

@@ -486,10 +486,13 @@ def test_rccl_path_with_one_rank(golden):
 # ---- split pass (residuals, then X^T R for sixteen lane slots on the matrix cores) ----------------------
 @pytest.mark.parametrize("n,p", [(1, 1), (7, 40), (25, 30), (257, 129), (1000, 1000), (333, 1537), (4099, 48),
                                  (20011, 600), (700, 5000), (513, 5120)])
-def test_split_gradient_matches_numpy(eng, n, p, monkeypatch):
-    # SLM_GRAD_SPLIT=1 routes slm_gradient through rowdot_ring_kernel + xtr_mfma_kernel (row blocks with
-    # fewer than 8 rows, a last block cut short, rows that end inside a 32-column chunk)
+@pytest.mark.parametrize("rowdot", ["mfma", "ring"])
+def test_split_gradient_matches_numpy(eng, n, p, rowdot, monkeypatch):
+    # SLM_GRAD_SPLIT=1 routes slm_gradient through rowdot_mfma_kernel (or, SLM_ROWDOT_RING=1,
+    # rowdot_ring_kernel) + xtr_mfma_kernel (row blocks with fewer than 8 rows, a last block cut short, rows
+    # that end inside a 32-column chunk, row blocks that start on an odd row)
     monkeypatch.setenv("SLM_GRAD_SPLIT", "1")
+    monkeypatch.setenv("SLM_ROWDOT_RING", "1" if rowdot == "ring" else "0")
     rng = np.random.default_rng(n * 31 + p)
     X = rng.standard_normal((n, p))
     y = rng.standard_normal(n)
