@@ -211,7 +211,8 @@ def main():
         assert res is not None and res.converged, "path did not converge"
         # algorithmic bytes of one launch: X once, y once, per lane z read and g written
         # p = 5000: the fused kernels stop at four lanes; the split pass of working-set solves has sixteen
-        split = not args.no_ws and res.ws_builds > 0
+        # (and plain solves of more than four lanes on large X: the same two matrix-core halves)
+        split = (not args.no_ws and res.ws_builds > 0) or (min(args.lanes, K) > 4 and n * p >= 2**26 and p <= 5120)
         lanes_used = max(1, min(args.lanes, 16 if split else 4))
         if split:  # xtr_mfma_kernel: X once, the row residuals of 16 lane slots, 16 gradient rows out
             bytes_per_grad = 8.0 * (n * p + 16 * n + 16 * p)

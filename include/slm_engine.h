@@ -225,8 +225,9 @@ int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point
  * cross-validation, or both.  n_lanes <= SLM_MAX_LANES; SLM_ERR_UNSUPPORTED if no kernel variant
  * covers (p, n_lanes) -- callers then fall back to fewer lanes.  How many lanes a pass can serve:
  * the fused kernels go up to 4 at p = 5000 (6 up to 3072 columns: z and the accumulators of every
- * lane live in registers); working-set solves on rows of up to 5120 columns use the split pass, whose
- * accumulate-only stream over X serves SLM_MAX_LANES.
+ * lane live in registers); on rows of up to 5120 columns working-set solves, and any solve on a large X
+ * (n * ld >= 2^26 doubles), use the split pass, whose two halves -- residuals, then X^T R -- run on the
+ * matrix cores for SLM_MAX_LANES lanes per read of X.  slm_dataset_max_lanes() tells.
  */
 #define SLM_MAX_LANES 16
 typedef struct slm_lane {

@@ -1283,7 +1283,7 @@ static int ws_policy(const slm_dataset* ds, uint32_t flags) {
 // most lanes one solve can run: the fused kernels' table, or the split pass's sixteen when the working
 // set is on from the start
 static int max_lanes_for(const slm_dataset* ds, uint32_t flags) {
-  if (ws_policy(ds, flags) == 2 && ds->sk) return SPLIT_LANES;
+  if (ds->sk && (ws_policy(ds, flags) == 2 || (double)ds->n * (double)ds->ld >= 67108864.0)) return SPLIT_LANES;
   int B = kMaxLanes;
   while (B > 1 && !ds->gk[B - 1]) --B;
   return B;
@@ -1297,8 +1297,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   const int B = n_lanes;
   // the split pass costs four launches where the fused kernel costs one: take it when X is large (the
   // accumulate-only stream is then all that matters) or when only it has enough lanes
-  const bool split = ws_policy(ds, opts ? opts->flags : 0u) == 2 && ds->sk != nullptr &&
-                     ((double)ds->n * (double)ds->ld >= 67108864.0 || !ds->gk[B - 1]);
+  // -- the latter also without the working set when X is large: sixteen lanes on the two matrix-core halves
+  // (two reads of X per pass) move more problems per byte than four on the fused kernel (one read)
+  const bool big_x = (double)ds->n * (double)ds->ld >= 67108864.0;
+  const bool split = ds->sk != nullptr && (ws_policy(ds, opts ? opts->flags : 0u) == 2 ? (big_x || !ds->gk[B - 1])
+                                                                                      : (big_x && !ds->gk[B - 1]));
   // Shared path with the working set on from the start: the lanes take the points of the path in turn
   // (lane l: l, l + B, ...) instead of contiguous ranges.  Every lane then starts near alpha_max, where
   // the first working set (chosen from the gradient at zero) is enough, and all lanes move down the
@@ -1311,6 +1314,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
                           !getenv("SLM_NO_INTERLEAVE");
   if (!split && !ds->gk[B - 1])
     return fail(SLM_ERR_UNSUPPORTED, "no %d-lane gradient kernel covers p = %lld", B, (long long)ds->p);
+  if (split && B > ROWDOT_LANES) SLM_TRY(ensure_xt(ds));  // rowdot_mfma_kernel reads the column-major copy (optional)
   int64_t total_points = 0;
   bool any_rw = false, any_gn = false;
   for (int l = 0; l < B; ++l) {

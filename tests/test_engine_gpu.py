@@ -535,3 +535,30 @@ def test_sparse_hold_out_scoring_matches_dense_and_numpy(eng):
         # a solve afterwards still works (the scratch is shared with the working set)
         r = ds.solve_path([(0.1, 0, 0)], tol=1e-10, flags=_engine.FLAG_WORKING_SET)
         assert r.converged
+
+
+def test_sixteen_lane_plain_iteration_on_large_x(eng):
+    # without the working set, more lanes than the fused kernels serve run on the two matrix-core halves of
+    # the split pass when X is large (n * ld >= 2^26 doubles): same answers as one lane on the fused kernel
+    n, p = 20000, 3400
+    rng = np.random.default_rng(3)
+    coef = np.zeros(p)
+    coef[rng.choice(p, 30, replace=False)] = 10.0 * rng.standard_normal(30)
+    with eng.synthetic_dataset(n, p, seed=5, coef=coef, noise_sd=1.0) as ds:
+        assert ds.max_lanes(PLAIN) == _engine.MAX_LANES
+        g0, _ = ds.gradient(None)
+        amax = float(np.max(np.abs(g0)))
+        pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 0.02 * amax, 24)]
+        one = ds.solve_path(pts, tol=1e-10, flags=PLAIN)
+        many = ds.solve_path(pts, tol=1e-10, flags=PLAIN, lanes=16)
+        assert one.converged and many.converged
+        assert many.ws_builds == 0 and many.grad_launches < one.grad_launches / 6
+        assert rel_inf(many.betas, one.betas) < 1e-7
+        # independent lanes with their own masks, warm starts included
+        fold = rng.integers(0, 3, n)
+        specs = [dict(points=pts[4:10], row_weight=(fold != f % 3).astype(float), n_eff=int(np.sum(fold != f % 3)),
+                      beta0=one.betas[3] if f % 2 else None) for f in range(9)]
+        got = ds.solve_lanes(specs, tol=1e-10, flags=PLAIN)
+        for f in (0, 1, 5):
+            ref = ds.solve_lanes([specs[f]], tol=1e-10, flags=PLAIN)[0]
+            assert rel_inf(got[f].betas, ref.betas) < 1e-7
