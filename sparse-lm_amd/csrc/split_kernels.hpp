@@ -417,12 +417,14 @@ __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a
 // z[l & 15][c0 + 4q .. 4q + 3] once per 16 columns (32 bytes, rows of z are contiguous) and, for step
 // m = 0..3, XT[c0 + 4q + m][rows 2j, 2j + 1] (16 bytes: 4 columns x 256 contiguous bytes per
 // instruction); the two doubles feed two MFMAs (even / odd rows of a 32-row tile).  A wavefront carries
-// XZ_T tiles at once so they share the loads of z; 8 wavefronts cover 512 rows per round of the
-// workgroup's row block (the same blocks as resid_ws_kernel: both write loss_partial[block][lane]).
-// Two 16-column batches in flight per wavefront (register double buffering).
+// XZ_T adjacent tiles at once so they share the loads of z (128 rows = 1 KiB contiguous per column); 4
+// wavefronts cover 512 rows per round of the workgroup's row block (the same blocks as resid_ws_kernel:
+// both write loss_partial[block][lane]).  Two 16-column batches in flight per wavefront (register double
+// buffering, 256 VGPRs).  Measured at n = 100k, p = 5k: 0.74 ms (8 wavefronts x 2 tiles: 0.80 ms; tiles
+// dealt round-robin instead of adjacent: 0.84 ms).
 // ---------------------------------------------------------------------------------------------
-constexpr int XZ_WAVES = 8;
-constexpr int XZ_T = 2;
+constexpr int XZ_WAVES = 4;
+constexpr int XZ_T = 4;
 
 __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 rows of the MFMA A operand");
