@@ -162,13 +162,16 @@ __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
 
   const double inf = __builtin_huge_val();
   int n_new = 0, n_miss = 0;
-  const int it = blockIdx.x * blockDim.x + tid;  // (64-thread workgroups for groups: more CUs on few, heavier items)
-  if (it < nitems) {
-    double sc = 0.0;
-    bool in_w = false;
-    if (singleton) {
+  // features: one thread each.  Groups: SIXTEEN threads each, one per lane (a thread then walks the members
+  // of its group for one lane: 10 x 4 scattered loads instead of 16 x 10 x 4; the lanes' scores meet in a
+  // max over the 16 threads) -- 64-thread workgroups, four groups each.
+  const int gt = blockIdx.x * blockDim.x + tid;
+  const int it = singleton ? gt : gt >> 4;
+  if (singleton) {
+    if (it < nitems) {
+      double sc = 0.0;
       const int j = it;
-      in_w = had_w && w.pos[j] >= 0;
+      const bool in_w = had_w && w.pos[j] >= 0;
 #pragma unroll
       for (int l = 0; l < SLM_MAX_LANES; ++l) {
         if (l >= a.n_lanes || !lane_live[l]) continue;
@@ -184,11 +187,20 @@ __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
         }
       }
       if (sc >= w.theta && !in_w) n_new += 1;
-    } else {
-      const int k0 = a.gstart[it], k1 = a.gstart[it + 1];
+      w.score[it] = sc;
+    }
+  } else {
+    static_assert(SLM_MAX_LANES == 16, "one thread per (group, lane): 16-thread teams");
+    const int l = tid & 15;
+    const bool have = it < nitems;  // (a team is all in or all out)
+    double sc = 0.0;
+    bool in_w = false;
+    int k0 = 0, k1 = 0;
+    if (have) {
+      k0 = a.gstart[it];
+      k1 = a.gstart[it + 1];
       in_w = had_w && w.pos[a.order[k0]] >= 0;
-      for (int l = 0; l < a.n_lanes; ++l) {
-        if (!lane_live[l]) continue;
+      if (l < a.n_lanes && lane_live[l]) {
         const int64_t off = (int64_t)l * a.ld;
         const double* g = a.g + (int64_t)l * (a.ld + 16);
         double num = 0.0, rmax = 0.0;
@@ -205,11 +217,15 @@ __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
         }
         const double den = lane_sb[l] * a.b0[off + it];
         const double r = den > 0.0 ? sqrt(num) / den : rmax;
-        sc = act ? inf : fmax(sc, r);
+        sc = act ? inf : r;
       }
-      if (sc >= w.theta && !in_w) n_new += k1 - k0;
     }
-    w.score[it] = sc;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) sc = fmax(sc, __shfl_xor(sc, o, 64));
+    if (have && l == 0) {
+      if (sc >= w.theta && !in_w) n_new += k1 - k0;
+      w.score[it] = sc;
+    }
   }
   // integer counts: the order of the atomic additions does not matter
   if (n_new) atomicAdd(&cnt[0], n_new);
@@ -740,9 +756,9 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
 #pragma unroll 4
         for (int c = q; c < K; c += TPC) acc = __builtin_fma(Gl[c * K + k], delta[c], acc);
       }
-    } else if (dense) {
+    } else if (dense) {  // (Gram through L2: sixteen independent loads in flight per thread, not four)
       if (k < K) {
-#pragma unroll 4
+#pragma unroll 16
         for (int c = q; c < K; c += TPC) acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
       }
     } else {
@@ -760,7 +776,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
       __syncthreads();
       const int nnz = nnz_s;
       if (k < K) {
-#pragma unroll 4
+#pragma unroll 16
         for (int m = q; m < nnz; m += TPC) {
           const int c = nz[m];
           acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
