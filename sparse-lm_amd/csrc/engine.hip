@@ -1851,6 +1851,10 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       stats->ws_refined = wc.refined;
       stats->ws_misses = wc.misses;
       stats->ws_columns = wc.Kreal;
+      if (const char* trc = getenv("SLM_TRACE"))
+        if (trc[0] == '2')
+          fprintf(stderr, "[slm] working set: %d model-solver iterations over %d refinements, K = %d\n", wc.inner_iters,
+                  wc.refined, wc.K);
     }
     stats->wall_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

@@ -57,6 +57,7 @@ struct WsCtl {
   int32_t sweep_miss; // ... and coordinates a plain step moved outside W (both reset by ws_select_kernel)
   int32_t staged;     // row-sharded mode: the local Gram parts sit in the staging matrix, waiting for the
                       // all-reduce and ws_publish_kernel
+  int32_t inner_iters;  // model-solver iterations of all refinements (diagnostics: SLM_TRACE=2)
   int32_t last_point[SLM_MAX_LANES];  // path point of each lane's last refinement ...
   int32_t repeats[SLM_MAX_LANES];     // ... and how many times in a row it was that point
   double Lw[SLM_MAX_LANES];  // lambda_max estimate per Gram (0 = not yet computed)
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(256) void ws_publish_kernel(WsArgs w) {
 
 // ---------------------------------------------------------------------------------------------
 // (iv) refinement: one workgroup per lane minimises the penalised quadratic model over W.
-// Threads TPC k + q work on working-set position k (q splits the matrix-vector product; TPC = 4, or 2
+// Threads q KP + k work on working-set position k (q splits the matrix-vector product; TPC = 4 parts, or 2
 // beyond 256 positions).  Up to
 // WS_KLDS columns the Gram is copied into LDS first, so an inner iteration never leaves the CU.
 // ---------------------------------------------------------------------------------------------
@@ -684,6 +685,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   __shared__ double uim[WS_KCAP];
   __shared__ int nz[WS_KCAP];
   __shared__ int nnz_s;
+  __shared__ double part[WS_THREADS];
   __shared__ double Gl[WS_KLDS * WS_KLDS];
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
@@ -728,9 +730,15 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   }
 
   // 4 threads per position up to 256 positions, 2 beyond (1024 threads, WS_KCAP = 512)
+  // Thread q KP + k works on position k, KP = WS_THREADS / TPC: the lanes of a wavefront hold CONSECUTIVE
+  // positions and one q, so a Gram row segment is one coalesced 512-byte load.  (With the TPC threads of a
+  // position next to each other the lanes alternated between TPC rows 4 KiB apart and every lane became
+  // its own memory request: 28 us per product at K = 272, in-kernel clock marks.)
   const int tsh = K <= 256 ? 2 : 1;
   const int TPC = 1 << tsh;
-  const int k = tid >> tsh, q = tid & (TPC - 1);
+  const int KP = WS_THREADS >> tsh;
+  const int k = tid & (KP - 1), q = tid >> (10 - tsh);
+  static_assert(WS_THREADS == 1024, "q = tid >> (10 - tsh)");
   const int j = k < K ? w.idx[k] : -1;
   const bool live = j >= 0;
   const bool mine = live && q == 0;  // the thread that accounts for position k in reductions
@@ -756,10 +764,20 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
 #pragma unroll 4
         for (int c = q; c < K; c += TPC) acc = __builtin_fma(Gl[c * K + k], delta[c], acc);
       }
-    } else if (dense) {  // (Gram through L2: sixteen independent loads in flight per thread, not four)
+    } else if (dense) {
+      // Gram through L2 (K > WS_KLDS): the loads of a batch are issued together, then consumed in the same
+      // order as before (one FMA chain).  Left to the compiler the loop ran one load at a time: 28 us per
+      // product at K = 272 (in-kernel clock marks), i.e. 0.3 ms of power iteration per selection.
       if (k < K) {
-#pragma unroll 16
-        for (int c = q; c < K; c += TPC) acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
+        int c = q;
+        for (; c + 15 * TPC < K; c += 16 * TPC) {
+          double gv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) gv[u] = Gm[(c + u * TPC) * WS_KCAP + k];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = __builtin_fma(gv[u], delta[c + u * TPC], acc);
+        }
+        for (; c < K; c += TPC) acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
       }
     } else {
       if (tid < 64) {  // compact list of the non-zero entries (wave 0, ballots)
@@ -776,16 +794,29 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
       __syncthreads();
       const int nnz = nnz_s;
       if (k < K) {
-#pragma unroll 16
-        for (int m = q; m < nnz; m += TPC) {
+        int m = q;
+        for (; m + 15 * TPC < nnz; m += 16 * TPC) {
+          int cc[16];
+          double gv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) cc[u] = nz[m + u * TPC];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) gv[u] = Gm[cc[u] * WS_KCAP + k];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = __builtin_fma(gv[u], delta[cc[u]], acc);
+        }
+        for (; m < nnz; m += TPC) {
           const int c = nz[m];
           acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
         }
       }
     }
-    acc += __shfl_xor(acc, 1, 64);
-    if (TPC == 4) acc += __shfl_xor(acc, 2, 64);
-    return acc;
+    // the TPC parts of a position sit in different wavefronts: fold them through LDS, in a fixed order
+    part[tid] = acc;
+    __syncthreads();
+    double tot = part[k];
+    for (int qq = 1; qq < TPC; ++qq) tot += part[qq * KP + k];
+    return tot;
   };
   // prox of the lane's penalty at the current path point, step s, on the W coordinates
   auto prox_w = [&](double v, double s) -> double {
@@ -862,7 +893,9 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     m_start = s[0] + s[1];
   }
   bool ok = true;
+  int n_inner = 0;
   for (int it = 0; it < WS_INNER_MAX; ++it) {
+    ++n_inner;
     const double gv = g0 + matvec(v, false);
     const double u = prox_w(v - gv / L, 1.0 / L);
     //  s[0] = ||u - v||^2  s[1] = ||u||^2  s[2] = (v - u).(u - x)  s[3] = #non-finite
@@ -934,6 +967,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     ws->repeats[lane_id] = reps + 1;
     if (L > ws->Lw[set]) ws->Lw[set] = L;
     atomicAdd(&ws->refined, 1);
+    atomicAdd(&ws->inner_iters, n_inner);
   }
 }
 
