@@ -852,7 +852,11 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
   a.p2 = (int)(ds->ld / 2);
   a.n_lanes = ls.B;
   launch_rowdot(ds, sk, nblk, ls.B, a, s);
-  if (wa && ctl) hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
+  if (wa && ctl) {  // residuals from the gathered columns: matrix cores (SLM_RESID_VEC=1: a row per thread)
+    const char* env = getenv("SLM_RESID_VEC");
+    if (env && env[0] == '1') hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(resid_mfma_kernel, dim3(nblk), dim3(RM_WAVES * 64), 0, s, a);
+  }
   // (SLM_FLAG_PROFILE brackets the kernel that streams X, the one the roofline is quoted on)
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
   const int xblk = launch_xtr(ds->eng->cus, a, s);

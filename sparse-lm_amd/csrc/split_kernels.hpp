@@ -7,8 +7,8 @@
 // skinny GEMM, run on the matrix cores, so SIXTEEN lanes share one read of X where the fused kernel tops
 // out at four, and its row loop has no dot product, no cross-wave exchange and no barrier at all.
 //
-//   resid_ws_kernel      R[i][l] = w_l,i (XW_i . zW_l - y_i)      lanes whose z is supported on W
-//   rowdot_ring_kernel   R[i][l] = w_l,i (x_i . z_l - y_i)        the others (reads X; returns at once
+//   resid_mfma_kernel    R[i][l] = w_l,i (XW_i . zW_l - y_i)      lanes whose z is supported on W
+//   rowdot_mfma_kernel   R[i][l] = w_l,i (x_i . z_l - y_i)        the others (reads X; returns at once
 //                                                                 when there are none)
 //   xtr_mfma_kernel      partial[blk][l][:] = sum_{i in blk} R[i][l] x_i     (reads X once)
 //
@@ -558,6 +558,95 @@ __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a)
   if (tid < SPLIT_LANES && ((mask >> tid) & 1u)) {
     double t = 0.0;
     for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2][tid];
+    a.loss_partial[b * SPLIT_LANES + tid] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The residuals from the gathered columns on the matrix cores: R[row][l] = w_l,row (XW_row . zW_l - y_row)
+// is the (n x K)(K x 16) product XW zW.  D[i][j] += sum_k A[i][k] B[k][j] with i = row, j = lane slot,
+// k = position in W: lane l = (i = l & 15, q = l >> 4) loads XW[row_i][16 g + 4 q .. 4 q + 3] (32 bytes: a
+// load instruction is 16 rows x one full 128-byte line) and its four doubles feed four MFMAs, step m
+// contracting positions 16 g + 4 q + m against zW[16 g + 4 q + m][j] from the LDS image.  Result register
+// r of lane l is row (l >> 4) + 4 r, lane slot l & 15: a row of R is stored as one 128-byte segment.
+// (resid_ws_kernel walks a row per thread: every lane of a load is its own cache line, 83 us at K = 268.)
+// ---------------------------------------------------------------------------------------------
+constexpr int RM_WAVES = 4;
+constexpr int RM_U = 4;  // 16-position groups per batch (two batches in flight)
+
+__global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) {
+  static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 columns of the MFMA B operand");
+  if (a.done != nullptr && *a.done != 0) return;
+  const unsigned mask = split_ws_mask(a);
+  if (mask == 0u) return;
+  __shared__ double zw[WS_KCAP][SPLIT_LANES];  // 64 KiB
+  __shared__ double lsum[RM_WAVES][SPLIT_LANES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = a.ws->K;  // multiple of 16; positions >= Kreal hold zero columns
+  const int64_t b = blockIdx.x;
+  const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
+  const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
+  const int64_t rend = r0 + nrows;
+  for (int e = tid; e < K * SPLIT_LANES; e += RM_WAVES * 64) {
+    const int k = e >> 4, l = e & 15;
+    const int j = a.idx[k];
+    zw[k][l] = (j >= 0 && l < a.n_lanes) ? a.z[(int64_t)l * a.ld + j] : 0.0;
+  }
+  __syncthreads();
+  const int i16 = lane & 15, q = lane >> 4;
+  const int ngroups = K >> 4;
+  const int ntiles = (int)((nrows + 15) >> 4);
+  double loss = 0.0;  // of lane slot i16 over this lane's rows
+  for (int t = wave; t < ntiles; t += RM_WAVES) {
+    const int64_t row0 = r0 + 16 * (int64_t)t;
+    const int64_t rl = row0 + i16 < rend ? row0 + i16 : rend - 1;  // (rows past the block are computed and dropped)
+    const double* xp = a.XW + rl * WS_KCAP + 4 * q;
+    slm_d4 acc = slm_d4{0.0, 0.0, 0.0, 0.0};
+    slm_d4 xa[RM_U], xb[RM_U];
+    auto load = [&](slm_d4(&xv)[RM_U], int g0) {
+#pragma unroll
+      for (int u = 0; u < RM_U; ++u)
+        if (g0 + u < ngroups) xv[u] = *reinterpret_cast<const slm_d4*>(xp + 16 * (g0 + u));
+    };
+    auto compute = [&](const slm_d4(&xv)[RM_U], int g0) {
+#pragma unroll
+      for (int u = 0; u < RM_U; ++u)
+        if (g0 + u < ngroups) {
+          const double* zr = &zw[16 * (g0 + u) + 4 * q][i16];
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][m], zr[m * SPLIT_LANES], acc, 0, 0, 0);
+        }
+    };
+    load(xa, 0);
+    for (int g0 = 0; g0 < ngroups; g0 += 2 * RM_U) {
+      if (g0 + RM_U < ngroups) load(xb, g0 + RM_U);
+      compute(xa, g0);
+      if (g0 + 2 * RM_U < ngroups) load(xa, g0 + 2 * RM_U);
+      if (g0 + RM_U < ngroups) compute(xb, g0 + RM_U);
+    }
+    if ((mask >> i16) & 1u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + q + 4 * r;
+        if (row < rend) {
+          const double m = a.rw ? a.rw[(int64_t)i16 * a.rw_stride + row] : 1.0;
+          const double err = acc[r] - a.y[row];
+          const double res = err * m;
+          a.R[row * SPLIT_RSTRIDE + i16] = res;
+          loss = __builtin_fma(res, err, loss);
+        }
+      }
+    }
+  }
+  loss += __shfl_xor(loss, 16, 64);
+  loss += __shfl_xor(loss, 32, 64);
+  if (lane < SPLIT_LANES) lsum[wave][lane] = loss;
+  __syncthreads();
+  if (tid < SPLIT_LANES && ((mask >> tid) & 1u)) {
+    double t = 0.0;
+    for (int w2 = 0; w2 < RM_WAVES; ++w2) t += lsum[w2][tid];
     a.loss_partial[b * SPLIT_LANES + tid] = t;
   }
 }

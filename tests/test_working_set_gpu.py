@@ -382,3 +382,24 @@ def test_randomised_cross_check_against_plain_iteration():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "FUZZ cases 120" in out.stdout and "flagged 0" in out.stdout
+
+
+def test_vector_and_matrix_core_residual_kernels_agree(eng, monkeypatch):
+    # residuals from the gathered columns: resid_mfma_kernel (default) against resid_ws_kernel (SLM_RESID_VEC=1)
+    rng = np.random.default_rng(12)
+    n, p = 2100, 640
+    X = rng.standard_normal((n, p))
+    beta = np.zeros(p)
+    beta[rng.choice(p, 25, replace=False)] = rng.standard_normal(25) * 4
+    y = X @ beta + rng.standard_normal(n)
+    w = rng.uniform(0.2, 2.0, n)
+    amax = float(np.max(np.abs(X.T @ (w * y)))) / n
+    pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 0.01 * amax, 30)]
+    out = {}
+    for name, flag in (("mfma", "0"), ("vec", "1")):
+        monkeypatch.setenv("SLM_RESID_VEC", flag)
+        with eng.dataset(X, y, row_weight=w) as ds:
+            out[name] = ds.solve_path(pts, tol=1e-11, lanes=12, flags=_engine.FLAG_WORKING_SET)
+    assert out["mfma"].converged and out["vec"].converged and out["mfma"].ws_refined > 0
+    scale = np.max(np.abs(out["vec"].betas))
+    assert np.max(np.abs(out["mfma"].betas - out["vec"].betas)) < 1e-8 * scale
