@@ -333,10 +333,22 @@ __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a
   if (a.done != nullptr && *a.done != 0) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int col0 = ((int)blockIdx.x * XTR_WAVES + wave) * XTR_CW;
+  // XCD-aware tile order (for speed only): workgroups are handed to the 8 XCDs round-robin by linear id, and
+  // the column blocks of one row block all read that block's slice of R -- give each XCD a contiguous run of
+  // (row block, column block) tiles so a slice is fetched into one L2 instead of eight (PMC: 103 MB of the
+  // 4.109 GB read per launch were R re-reads).
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  {
+    const int total = (int)(gridDim.x * gridDim.y), lin = bx + (int)gridDim.x * by;
+    const int xcd = lin & 7, slot = lin >> 3, base = total >> 3, rem = total & 7;
+    const int m = xcd * base + (xcd < rem ? xcd : rem) + slot;
+    bx = m % (int)gridDim.x;
+    by = m / (int)gridDim.x;
+  }
+  const int col0 = (bx * XTR_WAVES + wave) * XTR_CW;
   const int ld = (int)a.ld;
   if (col0 >= ld) return;  // (no barrier below)
-  const int64_t r0 = (int64_t)blockIdx.y * a.xrows;
+  const int64_t r0 = (int64_t)by * a.xrows;
   const int64_t r1 = r0 + a.xrows < a.n ? r0 + a.xrows : a.n;
   const int kq = lane >> 4, i16 = lane & 15;
   int coff[4];  // columns past the row (ld is a multiple of 16, not of 32) re-read its last pair; not stored
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a
     }
   }
   if (i16 < SPLIT_LANES) {  // tile 2c+e holds columns col0 + 32 c + 2 i + e
-    double* out = a.partial + ((int64_t)blockIdx.y * SPLIT_LANES + i16) * a.ld;
+    double* out = a.partial + ((int64_t)by * SPLIT_LANES + i16) * a.ld;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
