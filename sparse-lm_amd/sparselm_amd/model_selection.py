@@ -170,9 +170,15 @@ class GridSearchCV(_GridSearchCV):
         splits = list(cv.split(X, y, groups))
         n_splits = len(splits)
         candidates = list(ParameterGrid(self.param_grid))
-        # validate every candidate the way fit() would (same error classes)
+        # validate the way fit() would (same error classes): every distinct value of every grid parameter once
+        # (the constraints are per parameter; 60 clones instead of 500 on a 50 x 10 grid, whose
+        # clone / get_params / inspect.signature cost was a quarter of the search)
+        seen = set()
         for params in candidates:
-            clone(est).set_params(**params)._validate_params(X, y)
+            fresh = [k for k, v in params.items() if (k, repr(v)) not in seen]
+            if fresh:
+                seen.update((k, repr(v)) for k, v in params.items())
+                clone(est).set_params(**params)._validate_params(X, y)
 
         # units: (non-alpha params, fold) -> one warm-started alpha path
         by_combo = defaultdict(list)
