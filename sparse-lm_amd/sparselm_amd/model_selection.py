@@ -230,6 +230,7 @@ class GridSearchCV(_GridSearchCV):
             my_units = [units[i] for i in D.shard_units(len(units), rank, world)]
             lanes = max(1, min(int(self.lanes), _engine.MAX_LANES, ds.max_lanes()))
             opts = _solver_options(est)
+            opts.setdefault("tol", _backend.default_tol(n, p))
             local = {}
             for k0 in range(0, len(my_units), lanes):
                 batch = my_units[k0 : k0 + lanes]
