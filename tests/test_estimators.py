@@ -402,3 +402,30 @@ def test_stepwise_estimator(backend, golden):
         StepwiseEstimator([("a", Lasso()), ("b", Lasso(fit_intercept=True))], scopes).fit(X, y)
     with pytest.raises(InvalidParameterError):  # no nesting
         StepwiseEstimator([("a", Lasso()), ("b", step)], scopes).fit(X, y)
+
+
+@pytest.mark.gpu
+def test_default_tolerance_holds_1e6_on_correlated_reference_sized_designs():
+    # `tol` bounds the last prox step, the error is about the condition number times that: the
+    # estimators' default (1e-10 at these sizes) keeps strongly correlated designs of the reference's own sizes
+    # within the stated 1e-6 of an exact solver (scikit-learn's coordinate descent as referee)
+    from sklearn.linear_model import Lasso as SkLasso
+
+    from sparselm_amd.model import Lasso
+
+    rng = np.random.default_rng(4)
+    for n, p, rho in ((400, 100, 0.95), (250, 120, 0.9), (2000, 300, 0.97)):
+        E = rng.standard_normal((n, p))
+        X = E.copy()
+        for j in range(1, p):
+            X[:, j] = rho * X[:, j - 1] + np.sqrt(1 - rho**2) * E[:, j]
+        beta = np.zeros(p)
+        beta[rng.choice(p, 8, replace=False)] = rng.standard_normal(8) * 2
+        y = X @ beta + 0.5 * rng.standard_normal(n)
+        amax = np.max(np.abs(X.T @ y)) / n
+        for frac in (0.3, 0.03, 0.003):
+            ref = SkLasso(alpha=frac * amax, fit_intercept=False, tol=1e-14, max_iter=1000000).fit(X, y).coef_
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                got = Lasso(alpha=frac * amax).fit(X, y).coef_
+            assert np.max(np.abs(got - ref)) <= 1e-6 * np.max(np.abs(ref)), (n, p, rho, frac)
