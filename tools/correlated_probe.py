@@ -28,4 +28,4 @@ for name in ("ar1_0.95", "lowrank+noise", "scaled_columns"):
         t = time.perf_counter(); r = ds.solve_path(pts, lanes=16, flags=_engine.FLAG_FRESH_L, max_iter=200000); dt = time.perf_counter() - t
         t = time.perf_counter(); q = ds.solve_path(pts, lanes=4, flags=_engine.FLAG_NO_WORKING_SET | _engine.FLAG_FRESH_L, tol=1e-9, max_iter=200000); dq = time.perf_counter() - t
         err = float(np.max(np.abs(r.betas - q.betas)) / np.max(np.abs(q.betas)))
-        print(f"{name:15s}: working set {dt*1e3:8.1f} ms / {r.grad_launches:5d} passes (L {r.L:.3g}, cols {r.ws_columns}, misses {r.ws_misses}); plain {dq*1e3:9.1f} ms / {q.grad_launches:6d} passes (L {q.L:.3g}); rel-inf {err:.1e}; converged {r.converged} {q.converged}", flush=True)
+        print(f"{name:15s}: working set {dt*1e3:8.1f} ms / {r.grad_launches:5d} passes (cols {r.ws_columns}, misses {r.ws_misses}); plain {dq*1e3:9.1f} ms / {q.grad_launches:6d} passes; rel-inf {err:.1e}; converged {r.converged} {q.converged}", flush=True)
