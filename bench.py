@@ -3,17 +3,31 @@
 
 A "step" is one complete path solve on one GPU: seed Lipschitz estimate (power iteration, re-done
 every step) + 50 converged alpha points (tol 1e-8), with (X, y) already resident in HBM.  The path
-is walked by `--lanes` (default 4) ranges that share every pass over X (work-stealing between them);
-`--lanes 1` is the strictly sequential warm-started path.  At N > 1 every
-rank owns an independent unit of the (alpha x CV-fold) grid -- its own synthetic fold, same law,
-different seed -- so there is no data-path collective ("weak" scaling); ranks are launched by
-``python -m torch.distributed.run`` and only the barrier / max-over-ranks uses torch.distributed.
+is walked by `--lanes` (default 16) lanes that share every pass over X; `--lanes 1` is the strictly
+sequential warm-started path.
+
+Ranks.  ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself: the parent process -- before it has touched HIP in any way -- runs
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` on this
+file as a CHILD process, relays its output and exits with its code.  Launched under torchrun (the
+driver's form) WORLD_SIZE is taken from the environment.  At N > 1 every rank owns an independent unit of
+the (alpha x CV-fold) grid -- its own synthetic fold, same law, different seed -- so the headline has no
+data-path collective ("weak" scaling); torch.distributed (gloo) carries the barrier, the max-over-ranks
+of the timings and the per-rank device report.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     -- achieved HBM GB/s of the fused gradient kernel from HIP events recorded on the
+  roofline     -- achieved HBM GB/s of the kernel that streams X, from HIP events recorded on the
                   engine's own stream inside the timed region, against the 8 TB/s peak;
   cpu_baseline -- the oracle's C twin (OpenMP, all host cores) timed on a bounded prefix of the same
-                  path on rank 0 at N = 1 (a reported baseline, not the target).
+                  path on rank 0 at N = 1 (a reported baseline, not the target);
+  ranks        -- rank -> device of every rank and the imbalance (slowest rank / mean rank);
+  extra_legs   -- measured AFTER the timed region, never part of `value`:
+                  "config4_grid": BASELINE config 4 (SparseGroupLasso, 5 folds x 10 l1_ratio x 50 alpha =
+                  2500 fits) with its 50 (fold, l1_ratio) units dealt to the ranks (strong scaling);
+                  "rowshard": BASELINE config 5's shape (AdaptiveGroupLasso, 3 re-weighting solves,
+                  125 000 rows x 10 000 columns PER RANK) through the engine's RCCL communicator over all
+                  ranks (weak scaling in rows; one all-reduce of the gradients per pass).
+                  `--no-extra` skips them; `--rowshard` / `--grid` run only that leg as the step.
 """
 
 from __future__ import annotations
@@ -21,7 +35,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -58,8 +75,12 @@ def make_coef(p, n_informative, seed):
     return coef
 
 
+# ---------------------------------------------------------------------------------------------------
+# CPU legs (rank 0, N = 1 only; after the timed region)
+# ---------------------------------------------------------------------------------------------------
 def cpu_baseline(ds, alphas, L, tol, gpu_betas, budget_s):
-    """Time the C oracle on a prefix of the same path (full n x p) on the host cores."""
+    """Time the C oracle on the same path (full n x p) on the host cores: the whole path when it fits the
+    budget, otherwise a prefix (the sample string says which)."""
     import oracle
     from oracle import cref
 
@@ -70,12 +91,11 @@ def cpu_baseline(ds, alphas, L, tol, gpu_betas, budget_s):
     numa = cref.NumaMatrix(X0)  # pages first-touched by the threads that stream them
     del X0
     X = numa.array
-    t0 = time.perf_counter()
-    cref.gradient(X, y, z)
-    t_grad = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    cref.gradient(X, y, z)
-    t_grad = min(t_grad, time.perf_counter() - t0)
+    t_grad = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        cref.gradient(X, y, z)
+        t_grad = min(t_grad, time.perf_counter() - t0)
     beta = None
     done = 0
     iters = 0
@@ -91,14 +111,16 @@ def cpu_baseline(ds, alphas, L, tol, gpu_betas, budget_s):
         if k > 0 and ref_max > 0:  # k = 0 is alpha_max: the solution is 0 up to rounding of alpha_max
             worst = max(worst, float(np.max(np.abs(gpu_betas[k] - beta)) / ref_max))
     elapsed = time.perf_counter() - t_start
+    whole = done == len(alphas)
     out = {
         "value": done / elapsed,
         "unit": "fits/s",
         "cores": cref.num_threads(),
         "kind": "port",
-        "sample": f"first {done} of {len(alphas)} alphas of the same warm-started path, full "
+        "sample": ("the whole" if whole else f"first {done} of the") + f" {len(alphas)}-alpha warm-started path, full "
         f"{n}x{p} fp64, tol {tol:g}, {iters} fused one-pass gradients "
-        f"({t_grad * 1e3:.0f} ms each) by oracle/fista_ref.c with OpenMP",
+        f"({t_grad * 1e3:.0f} ms each = {8e-9 * n * p / t_grad:.0f} GB/s) by oracle/fista_ref.c with OpenMP"
+        + ("" if whole else "; the later (denser) points cost more gradients each, so the whole path would rate lower"),
         "beta_rel_inf_err_gpu_vs_oracle": worst,
     }
     # Second CPU line: scikit-learn's coordinate-descent lasso_path with a precomputed
@@ -129,8 +151,172 @@ def cpu_baseline(ds, alphas, L, tol, gpu_betas, budget_s):
             del Xf
         except Exception as exc:  # never let the extra line break the contract line
             out["sklearn_lasso_path"] = {"error": repr(exc)}
+    out["cvxpy"] = cvxpy_leg(X, y, alphas, gpu_betas)
     numa.__exit__()
     return out
+
+
+def cvxpy_leg(X, y, alphas, gpu_betas, n_red=10_000, p_red=500, cap_s=60.0):
+    """the reference's own route -- a cvxpy problem handed to a conic solver
+    (reference src/sparselm/model/_base.py:512-519, objective _lasso.py:109-121) -- written here from the
+    math, at the reduced size the plan names (n = 10 000, p = 500: the full 100 000 x 5 000 problem is a
+    5e8-nonzero conic matrix) on the first rows / columns of the same data.  Recorded as unavailable when
+    cvxpy cannot be imported on the box."""
+    try:
+        import cvxpy as cp
+    except Exception as exc:
+        return {"status": "cvxpy unavailable on box", "detail": repr(exc)[:120]}
+    try:
+        Xr = np.ascontiguousarray(X[:n_red, :p_red])
+        yr = y[:n_red]
+        alpha = float(alphas[len(alphas) // 2])
+        beta = cp.Variable(p_red)
+        prob = cp.Problem(cp.Minimize(cp.sum_squares(Xr @ beta - yr) / (2 * n_red) + alpha * cp.norm1(beta)))
+        t0 = time.perf_counter()
+        prob.solve()
+        dt = time.perf_counter() - t0
+        return {"status": "ok", "value": 1.0 / dt, "unit": "fits/s", "seconds_per_fit": dt, "n": n_red, "p": p_red,
+                "alpha": alpha, "solver": str(prob.solver_stats.solver_name), "capped_at_s": cap_s,
+                "what": "one cold cvxpy solve at the path's middle alpha, reduced size"}
+    except Exception as exc:
+        return {"status": "cvxpy failed", "detail": repr(exc)[:200]}
+
+
+# ---------------------------------------------------------------------------------------------------
+# extra legs (all ranks; after the timed region; never part of `value`)
+# ---------------------------------------------------------------------------------------------------
+class Watchdog:
+    """Hard stop for a leg that might hang in a collective: past the limit, rank 0 prints the line it
+    already holds (with the leg marked as timed out) and every rank leaves through os._exit, so a stuck
+    exchange never takes the contract line or the driver's run with it."""
+
+    def __init__(self, seconds, on_expire):
+        self._t = threading.Timer(seconds, on_expire)
+        self._t.daemon = True
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._t.cancel()
+
+
+def leg_config4_grid(eng, rank, world, n, p, reps=1):
+    """BASELINE config 4 on the grid mode: 5 folds x 10 l1_ratio, each a 50-alpha SparseGroupLasso path; the
+    50 (fold, l1_ratio) units are dealt to the ranks (LPT by cost), sixteen lanes per call.  Every rank
+    generates the SAME (X, y) (same seed): X replicated per GPU, no data-path collective."""
+    from sparselm_amd import _engine
+    from sparselm_amd import distributed as D
+
+    G = p // 10
+    rng = np.random.default_rng(1)
+    groups = rng.permutation(np.repeat(np.arange(G), 10))
+    coef = np.zeros(p)
+    for g in rng.choice(G, 25, replace=False):
+        coef[groups == g] = 100.0 * rng.uniform(size=10)
+    ds = eng.synthetic_dataset(n, p, seed=11, coef=coef, noise_sd=10.0)
+    try:
+        ds.set_groups(groups, G)
+        g0, _ = ds.gradient(None)
+        gnorm = np.sqrt(np.bincount(groups, weights=g0 * g0, minlength=G))
+        bmax, amax1 = float(gnorm.max()), float(np.max(np.abs(g0)))
+        l1_ratios = np.linspace(0.05, 0.95, 10)
+        folds = np.random.default_rng(0).permutation(n) % 5  # KFold(5, shuffle=True)
+        masks = [(folds != f).astype(float) for f in range(5)]
+        units = [(f, r) for f in range(5) for r in l1_ratios]  # fold-major: a batch shares a row mask and its Gram
+        # cost model for the deal: every unit is a 50-point path; the l1-heavy ones end with more columns
+        mine = [units[i] for i in D.shard_units(len(units), rank, world, costs=[1.0 + 0.3 * r for _, r in units])]
+        lanes = _engine.MAX_LANES
+
+        def run():
+            passes = 0
+            for k0 in range(0, len(mine), lanes):
+                batch = mine[k0 : k0 + lanes]
+                split = max(1, lanes // len(batch))  # spare lane slots: cut each path into contiguous ranges
+                specs = []
+                for f, r in batch:
+                    amax = min(bmax / (1 - r), amax1 / r)
+                    al = np.geomspace(amax, 1e-3 * amax, 50)
+                    pts = np.c_[r * al, (1 - r) * al, 0 * al]
+                    for part in np.array_split(np.arange(50), split):
+                        specs.append(dict(points=pts[part], row_weight=masks[f], n_eff=int(masks[f].sum())))
+                out = ds.solve_lanes(specs)
+                passes += out[0].grad_launches
+                if not all(o.converged for o in out):
+                    raise RuntimeError("config 4: a path did not converge")
+            return passes
+
+        run()  # warm (column-major copy, buffers)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        passes = 0
+        for _ in range(reps):
+            passes = run()
+        eng.synchronize()
+        return {"seconds": (time.perf_counter() - t0) / reps, "passes": passes, "units": len(mine)}
+    finally:
+        ds.close()
+
+
+def leg_rowshard(eng, rank, world, n_rank, p, reps=2):
+    """BASELINE config 5's shape through the engine's RCCL communicator: rank r owns rows
+    [r n_rank, (r + 1) n_rank) of one synthetic matrix (generated on the device), 1000 groups x 10,
+    AdaptiveGroupLasso with 3 re-weighting solves at alpha = 0.1 alpha_max; every pass all-reduces the
+    lanes' gradients (and stop words) over the ranks."""
+    from sparselm_amd import distributed as D
+
+    G = p // 10
+    groups = np.repeat(np.arange(G), 10)
+    rng = np.random.default_rng(0)
+    coef = np.zeros(p)
+    for g in rng.choice(G, 30, replace=False):
+        coef[groups == g] = rng.uniform(1, 5, 10)
+    D.init_row_sharding(eng, rank=rank, world_size=world)
+    ds = None
+    try:
+        comm_ranks = eng.comm_ranks()
+        ds = eng.synthetic_dataset(n_rank, p, seed=1000, coef=coef, noise_sd=5.0, row_offset=rank * n_rank)
+        ds.set_global_rows(n_rank * world)
+        ds.set_groups(groups, G)
+        g0, _ = ds.gradient(None)  # (all-reduced: identical on every rank)
+        amax = float(np.max(np.sqrt(np.bincount(groups, weights=g0 * g0, minlength=G))))
+        alpha, eps = 0.1 * amax, 1e-6
+        out = {}
+        for rep in range(reps + 1):  # first repetition warms up
+            w = alpha * np.ones(G)
+            beta = None
+            passes = 0
+            eng.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                res = ds.solve_path([(0.0, 1.0, 0.0)], b=w, beta0=beta, tol=1e-8, want_group_norms=True)
+                beta = res.betas[0]
+                passes += res.grad_launches
+                w = alpha * (alpha / (res.group_norms[0] + eps))
+            eng.synchronize()
+            dt = time.perf_counter() - t0
+            out = {"seconds_per_fit": dt, "passes": passes, "converged": bool(res.converged),
+                   "active_groups": int(np.sum(res.group_norms[0] > 0)), "rccl_ranks": comm_ranks,
+                   "beta_checksum": float(np.sum(beta * np.arange(1, p + 1)))}
+        return out
+    finally:
+        if ds is not None:
+            ds.close()
+        eng.comm_destroy()
+
+
+# ---------------------------------------------------------------------------------------------------
+def spawn_ranks(n_ranks):
+    """Start the ranks as a CHILD torchrun (this process has made no HIP call) and leave with its code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -145,11 +331,20 @@ def main():
     ap.add_argument("--lanes", type=int, default=16, help="ranges of the path advancing together on one pass over X")
     ap.add_argument("--no-ws", action="store_true", help="disable the working-set refinement (A/B runs)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config-4 grid and row-sharded legs")
+    ap.add_argument("--extra-timeout", type=float, default=240.0, help="hard limit (s) on the extra legs")
+    ap.add_argument("--rowshard-rows", type=int, default=125_000, help="rows per rank of the row-sharded leg")
+    ap.add_argument("--rowshard-cols", type=int, default=10_000)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0 and world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus = {world}", file=sys.stderr)
 
     import torch
     import torch.distributed as dist
@@ -161,9 +356,11 @@ def main():
 
     from sparselm_amd import _engine
 
+    n_dev = max(1, _engine.device_count())
+    device_id = local_rank % n_dev  # one rank per GPU; on a box with fewer GPUs than ranks (tests) ranks share devices
     have_torch_gpu = torch.cuda.is_available()
     if have_torch_gpu:
-        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+        torch.cuda.set_device(device_id % max(1, torch.cuda.device_count()))
 
     def sync_all():
         if use_dist:
@@ -172,13 +369,24 @@ def main():
             torch.cuda.synchronize()
         eng.synchronize()
 
-    # one rank per GPU; on a box with fewer GPUs than ranks (tests) ranks share devices
-    eng = _engine.get_engine(local_rank % max(1, _engine.device_count()))
+    def all_gather(obj):
+        if not use_dist:
+            return [obj]
+        parts = [None] * world
+        dist.all_gather_object(parts, obj)
+        return parts
+
+    eng = _engine.get_engine(device_id)
     n, p, K = args.n, args.p, args.alphas
     coef = make_coef(p, 50, seed=0)
     # independent unit per rank: fold/seed differs, law identical
+    t_c = time.perf_counter()
     ds = eng.synthetic_dataset(n, p, seed=1000 + rank, coef=coef, noise_sd=10.0)
+    eng.synchronize()
+    create_ms = 1e3 * (time.perf_counter() - t_c)
+    t_c = time.perf_counter()
     g0, _, _ = ds.gradient(None, reps=50)  # alpha_max; the extra launches bring the clocks up (setup)
+    clock_warmup_ms = 1e3 * (time.perf_counter() - t_c)
     amax = float(np.max(np.abs(g0)))
     alphas = np.geomspace(amax, 1e-3 * amax, K)
     points = [(a, 0.0, 0.0) for a in alphas]
@@ -186,8 +394,12 @@ def main():
     if args.no_ws:
         flags |= _engine.FLAG_NO_WORKING_SET
 
+    first_ms = None
     for _ in range(args.warmup):
+        t_c = time.perf_counter()
         ds.solve_path(points, tol=args.tol, flags=flags, lanes=args.lanes)
+        if first_ms is None:  # includes the one-off column-major copy of X and the work-space allocations
+            first_ms = 1e3 * (time.perf_counter() - t_c)
 
     sync_all()
     t0 = time.perf_counter()
@@ -200,19 +412,27 @@ def main():
         grad_ms += res.grad_ms_total
         grad_launches += res.grad_launches
         grad_timed += res.grad_timed
+    eng.synchronize()
+    my_elapsed = time.perf_counter() - t0
     sync_all()
     elapsed = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    assert res is not None
+    info = eng.device_info()
+    per_rank = all_gather({"rank": rank, "local_rank": local_rank, "device": device_id, "name": info["name"],
+                           "seconds": my_elapsed, "converged": bool(res.converged),
+                           "host": socket.gethostname(), "pid": os.getpid()})
 
+    out = None
     if rank == 0:
-        assert res is not None and res.converged, "path did not converge"
+        assert all(r["converged"] for r in per_rank), "a path did not converge"
         # algorithmic bytes of one launch: X once, y once, per lane z read and g written
         # p = 5000: the fused kernels stop at four lanes; the split pass of working-set solves has sixteen
         # (and plain solves of more than four lanes on large X: the same two matrix-core halves)
-        split = (not args.no_ws and res.ws_builds > 0) or (min(args.lanes, K) > 4 and n * p >= 2**26 and p <= 5120)
+        split = (not args.no_ws and res.ws_builds > 0) or (min(args.lanes, K) > 4 and n * p >= 2**26 and p <= 10240)
         lanes_used = max(1, min(args.lanes, 16 if split else 4))
         if split:  # xtr_mfma_kernel: X once, the row residuals of 16 lane slots, 16 gradient rows out
             bytes_per_grad = 8.0 * (n * p + 16 * n + 16 * p)
@@ -220,6 +440,7 @@ def main():
             bytes_per_grad = 8.0 * (n * p + 2 * n + 2 * p * lanes_used)
         t_grad_ms = grad_ms / max(1, grad_timed)
         achieved = bytes_per_grad / (t_grad_ms * 1e-3) / 1e9 if t_grad_ms > 0 else 0.0
+        secs = [r["seconds"] for r in per_rank]
         out = {
             "metric": "fits/sec over 50-alpha Lasso path at n=100k p=5k",
             "value": world * args.steps * K / elapsed,
@@ -246,6 +467,19 @@ def main():
                 "grad_evals_per_path": grad_launches / args.steps,
                 "lipschitz_ms_per_path": res.lipschitz_ms,
                 "working_set": {"builds": res.ws_builds, "appends": res.ws_appends, "refined": res.ws_refined, "misses": res.ws_misses, "columns": res.ws_columns},
+                "one_off_costs_outside_value_ms": {
+                    "what": "paid once per dataset, before the timed region",
+                    "dataset_generation": create_ms,
+                    "clock_warmup_50_gradient_launches": clock_warmup_ms,
+                    "first_path_incl_column_major_copy_and_workspace": first_ms,
+                },
+            },
+            "ranks": {
+                "devices": {str(r["rank"]): r["device"] for r in per_rank},
+                "distinct_devices": len({(r["host"], r["device"]) for r in per_rank}),
+                "device_names": sorted({r["name"] for r in per_rank}),
+                "seconds_per_rank": secs,
+                "imbalance_max_over_mean": max(secs) / (sum(secs) / len(secs)),
             },
             "roofline": {
                 "bound": "hbm",
@@ -261,14 +495,70 @@ def main():
                 "launches": grad_launches,
                 "launches_timed_with_hip_events": grad_timed,
                 "algorithmic_bytes_per_launch": bytes_per_grad,
+                "path_level": {
+                    "what": "algorithmic bytes of all passes of a path / whole path time (everything between the passes counted)",
+                    "achieved": (grad_launches / args.steps) * bytes_per_grad / (1e-3 * 1e3 * elapsed / args.steps) / 1e9,
+                    "frac": (grad_launches / args.steps) * bytes_per_grad / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                },
             },
         }
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"] = cpu_baseline(ds, alphas, res.L, args.tol, res.betas, args.cpu_budget)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
     ds.close()
+
+    # ---- extra legs: after the timed region, guarded by a hard limit ------------------------------------
+    if not args.no_extra:
+        legs = {}
+        if out is not None:
+            out["extra_legs"] = legs
+
+        def expire():
+            if out is not None:
+                legs["timed_out_after_s"] = args.extra_timeout
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        with Watchdog(args.extra_timeout, expire):
+            for name, fn in (("config4_grid", lambda: leg_config4_grid(eng, rank, world, n, p)),
+                             ("rowshard", lambda: leg_rowshard(eng, rank, world, args.rowshard_rows, args.rowshard_cols))):
+                try:
+                    mine = {"ok": True, **fn()}
+                except Exception as exc:  # a leg never breaks the contract line
+                    mine = {"ok": False, "error": repr(exc)[:300]}
+                if use_dist:
+                    dist.barrier()
+                parts = all_gather(mine)
+                if out is None:
+                    continue
+                if not all(q["ok"] for q in parts):
+                    legs[name] = {"error": [q.get("error") for q in parts if not q["ok"]][:2]}
+                elif name == "config4_grid":
+                    secs = [q["seconds"] for q in parts]
+                    legs[name] = {
+                        "what": "SparseGroupLasso 5 folds x 10 l1_ratio x 50 alpha = 2500 fits at n=100k p=5k, the 50 "
+                        "(fold, l1_ratio) units dealt to the ranks (LPT), 16 lanes per call; strong scaling",
+                        "fits_per_s": 2500.0 / max(secs), "seconds_per_grid": max(secs), "seconds_per_rank": secs,
+                        "units_per_rank": [q["units"] for q in parts], "passes_per_rank": [q["passes"] for q in parts],
+                        "imbalance_max_over_mean": max(secs) / (sum(secs) / len(secs)),
+                    }
+                else:
+                    secs = [q["seconds_per_fit"] for q in parts]
+                    sums = [q["beta_checksum"] for q in parts]
+                    legs[name] = {
+                        "what": f"AdaptiveGroupLasso, 3 re-weighting solves, {args.rowshard_rows} rows x {args.rowshard_cols} "
+                        f"columns per rank ({world * args.rowshard_rows} rows in all), RCCL all-reduce of the lanes' "
+                        "gradients every pass; weak scaling in rows",
+                        "fits_per_s": 1.0 / max(secs), "seconds_per_fit": max(secs), "seconds_per_rank": secs,
+                        "passes": parts[0]["passes"], "passes_agree": len({q["passes"] for q in parts}) == 1,
+                        "rccl_ranks": parts[0]["rccl_ranks"], "converged": all(q["converged"] for q in parts),
+                        "active_groups": parts[0]["active_groups"],
+                        "ranks_hold_identical_coefficients": max(sums) == min(sums),
+                        "rows_per_s": world * args.rowshard_rows * parts[0]["passes"] / max(secs),
+                    }
+    if out is not None:
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

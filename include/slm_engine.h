@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 3
+#define SLM_ABI_VERSION 4
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -146,6 +146,16 @@ int slm_eval_sse(slm_dataset* ds, const double* Z, int32_t m, const double* row_
 int slm_eval_sse_sparse(slm_dataset* ds, const int32_t* cols, int32_t n_cols, const double* Zs, int32_t m,
                         const double* row_weight, double* sse_out);
 
+/*
+ * Diagnostic: x = H^-1 rhs for one dense symmetric positive definite m x m matrix (row-major, host,
+ * m <= 512) with the one-workgroup blocked Cholesky the working-set model solver uses for its direct
+ * steps (csrc/newton_kernels.hpp); mu_out (nullable) receives its estimate of lambda_min(H).
+ * SLM_ERR_BAD_ARG when H is not numerically positive definite.  No reference counterpart (the
+ * factorisations live inside the solvers cvxpy calls, model/_base.py:516-518); used by the tests.
+ */
+int slm_dense_spd_solve(slm_engine* eng, const double* H, int32_t m, const double* rhs, double* x_out,
+                        double* mu_out);
+
 /* ---- solve ----------------------------------------------------------------------------------- */
 typedef struct slm_penalty {
   const double* a; /* length p, per-coefficient l1 weight; NULL => all ones            */
@@ -173,7 +183,9 @@ typedef struct slm_path_point {
 #define SLM_FLAG_NO_WORKING_SET 64u  /* never refine: every iterate comes from a pass over X        */
 
 typedef struct slm_solve_opts {
-  double tol;          /* stop when ||beta+ - z||_2 <= tol * ||beta+||_2; <= 0 => 1e-8   */
+  double tol;          /* relative distance to the minimiser a point is accepted at: stop when the KKT
+                          residual ||G(z)||_2 (prox-gradient mapping) <= tol * mu * ||beta||_2, mu the
+                          strong-convexity estimate of the face (slm_point_info.mu); <= 0 => 1e-8 */
   int32_t max_iter;    /* per path point; <= 0 => 10000                                  */
   int32_t check_every; /* iterations queued between host polls; <= 0 => automatic        */
   double L;            /* Lipschitz constant to use; <= 0 => slm_dataset_lipschitz()     */
@@ -189,6 +201,12 @@ typedef struct slm_point_info {
   double L;          /* inverse step in use at exit (Lipschitz constant in FISTA mode)   */
   int32_t mode;      /* 1 = spectral (Barzilai-Borwein) steps, 0 = FISTA (after fallback) */
   int32_t rejects;   /* spectral candidates rejected so far in this solve                */
+  double kkt;        /* KKT residual at exit: ||(z - prox_s(z - s grad f(z))) / s||_2 -- zero exactly at
+                        the minimiser (the certificate SURVEY 8c-3 names; the reference's solver reports
+                        its own through cvxpy's solver_stats, model/_base.py:516-518)               */
+  double mu;         /* strong-convexity estimate the point was accepted with: kkt / mu bounds the
+                        distance to the minimiser (smallest eigenvalue of the face Hessian from the model
+                        solver's Cholesky factor, or the smallest curvature measured along the steps)  */
 } slm_point_info;
 
 typedef struct slm_solve_stats {
@@ -202,6 +220,9 @@ typedef struct slm_solve_stats {
   int64_t ws_refined;     /* iterates moved by the working-set refinement, all lanes       */
   int64_t ws_misses;      /* times an iterate left the working set (columns get appended)  */
   int64_t ws_columns;     /* columns in the working set at the end of the solve            */
+  int64_t ws_inner_iters; /* proximal-gradient iterations of the model solver, all refinements */
+  int64_t ws_direct_steps;/* direct (Cholesky) steps of the model solver: exact minimisation over the
+                             face of the iterate, taken when the iteration is slow (ill-conditioned faces) */
 } slm_solve_stats;
 
 /*
@@ -267,6 +288,8 @@ int slm_comm_unique_id(uint8_t id_out[SLM_COMM_ID_BYTES]);
    sum X^T r (and the loss / n) over ranks with RCCL; n_global replaces n in the 1/n scaling. */
 int slm_comm_init(slm_engine* eng, int32_t rank, int32_t n_ranks,
                   const uint8_t id[SLM_COMM_ID_BYTES]);
+/* Rank and size of the engine's communicator as RCCL reports them (1 rank, rank 0 without one). */
+int slm_comm_info(slm_engine* eng, int32_t* rank_out, int32_t* n_ranks_out);
 /* n_global replaces n in the 1/n (gradient) and 1/(2n) (loss) scaling: the global row count of a
    row-sharded matrix, or the number of unmasked rows when row weights act as a CV-fold mask. */
 int slm_dataset_set_global_rows(slm_dataset* ds, int64_t n_global);

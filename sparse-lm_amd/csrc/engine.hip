@@ -68,6 +68,8 @@ struct RcclApi {
   int (*CommInitRank)(rcclComm_t*, int, rcclUniqueId_t, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
   int (*CommDestroy)(rcclComm_t) = nullptr;
+  int (*CommCount)(rcclComm_t, int*) = nullptr;
+  int (*CommUserRank)(rcclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 static RcclApi g_rccl;
@@ -88,6 +90,8 @@ static int load_rccl() {
   g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(lib, "ncclCommCount");
+  g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(lib, "ncclCommUserRank");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
     return fail(SLM_ERR_COMM, "librccl is missing required symbols");
   g_rccl.lib = lib;
@@ -260,6 +264,7 @@ struct slm_dataset {
   WsCtl* ws_ctl = nullptr;
   int32_t *ws_idx = nullptr, *ws_pos = nullptr, *ws_gs = nullptr, *ws_gl = nullptr;
   double *ws_score = nullptr, *ws_XW = nullptr, *ws_part = nullptr, *ws_G = nullptr, *ws_Gx = nullptr;
+  double* ws_nt = nullptr;  // [kMaxLanes][NT_SCRATCH] factors of the model solver's direct steps
   double* XT = nullptr;  // column-major copy of X for the column gathers ([ld][ldt]), built on first use
   int64_t ldt = 0;
   bool XT_ready = false, XT_failed = false;
@@ -408,6 +413,7 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->pts); dfree(ds->betas_out); dfree(ds->gn_out); dfree(ds->infos);
   dfree(ds->ws_ctl); dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
   dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
+  dfree(ds->ws_nt);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   for (auto& e : ds->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1559,6 +1565,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (!ds->ws_pos) SLM_TRY(dalloc(&ds->ws_pos, (size_t)ld));
     if (!ds->ws_score) SLM_TRY(dalloc(&ds->ws_score, (size_t)ld));
     if (!ds->ws_XW) SLM_TRY(dalloc(&ds->ws_XW, (size_t)n * WS_KCAP));
+    if (!ds->ws_nt && !getenv("SLM_NO_DIRECT")) SLM_TRY(dalloc(&ds->ws_nt, (size_t)kMaxLanes * NT_SCRATCH));
     if (ds->ws_sets < n_sets) {
       dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
       ds->ws_sets = 0;
@@ -1581,6 +1588,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     wa.ws = ds->ws_ctl;
     wa.idx = ds->ws_idx; wa.pos = ds->ws_pos; wa.gs = ds->ws_gs; wa.gl = ds->ws_gl;
     wa.score = ds->ws_score; wa.XW = ds->ws_XW; wa.part = ds->ws_part; wa.Gm = ds->ws_G;
+    wa.nt = getenv("SLM_NO_DIRECT") ? nullptr : ds->ws_nt;
     if (eng->comm && !ds->ws_Gx) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)ds->ws_sets * WS_KCAP * WS_KCAP));
     wa.Gx = eng->comm ? ds->ws_Gx : nullptr;  // row-sharded: Gram parts are summed over ranks before use
     wa.X = ds->X; wa.XT = ds->XT; wa.ldt = ds->ldt; wa.n = n; wa.ld = ld;
@@ -1613,7 +1621,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // more lanes than the fused kernels serve, which only the split pass can do)
   auto ws_release = [&]() {
     dfree(ds->ws_ctl); dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
-    dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
+    dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->ws_nt);
     ds->ws_sets = 0;
     (void)hipGetLastError();
   };
@@ -1847,6 +1855,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
     stats->lipschitz_ms = lipschitz_ms;
     stats->ws_builds = stats->ws_appends = stats->ws_refined = stats->ws_misses = stats->ws_columns = 0;
+    stats->ws_inner_iters = stats->ws_direct_steps = 0;
     if (use_ws) {
       WsCtl wc;
       HIP_TRY(hipMemcpy(&wc, ds->ws_ctl, sizeof(wc), hipMemcpyDeviceToHost));
@@ -1855,10 +1864,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       stats->ws_refined = wc.refined;
       stats->ws_misses = wc.misses;
       stats->ws_columns = wc.Kreal;
+      stats->ws_inner_iters = wc.inner_iters;
+      stats->ws_direct_steps = wc.newton_steps;
       if (const char* trc = getenv("SLM_TRACE"))
         if (trc[0] == '2')
-          fprintf(stderr, "[slm] working set: %d model-solver iterations over %d refinements, K = %d\n", wc.inner_iters,
-                  wc.refined, wc.K);
+          fprintf(stderr, "[slm] working set: %d model-solver iterations over %d refinements, %d direct steps (%d refused, %d of them not positive definite), K = %d\n",
+                  wc.inner_iters, wc.refined, wc.newton_steps, wc.newton_fails, wc.newton_nopd, wc.K);
     }
     stats->wall_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -1925,8 +1936,62 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
 }
 
 // ------------------------------------------------------------------------------------------------
+// diagnostic: the model solver's dense SPD solve on its own
+// ------------------------------------------------------------------------------------------------
+extern "C" int slm_dense_spd_solve(slm_engine* eng, const double* H, int32_t m, const double* rhs, double* x_out,
+                                   double* mu_out) {
+  if (!eng || !H || !rhs || !x_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  if (m < 1 || m > NT_MAXT * NT_B) return fail(SLM_ERR_BAD_ARG, "m must be in [1, %d] (got %d)", NT_MAXT * NT_B, m);
+  for (int64_t e = 0; e < (int64_t)m * m; ++e)
+    if (!std::isfinite(H[e])) return fail(SLM_ERR_BAD_ARG, "H contains a non-finite value");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipStream_t s = eng->stream;
+  double *dH = nullptr, *dv = nullptr, *scratch = nullptr;
+  int* dst = nullptr;
+  int rc = dalloc(&dH, (size_t)m * m);
+  if (rc == SLM_OK) rc = dalloc(&dv, (size_t)2 * m + 1);
+  if (rc == SLM_OK) rc = dalloc(&scratch, (size_t)NT_SCRATCH);
+  if (rc == SLM_OK) rc = dalloc(&dst, 1);
+  int status = 0;
+  double mu = 0.0;
+  auto bail = [&](hipError_t e) {
+    if (e != hipSuccess && rc == SLM_OK) rc = fail(SLM_ERR_HIP, "slm_dense_spd_solve: %s", hipGetErrorString(e));
+  };
+  if (rc == SLM_OK) {
+    bail(hipMemcpyAsync(dH, H, sizeof(double) * (size_t)m * m, hipMemcpyHostToDevice, s));
+    bail(hipMemcpyAsync(dv, rhs, sizeof(double) * m, hipMemcpyHostToDevice, s));
+    DenseSolveArgs a;
+    a.H = dH; a.rhs = dv; a.x = dv + m; a.mu = dv + 2 * m; a.status = dst; a.scratch = scratch; a.m = m;
+    hipLaunchKernelGGL(dense_spd_solve_kernel, dim3(1), dim3(TAIL_THREADS), 0, s, a);
+    bail(hipGetLastError());
+    bail(hipMemcpyAsync(x_out, dv + m, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+    bail(hipMemcpyAsync(&mu, dv + 2 * m, sizeof(double), hipMemcpyDeviceToHost, s));
+    bail(hipMemcpyAsync(&status, dst, sizeof(int), hipMemcpyDeviceToHost, s));
+    bail(hipStreamSynchronize(s));
+  }
+  dfree(dH); dfree(dv); dfree(scratch); dfree(dst);
+  if (rc != SLM_OK) return rc;
+  if (status != 0) return fail(SLM_ERR_BAD_ARG, "H is not numerically positive definite");
+  if (mu_out) *mu_out = mu;
+  return SLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // row-sharded mode
 // ------------------------------------------------------------------------------------------------
+extern "C" int slm_comm_info(slm_engine* eng, int32_t* rank_out, int32_t* n_ranks_out) {
+  if (!eng) return fail(SLM_ERR_BAD_ARG, "engine is NULL");
+  int rank = 0, count = 1;
+  if (eng->comm) {
+    if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(SLM_ERR_COMM, "librccl lacks ncclCommCount / ncclCommUserRank");
+    RCCL_TRY(g_rccl.CommCount(eng->comm, &count));
+    RCCL_TRY(g_rccl.CommUserRank(eng->comm, &rank));
+  }
+  if (rank_out) *rank_out = rank;
+  if (n_ranks_out) *n_ranks_out = count;
+  return SLM_OK;
+}
+
 extern "C" int slm_comm_unique_id(uint8_t id_out[SLM_COMM_ID_BYTES]) {
   if (!id_out) return fail(SLM_ERR_BAD_ARG, "id_out is NULL");
   SLM_TRY(load_rccl());

@@ -58,6 +58,10 @@ struct PathCtl {
                        // number of lanes when the lanes of a shared path take its points in turn
   int32_t zsup;        // z is zero outside the working set: its residual can come from the gathered
                        // columns (split_kernels.hpp); maintained by ws_solve_kernel
+  int32_t stop_seen;   // row-sharded mode: the stop word of this lane as the last all-reduce delivered it
+  double mu;           // strong-convexity estimate on the face of the point under verification, set by the
+                       // working-set model solver (0 = unknown); reset when the lane moves to the next point
+  double mu_rq;        // smallest Barzilai-Borwein curvature <dz, dg> / <dz, dz> accepted on this point (0 = none yet)
 };
 
 constexpr int BB_HIST = 5;
@@ -68,6 +72,10 @@ constexpr double BB_SIGMA = 1e-4;
 // step itself (16 ulp of the gradient); below it `tol * ||beta||` cannot be met in fp64 when the
 // minimiser is itself a rounding-level number (alpha ~ alpha_max).
 constexpr double kRoundFloor = 16.0 * 2.220446049250313e-16;
+// Strong-convexity estimates below kMuFloor * lambda_max are not trusted: p > n problems, duplicated
+// columns -- the objective is then flat along some direction of the face (mu = 0: the minimiser is not
+// unique and no residual bounds the distance to "it"); the rule then bounds the residual itself.
+constexpr double kMuFloor = 1e-6;
 
 // One workgroup per lane (blockIdx.x): vectors of lane l start at l * ld (g: l * (ld + 16)).
 struct TailArgs {
@@ -178,11 +186,20 @@ __device__ __forceinline__ void for_each_group_sumsq(const double* src, const in
 //    it for good after BB_REJECT_LIMIT rejections or BB_POINT_LIMIT spectral iterations on one point
 //    (ill-conditioned / p > n problems, where FISTA's worst-case rate wins).
 //
-// Both stop on the prox-gradient residual ||prox step||_2 <= tol ||beta||_2 measured with a step no
-// longer than 1/Lhat, so the meaning of `tol` does not depend on the mode.
+// Stopping rule (both modes).  With G_s(z) = (z - prox_s(z - s grad f(z))) / s the prox-gradient mapping --
+// the KKT residual of z: it vanishes exactly at the minimiser and its norm is at most that of the smallest
+// subgradient of the objective at z -- a point is accepted when
+//       ||G_s(z)||_2  <=  tol * mu * ||beta||_2 ,
+// mu an estimate of the strong convexity of the objective on the face of z: for a mu-strongly convex
+// objective ||z - z*|| <= (1 + L s) ||G_s(z)|| / mu, so `tol` bounds the RELATIVE DISTANCE TO THE MINIMISER
+// (up to that factor <= 2), whatever the conditioning.  mu comes from the working-set model solver when it
+// refined this point (PathCtl::mu: the smallest eigenvalue of the face Hessian from its Cholesky factor, or
+// the smallest Rayleigh quotient along its moves), capped by the curvatures this kernel measures itself:
+// the smallest Barzilai-Borwein quotient accepted on this point and Lhat (spectral mode), L (FISTA mode).
+// Without any of these the rule is the classical ||prox step|| <= tol ||beta|| with a step 1/L.
 template <int E>
 __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
-  __shared__ double red[8][TAIL_WAVES];
+  __shared__ double red[9][TAIL_WAVES];
   // image of the thresholded vector for the group gathers: LDS up to 16K features, the per-lane
   // global scratch beyond (long-row fallback; the tail is negligible next to a two-pass gradient)
   constexpr bool US_IN_LDS = E <= 16;
@@ -239,6 +256,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   const double ak_old = ctl->ak;
   const double Lhat_old = ctl->Lhat;
   const double pen_z = ctl->pen_z;
+  const double mu_ws = ctl->mu;
+  const double mu_rq_old = ctl->mu_rq;
   double hist[BB_HIST];
 #pragma unroll
   for (int k = 0; k < BB_HIST; ++k) hist[k] = ctl->hist[k];
@@ -310,6 +329,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   double nb[E];  // new beta when !finalize
   bool finalize = false, conv = false, nonfinite = false;
   double resid = 0.0, bnorm = 0.0;
+  double kkt = 0.0, mu_eff = 0.0, new_mu_rq = mu_rq_old;
   // control-block updates
   int new_mode = mode, new_have_base = have_base, new_rejects = rejects, new_n_hist = n_hist;
   double new_t = t_old, new_L = L, new_ak = ak_old, new_Lhat = Lhat_old, new_pen_z = pen_z;
@@ -374,6 +394,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
           new_ak = s[1] > 0.0 ? s[1] / s[0] : new_Lhat;
         }
         new_ak = fmin(fmax(new_ak, 1e-6 * new_Lhat), 1e6 * new_Lhat);
+        // (a step at the rounding level of the iterate or of the gradient measures nothing)
+        if (s[1] > 0.0 && s[0] * new_Lhat * new_Lhat > 1e-20 * s[5] && s[2] > 1e-20 * s[5])
+          new_mu_rq = mu_rq_old > 0.0 ? fmin(mu_rq_old, new_ak) : new_ak;
       } else {
         new_ak = fmin(2.0 * ak_old, 1e6 * Lhat_old);
         new_rejects = rejects + 1;
@@ -442,16 +465,21 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       new_pen_z = q[2];
       resid = sqrt(q[0]) * fmax(1.0, new_ak / new_Lhat);
       bnorm = sqrt(q[1]);
+      kkt = sqrt(q[0]) * new_ak;  // ||G_s(base)||, s = 1 / ak
+      mu_eff = fmin(new_ak, new_Lhat);
+      if (new_mu_rq > 0.0) mu_eff = fmin(mu_eff, new_mu_rq);
+      if (mu_ws > 0.0) mu_eff = fmin(mu_eff, mu_ws);
+      mu_eff = fmax(mu_eff, kMuFloor * new_Lhat);
       // (second term: a prox step at the rounding level of the gradient itself cannot be improved)
-      conv = resid <= fmax(tol * fmax(bnorm, bnorm_floor), kRoundFloor * sqrt(s[5]) / fmin(new_ak, new_Lhat));
+      conv = kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * sqrt(s[5]));
       finalize = nonfinite || conv || hit_max;
     }
   } else {
     // ================= FISTA scheme =================================================================
     //  s[0] = ||b+ - z||^2   s[1] = ||b+||^2   s[2] = (z - b+).(b+ - b)   s[3] = ||g - gprev||^2
     //  s[4] = ||z - zprev||^2   s[5] = ||z||^2   s[6] = #non-finite
-    //  s[7] = ||g||^2
-    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    //  s[7] = ||g||^2   s[8] = <g - gprev, z - zprev>
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const double step = 1.0 / L;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -460,6 +488,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
         const double dg = gj[e] - gpv[e], dzz = zj[e] - a.zprev[j];
         s[3] = __builtin_fma(dg, dg, s[3]);
         s[4] = __builtin_fma(dzz, dzz, s[4]);
+        s[8] = __builtin_fma(dg, dzz, s[8]);
         s[5] = __builtin_fma(zj[e], zj[e], s[5]);
         s[7] = __builtin_fma(gj[e], gj[e], s[7]);
         a.gprev[j] = gj[e];
@@ -479,7 +508,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
         if (!isfinite(bn)) s[6] += 1.0;
       }
     }
-    block_sum<8>(s, red);
+    block_sum<9>(s, red);
     nonfinite = s[6] > 0.0 || !isfinite(s[0]) || !isfinite(s[1]) || !isfinite(loss_z);
     // Curvature guard: ||A dz|| / ||dz|| is a lower bound on lambda_max(A), A = X^T W X / n.  If it
     // exceeds L the step 1/L was too long: raise L, discard the step and restart from beta.
@@ -489,6 +518,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
         l_bad = true;
         new_L = 1.02 * curv;
       }
+      // curvature along the move of the extrapolated point: a Rayleigh quotient of X^T W X / n, i.e. an upper
+      // estimate of the strong convexity on the face the iteration is on
+      if (s[8] > 0.0 && s[3] > 1e-20 * s[7]) new_mu_rq = mu_rq_old > 0.0 ? fmin(mu_rq_old, s[8] / s[4]) : s[8] / s[4];
     }
     did_restart = !(flags & SLM_FLAG_NO_RESTART) && s[2] > 0.0;
     const double t_use = did_restart ? 1.0 : t_old;
@@ -496,7 +528,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     const double mom = (t_use - 1.0) / t_new;
     resid = sqrt(s[0]);
     bnorm = sqrt(s[1]);
-    conv = !l_bad && (resid <= fmax(tol * fmax(bnorm, bnorm_floor), kRoundFloor * sqrt(s[7]) / L));
+    kkt = resid * L;  // ||G_s(z)||, s = 1 / L
+    mu_eff = mu_ws > 0.0 ? fmin(mu_ws, L) : L;
+    if (new_mu_rq > 0.0) mu_eff = fmin(mu_eff, new_mu_rq);
+    mu_eff = fmax(mu_eff, kMuFloor * L);
+    conv = !l_bad && (kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * sqrt(s[7])));
     finalize = nonfinite || conv || hit_max;
     new_t = l_bad ? 1.0 : t_new;
 #pragma unroll
@@ -576,7 +612,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       info.L = new_mode == 1 ? new_ak : new_L;
       info.mode = new_mode;
       info.rejects = new_rejects;
+      info.kkt = kkt;
+      info.mu = mu_eff;
       a.infos[point] = info;
+      ctl->mu = 0.0;     // (the next point has its own face)
+      ctl->mu_rq = 0.0;
       ctl->iter = 0;
       ctl->t = 1.0;
       ctl->have_base = 0;  // the next point's objective differs: start its history afresh
@@ -600,6 +640,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       ctl->have_base = new_have_base;
       ctl->n_hist = new_n_hist;
       ctl->pen_z = new_pen_z;
+      ctl->mu_rq = new_mu_rq;
 #pragma unroll
       for (int k = 0; k < BB_HIST; ++k) ctl->hist[k] = hist[k];
     }

@@ -26,16 +26,27 @@
 #include <stdint.h>
 
 #include "tail_kernels.hpp"
+#include "newton_kernels.hpp"
 
 namespace slm {
 
 constexpr int WS_KCAP = 512;        // capacity of the working set (leading dimension of G and XW)
-constexpr int WS_KLDS = 128;        // up to this many columns the Gram lives in LDS during the model solve
+constexpr int WS_KLDS = 112;        // up to this many columns the Gram lives in LDS during the model solve
 constexpr int WS_TILES = WS_KCAP / 16; // 16x16 tiles per side of the Gram
 constexpr int WS_THREADS = 1024;
 constexpr int WS_INNER_MAX = 400;   // inner iterations per refinement
 constexpr double WS_INNER_TOL = 0.05;  // inner stop: residual <= WS_INNER_TOL * tol * ||b||
 constexpr int WS_MAX_REPEATS = 6;   // refinements of one path point before the lane iterates plainly
+// Direct step of the model solver (newton_kernels.hpp): when the proximal-gradient iteration on the model has
+// not converged after WS_NEWTON_AFTER iterations -- or the curvature it measures along its own moves says
+// the face is ill-conditioned (Rayleigh quotient below WS_NEWTON_RQ of lambda_max) -- a projected Newton step
+// on the free coordinates (Cholesky solve, see `direct_step`) replaces further iterations; one prox-gradient
+// step after it tests convergence, and the next direct step follows at once if that fails.
+constexpr int WS_NEWTON_AFTER = 16;
+constexpr int WS_NEWTON_AGAIN = 1;   // iterations between two direct steps (one prox-gradient step: the convergence test)
+constexpr int WS_NEWTON_MAX = 16;    // direct steps per refinement
+constexpr double WS_NEWTON_RQ = 0.05;
+static_assert(NT_MAXT * NT_B == WS_KCAP, "the direct solve covers a full working set");
 
 struct WsCtl {
   int32_t request;    // (re)build W at the next opportunity
@@ -58,8 +69,12 @@ struct WsCtl {
   int32_t staged;     // row-sharded mode: the local Gram parts sit in the staging matrix, waiting for the
                       // all-reduce and ws_publish_kernel
   int32_t inner_iters;  // model-solver iterations of all refinements (diagnostics: SLM_TRACE=2)
+  int32_t newton_steps; // direct (Cholesky) steps taken by the model solver, all lanes
+  int32_t newton_fails; // ... refused: face not positive definite, or the step did not lower the model
+  int32_t newton_nopd;  // ... of which: Cholesky pivot below the floor
   int32_t last_point[SLM_MAX_LANES];  // path point of each lane's last refinement ...
-  int32_t repeats[SLM_MAX_LANES];     // ... and how many times in a row it was that point
+  int32_t repeats[SLM_MAX_LANES];     // ... and how many times in a row it was that point WITH the same columns
+  int32_t last_cols[SLM_MAX_LANES];   // columns W held at each lane's last refinement (growth resets the count)
   double Lw[SLM_MAX_LANES];  // lambda_max estimate per Gram (0 = not yet computed)
 };
 
@@ -73,6 +88,7 @@ struct WsArgs {
   double* XW;      // [n][WS_KCAP] gathered columns
   double* part;    // [n_sets][tile][nblk][16 x 16] partial Grams
   double* Gm;      // [n_sets][WS_KCAP * WS_KCAP]
+  double* nt;      // [SLM_MAX_LANES][NT_SCRATCH] factor of each lane's direct solve (nullptr: no direct solves)
   double* Gx;      // row-sharded mode: [n_sets][WS_KCAP * WS_KCAP] staging, zeroed every pass, summed over
                    // ranks between ws_gram_reduce_kernel and ws_publish_kernel (nullptr otherwise)
   const double* X;
@@ -360,12 +376,19 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
     count_at(inf, false, &n_sel, &smax);
     if (n_sel > (double)WS_KCAP) {
       // the non-zero coefficients of the expansion points alone do not fit (dense early iterates of
-      // a cold start, or a dense solution): try again after the next pass, give up after 50 tries
+      // a cold start, a dense solution, or ONE lane whose plain steps went dense): with a W in place it
+      // stays -- the lanes it still serves keep refining, the ones that left it iterate plainly (`stale`);
+      // without one, try again after the next pass and give up after 50 tries
       if (tid == 0) {
-        ws->request = 1;
-        ws->valid = 0;
         ws->overflows += 1;
-        if (ws->overflows >= 50) ws->disabled = 1;
+        if (had_w) {
+          ws->request = 0;
+          ws->stale = 1;
+        } else {
+          ws->request = 1;
+          ws->valid = 0;
+          if (ws->overflows >= 50) ws->disabled = 1;
+        }
       }
       return;
     }
@@ -687,6 +710,12 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   __shared__ int nnz_s;
   __shared__ double part[WS_THREADS];
   __shared__ double Gl[WS_KLDS * WS_KLDS];
+  // direct step (newton_kernels.hpp)
+  __shared__ NtShared nts;
+  __shared__ double nv[WS_KCAP];   // right-hand side / solution, indexed by rank in the face
+  __shared__ int act[WS_KCAP];     // position of the ii-th face coordinate
+  __shared__ int rank_of[WS_KCAP]; // rank of a position in the face, or -1
+  __shared__ int m_s;
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
   WsCtl* ws = w.ws;
@@ -714,7 +743,9 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     if (out[0] != 0.0) return;
   }
   const int point_now = ctl->point + ctl->pt_off;
-  const int reps = ws->last_point[lane_id] == point_now ? ws->repeats[lane_id] : 0;
+  // (a point whose refinements keep being sent back because W had to grow -- strongly correlated designs
+  // discover their support in waves -- is a different matter from one the model cannot settle)
+  const int reps = (ws->last_point[lane_id] == point_now && ws->last_cols[lane_id] == ws->Kreal) ? ws->repeats[lane_id] : 0;
   if (reps >= WS_MAX_REPEATS) return;
 
   const slm_path_point pt = a.pts[ctl->point];
@@ -878,6 +909,174 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     if (!(Lw > 0.0)) return;  // empty / zero Gram: nothing to refine
   }
 
+  // ---- direct step: projected Newton on the free coordinates ---------------------------------------
+  // Free set F: the non-zero coordinates of x plus the zero ones whose model gradient exceeds their
+  // threshold (they want to leave zero); orthant: sign(x), or the side such a coordinate wants to move to.
+  // Inside the orthant the model + penalty is a smooth quadratic: d = H_FF^-1 (pseudo-gradient) by a Cholesky
+  // solve, then x - t d projected back onto the orthant (a coordinate that would change sign stops at zero),
+  // t = 1, 1/2, ... until the model value falls (two-metric projection: F holds no coordinate that the
+  // gradient pins at zero, so the projected arc is a descent arc).  When nothing is projected at t = 1 the
+  // result IS the minimiser over that face.  Returns 1 when x moved, 0 when there was nothing to do, -1 when
+  // H_FF is not positive definite or no trial lowered the model (the iteration simply carries on).  mu_out:
+  // estimate of the smallest eigenvalue of the face Hessian (0 = not computed).  Per-feature penalties
+  // (and singleton "groups") only: a group norm adds curvature that depends on the iterate -- those lanes keep
+  // to the iteration.
+  const bool newton_capable = w.nt != nullptr && !(group_pen && !a.singleton);
+  double* ntF = newton_capable ? w.nt + (int64_t)lane_id * NT_SCRATCH : nullptr;
+  double* ntD = newton_capable ? ntF + (int64_t)NT_TILES * 256 : nullptr;
+  auto block_min = [&](double val) -> double {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) val = fmin(val, __shfl_xor(val, off, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[0][tid >> 6] = val;
+    __syncthreads();
+    double mm = red[0][0];
+#pragma unroll
+    for (int wv = 1; wv < TAIL_WAVES; ++wv) mm = fmin(mm, red[0][wv]);
+    return mm;
+  };
+  auto direct_step = [&](double& x, double Lmax, double* mu_out, bool want_mu) -> int {
+    *mu_out = 0.0;
+    const double gd0 = matvec(x, false);  // G (x - z0)
+    const double gx = g0 + gd0;           // model gradient at x
+    const double thr = pa + pb;           // (singleton groups: b acts as a second l1 weight)
+    double pg, xi;                        // pseudo-gradient and orthant sign of this position
+    if (x != 0.0) {
+      xi = x > 0.0 ? 1.0 : -1.0;
+      pg = gx + thr * xi + pd * x;
+    } else {
+      pg = fabs(gx) > thr * (1.0 + 1e-12) ? gx - copysign(thr, gx) : 0.0;
+      xi = pg > 0.0 ? -1.0 : 1.0;
+    }
+    bool is_free = live && (x != 0.0 || pg != 0.0);
+    // m_old: model value at x (relative to the expansion point)
+    double m_old;
+    {
+      double sv[2] = {mine ? (x - z0) * (g0 + 0.5 * gd0) : 0.0, 0.0};
+      sv[1] = pen_part(x);
+      block_sum<2>(sv, red);
+      m_old = sv[0] + sv[1];
+    }
+    // On an ill-conditioned face the Newton direction lives on cancellations between near-collinear columns:
+    // projecting some of its coordinates away leaves a step that is no descent step at any useful length.
+    // So a zero coordinate only stays in F if the solve moves it to the side it wants to go; the others are
+    // dropped and the system is solved again (twice at most: then the projected arc has to do).
+    int m = 0, T = 0, mp = 0, my_rank = -1;
+    double dk = 0.0;
+    for (int resolve = 0; resolve < 3; ++resolve) {
+      // free positions in position order
+      __syncthreads();
+      if (q == 0 && k < WS_KCAP) {
+        nv[k] = is_free ? 1.0 : 0.0;
+        rank_of[k] = -1;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        int basep = 0;
+        for (int c0 = 0; c0 < K; c0 += 64) {
+          const int kk = c0 + tid;
+          const bool on = kk < K && nv[kk] != 0.0;
+          const uint64_t mk = __ballot(on);
+          if (on) {
+            const int ii = basep + __popcll(mk & ((1ull << tid) - 1ull));
+            act[ii] = kk;
+            rank_of[kk] = ii;
+          }
+          basep += __popcll(mk);
+        }
+        if (tid == 0) m_s = basep;
+      }
+      __syncthreads();
+      m = m_s;
+      if (m == 0) return 0;
+      T = (m + 15) >> 4;
+      mp = 16 * T;
+      my_rank = (k < K) ? rank_of[k] : -1;
+      __syncthreads();
+      if (tid < mp) nv[tid] = 0.0;
+      if (q == 0 && k < WS_KCAP) delta[k] = pd;  // (matvec is done with delta: it now carries the ridge diagonal)
+      __syncthreads();
+      if (q == 0 && my_rank >= 0) nv[my_rank] = pg;
+      // H_FF, tile by tile (G is symmetric: read along rows)
+      const int ntl = T * (T + 1) / 2;
+      for (int e = tid; e < ntl * 256; e += WS_THREADS) {
+        const int tl = e >> 8, wi = e & 255;
+        int I = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
+        while (I * (I + 1) / 2 > tl) --I;
+        while ((I + 1) * (I + 2) / 2 <= tl) ++I;
+        const int J = tl - I * (I + 1) / 2;
+        const int l6 = wi & 63, st = wi >> 6;
+        const int ii = 16 * I + (l6 & 15), jj = 16 * J + (l6 >> 4) + 4 * st;
+        double hv;
+        if (ii < m && jj < m) {
+          const int pi = act[ii], pj = act[jj];
+          hv = Gm[pj * WS_KCAP + pi];
+          if (ii == jj) hv += delta[pi];
+        } else {
+          hv = ii == jj ? 1.0 : 0.0;
+        }
+        ntF[e] = hv;
+      }
+      __syncthreads();
+      if (!nt_factor(ntF, ntD, T, 1e-12 * Lmax, nts)) {
+        if (tid == 0) atomicAdd(&ws->newton_nopd, 1);
+        return -1;
+      }
+      nt_solve(ntF, ntD, T, nv);  // nv = H_FF^-1 pg
+      dk = my_rank >= 0 ? nv[my_rank] : 0.0;
+      // zero coordinates the solve would move to the wrong side (or not at all)
+      const bool wrong = my_rank >= 0 && x == 0.0 && !(dk * pg > 0.0);
+      double cnt[1] = {mine && wrong ? 1.0 : 0.0};
+      block_sum<1>(cnt, red);
+      if (cnt[0] == 0.0 || resolve == 2) break;
+      if (wrong) is_free = false;
+    }
+    // trial steps: 1, 1/2, 1/4 along the projected arc, then the straight segment up to the first sign change
+    // of a non-zero coordinate (a guaranteed descent step: no projection happens on it)
+    double tcross = 2.0;
+    if (my_rank >= 0 && x != 0.0 && x * dk > 0.0 && fabs(dk) >= fabs(x)) tcross = x / dk;
+    tcross = fmin(1.0, block_min(tcross));
+    double tstep = 1.0, xn = x;
+    bool moved = false, projected = false;
+    for (int trial = 0; trial < 4 && !moved; ++trial) {
+      const double tt = trial < 3 ? tstep : tcross;
+      if (trial == 3 && !(tcross > 1e-14)) break;
+      double xc = x;
+      double cut = 0.0;
+      if (my_rank >= 0) {
+        xc = x - tt * dk;
+        if (xc * xi <= 0.0) {  // left the orthant (or landed on its boundary): stops at zero
+          if (x != 0.0 || xc != 0.0) cut = 1.0;
+          xc = 0.0;
+        }
+      }
+      const double gdn = matvec(xc, false);
+      double sv[4] = {0.0, 0.0, 0.0, 0.0};
+      if (mine) {
+        sv[0] = (xc - z0) * (g0 + 0.5 * gdn);
+        sv[2] = cut;
+        if (!isfinite(xc)) sv[3] = 1.0;
+      }
+      sv[1] = pen_part(xc);
+      block_sum<4>(sv, red);
+      if (sv[3] == 0.0 && sv[0] + sv[1] < m_old) {
+        moved = true;
+        projected = sv[2] > 0.0;
+        xn = xc;
+        tstep = tt;
+      } else {
+        tstep *= 0.5;
+      }
+    }
+    if (!moved) return -1;
+    if (want_mu && tstep == 1.0 && !projected) {  // H_FF is the Hessian on the face of the new point: its smallest
+      __syncthreads();                            // eigenvalue, two inverse-iteration steps from the step itself
+      *mu_out = nt_lambda_min(ntF, ntD, T, mp, nv, red, 2);
+    }
+    x = xn;
+    return 1;
+  };
+
   // ---- FISTA on the model ------------------------------------------------------------------------
   double L = Lw;
   double x = x_start, v = x_start, t = 1.0;
@@ -894,13 +1093,21 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   }
   bool ok = true;
   int n_inner = 0;
+  // smallest Rayleigh quotient <dv, G dv> / <dv, dv> along the moves of the iteration: an upper estimate
+  // of the smallest eigenvalue on the face that closes in as the slow modes come to dominate the moves
+  double rq_min = 0.0;
+  int rq_n = 0;
+  double mu_face = 0.0;       // from the factor of a direct step (0: none taken)
+  int since_direct = 0, n_direct = 0, n_direct_bad = 0;
+  bool direct_on = newton_capable;
   for (int it = 0; it < WS_INNER_MAX; ++it) {
     ++n_inner;
     const double gv = g0 + matvec(v, false);
     const double u = prox_w(v - gv / L, 1.0 / L);
     //  s[0] = ||u - v||^2  s[1] = ||u||^2  s[2] = (v - u).(u - x)  s[3] = #non-finite
     //  s[4] = ||v - v_prev||^2  s[5] = ||gv - gv_prev||^2   (curvature along the last move of v)
-    double s[6] = {0, 0, 0, 0, 0, 0};
+    //  s[6] = <v - v_prev, gv - gv_prev>
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};
     if (mine) {
       const double r = u - v;
       s[0] = r * r;
@@ -911,9 +1118,10 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
         const double dv = v - v_prev, dg = gv - gv_prev;
         s[4] = dv * dv;
         s[5] = dg * dg;
+        s[6] = dv * dg;
       }
     }
-    block_sum<6>(s, red);
+    block_sum<7>(s, red);
     if (s[3] > 0.0 || !isfinite(s[0])) {
       ok = false;
       break;
@@ -921,6 +1129,11 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     v_prev = v;
     gv_prev = gv;
     have_prev = true;
+    if (s[4] > 1e-20 * s[1] && s[4] > 0.0) {  // (a move at the rounding level measures nothing)
+      const double rq = s[6] / s[4];
+      if (rq > 0.0 && (rq_n == 0 || rq < rq_min)) rq_min = rq;
+      rq_n += 1;
+    }
     if (s[4] > 0.0 && sqrt(s[5] / s[4]) > L) {  // the step 1/L was too long: redo it from x
       L = 1.05 * sqrt(s[5] / s[4]);
       v = x;
@@ -935,6 +1148,24 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     x = u;
     t = t_new;
     if (sqrt(s[0]) <= WS_INNER_TOL * tol * sqrt(s[1])) break;
+    since_direct += 1;
+    if (direct_on && n_direct < WS_NEWTON_MAX &&
+        (since_direct >= (n_direct ? WS_NEWTON_AGAIN : WS_NEWTON_AFTER) ||
+         (n_direct == 0 && rq_n >= 5 && rq_min < WS_NEWTON_RQ * L))) {
+      double mu_new = 0.0;
+      const int rc = direct_step(x, L, &mu_new, mu_face == 0.0);
+      since_direct = 0;
+      n_direct += 1;
+      if (rc > 0) {
+        if (mu_new > 0.0) mu_face = mu_new;
+        v = x;
+        t = 1.0;
+        have_prev = false;
+      } else if (rc < 0) {
+        n_direct_bad += 1;
+        direct_on = false;  // singular face or a useless step: the iteration finishes the job
+      }
+    }
   }
   if (!ok) return;
   // accept only if the model says the refined point is no worse than the start
@@ -965,9 +1196,16 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     ctl->zzero = 0;
     ws->last_point[lane_id] = point_now;
     ws->repeats[lane_id] = reps + 1;
+    ws->last_cols[lane_id] = ws->Kreal;
     if (L > ws->Lw[set]) ws->Lw[set] = L;
     atomicAdd(&ws->refined, 1);
     atomicAdd(&ws->inner_iters, n_inner);
+    if (n_direct) atomicAdd(&ws->newton_steps, n_direct - n_direct_bad);
+    if (n_direct_bad) atomicAdd(&ws->newton_fails, n_direct_bad);
+    // strong convexity on the face of the refined point, for the stopping rule of the pass that verifies it
+    // (fista_tail_kernel): from the factor when a direct step stood, else from the iteration's own moves
+    // (halved: both are estimates from above); 0 = unknown.
+    ctl->mu = mu_face > 0.0 ? 0.5 * mu_face : (rq_n >= 3 ? 0.5 * rq_min : 0.0);
   }
 }
 

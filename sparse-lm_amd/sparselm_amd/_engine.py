@@ -41,7 +41,7 @@ FLAG_WORKING_SET = 32  # force the Gram-assisted refinement even for small X
 FLAG_NO_WORKING_SET = 64
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 3  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 4  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -66,11 +66,13 @@ ABI_SYMBOLS = (
     "slm_gradient",
     "slm_eval_sse",
     "slm_eval_sse_sparse",
+    "slm_dense_spd_solve",
     "slm_solve_path",
     "slm_solve_lanes",
     "slm_solve_path_lanes",
     "slm_comm_unique_id",
     "slm_comm_init",
+    "slm_comm_info",
     "slm_dataset_set_global_rows",
     "slm_comm_destroy",
 )
@@ -112,6 +114,8 @@ class _PointInfo(C.Structure):
         ("L", C.c_double),
         ("mode", C.c_int32),
         ("rejects", C.c_int32),
+        ("kkt", C.c_double),
+        ("mu", C.c_double),
     ]
 
 
@@ -127,6 +131,8 @@ class _SolveStats(C.Structure):
         ("ws_refined", C.c_int64),
         ("ws_misses", C.c_int64),
         ("ws_columns", C.c_int64),
+        ("ws_inner_iters", C.c_int64),
+        ("ws_direct_steps", C.c_int64),
     ]
 
 
@@ -149,7 +155,7 @@ MAX_LANES = 16
 # numpy views of the two per-point structs (no per-point Python objects on the way in or out)
 _INFO_DTYPE = np.dtype(
     [("n_iter", "<i4"), ("status", "<i4"), ("resid", "<f8"), ("beta_norm", "<f8"), ("loss", "<f8"), ("L", "<f8"),
-     ("mode", "<i4"), ("rejects", "<i4")]
+     ("mode", "<i4"), ("rejects", "<i4"), ("kkt", "<f8"), ("mu", "<f8")]
 )
 assert _INFO_DTYPE.itemsize == C.sizeof(_PointInfo) and C.sizeof(_PathPoint) == 32
 
@@ -221,6 +227,7 @@ def load_library():
             "slm_gradient": [vp, vp, vp, P(dbl), i32, P(dbl)],
             "slm_eval_sse": [vp, vp, i32, vp, vp],
             "slm_eval_sse_sparse": [vp, vp, i32, vp, i32, vp, vp],
+            "slm_dense_spd_solve": [vp, vp, i32, vp, vp, P(dbl)],
             "slm_solve_path": [
                 vp,
                 P(_PenaltyStruct),
@@ -239,6 +246,7 @@ def load_library():
             ],
             "slm_comm_unique_id": [vp],
             "slm_comm_init": [vp, i32, i32, vp],
+            "slm_comm_info": [vp, P(i32), P(i32)],
             "slm_dataset_set_global_rows": [vp, i64],
             "slm_comm_destroy": [vp],
         }
@@ -328,10 +336,42 @@ class PathResult:
     ws_refined: int = 0
     ws_misses: int = 0
     ws_columns: int = 0  # columns in the working set at the end
+    ws_inner_iters: int = 0  # proximal-gradient iterations of the model solver
+    ws_direct_steps: int = 0  # direct (Cholesky) steps of the model solver
+    kkt: np.ndarray | None = None  # (n_points,) KKT residual ||G(z)||_2 at exit
+    mu: np.ndarray | None = None  # (n_points,) strong-convexity estimate the point was accepted with
 
     @property
     def converged(self) -> bool:
         return bool(np.all(self.status == SLM_OK))
+
+
+def _path_result(betas, gn, infos, K, stats) -> PathResult:
+    return PathResult(
+        betas=betas,
+        group_norms=gn,
+        n_iter=infos["n_iter"].astype(np.int64),
+        status=infos["status"].astype(np.int64),
+        resid=infos["resid"].copy(),
+        beta_norm=infos["beta_norm"].copy(),
+        loss=infos["loss"].copy(),
+        mode=infos["mode"].astype(np.int64),
+        L=float(infos["L"][K - 1]),
+        grad_launches=int(stats.grad_launches),
+        grad_timed=int(stats.grad_timed),
+        grad_ms_total=float(stats.grad_ms_total),
+        wall_ms=float(stats.wall_ms),
+        lipschitz_ms=float(stats.lipschitz_ms),
+        ws_builds=int(stats.ws_builds),
+        ws_appends=int(stats.ws_appends),
+        ws_refined=int(stats.ws_refined),
+        ws_misses=int(stats.ws_misses),
+        ws_columns=int(stats.ws_columns),
+        ws_inner_iters=int(stats.ws_inner_iters),
+        ws_direct_steps=int(stats.ws_direct_steps),
+        kkt=infos["kkt"].copy(),
+        mu=infos["mu"].copy(),
+    )
 
 
 class Engine:
@@ -427,6 +467,28 @@ class Engine:
 
     def comm_destroy(self):
         _check(self._lib.slm_comm_destroy(self._h))
+
+    def comm_info(self) -> tuple[int, int]:
+        """(rank, ranks) of the communicator as RCCL reports them; (0, 1) without one."""
+        r, n = C.c_int32(), C.c_int32()
+        _check(self._lib.slm_comm_info(self._h, C.byref(r), C.byref(n)))
+        return int(r.value), int(n.value)
+
+    def comm_ranks(self) -> int:
+        return self.comm_info()[1]
+
+    # -- diagnostics ------------------------------------------------------------------------------
+    def dense_spd_solve(self, H, rhs):
+        """(H^-1 rhs, lambda_min estimate) by the model solver's one-workgroup Cholesky (m <= 512)."""
+        H = _f64(H, "H")
+        m = H.shape[0]
+        if H.shape != (m, m):
+            raise ValueError("H must be square")
+        rhs = _f64(rhs, "rhs", (m,))
+        x = np.empty(m)
+        mu = C.c_double()
+        _check(self._lib.slm_dense_spd_solve(self._h, _ptr(H), m, _ptr(rhs), _ptr(x), C.byref(mu)))
+        return x, mu.value
 
 
 class Dataset:
@@ -598,32 +660,7 @@ class Dataset:
         opts = _SolveOpts(float(tol), int(max_iter), int(check_every), float(L), int(flags))
         stats = _SolveStats()
         _check(self._lib.slm_solve_lanes(self._h, clanes, nl, C.byref(opts), C.byref(stats)))
-        results = []
-        for betas, gn, infos, K in outs:
-            results.append(
-                PathResult(
-                    betas=betas,
-                    group_norms=gn,
-                    n_iter=infos["n_iter"].astype(np.int64),
-                    status=infos["status"].astype(np.int64),
-                    resid=infos["resid"].copy(),
-                    beta_norm=infos["beta_norm"].copy(),
-                    loss=infos["loss"].copy(),
-                    mode=infos["mode"].astype(np.int64),
-                    L=float(infos["L"][K - 1]),
-                    grad_launches=int(stats.grad_launches),
-                    grad_timed=int(stats.grad_timed),
-                    grad_ms_total=float(stats.grad_ms_total),
-                    wall_ms=float(stats.wall_ms),
-                    lipschitz_ms=float(stats.lipschitz_ms),
-                    ws_builds=int(stats.ws_builds),
-                    ws_appends=int(stats.ws_appends),
-                    ws_refined=int(stats.ws_refined),
-                    ws_misses=int(stats.ws_misses),
-                    ws_columns=int(stats.ws_columns),
-                )
-            )
-        return results
+        return [_path_result(betas, gn, infos, K, stats) for betas, gn, infos, K in outs]
 
     def solve_path(
         self,
@@ -677,27 +714,7 @@ class Dataset:
                 _as(infos, _PointInfo), C.byref(stats),
             )
         )
-        return PathResult(
-            betas=betas,
-            group_norms=gn,
-            n_iter=infos["n_iter"].astype(np.int64),
-            status=infos["status"].astype(np.int64),
-            resid=infos["resid"].copy(),
-            beta_norm=infos["beta_norm"].copy(),
-            loss=infos["loss"].copy(),
-            mode=infos["mode"].astype(np.int64),
-            L=float(infos["L"][K - 1]),
-            grad_launches=int(stats.grad_launches),
-            grad_timed=int(stats.grad_timed),
-            grad_ms_total=float(stats.grad_ms_total),
-            wall_ms=float(stats.wall_ms),
-            lipschitz_ms=float(stats.lipschitz_ms),
-            ws_builds=int(stats.ws_builds),
-            ws_appends=int(stats.ws_appends),
-            ws_refined=int(stats.ws_refined),
-            ws_misses=int(stats.ws_misses),
-            ws_columns=int(stats.ws_columns),
-        )
+        return _path_result(betas, gn, infos, K, stats)
 
 
 # -- default engine per process / device ------------------------------------------------------------

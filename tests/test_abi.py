@@ -3,6 +3,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -25,16 +26,61 @@ def test_library_exports_every_declared_symbol():
     lib = _engine.load_library()
     for name in _declared_functions():
         assert hasattr(lib, name), name
-    assert lib.slm_abi_version() == 3
+    header = open(os.path.join(ROOT, "include", "slm_engine.h")).read()
+    version = int(re.search(r"#define\s+SLM_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.slm_abi_version() == version == _engine.ABI_VERSION
 
 
-def test_struct_layouts_match_header():
-    # sizes the C side uses (checked against natural alignment of the header's structs)
-    assert ctypes.sizeof(_engine._PathPoint) == 32
-    assert ctypes.sizeof(_engine._SolveOpts) == 32
-    assert ctypes.sizeof(_engine._PointInfo) == 48
-    assert ctypes.sizeof(_engine._SolveStats) == 80
-    assert ctypes.sizeof(_engine._PenaltyStruct) == 24
+# every struct of the header with the ctypes class that mirrors it
+_STRUCTS = {
+    "slm_penalty": "_PenaltyStruct",
+    "slm_path_point": "_PathPoint",
+    "slm_solve_opts": "_SolveOpts",
+    "slm_point_info": "_PointInfo",
+    "slm_solve_stats": "_SolveStats",
+    "slm_lane": "_Lane",
+}
+
+
+def _header_layout(tmp_path):
+    """sizeof / offsetof of every field of every struct, as the C compiler lays the header out."""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "slm_engine.h")).read(), flags=re.S)
+    fields = {}
+    for name in _STRUCTS:
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S).group(1)
+        fields[name] = [re.search(r"(\w+)\s*$", part.strip()).group(1)
+                        for decl in body.split(";") if decl.strip() for part in decl.split(",")]
+    lines = ["#include <stddef.h>", "#include <stdio.h>", '#include "slm_engine.h"', "int main(void) {"]
+    for name, flds in fields.items():
+        lines.append(f'  printf("{name} size %zu\\n", sizeof({name}));')
+        for f in flds:
+            lines.append(f'  printf("{name} {f} %zu\\n", offsetof({name}, {f}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    layout = {}
+    for line in out.splitlines():
+        name, field, value = line.split()
+        layout.setdefault(name, {})[field] = int(value)
+    return layout, fields
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """Field order, offsets and sizes of the ctypes mirrors against the header itself (compiled with gcc)."""
+    layout, fields = _header_layout(tmp_path)
+    for name, cls_name in _STRUCTS.items():
+        cls = getattr(_engine, cls_name)
+        assert [f[0] for f in cls._fields_] == fields[name], name
+        assert ctypes.sizeof(cls) == layout[name]["size"], name
+        for f in fields[name]:
+            assert getattr(cls, f).offset == layout[name][f], (name, f)
+    # the numpy view of slm_point_info used on the way out
+    assert _engine._INFO_DTYPE.itemsize == layout["slm_point_info"]["size"]
+    for f in fields["slm_point_info"]:
+        assert _engine._INFO_DTYPE.fields[f][1] == layout["slm_point_info"][f], f
 
 
 def test_no_cpu_fallback_without_device():
