@@ -185,6 +185,28 @@ def cvxpy_leg(X, y, alphas, gpu_betas, n_red=10_000, p_red=500, cap_s=60.0):
 # ---------------------------------------------------------------------------------------------------
 # extra legs (all ranks; after the timed region; never part of `value`)
 # ---------------------------------------------------------------------------------------------------
+class StdoutToStderr:
+    """File descriptor 1 points at stderr for the duration: RCCL prints a version banner to stdout when a
+    communicator is created, and stdout carries the ONE contract line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        try:  # the banner sits in the C library's buffer (stdout is a pipe): push it out while fd 1 is still stderr
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 class Watchdog:
     """Hard stop for a leg that might hang in a collective: past the limit, rank 0 prints the line it
     already holds (with the leg marked as timed out) and every rank leaves through os._exit, so a stuck
@@ -514,17 +536,20 @@ def main():
         if out is not None:
             out["extra_legs"] = legs
 
+        real_stdout = os.dup(1)  # (a leg may have fd 1 pointing at stderr when the limit strikes)
+
         def expire():
             if out is not None:
                 legs["timed_out_after_s"] = args.extra_timeout
-                print(json.dumps(out), flush=True)
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
             os._exit(0)
 
         with Watchdog(args.extra_timeout, expire):
             for name, fn in (("config4_grid", lambda: leg_config4_grid(eng, rank, world, n, p)),
                              ("rowshard", lambda: leg_rowshard(eng, rank, world, args.rowshard_rows, args.rowshard_cols))):
                 try:
-                    mine = {"ok": True, **fn()}
+                    with StdoutToStderr():
+                        mine = {"ok": True, **fn()}
                 except Exception as exc:  # a leg never breaks the contract line
                     mine = {"ok": False, "error": repr(exc)[:300]}
                 if use_dist:

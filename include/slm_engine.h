@@ -280,7 +280,11 @@ int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, const slm_path
                          const double* beta0, double* betas_out, double* group_norms_out,
                          slm_point_info* infos, slm_solve_stats* stats);
 
-/* ---- row-sharded mode (very tall X split by rows over ranks; one all-reduce per iteration) ---- */
+/* ---- row-sharded mode (very tall X split by rows over ranks) ----------------------------------------
+ * Every rank holds a block of rows and runs the whole state machine; per pass the ranks all-reduce the
+ * lanes' gradients (ld + 16 doubles each), a 16-double stop vector, and -- in working-set solves -- the
+ * staged Gram parts.  slm_dataset_center all-reduces the weighted sums and X^T w, so the global means are
+ * subtracted.  HBM per rank: X plus, in working-set solves, its column-major copy (2 x 8 n p bytes). */
 #define SLM_COMM_ID_BYTES 128
 /* Rank 0 creates the id and distributes the 128 bytes to the other ranks out of band. */
 int slm_comm_unique_id(uint8_t id_out[SLM_COMM_ID_BYTES]);
@@ -290,6 +294,18 @@ int slm_comm_init(slm_engine* eng, int32_t rank, int32_t n_ranks,
                   const uint8_t id[SLM_COMM_ID_BYTES]);
 /* Rank and size of the engine's communicator as RCCL reports them (1 rank, rank 0 without one). */
 int slm_comm_info(slm_engine* eng, int32_t* rank_out, int32_t* n_ranks_out);
+/* All-reduces this engine has entered since its communicator was created: ranks of one job must agree
+   on it at every quiescent point (the row-sharded state machine takes its stop decision from a word the
+   ranks all-reduce after every pass, so that they do whatever their own states say). */
+int slm_comm_collectives(slm_engine* eng, int64_t* count_out);
+/*
+ * In-process communicator: the n_ranks engines (one process, ONE device, each driven by its own host
+ * thread) become the ranks of a row-sharded job; the all-reduce is a rendezvous of their streams with the
+ * staged buffers added in rank order.  For single-GPU boxes, where RCCL cannot form a group of several
+ * ranks, and for the tests of the multi-rank state machine; a rank that fails to enter a collective within
+ * timeout_s (<= 0: 30 s) fails it with SLM_ERR_COMM on the others instead of hanging them.
+ */
+int slm_comm_init_local(slm_engine** engines, int32_t n_ranks, double timeout_s);
 /* n_global replaces n in the 1/n (gradient) and 1/(2n) (loss) scaling: the global row count of a
    row-sharded matrix, or the number of unmasked rows when row weights act as a CV-fold mask. */
 int slm_dataset_set_global_rows(slm_dataset* ds, int64_t n_global);

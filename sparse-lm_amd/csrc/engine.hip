@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -161,7 +163,10 @@ static const GradKernel kGradTwoPass = {8, 4, 2, 1, -1, nullptr};
 static const int kTwoPassC = 4;  // column tile of xtr_kernel: 512 * 4 chunks = 4096 columns
 
 // Split pass (split_kernels.hpp) for working-set solves: sixteen lanes per read of X.  The table is for
-// rowdot_ring_kernel (rows of up to 5120 columns, D rows in flight as for the fused ring kernel).
+// rowdot_ring_kernel (rows of up to 5120 columns, D rows in flight as for the fused ring kernel); rows of
+// 5 121 ... 10 240 columns (BASELINE config 5: p = 10 000) have no ring variant -- their LDS ring would not
+// fit -- and take every residual that needs X from rowdot_mfma_kernel, which has no column limit but needs
+// the column-major copy of X (`rowdot == nullptr`: the split pass is then only used when that copy exists).
 struct SplitKernel {
   int W, C, B, D;
   void (*rowdot)(SplitArgs);
@@ -169,7 +174,8 @@ struct SplitKernel {
 };
 #define SLM_SK(C, D)                                                                                   \
   {8, C, SPLIT_LANES, D, rowdot_ring_kernel<8, C, ROWDOT_LANES, D>, resid_ws_kernel<SPLIT_LANES>}
-static const SplitKernel kSplit[] = {SLM_SK(1, 3), SLM_SK(2, 3), SLM_SK(3, 3), SLM_SK(4, 3), SLM_SK(5, 2)};
+static const SplitKernel kSplit[] = {SLM_SK(1, 3), SLM_SK(2, 3), SLM_SK(3, 3), SLM_SK(4, 3), SLM_SK(5, 2),
+                                     {8, 10, SPLIT_LANES, 0, nullptr, resid_ws_kernel<SPLIT_LANES>}};
 static const SplitKernel* pick_split_kernel(int64_t p2) {
   const char* env = getenv("SLM_SPLIT");
   if (env && env[0] == '0') return nullptr;
@@ -223,17 +229,104 @@ static const GradKernel* pick_grad_kernel(int64_t p2, int B) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// handles
+// In-process communicator (slm_comm_init_local): the engines of ONE process on ONE device form the ranks
+// of a row-sharded job, each driven by its own host thread.  The all-reduce is a rendezvous of their
+// streams -- every rank copies its buffer into a staging area, the host threads meet, every rank waits for
+// the others' copies (events) and adds the staged buffers in rank order, so all ranks get identical bits,
+// like the ring all-reduce RCCL runs between GPUs.  It exists so that the multi-rank state machine (stop
+// agreement, Gram exchange, sharded centring) can run -- and be tested -- where RCCL cannot form a group:
+// several ranks on one GPU.  A rank that does not show up within `timeout_s` fails the collective with
+// SLM_ERR_COMM on the ranks that did: mismatched collective counts are an error report, not a hang.
 // ------------------------------------------------------------------------------------------------
+struct LocalComm {
+  static const int kMaxRanks = 8;
+  int n_ranks = 0;
+  int device = 0;
+  size_t cap = 0;                   // doubles per rank of staging
+  double* stage[kMaxRanks] = {};    // device
+  hipEvent_t ready[kMaxRanks][2] = {};     // rank r's copy of round k (parity k & 1) is in its staging area
+  hipEvent_t consumed[kMaxRanks][2] = {};  // rank r has finished reading every staging area of round k
+  std::mutex m;
+  std::condition_variable cv;
+  long arrived[2] = {0, 0};         // host threads that have recorded `ready` / `consumed` for the round
+  long round_of[kMaxRanks] = {};    // collectives each rank has entered
+  int refs = 0;
+  double timeout_s = 30.0;
+};
+
 struct slm_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   hipDeviceProp_t prop;
   int cus = 0;
-  // row-sharded mode
+  // row-sharded mode: RCCL communicator, or the in-process one
   rcclComm_t comm = nullptr;
+  LocalComm* local = nullptr;
   int rank = 0, n_ranks = 1;
+  long collectives = 0;  // all-reduces this engine has entered (diagnostics, slm_comm_info)
+  bool sharded() const { return comm != nullptr || local != nullptr; }
 };
+
+__global__ void local_sum_kernel(double* out, const double* const* stage, int n_ranks, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    double t = stage[0][i];
+    for (int r = 1; r < n_ranks; ++r) t += stage[r][i];  // fixed order: every rank gets the same bits
+    out[i] = t;
+  }
+}
+
+static int fail(int code, const char* fmt, ...);
+
+// host threads of all ranks meet; returns false on timeout
+static bool local_meet(LocalComm* lc, int phase, long round) {
+  std::unique_lock<std::mutex> lk(lc->m);
+  lc->arrived[phase] += 1;
+  const long want = (round + 1) * lc->n_ranks;
+  lc->cv.notify_all();
+  return lc->cv.wait_for(lk, std::chrono::duration<double>(lc->timeout_s), [&] { return lc->arrived[phase] >= want; });
+}
+
+// sum `count` doubles at `buf` (device) over the ranks, in place, on the engine's stream
+static int all_reduce_sum(slm_engine* eng, double* buf, size_t count) {
+  hipStream_t s = eng->stream;
+  eng->collectives += 1;
+  if (eng->comm) {
+    const int e = g_rccl.AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, eng->comm, s);
+    if (e != 0) return fail(SLM_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "rccl error");
+    return SLM_OK;
+  }
+  LocalComm* lc = eng->local;
+  if (!lc) return SLM_OK;
+  if (count > lc->cap) return fail(SLM_ERR_COMM, "in-process all-reduce of %zu doubles exceeds the staging area (%zu)", count, lc->cap);
+  const int r = eng->rank;
+  const long round = lc->round_of[r]++;
+  const int par = (int)(round & 1);
+  hipError_t e = hipSuccess;
+  // my staging area is free once every rank has consumed the round before the previous one of this parity
+  if (round >= 2)
+    for (int q = 0; q < lc->n_ranks && e == hipSuccess; ++q) e = hipStreamWaitEvent(s, lc->consumed[q][par], 0);
+  if (e == hipSuccess) e = hipMemcpyAsync(lc->stage[r] + (size_t)par * lc->cap, buf, sizeof(double) * count, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipEventRecord(lc->ready[r][par], s);
+  if (e != hipSuccess) return fail(SLM_ERR_HIP, "in-process all-reduce (stage): %s", hipGetErrorString(e));
+  if (!local_meet(lc, 0, round))
+    return fail(SLM_ERR_COMM, "in-process all-reduce %ld: a rank did not arrive within %.0f s (mismatched collective counts?)",
+                round, lc->timeout_s);
+  for (int q = 0; q < lc->n_ranks && e == hipSuccess; ++q)
+    if (q != r) e = hipStreamWaitEvent(s, lc->ready[q][par], 0);
+  if (e == hipSuccess) {
+    // (pointer table of this parity lives behind the staging areas of rank 0)
+    const double* const* tab = reinterpret_cast<const double* const*>(lc->stage[0] + 2 * lc->cap) + (size_t)par * LocalComm::kMaxRanks;
+    const int blocks = (int)std::min<size_t>(256, (count + 255) / 256);
+    hipLaunchKernelGGL(local_sum_kernel, dim3(blocks), dim3(256), 0, s, buf, tab, lc->n_ranks, count);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipEventRecord(lc->consumed[r][par], s);
+  if (e != hipSuccess) return fail(SLM_ERR_HIP, "in-process all-reduce (sum): %s", hipGetErrorString(e));
+  // (the `consumed` events of this round must exist before any rank waits on them two rounds from now)
+  if (!local_meet(lc, 1, round))
+    return fail(SLM_ERR_COMM, "in-process all-reduce %ld: a rank did not finish within %.0f s", round, lc->timeout_s);
+  return SLM_OK;
+}
 
 static const int kMaxLanes = SLM_MAX_LANES;
 
@@ -242,7 +335,9 @@ struct GlobalCtl {
   int32_t done;        // every lane finished, or abort
   int32_t lanes_done;
   int32_t hard;        // most passes any lane has spent on one path point so far (TailArgs::gdone[2])
-  int32_t pad_;
+  int32_t done_local;  // row-sharded mode: this rank has finished (TailArgs::gdone[3]); `done` follows once all have
+  int32_t diverged;    // row-sharded mode: the ranks' control blocks differ (TailArgs::gdone[4]); ends the solve
+  int32_t pad_[3];
 };
 static const int kWsLateIters = 24;  // passes on one point after which a small problem gets the working set
 
@@ -265,6 +360,7 @@ struct slm_dataset {
   int32_t *ws_idx = nullptr, *ws_pos = nullptr, *ws_gs = nullptr, *ws_gl = nullptr;
   double *ws_score = nullptr, *ws_XW = nullptr, *ws_part = nullptr, *ws_G = nullptr, *ws_Gx = nullptr;
   double* ws_nt = nullptr;  // [kMaxLanes][NT_SCRATCH] factors of the model solver's direct steps
+  double* stop_words = nullptr;  // [STOP_WORDS] row-sharded mode: the vector the ranks all-reduce after every pass
   double* XT = nullptr;  // column-major copy of X for the column gathers ([ld][ldt]), built on first use
   int64_t ldt = 0;
   bool XT_ready = false, XT_failed = false;
@@ -369,7 +465,7 @@ extern "C" int slm_comm_destroy(slm_engine* eng);
 extern "C" int slm_engine_destroy(slm_engine* eng) {
   if (!eng) return SLM_OK;
   (void)hipSetDevice(eng->device);
-  if (eng->comm) (void)slm_comm_destroy(eng);
+  if (eng->sharded()) (void)slm_comm_destroy(eng);
   if (eng->stream) (void)hipStreamDestroy(eng->stream);
   delete eng;
   return SLM_OK;
@@ -413,7 +509,7 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->pts); dfree(ds->betas_out); dfree(ds->gn_out); dfree(ds->infos);
   dfree(ds->ws_ctl); dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
   dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
-  dfree(ds->ws_nt);
+  dfree(ds->ws_nt); dfree(ds->stop_words);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   for (auto& e : ds->ev)
     if (e) (void)hipEventDestroy(e);
@@ -809,10 +905,8 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
     ra.loss_scale[l] = 0.5 / ne;
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(ds->ld / 16 + 1), B), dim3(256), 0, s, ra);
-  if (ds->eng->comm) {  // also with one rank: keeps the RCCL path exercised on a single GPU
-    RCCL_TRY(g_rccl.AllReduce(ds->g, ds->g, (size_t)B * (size_t)(ds->ld + 16), kNcclFloat64, kNcclSum,
-                              ds->eng->comm, s));
-  }
+  if (ds->eng->sharded())  // also with one rank: keeps the RCCL path exercised on a single GPU
+    SLM_TRY(all_reduce_sum(ds->eng, ds->g, (size_t)B * (size_t)(ds->ld + 16)));
   return SLM_OK;
 }
 
@@ -827,15 +921,25 @@ static void launch_rowdot(slm_dataset* ds, const SplitKernel* sk, int nblk, int 
   // Measured at n = 100k, p = 5k (tools/rowdot_probe.py): matrix cores 0.75-0.80 ms whatever the lane count;
   // vector kernel 0.62 ms for one lane, 0.81 ms for five, 3.1 ms for sixteen (four reads of X).
   const char* env = getenv("SLM_ROWDOT_RING");
-  const bool ring = env ? env[0] == '1' : B <= ROWDOT_LANES;
+  const bool ring = sk->rowdot != nullptr && (env ? env[0] == '1' : B <= ROWDOT_LANES);
   a.lane0 = 0;
-  if (!ring && ds->XT && ds->XT_ready) {
+  if ((!ring || sk->rowdot == nullptr) && ds->XT && ds->XT_ready) {
     a.XT = ds->XT;
     a.ldt = ds->ldt;
     hipLaunchKernelGGL(rowdot_mfma_kernel, dim3(nblk), dim3(XZ_WAVES * 64), 0, s, a);
-  } else {
+  } else if (sk->rowdot != nullptr) {
     hipLaunchKernelGGL(sk->rowdot, dim3(nblk, (B + ROWDOT_LANES - 1) / ROWDOT_LANES), dim3(sk->W * 64), 0, s, a);
   }
+  // (no ring variant and no column-major copy: split_usable() keeps such datasets off the split pass)
+}
+
+// The split pass needs a kernel for the residuals that come from X: a ring variant, or the column-major copy.
+static int ensure_xt(slm_dataset* ds);
+static bool split_usable(slm_dataset* ds) {
+  if (!ds->sk) return false;
+  if (ds->sk->rowdot != nullptr) return true;
+  if (ensure_xt(ds) != SLM_OK) return false;
+  return ds->XT != nullptr;
 }
 
 static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done,
@@ -882,10 +986,8 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
     ra.loss_scale[l] = 0.5 / ne;
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(ds->ld / 16 + 1), ls.B), dim3(256), 0, s, ra);
-  if (ds->eng->comm) {  // row-sharded: sum the gradients (and losses) of the row blocks over ranks
-    RCCL_TRY(g_rccl.AllReduce(ds->g, ds->g, (size_t)ls.B * (size_t)(ds->ld + 16), kNcclFloat64, kNcclSum,
-                              ds->eng->comm, s));
-  }
+  if (ds->eng->sharded())  // row-sharded: sum the gradients (and losses) of the row blocks over ranks
+    SLM_TRY(all_reduce_sum(ds->eng, ds->g, (size_t)ls.B * (size_t)(ds->ld + 16)));
   return SLM_OK;
 }
 
@@ -951,7 +1053,7 @@ static int power_iteration(slm_dataset* ds, const LaneSetup& ls_in, double* L_ou
     if (ds->gk[ls.B - 1]) {
       SLM_TRY(enqueue_gradient(ds, ls, ds->yzero, nullptr, nullptr, nullptr, n_rows));
     } else {  // more lanes than the fused kernels serve (working-set solves): the split pass has ten
-      if (!ds->sk) return fail(SLM_ERR_UNSUPPORTED, "no %d-lane kernel for p = %lld", ls.B, (long long)ds->p);
+      if (!split_usable(ds)) return fail(SLM_ERR_UNSUPPORTED, "no %d-lane kernel for p = %lld", ls.B, (long long)ds->p);
       SLM_TRY(enqueue_gradient_split(ds, ls, ds->yzero, nullptr, nullptr, nullptr, nullptr, nullptr, n_rows));
     }
     PowerArgs pa;
@@ -1000,12 +1102,14 @@ extern "C" int slm_dataset_lipschitz(slm_dataset* ds, double* L_out) {
 // ------------------------------------------------------------------------------------------------
 extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y_mean_out) {
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
-  if (ds->eng->comm) return fail(SLM_ERR_UNSUPPORTED, "centring a row-sharded dataset is not implemented");
   HIP_TRY(hipSetDevice(ds->eng->device));
   hipStream_t s = ds->eng->stream;
   const int64_t n = ds->n, p = ds->p, ld = ds->ld;
-  // sum w, sum w y
+  // sum w, sum w y -- of ALL rows: a row-sharded dataset adds its ranks' sums here and its ranks' X_r^T w_r
+  // in the gradient launch below (one all-reduce each), so every rank subtracts the global means
+  // (reference model/_base.py:216-222 on the whole matrix)
   hipLaunchKernelGGL(weighted_sums_kernel, dim3(1), dim3(1024), 0, s, ds->y, ds->rw, n, ds->lambda);
+  if (ds->eng->sharded()) SLM_TRY(all_reduce_sum(ds->eng, ds->lambda, 2));
   double sums[2] = {0.0, 0.0};
   HIP_TRY(hipMemcpyAsync(sums, ds->lambda, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1045,7 +1149,7 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
   HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * ds->ld, s));
   if (z) HIP_TRY(hipMemcpyAsync(ds->z, z, sizeof(double) * ds->p, hipMemcpyHostToDevice, s));
   const char* split_env = getenv("SLM_GRAD_SPLIT");  // tests: take the split pass (residuals from X)
-  const bool use_split = split_env && split_env[0] == '1' && ds->sk != nullptr;
+  const bool use_split = split_env && split_env[0] == '1' && split_usable(ds);
   if (use_split) SLM_TRY(ensure_xt(ds));  // (so that tests and probes reach rowdot_mfma_kernel; optional copy)
   if (use_split) SLM_TRY(enqueue_gradient_split(ds, ls, ds->y, nullptr, nullptr, nullptr, nullptr, nullptr));
   else SLM_TRY(enqueue_gradient(ds, ls, ds->y, nullptr, nullptr, nullptr));
@@ -1292,8 +1396,8 @@ static int ws_policy(const slm_dataset* ds, uint32_t flags) {
 }
 // most lanes one solve can run: the fused kernels' table, or the split pass's sixteen when the working
 // set is on from the start
-static int max_lanes_for(const slm_dataset* ds, uint32_t flags) {
-  if (ds->sk && (ws_policy(ds, flags) == 2 || (double)ds->n * (double)ds->ld >= 67108864.0)) return SPLIT_LANES;
+static int max_lanes_for(slm_dataset* ds, uint32_t flags) {
+  if ((ws_policy(ds, flags) == 2 || (double)ds->n * (double)ds->ld >= 67108864.0) && split_usable(ds)) return SPLIT_LANES;
   int B = kMaxLanes;
   while (B > 1 && !ds->gk[B - 1]) --B;
   return B;
@@ -1310,8 +1414,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // -- the latter also without the working set when X is large: sixteen lanes on the two matrix-core halves
   // (two reads of X per pass) move more problems per byte than four on the fused kernel (one read)
   const bool big_x = (double)ds->n * (double)ds->ld >= 67108864.0;
-  const bool split = ds->sk != nullptr && (ws_policy(ds, opts ? opts->flags : 0u) == 2 ? (big_x || !ds->gk[B - 1])
-                                                                                      : (big_x && !ds->gk[B - 1]));
+  // (rows beyond 5120 columns have no ring variant for the residuals that need X: every such residual is a
+  //  second full read, of the column-major copy -- the split pass is worth it there only for more lanes than
+  //  the fused kernel serves: measured on config 5's shape, one lane, 2.9 ms per pass against 2.4 ms fused)
+  const bool wide = ds->sk != nullptr && ds->sk->rowdot == nullptr;
+  const bool want_split = (ws_policy(ds, opts ? opts->flags : 0u) == 2 && !wide) ? (big_x || !ds->gk[B - 1]) : (big_x && !ds->gk[B - 1]);
+  const bool split = want_split && split_usable(ds);
   // Shared path with the working set on from the start: the lanes take the points of the path in turn
   // (lane l: l, l + B, ...) instead of contiguous ranges.  Every lane then starts near alpha_max, where
   // the first working set (chosen from the gradient at zero) is enough, and all lanes move down the
@@ -1503,6 +1611,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   ta.ctl = ds->ctl;
   ta.gdone = reinterpret_cast<int*>(ds->gctl);
   ta.n_lanes = B;
+  ta.done_slot = eng->sharded() ? 3 : 0;
   ta.steal = (shared_path && !interleave) ? 1 : 0;  // interleaved lanes are balanced by construction
   ta.pts = ds->pts;
   ta.p = (int)p;
@@ -1539,8 +1648,10 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   {
     const int pol = ws_policy(ds, o.flags);
     use_ws = pol == 2;
-    ws_late = pol == 1;
+    // (row-sharded: the switch would change the collectives of a pass on the strength of one rank's state)
+    ws_late = pol == 1 && !eng->sharded();
   }
+  if (eng->sharded() && !ds->stop_words) SLM_TRY(dalloc(&ds->stop_words, STOP_WORDS));
   auto ws_setup = [&]() -> int {
     // lanes with the same row weights (same host pointer: the folds of a CV grid) and the same 1/n
     // scaling share one Gram
@@ -1569,7 +1680,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (ds->ws_sets < n_sets) {
       dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
       ds->ws_sets = 0;
-      if (eng->comm) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)n_sets * WS_KCAP * WS_KCAP));
+      if (eng->sharded()) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)n_sets * WS_KCAP * WS_KCAP));
       SLM_TRY(dalloc(&ds->ws_part, (size_t)ws_nblk * n_sets * WS_KCAP * WS_KCAP));  // (ws_nblk depends on n only)
       SLM_TRY(dalloc(&ds->ws_G, (size_t)n_sets * WS_KCAP * WS_KCAP));
       ds->ws_sets = n_sets;
@@ -1589,8 +1700,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     wa.idx = ds->ws_idx; wa.pos = ds->ws_pos; wa.gs = ds->ws_gs; wa.gl = ds->ws_gl;
     wa.score = ds->ws_score; wa.XW = ds->ws_XW; wa.part = ds->ws_part; wa.Gm = ds->ws_G;
     wa.nt = getenv("SLM_NO_DIRECT") ? nullptr : ds->ws_nt;
-    if (eng->comm && !ds->ws_Gx) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)ds->ws_sets * WS_KCAP * WS_KCAP));
-    wa.Gx = eng->comm ? ds->ws_Gx : nullptr;  // row-sharded: Gram parts are summed over ranks before use
+    if (eng->sharded() && !ds->ws_Gx) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)ds->ws_sets * WS_KCAP * WS_KCAP));
+    wa.Gx = eng->sharded() ? ds->ws_Gx : nullptr;  // row-sharded: Gram parts are summed over ranks before use
     wa.X = ds->X; wa.XT = ds->XT; wa.ldt = ds->ldt; wa.n = n; wa.ld = ld;
     wa.rw = ls.rw; wa.rw_stride = ls.rw_stride;
     for (int l = 0; l < kMaxLanes; ++l) {
@@ -1646,6 +1757,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   auto enqueue_after_gradient = [&]() {
     launch_tail(ta, s);
     if (shared_path && !interleave) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
+    if (eng->sharded()) {  // the ranks agree on "finished" before anything acts on it
+      hipLaunchKernelGGL(stop_pack_kernel, dim3(1), dim3(64), 0, s, ta.gdone, ds->ctl, B, ds->stop_words);
+      if (ws_comm_rc == 0) ws_comm_rc = all_reduce_sum(eng, ds->stop_words, STOP_WORDS);
+      hipLaunchKernelGGL(stop_apply_kernel, dim3(1), dim3(64), 0, s, ta.gdone, ds->stop_words);
+    }
     if (use_ws) {
       {
         const int bs = ds->singleton ? 256 : 64;
@@ -1663,8 +1779,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       if (wa.Gx) {
         // one collective per pass on every rank whether or not a build is under way: the ranks run the
         // same state machine on the same all-reduced gradients, so they agree on when that is
-        ws_comm_rc = g_rccl.AllReduce(wa.Gx, wa.Gx, (size_t)wa.n_sets * WS_KCAP * WS_KCAP, kNcclFloat64, kNcclSum,
-                                      eng->comm, s);
+        if (ws_comm_rc == 0) ws_comm_rc = all_reduce_sum(eng, wa.Gx, (size_t)wa.n_sets * WS_KCAP * WS_KCAP);
         hipLaunchKernelGGL(ws_publish_kernel, dim3(WS_KCAP * WS_KCAP / 256, (unsigned)wa.n_sets), dim3(256), 0, s,
                            wa);
       }
@@ -1700,7 +1815,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   bool use_graph = false;
   {
     const char* env = getenv("SLM_GRAPH");
-    if (env && env[0] == '1' && !profile && !eng->comm && chunk >= 4) {
+    if (env && env[0] == '1' && !profile && !eng->sharded() && chunk >= 4) {
       use_graph = true;
       for (int k = 0; k < 2 && use_graph; ++k) {
         hipGraph_t graph = nullptr;
@@ -1772,7 +1887,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         ++enq;
       }
       SLM_TRY(check_launch());
-      if (ws_comm_rc != 0) return fail(SLM_ERR_COMM, "ncclAllReduce of the working-set Gram failed (%d)", ws_comm_rc);
+      if (ws_comm_rc != 0) return ws_comm_rc;  // (all_reduce_sum has set the message)
       HIP_TRY(hipMemcpyAsync(&ds->hctl[slot].g, ds->gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipEventRecord(ds->ev[slot], s));
@@ -1803,6 +1918,13 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   }
   HIP_TRY(hipStreamSynchronize(s));
   tr[3] = t_mark();
+  if (eng->sharded()) {
+    GlobalCtl gfin;
+    HIP_TRY(hipMemcpy(&gfin, ds->gctl, sizeof(gfin), hipMemcpyDeviceToHost));
+    if (gfin.diverged)
+      return fail(SLM_ERR_COMM, "row-sharded solve aborted: the ranks' solver states differ (different arguments on "
+                  "different ranks, or an all-reduce that is not bit-identical on every rank)");
+  }
   PathCtl fin[SLM_MAX_LANES];
   HIP_TRY(hipMemcpy(fin, ds->ctl, sizeof(PathCtl) * B, hipMemcpyDeviceToHost));
   int64_t passes = 0;
@@ -1866,10 +1988,32 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       stats->ws_columns = wc.Kreal;
       stats->ws_inner_iters = wc.inner_iters;
       stats->ws_direct_steps = wc.newton_steps;
-      if (const char* trc = getenv("SLM_TRACE"))
-        if (trc[0] == '2')
-          fprintf(stderr, "[slm] working set: %d model-solver iterations over %d refinements, %d direct steps (%d refused, %d of them not positive definite), K = %d\n",
-                  wc.inner_iters, wc.refined, wc.newton_steps, wc.newton_fails, wc.newton_nopd, wc.K);
+      const char* trc = getenv("SLM_TRACE");
+      if (trc && trc[0] == '2') {
+        fprintf(stderr, "[slm] working set: %d model-solver iterations over %d refinements, %d direct steps (%d refused, %d of them not positive definite), K = %d\n",
+                wc.inner_iters, wc.refined, wc.newton_steps, wc.newton_fails, wc.newton_nopd, wc.K);
+        if (wc.newton_factors) {
+          fprintf(stderr, "[slm] direct steps: accepted at t = 1: %d, 1/2: %d, 1/4: %d, first sign change: %d; %d factorisations, %.0f unknowns on average\n",
+                  wc.newton_trial[0], wc.newton_trial[1], wc.newton_trial[2], wc.newton_trial[3], wc.newton_factors,
+                  (double)wc.newton_unknowns / wc.newton_factors);
+          fprintf(stderr, "[slm] direct steps without a usable segment: t = 0: %d, slope <= 0: %d, curvature <= 0: %d; no decrease on it: %d\n",
+                  wc.newton_ref[0], wc.newton_ref[1], wc.newton_ref[2], wc.newton_ref[3]);
+          int worst = 0;
+          double worst_ms = -1.0;
+          for (int l = 0; l < B; ++l) {
+            double t = 0.0;
+            for (int k = 0; k < 6; ++k) t += wc.nt_ticks[l][k] * 1e-5;
+            if (t > worst_ms) {
+              worst_ms = t;
+              worst = l;
+            }
+          }
+          const unsigned long long* tk = wc.nt_ticks[worst];
+          fprintf(stderr, "[slm] direct steps of the busiest lane (%d: %d factorisations), ms: matvec + free set %.3f, assembly %.3f, "
+                  "factorisation %.3f, solve %.3f, trial points %.3f, mu %.3f\n", worst, wc.nt_factors[worst],
+                  tk[0] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5, tk[3] * 1e-5, tk[4] * 1e-5, tk[5] * 1e-5);
+        }
+      }
     }
     stats->wall_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -1986,9 +2130,84 @@ extern "C" int slm_comm_info(slm_engine* eng, int32_t* rank_out, int32_t* n_rank
     if (!g_rccl.CommCount || !g_rccl.CommUserRank) return fail(SLM_ERR_COMM, "librccl lacks ncclCommCount / ncclCommUserRank");
     RCCL_TRY(g_rccl.CommCount(eng->comm, &count));
     RCCL_TRY(g_rccl.CommUserRank(eng->comm, &rank));
+  } else if (eng->local) {
+    rank = eng->rank;
+    count = eng->local->n_ranks;
   }
   if (rank_out) *rank_out = rank;
   if (n_ranks_out) *n_ranks_out = count;
+  return SLM_OK;
+}
+
+extern "C" int slm_comm_collectives(slm_engine* eng, int64_t* count_out) {
+  if (!eng || !count_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  *count_out = eng->collectives;
+  return SLM_OK;
+}
+
+static void local_comm_release(LocalComm* lc) {
+  bool last = false;
+  {
+    std::lock_guard<std::mutex> lk(lc->m);
+    last = --lc->refs == 0;
+  }
+  if (!last) return;
+  (void)hipSetDevice(lc->device);
+  for (int r = 0; r < lc->n_ranks; ++r) {
+    if (lc->stage[r]) (void)hipFree(lc->stage[r]);
+    for (int k = 0; k < 2; ++k) {
+      if (lc->ready[r][k]) (void)hipEventDestroy(lc->ready[r][k]);
+      if (lc->consumed[r][k]) (void)hipEventDestroy(lc->consumed[r][k]);
+    }
+  }
+  delete lc;
+}
+
+extern "C" int slm_comm_init_local(slm_engine** engines, int32_t n_ranks, double timeout_s) {
+  if (!engines) return fail(SLM_ERR_BAD_ARG, "engines is NULL");
+  if (n_ranks < 1 || n_ranks > LocalComm::kMaxRanks)
+    return fail(SLM_ERR_BAD_ARG, "n_ranks must be in [1, %d] (got %d)", LocalComm::kMaxRanks, n_ranks);
+  for (int r = 0; r < n_ranks; ++r) {
+    if (!engines[r]) return fail(SLM_ERR_BAD_ARG, "engine %d is NULL", r);
+    if (engines[r]->sharded()) return fail(SLM_ERR_BAD_ARG, "engine %d already has a communicator", r);
+    if (engines[r]->device != engines[0]->device) return fail(SLM_ERR_BAD_ARG, "the engines of an in-process communicator share one device");
+    for (int q = 0; q < r; ++q)
+      if (engines[q] == engines[r]) return fail(SLM_ERR_BAD_ARG, "engine %d is listed twice", r);
+  }
+  HIP_TRY(hipSetDevice(engines[0]->device));
+  LocalComm* lc = new LocalComm();
+  lc->n_ranks = n_ranks;
+  lc->device = engines[0]->device;
+  lc->refs = n_ranks;
+  if (timeout_s > 0.0) lc->timeout_s = timeout_s;
+  // the largest exchange is the staged working-set Gram of every lane set
+  lc->cap = (size_t)SLM_MAX_LANES * WS_KCAP * WS_KCAP;
+  const size_t tab_doubles = 2 * LocalComm::kMaxRanks;  // two pointer tables behind rank 0's staging areas
+  hipError_t e = hipSuccess;
+  for (int r = 0; r < n_ranks && e == hipSuccess; ++r) {
+    e = hipMalloc((void**)&lc->stage[r], sizeof(double) * (2 * lc->cap + (r == 0 ? tab_doubles : 0)));
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+      e = hipEventCreateWithFlags(&lc->ready[r][k], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&lc->consumed[r][k], hipEventDisableTiming);
+    }
+  }
+  if (e == hipSuccess) {
+    const double* tab[2][LocalComm::kMaxRanks] = {};
+    for (int k = 0; k < 2; ++k)
+      for (int r = 0; r < n_ranks; ++r) tab[k][r] = lc->stage[r] + (size_t)k * lc->cap;
+    e = hipMemcpy(lc->stage[0] + 2 * lc->cap, tab, sizeof(tab), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    lc->refs = 1;
+    local_comm_release(lc);
+    return fail(e == hipErrorOutOfMemory ? SLM_ERR_OOM : SLM_ERR_HIP, "slm_comm_init_local: %s", hipGetErrorString(e));
+  }
+  for (int r = 0; r < n_ranks; ++r) {
+    engines[r]->local = lc;
+    engines[r]->rank = r;
+    engines[r]->n_ranks = n_ranks;
+    engines[r]->collectives = 0;
+  }
   return SLM_OK;
 }
 
@@ -2005,7 +2224,7 @@ extern "C" int slm_comm_init(slm_engine* eng, int32_t rank, int32_t n_ranks,
                              const uint8_t id_in[SLM_COMM_ID_BYTES]) {
   if (!eng || !id_in) return fail(SLM_ERR_BAD_ARG, "NULL argument");
   if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(SLM_ERR_BAD_ARG, "bad rank %d of %d", rank, n_ranks);
-  if (eng->comm) return fail(SLM_ERR_BAD_ARG, "communicator already initialised");
+  if (eng->sharded()) return fail(SLM_ERR_BAD_ARG, "communicator already initialised");
   SLM_TRY(load_rccl());
   HIP_TRY(hipSetDevice(eng->device));
   rcclUniqueId_t id;
@@ -2013,6 +2232,7 @@ extern "C" int slm_comm_init(slm_engine* eng, int32_t rank, int32_t n_ranks,
   RCCL_TRY(g_rccl.CommInitRank(&eng->comm, n_ranks, id, rank));
   eng->rank = rank;
   eng->n_ranks = n_ranks;
+  eng->collectives = 0;
   return SLM_OK;
 }
 
@@ -2025,6 +2245,15 @@ extern "C" int slm_comm_destroy(slm_engine* eng) {
     eng->comm = nullptr;
     eng->n_ranks = 1;
     eng->rank = 0;
+  }
+  if (eng->local) {
+    (void)hipSetDevice(eng->device);
+    (void)hipStreamSynchronize(eng->stream);
+    LocalComm* lc = eng->local;
+    eng->local = nullptr;
+    eng->n_ranks = 1;
+    eng->rank = 0;
+    local_comm_release(lc);
   }
   return SLM_OK;
 }

@@ -80,8 +80,14 @@ constexpr double kMuFloor = 1e-6;
 // One workgroup per lane (blockIdx.x): vectors of lane l start at l * ld (g: l * (ld + 16)).
 struct TailArgs {
   PathCtl* ctl;               // [n_lanes]
-  int* gdone;                 // [0] = every lane finished (or abort), [1] = lanes finished so far,
-                              // [2] = most passes spent on one point so far
+  int* gdone;                 // [0] = every lane finished (or abort): every later kernel returns at once,
+                              // [1] = lanes finished so far, [2] = most passes spent on one point so far,
+                              // [3] = row-sharded mode: THIS rank has finished (see done_slot),
+                              // [4] = row-sharded mode: the ranks' states differ (stop_apply_kernel)
+  int done_slot;              // where this rank records "finished": 0 -- it takes effect at once -- or, in
+                              // row-sharded mode, 3: [0] is then only set by stop_apply_kernel, from a word
+                              // the ranks have all-reduced, so that every rank stops after the same pass
+                              // (and enters the same number of collectives) whatever its own state says
   int n_lanes;
   int steal;                  // 1 => all lanes walk ONE path: an idle lane takes over the upper half of
                               //      the points the busiest lane has not reached yet (cold start)
@@ -626,12 +632,12 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       if (nonfinite) {
         ctl->nonfinite = 1;
         ctl->done = 1;
-        a.gdone[0] = 1;  // abort every lane
+        a.gdone[a.done_slot] = 1;  // abort every lane
       } else if (goes_idle) {
         ctl->idle = 1;
       } else if (range_end) {
         ctl->done = 1;
-        if (atomicAdd(&a.gdone[1], 1) + 1 == a.n_lanes) a.gdone[0] = 1;
+        if (atomicAdd(&a.gdone[1], 1) + 1 == a.n_lanes) a.gdone[a.done_slot] = 1;
       }
     } else {
       ctl->iter = iter + 1;
@@ -686,13 +692,56 @@ __global__ __launch_bounds__(256) void steal_kernel(TailArgs a) {
       } else {
         me->idle = 0;
         me->done = 1;
-        if (atomicAdd(&a.gdone[1], 1) + 1 == a.n_lanes) a.gdone[0] = 1;
+        if (atomicAdd(&a.gdone[1], 1) + 1 == a.n_lanes) a.gdone[a.done_slot] = 1;
       }
     }
   }
   __syncthreads();
   // (the tail kernel already zeroed beta and z of a lane that went idle: cold start is in place)
   (void)took;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-sharded mode: the stop decision is taken from reduced data.  After the tail (and hand-out) kernels of a
+// pass every rank packs "I have finished" into a small vector, the vector is summed over the ranks, and
+// gdone[0] -- the flag every kernel and the host loop obey -- is set only when ALL ranks reported it.  The ranks
+// run the same state machine on the same all-reduced gradients, so they normally finish in the same pass;
+// if their states ever differ (a collective that is not bit-identical on every rank, a rank-dependent
+// rounding) the late ranks simply keep the early ones in the loop: the collective counts stay equal.
+// ---------------------------------------------------------------------------------------------
+constexpr int STOP_WORDS = 16;
+// words: [0] ranks that have finished, [1] ranks taking part, [2] c, [3] c^2 with c a small-integer digest of
+// this rank's control blocks (path point, passes on it, mode, done of every lane): if the ranks' states are the
+// same, n sum(c^2) == (sum c)^2 exactly (all terms are integers below 2^53); if not, the solve is over -- its
+// ranks no longer iterate on one problem -- and every rank reports it (gdone[4]) after the same pass.
+__global__ void stop_pack_kernel(const int* gdone, const PathCtl* ctl, int n_lanes, double* words) {
+  if (threadIdx.x < STOP_WORDS) words[threadIdx.x] = 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long c = 0ull;
+    for (int l = 0; l < n_lanes; ++l) {
+      const PathCtl& q = ctl[l];
+      const unsigned long long v = (unsigned long long)(unsigned)q.point * 1031ull + (unsigned long long)(unsigned)q.iter * 7ull +
+                                   (unsigned long long)(q.done ? 3 : 0) + (unsigned long long)(q.mode ? 1 : 0) +
+                                   (unsigned long long)(q.idle ? 5 : 0);
+      c = (c * 31ull + v * (unsigned long long)(l + 1)) & 0xfffffull;  // < 2^20: c^2 and the sums stay exact
+    }
+    words[0] = gdone[3] != 0 ? 1.0 : 0.0;
+    words[1] = 1.0;
+    words[2] = (double)c;
+    words[3] = (double)c * (double)c;
+  }
+}
+__global__ void stop_apply_kernel(int* gdone, const double* words) {
+  if (threadIdx.x != 0) return;
+  const double n = words[1];
+  if (!(n >= 1.0)) return;
+  if (n * words[3] != words[2] * words[2]) {
+    gdone[4] = 1;
+    gdone[0] = 1;
+  } else if (words[0] >= n) {
+    gdone[0] = 1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -43,9 +43,14 @@ constexpr int WS_MAX_REPEATS = 6;   // refinements of one path point before the 
 // on the free coordinates (Cholesky solve, see `direct_step`) replaces further iterations; one prox-gradient
 // step after it tests convergence, and the next direct step follows at once if that fails.
 constexpr int WS_NEWTON_AFTER = 16;
-constexpr int WS_NEWTON_AGAIN = 1;   // iterations between two direct steps (one prox-gradient step: the convergence test)
-constexpr int WS_NEWTON_MAX = 16;    // direct steps per refinement
+constexpr int WS_NEWTON_MAX = 64;    // direct steps per refinement
+constexpr int WS_AFTER_DIRECT = 40;  // iterations left to a refinement whose direct steps are used up: on a face that
+                                     // needed them more would not converge either -- the next pass re-expands the model
+                                     // at the point reached and the refinement resumes from there
 constexpr double WS_NEWTON_RQ = 0.05;
+constexpr int WS_NEWTON_REFUSALS = 4; // refused direct steps after which a refinement stops trying
+constexpr double WS_NEWTON_ENTER = 0.3;
+constexpr int WS_NEWTON_RESOLVE = 5; // solves per direct step while the free set is being made consistent
 static_assert(NT_MAXT * NT_B == WS_KCAP, "the direct solve covers a full working set");
 
 struct WsCtl {
@@ -69,9 +74,19 @@ struct WsCtl {
   int32_t staged;     // row-sharded mode: the local Gram parts sit in the staging matrix, waiting for the
                       // all-reduce and ws_publish_kernel
   int32_t inner_iters;  // model-solver iterations of all refinements (diagnostics: SLM_TRACE=2)
+  int32_t hard;         // direct steps were needed earlier in this call: refinements start with them
+  int32_t hard_next;    // ... as recorded during the current pass (ws_select_kernel publishes it between passes)
   int32_t newton_steps; // direct (Cholesky) steps taken by the model solver, all lanes
   int32_t newton_fails; // ... refused: face not positive definite, or the step did not lower the model
   int32_t newton_nopd;  // ... of which: Cholesky pivot below the floor
+  int32_t newton_trial[4];  // accepted trial of a direct step: full step, 1/2, 1/4, up to the first sign change
+  int32_t newton_ref[4];    // refused steps: no sign-consistent segment (t = 0), slope <= 0, curvature <= 0, no decrease
+  int32_t newton_factors;   // Cholesky factorisations (a direct step re-solves when zero coordinates move the wrong way)
+  int32_t newton_unknowns;  // sum of their sizes
+  // device clock ticks (wall_clock64: 100 MHz) spent by each lane's workgroup in the parts of its direct steps
+  // (SLM_TRACE=2 prints them): matvec + free set, assembly, factorisation, solve, trial points, mu
+  unsigned long long nt_ticks[SLM_MAX_LANES][6];
+  int32_t nt_factors[SLM_MAX_LANES];
   int32_t last_point[SLM_MAX_LANES];  // path point of each lane's last refinement ...
   int32_t repeats[SLM_MAX_LANES];     // ... and how many times in a row it was that point WITH the same columns
   int32_t last_cols[SLM_MAX_LANES];   // columns W held at each lane's last refinement (growth resets the count)
@@ -271,6 +286,7 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
   const int nitems = singleton ? p : G;
   const bool had_w = ws->valid != 0;
 
+  if (tid == 0 && ws->hard_next) ws->hard = 1;
   const bool requested = ws->request != 0;
   if (!requested && !had_w) return;
   if (ws->builds >= ws->max_builds || ws->appends >= 8 * ws->max_builds) {
@@ -935,35 +951,57 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     for (int wv = 1; wv < TAIL_WAVES; ++wv) mm = fmin(mm, red[0][wv]);
     return mm;
   };
+  int resolve_cap = WS_NEWTON_RESOLVE;
   auto direct_step = [&](double& x, double Lmax, double* mu_out, bool want_mu) -> int {
     *mu_out = 0.0;
-    const double gd0 = matvec(x, false);  // G (x - z0)
-    const double gx = g0 + gd0;           // model gradient at x
-    const double thr = pa + pb;           // (singleton groups: b acts as a second l1 weight)
-    double pg, xi;                        // pseudo-gradient and orthant sign of this position
-    if (x != 0.0) {
-      xi = x > 0.0 ? 1.0 : -1.0;
-      pg = gx + thr * xi + pd * x;
-    } else {
-      pg = fabs(gx) > thr * (1.0 + 1e-12) ? gx - copysign(thr, gx) : 0.0;
-      xi = pg > 0.0 ? -1.0 : 1.0;
-    }
-    bool is_free = live && (x != 0.0 || pg != 0.0);
-    // m_old: model value at x (relative to the expansion point)
-    double m_old;
-    {
-      double sv[2] = {mine ? (x - z0) * (g0 + 0.5 * gd0) : 0.0, 0.0};
-      sv[1] = pen_part(x);
-      block_sum<2>(sv, red);
-      m_old = sv[0] + sv[1];
-    }
+    const double thr = pa + pb;  // (singleton groups: b acts as a second l1 weight)
     // On an ill-conditioned face the Newton direction lives on cancellations between near-collinear columns:
     // projecting some of its coordinates away leaves a step that is no descent step at any useful length.
-    // So a zero coordinate only stays in F if the solve moves it to the side it wants to go; the others are
-    // dropped and the system is solved again (twice at most: then the projected arc has to do).
+    // So the free set is made consistent first, active-set fashion: a zero coordinate stays in F only if the
+    // solve moves it to the side it wants to go, a non-zero one only if the solve does not carry it across
+    // zero -- the others are set to / kept at zero (and stay out of F for the rest of this call), the
+    // pseudo-gradient is re-evaluated there and the system is solved again (WS_NEWTON_RESOLVE times at most:
+    // then the projected arc has to do).
+    double xb = x;          // base point of the solve: x with the coordinates dropped so far at zero
+    bool banned = false;    // this position was dropped: it stays at zero and out of F
+    double m_old = 0.0;     // model value at x (relative to the expansion point)
+    double d_first = 0.0, t_first = 2.0;  // first solve: direction and the step to the first sign change from x
+    bool ok_first = true, tiny_first = false;
+    double pg_first = 0.0;
     int m = 0, T = 0, mp = 0, my_rank = -1;
-    double dk = 0.0;
-    for (int resolve = 0; resolve < 3; ++resolve) {
+    double dk = 0.0, xi = 1.0;
+    unsigned long long tk = wall_clock64();
+    auto lap = [&](int slot) {
+      if (tid == 0) {
+        const unsigned long long now = wall_clock64();
+        ws->nt_ticks[lane_id][slot] += now - tk;
+        tk = now;
+      }
+    };
+    for (int resolve = 0; resolve < resolve_cap; ++resolve) {
+      lap(4);
+      const double gdb = matvec(xb, false);  // G (xb - z0)
+      const double gx = g0 + gdb;            // model gradient at xb
+      if (resolve == 0) {
+        double sv[2] = {mine ? (x - z0) * (g0 + 0.5 * gdb) : 0.0, 0.0};
+        sv[1] = pen_part(x);
+        block_sum<2>(sv, red);
+        m_old = sv[0] + sv[1];
+      }
+      double pg;  // pseudo-gradient of this position at xb; xi: the orthant it may move in
+      if (xb != 0.0) {
+        xi = xb > 0.0 ? 1.0 : -1.0;
+        pg = gx + thr * xi + pd * xb;
+      } else {
+        pg = fabs(gx) > thr * (1.0 + 1e-12) ? gx - copysign(thr, gx) : 0.0;
+        xi = pg > 0.0 ? -1.0 : 1.0;
+      }
+      // of the zero coordinates that want to leave zero only the strongest enter now (within WS_NEWTON_ENTER of
+      // the largest violation): on correlated designs most violators stop violating once a few of them have
+      // moved, and a free set full of them solves for a direction that means nothing
+      const double viol = (live && !banned && xb == 0.0) ? fabs(pg) : 0.0;
+      const double viol_max = -block_min(-viol);
+      const bool is_free = live && !banned && (xb != 0.0 || (viol > 0.0 && viol >= WS_NEWTON_ENTER * viol_max));
       // free positions in position order
       __syncthreads();
       if (q == 0 && k < WS_KCAP) {
@@ -988,7 +1026,12 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
       }
       __syncthreads();
       m = m_s;
-      if (m == 0) return 0;
+      if (m == 0) {
+        if (resolve == 0) return 0;
+        dk = 0.0;
+        my_rank = -1;
+        break;  // everything was dropped: the base point itself is the candidate
+      }
       T = (m + 15) >> 4;
       mp = 16 * T;
       my_rank = (k < K) ? rank_of[k] : -1;
@@ -997,6 +1040,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
       if (q == 0 && k < WS_KCAP) delta[k] = pd;  // (matvec is done with delta: it now carries the ridge diagonal)
       __syncthreads();
       if (q == 0 && my_rank >= 0) nv[my_rank] = pg;
+      lap(0);
       // H_FF, tile by tile (G is symmetric: read along rows)
       const int ntl = T * (T + 1) / 2;
       for (int e = tid; e < ntl * 256; e += WS_THREADS) {
@@ -1018,37 +1062,83 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
         ntF[e] = hv;
       }
       __syncthreads();
+      lap(1);
       if (!nt_factor(ntF, ntD, T, 1e-12 * Lmax, nts)) {
         if (tid == 0) atomicAdd(&ws->newton_nopd, 1);
         return -1;
       }
+      lap(2);
       nt_solve(ntF, ntD, T, nv);  // nv = H_FF^-1 pg
+      lap(3);
+      if (tid == 0) {
+        atomicAdd(&ws->newton_factors, 1);
+        ws->nt_factors[lane_id] += 1;
+        atomicAdd(&ws->newton_unknowns, m);
+      }
       dk = my_rank >= 0 ? nv[my_rank] : 0.0;
-      // zero coordinates the solve would move to the wrong side (or not at all)
-      const bool wrong = my_rank >= 0 && x == 0.0 && !(dk * pg > 0.0);
+      if (resolve == 0) {
+        ok_first = my_rank >= 0 && (x != 0.0 || dk * pg > 0.0);
+        d_first = ok_first ? dk : 0.0;  // (a zero coordinate the first solve sent the wrong way stays where it is)
+        pg_first = pg;
+        // a coordinate the solve carries across zero ends the straight segment -- unless it sits so close to
+        // zero (the dust a prox-gradient step leaves on every violator) that the segment would have no
+        // length: those go to zero outright and take no part in the direction
+        tiny_first = my_rank >= 0 && x != 0.0 && x * dk > 0.0 && fabs(x) < 1e-6 * fabs(dk);
+        if (tiny_first) d_first = 0.0;
+        else if (my_rank >= 0 && x != 0.0 && x * dk > 0.0 && fabs(dk) >= fabs(x)) t_first = x / dk;
+      }
+      // zero coordinates the solve would move to the wrong side (or not at all), non-zero ones it would carry
+      // across zero
+      const bool wrong = my_rank >= 0 && (xb == 0.0 ? !(dk * pg > 0.0) : (xb - dk) * xi <= 0.0);
       double cnt[1] = {mine && wrong ? 1.0 : 0.0};
       block_sum<1>(cnt, red);
-      if (cnt[0] == 0.0 || resolve == 2) break;
-      if (wrong) is_free = false;
+      if (cnt[0] == 0.0 || resolve == resolve_cap - 1) break;
+      if (wrong) {
+        banned = true;
+        xb = 0.0;
+      }
     }
-    // trial steps: 1, 1/2, 1/4 along the projected arc, then the straight segment up to the first sign change
-    // of a non-zero coordinate (a guaranteed descent step: no projection happens on it)
-    double tcross = 2.0;
-    if (my_rank >= 0 && x != 0.0 && x * dk > 0.0 && fabs(dk) >= fabs(x)) tcross = x / dk;
-    tcross = fmin(1.0, block_min(tcross));
-    double tstep = 1.0, xn = x;
-    bool moved = false, projected = false;
+    t_first = fmin(1.0, block_min(t_first));
+    {
+      // the model along x - t d_first, 0 <= t <= t_first (no coordinate changes sign there), is the parabola
+      // m_old - t <pg, d> + t^2/2 <d, H d>: with the wrong-way coordinates held back d is not the Newton direction
+      // of what moves, so the full segment need not descend -- its minimiser does
+      const double gd = matvec(z0 + d_first, false);  // G d_first
+      double sv[2] = {0.0, 0.0};
+      if (mine) {
+        sv[0] = pg_first * d_first;
+        sv[1] = d_first * (gd + pd * d_first);
+      }
+      block_sum<2>(sv, red);
+      if (tid == 0) {
+        if (!(t_first > 1e-14)) atomicAdd(&ws->newton_ref[0], 1);
+        else if (!(sv[0] > 0.0)) atomicAdd(&ws->newton_ref[1], 1);
+        else if (!(sv[1] > 0.0)) atomicAdd(&ws->newton_ref[2], 1);
+      }
+      t_first = (sv[0] > 0.0 && sv[1] > 0.0) ? fmin(t_first, sv[0] / sv[1]) : 0.0;
+    }
+    // trial points: the base point minus the (projected) step at t = 1, 1/2, 1/4, then -- from x itself, along
+    // the first solve -- the straight segment up to the first sign change (a guaranteed descent step: nothing
+    // is projected on it)
+    double xn = x;
+    bool moved = false, projected = false, full = false;
     for (int trial = 0; trial < 4 && !moved; ++trial) {
-      const double tt = trial < 3 ? tstep : tcross;
-      if (trial == 3 && !(tcross > 1e-14)) break;
-      double xc = x;
-      double cut = 0.0;
-      if (my_rank >= 0) {
-        xc = x - tt * dk;
-        if (xc * xi <= 0.0) {  // left the orthant (or landed on its boundary): stops at zero
-          if (x != 0.0 || xc != 0.0) cut = 1.0;
-          xc = 0.0;
+      if (trial == 3 && !(t_first > 1e-14)) break;
+      double xc, cut = 0.0;
+      if (trial < 3) {
+        const double tt = trial == 0 ? 1.0 : (trial == 1 ? 0.5 : 0.25);
+        xc = xb;
+        if (my_rank >= 0) {
+          xc = xb - tt * dk;
+          if (xc * xi <= 0.0) {  // left the orthant (or landed on its boundary): stops at zero
+            if (xb != 0.0 || xc != 0.0) cut = 1.0;
+            xc = 0.0;
+          }
         }
+      } else {
+        xc = x - t_first * d_first;
+        if (tiny_first || (x != 0.0 && xc * x <= 0.0)) xc = 0.0;  // the coordinate that reaches zero there
+        cut = 1.0;
       }
       const double gdn = matvec(xc, false);
       double sv[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1062,16 +1152,21 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
       if (sv[3] == 0.0 && sv[0] + sv[1] < m_old) {
         moved = true;
         projected = sv[2] > 0.0;
+        full = trial == 0;
         xn = xc;
-        tstep = tt;
-      } else {
-        tstep *= 0.5;
+        if (tid == 0) atomicAdd(&ws->newton_trial[trial], 1);
+        // dropping every inconsistent coordinate at once did not settle the free set and the step fell back
+        // to the segment: on this face (strong cancellations) the following steps go there directly
+        if (trial == 3) resolve_cap = 1;
       }
     }
+    lap(4);
+    if (!moved && tid == 0 && t_first > 1e-14) atomicAdd(&ws->newton_ref[3], 1);
     if (!moved) return -1;
-    if (want_mu && tstep == 1.0 && !projected) {  // H_FF is the Hessian on the face of the new point: its smallest
-      __syncthreads();                            // eigenvalue, two inverse-iteration steps from the step itself
-      *mu_out = nt_lambda_min(ntF, ntD, T, mp, nv, red, 2);
+    if (want_mu && full && !projected && m > 0) {  // H_FF is the Hessian on the face of the new point: its
+      __syncthreads();                                      // smallest eigenvalue, two inverse-iteration steps
+      *mu_out = nt_lambda_min(ntF, ntD, T, mp, nv, red, 2); // from the step itself
+      lap(5);
     }
     x = xn;
     return 1;
@@ -1100,7 +1195,14 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   double mu_face = 0.0;       // from the factor of a direct step (0: none taken)
   int since_direct = 0, n_direct = 0, n_direct_bad = 0;
   bool direct_on = newton_capable;
-  for (int it = 0; it < WS_INNER_MAX; ++it) {
+  // direct mode: the iterate only moves by direct steps; the prox-gradient step of every round is just the
+  // convergence test (taken when it passes).  Taking it regardless would wreck the next direct step: from a
+  // face minimiser one prox-gradient step gives EVERY violator a tiny non-zero value, and a free set full of
+  // those solves for a direction that means nothing.  A solve starts in this mode when an earlier refinement
+  // of this call needed direct steps (WsCtl::hard, published between passes by ws_select_kernel).
+  bool direct_mode = direct_on && ws->hard != 0;
+  int it_end = WS_INNER_MAX;
+  for (int it = 0; it < it_end; ++it) {
     ++n_inner;
     const double gv = g0 + matvec(v, false);
     const double u = prox_w(v - gv / L, 1.0 / L);
@@ -1140,6 +1242,35 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
       t = 1.0;
       continue;
     }
+    const bool inner_conv = sqrt(s[0]) <= WS_INNER_TOL * tol * sqrt(s[1]);
+    if (direct_mode && !inner_conv) {
+      bool stepped = false;
+      if (n_direct < WS_NEWTON_MAX) {
+        double mu_new = 0.0;
+        const int rc = direct_step(x, L, &mu_new, mu_face == 0.0);
+        n_direct += 1;
+        if (rc > 0) {
+          if (mu_new > 0.0) mu_face = mu_new;
+          stepped = true;
+        } else if (rc < 0) {
+          n_direct_bad += 1;
+        }
+      }
+      if (stepped) {
+        v = x;
+        t = 1.0;
+        continue;
+      }
+      // no usable step from this point (e.g. the coordinates it had to hold back carried the descent): one
+      // prox-gradient step moves the iterate somewhere else and the next round tries again; after
+      // WS_NEWTON_REFUSALS of those, or at the cap, the iteration finishes the job
+      if (n_direct_bad >= WS_NEWTON_REFUSALS || n_direct >= WS_NEWTON_MAX) {
+        direct_mode = false;
+        direct_on = false;
+        since_direct = 0;
+        it_end = min(it_end, it + WS_AFTER_DIRECT);
+      }
+    }
     const bool restart = s[2] > 0.0;
     const double t_use = restart ? 1.0 : t;
     const double t_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t_use * t_use));
@@ -1147,11 +1278,10 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     v = u + mom * (u - x);
     x = u;
     t = t_new;
-    if (sqrt(s[0]) <= WS_INNER_TOL * tol * sqrt(s[1])) break;
+    if (inner_conv) break;
     since_direct += 1;
     if (direct_on && n_direct < WS_NEWTON_MAX &&
-        (since_direct >= (n_direct ? WS_NEWTON_AGAIN : WS_NEWTON_AFTER) ||
-         (n_direct == 0 && rq_n >= 5 && rq_min < WS_NEWTON_RQ * L))) {
+        (since_direct >= WS_NEWTON_AFTER || (rq_n >= 5 && rq_min < WS_NEWTON_RQ * L))) {
       double mu_new = 0.0;
       const int rc = direct_step(x, L, &mu_new, mu_face == 0.0);
       since_direct = 0;
@@ -1160,10 +1290,13 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
         if (mu_new > 0.0) mu_face = mu_new;
         v = x;
         t = 1.0;
-        have_prev = false;
+        direct_mode = true;
       } else if (rc < 0) {
         n_direct_bad += 1;
-        direct_on = false;  // singular face or a useless step: the iteration finishes the job
+        if (n_direct_bad >= WS_NEWTON_REFUSALS) {  // singular face / useless steps: the iteration finishes the job
+          direct_on = false;
+          if (n_direct > n_direct_bad) it_end = min(it_end, it + WS_AFTER_DIRECT);
+        }
       }
     }
   }
@@ -1201,6 +1334,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     atomicAdd(&ws->refined, 1);
     atomicAdd(&ws->inner_iters, n_inner);
     if (n_direct) atomicAdd(&ws->newton_steps, n_direct - n_direct_bad);
+    if (n_direct > n_direct_bad) ws->hard_next = 1;  // (same value from every lane: the order of the stores is immaterial)
     if (n_direct_bad) atomicAdd(&ws->newton_fails, n_direct_bad);
     // strong convexity on the face of the refined point, for the stopping rule of the pass that verifies it
     // (fista_tail_kernel): from the factor when a direct step stood, else from the iteration's own moves

@@ -73,6 +73,8 @@ ABI_SYMBOLS = (
     "slm_comm_unique_id",
     "slm_comm_init",
     "slm_comm_info",
+    "slm_comm_collectives",
+    "slm_comm_init_local",
     "slm_dataset_set_global_rows",
     "slm_comm_destroy",
 )
@@ -247,6 +249,8 @@ def load_library():
             "slm_comm_unique_id": [vp],
             "slm_comm_init": [vp, i32, i32, vp],
             "slm_comm_info": [vp, P(i32), P(i32)],
+            "slm_comm_collectives": [vp, P(i64)],
+            "slm_comm_init_local": [P(vp), i32, dbl],
             "slm_dataset_set_global_rows": [vp, i64],
             "slm_comm_destroy": [vp],
         }
@@ -476,6 +480,12 @@ class Engine:
 
     def comm_ranks(self) -> int:
         return self.comm_info()[1]
+
+    def comm_collectives(self) -> int:
+        """All-reduces this engine has entered since its communicator was created."""
+        n = C.c_int64()
+        _check(self._lib.slm_comm_collectives(self._h, C.byref(n)))
+        return int(n.value)
 
     # -- diagnostics ------------------------------------------------------------------------------
     def dense_spd_solve(self, H, rhs):
@@ -715,6 +725,13 @@ class Dataset:
             )
         )
         return _path_result(betas, gn, infos, K, stats)
+
+
+def init_local_comm(engines, timeout_s: float = 0.0) -> None:
+    """Make ``engines`` (same process, same device, one host thread each) the ranks of a row-sharded job."""
+    lib = load_library()
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    _check(lib.slm_comm_init_local(arr, len(engines), float(timeout_s)))
 
 
 # -- default engine per process / device ------------------------------------------------------------

@@ -26,6 +26,9 @@ for name in which:
         amax = float(np.max(np.abs(g0)))
         alphas = np.geomspace(amax, 1e-3 * amax, K)
         r = ds.solve_path([(a, 0.0, 0.0) for a in alphas], lanes=16, flags=_engine.FLAG_FRESH_L)
+        import time
+        t0 = time.perf_counter(); r = ds.solve_path([(a, 0.0, 0.0) for a in alphas], lanes=16, flags=_engine.FLAG_FRESH_L); dt = time.perf_counter() - t0
+        print(f"{name}: second solve {dt * 1e3:.2f} ms")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         _, ref, _ = lasso_path(X, y, alphas=alphas, precompute=X.T @ X, Xy=X.T @ y, tol=1e-14, max_iter=400000)
