@@ -1073,7 +1073,9 @@ static int power_iteration(slm_dataset* ds, const LaneSetup& ls_in, double* L_ou
     // ||A v|| after k steps under-estimates lambda_max by a few per cent on flat spectra; the margin
     // below plus the in-loop curvature guard (fista_tail_kernel) keep the step 1/L safe.
     double L = lam[l] * 1.08;
-    if (!(L > 0.0)) L = 1.0;  // X == 0
+    // (zero: X == 0 on the rows used -- the whole matrix, or, for a sketch, a window the lane's row mask
+    //  blanks out: the caller then repeats with all rows before settling for 1)
+    if (!(L > 0.0)) L = (n_rows > 0) ? 0.0 : 1.0;
     L_out[l] = L;
   }
   return SLM_OK;
@@ -1503,12 +1505,18 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   } else {
     const auto t0 = std::chrono::steady_clock::now();
     bool ran = false;
-    // working-set solves barely use L (first candidate, fallback steps): a bound from the first eighth
-    // of the rows, four power steps, costs a quarter of the two full passes
+    // working-set solves barely use L (first candidate, fallback steps): a bound from the first sixteenth
+    // of the rows, three power steps, costs a sixth of the two full passes
     const bool sketch = ws_policy(ds, o.flags) == 2 && n >= 65536 && !getenv("SLM_NO_L_SKETCH");
     if (sketch && !(ds->L_valid && !(o.flags & SLM_FLAG_FRESH_L) && !any_rw && !custom_scale)) {
-      SLM_TRY(power_iteration(ds, (any_rw || custom_scale) ? ls : default_lanes(ds, 1), L, kPowerItersSketch, n / 16));
-      if (!(any_rw || custom_scale))
+      const bool per_lane = any_rw || custom_scale;
+      SLM_TRY(power_iteration(ds, per_lane ? ls : default_lanes(ds, 1), L, kPowerItersSketch, n / 16));
+      // A lane whose row weights vanish on the window (scikit-learn's default cv = unshuffled KFold: the first
+      // fold's training mask is zero on the first n / k rows) measured nothing there: all rows, then.
+      bool blank = false;
+      for (int l = 0; l < (per_lane ? B : 1); ++l) blank = blank || !(L[l] > 0.0);
+      if (blank) SLM_TRY(power_iteration(ds, per_lane ? ls : default_lanes(ds, 1), L, kPowerItersSolve));
+      if (!per_lane)
         for (int l = 1; l < B; ++l) L[l] = L[0];
       ran = true;
     } else if (any_rw || custom_scale) {

@@ -152,3 +152,136 @@ def test_config5_adaptive_group_lasso_row_sharded_reduced():
     finally:
         eng2.comm_destroy()
         eng2.close()
+
+
+def _kkt_of_cell(ds, beta, mask, n_train, a, b, gidx, G):
+    """KKT residual of one (fold, penalty) cell from one more device gradient with the fold's row mask and
+    1/n_train scaling (what slm_solve_lanes used for that lane)."""
+    ds.set_row_weights(mask)
+    ds.set_global_rows(n_train)
+    g, _ = ds.gradient(beta)
+    return oracle.kkt_residual(g, beta, a, b, np.zeros(G), gidx, G)
+
+
+def test_config4_full_size_cells_are_kkt_certified(eng):
+    """configs[3] at FULL size (n = 100k, p = 5k, fold masks, sixteen lanes per call) on a shortened grid:
+    2 folds x 2 l1_ratio x 50 alpha, every (fold, l1_ratio) unit cut into four lanes; sampled cells are
+    certified through their KKT residual under the fold's own mask and 1/n_train scaling."""
+    rng = np.random.default_rng(1)
+    groups = rng.permutation(np.repeat(np.arange(500), 10))
+    gidx, G = oracle.group_index(groups, P)
+    coef = make_coef(P, 25, 2, groups)
+    folds = np.random.default_rng(0).permutation(N) % 5  # KFold(5, shuffle=True): two of its folds
+    with eng.synthetic_dataset(N, P, seed=11, coef=coef, noise_sd=10.0) as ds:
+        ds.set_groups(gidx, G)
+        g0, _ = ds.gradient(None)
+        bmax = float(np.max(np.sqrt(np.bincount(gidx, weights=g0 * g0, minlength=G))))
+        amax1 = float(np.max(np.abs(g0)))
+        specs, cells = [], []
+        for f in (0, 3):
+            mask = (folds != f).astype(float)
+            for r in (0.05, 0.95):
+                amax = min(bmax / (1 - r), amax1 / r)
+                al = np.geomspace(amax, 1e-3 * amax, 50)
+                pts = np.c_[r * al, (1 - r) * al, 0 * al]
+                for part in np.array_split(np.arange(50), 4):
+                    specs.append(dict(points=pts[part], row_weight=mask, n_eff=int(mask.sum())))
+                    cells.append((f, r, al[part], mask))
+        assert len(specs) == 16 and ds.max_lanes() >= 16
+        out = ds.solve_lanes(specs)
+        assert all(o.converged for o in out)
+        assert out[0].grad_launches <= 40  # sixteen 12-13-point lanes: about a pass per point
+        for lane in (0, 3, 7, 9, 12, 15):
+            f, r, al, mask = cells[lane]
+            for k in (1, len(al) - 1):
+                beta = out[lane].betas[k]
+                kkt = _kkt_of_cell(ds, beta, mask, int(mask.sum()), r * al[k] * np.ones(P), (1 - r) * al[k] * np.ones(G), gidx, G)
+                assert kkt / 0.45 < 1e-6 * max(np.max(np.abs(beta)), 1e-300), (lane, k, kkt)
+        # the four lanes of a unit are one warm-started path: denser towards its end
+        nnz = [(o.betas != 0).sum(axis=1) for o in out[:4]]
+        assert nnz[3][-1] >= nnz[0][-1]
+
+
+def test_config5_per_rank_share_full_size_with_lanes(eng):
+    """configs[4]'s per-rank share at FULL size -- 125 000 x 10 000 (10 GB), 1 000 groups x 10 -- through a
+    one-rank RCCL communicator: the AdaptiveGroupLasso re-weighting loop (3 solves, working set on), then a
+    sixteen-lane call (four CV-fold masks x four alphas) that only the split pass for rows of 5 121 ... 10 240
+    columns can serve; every result certified by its KKT residual."""
+    from sparselm_amd import distributed as D
+
+    n, p, G = 125_000, 10_000, 1_000
+    groups = np.repeat(np.arange(G), 10)
+    gidx = groups
+    rng = np.random.default_rng(0)
+    coef = np.zeros(p)
+    for g in rng.choice(G, 30, replace=False):
+        coef[groups == g] = rng.uniform(1, 5, 10)
+    eng2 = _engine.Engine(0)
+    try:
+        D.init_row_sharding(eng2, rank=0, world_size=1)
+        with eng2.synthetic_dataset(n, p, seed=1000, coef=coef, noise_sd=5.0) as ds:
+            ds.set_global_rows(n)
+            ds.set_groups(groups, G)
+            g0, _ = ds.gradient(None)
+            amax = float(np.max(np.sqrt(np.bincount(groups, weights=g0 * g0, minlength=G))))
+            alpha, eps = 0.1 * amax, 1e-6
+            w = alpha * np.ones(G)
+            beta = None
+            passes = 0
+            for _ in range(3):
+                res = ds.solve_path([(0.0, 1.0, 0.0)], b=w, beta0=beta, want_group_norms=True)
+                assert res.converged
+                w_used = w
+                beta = res.betas[0]
+                passes += res.grad_launches
+                w = alpha * (alpha / (res.group_norms[0] + eps))
+            g, _ = ds.gradient(beta)
+            kkt = oracle.kkt_residual(g, beta, np.zeros(p), w_used, np.zeros(G), gidx, G)
+            assert kkt / 0.45 < 1e-6 * np.max(np.abs(beta)), kkt
+            assert int(np.sum(res.group_norms[0] > 0)) == 30 and passes <= 15
+            # sixteen lanes at p = 10 000: 4 fold masks x 4 alphas (one point each)
+            assert ds.max_lanes() == 16
+            folds = np.random.default_rng(1).permutation(n) % 4
+            specs, cells = [], []
+            for f in range(4):
+                mask = (folds != f).astype(float)
+                for a in (0.5, 0.2, 0.1, 0.05):
+                    specs.append(dict(points=[(0.0, a * amax, 0.0)], row_weight=mask, n_eff=int(mask.sum())))
+                    cells.append((mask, a * amax))
+            out = ds.solve_lanes(specs)
+            assert all(o.converged for o in out)
+            for lane in (0, 5, 10, 15):
+                mask, a = cells[lane]
+                bl = out[lane].betas[0]
+                kk = _kkt_of_cell(ds, bl, mask, int(mask.sum()), np.zeros(p), a * np.ones(G), gidx, G)
+                assert kk / 0.45 < 1e-6 * np.max(np.abs(bl)), (lane, kk)
+    finally:
+        eng2.comm_destroy()
+        eng2.close()
+
+
+def test_default_kfold_without_shuffling_on_large_x(eng):
+    """scikit-learn's default `cv=5` is an UNSHUFFLED KFold: the first fold's training mask is zero on the
+    first fifth of the rows, which blanks the window the sketched step-size bound looks at (n >= 65536).  The
+    lanes must still get a usable bound and converge in about a pass per point."""
+    n, p = 80_000, 900
+    coef = make_coef(p, 20, 4)
+    with eng.synthetic_dataset(n, p, seed=3, coef=coef, noise_sd=5.0) as ds:
+        g0, _ = ds.gradient(None)
+        amax = float(np.max(np.abs(g0)))
+        alphas = np.geomspace(0.8 * amax, 0.02 * amax, 6)
+        bounds = np.linspace(0, n, 6).astype(int)
+        specs = []
+        for f in range(5):
+            mask = np.ones(n)
+            mask[bounds[f]:bounds[f + 1]] = 0.0
+            specs.append(dict(points=[(a, 0.0, 0.0) for a in alphas], row_weight=mask, n_eff=int(mask.sum())))
+        out = ds.solve_lanes(specs)
+        assert all(o.converged for o in out)
+        assert out[0].grad_launches <= 12 and all(np.all(o.mode == 1) for o in out)  # no fall-back to FISTA
+        gidx, G = oracle.group_index(None, p)
+        for f in (0, 2):
+            mask = np.ones(n)
+            mask[bounds[f]:bounds[f + 1]] = 0.0
+            kkt = _kkt_of_cell(ds, out[f].betas[-1], mask, int(mask.sum()), alphas[-1] * np.ones(p), np.zeros(G), gidx, G)
+            assert kkt / 0.5 < 1e-6 * np.max(np.abs(out[f].betas[-1]))

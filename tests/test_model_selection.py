@@ -294,3 +294,36 @@ def test_overlap_and_standardized_searches_take_the_generic_path(golden):
     assert not hasattr(gs, "search_time_")
     np.testing.assert_allclose(gs.cv_results_["mean_test_score"], ref.cv_results_["mean_test_score"], rtol=1e-8)
     np.testing.assert_allclose(gs.best_estimator_.coef_, ref.best_estimator_.coef_, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("intercept", [False, True])
+def test_device_fast_path_against_the_oracle_backend(golden, intercept):
+    """The device-resident grid path checked DIRECTLY against the CPU oracle (not against the HIP generic loop):
+    scikit-learn's own GridSearchCV over the same estimators with every fit routed through oracle.fista has to
+    produce the same cv_results_, the same selection and the same refitted coefficients."""
+    X, y, groups, gw = golden["grp_X"], golden["grp_y"], golden["grp_groups"], golden["grp_gw"]
+    cv = KFold(4, shuffle=True, random_state=3)
+    cases = [
+        (Lasso(fit_intercept=intercept), {"alpha": list(np.geomspace(20, 0.05, 6))}),
+        (GroupLasso(groups=groups, group_weights=gw, fit_intercept=intercept), {"alpha": list(np.geomspace(20, 0.1, 5))}),
+        (SparseGroupLasso(groups=groups, fit_intercept=intercept), {"alpha": list(np.geomspace(10, 0.1, 4)), "l1_ratio": [0.2, 0.8]}),
+        (AdaptiveLasso(fit_intercept=intercept, max_iter=3), {"alpha": list(np.geomspace(5, 0.1, 4))}),
+    ]
+    for est, grid in cases:
+        est.set_params(solver_options={"tol": 1e-11})
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fast = GridSearchCV(est, grid, cv=cv).fit(X, y)
+            assert hasattr(fast, "search_time_")  # the device path ran
+            with _backend.use_backend(OracleBackend()):
+                ref_est = est.__class__(**{**est.get_params(), "solver_options": {"tol": 1e-13}})
+                ref = SkGridSearchCV(ref_est, grid, cv=cv, scoring="neg_root_mean_squared_error").fit(X, y)
+        assert fast.cv_results_["params"] == ref.cv_results_["params"]
+        for f in range(4):
+            np.testing.assert_allclose(fast.cv_results_[f"split{f}_test_score"], ref.cv_results_[f"split{f}_test_score"],
+                                       rtol=1e-6, atol=1e-8)
+        assert fast.best_index_ == ref.best_index_
+        scale = np.max(np.abs(ref.best_estimator_.coef_))
+        np.testing.assert_allclose(fast.best_estimator_.coef_, ref.best_estimator_.coef_, rtol=0, atol=1e-6 * scale)
+        assert fast.best_estimator_.intercept_ == pytest.approx(ref.best_estimator_.intercept_, abs=1e-6 * max(1.0, abs(ref.best_estimator_.intercept_)))
