@@ -29,6 +29,21 @@ def world():
     )
 
 
+def active_world():
+    """(rank, world_size) the grid search shards over: torch.distributed's, when a process group is
+    INITIALISED; (0, 1) otherwise -- whatever RANK / WORLD_SIZE say.  A launcher (torchrun, SLURM) that sets
+    those variables for a script which never calls ``init_process_group`` must not make each process solve
+    1/world of the grid and keep the rest as NaN: without a process group there is nobody to gather from, so
+    every process solves everything.  torch is only imported when the environment hints at more than one rank."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return 0, 1
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def shard_units(n_units: int, rank: int, world_size: int, costs: Sequence[float] | None = None) -> list[int]:
     """Indices of the units rank ``rank`` owns.
 

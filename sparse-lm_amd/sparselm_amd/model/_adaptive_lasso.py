@@ -132,15 +132,17 @@ class AdaptiveLasso(Lasso):
         previous_weights = weights.copy()
         # standardize=True: the loop runs in the per-group QR coordinates, where the engine's group norms
         # are ||X_g b_g|| -- what the reference feeds to the weight update (_adaptive_lasso.py:364-374)
-        Xu, back = self._design_transform(X)
-        problem = self._open_problem(Xu, y, gidx, G, solver_options)
+        dz = self._design_transform(X)
+        problem = self._open_problem(dz.X, dz.target(y), gidx, G, solver_options)
         beta = None
-        warm = self._warm_beta(p) if (hasattr(self, "coef_") and back is None) else None
+        warm = dz.warm(self._warm_beta(p)) if hasattr(self, "coef_") else None
         infos = []
         self.n_iter_ = 0
         try:
             for i in range(self.max_iter):
                 a, b, d = self._weights_to_penalty(weights, p, G)
+                if dz.ridge_absorbed:
+                    d = np.zeros(G)
                 beta0 = warm if beta is None else (beta if self.warm_start else None)
                 beta, group_norms, info = problem.solve(
                     a, b, d, beta0=beta0, want_group_norms=self._needs_group_norms
@@ -158,7 +160,7 @@ class AdaptiveLasso(Lasso):
             raise ValueError("max_iter=0 performs no solve; coef_ would be undefined")
         self.adaptive_weights_ = weights
         self.solver_info_ = {"solves": infos}
-        return beta if back is None else back(beta)
+        return dz.back(beta)
 
 
 class AdaptiveGroupLasso(AdaptiveLasso, GroupLasso):
@@ -263,10 +265,10 @@ class AdaptiveOverlapGroupLasso(AdaptiveGroupLasso, OverlapGroupLasso):
         return np.bincount(bidx, weights=beta_ext, minlength=p)
 
     def _design_transform(self, X_ext):
-        if not self.standardize:
-            return X_ext, None
-        from ._lasso import standardize_groups
+        from ._lasso import Design, standardize_groups
 
+        if not self.standardize:
+            return Design(X_ext)
         return standardize_groups(X_ext, self._ext_groups, int(self._ext_groups.max()) + 1)
 
     def _adaptive_setup(self, X_ext):

@@ -32,9 +32,11 @@ class ProxRegressor(RegressorMixin, BaseEstimator):
         warm_start (bool): start from the previous ``coef_`` when re-fitting.
         solver (str | None): ``None`` or ``"hip"``.  cvxpy solver names are accepted and ignored
             with a warning so reference scripts run unchanged.
-        solver_options (dict | None): engine options: ``tol`` (default 1e-8, relative prox-gradient
-            residual), ``max_iter`` (10000), ``L`` (Lipschitz constant, default estimated),
-            ``restart`` (True), ``device``.
+        solver_options (dict | None): engine options: ``tol`` -- the relative distance to the minimiser a
+            solution is accepted at (KKT residual <= tol * mu * ||coef||, mu the strong-convexity estimate of
+            the active face; default 1e-10 below 2^26 matrix entries, 1e-8 above: ``_backend.default_tol``),
+            ``max_iter`` (10000), ``L`` (Lipschitz constant, default estimated), ``restart`` (True),
+            ``check_every``, ``device``.
 
     Attributes:
         coef_ (ndarray of shape (n_features,)), intercept_ (float), solver_info_ (dict).
@@ -165,9 +167,11 @@ class ProxRegressor(RegressorMixin, BaseEstimator):
         return problem
 
     def _design_transform(self, X):
-        """Hook: return (X_used, back) where ``back`` maps the solution on X_used to coefficients of X
-        (None = identity).  Used by ``standardize=True``."""
-        return X, None
+        """Hook: the design the engine is given and the maps between its unknowns and the coefficients of X
+        (a ``_lasso.Design``; the identity here).  Used by ``standardize=True``."""
+        from ._lasso import Design
+
+        return Design(X)
 
     def _warm_beta(self, n_features):
         if self.warm_start and hasattr(self, "coef_") and np.shape(self.coef_) == (n_features,):
@@ -179,19 +183,19 @@ class ProxRegressor(RegressorMixin, BaseEstimator):
         """Counterpart of CVXRegressor._solve (reference _base.py:512-519): one minimisation."""
         a, b, d, gidx, G = self._penalty(X)
         p = X.shape[1]
-        Xu, back = self._design_transform(X)
-        problem = self._open_problem(Xu, y, gidx, G, solver_options)
+        dz = self._design_transform(X)
+        problem = self._open_problem(dz.X, dz.target(y), gidx, G, solver_options)
         try:
             beta, _, info = problem.solve(
                 np.zeros(p) if a is None else a,
                 np.zeros(G) if b is None else b,
-                np.zeros(G) if d is None else d,
-                beta0=self._warm_beta(p) if back is None else None,
+                np.zeros(G) if (d is None or dz.ridge_absorbed) else d,
+                beta0=dz.warm(self._warm_beta(p)),
             )
         finally:
             problem.close()
         self.solver_info_ = info
-        return beta if back is None else back(beta)
+        return dz.back(beta)
 
     def __sklearn_tags__(self):
         tags = super().__sklearn_tags__()

@@ -68,8 +68,9 @@ class GroupLasso(Lasso):
         alpha (float): regularisation strength.
         group_weights (ndarray | None): weight per group; default ones (reference :233-235 -- the
             reference docstring says sqrt(group size) but the code uses ones).
-        standardize (bool): penalise ``||X_g b_g||`` instead of ``||b_g||`` (reference :249-252).
-            Not implemented by the HIP engine yet.
+        standardize (bool): penalise ``||X_g b_g||`` instead of ``||b_g||`` (reference :249-252): solved
+            through a per-group change of variables (``standardize_groups``); rank-deficient groups get the
+            minimum-norm coefficients among those the objective cannot tell apart.
     """
 
     def __init__(
@@ -113,12 +114,14 @@ class GroupLasso(Lasso):
         check_group_weights(self.group_weights, n_groups)
         if self.standardize and not self._supports_standardize:
             raise NotImplementedError(
-                f"standardize=True is not implemented for {self.__class__.__name__}: its penalty mixes "
-                "||X_g b_g|| with terms on b itself, which the per-group QR change of variables does not keep separable"
+                f"standardize=True is not implemented for {self.__class__.__name__}: its penalty "
+                "lambda1 ||b||_1 + lambda2 sum_g w_g ||X_g b_g||_2 (reference _lasso.py:616-639 with :249-252) mixes a "
+                "norm of X_g b_g with an l1 norm of b itself; no per-group change of variables makes both separable, "
+                "so the proximal step of the engine does not apply"
             )
 
-    # standardize=True is a per-group change of variables (see standardize_groups); it only keeps the
-    # problem inside the prox family for pure group penalties
+    # standardize=True is a per-group change of variables (see standardize_groups); it keeps the problem
+    # inside the prox family for the group penalties (plain, ridged, adaptive, overlap), not for SparseGroupLasso
     _supports_standardize = True
 
     def _needs_host_preprocessing(self) -> bool:
@@ -126,7 +129,7 @@ class GroupLasso(Lasso):
 
     def _design_transform(self, X):
         if not self.standardize:
-            return X, None
+            return Design(X)
         gidx, G = dense_group_index(self.groups, X.shape[1])
         return standardize_groups(X, gidx, G)
 
@@ -140,35 +143,116 @@ class GroupLasso(Lasso):
         return None, self.alpha * w, None, gidx, G
 
 
-def standardize_groups(X, gidx, n_groups):
-    """Per-group thin QR, ``X_g = Q_g R_g``: with ``gamma_g = R_g beta_g`` the standardised penalty
-    ``||X_g beta_g||_2`` (reference _lasso.py:249-252) is the ordinary ``||gamma_g||_2`` on the design
-    ``Q`` and the loss is unchanged (``X beta = Q gamma``).  Returns (Q, back) with
-    ``back(gamma) = beta``.  Needs every group to have full column rank."""
-    from scipy.linalg import solve_triangular
+class Design:
+    """The design the engine is given for one fit, with the maps between its unknowns and the estimator's
+    coefficients (identity unless ``standardize=True``).
 
+    ``X``: the design; ``back(gamma) -> beta``; ``forward(beta) -> gamma`` (warm starts); ``extra_rows``
+    rows of ``X`` carry a quadratic term instead of observations -- the targets there are zero -- and
+    ``scale`` = sqrt(rows / n) multiplies design and targets so that the engine's 1/(2 rows) loss equals the
+    reference's 1/(2 n); ``ridge_absorbed``: the ridge term lives in those rows, the penalty's ``d`` is dropped.
+    """
+
+    def __init__(self, X, back=None, forward=None, extra_rows=0, scale=1.0, ridge_absorbed=False):
+        self.X, self._back, self._forward = X, back, forward
+        self.extra_rows, self.scale, self.ridge_absorbed = int(extra_rows), float(scale), bool(ridge_absorbed)
+
+    @property
+    def identity(self):
+        return self._back is None
+
+    def back(self, gamma):
+        return gamma if self._back is None else self._back(gamma)
+
+    def warm(self, beta):
+        if beta is None or self._forward is None:
+            return beta if self._back is None else None
+        return self._forward(beta)
+
+    def target(self, y):
+        if not self.extra_rows:
+            return y
+        return self.scale * np.concatenate([np.asarray(y, dtype=np.float64), np.zeros(self.extra_rows)])
+
+
+def standardize_groups(X, gidx, n_groups, delta=None):
+    """``standardize=True`` as a per-group change of variables that turns the penalised quantity into an
+    ordinary group norm, so the problem stays inside the prox family.
+
+    * ``delta is None`` -- GroupLasso and its adaptive / overlap variants: the penalty is ``||X_g beta_g||_2``
+      (reference _lasso.py:249-252).  Thin SVD ``X_g = U_g S_g V_g^T``; with ``gamma_g = S_g V_g^T beta_g`` the
+      penalty is ``||gamma_g||_2`` on the design ``U`` and the loss is unchanged (``X beta = U gamma``).  A
+      rank-deficient group (duplicated columns, more features than samples) keeps as many unknowns as its
+      rank -- the other columns of the design are zero and stay at zero -- and ``back`` returns the
+      minimum-norm ``beta_g = V_g S_g^-1 gamma_g`` among the coefficient vectors with that ``X_g beta_g``
+      (the objective does not tell them apart).
+    * ``delta`` given -- RidgedGroupLasso (reference _lasso.py:767-793): the penalty is
+      ``||M_g beta_g||_2`` with ``M_g = sqrtm(X_g^T X_g + sqrt(delta_g) I)`` and the ridge ``1/2 delta_g
+      ||beta_g||^2`` stays on ``beta``.  With ``gamma_g = M_g beta_g`` the design is ``X_g M_g^-1`` and the ridge
+      becomes the quadratic ``1/2 delta_g ||M_g^-1 gamma_g||^2`` -- carried as ``|g|`` extra rows
+      ``sqrt(n delta_g) M_g^-1`` with zero targets under the same 1/(2n) loss.
+
+    Returns a ``Design``."""
     X = np.asarray(X, dtype=np.float64)
-    gidx = np.arange(X.shape[1]) if gidx is None else np.asarray(gidx)
-    Q = np.empty_like(X)
+    n, p = X.shape
+    gidx = np.arange(p) if gidx is None else np.asarray(gidx)
     factors = []
+    if delta is None:
+        Q = np.zeros_like(X)
+        for g in range(n_groups):
+            cols = np.flatnonzero(gidx == g)
+            if not len(cols):
+                continue
+            u, sv, vt = np.linalg.svd(X[:, cols], full_matrices=False)
+            r = int(np.sum(sv > 1e-12 * max(sv[0], 1e-300))) if len(sv) else 0
+            Q[:, cols[:r]] = u[:, :r]
+            factors.append((cols, r, sv[:r], vt[:r]))
+
+        def back(gamma):
+            beta = np.zeros_like(gamma)
+            for cols, r, sv, vt in factors:
+                beta[cols] = vt.T @ (gamma[cols[:r]] / sv)
+            return beta
+
+        def forward(beta):
+            gamma = np.zeros_like(beta)
+            for cols, r, sv, vt in factors:
+                gamma[cols[:r]] = sv * (vt @ beta[cols])
+            return gamma
+
+        return Design(Q, back, forward)
+
+    delta = np.broadcast_to(np.asarray(delta, dtype=np.float64), (n_groups,))
+    rows = n + p
+    Xa = np.zeros((rows, p))
     for g in range(n_groups):
         cols = np.flatnonzero(gidx == g)
-        if len(cols) > X.shape[0]:
-            raise ValueError(f"standardize=True: group {g} has more features than there are samples")
-        q, r = np.linalg.qr(X[:, cols])
-        diag = np.abs(np.diag(r))
-        if len(cols) and diag.min() <= 1e-12 * max(diag.max(), 1e-300):
-            raise ValueError(f"standardize=True: the columns of group {g} are linearly dependent")
-        Q[:, cols] = q
-        factors.append((cols, r))
+        if not len(cols):
+            continue
+        lam, V = np.linalg.eigh(X[:, cols].T @ X[:, cols])
+        m = np.sqrt(np.maximum(lam, 0.0) + np.sqrt(delta[g]))
+        if m.min() <= 1e-12 * max(m.max(), 1e-300):
+            raise ValueError(f"standardize=True: group {g} is rank deficient and delta is zero there: "
+                             "sqrtm(X_g^T X_g + sqrt(delta_g) I) is singular")
+        Minv = (V / m) @ V.T
+        Xa[:n, cols] = X[:, cols] @ Minv
+        Xa[n + cols[:, None], cols[None, :]] = np.sqrt(n * delta[g]) * Minv
+        factors.append((cols, Minv, (V * m) @ V.T))
+    scale = np.sqrt(rows / n)
 
     def back(gamma):
-        beta = np.empty_like(gamma)
-        for cols, r in factors:
-            beta[cols] = solve_triangular(r, gamma[cols], lower=False)
+        beta = np.zeros_like(gamma)
+        for cols, Minv, _ in factors:
+            beta[cols] = Minv @ gamma[cols]
         return beta
 
-    return Q, back
+    def forward(beta):
+        gamma = np.zeros_like(beta)
+        for cols, _, M in factors:
+            gamma[cols] = M @ beta[cols]
+        return gamma
+
+    return Design(scale * Xa, back, forward, extra_rows=p, scale=scale, ridge_absorbed=True)
 
 
 def overlap_extension(group_list, n_features):
@@ -256,18 +340,15 @@ class OverlapGroupLasso(GroupLasso):
         p = X.shape[1]
         bidx, ext, G = self._extended(X)
         w = np.ones(G) if self.group_weights is None else np.asarray(self.group_weights, dtype=np.float64)
-        X_ext, back = np.ascontiguousarray(X[:, bidx]), None
-        if self.standardize:
-            X_ext, back = standardize_groups(X_ext, ext, G)
-        problem = self._open_problem(X_ext, y, ext, G, solver_options)
+        X_ext = np.ascontiguousarray(X[:, bidx])
+        dz = standardize_groups(X_ext, ext, G) if self.standardize else Design(X_ext)
+        problem = self._open_problem(dz.X, dz.target(y), ext, G, solver_options)
         try:
             beta_ext, _, info = problem.solve(np.zeros(len(bidx)), self.alpha * w, np.zeros(G))
         finally:
             problem.close()
         self.solver_info_ = info
-        if back is not None:
-            beta_ext = back(beta_ext)
-        return np.bincount(bidx, weights=beta_ext, minlength=p)
+        return np.bincount(bidx, weights=dz.back(beta_ext), minlength=p)
 
 
 class SparseGroupLasso(GroupLasso):
@@ -333,14 +414,20 @@ class RidgedGroupLasso(GroupLasso):
 
     Args:
         delta (ndarray | tuple): ridge weight, length 1 (shared) or one per group (:744-765).
+        standardize (bool): the group norms become ``||sqrtm(X_g^T X_g + sqrt(delta_g) I) b_g||_2``
+            (reference :767-793) while the ridge stays on ``b``; see ``standardize_groups(delta=...)``.
     """
-
-    _supports_standardize = False
 
     _hyper_parameter_constraints: dict = {
         "alpha": [Interval(type=Real, left=0.0, right=None, closed="left")],
         "delta": ["array-like", Interval(type=Real, left=0.0, right=None, closed="left")],
     }
+
+    def _design_transform(self, X):
+        if not self.standardize:
+            return Design(X)
+        gidx, G = dense_group_index(self.groups, X.shape[1])
+        return standardize_groups(X, gidx, G, delta=self._delta_vector(G))
 
     def __init__(
         self,

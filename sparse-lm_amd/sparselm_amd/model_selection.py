@@ -33,8 +33,8 @@ fit; sample weights, custom scorers, grids without ``alpha``) runs through sciki
 from __future__ import annotations
 
 import numbers
-import re
 import time
+import warnings
 from collections import defaultdict
 from copy import deepcopy
 
@@ -56,23 +56,28 @@ _FAST_SCORINGS = ("neg_root_mean_squared_error", "neg_mean_squared_error", "r2")
 
 
 def select_best_index_onestd(results, refit_metric="score"):
-    """One-standard-error rule (reference model_selection.py:190-223): among the candidates whose
-    summed non-negative numerical hyper-parameters are at least those of the best-scoring one,
-    take the one whose mean score is closest to (best mean - its std)."""
-    opt_index = results[f"rank_test_{refit_metric}"].argmin()
-    m = results[f"mean_test_{refit_metric}"][opt_index]
-    sig = results[f"std_test_{refit_metric}"][opt_index]
-    metrics = results[f"mean_test_{refit_metric}"]
-    params = []
-    for name in (key for key in results if re.match(r"^param_(\w+)", key)):
-        if all(isinstance(val, numbers.Number) for val in results[name]):
-            p = np.array(results[name], dtype=float)
-            if np.all(p > -1e-9):
-                params.append(p)
-    params_sum = np.sum(params, axis=0)
-    one_std_dists = np.abs(metrics - m + sig)
-    candidates = np.arange(len(metrics))[params_sum >= params_sum[opt_index]]
-    return int(candidates[np.argmin(one_std_dists[candidates])])
+    """One-standard-error rule (behaviour of reference model_selection.py:190-223).
+
+    Start from the best-ranked candidate, mean score ``m*`` with standard deviation ``s*`` over the folds.
+    Its "size" is the sum of its numerical hyper-parameters -- only the columns whose values are all numbers
+    and all >= 0 (up to 1e-9) count: regularisation strengths.  Among the candidates at least that large the
+    winner is the one whose mean score lies closest to ``m* - s*``: the most regularised model still within
+    one standard error of the best."""
+    mean = np.asarray(results[f"mean_test_{refit_metric}"], dtype=float)
+    best = int(np.argmin(results[f"rank_test_{refit_metric}"]))
+    target = mean[best] - results[f"std_test_{refit_metric}"][best]
+    size = np.zeros(len(mean))
+    for key, column in results.items():
+        if not key.startswith("param_"):
+            continue
+        values = list(column)
+        if not all(isinstance(v, numbers.Number) for v in values):
+            continue
+        values = np.asarray(values, dtype=float)
+        if np.all(values > -1e-9):
+            size += values
+    eligible = np.flatnonzero(size >= size[best])
+    return int(eligible[np.argmin(np.abs(mean[eligible] - target))])
 
 
 class GridSearchCV(_GridSearchCV):
@@ -85,8 +90,10 @@ class GridSearchCV(_GridSearchCV):
         opt_selection_method (str): "max_score" (default) or "one_std_score".
         scoring: default "neg_root_mean_squared_error" (reference :166).
         n_jobs, refit, cv, verbose, pre_dispatch, error_score, return_train_score: as scikit-learn.
-        lanes (int): (fold, grid-row) units solved per pass over X on the fast path (1..10, default
-            10; the engine falls back to fewer where no kernel variant serves that many).
+        lanes (int): (fold, grid-row) units solved per pass over X on the fast path (1..16, default
+            16; the engine falls back to fewer where no kernel variant serves that many).
+        error_score: as scikit-learn; on the fast path a batch whose solve fails (non-finite iterate) scores
+            ``error_score`` in its cells, or re-raises with ``error_score="raise"``.
     """
 
     def __init__(
@@ -148,12 +155,19 @@ class GridSearchCV(_GridSearchCV):
     # ---- generic: scikit-learn's loop + selection rule ------------------------------------------
     def _fit_generic(self, X, y, groups, fit_params):
         user_refit = self.refit
-        if self.opt_selection_method == "one_std_score" and user_refit is True:
+        onestd = self.opt_selection_method == "one_std_score"
+        if onestd and user_refit is True:
             self.refit = lambda results: select_best_index_onestd(results)
         try:
             super().fit(X, y, groups=groups, **fit_params)
         finally:
             self.refit = user_refit
+        # the rule applies to every single-metric search, refitted or not (reference :356-372): with
+        # refit=False (LineSearchCV lines do that) best_params_ must still be the one-std choice
+        if onestd and not self.multimetric_ and not (user_refit is True):
+            if isinstance(user_refit, str) or not user_refit:
+                self.best_index_ = select_best_index_onestd(self.cv_results_)
+                self.best_params_ = self.cv_results_["params"][self.best_index_]
         if hasattr(self, "best_index_"):
             self.best_score_ = self.cv_results_["mean_test_score"][self.best_index_]
             self.best_score_std_ = self.cv_results_["std_test_score"][self.best_index_]
@@ -201,7 +215,7 @@ class GridSearchCV(_GridSearchCV):
             t[test] = 1.0
             test_masks.append(t)
 
-        rank, world, local_rank = D.world()
+        rank, world = D.active_world()
         eng = _engine.get_engine()
         t0 = time.perf_counter()
         scores = np.full((len(candidates), n_splits), np.nan)
@@ -232,14 +246,23 @@ class GridSearchCV(_GridSearchCV):
             opts = _solver_options(est)
             opts.setdefault("tol", _backend.default_tol(n, p))
             local = {}
+            unconverged = 0
             for k0 in range(0, len(my_units), lanes):
                 batch = my_units[k0 : k0 + lanes]
                 if adaptive:
                     ests = [clone(est).set_params(**candidates[combos[c][0]]) for c, _ in batch]
                     t_batch = time.perf_counter()
-                    fits = _adaptive_lanes(ds, ests, X, [train_masks[f] for _, f in batch],
-                                           [len(splits[f][0]) for _, f in batch], opts, with_intercept)
+                    try:
+                        fits = _adaptive_lanes(ds, ests, X, [train_masks[f] for _, f in batch],
+                                               [len(splits[f][0]) for _, f in batch], opts, with_intercept)
+                    except _engine.NonFiniteError:
+                        if self.error_score == "raise":
+                            raise
+                        for c, f in batch:
+                            local[(c, f)] = (combos[c], np.full(len(combos[c]), self.error_score, dtype=float), 0.0)
+                        continue
                     dt = (time.perf_counter() - t_batch) / len(batch)
+                    unconverged += sum(not i["converged"] for fit in fits for i in fit["infos"])
                     for (c, f), fit in zip(batch, fits):
                         sse = ds.eval_sse(fit["beta"][None, :], test_masks[f])
                         local[(c, f)] = (combos[c], self._score_from_sse(sse, y[splits[f][1]]), dt)
@@ -266,7 +289,15 @@ class GridSearchCV(_GridSearchCV):
                         specs.append(dict(points=pts[part], a=a, b=b, d=d, row_weight=train_masks[f], n_eff=len(train)))
                     metas.append((cis, test, split))
                 t_batch = time.perf_counter()
-                results = _solve_lanes_with_fallback(ds, specs, opts)
+                try:
+                    results = _solve_lanes_with_fallback(ds, specs, opts)
+                except _engine.NonFiniteError:  # the counterpart of a failing fit in _fit_and_score
+                    if self.error_score == "raise":
+                        raise
+                    for (c, f), (cis, _, _) in zip(batch, metas):
+                        local[(c, f)] = (cis, np.full(len(cis), self.error_score, dtype=float), 0.0)
+                    continue
+                unconverged += sum(not r.converged for r in results)
                 dt = (time.perf_counter() - t_batch) / max(1, sum(len(m[0]) for m in metas))
                 at = 0
                 for (c, f), (cis, test, split) in zip(batch, metas):
@@ -274,10 +305,12 @@ class GridSearchCV(_GridSearchCV):
                     at += split
                     sse = ds.eval_sse(betas, test_masks[f])
                     local[(c, f)] = (cis, self._score_from_sse(sse, y[test]), dt)
-            merged = _gather(local, units)
+            merged = _gather(local, units, world)
             for (c, f), (cis, sc, dt) in merged.items():
                 scores[cis, f] = sc
                 fit_time[cis, f] = dt
+            if unconverged:
+                self._warn_unconverged(unconverged, "grid cell solves", opts)
 
             self.cv_results_ = _format_results(candidates, scores, fit_time)
             self.n_splits_ = n_splits
@@ -299,6 +332,8 @@ class GridSearchCV(_GridSearchCV):
                     best.n_iter_ = fit["n_iter"]
                     best.adaptive_weights_ = fit["weights"]
                     best.solver_info_ = {"solves": fit["infos"]}
+                    if not all(i["converged"] for i in fit["infos"]):
+                        self._warn_unconverged(1, "the refit", opts)
                 else:
                     a, b, d, _, G_b = best._penalty(X)
                     a, b, d = with_intercept(a, b, d, G_b if G_b is not None else p)
@@ -311,6 +346,8 @@ class GridSearchCV(_GridSearchCV):
                     )
                     beta_aug = res.betas[0]
                     best.solver_info_ = {"n_iter": int(res.n_iter[0]), "converged": res.converged}
+                    if not res.converged:
+                        self._warn_unconverged(1, "the refit", opts)
                 best.coef_ = beta_aug[:p].copy()
                 best.intercept_ = float(beta_aug[p]) if intercept else 0.0
                 best.n_features_in_ = p
@@ -318,6 +355,17 @@ class GridSearchCV(_GridSearchCV):
                 self.refit_time_ = time.perf_counter() - t1
         self.search_time_ = time.perf_counter() - t0
         return self
+
+    @staticmethod
+    def _warn_unconverged(count, what, opts):
+        from sklearn.exceptions import ConvergenceWarning
+
+        warnings.warn(
+            f"{count} of {what} stopped at max_iter={opts.get('max_iter', 10000)} before reaching "
+            f"tol={opts.get('tol')}: the scores / coefficients come from unconverged iterates; increase "
+            "solver_options['max_iter'].",
+            ConvergenceWarning,
+        )
 
     def _score_from_sse(self, sse, y_test):
         mse = sse / len(y_test)
@@ -437,6 +485,8 @@ class LineSearchCV(BaseSearchCV):
 
 
 def _solver_options(est) -> dict:
+    """``solver_options`` as keyword arguments of ``Dataset.solve_lanes`` / ``solve_path`` -- the same
+    options, with the same meaning, as ``_backend.SolveProblem.solve`` gives a plain ``fit``."""
     from ._backend import normalise_options
 
     o = normalise_options(est.solver_options)
@@ -445,6 +495,12 @@ def _solver_options(est) -> dict:
         out["tol"] = float(o["tol"])
     if "max_iter" in o:
         out["max_iter"] = int(o["max_iter"])
+    if "L" in o:
+        out["L"] = float(o["L"])
+    if "check_every" in o:
+        out["check_every"] = int(o["check_every"])
+    if not o.get("restart", True):
+        out["flags"] = _engine.FLAG_NO_RESTART
     return out
 
 
@@ -498,16 +554,17 @@ def _adaptive_lanes(ds, ests, X, row_weights, n_effs, opts, with_intercept):
     return [dict(beta=s["beta"], n_iter=s["n_iter"], weights=s["w"], infos=s["infos"]) for s in st]
 
 
-def _gather(local: dict, units) -> dict:
-    import torch.distributed as dist
+def _gather(local: dict, units, world: int = 1) -> dict:
+    """Every rank's cells on every rank; the check that no unit is missing runs whatever the world size."""
+    merged = dict(local)
+    if world > 1:
+        import torch.distributed as dist  # (only a multi-rank search needs torch at all)
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local
-    parts = [None] * dist.get_world_size()
-    dist.all_gather_object(parts, local)
-    merged = {}
-    for part in parts:
-        merged.update(part)
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, local)
+        merged = {}
+        for part in parts:
+            merged.update(part)
     missing = [u for u in units if u not in merged]
     if missing:
         raise RuntimeError(f"grid units {missing[:4]} were not solved by any rank")

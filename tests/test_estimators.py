@@ -202,6 +202,75 @@ def test_standardize_penalises_group_predictions(backend, golden):
         SparseGroupLasso(groups=groups, standardize=True).fit(X, y)
 
 
+def test_standardized_ridged_group_lasso_satisfies_its_optimality_conditions(backend, golden):
+    """standardize=True for the ridged penalty (reference _lasso.py:767-793): group norms
+    ||M_g b_g||, M_g = sqrtm(X_g^T X_g + sqrt(delta_g) I), ridge 1/2 delta_g ||b_g||^2 on b.  The fit is checked
+    through the optimality conditions in the ORIGINAL coordinates, which know nothing of the change of variables
+    the estimator solves it with."""
+    from scipy.linalg import sqrtm
+
+    X, y, groups, gw = golden["grp_X"], golden["grp_y"], golden["grp_groups"], golden["grp_gw"]
+    n = len(y)
+    gidx, G = oracle.group_index(groups, X.shape[1])
+    alpha = 0.6
+    delta = np.linspace(0.5, 2.0, G)
+    m = RidgedGroupLasso(groups=groups, alpha=alpha, delta=delta, group_weights=gw, standardize=True,
+                         solver_options=TIGHT).fit(X, y)
+    r = X @ m.coef_ - y
+    n_active = 0
+    for g in range(G):
+        cols = gidx == g
+        Xg, bg = X[:, cols], m.coef_[cols]
+        M = np.real(sqrtm(Xg.T @ Xg + np.sqrt(delta[g]) * np.eye(cols.sum())))
+        grad = Xg.T @ r / n + delta[g] * bg
+        if np.linalg.norm(bg) > 1e-10:
+            n_active += 1
+            sub = alpha * gw[g] * (M @ M @ bg) / np.linalg.norm(M @ bg)
+            assert np.max(np.abs(grad + sub)) < 1e-7 * max(1.0, np.max(np.abs(sub)))
+        else:
+            assert np.linalg.norm(np.linalg.solve(M, grad)) <= alpha * gw[g] * (1 + 1e-7)
+    assert 0 < n_active < G
+    # the unstandardised fit is a different model
+    m0 = RidgedGroupLasso(groups=groups, alpha=alpha, delta=delta, group_weights=gw, solver_options=TIGHT).fit(X, y)
+    assert rel_inf(m.coef_, m0.coef_) > 1e-3
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        am = AdaptiveRidgedGroupLasso(groups=groups, alpha=alpha, delta=delta, standardize=True, fit_intercept=True,
+                                      solver_options=TIGHT).fit(X, y)
+    assert am.n_iter_ >= 2 and np.all(np.isfinite(am.coef_)) and am.intercept_ != 0.0
+
+
+def test_standardize_with_a_rank_deficient_group_and_warm_starts(backend, golden):
+    """A group with a duplicated column: ||X_g b_g|| cannot tell its two copies apart.  The reference hands that
+    to cvxpy as it is; here the group keeps as many unknowns as its rank and the minimum-norm coefficients are
+    reported.  Optimality is checked on what the objective does see: X_g b_g."""
+    X, y, groups, gw = golden["grp_X"].copy(), golden["grp_y"], golden["grp_groups"], golden["grp_gw"]
+    n = len(y)
+    gidx, G = oracle.group_index(groups, X.shape[1])
+    cols0 = np.flatnonzero(gidx == 0)
+    X[:, cols0[1]] = X[:, cols0[0]]  # rank deficient on purpose
+    alpha = 0.3
+    est = GroupLasso(groups=groups, alpha=alpha, group_weights=gw, standardize=True, warm_start=True, solver_options=TIGHT)
+    m = est.fit(X, y)
+    assert m.coef_[cols0[0]] == pytest.approx(m.coef_[cols0[1]], abs=1e-9)  # minimum norm: the copies share the load
+    r = X @ m.coef_ - y
+    for g in range(G):
+        Xg = X[:, gidx == g]
+        fit = Xg @ m.coef_[gidx == g]
+        grad = Xg.T @ r / n
+        if np.linalg.norm(fit) > 1e-9:
+            assert np.max(np.abs(grad + alpha * gw[g] * Xg.T @ fit / np.linalg.norm(fit))) < 1e-7
+        else:
+            u = np.linalg.lstsq(alpha * gw[g] * Xg.T, -grad, rcond=None)[0]
+            assert np.linalg.norm(u) <= 1 + 1e-7
+    # warm start in the transformed coordinates: the second fit starts at the solution
+    first = m.coef_.copy()
+    n1 = m.solver_info_["n_iter"]
+    m2 = est.fit(X, y)
+    assert rel_inf(m2.coef_, first) < 1e-8
+    assert m2.solver_info_["n_iter"] <= max(2, n1 // 3)
+
+
 # ---- structural properties from the reference tests ------------------------------------------------
 def test_adaptive_lasso_sparser(backend, random_model):
     # /root/reference/tests/test_lasso.py:77-85

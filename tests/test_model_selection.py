@@ -327,3 +327,37 @@ def test_device_fast_path_against_the_oracle_backend(golden, intercept):
         scale = np.max(np.abs(ref.best_estimator_.coef_))
         np.testing.assert_allclose(fast.best_estimator_.coef_, ref.best_estimator_.coef_, rtol=0, atol=1e-6 * scale)
         assert fast.best_estimator_.intercept_ == pytest.approx(ref.best_estimator_.intercept_, abs=1e-6 * max(1.0, abs(ref.best_estimator_.intercept_)))
+
+
+def test_one_std_rule_applies_without_refit_on_the_generic_path():
+    """reference model_selection.py:356-372: the rule picks best_index_ for every single-metric search, refitted or
+    not -- LineSearchCV(refit=False) hands best_params_ from one line to the next."""
+    X, y = make_regression(n_samples=120, n_features=40, n_informative=6, noise=25.0, random_state=1)
+    params = {"alpha": np.logspace(-1, 1.5, 9)}
+    cv = KFold(4, shuffle=True, random_state=0)
+    with_refit = GridSearchCV(SkLasso(), params, opt_selection_method="one_std_score", cv=cv).fit(X, y)
+    no_refit = GridSearchCV(SkLasso(), params, opt_selection_method="one_std_score", cv=cv, refit=False).fit(X, y)
+    plain = GridSearchCV(SkLasso(), params, cv=cv, refit=False).fit(X, y)
+    assert no_refit.best_index_ == with_refit.best_index_ == select_best_index_onestd(no_refit.cv_results_)
+    assert no_refit.best_params_ == with_refit.best_params_
+    assert no_refit.best_params_["alpha"] > plain.best_params_["alpha"]  # (on this data the rule does move the choice)
+    assert no_refit.best_score_ == pytest.approx(no_refit.cv_results_["mean_test_score"][no_refit.best_index_])
+    assert not hasattr(no_refit, "best_estimator_")
+
+
+def test_world_size_in_the_environment_without_a_process_group_means_one_rank(monkeypatch):
+    """torchrun / SLURM export WORLD_SIZE whether or not the script ever calls init_process_group: without a group
+    there is nobody to gather from, so the search must not deal 1/world of the grid to this process."""
+    from sparselm_amd import distributed as D
+    from sparselm_amd.model_selection import _gather
+
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "2")
+    assert D.active_world() == (0, 1)
+    monkeypatch.delenv("WORLD_SIZE")
+    assert D.active_world() == (0, 1)
+    units = [(0, 0), (0, 1), (1, 0)]
+    full = {u: ([0], np.zeros(1), 0.0) for u in units}
+    assert _gather(full, units) == full
+    with pytest.raises(RuntimeError, match="not solved by any rank"):  # the check runs on the single-rank branch too
+        _gather({units[0]: full[units[0]]}, units)
