@@ -8,9 +8,12 @@ Sources of truth, none of which is this repo's product code:
   * closed-form weighted least squares (alpha = 0);
   * group labels produced by the reference's ``sparselm.dataset.make_group_regression``
     (importable here from /root/reference/src: it needs only numpy + sklearn);
-  * for group / sparse-group / ridged / adaptive fits, where no independent solver exists in this
-    container (cvxpy is absent), the oracle's own solutions together with their KKT residuals
-    ("parity unpinned" against cvxpy, certified optimal to the stated residual).
+  * for group / sparse-group / ridged / adaptive fits (cvxpy is absent, the reference's tests hold no
+    numbers): the oracle's solutions with their KKT residuals AND, next to each, the solution of
+    tests/golden/second_solver.py -- an active-set method with Newton's method on the optimality
+    conditions of the face (scipy.optimize.root), sharing no code with the oracle's proximal-gradient
+    iteration (keys ``*_coef2``; tests/test_oracle.py holds the two to 1e-8 of each other).  Still
+    "parity unpinned" against cvxpy itself, but no longer resting on one implementation.
 
 Usage:  python tests/golden/make_golden.py     (writes tests/golden/*.npz)
 """
@@ -29,7 +32,10 @@ ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference/src")
 
+sys.path.insert(0, HERE)
+
 import oracle  # noqa: E402
+import second_solver  # noqa: E402
 from sparselm.dataset import make_group_regression  # noqa: E402  (reference, numpy+sklearn only)
 
 
@@ -129,6 +135,14 @@ def main():
         Xg, yg, groups=groups, alpha=1.5, delta=(0.7,), group_weights=gw, fit_intercept=True
     )
     out["ada_rgl_coef"], out["ada_rgl_icpt"], out["ada_rgl_w"], out["ada_rgl_niter"] = r["coef"], r["intercept"], r["weights"], r["n_iter"]
+
+    # the same fits by the second, independent solver (active set + Newton on the face)
+    out["grp_gl_coef2"] = second_solver.group_lasso(Xg, yg, groups, alpha_g, gw)
+    out["grp_sgl_coef2"] = second_solver.group_lasso(Xg, yg, groups, alpha_g, gw, l1_ratio=0.3)
+    out["grp_rgl_coef2"] = second_solver.group_lasso(Xg, yg, groups, alpha_g, gw, delta=delta)
+    for key, kw in (("ada_gl", {}), ("ada_sgl", {"l1_ratio": 0.4}), ("ada_rgl", {"delta": (0.7,)})):
+        r2 = second_solver.adaptive(Xg, yg, groups, 1.5, gw, fit_intercept=True, **kw)
+        out[f"{key}_coef2"], out[f"{key}_icpt2"], out[f"{key}_niter2"] = r2["coef"], r2["intercept"], r2["n_iter"]
 
     # ---- 5. AdaptiveLasso inner-solve sequence pinned by sklearn CD (weights = alpha^2/(|b|+eps)) -
     alpha_a, eps = 1.5, 1e-6

@@ -498,3 +498,45 @@ def test_default_tolerance_holds_1e6_on_correlated_reference_sized_designs():
                 warnings.simplefilter("error")
                 got = Lasso(alpha=frac * amax).fit(X, y).coef_
             assert np.max(np.abs(got - ref)) <= 1e-6 * np.max(np.abs(ref)), (n, p, rho, frac)
+
+
+@pytest.mark.gpu
+def test_against_a_cvxpy_formulation_when_cvxpy_is_installed(golden):
+    """SURVEY 8(c), last bullet: where cvxpy can be imported (it cannot in the build container, and normally not
+    on the GPU box either -- the test is then skipped), the penalty family written out in cvxpy from the math
+        1/(2n) ||X b - y||^2 + a ||b||_1 + sum_g b_g ||b_g||_2 + 1/2 sum_g d_g ||b_g||_2^2
+    (reference src/sparselm/model/_lasso.py:109-121, 267-275, 627-639, 795-811) and handed to its default conic
+    solver is the reference's own route (`problem.solve()`, model/_base.py:516-518): the HIP estimators have to
+    land within the north-star 1e-6 rel-inf of it."""
+    cp = pytest.importorskip("cvxpy")
+    X, y, groups, gw = golden["grp_X"], golden["grp_y"], golden["grp_groups"], golden["grp_gw"]
+    n, p = X.shape
+    gidx, G = oracle.group_index(groups, p)
+    alpha = float(golden["grp_alpha"])
+    delta = golden["grp_delta"]
+
+    def cvx(a, b, d):
+        beta = cp.Variable(p)
+        obj = cp.sum_squares(X @ beta - y) / (2 * n) + a * cp.norm1(beta)
+        for g in range(G):
+            bg = beta[np.flatnonzero(gidx == g)]
+            obj = obj + b[g] * cp.norm2(bg) + 0.5 * d[g] * cp.sum_squares(bg)
+        prob = cp.Problem(cp.Minimize(obj))
+        try:
+            prob.solve(solver="CLARABEL", tol_gap_abs=1e-12, tol_gap_rel=1e-12, tol_feas=1e-12)
+        except Exception:
+            prob.solve()
+        return np.asarray(beta.value)
+
+    cases = [
+        (Lasso(alpha=alpha, solver_options=TIGHT), (alpha, np.zeros(G), np.zeros(G))),
+        (GroupLasso(groups=groups, alpha=alpha, group_weights=gw, solver_options=TIGHT), (0.0, alpha * gw, np.zeros(G))),
+        (SparseGroupLasso(groups=groups, l1_ratio=0.3, alpha=alpha, group_weights=gw, solver_options=TIGHT),
+         (0.3 * alpha, 0.7 * alpha * gw, np.zeros(G))),
+        (RidgedGroupLasso(groups=groups, alpha=alpha, delta=delta, group_weights=gw, solver_options=TIGHT),
+         (0.0, alpha * gw, delta)),
+    ]
+    for est, (a, b, d) in cases:
+        ref = cvx(a, b, d)
+        got = est.fit(X, y).coef_
+        assert np.max(np.abs(got - ref)) <= 1e-6 * np.max(np.abs(ref)), type(est).__name__

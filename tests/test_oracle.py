@@ -92,6 +92,46 @@ def test_group_fits_are_kkt_certified(golden, kind):
             assert m.all() or (~m).all()
 
 
+@pytest.mark.parametrize("kind", ["gl", "sgl", "rgl", "ada_gl", "ada_sgl", "ada_rgl"])
+def test_group_family_agrees_with_the_second_solver(golden, kind):
+    """The second pin of the group family: tests/golden/second_solver.py (active-set method, Newton's method
+    on the optimality conditions of the face; no code shared with the oracle's proximal-gradient iteration) is
+    run here AND its committed results are compared -- oracle, fresh second solve and fixture agree to 1e-8."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import second_solver as S
+
+    X, y, groups, gw = golden["grp_X"], golden["grp_y"], golden["grp_groups"], golden["grp_gw"]
+    alpha = float(golden["grp_alpha"])
+    if kind == "gl":
+        mine = oracle.fit_group_lasso(X, y, groups=groups, alpha=alpha, group_weights=gw)["coef"]
+        other = S.group_lasso(X, y, groups, alpha, gw)
+        stored = golden["grp_gl_coef2"]
+    elif kind == "sgl":
+        mine = oracle.fit_sparse_group_lasso(X, y, groups=groups, l1_ratio=0.3, alpha=alpha, group_weights=gw)["coef"]
+        other = S.group_lasso(X, y, groups, alpha, gw, l1_ratio=0.3)
+        stored = golden["grp_sgl_coef2"]
+    elif kind == "rgl":
+        mine = oracle.fit_ridged_group_lasso(X, y, groups=groups, alpha=alpha, delta=golden["grp_delta"], group_weights=gw)["coef"]
+        other = S.group_lasso(X, y, groups, alpha, gw, delta=golden["grp_delta"])
+        stored = golden["grp_rgl_coef2"]
+    else:
+        kw = {"ada_gl": {}, "ada_sgl": {"l1_ratio": 0.4}, "ada_rgl": {"delta": (0.7,)}}[kind]
+        fit = {"ada_gl": oracle.fit_adaptive_group_lasso, "ada_sgl": oracle.fit_adaptive_sparse_group_lasso,
+               "ada_rgl": oracle.fit_adaptive_ridged_group_lasso}[kind]
+        r = fit(X, y, groups=groups, alpha=1.5, group_weights=gw, fit_intercept=True, **kw)
+        r2 = S.adaptive(X, y, groups, 1.5, gw, fit_intercept=True, **kw)
+        assert r["n_iter"] == r2["n_iter"] == int(golden[f"{kind}_niter2"])
+        npt.assert_allclose(r["intercept"], r2["intercept"], rtol=1e-9)
+        mine, other, stored = r["coef"], r2["coef"], golden[f"{kind}_coef2"]
+    scale = np.max(np.abs(other))
+    assert np.max(np.abs(mine - other)) <= 1e-8 * scale
+    assert np.max(np.abs(other - stored)) <= 1e-8 * scale
+    assert np.array_equal(mine != 0, other != 0)  # same support, exact zeros on both sides
+
+
 def test_prox_matches_bruteforce_minimiser(rng):
     # prox_s(v) = argmin_u 1/2||u - v||^2 + s*pen(u): check optimality by perturbation on a tiny case
     p = 7
