@@ -360,6 +360,7 @@ struct slm_dataset {
   int32_t *ws_idx = nullptr, *ws_pos = nullptr, *ws_gs = nullptr, *ws_gl = nullptr;
   double *ws_score = nullptr, *ws_XW = nullptr, *ws_part = nullptr, *ws_G = nullptr, *ws_Gx = nullptr;
   double* ws_nt = nullptr;  // [kMaxLanes][NT_SCRATCH] factors of the model solver's direct steps
+  PathCtl h_stage[SLM_MAX_LANES];  // host staging of the control blocks of the solve in flight
   double* stop_words = nullptr;  // [STOP_WORDS] row-sharded mode: the vector the ranks all-reduce after every pass
   double* XT = nullptr;  // column-major copy of X for the column gathers ([ld][ldt]), built on first use
   int64_t ldt = 0;
@@ -1065,6 +1066,7 @@ static int power_iteration(slm_dataset* ds, const LaneSetup& ls_in, double* L_ou
     hipLaunchKernelGGL(power_step_kernel, dim3(ls.B), dim3(TAIL_THREADS), 0, s, pa);
   }
   SLM_TRY(check_launch());
+  if (!L_out) return SLM_OK;  // the caller consumes ds->lambda on the device (seed_step_kernel)
   double lam[SLM_MAX_LANES] = {};
   HIP_TRY(hipMemcpyAsync(lam, ds->lambda, sizeof(double) * ls.B, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1371,17 +1373,13 @@ extern "C" int slm_eval_sse_sparse(slm_dataset* ds, const int32_t* cols, int32_t
 // ------------------------------------------------------------------------------------------------
 // path solves
 // ------------------------------------------------------------------------------------------------
-static int upload_vec_or_const(double* dst, const double* src, int64_t count, double fill, hipStream_t s) {
-  if (src) {
-    for (int64_t i = 0; i < count; ++i)
-      if (!(src[i] >= 0.0) || !std::isfinite(src[i]))
-        return fail(SLM_ERR_BAD_ARG, "penalty weights must be finite and >= 0 (index %lld)", (long long)i);
-    HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  } else {
-    const int blocks = (int)std::min<int64_t>(1024, (count + 255) / 256);
-    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, dst, count, fill);
-  }
+// penalty weights handed over by the caller: validated, then queued for upload (the caller's buffer stays
+// valid for the whole call; solve_core synchronises once before it returns to anything that could free it)
+static int upload_weights(double* dst, const double* src, int64_t count, hipStream_t s) {
+  for (int64_t i = 0; i < count; ++i)
+    if (!(src[i] >= 0.0) || !std::isfinite(src[i]))
+      return fail(SLM_ERR_BAD_ARG, "penalty weights must be finite and >= 0 (index %lld)", (long long)i);
+  HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyHostToDevice, s));
   return SLM_OK;
 }
 
@@ -1455,6 +1453,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   slm_engine* eng = ds->eng;
   HIP_TRY(hipSetDevice(eng->device));
   hipStream_t s = eng->stream;
+  // Uploads from the caller's buffers and from the dataset's staging area are asynchronous: whichever way this
+  // function is left, the stream is drained first (on the normal path it already is: a no-op then).
+  struct DrainOnExit {
+    hipStream_t s;
+    ~DrainOnExit() { (void)hipStreamSynchronize(s); }
+  } drain_on_exit{s};
   const auto t_begin = std::chrono::steady_clock::now();
   auto t_mark = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   double tr[6] = {0, 0, 0, 0, 0, 0};
@@ -1500,6 +1504,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // ---- Lipschitz constants -----------------------------------------------------------------------
   double L[SLM_MAX_LANES];
   double lipschitz_ms = 0.0;
+  bool L_on_device = false;  // the estimate stays on the device (no host round trip before the first pass)
   if (o.L > 0.0) {
     for (int l = 0; l < B; ++l) L[l] = o.L;
   } else {
@@ -1510,6 +1515,15 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     const bool sketch = ws_policy(ds, o.flags) == 2 && n >= 65536 && !getenv("SLM_NO_L_SKETCH");
     if (sketch && !(ds->L_valid && !(o.flags & SLM_FLAG_FRESH_L) && !any_rw && !custom_scale)) {
       const bool per_lane = any_rw || custom_scale;
+      if (!per_lane && !ds->rw) {
+        // one operator for all lanes and no row weights that could blank the window: nothing on the host needs
+        // the number -- the power steps are queued, seed_step_kernel writes L, the first inverse step and the
+        // curvature floor into the control blocks, and the host goes on preparing the solve meanwhile
+        // (it used to wait for them: 0.2 ms of idle stream per path)
+        SLM_TRY(power_iteration(ds, default_lanes(ds, 1), nullptr, kPowerItersSketch, n / 16));
+        for (int l = 0; l < B; ++l) L[l] = 0.0;
+        L_on_device = true;
+      } else {
       SLM_TRY(power_iteration(ds, per_lane ? ls : default_lanes(ds, 1), L, kPowerItersSketch, n / 16));
       // A lane whose row weights vanish on the window (scikit-learn's default cv = unshuffled KFold: the first
       // fold's training mask is zero on the first n / k rows) measured nothing there: all rows, then.
@@ -1518,6 +1532,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       if (blank) SLM_TRY(power_iteration(ds, per_lane ? ls : default_lanes(ds, 1), L, kPowerItersSolve));
       if (!per_lane)
         for (int l = 1; l < B; ++l) L[l] = L[0];
+      }
       ran = true;
     } else if (any_rw || custom_scale) {
       SLM_TRY(power_iteration(ds, ls, L, kPowerItersSolve));  // lane-specific operators: not cached
@@ -1549,24 +1564,35 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     SLM_TRY(dalloc(&ds->gn_out, (size_t)total_points * G));
     ds->cap_gn = total_points * G;
   }
-  HIP_TRY(hipMemsetAsync(ds->beta, 0, sizeof(double) * kMaxLanes * ld, s));
-  HIP_TRY(hipMemsetAsync(ds->zprev, 0, sizeof(double) * kMaxLanes * ld, s));
-  HIP_TRY(hipMemsetAsync(ds->gprev, 0, sizeof(double) * kMaxLanes * ld, s));
-  HIP_TRY(hipMemsetAsync(ds->infos, 0, sizeof(slm_point_info) * total_points, s));
-  PathCtl h[SLM_MAX_LANES];
-  memset(h, 0, sizeof(h));
+  PathCtl* h = ds->h_stage;  // (lives as long as the dataset: the upload below is asynchronous)
+  memset(h, 0, sizeof(ds->h_stage));
+  SetupArgs su;
+  memset(&su, 0, sizeof(su));
+  su.beta = ds->beta; su.z = ds->z; su.zprev = ds->zprev; su.gprev = ds->gprev;
+  su.a0 = ds->a0; su.b0 = ds->b0; su.d0 = ds->d0;
+  su.infos = reinterpret_cast<unsigned char*>(ds->infos);
+  su.infos_bytes = (int64_t)(sizeof(slm_point_info) * total_points);
+  static_assert(sizeof(slm_point_info) % 8 == 0, "infos are zeroed in 8-byte words");
+  su.ld = ld; su.p = p; su.G = G; su.n_lanes = B; su.max_lanes = kMaxLanes;
   int64_t off = 0;
   bool same_pen = B > 1;
   for (int l = 1; l < B; ++l) same_pen = same_pen && lanes[l].pen == lanes[0].pen;
   for (int l = 0; l < B; ++l) {
     const slm_lane& ln = lanes[l];
     const slm_penalty* pen = ln.pen;
-    // lanes that share one penalty (the ranges of a shared path) get lane 0's copy from a device-side
-    // broadcast below instead of thirty small uploads
-    if (!same_pen || l == 0) {
-      SLM_TRY(upload_vec_or_const(ds->a0 + (size_t)l * ld, pen ? pen->a : nullptr, p, 1.0, s));
-      SLM_TRY(upload_vec_or_const(ds->b0 + (size_t)l * ld, pen ? pen->b : nullptr, G, 1.0, s));
-      SLM_TRY(upload_vec_or_const(ds->d0 + (size_t)l * ld, pen ? pen->d : nullptr, G, 1.0, s));
+    // what the caller gave is uploaded (lanes that share one penalty -- the ranges of a shared path -- copy lane
+    // 0's on the device); everything else is filled by solve_setup_kernel below, in one launch
+    const double* src[3] = {pen ? pen->a : nullptr, pen ? pen->b : nullptr, pen ? pen->d : nullptr};
+    double* dst[3] = {ds->a0 + (size_t)l * ld, ds->b0 + (size_t)l * ld, ds->d0 + (size_t)l * ld};
+    unsigned char* mode[3] = {&su.a_mode[l], &su.b_mode[l], &su.d_mode[l]};
+    const int64_t cnt[3] = {p, (int64_t)G, (int64_t)G};
+    for (int v = 0; v < 3; ++v) {
+      if (!src[v]) *mode[v] = 1;
+      else if (same_pen && l > 0) *mode[v] = 2;
+      else {
+        *mode[v] = 0;
+        SLM_TRY(upload_weights(dst[v], src[v], cnt[v], s));
+      }
     }
     if (l == 0 || ln.points != lanes[l - 1].points + lanes[l - 1].n_points) {  // (one copy per contiguous run)
       int64_t run = ln.n_points;
@@ -1578,6 +1604,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       for (int64_t j = 0; j < p; ++j)
         if (!std::isfinite(ln.beta0[j])) return fail(SLM_ERR_BAD_ARG, "beta0[%lld] is not finite", (long long)j);
       HIP_TRY(hipMemcpyAsync(ds->beta + (size_t)l * ld, ln.beta0, sizeof(double) * p, hipMemcpyHostToDevice, s));
+      su.beta_mode[l] = 1;
     }
     h[l].n_points = ln.n_points;
     h[l].max_iter = o.max_iter;
@@ -1603,16 +1630,17 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     h[l].Lhat = 0.5 * L[l];  // a sure lower bound of lambda_max for the residual scaling
     off += ln.n_points;
   }
-  if (same_pen) {
-    hipLaunchKernelGGL(broadcast_lanes_kernel, dim3(32), dim3(256), 0, s, ds->a0, p, ld, B);
-    hipLaunchKernelGGL(broadcast_lanes_kernel, dim3(32), dim3(256), 0, s, ds->b0, (int64_t)G, ld, B);
-    hipLaunchKernelGGL(broadcast_lanes_kernel, dim3(32), dim3(256), 0, s, ds->d0, (int64_t)G, ld, B);
-  }
-  HIP_TRY(hipMemcpyAsync(ds->z, ds->beta, sizeof(double) * kMaxLanes * ld, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(solve_setup_kernel, dim3(128), dim3(256), 0, s, su);
   HIP_TRY(hipMemcpyAsync(ds->ctl, h, sizeof(PathCtl) * B, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(ds->gctl, 0, sizeof(GlobalCtl), s));
+  if (L_on_device) {  // the power steps are still in flight: their result goes into the control blocks on the device
+    SeedArgs sa;
+    sa.ctl = ds->ctl; sa.lambda = ds->lambda; sa.n_lanes = B; sa.margin = 1.08;
+    hipLaunchKernelGGL(seed_step_kernel, dim3(1), dim3(64), 0, s, sa);
+  }
   tr[0] = t_mark();
-  HIP_TRY(hipStreamSynchronize(s));  // host staging buffers are free again
+  // (no wait here: the caller's buffers outlive the call, the control blocks are staged in the dataset, and
+  //  everything the host still has to prepare overlaps with the step-size seed running on the device)
   tr[1] = t_mark();
 
   TailArgs ta;
@@ -1697,13 +1725,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     // but X, kept for the life of the dataset; 2 ms for 4 GB).  Optional: without the memory for it
     // the gathers read the row-major X, one 64-byte sector per element.
     SLM_TRY(ensure_xt(ds));
-    WsCtl wc;
-    memset(&wc, 0, sizeof(wc));
-    wc.request = 1;
-    for (int l = 0; l < kMaxLanes; ++l) wc.last_point[l] = -1;
-    wc.max_builds = 24;
-    HIP_TRY(hipMemcpyAsync(ds->ws_ctl, &wc, sizeof(wc), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // (initialised on the device: a host-side copy would need the stream drained before its buffer goes away)
+    HIP_TRY(hipMemsetAsync(ds->ws_ctl, 0, sizeof(WsCtl), s));
+    hipLaunchKernelGGL(ws_ctl_init_kernel, dim3(1), dim3(64), 0, s, ds->ws_ctl, 24);
     wa.ws = ds->ws_ctl;
     wa.idx = ds->ws_idx; wa.pos = ds->ws_pos; wa.gs = ds->ws_gs; wa.gl = ds->ws_gl;
     wa.score = ds->ws_score; wa.XW = ds->ws_XW; wa.part = ds->ws_part; wa.Gm = ds->ws_G;

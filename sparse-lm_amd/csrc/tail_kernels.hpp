@@ -771,6 +771,26 @@ __global__ __launch_bounds__(TAIL_THREADS) void power_step_kernel(PowerArgs a) {
   if (threadIdx.x == 0) a.lambda[0] = nrm;
 }
 
+// Step-size seed of a solve straight from the power iteration's result (one estimate for all lanes): L with the
+// safety margin, a slightly short first inverse step, and half of L as the first curvature floor -- what the
+// host writes into the control blocks when it has the number (solve_core).  A non-finite estimate is left in:
+// the first tail kernel then reports the non-finite iterate.
+struct SeedArgs {
+  PathCtl* ctl;
+  const double* lambda;
+  int n_lanes;
+  double margin;
+};
+__global__ void seed_step_kernel(SeedArgs a) {
+  const int l = threadIdx.x;
+  if (l >= a.n_lanes) return;
+  double L = a.lambda[0] * a.margin;
+  if (L <= 0.0) L = 1.0;  // X == 0
+  a.ctl[l].L = L;
+  a.ctl[l].ak = 1.25 * L;
+  a.ctl[l].Lhat = 0.5 * L;
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
   x ^= x >> 27; x *= 0x94d049bb133111ebull;

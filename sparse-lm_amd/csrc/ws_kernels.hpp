@@ -124,6 +124,15 @@ struct WsArgs {
   int32_t pad_;
 };
 
+// state of a fresh solve (the block is zeroed first): a build is requested, no lane has been refined yet
+__global__ void ws_ctl_init_kernel(WsCtl* ws, int max_builds) {
+  if (threadIdx.x == 0) {
+    ws->request = 1;
+    ws->max_builds = max_builds;
+  }
+  if (threadIdx.x < SLM_MAX_LANES) ws->last_point[threadIdx.x] = -1;
+}
+
 // exclusive prefix sum of one int per thread over the 1024-thread workgroup
 __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[16]*/, int* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
