@@ -339,7 +339,7 @@ struct GlobalCtl {
   int32_t diverged;    // row-sharded mode: the ranks' control blocks differ (TailArgs::gdone[4]); ends the solve
   int32_t pad_[3];
 };
-static const int kWsLateIters = 24;  // passes on one point after which a small problem gets the working set
+static const int kWsLateIters = 12;  // passes on one point after which a small problem gets the working set
 
 struct HostCtl {  // pinned snapshot the host polls
   GlobalCtl g;
@@ -1838,69 +1838,21 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   bool pending[2] = {false, false};
   bool done = false;
 
-  // Optional hipGraph replay of a chunk (SLM_GRAPH=1): the chunk of iterations + the status copy is
-  // captured once per solve into two graphs (one per status slot).  OFF by default: measured on
-  // MI355X (tools/small_fit_timing.py) the small-problem loop is bound by the ~1.5 us dependent-kernel
-  // boundaries on the device (17 us per 3-kernel iteration), not by host launches, so replay gives
-  // 18.7 vs 16.9 us per iteration and adds ~0.6 ms of instantiation per solve.
-  hipGraphExec_t gexec[2] = {nullptr, nullptr};
-  bool use_graph = false;
-  {
-    const char* env = getenv("SLM_GRAPH");
-    if (env && env[0] == '1' && !profile && !eng->sharded() && chunk >= 4) {
-      use_graph = true;
-      for (int k = 0; k < 2 && use_graph; ++k) {
-        hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-          use_graph = false;
-          break;
-        }
-        int rc = SLM_OK;
-        for (int i = 0; i < chunk && rc == SLM_OK; ++i) {
-          rc = enqueue_pass_gradient(nullptr, nullptr);
-          enqueue_after_gradient();
-        }
-        hipError_t e1 = hipMemcpyAsync(&ds->hctl[k].g, ds->gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, s);
-        hipError_t e2 = hipStreamEndCapture(s, &graph);
-        if (rc != SLM_OK || e1 != hipSuccess || e2 != hipSuccess || !graph ||
-            hipGraphInstantiate(&gexec[k], graph, nullptr, nullptr, 0) != hipSuccess) {
-          use_graph = false;
-        }
-        if (graph) (void)hipGraphDestroy(graph);
-      }
-      if (!use_graph) {
-        (void)hipGetLastError();  // clear; fall back to eager launches
-        for (auto& ge : gexec)
-          if (ge) {
-            (void)hipGraphExecDestroy(ge);
-            ge = nullptr;
-          }
-      }
-    }
-  }
-  struct GraphGuard {
-    hipGraphExec_t* g;
-    ~GraphGuard() {
-      for (int k = 0; k < 2; ++k)
-        if (g[k]) (void)hipGraphExecDestroy(g[k]);
-    }
-  } graph_guard{gexec};
-
+  // (hipGraph replay of a chunk of passes was tried in round 1 and removed: the loop is bound by the ~1.5 us
+  //  dependent-kernel boundaries on the device, not by host launches -- 18.7 against 16.9 us per three-kernel pass on
+  //  small problems -- and instantiation cost 0.6 ms per solve)
   tr[2] = t_mark();
   // Working-set solves from the start verify one point per lane and pass, after the pass at zero: the
   // queue is cut to end exactly there, and polls go pass by pass after it (a miss adds a pass or two).
   // Without this a 5-pass path drags three queued no-op passes behind it (12 launches each).
   int64_t expected = 0;
-  if (use_ws && !ws_late && !use_graph && o.check_every <= 0) {
+  if (use_ws && !ws_late && o.check_every <= 0) {
     int64_t most = 0;
     for (int l = 0; l < B; ++l) most = std::max<int64_t>(most, shared_path && interleave ? (total_points - l + B - 1) / B : lanes[l].n_points);
     expected = 1 + most;
   }
   while (!done) {
-    if (use_graph) {
-      HIP_TRY(hipGraphLaunch(gexec[slot], s));
-      enq += chunk;
-    } else {
+    {
       const int this_chunk = expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(chunk, expected - enq) : 1);
       for (int i = 0; i < this_chunk; ++i) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1929,7 +1881,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       HIP_TRY(hipEventSynchronize(ds->ev[other]));
       pending[other] = false;
       if (ds->hctl[other].g.done) done = true;
-      if (!done && ws_late && !use_graph && ds->hctl[other].g.hard >= kWsLateIters) {
+      if (!done && ws_late && ds->hctl[other].g.hard >= kWsLateIters) {
         const int rc = ws_setup();  // (waits for the stream: the queued passes simply finish first)
         ws_late = false;
         if (rc == SLM_OK) {

@@ -19,8 +19,109 @@ from . import _engine
 _KNOWN_OPTIONS = {"tol", "max_iter", "L", "restart", "check_every", "device"}
 
 
+class DatasetCache:
+    """Device-resident datasets kept across ``fit`` calls -- the counterpart of the reference's ``cached_X_`` /
+    ``cached_y_`` (src/sparselm/model/_base.py:182-195: a re-fit on identical data re-uses the cvxpy problem).
+
+    scikit-learn's stock ``GridSearchCV`` fits ``clone(estimator)`` on ``X[train]`` once per (candidate, fold):
+    fifty fits of the README example touch five distinct training sets.  Creating an engine dataset costs a few
+    dozen device allocations (about a millisecond: more than a small solve), so datasets are kept in a small
+    LRU keyed by the CONTENT of what was uploaded -- a 128-bit xxh3 digest of X, y and the row weights, with
+    shape, layout, the centring flag, device and process id.  A key is only computed for arrays up to
+    ``max_bytes`` (hashing a 4 GB matrix costs more than uploading it); larger ones are not cached.  A dataset
+    handed out is marked busy until ``release``: a second user in another thread gets a fresh one.
+    """
+
+    def __init__(self, capacity=8, max_bytes=64 << 20):
+        import threading
+
+        self.capacity, self.max_bytes = int(capacity), int(max_bytes)
+        self._lock = threading.Lock()
+        self._items = {}  # key -> [dataset, x_mean, y_mean, busy, stamp]
+        self._clock = 0
+        self.hits = self.misses = 0
+
+    def _key(self, engine, X, y, row_weight, center):
+        import os
+
+        try:
+            import xxhash
+        except ImportError:  # no digest, no cache
+            return None
+        X = np.asarray(X)
+        if X.nbytes > self.max_bytes or X.ndim != 2:
+            return None
+        X = np.asarray(X, dtype=np.float64)
+        fortran = X.flags.f_contiguous and not X.flags.c_contiguous
+        h = xxhash.xxh3_128()
+        h.update(np.ascontiguousarray(X.T if fortran else X))  # (a view when the layout already fits: no copy)
+        h.update(np.ascontiguousarray(y, dtype=np.float64))
+        if row_weight is not None:
+            h.update(np.ascontiguousarray(row_weight, dtype=np.float64))
+        return (os.getpid(), engine.device_id, X.shape, fortran, row_weight is not None, bool(center), h.digest())
+
+    def acquire(self, engine, X, y, row_weight, center):
+        """(dataset, x_mean, y_mean, key): from the cache when the same content was uploaded before."""
+        key = self._key(engine, X, y, row_weight, center)
+        if key is not None:
+            with self._lock:
+                item = self._items.get(key)
+                if item is not None and not item[3] and getattr(item[0], "_h", None):
+                    item[3] = True
+                    self._clock += 1
+                    item[4] = self._clock
+                    self.hits += 1
+                    return item[0], item[1], item[2], key
+        ds = engine.dataset(X, y, row_weight=row_weight)
+        # fit_intercept: centre the device copy in place (no centred host copy of X is ever made)
+        x_mean, y_mean = ds.center() if center else (None, None)
+        self.misses += 1
+        return ds, x_mean, y_mean, key
+
+    def release(self, ds, x_mean, y_mean, key):
+        if key is None:
+            ds.close()
+            return
+        evict = []
+        with self._lock:
+            item = self._items.get(key)
+            if item is not None and item[0] is ds:
+                item[3] = False
+            elif item is None:
+                self._clock += 1
+                self._items[key] = [ds, x_mean, y_mean, False, self._clock]
+                while len(self._items) > self.capacity:
+                    idle = [(v[4], k) for k, v in self._items.items() if not v[3]]
+                    if not idle:
+                        break
+                    evict.append(self._items.pop(min(idle)[1])[0])
+            else:  # the same content is cached already (another thread got there first)
+                evict.append(ds)
+        for d in evict:
+            d.close()
+
+    def clear(self):
+        with self._lock:
+            items, self._items = list(self._items.values()), {}
+        for item in items:
+            item[0].close()
+
+
+_dataset_cache = DatasetCache()
+# (device memory is handed back while the HIP runtime is still up: interpreter teardown destroys objects in no
+#  particular order, and a dataset released after the runtime's own static destructors aborts the process)
+import atexit  # noqa: E402
+
+atexit.register(_dataset_cache.clear)
+
+
+def dataset_cache() -> DatasetCache:
+    return _dataset_cache
+
+
 class SolveProblem:
-    """Device-resident problem: upload once, solve many penalties (adaptive loops, paths)."""
+    """Device-resident problem: upload once, solve many penalties (adaptive loops, paths); the dataset itself
+    outlives the problem in the ``DatasetCache``."""
 
     def __init__(self, backend, X, y, gidx, n_groups, options, row_weight=None, center=False):
         self.backend = backend
@@ -28,11 +129,9 @@ class SolveProblem:
         self.p = X.shape[1]
         self.n_groups = n_groups
         eng = _engine.get_engine(options.get("device"))
-        self.ds = eng.dataset(X, y, row_weight=row_weight)
-        # fit_intercept: centre the device copy in place (no centred host copy of X is ever made)
-        self.x_mean, self.y_mean = self.ds.center() if center else (None, None)
-        if gidx is not None:
-            self.ds.set_groups(gidx, n_groups)
+        self.ds, self.x_mean, self.y_mean, self._key = _dataset_cache.acquire(eng, X, y, row_weight, center)
+        # (a cached dataset may carry another estimator's groups: always set them)
+        self.ds.set_groups(gidx, n_groups if gidx is not None else None)
 
     def solve(self, a, b, d, beta0=None, want_group_norms=False):
         """One minimisation with penalty (a, b, d); returns (beta, group_norms or None, info)."""
@@ -71,7 +170,9 @@ class SolveProblem:
         return res.betas[0], gn, info
 
     def close(self):
-        self.ds.close()
+        if self.ds is not None:
+            _dataset_cache.release(self.ds, self.x_mean, self.y_mean, self._key)
+            self.ds = None
 
 
 class HipBackend:

@@ -739,6 +739,20 @@ _engines: dict[tuple[int, int], Engine] = {}
 _engines_lock = threading.Lock()
 
 
+def _close_engines():
+    with _engines_lock:
+        engines, pid = list(_engines.items()), os.getpid()
+        _engines.clear()
+    for (owner, _), eng in engines:
+        if owner == pid:  # (a forked child never touches its parent's handles)
+            eng.close()
+
+
+import atexit  # noqa: E402
+
+atexit.register(_close_engines)
+
+
 def get_engine(device_id: int | None = None) -> Engine:
     """Process-wide engine for ``device_id`` (default: ``LOCAL_RANK`` or 0).  Fork-safe by keying on pid."""
     if device_id is None:

@@ -540,3 +540,41 @@ def test_against_a_cvxpy_formulation_when_cvxpy_is_installed(golden):
         ref = cvx(a, b, d)
         got = est.fit(X, y).coef_
         assert np.max(np.abs(got - ref)) <= 1e-6 * np.max(np.abs(ref)), type(est).__name__
+
+
+@pytest.mark.gpu
+def test_device_datasets_are_cached_across_fits_by_content():
+    """The reference re-uses its cvxpy problem when fit() sees the same data again (model/_base.py:182-195).  Here
+    the device-resident dataset is what is expensive to set up: stock scikit-learn GridSearchCV over the README
+    example (10 alphas x 5 folds = 50 fits + the refit) must upload 5 + 1 distinct training sets, not 51 -- the
+    cache is keyed by content, for X[train] is a fresh array every time."""
+    from sklearn.datasets import make_regression
+
+    cache = _backend.dataset_cache()
+    cache.clear()
+    cache.hits = cache.misses = 0
+    X, y = make_regression(n_samples=100, n_features=80, n_informative=10, random_state=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gs = GridSearchCV(AdaptiveLasso(fit_intercept=False), {"alpha": np.logspace(-8, 2, 10)}).fit(X, y)
+    assert cache.misses == 6 and cache.hits == 45
+    assert gs.best_params_ == {"alpha": 1e-08}
+    # same content, different array object, Fortran order: still the same device dataset? no -- the layout is
+    # part of the key (the engine's copy is the same, the digest is computed on the bytes as given)
+    first = Lasso(alpha=0.3).fit(X, y).coef_
+    hits = cache.hits
+    again = Lasso(alpha=0.3).fit(X.copy(), y.copy()).coef_
+    assert cache.hits == hits + 1 and np.array_equal(first, again)
+    # a changed entry is a different dataset
+    X2 = X.copy()
+    X2[3, 4] += 1e-9
+    misses = cache.misses
+    Lasso(alpha=0.3).fit(X2, y)
+    assert cache.misses == misses + 1
+    # groups and penalties are per fit, not part of the dataset: one cached dataset serves both estimators
+    groups = np.repeat(np.arange(16), 5)
+    g1 = GroupLasso(groups=groups, alpha=0.3).fit(X, y).coef_
+    l1 = Lasso(alpha=0.3).fit(X, y).coef_
+    g2 = GroupLasso(groups=groups, alpha=0.3).fit(X, y).coef_
+    assert np.array_equal(g1, g2) and np.array_equal(l1, first)
+    cache.clear()

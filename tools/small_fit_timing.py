@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Wall time of reference-sized fits (launch-bound regime), with and without hipGraph replay."""
+"""Wall time of reference-sized fits (launch-bound regime): engine solves and whole estimator fits."""
 import os, sys, time, warnings
 import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -11,17 +11,15 @@ from sparselm_amd.model import Lasso, AdaptiveGroupLasso
 eng = _engine.get_engine(0)
 for n, p, alpha in ((25, 30, 0.1), (100, 80, 1e-3), (400, 100, 0.1), (2000, 200, 1.0)):
     X, y = make_regression(n_samples=n, n_features=p, n_informative=10, noise=1.0, random_state=0)
-    for graph in ("0", "1"):
-        os.environ["SLM_GRAPH"] = graph
+    for graph in ("-",):
         with eng.dataset(X, y) as ds:
             ds.solve_path([(alpha, 0, 0)], max_iter=20000)
             t0 = time.perf_counter()
             for _ in range(5):
                 r = ds.solve_path([(alpha, 0, 0)], max_iter=20000)
             dt = (time.perf_counter() - t0) / 5
-        print(f"n={n} p={p} alpha={alpha} graph={graph}: {1e3*dt:8.2f} ms per solve, {int(r.n_iter[0])} iterations, "
+        print(f"n={n} p={p} alpha={alpha}: {1e3*dt:8.2f} ms per solve, {int(r.n_iter[0])} iterations, "
               f"{1e6*dt/max(1,int(r.n_iter[0])):6.1f} us/iteration, converged={r.converged}", flush=True)
-os.environ.pop("SLM_GRAPH")
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     X, y = make_regression(n_samples=25, n_features=30, n_informative=10, random_state=1)
