@@ -360,6 +360,8 @@ struct slm_dataset {
   int32_t *ws_idx = nullptr, *ws_pos = nullptr, *ws_gs = nullptr, *ws_gl = nullptr;
   double *ws_score = nullptr, *ws_XW = nullptr, *ws_part = nullptr, *ws_G = nullptr, *ws_Gx = nullptr;
   double* ws_nt = nullptr;  // [kMaxLanes][NT_SCRATCH] factors of the model solver's direct steps
+  double *sse_Z = nullptr, *sse_part = nullptr;  // slm_eval_sse_sparse: coefficient block, partial sums
+  size_t sse_cap = 0;
   PathCtl h_stage[SLM_MAX_LANES];  // host staging of the control blocks of the solve in flight
   double* stop_words = nullptr;  // [STOP_WORDS] row-sharded mode: the vector the ranks all-reduce after every pass
   double* XT = nullptr;  // column-major copy of X for the column gathers ([ld][ldt]), built on first use
@@ -510,7 +512,7 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->pts); dfree(ds->betas_out); dfree(ds->gn_out); dfree(ds->infos);
   dfree(ds->ws_ctl); dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
   dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
-  dfree(ds->ws_nt); dfree(ds->stop_words);
+  dfree(ds->ws_nt); dfree(ds->stop_words); dfree(ds->sse_Z); dfree(ds->sse_part);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   for (auto& e : ds->ev)
     if (e) (void)hipEventDestroy(e);
@@ -912,7 +914,7 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
 }
 
 // The same for working-set solves through the split pass: residuals (from the gathered columns where a
-// lane's point is supported on W, from X otherwise), then X^T r for all eight lane slots on one read
+// lane's point is supported on W, from X otherwise), then X^T r for all sixteen lane slots on one read
 // of X.  ctl == nullptr: every lane takes its residual from X (slm_gradient with SLM_GRAD_SPLIT=1).
 // Residuals from X for the lanes the working set does not serve: all sixteen lane slots in one read of
 // the column-major copy on the matrix cores when that copy exists (working-set solves make it), otherwise
@@ -1053,7 +1055,7 @@ static int power_iteration(slm_dataset* ds, const LaneSetup& ls_in, double* L_ou
   for (int k = 0; k < iters; ++k) {
     if (ds->gk[ls.B - 1]) {
       SLM_TRY(enqueue_gradient(ds, ls, ds->yzero, nullptr, nullptr, nullptr, n_rows));
-    } else {  // more lanes than the fused kernels serve (working-set solves): the split pass has ten
+    } else {  // more lanes than the fused kernels serve (working-set solves): the split pass has sixteen
       if (!split_usable(ds)) return fail(SLM_ERR_UNSUPPORTED, "no %d-lane kernel for p = %lld", ls.B, (long long)ds->p);
       SLM_TRY(enqueue_gradient_split(ds, ls, ds->yzero, nullptr, nullptr, nullptr, nullptr, nullptr, n_rows));
     }
@@ -1329,12 +1331,16 @@ extern "C" int slm_eval_sse_sparse(slm_dataset* ds, const int32_t* cols, int32_t
   if (!ds->ws_XW) SLM_TRY(dalloc(&ds->ws_XW, (size_t)n * WS_KCAP));
   SLM_TRY(ensure_xt(ds));
   const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus * 4, (n + 255) / 256));
-  double *dZ = nullptr, *dpart = nullptr;
-  SLM_TRY(dalloc(&dZ, (size_t)m * n_cols));
-  if (dalloc(&dpart, (size_t)nblk * SSE_M) != SLM_OK) {
-    dfree(dZ);
-    return SLM_ERR_OOM;
+  // scratch of the scoring loop of a grid search, kept with the dataset (it used to be allocated and freed per
+  // call): the coefficient block grows on demand, the per-workgroup partial sums have a fixed size
+  if ((size_t)m * n_cols > ds->sse_cap) {
+    dfree(ds->sse_Z);
+    ds->sse_cap = 0;
+    SLM_TRY(dalloc(&ds->sse_Z, (size_t)m * n_cols));
+    ds->sse_cap = (size_t)m * n_cols;
   }
+  if (!ds->sse_part) SLM_TRY(dalloc(&ds->sse_part, (size_t)eng->cus * 4 * SSE_M));
+  double *dZ = ds->sse_Z, *dpart = ds->sse_part;
   int rc = SLM_OK;
   auto bail = [&](hipError_t e) {
     if (e != hipSuccess && rc == SLM_OK) rc = fail(SLM_ERR_HIP, "slm_eval_sse_sparse: %s", hipGetErrorString(e));
@@ -1365,7 +1371,6 @@ extern "C" int slm_eval_sse_sparse(slm_dataset* ds, const int32_t* cols, int32_t
     }
   }
   bail(hipStreamSynchronize(s));
-  dfree(dZ); dfree(dpart);
   if (rc == SLM_OK) rc = check_launch();
   return rc;
 }

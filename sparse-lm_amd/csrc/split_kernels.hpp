@@ -1,7 +1,7 @@
 // Split gradient pass for working-set solves: residuals first, then ONE stream over X for X^T r.
 //
 // With the working-set refinement (ws_kernels.hpp) nearly every point a lane asks the gradient at is
-// supported on W, the <= 256 columns already gathered into the compact matrix XW.  Its residual
+// supported on W, the <= 512 columns already gathered into the compact matrix XW.  Its residual
 // r = W (X z - y) then needs only XW (n x K, a few tens of MB), and the pass over X reduces to the
 // second half of the fused kernel, G = X^T R / n with R the n x 16 matrix of the lanes' residuals: a
 // skinny GEMM, run on the matrix cores, so SIXTEEN lanes share one read of X where the fused kernel tops
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
 // as v_mfma_f64_16x16x4_f64 products, D[i][j] += sum_k A[i][k] B[k][j] with k = 4 consecutive rows,
 // A[i][k] = X[row_k][col_i] (16 columns) and B[k][j] = R[row_k][j] -- R's 16-double rows ARE the B
 // operand (lane l of the wavefront holds B[k = l >> 4][j = l & 15]: one coalesced 512-byte load per four
-// rows; slots 10..15 are zero padding).  Lane l holds A[i = l & 15][k = l >> 4], so ONE 16-byte load per
+// rows; the slots of lanes a call does not use hold zeros).  Lane l holds A[i = l & 15][k = l >> 4], so ONE 16-byte load per
 // lane brings four rows x 32 consecutive columns (256 contiguous bytes per row) and its two doubles feed
 // two MFMAs (even and odd columns).  A wavefront owns 128 columns (8 result tiles = 64 registers), a
 // workgroup 512, grid.y splits the rows; two 8-row batches are in flight per wavefront (plain register
