@@ -1820,7 +1820,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         hipLaunchKernelGGL(ws_publish_kernel, dim3(WS_KCAP * WS_KCAP / 256, (unsigned)wa.n_sets), dim3(256), 0, s,
                            wa);
       }
-      hipLaunchKernelGGL(ws_solve_kernel, dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
+      if (ds->singleton) hipLaunchKernelGGL(ws_solve_kernel<false>, dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
+      else hipLaunchKernelGGL(ws_solve_kernel<true>, dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
     }
   };
 

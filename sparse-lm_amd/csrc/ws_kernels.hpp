@@ -728,6 +728,9 @@ __global__ __launch_bounds__(256) void ws_publish_kernel(WsArgs w) {
 // beyond 256 positions).  Up to
 // WS_KLDS columns the Gram is copied into LDS first, so an inner iteration never leaves the CU.
 // ---------------------------------------------------------------------------------------------
+// GROUPED: the dataset has real groups (compiled apart from the per-feature variant: each instance carries one
+// direct step, and the registers of the other's never weigh on its iteration loop).
+template <bool GROUPED>
 __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, double (*red)[TAIL_WAVES]) {
   __shared__ double delta[WS_KCAP];
   __shared__ double uim[WS_KCAP];
@@ -741,6 +744,9 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   __shared__ int act[WS_KCAP];     // position of the ii-th face coordinate
   __shared__ int rank_of[WS_KCAP]; // rank of a position in the face, or -1
   __shared__ int m_s;
+  __shared__ double xsl[WS_KCAP];  // direct step with group norms: the base point,
+  __shared__ double rgl[WS_KCAP];  // the norm of each position's group there,
+  __shared__ double pbl[WS_KCAP];  // and its group weight
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
   WsCtl* ws = w.ws;
@@ -943,10 +949,11 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   // gradient pins at zero, so the projected arc is a descent arc).  When nothing is projected at t = 1 the
   // result IS the minimiser over that face.  Returns 1 when x moved, 0 when there was nothing to do, -1 when
   // H_FF is not positive definite or no trial lowered the model (the iteration simply carries on).  mu_out:
-  // estimate of the smallest eigenvalue of the face Hessian (0 = not computed).  Per-feature penalties
-  // (and singleton "groups") only: a group norm adds curvature that depends on the iterate -- those lanes keep
-  // to the iteration.
-  const bool newton_capable = w.nt != nullptr && !(group_pen && !a.singleton);
+  // estimate of the smallest eigenvalue of the face Hessian (0 = not computed).  This is the variant for
+  // per-feature penalties (and singleton "groups"); real group norms: direct_step_group further down.
+  constexpr bool group_face = GROUPED;  // real groups: direct_step_group below (it also serves a lane of such a
+                                        // dataset whose current point has no group term: b = 0 adds no curvature)
+  const bool newton_capable = w.nt != nullptr;
   double* ntF = newton_capable ? w.nt + (int64_t)lane_id * NT_SCRATCH : nullptr;
   double* ntD = newton_capable ? ntF + (int64_t)NT_TILES * 256 : nullptr;
   auto block_min = [&](double val) -> double {
@@ -962,6 +969,9 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   };
   int resolve_cap = WS_NEWTON_RESOLVE;
   auto direct_step = [&](double& x, double Lmax, double* mu_out, bool want_mu) -> int {
+   if constexpr (GROUPED) {
+    return 0;  // (this instance uses direct_step_group)
+   } else {
     *mu_out = 0.0;
     const double thr = pa + pb;  // (singleton groups: b acts as a second l1 weight)
     // On an ill-conditioned face the Newton direction lives on cancellations between near-collinear columns:
@@ -1179,6 +1189,228 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     }
     x = xn;
     return 1;
+   }
+  };
+
+  // ---- direct step with group norms (GroupLasso, SparseGroupLasso, ridged; round 2) ----------------------
+  // On the face of the iterate -- its active groups, inside them the non-zero coordinates with their signs when
+  // there is an l1 term -- the objective is smooth but no longer quadratic: the norm of an active group adds the
+  // curvature (b_g / r_g)(I - u u^T), r_g = ||x_g||, u = x_g / r_g.  One call is one damped Newton step there:
+  // H = G_FF + d + those blocks, d = H^-1 (gradient of the smooth face objective), trial points x - t d for
+  // t = 1, 1/2, 1/4, 1/8 with the same projections as above (a coordinate with an l1 kink stops at zero; a group the
+  // step would carry through the origin goes to zero as a whole), the first that lowers model + penalty wins.
+  // Groups that are zero but want in (||soft(g_g, a)|| > b_g, the strongest violators only) first receive their
+  // prox-gradient value -- the penalty has no gradient at a zero group -- and join the face.  The free set is made
+  // consistent by dropping what the solve sends the wrong way, as in the l1 case.
+  auto group_sum = [&](double val) -> double {  // sum of `val` over the members of this position's group
+    __syncthreads();
+    if (q == 0 && k < WS_KCAP) uim[k] = (k < K && live) ? val : 0.0;
+    __syncthreads();
+    double ss = 0.0;
+    if (live)
+      for (int m2 = 0; m2 < glk; ++m2) ss += uim[gsk + m2];
+    return ss;
+  };
+  auto direct_step_group = [&](double& x, double Lmax, double* mu_out, bool want_mu) -> int {
+   if constexpr (!GROUPED) {
+    return 0;  // (this instance uses direct_step)
+   } else {
+    *mu_out = 0.0;
+    const bool kink = pa > 0.0;  // this coordinate has an l1 term: its sign is part of the face
+    double xb = x;
+    bool banned = false;
+    double m_old = 0.0;
+    int m = 0, T = 0, mp = 0, my_rank = -1;
+    double dk = 0.0, xi = 0.0;
+    for (int resolve = 0; resolve < resolve_cap; ++resolve) {
+      double gx = g0 + matvec(xb, false);
+      if (resolve == 0) {
+        double sv[2] = {mine ? (x - z0) * (g0 + 0.5 * (gx - g0)) : 0.0, 0.0};
+        sv[1] = pen_part(x);
+        block_sum<2>(sv, red);
+        m_old = sv[0] + sv[1];
+      }
+      double r2 = group_sum(xb * xb);
+      bool g_active = r2 > 0.0;
+      const double sk = (live && !banned && !g_active) ? soft(gx, pa) : 0.0;
+      const double S = sqrt(group_sum(sk * sk));
+      double viol = 0.0;
+      if (live && !banned) {
+        if (!g_active) viol = fmax(0.0, S - pb);
+        else if (xb == 0.0 && kink) viol = fmax(0.0, fabs(gx) - pa);
+      }
+      const double viol_max = -block_min(-viol);
+      if (resolve == 0 && viol_max > 0.0) {
+        const bool enter = live && !banned && !g_active && viol > 0.0 && viol >= WS_NEWTON_ENTER * viol_max;
+        double cnt[1] = {mine && enter ? 1.0 : 0.0};
+        block_sum<1>(cnt, red);
+        if (cnt[0] > 0.0) {  // (uniform: every thread takes the same branch)
+          if (enter) {
+            const double st = 1.0 / Lmax;
+            xb = -st * sk * (1.0 - pb / S) / (1.0 + st * pd);
+          }
+          gx = g0 + matvec(xb, false);
+          r2 = group_sum(xb * xb);
+          g_active = r2 > 0.0;
+        }
+      }
+      const double rg = sqrt(r2);
+      double pg = 0.0;
+      bool is_free = false;
+      xi = 0.0;
+      if (live && !banned && g_active) {
+        if (xb != 0.0) {
+          xi = kink ? (xb > 0.0 ? 1.0 : -1.0) : 0.0;
+          pg = gx + pa * (xb > 0.0 ? 1.0 : -1.0) + (pb / rg + pd) * xb;
+          is_free = true;
+        } else if (!kink) {
+          pg = gx;  // no l1 term: the objective is smooth in this coordinate at zero
+          is_free = gx != 0.0;
+        } else {
+          const double e = fabs(gx) - pa;
+          if (e > 0.0 && e >= WS_NEWTON_ENTER * viol_max) {
+            pg = gx - copysign(pa, gx);
+            xi = pg > 0.0 ? -1.0 : 1.0;
+            is_free = true;
+          }
+        }
+      }
+      // free positions in position order
+      __syncthreads();
+      if (q == 0 && k < WS_KCAP) {
+        nv[k] = is_free ? 1.0 : 0.0;
+        rank_of[k] = -1;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        int basep = 0;
+        for (int c0 = 0; c0 < K; c0 += 64) {
+          const int kk = c0 + tid;
+          const bool on = kk < K && nv[kk] != 0.0;
+          const uint64_t mk = __ballot(on);
+          if (on) {
+            const int ii = basep + __popcll(mk & ((1ull << tid) - 1ull));
+            act[ii] = kk;
+            rank_of[kk] = ii;
+          }
+          basep += __popcll(mk);
+        }
+        if (tid == 0) m_s = basep;
+      }
+      __syncthreads();
+      m = m_s;
+      if (m == 0) {
+        if (resolve == 0) return 0;
+        dk = 0.0;
+        my_rank = -1;
+        break;
+      }
+      T = (m + 15) >> 4;
+      mp = 16 * T;
+      my_rank = (k < K) ? rank_of[k] : -1;
+      __syncthreads();
+      if (tid < mp) nv[tid] = 0.0;
+      if (q == 0 && k < WS_KCAP) {
+        delta[k] = pd;
+        xsl[k] = (k < K && live) ? xb : 0.0;
+        rgl[k] = rg;
+        pbl[k] = pb;
+        nz[k] = gsk;  // (group id; the mat-vec rebuilds its own list when it next runs)
+      }
+      __syncthreads();
+      if (q == 0 && my_rank >= 0) nv[my_rank] = pg;
+      const int ntl = T * (T + 1) / 2;
+      for (int e = tid; e < ntl * 256; e += WS_THREADS) {
+        const int tl = e >> 8, wi = e & 255;
+        int I = (int)((sqrtf(8.0f * (float)tl + 1.0f) - 1.0f) * 0.5f);
+        while (I * (I + 1) / 2 > tl) --I;
+        while ((I + 1) * (I + 2) / 2 <= tl) ++I;
+        const int J = tl - I * (I + 1) / 2;
+        const int l6 = wi & 63, st = wi >> 6;
+        const int ii = 16 * I + (l6 & 15), jj2 = 16 * J + (l6 >> 4) + 4 * st;
+        double hv;
+        if (ii < m && jj2 < m) {
+          const int pi = act[ii], pj = act[jj2];
+          hv = Gm[pj * WS_KCAP + pi];
+          if (ii == jj2) hv += delta[pi];
+          if (nz[pi] == nz[pj]) {  // same group: curvature of its norm
+            const double rr = rgl[pi];
+            hv += (pbl[pi] / rr) * ((ii == jj2 ? 1.0 : 0.0) - xsl[pi] * xsl[pj] / (rr * rr));
+          }
+        } else {
+          hv = ii == jj2 ? 1.0 : 0.0;
+        }
+        ntF[e] = hv;
+      }
+      __syncthreads();
+      if (!nt_factor(ntF, ntD, T, 1e-12 * Lmax, nts)) {
+        if (tid == 0) atomicAdd(&ws->newton_nopd, 1);
+        return -1;
+      }
+      nt_solve(ntF, ntD, T, nv);
+      if (tid == 0) {
+        atomicAdd(&ws->newton_factors, 1);
+        atomicAdd(&ws->newton_unknowns, m);
+        ws->nt_factors[lane_id] += 1;
+      }
+      dk = my_rank >= 0 ? nv[my_rank] : 0.0;
+      // what the solve sends the wrong way: a kinked coordinate across (or to the wrong side of) zero, a whole
+      // group through the origin
+      bool wrong = false;
+      if (my_rank >= 0 && kink) wrong = xb == 0.0 ? !(dk * pg > 0.0) : (xb - dk) * xi <= 0.0;
+      const double radial = group_sum(live && !banned ? (xb - dk) * xb : 0.0);
+      const bool g_wrong = live && !banned && g_active && !(radial > 0.0);
+      double cnt[1] = {mine && (wrong || g_wrong) ? 1.0 : 0.0};
+      block_sum<1>(cnt, red);
+      if (cnt[0] == 0.0 || resolve == resolve_cap - 1) break;
+      if (wrong || g_wrong) {
+        banned = true;
+        xb = 0.0;
+      }
+    }
+    double xn = x;
+    bool moved = false, projected = false, full = false;
+    double tt = 1.0;
+    for (int trial = 0; trial < 4 && !moved; ++trial, tt *= 0.5) {
+      double xc = xb, cut = 0.0;
+      if (my_rank >= 0) {
+        xc = xb - tt * dk;
+        if (kink && xc * xi <= 0.0) {
+          if (xb != 0.0 || xc != 0.0) cut = 1.0;
+          xc = 0.0;
+        }
+      }
+      const double radial = group_sum(live ? xc * xb : 0.0);
+      const double r2b = group_sum(xb * xb);
+      if (live && r2b > 0.0 && !(radial > 0.0)) {  // the group would pass through the origin: it goes to zero
+        if (xc != 0.0) cut = 1.0;
+        xc = 0.0;
+      }
+      const double gdn = matvec(xc, false);
+      double sv[4] = {0.0, 0.0, 0.0, 0.0};
+      if (mine) {
+        sv[0] = (xc - z0) * (g0 + 0.5 * gdn);
+        sv[2] = cut;
+        if (!isfinite(xc)) sv[3] = 1.0;
+      }
+      sv[1] = pen_part(xc);
+      block_sum<4>(sv, red);
+      if (sv[3] == 0.0 && sv[0] + sv[1] < m_old) {
+        moved = true;
+        projected = sv[2] > 0.0;
+        full = trial == 0;
+        xn = xc;
+        if (tid == 0) atomicAdd(&ws->newton_trial[trial < 3 ? trial : 2], 1);
+      }
+    }
+    if (!moved) return -1;
+    if (want_mu && full && !projected && m > 0) {
+      __syncthreads();
+      *mu_out = nt_lambda_min(ntF, ntD, T, mp, nv, red, 2);
+    }
+    x = xn;
+    return 1;
+   }
   };
 
   // ---- FISTA on the model ------------------------------------------------------------------------
@@ -1256,7 +1488,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
       bool stepped = false;
       if (n_direct < WS_NEWTON_MAX) {
         double mu_new = 0.0;
-        const int rc = direct_step(x, L, &mu_new, mu_face == 0.0);
+        const int rc = group_face ? direct_step_group(x, L, &mu_new, mu_face == 0.0) : direct_step(x, L, &mu_new, mu_face == 0.0);
         n_direct += 1;
         if (rc > 0) {
           if (mu_new > 0.0) mu_face = mu_new;
@@ -1292,7 +1524,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     if (direct_on && n_direct < WS_NEWTON_MAX &&
         (since_direct >= WS_NEWTON_AFTER || (rq_n >= 5 && rq_min < WS_NEWTON_RQ * L))) {
       double mu_new = 0.0;
-      const int rc = direct_step(x, L, &mu_new, mu_face == 0.0);
+      const int rc = group_face ? direct_step_group(x, L, &mu_new, mu_face == 0.0) : direct_step(x, L, &mu_new, mu_face == 0.0);
       since_direct = 0;
       n_direct += 1;
       if (rc > 0) {
@@ -1352,12 +1584,13 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   }
 }
 
+template <bool GROUPED>
 __global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs w) {
   __shared__ double red[8][TAIL_WAVES];
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
   if (ctl->done != 0 || ctl->idle != 0 || a.gdone[0] != 0) return;
-  ws_refine_lane(a, w, red);  // (every return inside is taken by the whole workgroup)
+  ws_refine_lane<GROUPED>(a, w, red);  // (every return inside is taken by the whole workgroup)
   __syncthreads();
   // Is the point the next pass evaluates zero outside W?  Then its residual needs only the gathered
   // columns (resid_ws_kernel) and the pass over X is the accumulate-only xtr_ring_kernel.
