@@ -374,7 +374,9 @@ def main():
     use_dist = world > 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo")  # control plane only: barrier + max of the timings
+        with StdoutToStderr():  # (gloo announces its connections on stdout)
+            dist.init_process_group(backend="gloo")  # control plane only: barrier + max of the timings
+            dist.barrier()
 
     from sparselm_amd import _engine
 
