@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 4
+#define SLM_ABI_VERSION 5
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -110,6 +110,13 @@ int slm_dataset_download(slm_dataset* ds, double* X_out, double* y_out);
 int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y_mean_out);
 /* Replace the row weights (NULL => all ones).  Invalidates the cached Lipschitz constant. */
 int slm_dataset_set_row_weights(slm_dataset* ds, const double* row_weight);
+/*
+ * Replace the targets (host vector of length n, finite) and keep X and everything derived from it.  Several
+ * problems on one design -- the sub-problems of the splitting behind SparseGroupLasso(standardize=True)
+ * (reference model/_lasso.py:616-639 with :249-252), whose targets change between solves -- then share one
+ * upload.  A centred dataset expects targets that are already centred.
+ */
+int slm_dataset_set_targets(slm_dataset* ds, const double* y);
 /*
  * Group structure: gid[j] in [0, n_groups) is the dense group index of feature j in the
  * reference's order (i-th sorted unique label <-> group i, model/_lasso.py:248).  Groups need not

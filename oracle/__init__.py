@@ -35,6 +35,7 @@ from .penalty import (  # noqa: F401
     prox_fixed_point_residual,
 )
 from .fista import fista, lipschitz  # noqa: F401
+from .primal_dual import kkt_standardized, standardized_sparse_group  # noqa: F401
 from .estimators import (  # noqa: F401
     fit_adaptive_group_lasso,
     fit_adaptive_lasso,

@@ -11,6 +11,7 @@ import numpy as np
 
 from .fista import fista
 from .penalty import group_index
+from .primal_dual import group_factors, standardized_sparse_group
 
 
 # --------------------------------------------------------------------------------------------
@@ -119,14 +120,19 @@ def fit_sparse_group_lasso(
     group_weights=None,
     fit_intercept=False,
     sample_weight=None,
+    standardize=False,
     **kw,
 ):
-    """SparseGroupLasso: model/_lasso.py:505-639; lambda1 = l1_ratio*alpha, lambda2 = (1-l1_ratio)*alpha (:616-625)."""
+    """SparseGroupLasso: model/_lasso.py:505-639; lambda1 = l1_ratio*alpha, lambda2 = (1-l1_ratio)*alpha (:616-625).
+    ``standardize``: the group norms are ||X_g beta_g|| (:249-252), X the preprocessed design."""
     Xp, yp, xo, yo = preprocess(X, y, sample_weight, fit_intercept)
     p = Xp.shape[1]
     gidx, G = group_index(groups, p)
     w = _group_weights(group_weights, G)
     lam1, lam2 = l1_ratio * alpha, (1.0 - l1_ratio) * alpha
+    if standardize:
+        beta, info = standardized_sparse_group(Xp, yp, lam1 * np.ones(p), lam2 * w, gidx, G)
+        return {"coef": beta, "intercept": _intercept(beta, xo, yo, fit_intercept), "info": info}
     beta, info = _solve(Xp, yp, lam1 * np.ones(p), lam2 * w, np.zeros(G), gidx, G, **kw)
     return {"coef": beta, "intercept": _intercept(beta, xo, yo, fit_intercept), "info": info}
 
@@ -329,11 +335,13 @@ def fit_adaptive_sparse_group_lasso(
     update_function=None,
     fit_intercept=False,
     sample_weight=None,
+    standardize=False,
     **kw,
 ):
     """AdaptiveSparseGroupLasso: a0 = lambda1*1, b0 = lambda2*1 (:654-668); updates
     a = lambda1*update(beta), b = (lambda2*w_g)*update(||beta_g||) (:712-726); convergence is checked
-    on the concatenation [b, a] (:698-710)."""
+    on the concatenation [b, a] (:698-710).  ``standardize``: penalised and fed to the update are
+    ||X_g beta_g|| (``auxiliaries.group_norms.value`` with model/_lasso.py:249-252)."""
     Xp, yp, xo, yo = preprocess(X, y, sample_weight, fit_intercept)
     p = Xp.shape[1]
     gidx, G = group_index(groups, p)
@@ -342,11 +350,18 @@ def fit_adaptive_sparse_group_lasso(
     update = _default_update(alpha) if update_function is None else update_function
     zeros_g = np.zeros(G)
 
+    fac = group_factors(Xp, gidx, G) if standardize else None
+
     def solve_with(w, beta_prev):
+        if standardize:
+            return standardized_sparse_group(Xp, yp, w[G:], w[:G], gidx, G, beta0=beta_prev)[0]
         return _solve(Xp, yp, w[G:], w[:G], zeros_g, gidx, G, beta0=beta_prev, **kw)[0]
 
     def update_weights(beta):
-        norms = np.sqrt(np.bincount(gidx, weights=beta * beta, minlength=G))
+        if standardize:
+            norms = np.array([np.linalg.norm(Mg @ beta[cols]) for cols, Mg in fac])
+        else:
+            norms = np.sqrt(np.bincount(gidx, weights=beta * beta, minlength=G))
         a_new = lam1 * np.asarray(update(beta, eps), dtype=np.float64)
         b_new = (lam2 * gw) * np.asarray(update(norms, eps), dtype=np.float64)
         return np.concatenate((b_new, a_new))

@@ -790,6 +790,18 @@ extern "C" int slm_dataset_set_row_weights(slm_dataset* ds, const double* row_we
   return upload_row_weights(ds, row_weight);
 }
 
+// Replace the targets in place (X stays): y appears only in the residuals, so nothing cached with the
+// dataset (column-major copy, step-size bound) depends on it.
+extern "C" int slm_dataset_set_targets(slm_dataset* ds, const double* y) {
+  if (!ds || !y) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  for (int64_t i = 0; i < ds->n; ++i)
+    if (!std::isfinite(y[i])) return fail(SLM_ERR_BAD_ARG, "y[%lld] is not finite", (long long)i);
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  HIP_TRY(hipStreamSynchronize(ds->eng->stream));
+  HIP_TRY(hipMemcpy(ds->y, y, sizeof(double) * ds->n, hipMemcpyHostToDevice));
+  return SLM_OK;
+}
+
 extern "C" int slm_dataset_set_global_rows(slm_dataset* ds, int64_t n_global) {
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
   if (n_global < 1) return fail(SLM_ERR_BAD_ARG, "n_global must be positive (got %lld)", (long long)n_global);

@@ -123,13 +123,19 @@ class SolveProblem:
     """Device-resident problem: upload once, solve many penalties (adaptive loops, paths); the dataset itself
     outlives the problem in the ``DatasetCache``."""
 
-    def __init__(self, backend, X, y, gidx, n_groups, options, row_weight=None, center=False):
+    def __init__(self, backend, X, y, gidx, n_groups, options, row_weight=None, center=False, cache=True):
         self.backend = backend
         self.options = options
         self.p = X.shape[1]
         self.n_groups = n_groups
         eng = _engine.get_engine(options.get("device"))
-        self.ds, self.x_mean, self.y_mean, self._key = _dataset_cache.acquire(eng, X, y, row_weight, center)
+        if cache:
+            self.ds, self.x_mean, self.y_mean, self._key = _dataset_cache.acquire(eng, X, y, row_weight, center)
+        else:  # a dataset of its own: the caller is going to change its targets (set_targets)
+            self.ds = eng.dataset(X, y, row_weight=row_weight)
+            self.x_mean, self.y_mean = self.ds.center() if center else (None, None)
+            self._key = None
+        self._private = not cache
         # (a cached dataset may carry another estimator's groups: always set them)
         self.ds.set_groups(gidx, n_groups if gidx is not None else None)
 
@@ -169,6 +175,13 @@ class SolveProblem:
         gn = None if res.group_norms is None else res.group_norms[0]
         return res.betas[0], gn, info
 
+    def set_targets(self, y):
+        """New targets on the same design (problems opened with ``cache=False`` only: a cached dataset is
+        found again by the content it was uploaded with)."""
+        if not self._private:
+            raise RuntimeError("set_targets needs a problem opened with cache=False")
+        self.ds.set_targets(y)
+
     def close(self):
         if self.ds is not None:
             _dataset_cache.release(self.ds, self.x_mean, self.y_mean, self._key)
@@ -181,8 +194,8 @@ class HipBackend:
     # slm_dataset_center): the estimator hands over the raw validated arrays
     native_preprocessing = True
 
-    def problem(self, X, y, gidx, n_groups, options, row_weight=None, center=False) -> SolveProblem:
-        return SolveProblem(self, X, y, gidx, n_groups, options, row_weight=row_weight, center=center)
+    def problem(self, X, y, gidx, n_groups, options, row_weight=None, center=False, cache=True) -> SolveProblem:
+        return SolveProblem(self, X, y, gidx, n_groups, options, row_weight=row_weight, center=center, cache=cache)
 
 
 _backend = HipBackend()

@@ -41,7 +41,7 @@ FLAG_WORKING_SET = 32  # force the Gram-assisted refinement even for small X
 FLAG_NO_WORKING_SET = 64
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 4  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 5  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -60,6 +60,7 @@ ABI_SYMBOLS = (
     "slm_dataset_download",
     "slm_dataset_center",
     "slm_dataset_set_row_weights",
+    "slm_dataset_set_targets",
     "slm_dataset_set_groups",
     "slm_dataset_lipschitz",
     "slm_dataset_max_lanes",
@@ -223,6 +224,7 @@ def load_library():
             "slm_dataset_download": [vp, vp, vp],
             "slm_dataset_center": [vp, vp, P(dbl)],
             "slm_dataset_set_row_weights": [vp, vp],
+            "slm_dataset_set_targets": [vp, vp],
             "slm_dataset_set_groups": [vp, vp, i32],
             "slm_dataset_lipschitz": [vp, P(dbl)],
             "slm_dataset_max_lanes": [vp, C.c_uint32, P(i32)],
@@ -551,6 +553,11 @@ class Dataset:
     def set_row_weights(self, row_weight):
         rw = None if row_weight is None else _f64(row_weight, "row_weight", (self.n,))
         _check(self._lib.slm_dataset_set_row_weights(self._h, _ptr(rw)))
+
+    def set_targets(self, y):
+        """Replace y on the device (X and what was derived from it stay)."""
+        yv = _f64(y, "y", (self.n,))
+        _check(self._lib.slm_dataset_set_targets(self._h, _ptr(yv)))
 
     def set_global_rows(self, n_global: int):
         _check(self._lib.slm_dataset_set_global_rows(self._h, int(n_global)))

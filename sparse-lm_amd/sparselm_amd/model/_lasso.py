@@ -112,17 +112,6 @@ class GroupLasso(Lasso):
             n_groups = len(np.unique(self.groups))
         check_groups(self.groups, X.shape[1])
         check_group_weights(self.group_weights, n_groups)
-        if self.standardize and not self._supports_standardize:
-            raise NotImplementedError(
-                f"standardize=True is not implemented for {self.__class__.__name__}: its penalty "
-                "lambda1 ||b||_1 + lambda2 sum_g w_g ||X_g b_g||_2 (reference _lasso.py:616-639 with :249-252) mixes a "
-                "norm of X_g b_g with an l1 norm of b itself; no per-group change of variables makes both separable, "
-                "so the proximal step of the engine does not apply"
-            )
-
-    # standardize=True is a per-group change of variables (see standardize_groups); it keeps the problem
-    # inside the prox family for the group penalties (plain, ridged, adaptive, overlap), not for SparseGroupLasso
-    _supports_standardize = True
 
     def _needs_host_preprocessing(self) -> bool:
         return bool(self.standardize)  # the per-group QR works on the centred design
@@ -355,8 +344,6 @@ class SparseGroupLasso(GroupLasso):
     r"""Sparse Group Lasso: ``lambda1 ||b||_1 + lambda2 sum_g w_g ||b_g||_2`` with
     ``lambda1 = l1_ratio * alpha`` and ``lambda2 = (1 - l1_ratio) * alpha`` (reference _lasso.py:505-639)."""
 
-    _supports_standardize = False
-
     def __init__(
         self,
         groups=None,
@@ -401,6 +388,19 @@ class SparseGroupLasso(GroupLasso):
 
     def _lambdas(self):
         return self.l1_ratio * self.alpha, (1.0 - self.l1_ratio) * self.alpha
+
+    # standardize=True: lambda2 sum_g w_g ||X_g b_g||_2 next to an l1 norm of b itself (reference :627-639 with
+    # :249-252) -- no change of variables makes both separable, so the design stays as it is and the solve is a
+    # splitting around weighted-l1 engine solves (model/_split.py)
+    def _design_transform(self, X):
+        return Design(X)
+
+    def _open_problem(self, X, y, gidx, G, solver_options):
+        if not self.standardize:
+            return super()._open_problem(X, y, gidx, G, solver_options)
+        from ._split import StandardizedSparseGroupProblem
+
+        return StandardizedSparseGroupProblem(X, y, gidx, G, solver_options)
 
     def _penalty(self, X):
         gidx, G, w = self._group_setup(X)

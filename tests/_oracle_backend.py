@@ -27,6 +27,9 @@ class _OracleProblem:
             gn = np.sqrt(np.bincount(self.gidx, weights=beta * beta, minlength=self.G))
         return beta, gn, info
 
+    def set_targets(self, y):
+        self.y = np.asarray(y, float)
+
     def close(self):
         pass
 
@@ -34,5 +37,5 @@ class _OracleProblem:
 class OracleBackend:
     name = "oracle"
 
-    def problem(self, X, y, gidx, n_groups, options):
+    def problem(self, X, y, gidx, n_groups, options, cache=True):
         return _OracleProblem(X, y, gidx, n_groups, options)

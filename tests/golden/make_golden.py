@@ -144,6 +144,18 @@ def main():
         r2 = second_solver.adaptive(Xg, yg, groups, 1.5, gw, fit_intercept=True, **kw)
         out[f"{key}_coef2"], out[f"{key}_icpt2"], out[f"{key}_niter2"] = r2["coef"], r2["intercept"], r2["n_iter"]
 
+    # ---- 4b. standardised sparse-group penalty (reference model/_lasso.py:627-639 with the group norms of
+    # :249-252): the oracle's primal-dual solution with its optimality residual in the original problem
+    # (oracle.kkt_standardized, certificate computed without the solver's dual iterate)
+    r = oracle.fit_sparse_group_lasso(Xg, yg, groups=groups, l1_ratio=0.5, alpha=0.4, group_weights=gw, standardize=True)
+    out["std_sgl_coef"] = r["coef"]
+    out["std_sgl_kkt"] = oracle.kkt_standardized(Xg, yg, 0.2 * np.ones(p), 0.2 * gw, gidx, G, r["coef"])
+    r = oracle.fit_adaptive_sparse_group_lasso(
+        Xg, yg, groups=groups, l1_ratio=0.4, alpha=0.8, group_weights=gw, fit_intercept=True, standardize=True
+    )
+    out["std_ada_sgl_coef"], out["std_ada_sgl_icpt"], out["std_ada_sgl_w"], out["std_ada_sgl_niter"] = (
+        r["coef"], r["intercept"], r["weights"], r["n_iter"])
+
     # ---- 5. AdaptiveLasso inner-solve sequence pinned by sklearn CD (weights = alpha^2/(|b|+eps)) -
     alpha_a, eps = 1.5, 1e-6
     wseq = [alpha_a * np.ones(30)]
@@ -160,7 +172,7 @@ def main():
     path = os.path.join(HERE, "lasso_family_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
-    for k in ("grp_gl_kkt", "grp_sgl_kkt", "grp_rgl_kkt"):
+    for k in ("grp_gl_kkt", "grp_sgl_kkt", "grp_rgl_kkt", "std_sgl_kkt"):
         print(k, out[k])
 
 

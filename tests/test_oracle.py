@@ -132,6 +132,35 @@ def test_group_family_agrees_with_the_second_solver(golden, kind):
     assert np.array_equal(mine != 0, other != 0)  # same support, exact zeros on both sides
 
 
+def test_standardized_sparse_group_solution_is_certified_and_meets_its_special_cases(golden):
+    """oracle/primal_dual.py: the primal-dual solution of the standardised sparse-group problem (reference
+    model/_lasso.py:627-639 with :249-252) satisfies the optimality conditions of the original problem
+    (certificate computed from the coefficients alone), is the fixture, and at the ends of l1_ratio is the
+    Lasso (scikit-learn's coordinate descent) and the standardised GroupLasso (whitened FISTA)."""
+    from sklearn.linear_model import Lasso as SkLasso
+
+    X, y, groups, gw = golden["grp_X"], golden["grp_y"], golden["grp_groups"], golden["grp_gw"]
+    n, p = X.shape
+    gidx, G = oracle.group_index(groups, p)
+    scale = np.max(np.abs(X.T @ y)) / n
+    r = oracle.fit_sparse_group_lasso(X, y, groups=groups, l1_ratio=0.5, alpha=0.4, group_weights=gw, standardize=True)
+    assert r["info"]["converged"]
+    npt.assert_allclose(r["coef"], golden["std_sgl_coef"], rtol=0, atol=1e-10 * np.max(np.abs(r["coef"])))
+    assert oracle.kkt_standardized(X, y, 0.2 * np.ones(p), 0.2 * gw, gidx, G, r["coef"]) < 1e-11 * scale
+    # a perturbed point is not certified
+    bad = r["coef"].copy()
+    bad[np.argmax(np.abs(bad))] *= 1.001
+    assert oracle.kkt_standardized(X, y, 0.2 * np.ones(p), 0.2 * gw, gidx, G, bad) > 1e-6 * scale
+    # l1_ratio = 1: the Lasso
+    b1, _ = oracle.standardized_sparse_group(X, y, 0.4 * np.ones(p), np.zeros(G), gidx, G)
+    sk = SkLasso(alpha=0.4, fit_intercept=False, tol=1e-15, max_iter=1_000_000).fit(X, y).coef_
+    npt.assert_allclose(b1, sk, rtol=0, atol=1e-9 * np.max(np.abs(sk)))
+    # l1_ratio = 0: the standardised group lasso, solved in whitened coordinates by the FISTA oracle
+    b0, _ = oracle.standardized_sparse_group(X, y, np.zeros(p), 0.4 * gw, gidx, G)
+    gl = oracle.fit_group_lasso(X, y, groups=groups, alpha=0.4, group_weights=gw, standardize=True)["coef"]
+    npt.assert_allclose(b0, gl, rtol=0, atol=1e-8 * np.max(np.abs(gl)))
+
+
 def test_prox_matches_bruteforce_minimiser(rng):
     # prox_s(v) = argmin_u 1/2||u - v||^2 + s*pen(u): check optimality by perturbation on a tiny case
     p = 7
