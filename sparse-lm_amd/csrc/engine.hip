@@ -341,9 +341,18 @@ struct GlobalCtl {
 };
 static const int kWsLateIters = 12;  // passes on one point after which a small problem gets the working set
 
-struct HostCtl {  // pinned snapshot the host polls
+// Everything the host reads back about a solve sits in ONE device block -- the stop word, the lanes' control
+// blocks and the working set's counters -- so a poll is one copy, and the snapshot in which the host sees
+// `done` already holds the final statistics (after `done` every queued kernel returns at once: nothing in the
+// block changes any more).  Reading them one by one at the end cost four blocking copies, ~0.1 ms of host
+// round trips on a 5 ms path.
+struct DevCtl {
   GlobalCtl g;
+  WsCtl ws;  // (next to g: one fill clears both at the start of a solve)
   PathCtl lane[SLM_MAX_LANES];
+};
+struct HostCtl {  // pinned snapshot the host polls
+  DevCtl c;
 };
 
 struct slm_dataset {
@@ -356,7 +365,7 @@ struct slm_dataset {
   int G = 0, singleton = 1, team = 1, max_group = 1;
   int *order = nullptr, *gid = nullptr, *gstart = nullptr;
   // working-set refinement (ws_kernels.hpp), allocated on first use
-  WsCtl* ws_ctl = nullptr;
+  WsCtl* ws_ctl = nullptr;  // (inside dctl)
   int32_t *ws_idx = nullptr, *ws_pos = nullptr, *ws_gs = nullptr, *ws_gl = nullptr;
   double *ws_score = nullptr, *ws_XW = nullptr, *ws_part = nullptr, *ws_G = nullptr, *ws_Gx = nullptr;
   double* ws_nt = nullptr;  // [kMaxLanes][NT_SCRATCH] factors of the model solver's direct steps
@@ -379,8 +388,9 @@ struct slm_dataset {
   double *g = nullptr, *z = nullptr, *beta = nullptr, *zprev = nullptr, *gprev = nullptr;
   double *u = nullptr, *gscale = nullptr, *a0 = nullptr, *b0 = nullptr, *d0 = nullptr;
   double* lambda = nullptr;  // [kMaxLanes]
-  PathCtl* ctl = nullptr;    // [kMaxLanes]
-  GlobalCtl* gctl = nullptr;
+  DevCtl* dctl = nullptr;    // the block below is made of:
+  PathCtl* ctl = nullptr;    // [kMaxLanes]  (= dctl->lane)
+  GlobalCtl* gctl = nullptr; //              (= &dctl->g)
   HostCtl* hctl = nullptr;   // pinned, 2 slots
   hipEvent_t ev[2] = {nullptr, nullptr};
   // path buffers (grown on demand), concatenated over lanes
@@ -508,9 +518,9 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->partial); dfree(ds->loss_partial); dfree(ds->R);
   dfree(ds->g); dfree(ds->z); dfree(ds->beta); dfree(ds->zprev); dfree(ds->gprev);
   dfree(ds->u); dfree(ds->gscale); dfree(ds->a0); dfree(ds->b0); dfree(ds->d0);
-  dfree(ds->lambda); dfree(ds->ctl); dfree(ds->gctl);
+  dfree(ds->lambda); dfree(ds->dctl);
   dfree(ds->pts); dfree(ds->betas_out); dfree(ds->gn_out); dfree(ds->infos);
-  dfree(ds->ws_ctl); dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
+  dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
   dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
   dfree(ds->ws_nt); dfree(ds->stop_words); dfree(ds->sse_Z); dfree(ds->sse_part);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
@@ -605,8 +615,12 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
   A(dalloc(&ds->b0, ML * ld));
   A(dalloc(&ds->d0, ML * ld));
   A(dalloc(&ds->lambda, ML));
-  A(dalloc(&ds->ctl, ML));
-  A(dalloc(&ds->gctl, 1));
+  A(dalloc(&ds->dctl, 1));
+  if (rc == SLM_OK) {  // (addresses only: nothing is read through the device pointer here)
+    ds->ctl = ds->dctl->lane;
+    ds->gctl = &ds->dctl->g;
+    ds->ws_ctl = &ds->dctl->ws;
+  }
   if (rc == SLM_OK) {
     hipError_t e2 = hipHostMalloc((void**)&ds->hctl, 2 * sizeof(HostCtl), hipHostMallocDefault);
     if (e2 != hipSuccess) rc = fail(SLM_ERR_OOM, "hipHostMalloc: %s", hipGetErrorString(e2));
@@ -1649,7 +1663,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   }
   hipLaunchKernelGGL(solve_setup_kernel, dim3(128), dim3(256), 0, s, su);
   HIP_TRY(hipMemcpyAsync(ds->ctl, h, sizeof(PathCtl) * B, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(ds->gctl, 0, sizeof(GlobalCtl), s));
+  static_assert(offsetof(DevCtl, lane) >= offsetof(DevCtl, ws) + sizeof(WsCtl) && offsetof(DevCtl, g) == 0, "g, ws, lane");
+  HIP_TRY(hipMemsetAsync(ds->dctl, 0, offsetof(DevCtl, lane), s));  // stop words and working-set counters
   if (L_on_device) {  // the power steps are still in flight: their result goes into the control blocks on the device
     SeedArgs sa;
     sa.ctl = ds->ctl; sa.lambda = ds->lambda; sa.n_lanes = B; sa.margin = 1.08;
@@ -1705,7 +1720,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     ws_late = pol == 1 && !eng->sharded();
   }
   if (eng->sharded() && !ds->stop_words) SLM_TRY(dalloc(&ds->stop_words, STOP_WORDS));
-  auto ws_setup = [&]() -> int {
+  auto ws_setup = [&](bool late) -> int {
     // lanes with the same row weights (same host pointer: the folds of a CV grid) and the same 1/n
     // scaling share one Gram
     int set_of[SLM_MAX_LANES] = {}, set_lane[SLM_MAX_LANES] = {};
@@ -1722,7 +1737,6 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
     const int ws_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n / 64));  // (2 MiB of partials each)
     // (each on its own: slm_eval_sse_sparse may already have brought idx and XW in)
-    if (!ds->ws_ctl) SLM_TRY(dalloc(&ds->ws_ctl, 1));
     if (!ds->ws_idx) SLM_TRY(dalloc(&ds->ws_idx, WS_KCAP));
     if (!ds->ws_gs) SLM_TRY(dalloc(&ds->ws_gs, WS_KCAP));
     if (!ds->ws_gl) SLM_TRY(dalloc(&ds->ws_gl, WS_KCAP));
@@ -1743,7 +1757,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     // the gathers read the row-major X, one 64-byte sector per element.
     SLM_TRY(ensure_xt(ds));
     // (initialised on the device: a host-side copy would need the stream drained before its buffer goes away)
-    HIP_TRY(hipMemsetAsync(ds->ws_ctl, 0, sizeof(WsCtl), s));
+    if (late) HIP_TRY(hipMemsetAsync(ds->ws_ctl, 0, sizeof(WsCtl), s));  // (a fresh solve has cleared it already)
     hipLaunchKernelGGL(ws_ctl_init_kernel, dim3(1), dim3(64), 0, s, ds->ws_ctl, 24);
     wa.ws = ds->ws_ctl;
     wa.idx = ds->ws_idx; wa.pos = ds->ws_pos; wa.gs = ds->ws_gs; wa.gl = ds->ws_gl;
@@ -1780,13 +1794,13 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // no memory for the working-set buffers: the plain iteration still works (unless this solve runs
   // more lanes than the fused kernels serve, which only the split pass can do)
   auto ws_release = [&]() {
-    dfree(ds->ws_ctl); dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
+    dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
     dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->ws_nt);
     ds->ws_sets = 0;
     (void)hipGetLastError();
   };
   if (use_ws) {
-    const int rc = ws_setup();
+    const int rc = ws_setup(false);
     if (rc == SLM_ERR_OOM && !split) {
       ws_release();
       use_ws = false;
@@ -1869,6 +1883,37 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     for (int l = 0; l < B; ++l) most = std::max<int64_t>(most, shared_path && interleave ? (total_points - l + B - 1) / B : lanes[l].n_points);
     expected = 1 + most;
   }
+  // results: lanes whose host buffers follow each other (the ranges of one shared path do) travel in one
+  // copy -- a device-to-host copy into pageable memory costs ~40 us before the first byte moves.  Queued on the
+  // solve's stream; the caller waits for it.
+  auto enqueue_result_copies = [&]() -> int {
+    int64_t at = 0;
+    for (int l = 0; l < B;) {
+      int l1 = l + 1;
+      int64_t pts = lanes[l].n_points;
+      const bool gn = lanes[l].group_norms_out != nullptr, inf = lanes[l].infos != nullptr;
+      while (l1 < B && lanes[l1].betas_out == lanes[l].betas_out + (size_t)pts * p &&
+             (lanes[l1].group_norms_out != nullptr) == gn && (lanes[l1].infos != nullptr) == inf &&
+             (!gn || lanes[l1].group_norms_out == lanes[l].group_norms_out + (size_t)pts * G) &&
+             (!inf || lanes[l1].infos == lanes[l].infos + pts)) {
+        pts += lanes[l1].n_points;
+        ++l1;
+      }
+      HIP_TRY(hipMemcpyAsync(lanes[l].betas_out, ds->betas_out + (size_t)at * p, sizeof(double) * (size_t)pts * p,
+                             hipMemcpyDeviceToHost, s));
+      if (gn)
+        HIP_TRY(hipMemcpyAsync(lanes[l].group_norms_out, ds->gn_out + (size_t)at * G, sizeof(double) * (size_t)pts * G,
+                               hipMemcpyDeviceToHost, s));
+      if (inf)
+        HIP_TRY(hipMemcpyAsync(lanes[l].infos, ds->infos + at, sizeof(slm_point_info) * (size_t)pts,
+                               hipMemcpyDeviceToHost, s));
+      at += pts;
+      l = l1;
+    }
+    return SLM_OK;
+  };
+  int final_slot = 0;          // the snapshot in which the host saw `done`
+  bool results_copied = false;
   while (!done) {
     {
       const int this_chunk = expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(chunk, expected - enq) : 1);
@@ -1890,17 +1935,36 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       }
       SLM_TRY(check_launch());
       if (ws_comm_rc != 0) return ws_comm_rc;  // (all_reduce_sum has set the message)
-      HIP_TRY(hipMemcpyAsync(&ds->hctl[slot].g, ds->gctl, sizeof(GlobalCtl), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(&ds->hctl[slot].c, ds->dctl, sizeof(DevCtl), hipMemcpyDeviceToHost, s));
     }
+    // The pass the solve is expected to end with: the results follow it down the queue at once and the host
+    // waits for THIS chunk instead of queueing another pass behind it -- when the solve does end there (the
+    // usual case) nothing is left to do but read the snapshot.  Polling one chunk behind cost a queued pass
+    // that returned at once (eighteen launches, 0.09 ms) and four blocking copies (0.2 ms of host round trips)
+    // on every 5 ms path.  A solve that overruns gets a few more passes polled this way, then the pipelined polls.
+    const bool at_end = expected > 0 && enq >= expected && enq < expected + 4;
+    const bool spec_copy = expected > 0 && enq == expected;
+    if (spec_copy) SLM_TRY(enqueue_result_copies());
     HIP_TRY(hipEventRecord(ds->ev[slot], s));
     pending[slot] = true;
     const int other = slot ^ 1;
-    if (pending[other]) {
+    if (at_end) {
+      HIP_TRY(hipEventSynchronize(ds->ev[slot]));
+      pending[slot] = pending[other] = false;
+      if (ds->hctl[slot].c.g.done) {
+        done = true;
+        final_slot = slot;
+        results_copied = spec_copy;
+      }
+    } else if (pending[other]) {
       HIP_TRY(hipEventSynchronize(ds->ev[other]));
       pending[other] = false;
-      if (ds->hctl[other].g.done) done = true;
-      if (!done && ws_late && ds->hctl[other].g.hard >= kWsLateIters) {
-        const int rc = ws_setup();  // (waits for the stream: the queued passes simply finish first)
+      if (ds->hctl[other].c.g.done) {
+        done = true;
+        final_slot = other;
+      }
+      if (!done && ws_late && ds->hctl[other].c.g.hard >= kWsLateIters) {
+        const int rc = ws_setup(true);  // (waits for the stream: the queued passes simply finish first)
         ws_late = false;
         if (rc == SLM_OK) {
           use_ws = true;
@@ -1918,43 +1982,16 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       return fail(SLM_ERR_HIP, "internal error: path state machine did not terminate");
     }
   }
+  if (!results_copied) SLM_TRY(enqueue_result_copies());
   HIP_TRY(hipStreamSynchronize(s));
   tr[3] = t_mark();
-  if (eng->sharded()) {
-    GlobalCtl gfin;
-    HIP_TRY(hipMemcpy(&gfin, ds->gctl, sizeof(gfin), hipMemcpyDeviceToHost));
-    if (gfin.diverged)
-      return fail(SLM_ERR_COMM, "row-sharded solve aborted: the ranks' solver states differ (different arguments on "
-                  "different ranks, or an all-reduce that is not bit-identical on every rank)");
-  }
-  PathCtl fin[SLM_MAX_LANES];
-  HIP_TRY(hipMemcpy(fin, ds->ctl, sizeof(PathCtl) * B, hipMemcpyDeviceToHost));
+  const DevCtl& snap = ds->hctl[final_slot].c;  // (nothing in the block changes after `done`)
+  if (eng->sharded() && snap.g.diverged)
+    return fail(SLM_ERR_COMM, "row-sharded solve aborted: the ranks' solver states differ (different arguments on "
+                "different ranks, or an all-reduce that is not bit-identical on every rank)");
+  const PathCtl* fin = snap.lane;
   int64_t passes = 0;
   bool nonfinite = false;
-  // results: lanes whose host buffers follow each other (the ranges of one shared path do) travel in one
-  // copy -- a device-to-host copy into pageable memory costs ~40 us before the first byte moves
-  off = 0;
-  for (int l = 0; l < B;) {
-    int l1 = l + 1;
-    int64_t pts = lanes[l].n_points;
-    const bool gn = lanes[l].group_norms_out != nullptr, inf = lanes[l].infos != nullptr;
-    while (l1 < B && lanes[l1].betas_out == lanes[l].betas_out + (size_t)pts * p &&
-           (lanes[l1].group_norms_out != nullptr) == gn && (lanes[l1].infos != nullptr) == inf &&
-           (!gn || lanes[l1].group_norms_out == lanes[l].group_norms_out + (size_t)pts * G) &&
-           (!inf || lanes[l1].infos == lanes[l].infos + pts)) {
-      pts += lanes[l1].n_points;
-      ++l1;
-    }
-    HIP_TRY(hipMemcpy(lanes[l].betas_out, ds->betas_out + (size_t)off * p, sizeof(double) * (size_t)pts * p,
-                      hipMemcpyDeviceToHost));
-    if (gn)
-      HIP_TRY(hipMemcpy(lanes[l].group_norms_out, ds->gn_out + (size_t)off * G, sizeof(double) * (size_t)pts * G,
-                        hipMemcpyDeviceToHost));
-    if (inf)
-      HIP_TRY(hipMemcpy(lanes[l].infos, ds->infos + off, sizeof(slm_point_info) * (size_t)pts, hipMemcpyDeviceToHost));
-    off += pts;
-    l = l1;
-  }
   for (int l = 0; l < B; ++l) {
     passes = std::max<int64_t>(passes, fin[l].total_iter);
     nonfinite = nonfinite || fin[l].nonfinite;
@@ -1981,8 +2018,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     stats->ws_builds = stats->ws_appends = stats->ws_refined = stats->ws_misses = stats->ws_columns = 0;
     stats->ws_inner_iters = stats->ws_direct_steps = 0;
     if (use_ws) {
-      WsCtl wc;
-      HIP_TRY(hipMemcpy(&wc, ds->ws_ctl, sizeof(wc), hipMemcpyDeviceToHost));
+      const WsCtl& wc = snap.ws;
       stats->ws_builds = wc.builds;
       stats->ws_appends = wc.appends;
       stats->ws_refined = wc.refined;

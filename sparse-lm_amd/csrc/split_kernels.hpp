@@ -54,18 +54,35 @@ struct SplitArgs {
 };
 
 // which lanes take their residual from XW: live, flagged by ws_solve_kernel, and W still published
-__device__ __forceinline__ unsigned split_ws_mask(const SplitArgs& a) {
-  if (a.ctl == nullptr || a.ws == nullptr || !a.ws->valid || a.ws->building) return 0u;
-  unsigned m = 0u;
-  for (int l = 0; l < a.n_lanes; ++l)
-    if (!a.ctl[l].done && !a.ctl[l].idle && a.ctl[l].zsup) m |= 1u << l;
-  return m;
+// Which lane slots a residual kernel serves.  Lane l of every wavefront looks at control block l and the
+// wavefront votes: one round of loads.  (Walking the sixteen blocks in a loop with short-circuit tests made
+// every flag its own dependent load -- 11 us before rowdot_mfma_kernel found out it had nothing to do.)
+__device__ __forceinline__ void split_masks(const SplitArgs& a, unsigned& live, unsigned& on_ws) {
+  const int l = threadIdx.x & 63;
+  int lv = 0, sp = 0;
+  if (l < a.n_lanes) {
+    if (a.ctl == nullptr) {
+      lv = 1;
+    } else {
+      const int dn = a.ctl[l].done, id = a.ctl[l].idle, zs = a.ctl[l].zsup;
+      lv = (dn == 0) & (id == 0);
+      sp = lv & (zs != 0);
+    }
+  }
+  const bool ws_ok = a.ctl != nullptr && a.ws != nullptr && a.ws->valid && !a.ws->building;
+  live = (unsigned)__ballot(lv != 0);
+  on_ws = ws_ok ? (unsigned)__ballot(sp != 0) : 0u;
 }
-__device__ __forceinline__ unsigned split_live_mask(const SplitArgs& a) {
-  unsigned m = 0u;
-  for (int l = 0; l < a.n_lanes; ++l)
-    if (a.ctl == nullptr || (!a.ctl[l].done && !a.ctl[l].idle)) m |= 1u << l;
-  return m;
+__device__ __forceinline__ unsigned split_ws_mask(const SplitArgs& a) {
+  unsigned live, on_ws;
+  split_masks(a, live, on_ws);
+  return on_ws;
+}
+// lane slots whose residual has to come from X
+__device__ __forceinline__ unsigned split_x_mask(const SplitArgs& a) {
+  unsigned live, on_ws;
+  split_masks(a, live, on_ws);
+  return live & ~on_ws;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
   if (a.done != nullptr && *a.done != 0) return;
   // lanes served here: live, not served by resid_ws_kernel, inside this launch's window of B lanes
   const int lane0 = a.lane0 + (int)blockIdx.y * B;  // grid.y = windows of B lanes (one launch for all of them)
-  const unsigned mask = ((split_live_mask(a) & ~split_ws_mask(a)) >> lane0) & ((1u << B) - 1u);
+  const unsigned mask = (split_x_mask(a) >> lane0) & ((1u << B) - 1u);
   if (mask == 0u) return;
 
   __shared__ __attribute__((aligned(16))) char smem[RING + RED];
@@ -441,7 +458,7 @@ constexpr int XZ_T = 4;
 __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 rows of the MFMA A operand");
   if (a.done != nullptr && *a.done != 0) return;
-  const unsigned mask = split_live_mask(a) & ~split_ws_mask(a);
+  const unsigned mask = split_x_mask(a);
   if (mask == 0u) return;
   __shared__ double red[XZ_WAVES][SPLIT_LANES];
   const int tid = threadIdx.x, lane = tid & 63;
