@@ -341,6 +341,7 @@ struct GlobalCtl {
 };
 static const int kWsLateIters = 12;  // passes on one point after which a small problem gets the working set
 
+static const int kSnapInfos = 64;
 // Everything the host reads back about a solve sits in ONE device block -- the stop word, the lanes' control
 // blocks and the working set's counters -- so a poll is one copy, and the snapshot in which the host sees
 // `done` already holds the final statistics (after `done` every queued kernel returns at once: nothing in the
@@ -350,6 +351,7 @@ struct DevCtl {
   GlobalCtl g;
   WsCtl ws;  // (next to g: one fill clears both at the start of a solve)
   PathCtl lane[SLM_MAX_LANES];
+  slm_point_info infos[kSnapInfos];  // the per-point records of solves of up to kSnapInfos points ride along
 };
 struct HostCtl {  // pinned snapshot the host polls
   DevCtl c;
@@ -1601,7 +1603,10 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   memset(&su, 0, sizeof(su));
   su.beta = ds->beta; su.z = ds->z; su.zprev = ds->zprev; su.gprev = ds->gprev;
   su.a0 = ds->a0; su.b0 = ds->b0; su.d0 = ds->d0;
-  su.infos = reinterpret_cast<unsigned char*>(ds->infos);
+  // (small solves keep their per-point records inside the control block: one blocking copy less at the end)
+  const bool infos_in_snap = total_points <= kSnapInfos;
+  slm_point_info* d_infos = infos_in_snap ? ds->dctl->infos : ds->infos;
+  su.infos = reinterpret_cast<unsigned char*>(d_infos);
   su.infos_bytes = (int64_t)(sizeof(slm_point_info) * total_points);
   static_assert(sizeof(slm_point_info) % 8 == 0, "infos are zeroed in 8-byte words");
   su.ld = ld; su.p = p; su.G = G; su.n_lanes = B; su.max_lanes = kMaxLanes;
@@ -1702,7 +1707,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   ta.gstart = ds->gstart;
   ta.betas_out = ds->betas_out;
   ta.gn_out = any_gn ? ds->gn_out : nullptr;
-  ta.infos = ds->infos;
+  ta.infos = d_infos;
 
   // ---- working-set refinement (ws_kernels.hpp) -----------------------------------------------------
   // Worth it when a pass over X costs more than the one-workgroup model solve that replaces several
@@ -1904,7 +1909,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       if (gn)
         HIP_TRY(hipMemcpyAsync(lanes[l].group_norms_out, ds->gn_out + (size_t)at * G, sizeof(double) * (size_t)pts * G,
                                hipMemcpyDeviceToHost, s));
-      if (inf)
+      if (inf && !infos_in_snap)
         HIP_TRY(hipMemcpyAsync(lanes[l].infos, ds->infos + at, sizeof(slm_point_info) * (size_t)pts,
                                hipMemcpyDeviceToHost, s));
       at += pts;
@@ -1913,7 +1918,6 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     return SLM_OK;
   };
   int final_slot = 0;          // the snapshot in which the host saw `done`
-  bool results_copied = false;
   while (!done) {
     {
       const int this_chunk = expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(chunk, expected - enq) : 1);
@@ -1937,24 +1941,34 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       if (ws_comm_rc != 0) return ws_comm_rc;  // (all_reduce_sum has set the message)
       HIP_TRY(hipMemcpyAsync(&ds->hctl[slot].c, ds->dctl, sizeof(DevCtl), hipMemcpyDeviceToHost, s));
     }
-    // The pass the solve is expected to end with: the results follow it down the queue at once and the host
-    // waits for THIS chunk instead of queueing another pass behind it -- when the solve does end there (the
-    // usual case) nothing is left to do but read the snapshot.  Polling one chunk behind cost a queued pass
-    // that returned at once (eighteen launches, 0.09 ms) and four blocking copies (0.2 ms of host round trips)
-    // on every 5 ms path.  A solve that overruns gets a few more passes polled this way, then the pipelined polls.
+    // The pass the solve is expected to end with: the host waits for THIS chunk instead of queueing another pass
+    // behind it -- when the solve does end there (the usual case) the snapshot is final and only the coefficients
+    // remain to be fetched.  Polling one chunk behind cost a queued pass that returned at once (eighteen launches,
+    // 0.09 ms) and four blocking copies (0.2 ms of host round trips) on every 5 ms path.  A solve that overruns
+    // gets a few more passes polled this way, then the pipelined polls.
     const bool at_end = expected > 0 && enq >= expected && enq < expected + 4;
-    const bool spec_copy = expected > 0 && enq == expected;
-    if (spec_copy) SLM_TRY(enqueue_result_copies());
     HIP_TRY(hipEventRecord(ds->ev[slot], s));
     pending[slot] = true;
     const int other = slot ^ 1;
     if (at_end) {
-      HIP_TRY(hipEventSynchronize(ds->ev[slot]));
+      // sleep until the chunk before this one is through, then watch this one's event: a blocking wait wakes up
+      // 20-40 us after the event (interrupt + scheduler), a query loop within a microsecond or two -- and it
+      // runs for one chunk (a pass or two) at most
+      if (pending[other]) HIP_TRY(hipEventSynchronize(ds->ev[other]));
+      const auto t_spin = std::chrono::steady_clock::now();
+      for (;;) {
+        const hipError_t q = hipEventQuery(ds->ev[slot]);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIP_TRY(q);
+        if (std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(20)) {
+          HIP_TRY(hipEventSynchronize(ds->ev[slot]));
+          break;
+        }
+      }
       pending[slot] = pending[other] = false;
       if (ds->hctl[slot].c.g.done) {
         done = true;
         final_slot = slot;
-        results_copied = spec_copy;
       }
     } else if (pending[other]) {
       HIP_TRY(hipEventSynchronize(ds->ev[other]));
@@ -1982,7 +1996,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       return fail(SLM_ERR_HIP, "internal error: path state machine did not terminate");
     }
   }
-  if (!results_copied) SLM_TRY(enqueue_result_copies());
+  SLM_TRY(enqueue_result_copies());
   HIP_TRY(hipStreamSynchronize(s));
   tr[3] = t_mark();
   const DevCtl& snap = ds->hctl[final_slot].c;  // (nothing in the block changes after `done`)
@@ -1990,6 +2004,13 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     return fail(SLM_ERR_COMM, "row-sharded solve aborted: the ranks' solver states differ (different arguments on "
                 "different ranks, or an all-reduce that is not bit-identical on every rank)");
   const PathCtl* fin = snap.lane;
+  if (infos_in_snap) {
+    int64_t at = 0;
+    for (int l = 0; l < B; ++l) {
+      if (lanes[l].infos) memcpy(lanes[l].infos, snap.infos + at, sizeof(slm_point_info) * (size_t)lanes[l].n_points);
+      at += lanes[l].n_points;
+    }
+  }
   int64_t passes = 0;
   bool nonfinite = false;
   for (int l = 0; l < B; ++l) {
