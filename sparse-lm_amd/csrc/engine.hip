@@ -1513,11 +1513,18 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       double* dst = ds->rw_lanes + (size_t)l * n;
       if (lanes[l].row_weight) {
         const double* w = lanes[l].row_weight;
+        // lanes that bring the same host array (the grid rows of one CV fold) share one check and one upload
+        int same = -1;
+        for (int m = 0; m < l && same < 0; ++m)
+          if (lanes[m].row_weight == w) same = m;
+        if (same >= 0) {
+          HIP_TRY(hipMemcpyAsync(dst, ds->rw_lanes + (size_t)same * n, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+          continue;
+        }
         for (int64_t i = 0; i < n; ++i)
           if (!(w[i] >= 0.0) || !std::isfinite(w[i]))
             return fail(SLM_ERR_BAD_ARG, "lane %d: row_weight[%lld] is negative or not finite", l, (long long)i);
         HIP_TRY(hipMemcpyAsync(dst, w, sizeof(double) * n, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
       } else if (ds->rw) {
         HIP_TRY(hipMemcpyAsync(dst, ds->rw, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
       } else {

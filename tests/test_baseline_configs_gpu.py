@@ -63,6 +63,35 @@ def test_config2_lasso_path_full_size_is_kkt_certified(eng):
     assert set(np.flatnonzero(coef > 20)) <= set(np.flatnonzero(res.betas[25]))
 
 
+def test_headline_path_with_a_dense_end_leaves_the_working_set_and_stays_certified(eng):
+    """The headline shape on data whose path ends far beyond the 512 columns a working set holds (noise 100,
+    floor 1e-3 alpha_max: thousands of non-zeros, the regime of profiles/*_headline_soak.log): the first points
+    are refined, the dense rest runs as plain steps on the sixteen-lane split pass -- against the plain four-lane
+    iteration of the same data and the optimality conditions."""
+    rng = np.random.default_rng(8)
+    coef = np.zeros(P)
+    coef[rng.choice(P, 145, replace=False)] = 100.0 * rng.standard_normal(145)
+    with eng.synthetic_dataset(N, P, seed=108, coef=coef, noise_sd=100.0) as ds:
+        g0, _ = ds.gradient(None)
+        amax = float(np.max(np.abs(g0)))
+        alphas = np.geomspace(amax, 1e-3 * amax, 50)
+        pts = [(a, 0.0, 0.0) for a in alphas]
+        res = ds.solve_path(pts, lanes=16)
+        ref = ds.solve_path(pts, lanes=4, flags=_engine.FLAG_NO_WORKING_SET, tol=1e-9)
+        assert res.converged and ref.converged
+        nnz = (res.betas != 0).sum(axis=1)
+        assert nnz[-1] >= 2000 and res.ws_builds >= 1 and res.ws_refined >= 16
+        assert res.grad_launches < ref.grad_launches
+        assert np.max(np.abs(res.betas - ref.betas)) < 1e-6 * np.max(np.abs(ref.betas))
+        gidx, G = oracle.group_index(None, P)
+        zero = np.zeros(G)
+        for k in (10, 30, 49):  # sparse, at the cap, dense
+            beta = res.betas[k]
+            g, _ = ds.gradient(beta)
+            kkt = oracle.kkt_residual(g, beta, alphas[k] * np.ones(P), zero, zero, gidx, G)
+            assert kkt / 0.5 < 1e-6 * np.max(np.abs(beta)), (k, kkt, nnz[k])
+
+
 def test_config3_group_lasso_path_full_size_is_kkt_certified(eng):
     rng = np.random.default_rng(1)
     groups = rng.permutation(np.repeat(np.arange(500), 10))  # shuffled => non-contiguous labels
