@@ -27,7 +27,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                   "rowshard": BASELINE config 5's shape (AdaptiveGroupLasso, 3 re-weighting solves,
                   125 000 rows x 10 000 columns PER RANK) through the engine's RCCL communicator over all
                   ranks (weak scaling in rows; one all-reduce of the gradients per pass).
-                  `--no-extra` skips them; `--rowshard` / `--grid` run only that leg as the step.
+                  `--no-extra` skips them.
 """
 
 from __future__ import annotations

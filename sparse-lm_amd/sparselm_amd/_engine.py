@@ -297,10 +297,24 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+_extrap_cache: dict = {}  # bytes of the points -> secant factors (the folds and rows of a grid walk the same path)
+
+
 def path_extrapolation(pts) -> np.ndarray:
     """Secant factors gamma_k = (s_k - s_{k-1}) / (s_{k-1} - s_{k-2}) for a path whose points are all
     multiples s_k of one penalty direction (rank-one (K, 3) array); zeros otherwise."""
-    pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+    key = pts.tobytes()
+    hit = _extrap_cache.get(key)
+    if hit is None:
+        hit = _path_extrapolation(pts)
+        if len(_extrap_cache) >= 64:
+            _extrap_cache.clear()
+        _extrap_cache[key] = hit
+    return hit.copy()
+
+
+def _path_extrapolation(pts) -> np.ndarray:
     K = pts.shape[0]
     gam = np.zeros(K)
     if K < 3:
@@ -310,14 +324,16 @@ def path_extrapolation(pts) -> np.ndarray:
     if nrm <= 0.0:
         return gam
     s = pts @ ref / nrm
-    if not np.allclose(np.outer(s, ref), pts, rtol=1e-12, atol=1e-300):
+    # (plain array arithmetic: this runs between two solves, with the device idle -- a Python loop over the points
+    #  and np.allclose cost 0.15 ms per 50-point path, 3 % of the solve itself)
+    if np.max(np.abs(s[:, None] * ref[None, :] - pts)) > 1e-12 * np.max(np.abs(pts)):
         return gam  # the penalty changes shape along the path: prediction would be meaningless
-    for k in range(2, K):
-        den = s[k - 1] - s[k - 2]
-        if den != 0.0:
-            g = (s[k] - s[k - 1]) / den
-            if np.isfinite(g) and abs(g) <= 10.0:
-                gam[k] = g
+    den = s[1:-1] - s[:-2]
+    num = s[2:] - s[1:-1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        g = num / den
+    ok = (den != 0.0) & np.isfinite(g) & (np.abs(g) <= 10.0)
+    gam[2:] = np.where(ok, g, 0.0)
     return gam
 
 

@@ -337,6 +337,30 @@ def test_bad_arguments_are_rejected(eng, golden):
         eng.dataset(np.empty((0, 3)), np.empty(0))
 
 
+def test_targets_replaced_in_place_give_the_fit_of_a_fresh_dataset(eng, golden):
+    """slm_dataset_set_targets: several problems on one design share the upload (the sub-problems behind
+    SparseGroupLasso(standardize=True), model/_split.py): same coefficients as a dataset created with those
+    targets, also after a working-set solve has cached the column-major copy; bad targets are refused."""
+    X, y = golden["l1_X"], golden["l1_y"]
+    rng = np.random.default_rng(3)
+    y2 = y + rng.standard_normal(len(y))
+    alpha = 0.3 * np.max(np.abs(X.T @ y2)) / len(y2)
+    with eng.dataset(X, y2) as fresh:
+        want = fresh.solve_path([(alpha, 0.0, 0.0)], tol=1e-12).betas[0]
+    with eng.dataset(X, y) as ds:
+        ds.solve_path([(alpha, 0.0, 0.0)], tol=1e-12, flags=_engine.FLAG_WORKING_SET)
+        ds.set_targets(y2)
+        got = ds.solve_path([(alpha, 0.0, 0.0)], tol=1e-12)
+        got_ws = ds.solve_path([(alpha, 0.0, 0.0)], tol=1e-12, flags=_engine.FLAG_WORKING_SET)
+        assert got.converged and got_ws.converged
+        assert rel_inf(got.betas[0], want) < 1e-9 and rel_inf(got_ws.betas[0], want) < 1e-9
+        npt.assert_array_equal(ds.download(want_X=False)[1], y2)
+        with pytest.raises(ValueError):
+            ds.set_targets(np.full(len(y), np.nan))
+        with pytest.raises(ValueError):
+            ds.set_targets(y[:-1])
+
+
 def test_non_finite_data_raises(eng):
     X = np.ones((10, 3))
     X[2, 1] = np.inf
