@@ -184,16 +184,24 @@ static const SplitKernel* pick_split_kernel(int64_t p2) {
   return nullptr;
 }
 
-// X^T R of the split pass on the matrix cores (xtr_mfma_kernel): grid = (column blocks of 512, row blocks),
-// about two workgroups per CU; rows per block a multiple of 8.
-static int xtr_max_row_blocks(int cus, int64_t ld) {
+// X^T R of the split pass on the matrix cores (xtr_mfma_kernel): grid = (column blocks of 512, row blocks), ONE
+// workgroup (four wavefronts, 64 KB of rows in flight) per CU; rows per block a multiple of 8.  Two workgroups per CU
+// -- the first choice: more bytes in flight -- measured 4-6 % slower on every box (0.603 against 0.566 ms, 0.622
+// against 0.592 ms at n = 100k, p = 5k; tools/xtr_wgs_probe.py): twice as many row streams open at once, and the
+// kernel has the bytes in flight it needs with four wavefronts.  SLM_XTR_WGS_PER_CU=2 brings the old grid back.
+static int xtr_max_row_blocks(int cus, int64_t ld) {  // (sizes the partial buffer: the larger of the two grids)
   const int xb = (int)((ld + XTR_CB - 1) / XTR_CB);
   return std::max(1, 2 * cus / xb);
 }
 // sets a.xrows; returns the number of row blocks (= blocks of `partial` to reduce)
 static int launch_xtr(int cus, SplitArgs& a, hipStream_t s) {
   const int xb = (int)((a.ld + XTR_CB - 1) / XTR_CB);
-  const int64_t want = xtr_max_row_blocks(cus, a.ld);
+  double per_cu = 1.0;
+  if (const char* e = getenv("SLM_XTR_WGS_PER_CU")) {  // (A/B runs: workgroups per CU, up to 2)
+    const double f = atof(e);
+    if (f > 0.0 && f <= 2.0) per_cu = f;
+  }
+  const int64_t want = std::max<int64_t>(1, (int64_t)(xtr_max_row_blocks(cus, a.ld) * per_cu / 2.0));
   int64_t rows = (a.n + want - 1) / want;
   rows = (rows + 7) / 8 * 8;
   const int yb = (int)((a.n + rows - 1) / rows);  // <= want
