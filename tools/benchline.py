@@ -6,7 +6,7 @@ import json
 import sys
 
 for path in sys.argv[1:]:
-    d = json.loads(open(path).read().strip().splitlines()[-1])
+    d = json.loads([ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1])  # (rocprofv3 logs after it)
     r = d["roofline"]
     passes = d["config"]["grad_evals_per_path"]
     print(f"{path}: {d['value']:.0f} {d['unit']}, {d['ms_per_step']:.3f} ms/path, kernel {r['avg_kernel_ms']:.4f} ms "

@@ -311,6 +311,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   for (int nblk : {50, 25, 100}) {
+    run<1, 1>(X, ld, n, p2, nblk, false);
     run<1, 2>(X, ld, n, p2, nblk, false);
     run<2, 2>(X, ld, n, p2, nblk, false);
     run<3, 1>(X, ld, n, p2, nblk, false);
