@@ -334,16 +334,51 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
     return;
   }
 
+  // This thread's items (a contiguous run of `per`), read ONCE: score, feature count and whether the item sits in
+  // W already.  Up to eight items per thread (p <= 8192) they live in registers -- the counting sweeps below (up to
+  // fifteen of them when a threshold is fitted) and the position pass at the end then touch no memory; item by item
+  // every sweep was a chain of dependent round trips (29 us for this kernel on the headline path).
+  const int per = (nitems + WS_THREADS - 1) / WS_THREADS;
+  const int i0 = tid * per, i1 = min(i0 + per, nitems);
+  const bool cached = per <= 8;
+  double c_sc[8];
+  int c_sz[8];
+  bool c_inw[8];
+  if (cached) {
+    int first[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int it = (i0 + u < i1) ? i0 + u : 0;
+      c_sc[u] = (i0 + u < i1) ? w.score[it] : -1.0;  // (below every threshold: an item that is not there is never taken)
+      first[u] = singleton ? it : a.gstart[it];
+      c_sz[u] = singleton ? 1 : a.gstart[it + 1] - first[u];
+    }
+    if (!singleton) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) first[u] = a.order[first[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c_inw[u] = w.pos[first[u]] >= 0;
+  }
+
   // feature count of the items with score >= thr (optionally only those not yet in W), and the
   // largest finite score
   auto count_at = [&](double thr, bool only_new, double* n_sel, double* smax) {
     double v[2] = {0.0, 0.0};
-    for (int it = tid; it < nitems; it += WS_THREADS) {
-      const double sc = w.score[it];
-      const int first = singleton ? it : a.order[a.gstart[it]];
-      const int size = singleton ? 1 : a.gstart[it + 1] - a.gstart[it];
-      if (sc >= thr && !(only_new && w.pos[first] >= 0)) v[0] += (double)size;
-      if (sc < inf) v[1] = fmax(v[1], sc);
+    if (cached) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (c_sc[u] >= thr && !(only_new && c_inw[u])) v[0] += (double)c_sz[u];
+        if (c_sc[u] < inf) v[1] = fmax(v[1], c_sc[u]);
+      }
+    } else {
+      for (int it = tid; it < nitems; it += WS_THREADS) {
+        const double sc = w.score[it];
+        const int first = singleton ? it : a.order[a.gstart[it]];
+        const int size = singleton ? 1 : a.gstart[it + 1] - a.gstart[it];
+        if (sc >= thr && !(only_new && w.pos[first] >= 0)) v[0] += (double)size;
+        if (sc < inf) v[1] = fmax(v[1], sc);
+      }
     }
     double s[1] = {v[0]};
     block_sum<1>(s, red);
@@ -439,21 +474,27 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
   __syncthreads();
 
   // ---- positions: items in index order, members of a group contiguous -----------------------------
-  const int per = (nitems + WS_THREADS - 1) / WS_THREADS;
-  const int i0 = tid * per, i1 = min(i0 + per, nitems);
-  auto chosen = [&](int it) {
-    if (!(w.score[it] >= thr)) return false;
-    return !(append && w.pos[singleton ? it : a.order[a.gstart[it]]] >= 0);
-  };
+  // which of this thread's items are taken (decided before pos[] is written below), and their feature count
+  unsigned long long pick = 0ull;
   int mine = 0;
-  for (int it = i0; it < i1; ++it)
-    if (chosen(it)) mine += singleton ? 1 : a.gstart[it + 1] - a.gstart[it];
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (c_sc[u] >= thr && !(append && c_inw[u])) {
+        pick |= 1ull << u;
+        mine += c_sz[u];
+      }
+    }
+  } else {
+    for (int it = i0; it < i1 && it - i0 < 64; ++it) {
+      if (!(w.score[it] >= thr)) continue;
+      if (append && w.pos[singleton ? it : a.order[a.gstart[it]]] >= 0) continue;
+      pick |= 1ull << (it - i0);
+      mine += singleton ? 1 : a.gstart[it + 1] - a.gstart[it];
+    }
+  }
   int total = 0;
   int at = (append ? k_old : 0) + block_excl_scan(mine, wave_tot, &total);
-  // (chosen() reads pos[], the loop below writes it: decide first, then write)
-  unsigned long long pick = 0ull;
-  for (int it = i0; it < i1 && it - i0 < 64; ++it)
-    if (chosen(it)) pick |= 1ull << (it - i0);
   __syncthreads();
   for (int it = i0; it < i1 && it - i0 < 64; ++it) {
     if (!((pick >> (it - i0)) & 1ull)) continue;
