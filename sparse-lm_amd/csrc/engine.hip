@@ -1837,7 +1837,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   };
   int ws_comm_rc = 0;  // first RCCL error of the per-pass Gram all-reduce (checked after each chunk)
   // everything that follows the gradient of one pass
-  auto enqueue_after_gradient = [&]() {
+  // (in two halves: behind the pass a solve is expected to end with, the second half waits for the verdict)
+  auto enqueue_tail = [&]() {
     launch_tail(ta, s);
     if (shared_path && !interleave) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
     if (eng->sharded()) {  // the ranks agree on "finished" before anything acts on it
@@ -1845,6 +1846,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       if (ws_comm_rc == 0) ws_comm_rc = all_reduce_sum(eng, ds->stop_words, STOP_WORDS);
       hipLaunchKernelGGL(stop_apply_kernel, dim3(1), dim3(64), 0, s, ta.gdone, ds->stop_words);
     }
+  };
+  auto enqueue_refinement = [&]() {
     if (use_ws) {
       {
         const int bs = ds->singleton ? 256 : 64;
@@ -1933,6 +1936,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     return SLM_OK;
   };
   int final_slot = 0;          // the snapshot in which the host saw `done`
+  bool deferred = false;       // the refinement behind the last queued pass has not been queued yet
   while (!done) {
     {
       const int this_chunk = expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(chunk, expected - enq) : 1);
@@ -1949,8 +1953,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
           e1 = ds->prof[2 * slot_id + 1];
         }
         SLM_TRY(enqueue_pass_gradient(e0, e1));
-        enqueue_after_gradient();
+        enqueue_tail();
         ++enq;
+        // behind the pass the solve is expected to end with, the six launches of the refinement would only find
+        // out that there is nothing left to refine (30 us): they follow once the snapshot says otherwise
+        deferred = expected > 0 && enq == expected && !eng->sharded();
+        if (!deferred) enqueue_refinement();
       }
       SLM_TRY(check_launch());
       if (ws_comm_rc != 0) return ws_comm_rc;  // (all_reduce_sum has set the message)
@@ -1984,6 +1992,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       if (ds->hctl[slot].c.g.done) {
         done = true;
         final_slot = slot;
+      } else if (deferred) {  // the solve goes on: what was held back, then the next pass
+        enqueue_refinement();
+        deferred = false;
       }
     } else if (pending[other]) {
       HIP_TRY(hipEventSynchronize(ds->ev[other]));
