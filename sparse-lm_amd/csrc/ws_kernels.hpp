@@ -87,6 +87,9 @@ struct WsCtl {
   // (SLM_TRACE=2 prints them): matvec + free set, assembly, factorisation, solve, trial points, mu
   unsigned long long nt_ticks[SLM_MAX_LANES][6];
   int32_t nt_factors[SLM_MAX_LANES];
+  // ... and in the parts of lane 0's refinements: set-up, lambda_max of a new Gram, start value, the iteration,
+  // acceptance + write-back (SLM_TRACE=2)
+  unsigned long long solve_ticks[5];
   int32_t last_point[SLM_MAX_LANES];  // path point of each lane's last refinement ...
   int32_t repeats[SLM_MAX_LANES];     // ... and how many times in a row it was that point WITH the same columns
   int32_t last_cols[SLM_MAX_LANES];   // columns W held at each lane's last refinement (growth resets the count)
@@ -830,6 +833,14 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   const int reps = (ws->last_point[lane_id] == point_now && ws->last_cols[lane_id] == ws->Kreal) ? ws->repeats[lane_id] : 0;
   if (reps >= WS_MAX_REPEATS) return;
 
+  unsigned long long tk_s = wall_clock64();
+  auto mark = [&](int slot) {
+    if (tid == 0 && lane_id == 0) {
+      const unsigned long long now = wall_clock64();
+      ws->solve_ticks[slot] += now - tk_s;
+      tk_s = now;
+    }
+  };
   const slm_path_point pt = a.pts[ctl->point];
   const int mode = ctl->mode;
   const double tol = ctl->tol;
@@ -975,6 +986,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     return pv;
   };
 
+  mark(0);
   // ---- lambda_max of this Gram (once per selection): power iteration from a fixed start ---------
   double Lw = ws->Lw[set];
   if (!(Lw > 0.0)) {
@@ -1464,6 +1476,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
    }
   };
 
+  mark(1);
   // ---- FISTA on the model ------------------------------------------------------------------------
   double L = Lw;
   double x = x_start, v = x_start, t = 1.0;
@@ -1478,6 +1491,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     block_sum<2>(s, red);
     m_start = s[0] + s[1];
   }
+  mark(2);
   bool ok = true;
   int n_inner = 0;
   // smallest Rayleigh quotient <dv, G dv> / <dv, dv> along the moves of the iteration: an upper estimate
@@ -1592,6 +1606,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
       }
     }
   }
+  mark(3);
   if (!ok) return;
   // accept only if the model says the refined point is no worse than the start
   {
@@ -1633,6 +1648,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     // (halved: both are estimates from above); 0 = unknown.
     ctl->mu = mu_face > 0.0 ? 0.5 * mu_face : (rq_n >= 3 ? 0.5 * rq_min : 0.0);
   }
+  mark(4);
 }
 
 template <bool GROUPED>
