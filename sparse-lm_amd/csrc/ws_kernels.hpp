@@ -1618,12 +1618,25 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     const double m_end = s[0] + s[1];
     if (s[2] > 0.0 || !(m_end <= m_start)) return;
   }
-  // the refined point: model minimiser on W, the expansion point elsewhere
-  for (int f = tid; f < p; f += WS_THREADS) {
-    if (w.pos[f] < 0) {
-      const double zo = a.zprev[f];
-      a.z[f] = zo;
-      if (mode == 0) a.beta[f] = zo;
+  // the refined point: model minimiser on W, the expansion point elsewhere (eight features per round: their loads
+  // go out together -- one feature at a time every load waited for the one before it, 11 us per call)
+  for (int f0 = tid; f0 < p; f0 += 8 * WS_THREADS) {
+    int ps[8];
+    double zo[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = f0 + u * WS_THREADS;
+      const int ff = f < p ? f : 0;
+      ps[u] = f < p ? w.pos[ff] : 0;
+      zo[u] = a.zprev[ff];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int f = f0 + u * WS_THREADS;
+      if (f < p && ps[u] < 0) {
+        a.z[f] = zo[u];
+        if (mode == 0) a.beta[f] = zo[u];
+      }
     }
   }
   if (mine) {
@@ -1666,8 +1679,20 @@ __global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs
   double out[1] = {0.0};
   if (w_ok) {
     const double* z = a.z + (int64_t)lane_id * a.ld;
-    for (int j = threadIdx.x; j < a.p; j += WS_THREADS)
-      if (w.pos[j] < 0 && z[j] != 0.0) out[0] += 1.0;
+    for (int j0 = threadIdx.x; j0 < a.p; j0 += 8 * WS_THREADS) {
+      int ps[8];
+      double zj[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u * WS_THREADS;
+        const int jj = j < a.p ? j : 0;
+        ps[u] = j < a.p ? w.pos[jj] : 0;
+        zj[u] = z[jj];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (ps[u] < 0 && zj[u] != 0.0) out[0] += 1.0;
+    }
   }
   block_sum<1>(out, red);
   if (threadIdx.x == 0) ctl->zsup = (w_ok && out[0] == 0.0) ? 1 : 0;
