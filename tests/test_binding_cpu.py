@@ -1,0 +1,60 @@
+"""Host-side pieces of the ctypes binding that need no device."""
+
+import numpy as np
+
+from sparselm_amd import _engine
+
+
+def _secant_factors_by_loop(pts):
+    """The definition, point by point: gamma_k = (s_k - s_{k-1}) / (s_{k-1} - s_{k-2}) for points that are all
+    multiples s_k of one penalty direction; zeros otherwise, and where the quotient is not usable."""
+    pts = np.asarray(pts, dtype=np.float64).reshape(-1, 3)
+    K = pts.shape[0]
+    gam = np.zeros(K)
+    if K < 3:
+        return gam
+    ref = pts[np.argmax(np.abs(pts).sum(axis=1))]
+    nrm = float(ref @ ref)
+    if nrm <= 0.0:
+        return gam
+    s = pts @ ref / nrm
+    if not np.allclose(np.outer(s, ref), pts, rtol=1e-12, atol=1e-300):
+        return gam
+    for k in range(2, K):
+        den = s[k - 1] - s[k - 2]
+        if den != 0.0:
+            g = (s[k] - s[k - 1]) / den
+            if np.isfinite(g) and abs(g) <= 10.0:
+                gam[k] = g
+    return gam
+
+
+def test_secant_factors_match_their_definition():
+    rng = np.random.default_rng(0)
+    al = np.geomspace(1.0, 1e-3, 50)
+    cases = [
+        np.c_[al, 0 * al, 0 * al],                          # a Lasso path
+        np.c_[0.3 * al, 0.7 * al, 0 * al],                  # a sparse-group path: one direction
+        np.c_[0 * al, al, 0.5 * al][:7],
+        rng.uniform(size=(10, 3)),                          # no common direction: no prediction
+        np.array([[1.0, 0, 0], [1.0, 0, 0], [0.5, 0, 0], [0.5, 0, 0], [0.1, 0, 0]]),  # repeated points
+        np.array([[1.0, 0, 0], [0.5, 0, 0]]),               # too short
+        np.zeros((5, 3)),
+        np.array([[1.0, 0, 0], [0.999999, 0, 0], [1e-9, 0, 0], [0, 0, 0]]),          # quotient beyond the cap
+    ]
+    for pts in cases:
+        want = _secant_factors_by_loop(pts)
+        np.testing.assert_array_equal(_engine.path_extrapolation(pts), want)
+        np.testing.assert_array_equal(_engine.path_extrapolation(pts), want)  # (second call: from the cache)
+    # the cached array is not handed out itself
+    a = _engine.path_extrapolation(cases[0])
+    a[:] = 7.0
+    np.testing.assert_array_equal(_engine.path_extrapolation(cases[0]), _secant_factors_by_loop(cases[0]))
+
+
+def test_points_block_layout():
+    pts = np.arange(12, dtype=np.float64).reshape(4, 3)
+    blk = _engine._points_block(pts, np.array([0.0, 0.0, 0.5, 0.25]))
+    assert blk.shape == (4, 4) and blk.flags.c_contiguous
+    np.testing.assert_array_equal(blk[:, :3], pts)
+    np.testing.assert_array_equal(blk[:, 3], [0.0, 0.0, 0.5, 0.25])
