@@ -26,7 +26,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                   2500 fits) with its 50 (fold, l1_ratio) units dealt to the ranks (strong scaling);
                   "rowshard": BASELINE config 5's shape (AdaptiveGroupLasso, 3 re-weighting solves,
                   125 000 rows x 10 000 columns PER RANK) through the engine's RCCL communicator over all
-                  ranks (weak scaling in rows; one all-reduce of the gradients per pass).
+                  ranks (weak scaling in rows; one all-reduce of the gradients per pass);
+                  "concurrent_paths": the headline path on three engines of one GPU at once (per rank).
                   `--no-extra` skips them.
 """
 
@@ -279,6 +280,55 @@ def leg_config4_grid(eng, rank, world, n, p, reps=1):
         return {"seconds": (time.perf_counter() - t0) / reps, "passes": passes, "units": len(mine)}
     finally:
         ds.close()
+
+
+def leg_concurrent_paths(eng, device_id, rank, n, p, K, tol, lanes, streams=3, steps=10):
+    """The headline path on `streams` engines of ONE GPU at once (each with its own dataset of the same law and its
+    own host thread): the launches between the passes of one path run beside the passes of the other.  Not the
+    headline -- that is one path per GPU per step -- but what a grid search with more units than GPUs can do."""
+    from sparselm_amd import _engine
+
+    engines = [eng] + [_engine.Engine(device_id) for _ in range(streams - 1)]
+    coef = make_coef(p, 50, seed=0)
+    sets = []
+    try:
+        for i, e in enumerate(engines):
+            ds = e.synthetic_dataset(n, p, seed=5000 + 10 * rank + i, coef=coef, noise_sd=10.0)
+            g0, _ = ds.gradient(None)
+            amax = float(np.max(np.abs(g0)))
+            pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-3 * amax, K)]
+            ds.solve_path(pts, tol=tol, flags=_engine.FLAG_FRESH_L, lanes=lanes)  # warm (column-major copy, buffers)
+            sets.append((ds, pts))
+        ok = [True] * len(sets)
+
+        def work(i):
+            ds, pts = sets[i]
+            for _ in range(steps):
+                ok[i] = ok[i] and ds.solve_path(pts, tol=tol, flags=_engine.FLAG_FRESH_L, lanes=lanes).converged
+
+        def run(which):
+            threads = [threading.Thread(target=work, args=(i,)) for i in which]
+            for e in engines:
+                e.synchronize()
+            t0 = time.perf_counter()
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            for e in engines:
+                e.synchronize()
+            return time.perf_counter() - t0
+
+        alone = run([0])
+        together = run(list(range(len(sets))))
+        return {"streams": len(sets), "converged": all(ok), "fits_per_s_one_stream": steps * K / alone,
+                "fits_per_s_all_streams": len(sets) * steps * K / together, "ms_per_path_one_stream": 1e3 * alone / steps,
+                "ms_per_path_pair": 1e3 * together / steps}
+    finally:
+        for ds, _ in sets:
+            ds.close()
+        for e in engines[1:]:
+            e.close()
 
 
 def leg_rowshard(eng, rank, world, n_rank, p, reps=2):
@@ -548,6 +598,7 @@ def main():
 
         with Watchdog(args.extra_timeout, expire):
             for name, fn in (("config4_grid", lambda: leg_config4_grid(eng, rank, world, n, p)),
+                             ("concurrent_paths", lambda: leg_concurrent_paths(eng, device_id, rank, n, p, K, args.tol, args.lanes)),
                              ("rowshard", lambda: leg_rowshard(eng, rank, world, args.rowshard_rows, args.rowshard_cols))):
                 try:
                     with StdoutToStderr():
@@ -569,6 +620,16 @@ def main():
                         "fits_per_s": 2500.0 / max(secs), "seconds_per_grid": max(secs), "seconds_per_rank": secs,
                         "units_per_rank": [q["units"] for q in parts], "passes_per_rank": [q["passes"] for q in parts],
                         "imbalance_max_over_mean": max(secs) / (sum(secs) / len(secs)),
+                    }
+                elif name == "concurrent_paths":
+                    legs[name] = {
+                        "what": "the headline path on three engines (streams) of ONE GPU at once, a dataset and a host thread "
+                        "each: the launches between the passes of one path run beside the passes of the others; per rank",
+                        "streams": parts[0]["streams"],
+                        "fits_per_s_one_stream": [q["fits_per_s_one_stream"] for q in parts],
+                        "fits_per_s_all_streams": [q["fits_per_s_all_streams"] for q in parts],
+                        "gain": [q["fits_per_s_all_streams"] / q["fits_per_s_one_stream"] for q in parts],
+                        "converged": all(q["converged"] for q in parts),
                     }
                 else:
                     secs = [q["seconds_per_fit"] for q in parts]
