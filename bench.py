@@ -225,10 +225,12 @@ class Watchdog:
         self._t.cancel()
 
 
-def leg_config4_grid(eng, rank, world, n, p, reps=1):
+def leg_config4_grid(eng, rank, world, n, p, device_id=0, streams=3):
     """BASELINE config 4 on the grid mode: 5 folds x 10 l1_ratio, each a 50-alpha SparseGroupLasso path; the
     50 (fold, l1_ratio) units are dealt to the ranks (LPT by cost), sixteen lanes per call.  Every rank
-    generates the SAME (X, y) (same seed): X replicated per GPU, no data-path collective."""
+    generates the SAME (X, y) (same seed): X replicated per GPU, no data-path collective.  Timed twice: the rank's
+    calls one after the other on one engine, and -- when the rank has more than one call to make -- dealt to
+    `streams` standing engines (HIP streams) of its GPU, a dataset copy and a host thread each."""
     from sparselm_amd import _engine
     from sparselm_amd import distributed as D
 
@@ -239,6 +241,7 @@ def leg_config4_grid(eng, rank, world, n, p, reps=1):
     for g in rng.choice(G, 25, replace=False):
         coef[groups == g] = 100.0 * rng.uniform(size=10)
     ds = eng.synthetic_dataset(n, p, seed=11, coef=coef, noise_sd=10.0)
+    copies = [ds]
     try:
         ds.set_groups(groups, G)
         g0, _ = ds.gradient(None)
@@ -251,34 +254,72 @@ def leg_config4_grid(eng, rank, world, n, p, reps=1):
         # cost model for the deal: every unit is a 50-point path; the l1-heavy ones end with more columns
         mine = [units[i] for i in D.shard_units(len(units), rank, world, costs=[1.0 + 0.3 * r for _, r in units])]
         lanes = _engine.MAX_LANES
+        batches = [mine[k0 : k0 + lanes] for k0 in range(0, len(mine), lanes)]
 
-        def run():
-            passes = 0
-            for k0 in range(0, len(mine), lanes):
-                batch = mine[k0 : k0 + lanes]
-                split = max(1, lanes // len(batch))  # spare lane slots: cut each path into contiguous ranges
-                specs = []
-                for f, r in batch:
-                    amax = min(bmax / (1 - r), amax1 / r)
-                    al = np.geomspace(amax, 1e-3 * amax, 50)
-                    pts = np.c_[r * al, (1 - r) * al, 0 * al]
-                    for part in np.array_split(np.arange(50), split):
-                        specs.append(dict(points=pts[part], row_weight=masks[f], n_eff=int(masks[f].sum())))
-                out = ds.solve_lanes(specs)
-                passes += out[0].grad_launches
-                if not all(o.converged for o in out):
-                    raise RuntimeError("config 4: a path did not converge")
-            return passes
+        def run_batch(d, batch):
+            split = max(1, lanes // len(batch))  # spare lane slots: cut each path into contiguous ranges
+            specs = []
+            for f, r in batch:
+                amax = min(bmax / (1 - r), amax1 / r)
+                al = np.geomspace(amax, 1e-3 * amax, 50)
+                pts = np.c_[r * al, (1 - r) * al, 0 * al]
+                for part in np.array_split(np.arange(50), split):
+                    specs.append(dict(points=pts[part], row_weight=masks[f], n_eff=int(masks[f].sum())))
+            out = d.solve_lanes(specs)
+            if not all(o.converged for o in out):
+                raise RuntimeError("config 4: a path did not converge")
+            return out[0].grad_launches
 
-        run()  # warm (column-major copy, buffers)
-        eng.synchronize()
-        t0 = time.perf_counter()
-        passes = 0
-        for _ in range(reps):
-            passes = run()
-        eng.synchronize()
-        return {"seconds": (time.perf_counter() - t0) / reps, "passes": passes, "units": len(mine)}
+        def run(n_streams):
+            todo, lock, passes, errors = list(range(len(batches))), threading.Lock(), [0], []
+
+            def work(i):
+                try:
+                    while True:
+                        with lock:
+                            if not todo or errors:
+                                return
+                            b = todo.pop(0)
+                        k = run_batch(copies[i], batches[b])
+                        with lock:
+                            passes[0] += k
+                except BaseException as exc:
+                    with lock:
+                        errors.append(exc)
+
+            threads = [threading.Thread(target=work, args=(i,)) for i in range(1, n_streams)]
+            for c in copies[:n_streams]:
+                c.engine.synchronize()
+            t0 = time.perf_counter()
+            for t in threads:
+                t.start()
+            work(0)
+            for t in threads:
+                t.join()
+            for c in copies[:n_streams]:
+                c.engine.synchronize()
+            if errors:
+                raise errors[0]
+            return time.perf_counter() - t0, passes[0]
+
+        run(1)  # warm (column-major copy, buffers)
+        seconds, passes = run(1)
+        out = {"seconds": seconds, "passes": passes, "units": len(mine), "calls": len(batches)}
+        n_streams = min(streams, len(batches))
+        if n_streams > 1:
+            for _ in range(n_streams - 1):
+                c = ds.clone()
+                c.set_groups(groups, G)
+                copies.append(c)
+            run(n_streams)  # warm the copies
+            out["seconds_streams"], _ = run(n_streams)
+            out["streams"] = n_streams
+        return out
     finally:
+        for c in copies[1:]:
+            e = c.engine
+            c.close()
+            e.close()
         ds.close()
 
 
@@ -597,7 +638,7 @@ def main():
             os._exit(0)
 
         with Watchdog(args.extra_timeout, expire):
-            for name, fn in (("config4_grid", lambda: leg_config4_grid(eng, rank, world, n, p)),
+            for name, fn in (("config4_grid", lambda: leg_config4_grid(eng, rank, world, n, p, device_id)),
                              ("concurrent_paths", lambda: leg_concurrent_paths(eng, device_id, rank, n, p, K, args.tol, args.lanes)),
                              ("rowshard", lambda: leg_rowshard(eng, rank, world, args.rowshard_rows, args.rowshard_cols))):
                 try:
@@ -616,8 +657,12 @@ def main():
                     secs = [q["seconds"] for q in parts]
                     legs[name] = {
                         "what": "SparseGroupLasso 5 folds x 10 l1_ratio x 50 alpha = 2500 fits at n=100k p=5k, the 50 "
-                        "(fold, l1_ratio) units dealt to the ranks (LPT), 16 lanes per call; strong scaling",
+                        "(fold, l1_ratio) units dealt to the ranks (LPT), 16 lanes per call; strong scaling; *_streams: a "
+                        "rank's calls dealt to standing engines (HIP streams) of its GPU where it has more than one to make",
                         "fits_per_s": 2500.0 / max(secs), "seconds_per_grid": max(secs), "seconds_per_rank": secs,
+                        "seconds_per_grid_streams": (max(q["seconds_streams"] for q in parts)
+                                                     if all("seconds_streams" in q for q in parts) else None),
+                        "streams": parts[0].get("streams", 1), "calls_per_rank": [q["calls"] for q in parts],
                         "units_per_rank": [q["units"] for q in parts], "passes_per_rank": [q["passes"] for q in parts],
                         "imbalance_max_over_mean": max(secs) / (sum(secs) / len(secs)),
                     }

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 5
+#define SLM_ABI_VERSION 6
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -96,6 +96,13 @@ int slm_dataset_create_device(slm_engine* eng, const double* dX, int64_t n, int6
 int slm_dataset_create_synthetic(slm_engine* eng, int64_t n, int64_t p, uint64_t seed,
                                  int64_t row_offset, const double* coef, double noise_sd,
                                  slm_dataset** out);
+/*
+ * A copy of (X, y, row weights) on another engine of the SAME device, device to device: solves on different
+ * engines run side by side (the launches between the passes of one beside the passes of the other), which a grid
+ * search with more (fold, parameter) units than GPUs uses (sparselm_amd.model_selection.GridSearchCV(streams=...);
+ * the reference's counterpart is n_jobs > 1 of model_selection.py:273).  Group structure is set again by the caller.
+ */
+int slm_dataset_clone(slm_dataset* src, slm_engine* eng, slm_dataset** out);
 int slm_dataset_destroy(slm_dataset* ds);
 int slm_dataset_shape(slm_dataset* ds, int64_t* n, int64_t* p, int64_t* ld);
 /* Copy the engine's X (dense n x p, C-order) and/or y back to the host (either may be NULL). */

@@ -751,6 +751,23 @@ extern "C" int slm_dataset_create_device(slm_engine* eng, const double* dX, int6
   return SLM_OK;
 }
 
+// A copy of (X, y, row weights) on another engine of the same device: a second stream's own dataset without a
+// second trip over PCIe.  Group structure is not carried over (the caller sets it again).
+extern "C" int slm_dataset_clone(slm_dataset* src, slm_engine* eng, slm_dataset** out) {
+  if (!src || !eng || !out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  *out = nullptr;
+  if (eng->device != src->eng->device)
+    return fail(SLM_ERR_BAD_ARG, "the copy has to live on the device of the original (%d), not on %d", src->eng->device,
+                eng->device);
+  HIP_TRY(hipSetDevice(src->eng->device));
+  HIP_TRY(hipStreamSynchronize(src->eng->stream));
+  slm_dataset* ds = nullptr;
+  SLM_TRY(slm_dataset_create_device(eng, src->X, src->n, src->p, src->ld, src->y, src->rw, &ds));
+  ds->n_global = src->n_global;
+  *out = ds;
+  return SLM_OK;
+}
+
 extern "C" int slm_dataset_create_synthetic(slm_engine* eng, int64_t n, int64_t p, uint64_t seed,
                                             int64_t row_offset, const double* coef, double noise_sd,
                                             slm_dataset** out) {

@@ -41,7 +41,7 @@ FLAG_WORKING_SET = 32  # force the Gram-assisted refinement even for small X
 FLAG_NO_WORKING_SET = 64
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 5  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 6  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -61,6 +61,7 @@ ABI_SYMBOLS = (
     "slm_dataset_center",
     "slm_dataset_set_row_weights",
     "slm_dataset_set_targets",
+    "slm_dataset_clone",
     "slm_dataset_set_groups",
     "slm_dataset_lipschitz",
     "slm_dataset_max_lanes",
@@ -225,6 +226,7 @@ def load_library():
             "slm_dataset_center": [vp, vp, P(dbl)],
             "slm_dataset_set_row_weights": [vp, vp],
             "slm_dataset_set_targets": [vp, vp],
+            "slm_dataset_clone": [vp, vp, P(vp)],
             "slm_dataset_set_groups": [vp, vp, i32],
             "slm_dataset_lipschitz": [vp, P(dbl)],
             "slm_dataset_max_lanes": [vp, C.c_uint32, P(i32)],
@@ -396,8 +398,13 @@ def _path_result(betas, gn, infos, K, stats) -> PathResult:
     )
 
 
+_live_engines: "weakref.WeakSet[Engine]" = weakref.WeakSet()
+
+
 class Engine:
-    """One engine per (process, device): owns a HIP stream and, optionally, an RCCL communicator."""
+    """An engine owns a HIP stream and, optionally, an RCCL communicator.  ``get_engine`` hands out one per
+    (process, device); further ones on the same device (``Engine(device_id)``) are further streams: solves on
+    different engines run side by side -- the launches between the passes of one beside the passes of the other."""
 
     def __init__(self, device_id: int = 0):
         self._lib = load_library()
@@ -406,6 +413,8 @@ class Engine:
         self._h = h
         self.device_id = int(device_id)
         self._datasets = weakref.WeakSet()  # closed before the engine goes (their handles point at it)
+        self._pid = os.getpid()
+        _live_engines.add(self)  # (every engine, not only the per-device defaults, is released in order at exit)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -569,6 +578,14 @@ class Dataset:
     def set_row_weights(self, row_weight):
         rw = None if row_weight is None else _f64(row_weight, "row_weight", (self.n,))
         _check(self._lib.slm_dataset_set_row_weights(self._h, _ptr(rw)))
+
+    def clone(self, engine: "Engine | None" = None) -> "Dataset":
+        """A copy of this dataset (X, y, row weights; device to device) on ``engine`` -- default: a new engine
+        on the same device, i.e. a further stream.  Group structure is set again by the caller."""
+        eng = Engine(self.engine.device_id) if engine is None else engine
+        h = C.c_void_p()
+        _check(self._lib.slm_dataset_clone(self._h, eng._h, C.byref(h)))
+        return Dataset(eng, h, self.n, self.p)
 
     def set_targets(self, y):
         """Replace y on the device (X and what was derived from it stay)."""
@@ -764,10 +781,10 @@ _engines_lock = threading.Lock()
 
 def _close_engines():
     with _engines_lock:
-        engines, pid = list(_engines.items()), os.getpid()
+        pid = os.getpid()
         _engines.clear()
-    for (owner, _), eng in engines:
-        if owner == pid:  # (a forked child never touches its parent's handles)
+    for eng in list(_live_engines):
+        if eng._pid == pid:  # (a forked child never touches its parent's handles)
             eng.close()
 
 

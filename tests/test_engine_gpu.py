@@ -361,6 +361,44 @@ def test_targets_replaced_in_place_give_the_fit_of_a_fresh_dataset(eng, golden):
             ds.set_targets(y[:-1])
 
 
+def test_clone_lives_on_its_own_engine_and_solves_side_by_side(eng, golden):
+    """slm_dataset_clone: a device-to-device copy on a further engine (stream) of the device -- same gradient and
+    solution as the original, independent of it afterwards (its own targets), and two host threads may drive the
+    two at once."""
+    import threading
+
+    X, y = golden["l1_X"], golden["l1_y"]
+    w = np.random.default_rng(5).uniform(0.5, 1.5, len(y))
+    alpha = 0.2 * np.max(np.abs(X.T @ y)) / len(y)
+    with eng.dataset(X, y, row_weight=w) as ds:
+        cp = ds.clone()
+        try:
+            assert cp.engine is not ds.engine and cp.engine.device_id == ds.engine.device_id
+            g0, l0 = ds.gradient(None)
+            g1, l1 = cp.gradient(None)
+            npt.assert_array_equal(g0, g1)
+            assert l0 == l1
+            out = {}
+
+            def solve(name, d):
+                out[name] = d.solve_path([(alpha, 0.0, 0.0)] * 1 + [(0.5 * alpha, 0.0, 0.0)], tol=1e-12)
+
+            threads = [threading.Thread(target=solve, args=(k, d)) for k, d in (("a", ds), ("b", cp))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            assert out["a"].converged and out["b"].converged
+            npt.assert_array_equal(out["a"].betas, out["b"].betas)
+            cp.set_targets(2.0 * y)
+            npt.assert_array_equal(ds.download(want_X=False)[1], y)
+            npt.assert_array_equal(cp.download(want_X=False)[1], 2.0 * y)
+        finally:
+            e2 = cp.engine
+            cp.close()
+            e2.close()
+
+
 def test_non_finite_data_raises(eng):
     X = np.ones((10, 3))
     X[2, 1] = np.inf

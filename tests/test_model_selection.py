@@ -93,6 +93,27 @@ def test_fast_path_matches_generic_path(golden, scoring):
 
 
 @pytest.mark.gpu
+def test_fast_path_batches_dealt_to_several_streams_give_the_same_search(golden):
+    """streams > 1: the batches of the device path run on further engines of the device, each on its own copy of
+    the dataset and from its own host thread -- the same cells, the same numbers."""
+    X, y, groups = golden["grp_X"], golden["grp_y"], golden["grp_groups"]
+    cv = KFold(5, shuffle=True, random_state=0)
+    grid = {"alpha": list(np.geomspace(10, 0.1, 5)), "l1_ratio": [0.1, 0.5, 0.9]}
+    est = SparseGroupLasso(groups=groups, fit_intercept=True, solver_options={"tol": 1e-11})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        one = GridSearchCV(est, grid, cv=cv, lanes=4, streams=1).fit(X, y)
+        three = GridSearchCV(est, grid, cv=cv, lanes=4, streams=3).fit(X, y)
+        ada1 = GridSearchCV(AdaptiveLasso(), {"alpha": [0.5, 1.0, 2.0]}, cv=cv, lanes=4, streams=1).fit(X, y)
+        ada2 = GridSearchCV(AdaptiveLasso(), {"alpha": [0.5, 1.0, 2.0]}, cv=cv, lanes=4, streams=2).fit(X, y)
+    for a, b in ((one, three), (ada1, ada2)):
+        for f in range(5):
+            np.testing.assert_array_equal(a.cv_results_[f"split{f}_test_score"], b.cv_results_[f"split{f}_test_score"])
+        assert a.best_params_ == b.best_params_
+        np.testing.assert_array_equal(a.best_estimator_.coef_, b.best_estimator_.coef_)
+
+
+@pytest.mark.gpu
 def test_fast_path_one_std_and_fallbacks(golden):
     X, y = golden["l1_X"], golden["l1_y"]
     grid = {"alpha": list(np.logspace(-1, 1.5, 8))}

@@ -24,10 +24,10 @@ bmax = float(np.max(np.sqrt(np.bincount(groups, weights=c * c, minlength=G))))
 grid = {"alpha": list(np.geomspace(bmax, 1e-3 * bmax, 50)), "l1_ratio": list(np.linspace(0.05, 0.95, 10))}
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    for rep in range(2):
+    for rep, streams in enumerate((1, 1, 2, 3)):
         t0 = time.perf_counter()
-        gs = GridSearchCV(SparseGroupLasso(groups=groups), grid, cv=KFold(5, shuffle=True, random_state=0)).fit(X, y)
+        gs = GridSearchCV(SparseGroupLasso(groups=groups), grid, cv=KFold(5, shuffle=True, random_state=0), streams=streams).fit(X, y)
         dt = time.perf_counter() - t0
-        print(json.dumps({"rep": rep, "seconds": round(dt, 3), "fits": 2500, "fits_per_s": round(2500 / dt, 1),
+        print(json.dumps({"rep": rep, "streams": streams, "seconds": round(dt, 3), "search_seconds": round(gs.search_time_, 3), "fits": 2500, "fits_per_s": round(2500 / dt, 1),
                           "best": {k: float(v) for k, v in gs.best_params_.items()}, "best_score": float(gs.best_score_),
                           "nnz_groups": int(np.sum(np.bincount(groups, weights=gs.best_estimator_.coef_ != 0) > 0))}), flush=True)
