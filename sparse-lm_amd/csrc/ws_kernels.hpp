@@ -550,16 +550,27 @@ __global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
   __shared__ double tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int64_t row_tiles = (w.n + 31) / 32;
+  // the four columns this thread reads in every row tile: looked up once (inside the loop every load of X waited
+  // for the index load before it)
+  int jcol[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = k0 + ty + 8 * u;
+    jcol[u] = k < K ? w.idx[k] : -1;
+  }
   for (int64_t rt = blockIdx.x; rt < row_tiles; rt += gridDim.x) {
     const int64_t i0 = rt * 32;
-    __syncthreads();  // the tile of the previous round has been written out
-    for (int kk = ty; kk < 32; kk += 8) {  // read: lanes walk rows i (contiguous in XT)
-      const int k = k0 + kk;
-      const int j = k < K ? w.idx[k] : -1;
-      const int64_t i = i0 + tx;
+    const int64_t i = i0 + tx;
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // read: lanes walk rows i (contiguous in XT)
+      const int j = jcol[u];
       // (XT == nullptr: no memory for the column-major copy -- same tile, sector-granular reads from X)
-      tile[kk][tx] = (j >= 0 && i < w.n) ? (w.XT ? w.XT[(int64_t)j * w.ldt + i] : w.X[i * w.ld + j]) : 0.0;
+      v[u] = (j >= 0 && i < w.n) ? (w.XT ? w.XT[(int64_t)j * w.ldt + i] : w.X[i * w.ld + j]) : 0.0;
     }
+    __syncthreads();  // the tile of the previous round has been written out
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tile[ty + 8 * u][tx] = v[u];
     __syncthreads();
     for (int ii = ty; ii < 32; ii += 8) {  // write: lanes walk positions k (contiguous in XW)
       const int64_t i = i0 + ii;
