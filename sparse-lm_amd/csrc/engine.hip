@@ -1682,11 +1682,21 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     h[l].flags = o.flags;
     h[l].pt_off = shared_path ? 0 : (int32_t)off;
     h[l].stride = 1;
+    h[l].tail_pt = -1;
     if (shared_path && interleave) {  // lane l takes points l, l + B, l + 2B, ... of the whole path
       h[l].point = l;
       h[l].pt_lo = l;
       h[l].n_points = (int32_t)total_points;
       h[l].stride = B;
+      // The points beyond the last full band (two of a 50-point path on sixteen lanes) go to the LAST lanes -- the
+      // ones that have just solved their neighbours -- not to the first, which would reach them from sixteen points
+      // up the path: there the features of the last decade of alpha cannot be told yet, the first verification
+      // misses and a large append follows (0.33 ms on the headline path).
+      const int64_t rem = total_points % B, n_reg = total_points - rem;
+      if (rem > 0 && n_reg >= 2 * (int64_t)B && !getenv("SLM_NO_TAIL_BAND")) {
+        h[l].n_points = (int32_t)n_reg;
+        if (l >= B - rem) h[l].tail_pt = (int32_t)(n_reg + (l - (B - rem)));
+      }
     } else if (shared_path) {  // global indices: [off, off + n_points)
       h[l].point = (int32_t)off;
       h[l].pt_lo = (int32_t)off;
@@ -1920,7 +1930,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   int64_t expected = 0;
   if (use_ws && !ws_late && o.check_every <= 0) {
     int64_t most = 0;
-    for (int l = 0; l < B; ++l) most = std::max<int64_t>(most, shared_path && interleave ? (total_points - l + B - 1) / B : lanes[l].n_points);
+    for (int l = 0; l < B; ++l) {
+      int64_t mine = lanes[l].n_points;
+      if (shared_path && interleave) mine = (h[l].n_points - l + B - 1) / B + (h[l].tail_pt >= 0 ? 1 : 0);
+      most = std::max<int64_t>(most, mine);
+    }
     expected = 1 + most;
   }
   // results: lanes whose host buffers follow each other (the ranges of one shared path do) travel in one

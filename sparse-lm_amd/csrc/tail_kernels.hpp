@@ -62,6 +62,9 @@ struct PathCtl {
   double mu;           // strong-convexity estimate on the face of the point under verification, set by the
                        // working-set model solver (0 = unknown); reset when the lane moves to the next point
   double mu_rq;        // smallest Barzilai-Borwein curvature <dz, dg> / <dz, dz> accepted on this point (0 = none yet)
+  int32_t tail_pt;     // interleaved lanes: one more point after the lane's regular walk, or -1 (the points beyond
+                       // the last full band of a shared path go to the lanes that have just solved their neighbours)
+  int32_t pad2_;
 };
 
 constexpr int BB_HIST = 5;
@@ -564,7 +567,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     extrap = a.pts[point + 1].extrap;
   // End of this lane's range: in shared-path mode the lane goes idle and steal_kernel (launched
   // right after this kernel, when every lane's state is at rest) hands it new work or retires it.
-  const bool range_end = finalize && !nonfinite && (point + stride >= n_points);
+  const int tail_pt = ctl->tail_pt;
+  const bool walk_end = point + stride >= n_points;  // (the tail point itself lies beyond n_points)
+  const bool range_end = finalize && !nonfinite && walk_end && (tail_pt < 0 || point == tail_pt);
   const bool goes_idle = range_end && a.steal;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       ctl->have_base = 0;  // the next point's objective differs: start its history afresh
       ctl->n_hist = 0;
       ctl->pen_z = 0.0;
-      ctl->point = point + stride;
+      ctl->point = (walk_end && tail_pt >= 0 && point != tail_pt) ? tail_pt : point + stride;
       if (nonfinite) {
         ctl->nonfinite = 1;
         ctl->done = 1;

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
       for (int l = 0; l < a.n_lanes; ++l) path_end = max(path_end, a.ctl[l].n_points);
       const int end = a.steal ? path_end : c->pt_off + c->n_points;
       // (interleaved lanes jump `stride` points at a time: look at least as far as the next one)
-      const int look = min(c->pt_off + c->point + max(w.lookahead, c->stride), end - 1);
+      int look = min(c->pt_off + c->point + max(w.lookahead, c->stride), end - 1);
+      if (c->tail_pt >= 0 && c->point + c->stride >= c->n_points) look = c->pt_off + c->tail_pt;  // (its next point)
       const slm_path_point pe = a.pts[look < 0 ? 0 : look];
       sa = pe.sa;
       sb = pe.sb;
