@@ -371,6 +371,35 @@ def test_interleaved_lanes_of_a_shared_path(eng, monkeypatch):
     assert ri.grad_launches <= 1 + -(-len(alphas) // 5) + 2
 
 
+def test_long_shared_paths_whose_last_band_goes_to_the_last_lanes(eng, monkeypatch):
+    """Shared paths of 32-74 points on 8 / 12 / 16 interleaved lanes: the points beyond the last full band are
+    walked by the last lanes (PathCtl::tail_pt).  Every point is solved exactly once, against the plain iteration;
+    giving that band to the first lanes instead (SLM_NO_TAIL_BAND=1) changes the schedule, not the answers."""
+    rng = np.random.default_rng(0)
+    for case in range(10):
+        n = int(rng.integers(800, 4000))
+        p = int(rng.integers(100, 900))
+        X = rng.standard_normal((n, p))
+        beta = np.zeros(p)
+        nz = rng.choice(p, int(rng.integers(3, 40)), replace=False)
+        beta[nz] = rng.standard_normal(len(nz)) * 3
+        y = X @ beta + rng.standard_normal(n) * rng.choice([0.1, 1.0, 5.0])
+        amax = np.max(np.abs(X.T @ y)) / n
+        K = int(rng.integers(32, 75))
+        lanes = int(rng.choice([16, 16, 12, 8]))
+        pts = [(a, 0, 0) for a in np.geomspace(amax, rng.choice([0.1, 0.01, 0.001]) * amax, K)]
+        with eng.dataset(X, y) as ds:
+            r = ds.solve_path(pts, lanes=lanes, flags=WS, tol=1e-10)
+            q = ds.solve_path(pts, lanes=4, flags=NO_WS, tol=1e-11)
+            monkeypatch.setenv("SLM_NO_TAIL_BAND", "1")
+            o = ds.solve_path(pts, lanes=lanes, flags=WS, tol=1e-10)
+            monkeypatch.delenv("SLM_NO_TAIL_BAND")
+        assert r.converged and q.converged and o.converged, (case, K, lanes)
+        assert np.all(r.n_iter >= 1) and np.all(o.n_iter >= 1)  # every point was visited
+        assert rel_inf(r.betas, q.betas) < 1e-7, (case, K, lanes)
+        assert rel_inf(o.betas, q.betas) < 1e-7, (case, K, lanes)
+
+
 def test_randomised_cross_check_against_plain_iteration():
     """tools/ws_fuzz.py: random penalty kinds, group sizes, lane counts, fold masks and p > n; the working-set
     answer must match the plain iteration to 1e-6 or, where the minimiser is not unique, reach the same objective."""
