@@ -71,6 +71,10 @@ constexpr int BB_HIST = 5;
 constexpr int BB_REJECT_LIMIT = 3;    // rejected candidates before a lane falls back to FISTA
 constexpr int BB_POINT_LIMIT = 60;    // spectral iterations on one point before falling back
 constexpr double BB_SIGMA = 1e-4;
+// (round 2: the floor also counts the noise of the gradient itself, kRoundFloor * curvature * ||beta|| -- near a
+// minimiser ||g|| is of the size of the penalty while the rounding error of X^T (X beta - y) / n scales with
+// lambda_max ||beta||; on weakly convex faces (p > n, tol 1e-12) the rule otherwise asks for a residual below that
+// noise and is met, or not, by the luck of the summation order)
 // Stopping rule floor: ||prox step|| <= kRoundFloor * ||g|| / curvature is the rounding noise of the
 // step itself (16 ulp of the gradient); below it `tol * ||beta||` cannot be met in fp64 when the
 // minimiser is itself a rounding-level number (alpha ~ alpha_max).
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       if (mu_ws > 0.0) mu_eff = fmin(mu_eff, mu_ws);
       mu_eff = fmax(mu_eff, kMuFloor * new_Lhat);
       // (second term: a prox step at the rounding level of the gradient itself cannot be improved)
-      conv = kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * sqrt(s[5]));
+      conv = kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[5]) + new_Lhat * bnorm));
       finalize = nonfinite || conv || hit_max;
     }
   } else {
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     mu_eff = mu_ws > 0.0 ? fmin(mu_ws, L) : L;
     if (new_mu_rq > 0.0) mu_eff = fmin(mu_eff, new_mu_rq);
     mu_eff = fmax(mu_eff, kMuFloor * L);
-    conv = !l_bad && (kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * sqrt(s[7])));
+    conv = !l_bad && (kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[7]) + L * bnorm)));
     finalize = nonfinite || conv || hit_max;
     new_t = l_bad ? 1.0 : t_new;
 #pragma unroll

@@ -613,7 +613,10 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
   // Larger appends (a miss quadruples the cap) are cut into chunks of four tile rows, one per value of
   // blockIdx.z >> 2, each handled the same way (up to 16 new tile rows = 256 columns; the generic
   // mapping left most wavefronts idle on them: 0.44 ms for 170 new columns).
-  const bool row_split = tile_lo > 0 && tiles - tile_lo <= 4 * WS_GRAM_ZCHUNKS;
+  // (a small fresh selection -- the first 112 columns of a path: 7 x 7 tiles -- keeps half of the wavefronts of ONE
+  //  workgroup per row block busy under the usual mapping, each walking all rows of the block: 90 us; split by rows
+  //  like an append it is eight wavefronts of two workgroups on a quarter of the rows each)
+  const bool row_split = (tile_lo > 0 || tiles <= 8) && tiles - tile_lo <= 4 * WS_GRAM_ZCHUNKS;
   const int zhi = (int)blockIdx.z >> 2;
   if (row_split ? (tile_lo + 4 * zhi >= tiles) : (zhi >= 2)) return;
   const int part = row_split ? (wave >> 1) : 0;
