@@ -1,6 +1,5 @@
 import os, sys
 sys.path.insert(0, "/root/repo/sparse-lm_amd"); sys.path.insert(0, "/root/repo")
-import numpy as np
 from sparselm_amd import _engine
 from bench import make_coef
 eng = _engine.get_engine(0)
