@@ -1,5 +1,8 @@
-import sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/sparse-lm_amd")
+#!/usr/bin/env python3
+"""The headline path on 2 / 3 / 4 engines (streams) of one GPU at once (bench.leg_concurrent_paths)."""
+import os, sys
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "sparse-lm_amd")); sys.path.insert(0, ROOT)
 import bench
 from sparselm_amd import _engine
 eng = _engine.get_engine(0)

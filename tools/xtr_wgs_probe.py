@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""The pass over X of working-set solves (xtr_mfma_kernel) alone, at 2 / 1.5 / 1 / 0.75 / 0.5 workgroups per CU
+(SLM_XTR_WGS_PER_CU), n = 100 000, p = 5 000, sixteen lane slots."""
 import os, sys
-sys.path.insert(0, "/root/repo/sparse-lm_amd"); sys.path.insert(0, "/root/repo")
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "sparse-lm_amd")); sys.path.insert(0, ROOT)
 from sparselm_amd import _engine
 from bench import make_coef
 eng = _engine.get_engine(0)
