@@ -1836,6 +1836,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (const char* e = getenv("SLM_WS_LOOKAHEAD")) wa.lookahead = std::max(0, std::min(64, atoi(e)));
     if (const char* e = getenv("SLM_WS_APPEND")) wa.append_max = std::max(1, std::min(WS_KCAP, atoi(e)));
     if (const char* e = getenv("SLM_WS_KINIT")) wa.k_init = std::max(16, std::min(WS_KCAP, atoi(e)));
+    wa.bb_steps = 1;
+    if (const char* e = getenv("SLM_WS_BB")) wa.bb_steps = atoi(e) != 0;
     return SLM_OK;
   };
   // no memory for the working-set buffers: the plain iteration still works (unless this solve runs

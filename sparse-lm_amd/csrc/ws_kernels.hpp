@@ -35,6 +35,8 @@ constexpr int WS_KLDS = 112;        // up to this many columns the Gram lives in
 constexpr int WS_TILES = WS_KCAP / 16; // 16x16 tiles per side of the Gram
 constexpr int WS_THREADS = 1024;
 constexpr int WS_INNER_MAX = 400;   // inner iterations per refinement
+constexpr int WS_BB_ITERS = 14;         // spectral steps the model solver opens with
+constexpr double WS_BB_MAX_STEP = 20.0; // longest of them, in steps of 1/L
 constexpr double WS_INNER_TOL = 0.05;  // inner stop: residual <= WS_INNER_TOL * tol * ||b||
 constexpr int WS_MAX_REPEATS = 6;   // refinements of one path point before the lane iterates plainly
 // Direct step of the model solver (newton_kernels.hpp): when the proximal-gradient iteration on the model has
@@ -124,7 +126,7 @@ struct WsArgs {
   int32_t lookahead;   // path points ahead whose penalty decides what enters W now
   int32_t append_max;  // newcomers appended per pass (the likeliest first)
   int32_t k_init;      // a fresh selection is cut down to this size (or to its non-zeros)
-  int32_t pad_;
+  int32_t bb_steps;    // the model solver opens with spectral steps (SLM_WS_BB=0: accelerated steps throughout)
 };
 
 // state of a fresh solve (the block is zeroed first): a build is requested, no lane has been refined yet
@@ -1494,6 +1496,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   mark(1);
   // ---- FISTA on the model ------------------------------------------------------------------------
   double L = Lw;
+  double Ls = L;  // curvature the next step is taken with (L, or less while the steps are spectral)
   double x = x_start, v = x_start, t = 1.0;
   double v_prev = 0.0, gv_prev = 0.0;
   bool have_prev = false;
@@ -1514,11 +1517,15 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   // those solves for a direction that means nothing.  A solve starts in this mode when an earlier refinement
   // of this call needed direct steps (WsCtl::hard, published between passes by ws_select_kernel).
   bool direct_mode = direct_on && ws->hard != 0;
+  // The first WS_BB_ITERS steps carry no momentum and take their length from the curvature along the move
+  // before: on the well-conditioned faces of an easy path that is there in half the steps of the accelerated
+  // iteration, which takes over if it is not.
+  bool spectral = !direct_mode && w.bb_steps != 0;
   int it_end = WS_INNER_MAX;
   for (int it = 0; it < it_end; ++it) {
     ++n_inner;
     const double gv = g0 + matvec(v, false);
-    const double u = prox_w(v - gv / L, 1.0 / L);
+    const double u = prox_w(v - gv / Ls, 1.0 / Ls);
     //  s[0] = ||u - v||^2  s[1] = ||u||^2  s[2] = (v - u).(u - x)  s[3] = #non-finite
     //  s[4] = ||v - v_prev||^2  s[5] = ||gv - gv_prev||^2   (curvature along the last move of v)
     //  s[6] = <v - v_prev, gv - gv_prev>
@@ -1551,10 +1558,22 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     }
     if (s[4] > 0.0 && sqrt(s[5] / s[4]) > L) {  // the step 1/L was too long: redo it from x
       L = 1.05 * sqrt(s[5] / s[4]);
+      Ls = L;
       v = x;
       t = 1.0;
       continue;
     }
+    if (spectral) {
+      // the next step is as long as the curvature along this move allows (Barzilai-Borwein, first form),
+      // never longer than WS_BB_MAX_STEP steps of 1/L
+      const double rq = s[4] > 1e-20 * s[1] ? s[6] / s[4] : L;
+      Ls = fmin(L, fmax(rq, L / WS_BB_MAX_STEP));
+      if (it + 1 >= WS_BB_ITERS) {  // not there in the steps such a face takes: momentum from here
+        spectral = false;
+        Ls = L;
+      }
+    }
+    // (a spectral step is longer than 1/L and moves at least as far from the same point: the test is the stricter for it)
     const bool inner_conv = sqrt(s[0]) <= WS_INNER_TOL * tol * sqrt(s[1]);
     if (direct_mode && !inner_conv) {
       bool stepped = false;
@@ -1587,7 +1606,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     const bool restart = s[2] > 0.0;
     const double t_use = restart ? 1.0 : t;
     const double t_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t_use * t_use));
-    const double mom = (t_use - 1.0) / t_new;
+    const double mom = spectral ? 0.0 : (t_use - 1.0) / t_new;
     v = u + mom * (u - x);
     x = u;
     t = t_new;
