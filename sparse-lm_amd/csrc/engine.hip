@@ -1838,6 +1838,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (const char* e = getenv("SLM_WS_KINIT")) wa.k_init = std::max(16, std::min(WS_KCAP, atoi(e)));
     wa.bb_steps = 1;
     if (const char* e = getenv("SLM_WS_BB")) wa.bb_steps = atoi(e) != 0;
+    wa.one_solver = 0;
+    if (const char* e = getenv("SLM_WS_ONE_SOLVER")) wa.one_solver = atoi(e) != 0;
     return SLM_OK;
   };
   // no memory for the working-set buffers: the plain iteration still works (unless this solve runs
@@ -1898,8 +1900,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         hipLaunchKernelGGL(ws_publish_kernel, dim3(WS_KCAP * WS_KCAP / 256, (unsigned)wa.n_sets), dim3(256), 0, s,
                            wa);
       }
-      if (ds->singleton) hipLaunchKernelGGL(ws_solve_kernel<false>, dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
-      else hipLaunchKernelGGL(ws_solve_kernel<true>, dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
+      // the iteration alone, then -- for the lanes it left -- the solver with direct steps (ws_refine_lane)
+      if (wa.one_solver && wa.nt) {
+      } else if (ds->singleton) hipLaunchKernelGGL((ws_solve_kernel<false, false>), dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
+      else hipLaunchKernelGGL((ws_solve_kernel<true, false>), dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
+      if (wa.nt) {
+        if (ds->singleton) hipLaunchKernelGGL((ws_solve_kernel<false, true>), dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
+        else hipLaunchKernelGGL((ws_solve_kernel<true, true>), dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
+      }
     }
   };
 
@@ -2113,6 +2121,13 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         fprintf(stderr, "[slm] model solver, lane 0, ms over the solve: set-up %.3f, lambda_max of a new Gram %.3f, start value %.3f, "
                 "iteration %.3f, acceptance + write-back %.3f\n", wc.solve_ticks[0] * 1e-5, wc.solve_ticks[1] * 1e-5,
                 wc.solve_ticks[2] * 1e-5, wc.solve_ticks[3] * 1e-5, wc.solve_ticks[4] * 1e-5);
+        fprintf(stderr, "[slm] model solves by iterations:");
+        for (int i = 0; i < 32; ++i)
+          if (wc.iters_hist[i]) fprintf(stderr, " %d:%d", i, wc.iters_hist[i]);
+        fprintf(stderr, "\n");
+        fprintf(stderr, "[slm] model solver, ms per lane over the solve:");
+        for (int l = 0; l < B; ++l) fprintf(stderr, " %.3f", wc.lane_ticks[l] * 1e-5);
+        fprintf(stderr, "\n");
         if (wc.newton_factors) {
           fprintf(stderr, "[slm] direct steps: accepted at t = 1: %d, 1/2: %d, 1/4: %d, first sign change: %d; %d factorisations, %.0f unknowns on average\n",
                   wc.newton_trial[0], wc.newton_trial[1], wc.newton_trial[2], wc.newton_trial[3], wc.newton_factors,

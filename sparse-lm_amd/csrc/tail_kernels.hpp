@@ -431,16 +431,41 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     // base point and its gradient after the decision; (zprev, gprev) = (base, its gradient) stays a
     // consistent pair for the FISTA curvature guard should this lane fall back
     const double step = 1.0 / new_ak;
+    // (E <= 8, i.e. p <= 8192: two loops rather than `accept ? zj[e] : bo[e]` in one.  The compiler turns that
+    // into a choice between the ADDRESSES of the arrays, which puts all four of them in scratch memory -- sixteen
+    // stores, thirty loads and their lines to write back at the end of every call.  Beyond, the arrays do not fit
+    // the 128 registers of a thread anyway, and scratch arrays are the cheaper way of not fitting.)
+    if (E <= 8 && accept) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int j = tid + e * TAIL_THREADS;
-      nb[e] = accept ? zj[e] : bo[e];
-      const double gb = accept ? gj[e] : gpv[e];
-      if (j < p) {
-        if (accept) a.gprev[j] = gb;
-        a.zprev[j] = nb[e];
+      for (int e = 0; e < E; ++e) {
+        const int j = tid + e * TAIL_THREADS;
+        nb[e] = zj[e];
+        if (j < p) {
+          a.gprev[j] = gj[e];
+          a.zprev[j] = nb[e];
+        }
+        u[e] = nb[e] - step * gj[e];
       }
-      u[e] = nb[e] - step * gb;
+    } else if (E <= 8) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = tid + e * TAIL_THREADS;
+        nb[e] = bo[e];
+        if (j < p) a.zprev[j] = nb[e];
+        u[e] = nb[e] - step * gpv[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = tid + e * TAIL_THREADS;
+        nb[e] = accept ? zj[e] : bo[e];
+        const double gb = accept ? gj[e] : gpv[e];
+        if (j < p) {
+          if (accept) a.gprev[j] = gb;
+          a.zprev[j] = nb[e];
+        }
+        u[e] = nb[e] - step * gb;
+      }
     }
     const bool fallback = !nonfinite && (new_rejects >= BB_REJECT_LIMIT || iter + 1 > BB_POINT_LIMIT);
     if (fallback) {

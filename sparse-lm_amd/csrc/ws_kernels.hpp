@@ -92,6 +92,9 @@ struct WsCtl {
   // ... and in the parts of lane 0's refinements: set-up, lambda_max of a new Gram, start value, the iteration,
   // acceptance + write-back (SLM_TRACE=2)
   unsigned long long solve_ticks[5];
+  int32_t want_full[SLM_MAX_LANES];  // lanes the light model solver left to the one with direct steps (this pass)
+  int32_t iters_hist[32];  // (SLM_TRACE=2) model solves by their number of iterations (last bin: 31 or more)
+  unsigned long long lane_ticks[SLM_MAX_LANES];  // (SLM_TRACE=2) ws_solve_kernel, entry to exit, per lane
   int32_t last_point[SLM_MAX_LANES];  // path point of each lane's last refinement ...
   int32_t repeats[SLM_MAX_LANES];     // ... and how many times in a row it was that point WITH the same columns
   int32_t last_cols[SLM_MAX_LANES];   // columns W held at each lane's last refinement (growth resets the count)
@@ -127,6 +130,8 @@ struct WsArgs {
   int32_t append_max;  // newcomers appended per pass (the likeliest first)
   int32_t k_init;      // a fresh selection is cut down to this size (or to its non-zeros)
   int32_t bb_steps;    // the model solver opens with spectral steps (SLM_WS_BB=0: accelerated steps throughout)
+  int32_t one_solver;  // SLM_WS_ONE_SOLVER=1: every lane goes to the solver with direct steps (measurements)
+  int32_t pad_;
 };
 
 // state of a fresh solve (the block is zeroed first): a build is requested, no lane has been refined yet
@@ -801,8 +806,12 @@ __global__ __launch_bounds__(256) void ws_publish_kernel(WsArgs w) {
 // ---------------------------------------------------------------------------------------------
 // GROUPED: the dataset has real groups (compiled apart from the per-feature variant: each instance carries one
 // direct step, and the registers of the other's never weigh on its iteration loop).
-template <bool GROUPED>
-__device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, double (*red)[TAIL_WAVES]) {
+// DIRECT = false: the iteration alone.  A lane whose solve would take a direct step is left, untouched, to the
+// DIRECT instance launched right behind (WsCtl::want_full; returns false).  Most solves never take one, and the
+// kernel without the factorisation is a fifth of the code, keeps its registers (the full one spills 250 of them
+// at 128 per thread) and leaves no scratch lines for the end of the kernel to write back.
+template <bool GROUPED, bool DIRECT>
+__device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, double (*red)[TAIL_WAVES]) {
   __shared__ double delta[WS_KCAP];
   __shared__ double uim[WS_KCAP];
   __shared__ int nz[WS_KCAP];
@@ -821,7 +830,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
   WsCtl* ws = w.ws;
-  if (!ws->valid || ws->building || ws->disabled) return;
+  if (!ws->valid || ws->building || ws->disabled) return true;
   const int tid = threadIdx.x;
   const int p = a.p;
   const int K = ws->K;
@@ -842,13 +851,17 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     for (int j = tid; j < p; j += WS_THREADS)
       if (w.pos[j] < 0 && a.z[j] != a.zprev[j]) out[0] += 1.0;
     block_sum<1>(out, red);
-    if (out[0] != 0.0) return;
+    if (out[0] != 0.0) return true;
   }
   const int point_now = ctl->point + ctl->pt_off;
   // (a point whose refinements keep being sent back because W had to grow -- strongly correlated designs
   // discover their support in waves -- is a different matter from one the model cannot settle)
   const int reps = (ws->last_point[lane_id] == point_now && ws->last_cols[lane_id] == ws->Kreal) ? ws->repeats[lane_id] : 0;
-  if (reps >= WS_MAX_REPEATS) return;
+  if (reps >= WS_MAX_REPEATS) return true;
+  if (!DIRECT && w.nt != nullptr && ws->hard != 0) {  // a solve of this call needed direct steps: so may this one
+    if (tid == 0) ws->want_full[lane_id] = 1;
+    return false;
+  }
 
   unsigned long long tk_s = wall_clock64();
   auto mark = [&](int slot) {
@@ -1017,7 +1030,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
       vec = lam > 0.0 ? y / lam : 0.0;
     }
     Lw = lam * 1.1;  // from below; the curvature guard in the loop covers the rest
-    if (!(Lw > 0.0)) return;  // empty / zero Gram: nothing to refine
+    if (!(Lw > 0.0)) return true;  // empty / zero Gram: nothing to refine
   }
 
   // ---- direct step: projected Newton on the free coordinates ---------------------------------------
@@ -1556,12 +1569,14 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
       if (rq > 0.0 && (rq_n == 0 || rq < rq_min)) rq_min = rq;
       rq_n += 1;
     }
-    if (s[4] > 0.0 && sqrt(s[5] / s[4]) > L) {  // the step 1/L was too long: redo it from x
+    if (s[4] > 0.0 && sqrt(s[5] / s[4]) > L) {  // the bound was too low
       L = 1.05 * sqrt(s[5] / s[4]);
-      Ls = L;
-      v = x;
-      t = 1.0;
-      continue;
+      if (!spectral) {  // an accelerated step of 1/L was too long: redo it from x (a spectral step claims nothing of L)
+        Ls = L;
+        v = x;
+        t = 1.0;
+        continue;
+      }
     }
     if (spectral) {
       // the next step is as long as the curvature along this move allows (Barzilai-Borwein, first form),
@@ -1575,7 +1590,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     }
     // (a spectral step is longer than 1/L and moves at least as far from the same point: the test is the stricter for it)
     const bool inner_conv = sqrt(s[0]) <= WS_INNER_TOL * tol * sqrt(s[1]);
-    if (direct_mode && !inner_conv) {
+    if (DIRECT && direct_mode && !inner_conv) {
       bool stepped = false;
       if (n_direct < WS_NEWTON_MAX) {
         double mu_new = 0.0;
@@ -1617,6 +1632,10 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     since_direct += 1;
     if (direct_on && n_direct < WS_NEWTON_MAX &&
         (since_direct >= WS_NEWTON_AFTER || (rq_n >= 5 && rq_min < WS_NEWTON_RQ * L))) {
+      if (!DIRECT) {  // (nothing of this solve has been written yet)
+        if (tid == 0) ws->want_full[lane_id] = 1;
+        return false;
+      }
       double mu_new = 0.0;
       const int rc = group_face ? direct_step_group(x, L, &mu_new, mu_face == 0.0) : direct_step(x, L, &mu_new, mu_face == 0.0);
       since_direct = 0;
@@ -1636,7 +1655,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     }
   }
   mark(3);
-  if (!ok) return;
+  if (!ok) return true;
   // An iteration that ran out of steps is accepted only if the model says its point is no worse than the start (two
   // products with the Gram, 14 us per call: not spent on a point that met the tolerance -- a minimiser of the model
   // is no worse than anything)
@@ -1656,7 +1675,7 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     s[1] = pen_part(x);
     block_sum<3>(s, red);
     const double m_end = s[0] + s[1];
-    if (s[2] > 0.0 || !(m_end <= m_start)) return;
+    if (s[2] > 0.0 || !(m_end <= m_start)) return true;
   }
   // the refined point: model minimiser on W, the expansion point elsewhere (eight features per round: their loads
   // go out together -- one feature at a time every load waited for the one before it, 11 us per call)
@@ -1690,9 +1709,12 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     ws->last_point[lane_id] = point_now;
     ws->repeats[lane_id] = reps + 1;
     ws->last_cols[lane_id] = ws->Kreal;
-    if (L > ws->Lw[set]) ws->Lw[set] = L;
+    // (the lanes of a set end within microseconds of each other: read-compare-write let the smaller of two bounds
+    // land last now and then, and the next pass started from a different L -- positive doubles order as integers)
+    if (L > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(&ws->Lw[set]), (unsigned long long)__double_as_longlong(L));
     atomicAdd(&ws->refined, 1);
     atomicAdd(&ws->inner_iters, n_inner);
+    atomicAdd(&ws->iters_hist[n_inner < 31 ? n_inner : 31], 1);
     if (n_direct) atomicAdd(&ws->newton_steps, n_direct - n_direct_bad);
     if (n_direct > n_direct_bad) ws->hard_next = 1;  // (same value from every lane: the order of the stores is immaterial)
     if (n_direct_bad) atomicAdd(&ws->newton_fails, n_direct_bad);
@@ -1702,15 +1724,24 @@ __device__ __forceinline__ void ws_refine_lane(TailArgs a, const WsArgs& w, doub
     ctl->mu = mu_face > 0.0 ? 0.5 * mu_face : (rq_n >= 3 ? 0.5 * rq_min : 0.0);
   }
   mark(4);
+  return true;
 }
 
-template <bool GROUPED>
+template <bool GROUPED, bool DIRECT>
 __global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs w) {
   __shared__ double red[8][TAIL_WAVES];
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
   if (ctl->done != 0 || ctl->idle != 0 || a.gdone[0] != 0) return;
-  ws_refine_lane<GROUPED>(a, w, red);  // (every return inside is taken by the whole workgroup)
+  const unsigned long long tk_in = wall_clock64();
+  if (DIRECT) {  // only the lanes the light kernel left
+    const int mine = w.ws->want_full[lane_id] | w.one_solver;
+    __syncthreads();
+    if (!mine) return;
+    if (threadIdx.x == 0) w.ws->want_full[lane_id] = 0;
+  }
+  // (every return inside is taken by the whole workgroup)
+  if (!ws_refine_lane<GROUPED, DIRECT>(a, w, red)) return;
   __syncthreads();
   // Is the point the next pass evaluates zero outside W?  Then its residual needs only the gathered
   // columns (resid_ws_kernel) and the pass over X is the accumulate-only xtr_ring_kernel.
@@ -1735,7 +1766,10 @@ __global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs
     }
   }
   block_sum<1>(out, red);
-  if (threadIdx.x == 0) ctl->zsup = (w_ok && out[0] == 0.0) ? 1 : 0;
+  if (threadIdx.x == 0) {
+    ctl->zsup = (w_ok && out[0] == 0.0) ? 1 : 0;
+    w.ws->lane_ticks[lane_id] += wall_clock64() - tk_in;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
