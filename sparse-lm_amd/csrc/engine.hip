@@ -1086,8 +1086,16 @@ static int check_launch() {
 // magnitude (it measures curvature along its own steps) and FISTA's curvature guard repairs an
 // under-estimate, so a handful of passes is enough; slm_dataset_lipschitz() asks for more.
 static const int kPowerItersSolve = 2;
-static const int kPowerItersSketch = 3;  // on a sixteenth of the rows (working-set solves)
+static const int kPowerItersSketch = 3;  // on a thirty-second of the rows (working-set solves)
 static const int kPowerItersQuery = 16;
+// (a thirty-second of the rows: the bound is looser than from a sixteenth -- lambda_max of a sketch grows as it
+// shrinks -- and nothing downstream noticed down to a sixty-fourth, SLM_L_SKETCH_DIV; three steps on
+// 3 125 of 100 000 rows cost 0.10 ms where a sixteenth cost 0.17)
+static int64_t sketch_rows(int64_t n) {
+  int div = 32;
+  if (const char* e = getenv("SLM_L_SKETCH_DIV")) div = std::max(1, std::min(1024, atoi(e)));
+  return std::max<int64_t>(1, n / div);
+}
 
 // n_rows > 0: the operator of the first n_rows rows only, X_S^T W X_S / (n_eff n_rows / n).  Its largest
 // eigenvalue is, in expectation, no smaller than that of the full operator (Jensen: lambda_max is
@@ -1575,7 +1583,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   } else {
     const auto t0 = std::chrono::steady_clock::now();
     bool ran = false;
-    // working-set solves barely use L (first candidate, fallback steps): a bound from the first sixteenth
+    // working-set solves barely use L (first candidate, fallback steps): a bound from the first thirty-second
     // of the rows, three power steps, costs a sixth of the two full passes
     const bool sketch = ws_policy(ds, o.flags) == 2 && n >= 65536 && !getenv("SLM_NO_L_SKETCH");
     if (sketch && !(ds->L_valid && !(o.flags & SLM_FLAG_FRESH_L) && !any_rw && !custom_scale)) {
@@ -1585,11 +1593,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         // the number -- the power steps are queued, seed_step_kernel writes L, the first inverse step and the
         // curvature floor into the control blocks, and the host goes on preparing the solve meanwhile
         // (it used to wait for them: 0.2 ms of idle stream per path)
-        SLM_TRY(power_iteration(ds, default_lanes(ds, 1), nullptr, kPowerItersSketch, n / 16));
+        SLM_TRY(power_iteration(ds, default_lanes(ds, 1), nullptr, kPowerItersSketch, sketch_rows(n)));
         for (int l = 0; l < B; ++l) L[l] = 0.0;
         L_on_device = true;
       } else {
-      SLM_TRY(power_iteration(ds, per_lane ? ls : default_lanes(ds, 1), L, kPowerItersSketch, n / 16));
+      SLM_TRY(power_iteration(ds, per_lane ? ls : default_lanes(ds, 1), L, kPowerItersSketch, sketch_rows(n)));
       // A lane whose row weights vanish on the window (scikit-learn's default cv = unshuffled KFold: the first
       // fold's training mask is zero on the first n / k rows) measured nothing there: all rows, then.
       bool blank = false;

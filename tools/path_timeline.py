@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the last solve in a rocprofv3 kernel trace (csv): start offset, gap to the previous kernel, duration.
 
-usage: python tools/path_timeline.py <kernel_trace.csv> [n_xtr_launches_back]"""
+usage: python tools/path_timeline.py <kernel_trace.csv> [n_xtr_launches_back [shortest launch listed, us]]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -17,7 +17,7 @@ for name, a, b in seq[start:]:
     gap = (a - prev) / 1e3 if prev else 0.0
     dur = (b - a) / 1e3
     tot[nm] = tot.get(nm, 0.0) + dur
-    if dur > 12 or gap > 12:
+    if dur > float(sys.argv[3] if len(sys.argv) > 3 else 12) or gap > 12:
         print(f"{(a - t0) / 1e3:9.1f} us  gap {gap:6.1f}  {dur:8.1f} us  {nm[:60]}")
     prev = b
 print("--- totals over the window (us)")
