@@ -29,13 +29,14 @@
 #ifndef SLM_ENGINE_H
 #define SLM_ENGINE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 6
+#define SLM_ABI_VERSION 7
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -58,6 +59,16 @@ typedef struct slm_dataset slm_dataset; /* device-resident (X, y[, row weights][
 int slm_abi_version(void);
 const char* slm_last_error(void);
 int slm_device_count(int* count_out);
+
+/*
+ * Page-locked host memory for result buffers (betas_out / group_norms_out of the solve calls).  Any host pointer is
+ * accepted there; a buffer from here is written by the copy engine directly, while into ordinary memory the HIP
+ * runtime first locks the caller's pages and keeps the registration -- freeing such memory afterwards (numpy
+ * releasing a 2 MB result array, what the reference's `coef_` assignment of model/_base.py:201-202 amounts to) then
+ * stalls the next submissions for milliseconds.  The binding recycles these blocks (sparselm_amd._engine._HostPool).
+ */
+int slm_host_alloc(size_t bytes, void** out);
+int slm_host_free(void* ptr);
 
 /* ---- engine lifecycle ------------------------------------------------------------------------ */
 int slm_engine_create(int device_id, slm_engine** out);

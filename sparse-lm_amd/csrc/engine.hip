@@ -432,6 +432,26 @@ static void dfree(T*& p) {
 // library
 // ------------------------------------------------------------------------------------------------
 extern "C" int slm_abi_version(void) { return SLM_ABI_VERSION; }
+
+extern "C" int slm_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return fail(SLM_ERR_BAD_ARG, "slm_host_alloc: NULL out or zero size");
+  *out = nullptr;
+  void* ptr = nullptr;
+  const hipError_t e = hipHostMalloc(&ptr, bytes, hipHostMallocDefault);
+  if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+    (void)hipGetLastError();
+    return fail(SLM_ERR_OOM, "no %zu bytes of page-locked host memory", bytes);
+  }
+  HIP_TRY(e);
+  *out = ptr;
+  return SLM_OK;
+}
+
+extern "C" int slm_host_free(void* ptr) {
+  if (!ptr) return SLM_OK;
+  HIP_TRY(hipHostFree(ptr));
+  return SLM_OK;
+}
 extern "C" const char* slm_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int slm_device_count(int* count_out) {
@@ -1567,6 +1587,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     ls.rw = ds->rw_lanes;
     ls.rw_stride = n;
   }
+  const double tr_rw = t_mark();
   bool custom_scale = false;
   for (int l = 0; l < B; ++l)
     if (lanes[l].n_eff > 0) {
@@ -2165,7 +2186,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   tr[4] = t_mark();
   if (const char* trc = getenv("SLM_TRACE"))  // 1: slow solves only, 2: every solve (cumulative ms since entry)
     if (tr[4] > 15.0 || trc[0] == '2')
-      fprintf(stderr, "[slm] solve: L+buffers %.3f setup %.3f sync %.3f prequeue %.3f loop %.3f end %.3f ms\n", tr[5], tr[0], tr[1], tr[2], tr[3], tr[4]);
+      fprintf(stderr, "[slm] solve: row weights %.3f L %.3f setup %.3f sync %.3f prequeue %.3f loop %.3f end %.3f ms\n", tr_rw, tr[5], tr[0], tr[1], tr[2], tr[3], tr[4]);
   if (nonfinite) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
   return SLM_OK;
 }

@@ -172,8 +172,9 @@ class SolveProblem:
             "loss": float(res.loss[0]),
             "wall_ms": res.wall_ms,
         }
-        gn = None if res.group_norms is None else res.group_norms[0]
-        return res.betas[0], gn, info
+        # (copies: an estimator's coef_ must not keep a block of the engine's page-locked result pool alive)
+        gn = None if res.group_norms is None else res.group_norms[0].copy()
+        return res.betas[0].copy(), gn, info
 
     def set_targets(self, y):
         """New targets on the same design (problems opened with ``cache=False`` only: a cached dataset is

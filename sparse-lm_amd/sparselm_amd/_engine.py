@@ -41,13 +41,15 @@ FLAG_WORKING_SET = 32  # force the Gram-assisted refinement even for small X
 FLAG_NO_WORKING_SET = 64
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 6  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 7  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "slm_abi_version",
     "slm_last_error",
     "slm_device_count",
+    "slm_host_alloc",
+    "slm_host_free",
     "slm_engine_create",
     "slm_engine_destroy",
     "slm_engine_synchronize",
@@ -220,6 +222,8 @@ def load_library():
             "slm_dataset_create": [vp, vp, i64, i64, i64, i64, vp, vp, P(vp)],
             "slm_dataset_create_device": [vp, vp, i64, i64, i64, vp, vp, P(vp)],
             "slm_dataset_create_synthetic": [vp, i64, i64, C.c_uint64, i64, vp, dbl, P(vp)],
+            "slm_host_alloc": [C.c_size_t, P(vp)],
+            "slm_host_free": [vp],
             "slm_dataset_destroy": [vp],
             "slm_dataset_shape": [vp, P(i64), P(i64), P(i64)],
             "slm_dataset_download": [vp, vp, vp],
@@ -679,6 +683,12 @@ class Dataset:
         keep = []  # keep every buffer alive for the duration of the call
         clanes = (_Lane * nl)()
         outs = []
+        # one block for the coefficients of all lanes (and one for their group norms): the engine fetches buffers
+        # that follow each other in one copy
+        k_all = [int(np.asarray(spec["points"]).size // 3) for spec in lanes]
+        beta_block = _host_pool.empty(sum(k_all) * self.p)
+        gn_block = _host_pool.empty(sum(k_all) * G) if want_group_norms else None
+        at = 0
         for l, spec in enumerate(lanes):
             pts = np.ascontiguousarray(spec["points"], dtype=np.float64).reshape(-1, 3)
             K = pts.shape[0]
@@ -693,8 +703,9 @@ class Dataset:
             pen = _PenaltyStruct(_ptr(a_), _ptr(b_), _ptr(d_))
             b0 = None if spec.get("beta0") is None else _f64(spec["beta0"], "beta0", (self.p,))
             rw = None if spec.get("row_weight") is None else _f64(spec["row_weight"], "row_weight", (self.n,))
-            betas = np.empty((K, self.p))
-            gn = np.empty((K, G)) if want_group_norms else None
+            betas = beta_block[at * self.p : (at + K) * self.p].reshape(K, self.p)
+            gn = gn_block[at * G : (at + K) * G].reshape(K, G) if want_group_norms else None
+            at += K
             infos = np.zeros(K, dtype=_INFO_DTYPE)
             keep.append((cpts, a_, b_, d_, pen, b0, rw))
             clanes[l].pen = C.pointer(pen)
@@ -754,8 +765,8 @@ class Dataset:
         pen = _PenaltyStruct(_ptr(a_), _ptr(b_), _ptr(d_))
         b0 = None if beta0 is None else _f64(beta0, "beta0", (self.p,))
         opts = _SolveOpts(float(tol), int(max_iter), int(check_every), float(L), int(flags))
-        betas = np.empty((K, self.p))
-        gn = np.empty((K, G)) if want_group_norms else None
+        betas = _host_pool.empty(K * self.p).reshape(K, self.p)
+        gn = _host_pool.empty(K * G).reshape(K, G) if want_group_norms else None
         infos = np.zeros(K, dtype=_INFO_DTYPE)
         stats = _SolveStats()
         _check(
@@ -765,6 +776,66 @@ class Dataset:
             )
         )
         return _path_result(betas, gn, infos, K, stats)
+
+
+class _HostPool:
+    """Result buffers in page-locked host memory (``slm_host_alloc``), recycled.
+
+    The engine copies coefficients straight into whatever host pointer it is given.  Into ordinary numpy memory the
+    HIP runtime locks the pages first and remembers them; when numpy later frees such an array (a 2 MB path result,
+    32 MB for sixteen lanes) the driver has to tear that registration down, which now and then stalled the NEXT
+    solve's first submissions for 20 ms (bench.py's config-4 leg: 0.25 s instead of 0.16 s).  Blocks from this pool
+    are never unmapped while the process lives: an array handed out keeps its block until the last view of it is
+    gone (``weakref.finalize`` on the exporting buffer), then the block goes back on the free list of its size
+    class (powers of two from 64 KiB).  At most ``cap`` bytes sit idle; anything beyond goes back to the driver.
+    Small results, and everything after a fork, use plain numpy memory."""
+
+    MIN_BYTES = 1 << 16
+
+    def __init__(self, cap=1 << 30):
+        self.cap, self.idle = cap, 0
+        self.free: dict[int, list[int]] = {}
+        self.lock = threading.Lock()
+        self.pid = os.getpid()
+
+    def _take(self, size):
+        with self.lock:
+            blocks = self.free.get(size)
+            if blocks:
+                self.idle -= size
+                return blocks.pop()
+        ptr = C.c_void_p()
+        rc = load_library().slm_host_alloc(C.c_size_t(size), C.byref(ptr))
+        return ptr.value if rc == 0 and ptr.value else None
+
+    def _give(self, ptr, size, pid):
+        if pid != os.getpid() or _lib is None:  # (a forked child, or the library is already gone at exit)
+            return
+        with self.lock:
+            if self.idle + size <= self.cap:
+                self.free.setdefault(size, []).append(ptr)
+                self.idle += size
+                return
+        try:
+            _lib.slm_host_free(C.c_void_p(ptr))
+        except Exception:  # interpreter shutdown
+            pass
+
+    def empty(self, n_doubles: int) -> np.ndarray:
+        """Uninitialised float64 vector of `n_doubles` entries."""
+        nbytes = 8 * int(n_doubles)
+        if nbytes < self.MIN_BYTES or os.getpid() != self.pid or os.environ.get("SLM_NO_HOST_POOL"):
+            return np.empty(int(n_doubles))
+        size = 1 << (nbytes - 1).bit_length()
+        ptr = self._take(size)
+        if ptr is None:  # no page-locked memory to be had: ordinary memory works too
+            return np.empty(int(n_doubles))
+        buf = (C.c_char * size).from_address(ptr)
+        weakref.finalize(buf, self._give, ptr, size, self.pid)
+        return np.frombuffer(buf, dtype=np.float64, count=int(n_doubles))
+
+
+_host_pool = _HostPool()
 
 
 def init_local_comm(engines, timeout_s: float = 0.0) -> None:

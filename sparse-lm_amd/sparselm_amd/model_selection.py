@@ -355,7 +355,7 @@ class GridSearchCV(_GridSearchCV):
                         d=np.zeros(ds.n_groups) if d is None else d,
                         **opts,
                     )
-                    beta_aug = res.betas[0]
+                    beta_aug = res.betas[0].copy()
                     best.solver_info_ = {"n_iter": int(res.n_iter[0]), "converged": res.converged}
                     if not res.converged:
                         self._warn_unconverged(1, "the refit", opts)

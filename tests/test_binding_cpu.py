@@ -58,3 +58,17 @@ def test_points_block_layout():
     assert blk.shape == (4, 4) and blk.flags.c_contiguous
     np.testing.assert_array_equal(blk[:, :3], pts)
     np.testing.assert_array_equal(blk[:, 3], [0.0, 0.0, 0.5, 0.25])
+
+
+def test_host_pool_falls_back_to_numpy_memory():
+    """No page-locked memory to be had (no device here), a small request, or a forked child: plain numpy arrays."""
+    from sparselm_amd import _engine
+
+    pool = _engine._HostPool()
+    small = pool.empty(16)
+    assert small.shape == (16,) and small.flags.owndata
+    big = pool.empty(1 << 16)  # 512 KiB: asks the library, which has no device to lock pages for
+    assert big.shape == (1 << 16,) and big.dtype == np.float64
+    big[:] = 1.0
+    pool.pid = -1  # "another process"
+    assert pool.empty(1 << 16).flags.owndata

@@ -5,6 +5,8 @@ order only); solutions computed at tol=1e-12 agree with the oracle to 1e-9 rel-i
 default tol=1e-8 agree to 1e-6 rel-inf (BASELINE.json's stated bound).
 """
 
+import os
+
 import numpy as np
 import numpy.testing as npt
 import pytest
@@ -624,3 +626,47 @@ def test_sixteen_lane_plain_iteration_on_large_x(eng):
         for f in (0, 1, 5):
             ref = ds.solve_lanes([specs[f]], tol=1e-10, flags=PLAIN)[0]
             assert rel_inf(got[f].betas, ref.betas) < 1e-7
+
+
+@pytest.mark.gpu
+def test_results_come_in_recycled_page_locked_blocks():
+    """Path results of 64 KiB and more live in blocks of the binding's page-locked pool (include/slm_engine.h,
+    slm_host_alloc): a block returns to the pool when the last view of a result is gone and serves the next solve;
+    the numbers are those of plain numpy buffers (SLM_NO_HOST_POOL)."""
+    import gc
+
+    rng = np.random.default_rng(5)
+    n, p = 600, 1200
+    X = rng.standard_normal((n, p))
+    y = X[:, :5] @ np.array([3.0, -2.0, 1.5, 1.0, -1.0]) + 0.1 * rng.standard_normal(n)
+    eng = _engine.get_engine(0)
+    pool = _engine._host_pool
+    with eng.dataset(X, y) as ds:
+        g0, _ = ds.gradient(None)
+        pts = [(a, 0.0, 0.0) for a in np.geomspace(np.max(np.abs(g0)), 1e-2 * np.max(np.abs(g0)), 12)]
+        res = ds.solve_path(pts, tol=1e-10)
+        assert res.converged and 8 * res.betas.size >= pool.MIN_BYTES
+        assert not res.betas.flags.owndata  # a view of a pool block
+        first = res.betas.copy()
+        address = res.betas.ctypes.data
+        idle_before = pool.idle
+        row = res.betas[3]  # a view keeps the block
+        del res
+        gc.collect()
+        assert pool.idle == idle_before
+        np.testing.assert_array_equal(row, first[3])
+        del row
+        gc.collect()
+        assert pool.idle > idle_before
+        again = ds.solve_path(pts, tol=1e-10)
+        assert again.betas.ctypes.data == address  # the same block
+        np.testing.assert_array_equal(again.betas, first)
+        lanes = ds.solve_lanes([dict(points=pts[:6]), dict(points=pts[6:])], tol=1e-10)
+        assert lanes[1].betas.ctypes.data == lanes[0].betas.ctypes.data + 8 * 6 * p  # one block, one copy
+        os.environ["SLM_NO_HOST_POOL"] = "1"
+        try:
+            plain = ds.solve_path(pts, tol=1e-10)
+        finally:
+            del os.environ["SLM_NO_HOST_POOL"]
+        assert plain.betas.flags.owndata or plain.betas.base is not None
+        np.testing.assert_array_equal(plain.betas, first)

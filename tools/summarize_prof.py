@@ -32,7 +32,7 @@ def counters(tag):
         per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
     for k, v in per.items():
         # launches that early-exit (path already finished) move ~0 bytes: keep the working ones
-        big = [x for x in v if x > 0.5 * max(v)]
+        big = [x for x in v if x > 0.5 * max(v)] or v  # (a kernel that never moved a byte: all of its launches)
         out[k] = {"launches": len(v), "working_launches": len(big), "median_kib": statistics.median(big), "max_kib": max(v)}
     return out
 
