@@ -1657,9 +1657,12 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
   mark(3);
   if (!ok) return true;
   // An iteration that ran out of steps is accepted only if the model says its point is no worse than the start (two
-  // products with the Gram, 14 us per call: not spent on a point that met the tolerance -- a minimiser of the model
-  // is no worse than anything)
-  if (!settled) {
+  // products with the Gram, 14 us per call).  Not spent on a point that met the tolerance -- a minimiser of the model is
+  // no worse than anything -- unless the START already met it (one iteration): that point is one proximal step from
+  // where the lane stood, now and then a hair worse, and taking it resets the lane's step history for nothing.  On
+  // paths whose ends outgrow the working set such solves are common (a fifth to a half of all) and accepting them
+  // unseen cost 4-6 passes of 24-58 (tools/headline_soak.py); the headline path has none.
+  if (!settled || n_inner == 1) {
     double m_start;  // model values relative to the expansion point
     {
       const double gd = matvec(x_start, false);
