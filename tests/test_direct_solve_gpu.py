@@ -203,3 +203,50 @@ def test_group_penalties_on_correlated_designs_take_newton_steps(eng, design, ki
         if kind != "sparse_group":  # group all-or-nothing (reference tests/test_lasso.py:106-111)
             active = np.bincount(groups, weights=(res.betas[-1] != 0), minlength=G)
             assert np.all((active == 0) | (active == 8))
+
+
+def test_lanes_left_to_the_solver_with_direct_steps_give_what_one_kernel_gives(eng, monkeypatch):
+    """The model solver is two launches: the iteration alone, then -- for the lanes that would take a direct step --
+    the instance that carries them, which starts those solves over (ws_kernels.hpp, `ws_refine_lane<GROUPED, DIRECT>`).
+    Nothing of an abandoned solve may leak: every lane on the second instance (SLM_WS_ONE_SOLVER=1) gives the same bits,
+    and so does a second run."""
+    rng = np.random.default_rng(11)
+    n, p = 3000, 300
+    X = _ar1(rng, n, p, 0.97)
+    coef = np.zeros(p)
+    coef[rng.choice(p, 10, replace=False)] = rng.standard_normal(10) * 2
+    y = X @ coef + 0.5 * rng.standard_normal(n)
+    amax = float(np.max(np.abs(X.T @ y)) / n)
+    pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-2 * amax, 12)]
+    with eng.dataset(X, y) as ds:
+        two = ds.solve_path(pts, lanes=4, flags=_engine.FLAG_WORKING_SET, tol=1e-9)
+        again = ds.solve_path(pts, lanes=4, flags=_engine.FLAG_WORKING_SET, tol=1e-9)
+        monkeypatch.setenv("SLM_WS_ONE_SOLVER", "1")
+        one = ds.solve_path(pts, lanes=4, flags=_engine.FLAG_WORKING_SET, tol=1e-9)
+    assert two.converged and one.converged
+    assert two.ws_direct_steps > 0  # the design needs them: the light instance handed lanes over
+    np.testing.assert_array_equal(two.betas, again.betas)
+    np.testing.assert_array_equal(two.betas, one.betas)
+    assert two.grad_launches == one.grad_launches and two.ws_direct_steps == one.ws_direct_steps
+
+
+def test_spectral_steps_of_the_model_solver_save_iterations_not_accuracy(eng, monkeypatch):
+    """Easy design: the model solver's spectral opening (default) against accelerated steps throughout (SLM_WS_BB=0):
+    same passes, same solution to the solver's tolerance, fewer model iterations, no direct step either way."""
+    rng = np.random.default_rng(12)
+    n, p = 12000, 500  # (p / n as on the headline problem: faces with a condition number of 2-3)
+    X = rng.standard_normal((n, p))
+    coef = np.zeros(p)
+    coef[rng.choice(p, 25, replace=False)] = 5 * rng.standard_normal(25)
+    y = X @ coef + rng.standard_normal(n)
+    amax = float(np.max(np.abs(X.T @ y)) / n)
+    pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-2 * amax, 24)]
+    with eng.dataset(X, y) as ds:
+        bb = ds.solve_path(pts, lanes=8, flags=_engine.FLAG_WORKING_SET, tol=1e-10)
+        monkeypatch.setenv("SLM_WS_BB", "0")
+        acc = ds.solve_path(pts, lanes=8, flags=_engine.FLAG_WORKING_SET, tol=1e-10)
+    assert bb.converged and acc.converged
+    assert np.max(np.abs(bb.betas - acc.betas)) <= 1e-8 * np.max(np.abs(acc.betas))
+    assert bb.grad_launches <= acc.grad_launches + 1
+    assert bb.ws_direct_steps == 0 and acc.ws_direct_steps == 0
+    assert bb.ws_inner_iters < acc.ws_inner_iters

@@ -432,3 +432,36 @@ def test_vector_and_matrix_core_residual_kernels_agree(eng, monkeypatch):
     assert out["mfma"].converged and out["vec"].converged and out["mfma"].ws_refined > 0
     scale = np.max(np.abs(out["vec"].betas))
     assert np.max(np.abs(out["mfma"].betas - out["vec"].betas)) < 1e-8 * scale
+
+
+@pytest.mark.gpu
+def test_lanes_that_share_a_gram_give_the_same_bits_every_time():
+    """Grid rows of one CV fold share a row mask, hence one working-set Gram and one bound on its lambda_max, which
+    every lane of the set may raise (curvature guard of the model solver) and publishes by an integer atomic max
+    (ws_kernels.hpp).  The bound the next pass starts from must not depend on which lane ended last: five runs of
+    the same eight-lane call, and one on a device-to-device copy, bit for bit."""
+    rng = np.random.default_rng(21)
+    n, p = 3000, 400
+    X = rng.standard_normal((n, p)) + 0.6 * rng.standard_normal((n, 1))
+    coef = np.zeros(p)
+    coef[rng.choice(p, 20, replace=False)] = 3 * rng.standard_normal(20)
+    y = X @ coef + rng.standard_normal(n)
+    masks = [(np.arange(n) % 2 != f).astype(float) for f in range(2)]
+    eng = _engine.get_engine(0)
+    with eng.dataset(X, y) as ds:
+        g0, _ = ds.gradient(None)
+        amax = float(np.max(np.abs(g0)))
+        specs = []
+        for f in range(2):
+            for scale in (1.0, 0.8, 0.6, 0.45):
+                al = np.geomspace(scale * amax, 5e-3 * scale * amax, 14)
+                specs.append(dict(points=np.c_[al, 0 * al, 0 * al], row_weight=masks[f], n_eff=int(masks[f].sum())))
+        runs = [ds.solve_lanes(specs, tol=1e-11, flags=_engine.FLAG_WORKING_SET) for _ in range(5)]
+        with ds.clone() as copy:
+            runs.append(copy.solve_lanes(specs, tol=1e-11, flags=_engine.FLAG_WORKING_SET))
+            copy_engine = copy.engine
+        copy_engine.close()
+    assert all(r.converged for run in runs for r in run) and runs[0][0].ws_refined > 0
+    for run in runs[1:]:
+        for a, b in zip(runs[0], run):
+            np.testing.assert_array_equal(a.betas, b.betas)
