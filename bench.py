@@ -4,7 +4,10 @@
 A "step" is one complete path solve on one GPU: seed Lipschitz estimate (power iteration, re-done
 every step) + 50 converged alpha points (tol 1e-8), with (X, y) already resident in HBM.  The path
 is walked by `--lanes` (default 16) lanes that share every pass over X; `--lanes 1` is the strictly
-sequential warm-started path.
+sequential warm-started path.  Set-up, before the W warm-up steps: the dataset is generated on the device, fifty
+gradient launches bring the clocks up, and three untimed paths pay the dataset's one-off costs (column-major copy
+of X, work-space allocations, first block of the page-locked result pool; reported under
+`config.one_off_costs_outside_value_ms`).
 
 Ranks.  ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
 itself: the parent process -- before it has touched HIP in any way -- runs
