@@ -654,17 +654,24 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
     // two steps in flight: the loads of step s + 4 are issued before the 16 MFMAs of step s (the loop is
     // otherwise one load latency per 4 rows: ~100 dependent steps per wavefront)
     // (the row weight is applied in mma(), not at the load, so nothing waits on a load before the MFMAs)
+    // (every load of a step is issued whatever the tile pattern: a tile this wavefront does not need is read from
+    //  a column block that exists and never used.  With the loads under conditions the compiler could not count
+    //  them and waited for ALL of them -- the ones of the steps ahead included -- before the first MFMA of a step)
+    const int ta_max = WS_TILES - 1;
+    const double* rwp = rw ? rw : w.XW;  // (no row weights: any readable address, the value is replaced by 1)
+    const bool has_rw = rw != nullptr;
     auto load = [&](int64_t s, double(&av)[4], double(&bv)[4], double& wgt) {
       const int64_t i = s + kk;
       const bool ok = i < s_end;
       const int64_t row = r0 + (ok ? i : 0);
-      wgt = ok ? (rw ? rw[row] : 1.0) : 0.0;
+      const double wv = rwp[has_rw ? row : 0];
       const double* xr = w.XW + row * WS_KCAP + c;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        av[t] = (t >= ti_lo && t < nti) ? xr[16 * (ibase + t)] : 0.0;
-        bv[t] = t < ntj ? xr[16 * (4 * wj + t)] : 0.0;
+        av[t] = xr[16 * min(ibase + t, ta_max)];
+        bv[t] = xr[16 * min(4 * wj + t, ta_max)];
       }
+      wgt = ok ? (has_rw ? wv : 1.0) : 0.0;
     };
     auto mma = [&](const double(&av)[4], const double(&bv)[4], double wgt) {
 #pragma unroll
@@ -677,13 +684,24 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
         }
       }
     };
-    double a0[4], b0[4], a1[4], b1[4], w0 = 0.0, w1 = 0.0;
-    if (s_begin < s_end) load(s_begin, a0, b0, w0);
-    for (int64_t s = s_begin; s < s_end; s += 8) {
-      if (s + 4 < s_end) load(s + 4, a1, b1, w1);
+    // (four register sets, three steps of loads ahead of the MFMAs: with one step ahead a wavefront made a memory
+    //  round trip per eight rows, a dozen of them per row-split append -- the kernel ran at a third of the HBM rate,
+    //  51-81 us per pass on the headline path; the products are accumulated in the same order as before)
+    // (no conditions around the loads or the products either: a step beyond the wavefront's rows reads row 0 of the
+    //  block with weight zero)
+    double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4], w0, w1, w2, w3;
+    load(s_begin, a0, b0, w0);
+    load(s_begin + 4, a1, b1, w1);
+    load(s_begin + 8, a2, b2, w2);
+    for (int64_t s = s_begin; s < s_end; s += 16) {
+      load(s + 12, a3, b3, w3);
       mma(a0, b0, w0);
-      if (s + 8 < s_end) load(s + 8, a0, b0, w0);
-      if (s + 4 < s_end) mma(a1, b1, w1);
+      load(s + 16, a0, b0, w0);
+      mma(a1, b1, w1);
+      load(s + 20, a1, b1, w1);
+      mma(a2, b2, w2);
+      load(s + 24, a2, b2, w2);
+      mma(a3, b3, w3);
     }
   }
   if (row_split) {  // parts 0..3 in order: store, add + store, add + store, add (and write below)
