@@ -600,7 +600,7 @@ __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a)
 // r of lane l is row (l >> 4) + 4 r, lane slot l & 15: a row of R is stored as one 128-byte segment.
 // (resid_ws_kernel walks a row per thread: every lane of a load is its own cache line, 83 us at K = 268.)
 // ---------------------------------------------------------------------------------------------
-constexpr int RM_WAVES = 4;
+constexpr int RM_WAVES = 8;   // (4: 30.6 us per pass on the headline path, 8 or 16: 26.6 us -- six 16-row tiles per wavefront were a chain of six)
 constexpr int RM_U = 4;  // 16-position groups per batch (two batches in flight)
 
 __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) {
@@ -624,6 +624,8 @@ __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) 
   }
   __syncthreads();
   const int i16 = lane & 15, q = lane >> 4;
+  const bool has_rw = a.rw != nullptr;
+  const double* rwp = has_rw ? a.rw : a.y;  // (no row weights: any readable address)
   const int ngroups = K >> 4;
   const int ntiles = (int)((nrows + 15) >> 4);
   double loss = 0.0;  // of lane slot i16 over this lane's rows
@@ -633,10 +635,21 @@ __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) 
     const double* xp = a.XW + rl * WS_KCAP + 4 * q;
     slm_d4 acc = slm_d4{0.0, 0.0, 0.0, 0.0};
     slm_d4 xa[RM_U], xb[RM_U];
+    // targets and row weights of the four rows this lane finishes: asked for now, with the first columns (at the end
+    // of the tile each pair was a round trip of its own before the row could be stored)
+    double yv[4], mv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = row0 + q + 4 * r;
+      const int64_t rc = row < rend ? row : rend - 1;
+      yv[r] = a.y[rc];
+      mv[r] = rwp[has_rw ? (int64_t)i16 * a.rw_stride + rc : 0];
+    }
+    // (loads without conditions -- a group beyond K is read from the last one and not used: with the loads under
+    //  `if (g0 + u < ngroups)` the compiler could not count them and drained the queue before every batch of MFMAs)
     auto load = [&](slm_d4(&xv)[RM_U], int g0) {
 #pragma unroll
-      for (int u = 0; u < RM_U; ++u)
-        if (g0 + u < ngroups) xv[u] = *reinterpret_cast<const slm_d4*>(xp + 16 * (g0 + u));
+      for (int u = 0; u < RM_U; ++u) xv[u] = *reinterpret_cast<const slm_d4*>(xp + 16 * min(g0 + u, ngroups - 1));
     };
     auto compute = [&](const slm_d4(&xv)[RM_U], int g0) {
 #pragma unroll
@@ -650,18 +663,18 @@ __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) 
     };
     load(xa, 0);
     for (int g0 = 0; g0 < ngroups; g0 += 2 * RM_U) {
-      if (g0 + RM_U < ngroups) load(xb, g0 + RM_U);
+      load(xb, g0 + RM_U);
       compute(xa, g0);
-      if (g0 + 2 * RM_U < ngroups) load(xa, g0 + 2 * RM_U);
-      if (g0 + RM_U < ngroups) compute(xb, g0 + RM_U);
+      load(xa, g0 + 2 * RM_U);
+      compute(xb, g0 + RM_U);
     }
     if ((mask >> i16) & 1u) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t row = row0 + q + 4 * r;
         if (row < rend) {
-          const double m = a.rw ? a.rw[(int64_t)i16 * a.rw_stride + row] : 1.0;
-          const double err = acc[r] - a.y[row];
+          const double m = has_rw ? mv[r] : 1.0;
+          const double err = acc[r] - yv[r];
           const double res = err * m;
           a.R[row * SPLIT_RSTRIDE + i16] = res;
           loss = __builtin_fma(res, err, loss);
