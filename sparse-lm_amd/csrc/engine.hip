@@ -1916,7 +1916,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       }
       hipLaunchKernelGGL(ws_select_kernel, dim3(1), dim3(WS_THREADS), 0, s, ta, wa);
       hipLaunchKernelGGL(ws_gather_kernel, dim3((unsigned)std::min<int64_t>((n + 31) / 32, 1024), WS_KCAP / 32), dim3(256), 0, s, wa);
-      hipLaunchKernelGGL(ws_gram_kernel, dim3((unsigned)wa.nblk, (unsigned)wa.n_sets, 4 * WS_GRAM_ZCHUNKS), dim3(WS_GRAM_THREADS), 0, s,
+      hipLaunchKernelGGL(ws_gram_kernel, dim3((unsigned)wa.nblk, (unsigned)wa.n_sets, 1), dim3(WS_GRAM_THREADS), 0, s,
                          wa);
       if (wa.Gx)  // (zero where this pass builds nothing, so the unconditional all-reduce below is harmless)
         (void)hipMemsetAsync(wa.Gx, 0, sizeof(double) * (size_t)wa.n_sets * WS_KCAP * WS_KCAP, s);

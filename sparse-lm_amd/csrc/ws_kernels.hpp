@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
 // ---------------------------------------------------------------------------------------------
 typedef double ws_d4 __attribute__((ext_vector_type(4)));
 constexpr int WS_GRAM_THREADS = 512;
-constexpr int WS_GRAM_ZCHUNKS = 4;  // grid.z = 4 column quarters x this many row chunks
+constexpr int WS_GRAM_ZCHUNKS = 4;  // slices of a row block: 4 column quarters x this many chunks of tile rows
 
 __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
   if (!w.ws->building) return;
@@ -611,27 +611,17 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles = K >> 4;
-  const int wj = 2 * ((int)blockIdx.z & 3) + (wave & 1);
-  const int ntj = min(4, max(0, tiles - 4 * wj));
   // An append touches at most four tile rows.  With the usual mapping only the wavefronts whose tile
   // rows those are would work (2 of 8, 98 dependent steps each: 0.13 ms of latency); instead the four
   // wavefront pairs split the ROWS of the block between them, all on the new tile rows, and fold
   // their accumulators through LDS in a fixed order.
   // Larger appends (a miss quadruples the cap) are cut into chunks of four tile rows, one per value of
-  // blockIdx.z >> 2, each handled the same way (up to 16 new tile rows = 256 columns; the generic
+  // slice >> 2 below, each handled the same way (up to 16 new tile rows = 256 columns; the generic
   // mapping left most wavefronts idle on them: 0.44 ms for 170 new columns).
   // (a small fresh selection -- the first 112 columns of a path: 7 x 7 tiles -- keeps half of the wavefronts of ONE
   //  workgroup per row block busy under the usual mapping, each walking all rows of the block: 90 us; split by rows
   //  like an append it is eight wavefronts of two workgroups on a quarter of the rows each)
   const bool row_split = (tile_lo > 0 || tiles <= 8) && tiles - tile_lo <= 4 * WS_GRAM_ZCHUNKS;
-  const int zhi = (int)blockIdx.z >> 2;
-  if (row_split ? (tile_lo + 4 * zhi >= tiles) : (zhi >= 2)) return;
-  const int part = row_split ? (wave >> 1) : 0;
-  const int ibase = row_split ? tile_lo + 4 * zhi : 4 * (4 * zhi + (wave >> 1));
-  const int ti_lo = row_split ? 0 : max(0, tile_lo - ibase);  // first tile row of this wave to do
-  const int nti = min(4, max(0, tiles - ibase));
-  const bool active = ti_lo < nti && ntj > 0;
-  if (!row_split && !active) return;
   const int set = blockIdx.y;
   const int64_t b = blockIdx.x;
   const int64_t base = w.n / w.nblk, rem = w.n % w.nblk;
@@ -639,10 +629,26 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
   const int64_t nrows = base + (b < rem ? 1 : 0);
   const double* rw = w.rw ? w.rw + (int64_t)w.set_lane[set] * w.rw_stride : nullptr;
   // rows of this wavefront: everything, or the part-th quarter (in steps of four rows)
+  const int part = row_split ? (wave >> 1) : 0;
   const int64_t steps = (nrows + 3) >> 2;
   const int64_t s_begin = row_split ? 4 * (steps * part / 4) : 0;
   const int64_t s_end = row_split ? min(nrows, 4 * (steps * (part + 1) / 4)) : nrows;
 
+  // The (column quarter, chunk of tile rows) slices of this row block, one after the other in ONE workgroup.  As
+  // grid.z they were sixteen workgroups per row block of which an append on the headline path needs two: the other
+  // fourteen still had to be started, each holding the CU's registers and 64 KB of its LDS until it had read the
+  // control block and left -- half of the kernel's 67 us.
+  for (int slice = 0; slice < 4 * WS_GRAM_ZCHUNKS; ++slice) {
+  const int zhi = slice >> 2;
+  if (8 * (slice & 3) >= tiles) continue;  // (no column of this quarter exists)
+  if (row_split ? (tile_lo + 4 * zhi >= tiles) : (zhi >= 2)) continue;
+  const int wj = 2 * (slice & 3) + (wave & 1);
+  const int ntj = min(4, max(0, tiles - 4 * wj));
+  const int ibase = row_split ? tile_lo + 4 * zhi : 4 * (4 * zhi + (wave >> 1));
+  const int ti_lo = row_split ? 0 : max(0, tile_lo - ibase);  // first tile row of this wave to do
+  const int nti = min(4, max(0, tiles - ibase));
+  const bool active = ti_lo < nti && ntj > 0;
+  if (!row_split && !active) continue;  // (per wavefront: this mode has no barrier)
   ws_d4 acc[4][4];
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti)
@@ -719,8 +725,8 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
       }
       __syncthreads();
     }
-    if (part != 3 || !active) return;
   }
+  if (!row_split || (part == 3 && active)) {
   // partials are stored tile by tile, the row blocks of one tile next to each other:
   // part[set][tile (I, J)][b][16 x 16] -- the reduce kernel then walks 2 KiB strides, not 2 MiB ones
 #pragma unroll
@@ -734,6 +740,9 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[(kk + 4 * r) * 16 + c] = acc[ti][tj][r];
     }
+  }
+  }
+  if (row_split) __syncthreads();  // (the fold buffer is used again by the next slice)
   }
 }
 
