@@ -657,8 +657,6 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
 
   const int kk = lane >> 4, c = lane & 15;
   if (active) {
-    // two steps in flight: the loads of step s + 4 are issued before the 16 MFMAs of step s (the loop is
-    // otherwise one load latency per 4 rows: ~100 dependent steps per wavefront)
     // (the row weight is applied in mma(), not at the load, so nothing waits on a load before the MFMAs)
     // (every load of a step is issued whatever the tile pattern: a tile this wavefront does not need is read from
     //  a column block that exists and never used.  With the loads under conditions the compiler could not count
@@ -690,11 +688,10 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
         }
       }
     };
-    // (four register sets, three steps of loads ahead of the MFMAs: with one step ahead a wavefront made a memory
-    //  round trip per eight rows, a dozen of them per row-split append -- the kernel ran at a third of the HBM rate,
-    //  51-81 us per pass on the headline path; the products are accumulated in the same order as before)
-    // (no conditions around the loads or the products either: a step beyond the wavefront's rows reads row 0 of the
-    //  block with weight zero)
+    // Four register sets, three steps (twelve rows) of loads ahead of the MFMAs of a step, and no conditions around
+    // the loads or the products: a step beyond the wavefront's rows reads row 0 of the block with weight zero.  (With
+    // `if (s + 4 < s_end) load(...)` the waits became vmcnt(0): a memory round trip per step.)  The products are
+    // accumulated in row order whatever the depth.
     double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4], w0, w1, w2, w3;
     load(s_begin, a0, b0, w0);
     load(s_begin + 4, a1, b1, w1);
