@@ -21,7 +21,7 @@ of the timings and the per-rank device report.
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     -- achieved HBM GB/s of the kernel that streams X, from HIP events recorded on the
                   engine's own stream inside the timed region, against the 8 TB/s peak;
-  cpu_baseline -- the oracle's C twin (OpenMP, all host cores) timed on a bounded prefix of the same
+  cpu_baseline -- the oracle's C twin (OpenMP, as many threads as the cgroup grants CPUs) timed on a bounded prefix of the same
                   path on rank 0 at N = 1 (a reported baseline, not the target);
   ranks        -- rank -> device of every rank and the imbalance (slowest rank / mean rank);
   extra_legs   -- measured AFTER the timed region, never part of `value`:
@@ -45,7 +45,33 @@ import sys
 import threading
 import time
 
-import numpy as np
+
+
+def _host_cpu_share() -> int:
+    """CPUs this process may actually use: its affinity mask cut down to the cgroup's quota.  (A one-GPU box of the pool
+    shows all 256 hardware threads of the host but grants 16 CPUs' worth of time: 256 OpenMP threads on such a share are
+    throttled into a third of what 16 deliver, and noisily so.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, (quota + period // 2) // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+HOST_CPUS = _host_cpu_share()
+# (before numpy / the OpenMP runtime of the oracle's C twin are loaded: they size their pools once)
+os.environ.setdefault("OMP_NUM_THREADS", str(HOST_CPUS))
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "sparse-lm_amd")):
@@ -137,7 +163,7 @@ def cpu_baseline(ds, alphas, L, tol, gpu_betas, budget_s):
             from sklearn.linear_model import lasso_path
             from threadpoolctl import threadpool_limits
 
-            threads = min(64, os.cpu_count() or 1)
+            threads = min(64, HOST_CPUS)
             Xf = np.asfortranarray(X)
             with threadpool_limits(limits=threads):
                 t0 = time.perf_counter()
