@@ -468,33 +468,41 @@ __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a)
   const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
 
   bool all_zero = a.ctl != nullptr;  // cold start: e = -y without reading X (as rowdot_ring_kernel)
-  if (all_zero) {
-    for (int l = 0; l < a.n_lanes; ++l)
-      if (((mask >> l) & 1u) && !a.ctl[l].zzero) all_zero = false;
+  if (all_zero) {  // (lane l of every wavefront reads control block l: one round trip, not one per lane slot)
+    const bool moved = lane < a.n_lanes && ((mask >> lane) & 1u) && !a.ctl[lane < a.n_lanes ? lane : 0].zzero;
+    all_zero = __ballot(moved) == 0ull;
   }
   if (all_zero) {
-    double ls[SPLIT_LANES];
+    // thread = (row of a group of XZ_WAVES * 4, lane slot): a wavefront stores four whole rows of R, 512 contiguous
+    // bytes (one thread per row wrote its sixteen slots one by one, sixty-four lines per store instruction: 18 us
+    // for the 12.8 MB of the headline problem's first pass)
+    const int l = tid & 15;
+    const bool on = ((mask >> l) & 1u) != 0u;
+    double ls = 0.0;
+    const bool has_rw = a.rw != nullptr;
+    const double* rwp = has_rw ? a.rw + (int64_t)l * a.rw_stride : a.y;  // (no row weights: any readable address)
+    for (int64_t i0 = tid >> 4; i0 < nrows; i0 += 8 * XZ_WAVES * 4) {  // eight rows per round: their loads go out together
+      double yv[8], mv[8];
 #pragma unroll
-    for (int l = 0; l < SPLIT_LANES; ++l) ls[l] = 0.0;
-    for (int64_t i = tid; i < nrows; i += XZ_WAVES * 64) {
-      const int64_t row = r0 + i;
-      const double e = -a.y[row];
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = i0 + u * (XZ_WAVES * 4);
+        const int64_t row = r0 + (i < nrows ? i : 0);
+        yv[u] = a.y[row];
+        mv[u] = rwp[row];
+      }
 #pragma unroll
-      for (int l = 0; l < SPLIT_LANES; ++l) {
-        if ((mask >> l) & 1u) {
-          const double m = a.rw ? a.rw[(int64_t)l * a.rw_stride + row] : 1.0;
-          a.R[row * SPLIT_RSTRIDE + l] = e * m;
-          ls[l] = __builtin_fma(e * m, e, ls[l]);
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = i0 + u * (XZ_WAVES * 4);
+        if (on && i < nrows) {
+          const double e = -yv[u], m = has_rw ? mv[u] : 1.0;
+          a.R[(r0 + i) * SPLIT_RSTRIDE + l] = e * m;
+          ls = __builtin_fma(e * m, e, ls);
         }
       }
     }
-#pragma unroll
-    for (int l = 0; l < SPLIT_LANES; ++l) {
-      double t = ls[l];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-      if (lane == 0) red[wave][l] = t;
-    }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    if (lane < SPLIT_LANES) red[wave][lane] = ls;
     __syncthreads();
     if (tid < SPLIT_LANES && ((mask >> tid) & 1u)) {
       double t = 0.0;
