@@ -589,10 +589,10 @@ __global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// (iii) partial Grams with v_mfma_f64_16x16x4_f64.  Grid (nblk, n_sets, 4 WS_GRAM_ZCHUNKS); 8 wavefronts per
+// (iii) partial Grams with v_mfma_f64_16x16x4_f64.  Grid (nblk, n_sets); 8 wavefronts per
 // workgroup laid out 4 x 2, each owning a 4 x 4 block of 16x16 output tiles, so a workgroup covers
-// 256 x 128 of the 512 x 512 capacity and blockIdx.z picks which (2 row halves x 4 column quarters;
-// workgroups beyond K return at once).  16 accumulator tiles = 128 registers per lane, which is why
+// 256 x 128 of the 512 x 512 capacity at a time and walks the slices that exist (2 row halves x 4 column
+// quarters; see the loop over `slice`).  16 accumulator tiles = 128 registers per lane, which is why
 // it is not one 1024-thread workgroup.  Only the tile
 // rows that hold new positions (I >= k_new / 16) are computed; the reduce kernel mirrors them into
 // the columns.  Operand maps (guide "Fragment layout"): lane l holds A[i = l & 15][k = l >> 4] and
