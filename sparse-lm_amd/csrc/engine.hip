@@ -437,7 +437,8 @@ extern "C" int slm_host_alloc(size_t bytes, void** out) {
   if (!out || bytes == 0) return fail(SLM_ERR_BAD_ARG, "slm_host_alloc: NULL out or zero size");
   *out = nullptr;
   void* ptr = nullptr;
-  const hipError_t e = hipHostMalloc(&ptr, bytes, hipHostMallocDefault);
+  // (portable: the block serves whichever device the calling process's engines sit on)
+  const hipError_t e = hipHostMalloc(&ptr, bytes, hipHostMallocPortable);
   if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
     (void)hipGetLastError();
     return fail(SLM_ERR_OOM, "no %zu bytes of page-locked host memory", bytes);
