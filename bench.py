@@ -82,14 +82,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 PRIMING_PATHS = 3  # untimed solves of the path right after the dataset is made (set-up, see main)
 
 
-def measured_traffic(n, p, lanes):
+def measured_traffic(n, p, lanes, kernel):
     """HBM bytes per gradient launch from the committed PMC passes (profiles/roofline_traffic.json,
     produced by tools/summarize_prof.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`), or
-    None when no counter run exists for this (n, p)."""
+    None when no counter run exists for this (n, p) AND this kernel: the figure is a committed measurement, not
+    one of this run, so it is only quoted for the kernel it was taken on."""
     try:
         with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
             t = json.load(f)
-        if t["workload"] == {"n": n, "p": p, "lanes": lanes}:
+        if t["workload"] == {"n": n, "p": p, "lanes": lanes} and kernel in t["kernel"]:
             return t["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -255,102 +256,146 @@ class Watchdog:
         self._t.cancel()
 
 
-def leg_config4_grid(eng, rank, world, n, p, device_id=0, streams=3):
-    """BASELINE config 4 on the grid mode: 5 folds x 10 l1_ratio, each a 50-alpha SparseGroupLasso path; the
-    50 (fold, l1_ratio) units are dealt to the ranks (LPT by cost), sixteen lanes per call.  Every rank
-    generates the SAME (X, y) (same seed): X replicated per GPU, no data-path collective.  Timed twice: the rank's
-    calls one after the other on one engine, and -- when the rank has more than one call to make -- dealt to
-    `streams` standing engines (HIP streams) of its GPU, a dataset copy and a host thread each."""
-    from sparselm_amd import _engine
-    from sparselm_amd import distributed as D
+class Config4:
+    """BASELINE config 4 as a device-resident problem: 5 folds x 10 l1_ratio, each a 50-alpha SparseGroupLasso path =
+    2500 fits on make_regression-law data with 500 shuffled groups of 10 (25 informative).  `calls_of(world, rank)` is
+    the share of one rank: the path POINTS of the 50 (fold, l1_ratio) units are dealt to the lane slots of all ranks by
+    `distributed.plan_lane_calls` (sixteen lanes per call; whole paths while there are more units than slots, evenly
+    spread pieces of paths otherwise).  Every rank generates the SAME (X, y) (same seed): X replicated per GPU, no
+    data-path collective."""
 
-    G = p // 10
-    rng = np.random.default_rng(1)
-    groups = rng.permutation(np.repeat(np.arange(G), 10))
-    coef = np.zeros(p)
-    for g in rng.choice(G, 25, replace=False):
-        coef[groups == g] = 100.0 * rng.uniform(size=10)
-    ds = eng.synthetic_dataset(n, p, seed=11, coef=coef, noise_sd=10.0)
-    copies = [ds]
-    try:
+    K = 50
+
+    def __init__(self, eng, n, p):
+        from sparselm_amd import _engine
+
+        self.G = G = p // 10
+        rng = np.random.default_rng(1)
+        self.groups = groups = rng.permutation(np.repeat(np.arange(G), 10))
+        coef = np.zeros(p)
+        for g in rng.choice(G, 25, replace=False):
+            coef[groups == g] = 100.0 * rng.uniform(size=10)
+        self.ds = ds = eng.synthetic_dataset(n, p, seed=11, coef=coef, noise_sd=10.0)
+        self.copies = [ds]
         ds.set_groups(groups, G)
         g0, _ = ds.gradient(None)
         gnorm = np.sqrt(np.bincount(groups, weights=g0 * g0, minlength=G))
         bmax, amax1 = float(gnorm.max()), float(np.max(np.abs(g0)))
-        l1_ratios = np.linspace(0.05, 0.95, 10)
         folds = np.random.default_rng(0).permutation(n) % 5  # KFold(5, shuffle=True)
-        masks = [(folds != f).astype(float) for f in range(5)]
-        units = [(f, r) for f in range(5) for r in l1_ratios]  # fold-major: a batch shares a row mask and its Gram
-        # cost model for the deal: every unit is a 50-point path; the l1-heavy ones end with more columns
-        mine = [units[i] for i in D.shard_units(len(units), rank, world, costs=[1.0 + 0.3 * r for _, r in units])]
-        lanes = _engine.MAX_LANES
-        batches = [mine[k0 : k0 + lanes] for k0 in range(0, len(mine), lanes)]
+        self.masks = [(folds != f).astype(float) for f in range(5)]
+        # fold-major: a call shares row masks and their Grams
+        self.units = [(f, r) for f in range(5) for r in np.linspace(0.05, 0.95, 10)]
+        self.unit_pts = []
+        for f, r in self.units:
+            amax = min(bmax / (1 - r), amax1 / r)
+            al = np.geomspace(amax, 1e-3 * amax, self.K)
+            self.unit_pts.append(np.c_[r * al, (1 - r) * al, 0 * al])
+        self.lanes = _engine.MAX_LANES
 
-        def run_batch(d, batch):
-            split = max(1, lanes // len(batch))  # spare lane slots: cut each path into contiguous ranges
-            specs = []
-            for f, r in batch:
-                amax = min(bmax / (1 - r), amax1 / r)
-                al = np.geomspace(amax, 1e-3 * amax, 50)
-                pts = np.c_[r * al, (1 - r) * al, 0 * al]
-                for part in np.array_split(np.arange(50), split):
-                    specs.append(dict(points=pts[part], row_weight=masks[f], n_eff=int(masks[f].sum())))
-            out = d.solve_lanes(specs)
-            if not all(o.converged for o in out):
-                raise RuntimeError("config 4: a path did not converge")
-            return out[0].grad_launches
+    def calls_of(self, world, rank):
+        from sparselm_amd import distributed as D
 
-        def run(n_streams):
-            todo, lock, passes, errors = list(range(len(batches))), threading.Lock(), [0], []
+        return D.plan_lane_calls([self.K] * len(self.units), [f for f, _ in self.units], world, self.lanes)[rank]
 
-            def work(i):
-                try:
-                    while True:
-                        with lock:
-                            if not todo or errors:
-                                return
-                            b = todo.pop(0)
-                        k = run_batch(copies[i], batches[b])
-                        with lock:
-                            passes[0] += k
-                except BaseException as exc:
+    def run_call(self, d, call, keep=None):
+        from sparselm_amd import _engine
+
+        specs = []
+        for lane in call:
+            pts, gam = _engine.lane_points([self.unit_pts[u][idx] for u, idx in lane])
+            f = self.units[lane[0][0]][0]
+            specs.append(dict(points=pts, extrap=gam, row_weight=self.masks[f], n_eff=int(self.masks[f].sum())))
+        out = d.solve_lanes(specs)
+        if not all(o.converged for o in out):
+            raise RuntimeError("config 4: a path did not converge")
+        if keep is not None:  # (unit, point) -> coefficients, for the checks
+            for lane, o in zip(call, out):
+                at = 0
+                for u, idx in lane:
+                    for k, i in enumerate(idx):
+                        keep[(u, i)] = o.betas[at + k].copy()
+                    at += len(idx)
+        return out[0].grad_launches
+
+    def run(self, calls, n_streams=1):
+        """(seconds, passes) of `calls`, one after the other on one engine or dealt to `n_streams` standing ones"""
+        todo, lock, passes, errors = list(range(len(calls))), threading.Lock(), [0], []
+
+        def work(i):
+            try:
+                while True:
                     with lock:
-                        errors.append(exc)
+                        if not todo or errors:
+                            return
+                        b = todo.pop(0)
+                    k = self.run_call(self.copies[i], calls[b])
+                    with lock:
+                        passes[0] += k
+            except BaseException as exc:
+                with lock:
+                    errors.append(exc)
 
-            threads = [threading.Thread(target=work, args=(i,)) for i in range(1, n_streams)]
-            for c in copies[:n_streams]:
-                c.engine.synchronize()
-            t0 = time.perf_counter()
-            for t in threads:
-                t.start()
-            work(0)
-            for t in threads:
-                t.join()
-            for c in copies[:n_streams]:
-                c.engine.synchronize()
-            if errors:
-                raise errors[0]
-            return time.perf_counter() - t0, passes[0]
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(1, n_streams)]
+        for c in self.copies[:n_streams]:
+            c.engine.synchronize()
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        work(0)
+        for t in threads:
+            t.join()
+        for c in self.copies[:n_streams]:
+            c.engine.synchronize()
+        if errors:
+            raise errors[0]
+        return time.perf_counter() - t0, passes[0]
 
-        run(1)  # warm (column-major copy, buffers)
-        seconds, passes = run(1)
-        out = {"seconds": seconds, "passes": passes, "units": len(mine), "calls": len(batches)}
-        n_streams = min(streams, len(batches))
-        if n_streams > 1:
-            for _ in range(n_streams - 1):
-                c = ds.clone()
-                c.set_groups(groups, G)
-                copies.append(c)
-            run(n_streams)  # warm the copies
-            out["seconds_streams"], _ = run(n_streams)
-            out["streams"] = n_streams
-        return out
-    finally:
-        for c in copies[1:]:
+    def add_streams(self, n_streams):
+        while len(self.copies) < n_streams:
+            c = self.ds.clone()
+            c.set_groups(self.groups, self.G)
+            self.copies.append(c)
+
+    def close(self):
+        for c in self.copies[1:]:
             e = c.engine
             c.close()
             e.close()
-        ds.close()
+        self.ds.close()
+
+
+def leg_config4_grid(eng, rank, world, n, p, device_id=0, streams=3, emulate_world=8):
+    """BASELINE config 4 on the grid mode (`Config4`).  Timed: the rank's calls one after the other on one engine; dealt
+    to `streams` standing engines (HIP streams) of its GPU when it has more than one call to make; and, at world == 1,
+    the share of every rank of an `emulate_world`-rank job, one after the other on this GPU (what each of 8 GPUs would
+    be doing side by side)."""
+    c4 = Config4(eng, n, p)
+    try:
+        def points(calls):
+            return sum(len(idx) for call in calls for lane in call for _, idx in lane)
+
+        mine = c4.calls_of(world, rank)
+        c4.run(mine)  # warm (column-major copy, buffers)
+        seconds, passes = min(c4.run(mine) for _ in range(2))
+        out = {"seconds": seconds, "passes": passes, "calls": len(mine), "points": points(mine)}
+        if world == 1 and emulate_world > 1:
+            shares = []
+            for r in range(emulate_world):
+                calls = c4.calls_of(emulate_world, r)
+                c4.run(calls)
+                sec, pas = min(c4.run(calls) for _ in range(2))
+                shares.append({"seconds": sec, "passes": pas, "lanes": [len(c) for c in calls], "points": points(calls),
+                               "row_masks": [len({c4.units[u][0] for lane in c for u, _ in lane}) for c in calls]})
+            out["emulated"] = {"world": emulate_world, "shares": shares}
+        n_streams = min(streams, len(mine))
+        if n_streams > 1:
+            c4.add_streams(n_streams)
+            c4.run(mine, n_streams)  # warm the copies
+            out["seconds_streams"], _ = c4.run(mine, n_streams)
+            out["streams"] = n_streams
+        return out
+    finally:
+        c4.close()
 
 
 def leg_concurrent_paths(eng, device_id, rank, n, p, K, tol, lanes, streams=3, steps=10):
@@ -638,7 +683,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(n, p, lanes_used),
+                "traffic": measured_traffic(n, p, lanes_used, "xtr_mfma_kernel" if split else "grad_fused_kernel"),
                 "traffic_unit": "HBM bytes per launch (PMC, profiles/roofline_traffic.json)",
                 "kernel": (f"xtr_mfma_kernel (X^T R of the split pass on the matrix cores, lanes={lanes_used})" if split
                            else f"grad_fused_kernel (lanes={lanes_used})"),
@@ -668,10 +713,13 @@ def main():
         real_stdout = os.dup(1)  # (a leg may have fd 1 pointing at stderr when the limit strikes)
 
         def expire():
+            # the contract line goes out (the timed region is long over), then every rank leaves with a code of its own:
+            # a stuck leg must not read as success to torchrun / the driver
             if out is not None:
                 legs["timed_out_after_s"] = args.extra_timeout
                 os.write(real_stdout, (json.dumps(out) + "\n").encode())
-            os._exit(0)
+            os.write(2, f"[bench] rank {rank}: extra legs exceeded {args.extra_timeout:.0f} s, leaving with status 3\n".encode())
+            os._exit(3)
 
         with Watchdog(args.extra_timeout, expire):
             for name, fn in (("config4_grid", lambda: leg_config4_grid(eng, rank, world, n, p, device_id)),
@@ -691,17 +739,35 @@ def main():
                     legs[name] = {"error": [q.get("error") for q in parts if not q["ok"]][:2]}
                 elif name == "config4_grid":
                     secs = [q["seconds"] for q in parts]
+                    pts = [q["points"] for q in parts]
                     legs[name] = {
-                        "what": "SparseGroupLasso 5 folds x 10 l1_ratio x 50 alpha = 2500 fits at n=100k p=5k, the 50 "
-                        "(fold, l1_ratio) units dealt to the ranks (LPT), 16 lanes per call; strong scaling; *_streams: a "
-                        "rank's calls dealt to standing engines (HIP streams) of its GPU where it has more than one to make",
+                        "what": "SparseGroupLasso 5 folds x 10 l1_ratio x 50 alpha = 2500 fits at n=100k p=5k; the path points "
+                        "of the 50 (fold, l1_ratio) units dealt to the lane slots of the ranks (distributed.plan_lane_calls), 16 "
+                        "lanes per call; strong scaling; *_streams: a rank's calls dealt to standing engines (HIP streams) of "
+                        "its GPU where it has more than one to make",
                         "fits_per_s": 2500.0 / max(secs), "seconds_per_grid": max(secs), "seconds_per_rank": secs,
                         "seconds_per_grid_streams": (max(q["seconds_streams"] for q in parts)
                                                      if all("seconds_streams" in q for q in parts) else None),
                         "streams": parts[0].get("streams", 1), "calls_per_rank": [q["calls"] for q in parts],
-                        "units_per_rank": [q["units"] for q in parts], "passes_per_rank": [q["passes"] for q in parts],
+                        "points_per_rank": pts, "passes_per_rank": [q["passes"] for q in parts],
                         "imbalance_max_over_mean": max(secs) / (sum(secs) / len(secs)),
                     }
+                    if "emulated" in parts[0]:
+                        em = parts[0]["emulated"]
+                        sh = em["shares"]
+                        worst = max(q["seconds"] for q in sh)
+                        legs["config4_grid_emulated_world8"] = {
+                            "what": f"the same grid as dealt to {em['world']} ranks: every rank's share timed on THIS GPU, one after "
+                            "the other (on a node each runs on its own GPU, X replicated, no collective); speed-up = the "
+                            "one-GPU grid time above / the slowest share",
+                            "world": em["world"], "full_grid_s": max(secs), "max_share_s": worst,
+                            "speedup_full_over_max_share": max(secs) / worst,
+                            "share_seconds": [q["seconds"] for q in sh], "share_passes": [q["passes"] for q in sh],
+                            "share_points": [q["points"] for q in sh], "share_lanes": [q["lanes"] for q in sh],
+                            "share_row_masks": [q["row_masks"] for q in sh], "full_grid_passes": parts[0]["passes"],
+                            "points_imbalance_max_over_mean": max(q["points"] for q in sh) / (sum(q["points"] for q in sh) / len(sh)),
+                            "seconds_imbalance_max_over_mean": worst / (sum(q["seconds"] for q in sh) / len(sh)),
+                        }
                 elif name == "concurrent_paths":
                     legs[name] = {
                         "what": "the headline path on three engines (streams) of ONE GPU at once, a dataset and a host thread "

@@ -1882,7 +1882,10 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   };
   if (use_ws) {
     const int rc = ws_setup(false);
-    if (rc == SLM_ERR_OOM && !split) {
+    // (row-sharded: a rank that fell back on its own would stop entering the per-pass Gram all-reduce while its peers
+    //  still do -- mismatched collectives, which RCCL answers with a hang: no memory for the working set is an error
+    //  there, reported by the rank that ran out, and the caller frees memory or passes SLM_FLAG_NO_WORKING_SET on all)
+    if (rc == SLM_ERR_OOM && !split && !eng->sharded()) {
       ws_release();
       use_ws = false;
     } else if (rc != SLM_OK) {

@@ -46,14 +46,20 @@ class DatasetCache:
 
         try:
             import xxhash
-        except ImportError:  # no digest, no cache
-            return None
+
+            new_digest = xxhash.xxh3_128
+        except ImportError:  # (xxhash is optional: the standard library's blake2b, a few times slower, serves as well)
+            import hashlib
+
+            def new_digest():
+                return hashlib.blake2b(digest_size=16)
+
         X = np.asarray(X)
         if X.nbytes > self.max_bytes or X.ndim != 2:
             return None
         X = np.asarray(X, dtype=np.float64)
         fortran = X.flags.f_contiguous and not X.flags.c_contiguous
-        h = xxhash.xxh3_128()
+        h = new_digest()
         h.update(np.ascontiguousarray(X.T if fortran else X))  # (a view when the layout already fits: no copy)
         h.update(np.ascontiguousarray(y, dtype=np.float64))
         if row_weight is not None:
@@ -87,7 +93,7 @@ class DatasetCache:
             item = self._items.get(key)
             if item is not None and item[0] is ds:
                 item[3] = False
-            elif item is None:
+            elif item is None or not getattr(item[0], "_h", None):  # (a closed dataset -- its engine went -- gives way)
                 self._clock += 1
                 self._items[key] = [ds, x_mean, y_mean, False, self._clock]
                 while len(self._items) > self.capacity:
@@ -100,11 +106,22 @@ class DatasetCache:
         for d in evict:
             d.close()
 
-    def clear(self):
+    def discard(self, ds, key):
+        """A dataset handed out by `acquire` that turned out unusable: out of the cache, closed."""
         with self._lock:
-            items, self._items = list(self._items.values()), {}
-        for item in items:
-            item[0].close()
+            item = self._items.get(key) if key is not None else None
+            if item is not None and item[0] is ds:
+                del self._items[key]
+        ds.close()
+
+    def clear(self):
+        import os
+
+        with self._lock:
+            items, self._items = list(self._items.items()), {}
+        for key, item in items:
+            if key[0] == os.getpid():  # (a forked child never touches its parent's handles)
+                item[0].close()
 
 
 _dataset_cache = DatasetCache()
@@ -137,7 +154,12 @@ class SolveProblem:
             self._key = None
         self._private = not cache
         # (a cached dataset may carry another estimator's groups: always set them)
-        self.ds.set_groups(gidx, n_groups if gidx is not None else None)
+        try:
+            self.ds.set_groups(gidx, n_groups if gidx is not None else None)
+        except BaseException:  # (never leave a cache entry marked busy behind)
+            _dataset_cache.discard(self.ds, self._key)
+            self.ds = None
+            raise
 
     def solve(self, a, b, d, beta0=None, want_group_norms=False):
         """One minimisation with penalty (a, b, d); returns (beta, group_norms or None, info)."""
@@ -219,11 +241,12 @@ def use_backend(backend):
 
 
 def default_tol(n: int, p: int) -> float:
-    """Stopping tolerance when ``solver_options`` names none.  ``tol`` bounds the last prox step relative to
-    ``||beta||``; the distance to the minimiser is about the condition number times that.  Small
-    problems -- the reference's own sizes, often strongly correlated features -- are launch-bound, so two more
-    digits cost little there: 1e-10 below 2^26 matrix entries, 1e-8 (1e-9...2e-8 from the minimiser on the
-    BASELINE designs) above."""
+    """Stopping tolerance when ``solver_options`` names none.  A point is accepted when its KKT residual (the
+    prox-gradient mapping) is below ``tol * mu * ||beta||``, mu the strong-convexity estimate of the face
+    (include/slm_engine.h, ``slm_solve_opts.tol``): ``tol`` bounds the relative distance to the
+    minimiser whatever the conditioning.  Small problems -- the reference's own sizes -- are launch-bound, so two
+    more digits cost little there: 1e-10 below 2^26 matrix entries, 1e-8 (5e-11...2e-8 from scikit-learn's
+    coordinate descent on the BASELINE designs) above."""
     return 1e-10 if int(n) * int(p) < (1 << 26) else 1e-8
 
 

@@ -314,7 +314,7 @@ def path_extrapolation(pts) -> np.ndarray:
     hit = _extrap_cache.get(key)
     if hit is None:
         hit = _path_extrapolation(pts)
-        if len(_extrap_cache) >= 64:
+        if len(_extrap_cache) >= 4096:  # (a grid cut into pieces brings a few hundred distinct ones)
             _extrap_cache.clear()
         _extrap_cache[key] = hit
     return hit.copy()
@@ -341,6 +341,15 @@ def _path_extrapolation(pts) -> np.ndarray:
     ok = (den != 0.0) & np.isfinite(g) & (np.abs(g) <= 10.0)
     gam[2:] = np.where(ok, g, 0.0)
     return gam
+
+
+def lane_points(segments) -> tuple[np.ndarray, np.ndarray]:
+    """(points, extrap) of a lane that walks several pieces of paths one after the other (the lanes
+    ``distributed.plan_lane_calls`` plans): ``segments`` is a list of (K_s, 3) arrays in the order the lane takes
+    them; the secant factors are those of each piece on its own, zero on the first two points of every piece (the
+    two solutions before them belong to another path)."""
+    pts = [np.ascontiguousarray(s, dtype=np.float64).reshape(-1, 3) for s in segments]
+    return np.vstack(pts), np.concatenate([path_extrapolation(s) for s in pts])
 
 
 @dataclass
@@ -673,8 +682,9 @@ class Dataset:
         """Solve up to MAX_LANES independent warm-started paths on ONE pass over X per iteration.
 
         ``lanes``: list of dicts with ``points`` (K_l, 3) and optionally ``a``, ``b``, ``d``,
-        ``beta0``, ``row_weight`` (length n, e.g. a CV-fold mask) and ``n_eff`` (1/n scaling, e.g. the
-        number of training rows).  Returns one ``PathResult`` per lane (shared timing fields).
+        ``beta0``, ``row_weight`` (length n, e.g. a CV-fold mask), ``n_eff`` (1/n scaling, e.g. the
+        number of training rows) and ``extrap`` (K_l secant factors, see ``lane_points``; default: derived from
+        the points).  Returns one ``PathResult`` per lane (shared timing fields).
         """
         nl = len(lanes)
         if not (1 <= nl <= MAX_LANES):
@@ -692,7 +702,10 @@ class Dataset:
         for l, spec in enumerate(lanes):
             pts = np.ascontiguousarray(spec["points"], dtype=np.float64).reshape(-1, 3)
             K = pts.shape[0]
-            gam = path_extrapolation(pts) if extrapolate else np.zeros(K)
+            if spec.get("extrap") is not None:  # (lanes that walk pieces of several paths bring their own factors)
+                gam = _f64(spec["extrap"], "extrap", (K,))
+            else:
+                gam = path_extrapolation(pts) if extrapolate else np.zeros(K)
             cpts = _points_block(pts, gam)
 
             def vec(name, size):
@@ -795,7 +808,9 @@ class _HostPool:
     def __init__(self, cap=1 << 30):
         self.cap, self.idle = cap, 0
         self.free: dict[int, list[int]] = {}
-        self.lock = threading.Lock()
+        # (re-entrant: `_give` runs from weakref.finalize, which a garbage collection inside `_take` / `_give` -- while
+        #  the lock is held -- can trigger on this very thread)
+        self.lock = threading.RLock()
         self.pid = os.getpid()
 
     def _take(self, size):

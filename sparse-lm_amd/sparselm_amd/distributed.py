@@ -122,3 +122,105 @@ def init_row_sharding(engine, rank: int | None = None, world_size: int | None = 
         dist.broadcast(buf, src=0)
         uid = bytes(buf.tolist())
     engine.comm_init(rank, world_size, uid)
+
+
+# ---------------------------------------------------------------------------------------------------
+# grid mode, fine-grained: path POINTS, not whole paths, are what gets dealt
+# ---------------------------------------------------------------------------------------------------
+def _spread(sizes: Sequence[int]) -> list[list[int]]:
+    """Deal the points 0..K-1 (K = sum(sizes)) of one path to pieces of the given sizes so that every piece is
+    spread evenly over the whole path (largest-deficit dealing): a piece of 20 and a piece of 10 of a 50-point
+    path take two of every five and one of every five points.  Every piece then starts near the top of the path
+    -- where the first working set of a solve suffices -- and all pieces move down the path together."""
+    K = int(sum(sizes))
+    got = [[] for _ in sizes]
+    for i in range(K):
+        # the piece that is furthest behind its share of the first i + 1 points (ties: the larger piece, then the first)
+        j = max(range(len(sizes)), key=lambda q: (sizes[q] * (i + 1) / K - len(got[q]), sizes[q], -q)
+                if len(got[q]) < sizes[q] else (-1e300, 0, 0))
+        got[j].append(i)
+    return got
+
+
+def plan_lane_calls(unit_points: Sequence[int], unit_keys: Sequence[Any], world_size: int, lanes: int,
+                    fine: bool = True) -> list[list[list[list[tuple[int, list[int]]]]]]:
+    """The calls every rank makes to solve a grid of warm-started paths, ``lanes`` lanes per call.
+
+    ``unit_points[u]`` is the number of points of unit u's path (a unit: one (fold, other-parameters) pair of a
+    grid search; the reference hands every single (candidate, fold) fit to joblib, src/sparselm/model_selection.py:273,
+    304-323), ``unit_keys[u]`` what two units must have in common for pieces of them to follow each other in ONE lane
+    (same row mask, proportional penalty vectors).  Returns ``plan[rank]`` = list of calls, a call = list of lanes, a
+    lane = list of segments ``(u, point indices in the order the lane walks them)``.
+
+    A pass over X advances every lane of a call by one point, so a call costs 1 + (points of its longest lane)
+    passes and the cheapest plan fills ``world_size * lanes`` lanes evenly.  Whole rounds of ``world_size * lanes``
+    units go out as whole paths, contiguous runs of the given order per call (callers order units fold-major: the
+    lanes of a call then share row masks and their Grams).  What is left -- everything, when there are fewer units
+    than lane slots, as for the 50 units of BASELINE config 4 on 8 x 16 slots -- is cut: with d = the fewest points per
+    lane that fits, unit u becomes floor(K_u / d) pieces of d points and one shorter piece, each spread evenly over
+    the path (`_spread`); the short pieces of units with the same key share lanes (first fit, decreasing), walked in
+    alternating direction -- down one path, up the next -- so that consecutive points stay neighbours.  ``fine=False``
+    (few lanes: the fused kernels without the working set, where a lane's cold start costs tens of passes) leaves
+    units whole.  Deterministic: every rank computes the same plan."""
+    n_units = len(unit_points)
+    if len(unit_keys) != n_units:
+        raise ValueError("one key per unit")
+    if world_size < 1 or lanes < 1:
+        raise ValueError("world_size and lanes must be positive")
+    slots = world_size * lanes
+    plan: list[list[list]] = [[] for _ in range(world_size)]
+    whole = (n_units // slots) * slots if fine else n_units
+    for i0 in range(0, whole, lanes):  # call after call, rank after rank
+        call = [[(u, list(range(unit_points[u])))] for u in range(i0, min(i0 + lanes, whole))]
+        plan[(i0 // lanes) % world_size].append(call)
+    rest = list(range(whole, n_units))
+    if not rest:
+        return plan
+    total = sum(unit_points[u] for u in rest)
+    kmax = max(unit_points[u] for u in rest)
+    d = max(1, -(-total // slots))
+    while True:
+        long_lanes, short = [], {}
+        for u in rest:
+            K = unit_points[u]
+            sizes = [d] * (K // d) + ([K % d] if K % d else [])
+            for size, idx in zip(sizes, _spread(sizes)):
+                if size == d:
+                    long_lanes.append((unit_keys[u], [(u, idx)]))
+                else:
+                    short.setdefault(unit_keys[u], []).append((size, u, idx))
+        packed = []
+        for key, pieces in short.items():  # first fit, decreasing, inside a key
+            bins: list[tuple[int, list]] = []
+            for size, u, idx in sorted(pieces, key=lambda t: (-t[0], t[1])):
+                for b, (fill, segs) in enumerate(bins):
+                    if fill + size <= d:
+                        bins[b] = (fill + size, segs + [(u, idx)])
+                        break
+                else:
+                    bins.append((size, [(u, idx)]))
+            for _, segs in bins:
+                segs = [(u, idx if k % 2 == 0 else idx[::-1]) for k, (u, idx) in enumerate(segs)]
+                packed.append((key, segs))
+        if len(long_lanes) + len(packed) <= slots or d >= kmax:
+            break
+        d += 1
+    # lanes of one key next to each other (a call then holds few distinct row masks); contiguous, even chunks per rank
+    all_lanes = long_lanes + packed
+    order = {}
+    for key, _ in all_lanes:
+        order.setdefault(key, len(order))
+    all_lanes.sort(key=lambda t: order[t[0]])  # (stable)
+    lane_lists = [segs for _, segs in all_lanes]
+    n_calls = -(-len(lane_lists) // slots)  # (more than one only when d == kmax still does not fit: cannot happen for rest < slots)
+    per_round = -(-len(lane_lists) // n_calls)
+    for c in range(n_calls):
+        chunk = lane_lists[c * per_round : (c + 1) * per_round]
+        base, rem = divmod(len(chunk), world_size)
+        at = 0
+        for r in range(world_size):
+            take = base + (1 if r < rem else 0)
+            if take:
+                plan[r].append(chunk[at : at + take])
+            at += take
+    return plan

@@ -53,6 +53,13 @@ from .model._base import ProxRegressor
 __all__ = ["GridSearchCV", "LineSearchCV"]
 
 _FAST_SCORINGS = ("neg_root_mean_squared_error", "neg_mean_squared_error", "r2")
+# What a grid of the device path may vary: parameters that only enter through `_penalty` (evaluated per unit on a clone
+# with the candidate's values) and, for the Adaptive* classes, the controls of the re-weighting loop (every candidate runs
+# its own).  Anything else -- `standardize`, `fit_intercept`, `groups`, `solver_options`, ... -- changes the design, the
+# group structure on the device or the preprocessing, which the device path sets up ONCE from the base estimator: such
+# grids go through scikit-learn's generic loop.
+_PENALTY_PARAMS = frozenset({"alpha", "l1_ratio", "delta", "group_weights"})
+_ADAPTIVE_LOOP_PARAMS = frozenset({"max_iter", "eps", "tol", "update_function", "warm_start"})
 
 
 def select_best_index_onestd(results, refit_metric="score"):
@@ -150,7 +157,8 @@ class GridSearchCV(_GridSearchCV):
         if self.refit not in (True, False):
             return False
         grids = self.param_grid if isinstance(self.param_grid, (list, tuple)) else [self.param_grid]
-        return all(isinstance(g, dict) and "alpha" in g for g in grids)
+        allowed = _PENALTY_PARAMS | (_ADAPTIVE_LOOP_PARAMS if isinstance(est, AdaptiveLasso) else frozenset())
+        return all(isinstance(g, dict) and "alpha" in g and set(g) <= allowed for g in grids)
 
     def fit(self, X, y=None, *, groups=None, **fit_params):
         """Run the search (reference model_selection.py:226-424)."""
@@ -183,148 +191,17 @@ class GridSearchCV(_GridSearchCV):
 
     # ---- device-resident fast path ------------------------------------------------------------------
     def _fit_device(self, X, y, groups):
-        est = self.estimator
-        X, y, groups = indexable(X, y, groups)
-        X = np.asarray(X, dtype=np.float64)
-        y = np.asarray(y, dtype=np.float64)
-        n, p = X.shape
-        cv = check_cv(self.cv, y, classifier=is_classifier(est))
-        splits = list(cv.split(X, y, groups))
-        n_splits = len(splits)
-        candidates = list(ParameterGrid(self.param_grid))
-        # validate the way fit() would (same error classes): every distinct value of every grid parameter once
-        # (the constraints are per parameter; 60 clones instead of 500 on a 50 x 10 grid, whose
-        # clone / get_params / inspect.signature cost was a quarter of the search)
-        seen = set()
-        for params in candidates:
-            fresh = [k for k, v in params.items() if (k, repr(v)) not in seen]
-            if fresh:
-                seen.update((k, repr(v)) for k, v in params.items())
-                clone(est).set_params(**params)._validate_params(X, y)
-
-        # units: (non-alpha params, fold) -> one warm-started alpha path
-        by_combo = defaultdict(list)
-        for ci, params in enumerate(candidates):
-            key = tuple(sorted((k, repr(v)) for k, v in params.items() if k != "alpha"))
-            by_combo[key].append(ci)
-        adaptive = isinstance(est, AdaptiveLasso)
-        if adaptive:  # every (candidate, fold) is its own re-weighting loop: no shared alpha path
-            by_combo = {ci: [ci] for ci in range(len(candidates))}
-        combos = list(by_combo.values())
-        # fold-major: the units of one batch then mostly share a fold, i.e. one row mask, and the
-        # engine builds ONE working-set Gram for all lanes with the same mask (same host array)
-        units = [(c, f) for f in range(n_splits) for c in range(len(combos))]
-        train_masks, test_masks = [], []
-        for train, test in splits:
-            m = np.zeros(n)
-            m[train] = 1.0
-            train_masks.append(m)
-            t = np.zeros(n)
-            t[test] = 1.0
-            test_masks.append(t)
-
         rank, world = D.active_world()
-        eng = _engine.get_engine()
+        grid = _DeviceGrid(self, X, y, groups)
         t0 = time.perf_counter()
-        scores = np.full((len(candidates), n_splits), np.nan)
-        fit_time = np.zeros((len(candidates), n_splits))
-        # fit_intercept=True: the intercept is an unpenalised coefficient on a column of ones appended to
-        # the device copy (its own group, zero weights).  Minimising over it jointly is what centring X and
-        # y by their training-fold means does (reference _base.py:207-227), fold by fold, without a
-        # centred copy per fold.
-        intercept = bool(est.fit_intercept)
-        Xd = np.hstack([X, np.ones((n, 1))]) if intercept else X
-
-        def with_intercept(a, b, d, G):
-            """penalty vectors of the augmented problem (None stays None: that term is off)"""
-            if not intercept:
-                return a, b, d
-            a = None if a is None else np.append(np.broadcast_to(a, (p,)), 0.0)
-            b = None if b is None else np.append(np.broadcast_to(b, (G,)), 0.0)
-            d = None if d is None else np.append(np.broadcast_to(d, (G,)), 0.0)
-            return a, b, d
-
-        with eng.dataset(Xd, y) as ds:
-            base = clone(est).set_params(alpha=1.0)
-            a1, b1, d1, gidx, G = base._penalty(X)
-            if gidx is not None:
-                ds.set_groups(np.append(gidx, G) if intercept else gidx, G + 1 if intercept else G)
-            my_units = [units[i] for i in D.shard_units(len(units), rank, world)]
-            lanes = max(1, min(int(self.lanes), _engine.MAX_LANES, ds.max_lanes()))
-            opts = _solver_options(est)
-            opts.setdefault("tol", _backend.default_tol(n, p))
-            local = {}
-            batches = [my_units[k0 : k0 + lanes] for k0 in range(0, len(my_units), lanes)]
-
-            def run_batch(ds, batch):
-                """One call of the engine for the units of `batch` on dataset `ds` (this stream's copy); the scores
-                go into `local`, the return value counts solves that stopped short of the tolerance."""
-                if adaptive:
-                    ests = [clone(est).set_params(**candidates[combos[c][0]]) for c, _ in batch]
-                    t_batch = time.perf_counter()
-                    try:
-                        fits = _adaptive_lanes(ds, ests, X, [train_masks[f] for _, f in batch],
-                                               [len(splits[f][0]) for _, f in batch], opts, with_intercept)
-                    except _engine.NonFiniteError:
-                        if self.error_score == "raise":
-                            raise
-                        for c, f in batch:
-                            local[(c, f)] = (combos[c], np.full(len(combos[c]), self.error_score, dtype=float), 0.0)
-                        return 0
-                    dt = (time.perf_counter() - t_batch) / len(batch)
-                    for (c, f), fit in zip(batch, fits):
-                        sse = ds.eval_sse(fit["beta"][None, :], test_masks[f])
-                        local[(c, f)] = (combos[c], self._score_from_sse(sse, y[splits[f][1]]), dt)
-                    return sum(not i["converged"] for fit in fits for i in fit["infos"])
-                # a batch with spare lane slots (the last one; every one when there are fewer units than
-                # lanes, e.g. a grid dealt over 8 GPUs) cuts each unit's path into contiguous ranges, one
-                # lane each: a pass advances every lane by one point, so the call needs K / split passes
-                specs, metas = [], []
-                for c, f in batch:
-                    cis = sorted(combos[c], key=lambda ci: -candidates[ci]["alpha"])
-                    e = clone(est).set_params(**{k: v for k, v in candidates[cis[0]].items() if k != "alpha"})
-                    e.set_params(alpha=1.0)
-                    a, b, d, _, G_e = e._penalty(X)
-                    a, b, d = with_intercept(a, b, d, G_e if G_e is not None else p)
-                    alphas = np.array([candidates[ci]["alpha"] for ci in cis], dtype=float)
-                    pts = np.c_[
-                        alphas if a is not None else 0 * alphas,
-                        alphas if b is not None else 0 * alphas,
-                        np.ones_like(alphas) if d is not None else 0 * alphas,
-                    ]
-                    train, test = splits[f]
-                    split = max(1, min(lanes // len(batch), len(cis) // 4)) if lanes >= 8 else 1
-                    for part in np.array_split(np.arange(len(cis)), split):
-                        specs.append(dict(points=pts[part], a=a, b=b, d=d, row_weight=train_masks[f], n_eff=len(train)))
-                    metas.append((cis, test, split))
-                t_batch = time.perf_counter()
-                try:
-                    results = _solve_lanes_with_fallback(ds, specs, opts)
-                except _engine.NonFiniteError:  # the counterpart of a failing fit in _fit_and_score
-                    if self.error_score == "raise":
-                        raise
-                    for (c, f), (cis, _, _) in zip(batch, metas):
-                        local[(c, f)] = (cis, np.full(len(cis), self.error_score, dtype=float), 0.0)
-                    return 0
-                dt = (time.perf_counter() - t_batch) / max(1, sum(len(m[0]) for m in metas))
-                at = 0
-                for (c, f), (cis, test, split) in zip(batch, metas):
-                    betas = np.vstack([r.betas for r in results[at : at + split]])
-                    at += split
-                    sse = ds.eval_sse(betas, test_masks[f])
-                    local[(c, f)] = (cis, self._score_from_sse(sse, y[test]), dt)
-                return sum(not r.converged for r in results)
-
-            unconverged = self._run_batches(ds, batches, run_batch, gidx, G, intercept)
-            merged = _gather(local, units, world)
-            for (c, f), (cis, sc, dt) in merged.items():
-                scores[cis, f] = sc
-                fit_time[cis, f] = dt
+        with grid.open() as ds:
+            local, unconverged = grid.solve_share(ds, rank, world)
+            scores, fit_time = grid.merge(_gather(local, grid.cells, world))
             if unconverged:
-                self._warn_unconverged(unconverged, "grid cell solves", opts)
-
+                self._warn_unconverged(unconverged, "grid cell solves", grid.opts)
+            candidates = grid.candidates
             self.cv_results_ = _format_results(candidates, scores, fit_time)
-            self.n_splits_ = n_splits
+            self.n_splits_ = grid.n_splits
             self.multimetric_ = False
             self.scorer_ = self.scoring
             if self.opt_selection_method == "one_std_score":
@@ -336,38 +213,24 @@ class GridSearchCV(_GridSearchCV):
             self.best_score_std_ = self.cv_results_["std_test_score"][self.best_index_]
             if self.refit:
                 t1 = time.perf_counter()
-                best = clone(est).set_params(**self.best_params_)
-                if adaptive:
-                    fit = _adaptive_lanes(ds, [best], X, [None], [n], opts, with_intercept)[0]
-                    beta_aug = fit["beta"]
-                    best.n_iter_ = fit["n_iter"]
-                    best.adaptive_weights_ = fit["weights"]
-                    best.solver_info_ = {"solves": fit["infos"]}
-                    if not all(i["converged"] for i in fit["infos"]):
-                        self._warn_unconverged(1, "the refit", opts)
-                else:
-                    a, b, d, _, G_b = best._penalty(X)
-                    a, b, d = with_intercept(a, b, d, G_b if G_b is not None else p)
-                    res = ds.solve_path(
-                        [(1.0, 1.0, 1.0)],
-                        a=np.zeros(ds.p) if a is None else a,
-                        b=np.zeros(ds.n_groups) if b is None else b,
-                        d=np.zeros(ds.n_groups) if d is None else d,
-                        **opts,
-                    )
-                    beta_aug = res.betas[0].copy()
-                    best.solver_info_ = {"n_iter": int(res.n_iter[0]), "converged": res.converged}
-                    if not res.converged:
-                        self._warn_unconverged(1, "the refit", opts)
-                best.coef_ = beta_aug[:p].copy()
-                best.intercept_ = float(beta_aug[p]) if intercept else 0.0
-                best.n_features_in_ = p
-                self.best_estimator_ = best
+                self.best_estimator_ = grid.refit(ds, self.best_params_)
                 self.refit_time_ = time.perf_counter() - t1
         self.search_time_ = time.perf_counter() - t0
         return self
 
-    def _run_batches(self, ds, batches, run_batch, gidx, G, intercept):
+    def _device_cells(self, X, y, groups=None, rank=0, world=1):
+        """The (candidate, fold) scores rank ``rank`` of a ``world``-rank search computes, as a (candidates x folds)
+        array with NaN in the cells of the other ranks -- the share `_fit_device` would solve in that process, without a
+        process group (tests; `bench.py`'s emulated multi-rank legs)."""
+        grid = _DeviceGrid(self, X, y, groups)
+        with grid.open() as ds:
+            local, _ = grid.solve_share(ds, rank, world)
+        scores = np.full((len(grid.candidates), grid.n_splits), np.nan)
+        for cis, f, sc, _ in local.values():
+            scores[cis, f] = sc
+        return scores
+
+    def _run_batches(self, ds, batches, run_batch, grid):
         """Deal the batches to ``streams`` engines of the device: the first works on `ds` itself from this thread,
         every further one on a device-to-device copy from a thread of its own (the engine calls release the GIL).
         One stream, or fewer batches than two: plain loop."""
@@ -381,8 +244,8 @@ class GridSearchCV(_GridSearchCV):
             for _ in range(streams - 1):
                 c = ds.clone()
                 copies.append(c)
-                if gidx is not None:
-                    c.set_groups(np.append(gidx, G) if intercept else gidx, G + 1 if intercept else G)
+                if grid.gidx is not None:
+                    grid._set_groups(c)
             todo = list(range(len(batches)))
             lock = threading.Lock()
             counts, errors = [0] * streams, []
@@ -437,6 +300,247 @@ class GridSearchCV(_GridSearchCV):
     def predict(self, X):
         check_is_fitted(self, "best_estimator_")
         return self.best_estimator_.predict(X)
+
+
+class _DeviceGrid:
+    """One device-resident search: the grid laid out as units, the dataset, the calls of a rank's share.
+
+    A *unit* is one warm-started alpha path: a (fold, other-parameters) pair -- or, for the Adaptive* estimators, one
+    (candidate, fold) re-weighting loop.  The POINTS of the units' paths are dealt to the lane slots of all ranks by
+    `distributed.plan_lane_calls`; what every rank reports back are *cells*: (unit, first point) -> (candidate
+    indices, fold, scores, seconds per fit)."""
+
+    def __init__(self, search, X, y, groups):
+        est = search.estimator
+        self.search, self.est = search, est
+        X, y, groups = indexable(X, y, groups)
+        self.X = X = np.asarray(X, dtype=np.float64)
+        self.y = y = np.asarray(y, dtype=np.float64)
+        n, p = X.shape
+        cv = check_cv(search.cv, y, classifier=is_classifier(est))
+        self.splits = splits = list(cv.split(X, y, groups))
+        self.n_splits = len(splits)
+        self.candidates = candidates = list(ParameterGrid(search.param_grid))
+        # validate the way fit() would (same error classes): every distinct value of every grid parameter once
+        # (the constraints are per parameter; 60 clones instead of 500 on a 50 x 10 grid, whose
+        # clone / get_params / inspect.signature cost was a quarter of the search)
+        seen = set()
+        for params in candidates:
+            fresh = [k for k, v in params.items() if (k, repr(v)) not in seen]
+            if fresh:
+                seen.update((k, repr(v)) for k, v in params.items())
+                clone(est).set_params(**params)._validate_params(X, y)
+        # units: (non-alpha params, fold) -> one warm-started alpha path
+        by_combo = defaultdict(list)
+        for ci, params in enumerate(candidates):
+            key = tuple(sorted((k, repr(v)) for k, v in params.items() if k != "alpha"))
+            by_combo[key].append(ci)
+        self.adaptive = isinstance(est, AdaptiveLasso)
+        if self.adaptive:  # every (candidate, fold) is its own re-weighting loop: no shared alpha path
+            by_combo = {ci: [ci] for ci in range(len(candidates))}
+        # (the candidates of a combination in path order: alpha descending)
+        self.combos = [sorted(cis, key=lambda ci: -candidates[ci]["alpha"]) for cis in by_combo.values()]
+        # fold-major: the units of one call then mostly share a fold, i.e. one row mask, and the
+        # engine builds ONE working-set Gram for all lanes with the same mask (same host array)
+        self.units = [(c, f) for f in range(self.n_splits) for c in range(len(self.combos))]
+        self.train_masks, self.test_masks = [], []
+        for train, test in splits:
+            m = np.zeros(n)
+            m[train] = 1.0
+            self.train_masks.append(m)
+            t = np.zeros(n)
+            t[test] = 1.0
+            self.test_masks.append(t)
+        # fit_intercept=True: the intercept is an unpenalised coefficient on a column of ones appended to
+        # the device copy (its own group, zero weights).  Minimising over it jointly is what centring X and
+        # y by their training-fold means does (reference _base.py:207-227), fold by fold, without a
+        # centred copy per fold.
+        self.intercept = bool(est.fit_intercept)
+        base = clone(est).set_params(alpha=1.0)
+        _, _, _, self.gidx, self.G = base._penalty(X)
+        self.opts = _solver_options(est)
+        self.opts.setdefault("tol", _backend.default_tol(n, p))
+        self._pen = {}
+        # every (unit, first point index of a piece) some rank has to report (`_gather` checks that none is missing)
+        self.cells = None
+
+    def open(self):
+        n = self.X.shape[0]
+        Xd = np.hstack([self.X, np.ones((n, 1))]) if self.intercept else self.X
+        ds = _engine.get_engine().dataset(Xd, self.y)
+        if self.gidx is not None:
+            self._set_groups(ds)
+        self.lanes = max(1, min(int(self.search.lanes), _engine.MAX_LANES, ds.max_lanes()))
+        self._plan_world = None
+        return ds
+
+    def _set_groups(self, ds):
+        ds.set_groups(np.append(self.gidx, self.G) if self.intercept else self.gidx, self.G + 1 if self.intercept else self.G)
+
+    def with_intercept(self, a, b, d, G):
+        """penalty vectors of the augmented problem (None stays None: that term is off)"""
+        if not self.intercept:
+            return a, b, d
+        p = self.X.shape[1]
+        a = None if a is None else np.append(np.broadcast_to(a, (p,)), 0.0)
+        b = None if b is None else np.append(np.broadcast_to(b, (G,)), 0.0)
+        d = None if d is None else np.append(np.broadcast_to(d, (G,)), 0.0)
+        return a, b, d
+
+    def penalty_of(self, c):
+        """Combination c's penalty at alpha = 1 as (unit-scaled vectors, scales, key): ``a = sa * a_unit`` etc. with
+        max |a_unit| = 1, so that combinations whose vectors are proportional -- the rows of an l1_ratio grid -- bring
+        the SAME vectors and differ in the scales their path points carry; pieces of such units can follow each other
+        in one lane (`key` is equal exactly then)."""
+        hit = self._pen.get(c)
+        if hit is None:
+            cand = self.candidates[self.combos[c][0]]
+            e = clone(self.est).set_params(**{k: v for k, v in cand.items() if k != "alpha"})
+            e.set_params(alpha=1.0)
+            a, b, d, _, G_e = e._penalty(self.X)
+            vecs, scales, key = [], [], []
+            for v in self.with_intercept(a, b, d, G_e if G_e is not None else self.X.shape[1]):
+                if v is None:
+                    vecs.append(None); scales.append(0.0); key.append(b"-")
+                    continue
+                v = np.asarray(v, dtype=np.float64)
+                top = float(np.max(np.abs(v))) if v.size else 0.0
+                if top > 0.0 and np.isfinite(top):
+                    vecs.append(v / top); scales.append(top); key.append(np.round(v / top, 12).tobytes())
+                else:
+                    vecs.append(v); scales.append(1.0); key.append(b"0")
+            hit = self._pen[c] = (vecs, scales, tuple(key))
+        return hit
+
+    def plan(self, world):
+        """plan[rank] = calls (lists of lanes, a lane a list of (unit, point indices)), for all ranks"""
+        if self._plan_world != world:
+            if self.adaptive:  # one point per unit: a call is `lanes` re-weighting loops side by side
+                mine = [D.shard_units(len(self.units), r, world) for r in range(world)]
+                self._plan = [[[[(u, [0])] for u in own[k0 : k0 + self.lanes]] for k0 in range(0, len(own), self.lanes)]
+                              for own in mine]
+            else:
+                keys = [(f, self.penalty_of(c)[2]) for c, f in self.units]
+                # a lane's cold start costs tens of passes without the working set (the fused kernels' few lanes):
+                # paths are only cut into pieces where sixteen lanes share a pass
+                self._plan = D.plan_lane_calls([len(self.combos[c]) for c, _ in self.units], keys, world, self.lanes,
+                                               fine=self.lanes >= 8)
+            self._plan_world = world
+            self.cells = [(u, idx[0]) for calls in self._plan for call in calls for lane in call for u, idx in lane]
+        return self._plan
+
+    def solve_share(self, ds, rank, world):
+        """(cells of rank `rank`, number of solves that stopped short of the tolerance)"""
+        calls = self.plan(world)[rank]
+        local = {}
+        run = self._run_adaptive if self.adaptive else self._run_call
+        unconverged = self.search._run_batches(ds, calls, lambda d, call: run(d, call, local), self)
+        return local, unconverged
+
+    def _run_call(self, ds, call, local):
+        """One call of the engine for the lanes of `call` on dataset `ds` (this stream's copy); scores go into `local`."""
+        search, cands = self.search, self.candidates
+        specs = []
+        for lane in call:
+            c0, f = self.units[lane[0][0]]
+            vecs, _, _ = self.penalty_of(c0)
+            segs = []
+            for u, idx in lane:
+                c, _ = self.units[u]
+                _, (sa, sb, sd), _ = self.penalty_of(c)
+                alphas = np.array([cands[self.combos[c][i]]["alpha"] for i in idx], dtype=float)
+                segs.append(np.c_[alphas * sa, alphas * sb, np.full(len(alphas), sd)])
+            pts, gam = _engine.lane_points(segs)
+            specs.append(dict(points=pts, extrap=gam, a=vecs[0], b=vecs[1], d=vecs[2], row_weight=self.train_masks[f],
+                              n_eff=len(self.splits[f][0])))
+        n_fits = sum(len(idx) for lane in call for _, idx in lane)
+        t_call = time.perf_counter()
+        try:
+            results = _solve_lanes_with_fallback(ds, specs, self.opts)
+        except _engine.NonFiniteError:  # the counterpart of a failing fit in _fit_and_score
+            if search.error_score == "raise":
+                raise
+            for lane in call:
+                for u, idx in lane:
+                    c, f = self.units[u]
+                    local[(u, idx[0])] = ([self.combos[c][i] for i in idx], f, np.full(len(idx), search.error_score, dtype=float), 0.0)
+            return 0
+        dt = (time.perf_counter() - t_call) / max(1, n_fits)
+        # hold-out scores, fold by fold: one scoring call for all the coefficient vectors of the call that share a test mask
+        by_fold = defaultdict(list)
+        for lane, res in zip(call, results):
+            at = 0
+            for u, idx in lane:
+                by_fold[self.units[u][1]].append((u, idx, res.betas[at : at + len(idx)]))
+                at += len(idx)
+        for f, parts in by_fold.items():
+            sse = ds.eval_sse(np.vstack([b for _, _, b in parts]), self.test_masks[f])
+            sc = search._score_from_sse(sse, self.y[self.splits[f][1]])
+            at = 0
+            for u, idx, _ in parts:
+                c = self.units[u][0]
+                local[(u, idx[0])] = ([self.combos[c][i] for i in idx], f, sc[at : at + len(idx)], dt)
+                at += len(idx)
+        return sum(not r.converged for r in results)
+
+    def _run_adaptive(self, ds, call, local):
+        search = self.search
+        batch = [self.units[lane[0][0]] for lane in call]
+        us = [lane[0][0] for lane in call]
+        ests = [clone(self.est).set_params(**self.candidates[self.combos[c][0]]) for c, _ in batch]
+        t_batch = time.perf_counter()
+        try:
+            fits = _adaptive_lanes(ds, ests, self.X, [self.train_masks[f] for _, f in batch],
+                                   [len(self.splits[f][0]) for _, f in batch], self.opts, self.with_intercept)
+        except _engine.NonFiniteError:
+            if search.error_score == "raise":
+                raise
+            for u, (c, f) in zip(us, batch):
+                local[(u, 0)] = (self.combos[c], f, np.full(len(self.combos[c]), search.error_score, dtype=float), 0.0)
+            return 0
+        dt = (time.perf_counter() - t_batch) / len(batch)
+        for u, (c, f), fit in zip(us, batch, fits):
+            sse = ds.eval_sse(fit["beta"][None, :], self.test_masks[f])
+            local[(u, 0)] = (self.combos[c], f, search._score_from_sse(sse, self.y[self.splits[f][1]]), dt)
+        return sum(not i["converged"] for fit in fits for i in fit["infos"])
+
+    def merge(self, cells):
+        scores = np.full((len(self.candidates), self.n_splits), np.nan)
+        fit_time = np.zeros((len(self.candidates), self.n_splits))
+        for cis, f, sc, dt in cells.values():
+            scores[cis, f] = sc
+            fit_time[cis, f] = dt
+        return scores, fit_time
+
+    def refit(self, ds, best_params):
+        search, p = self.search, self.X.shape[1]
+        best = clone(self.est).set_params(**best_params)
+        if self.adaptive:
+            fit = _adaptive_lanes(ds, [best], self.X, [None], [self.X.shape[0]], self.opts, self.with_intercept)[0]
+            beta_aug = fit["beta"]
+            best.n_iter_ = fit["n_iter"]
+            best.adaptive_weights_ = fit["weights"]
+            best.solver_info_ = {"solves": fit["infos"]}
+            if not all(i["converged"] for i in fit["infos"]):
+                search._warn_unconverged(1, "the refit", self.opts)
+        else:
+            a, b, d, _, G_b = best._penalty(self.X)
+            a, b, d = self.with_intercept(a, b, d, G_b if G_b is not None else p)
+            res = ds.solve_path(
+                [(1.0, 1.0, 1.0)],
+                a=np.zeros(ds.p) if a is None else a,
+                b=np.zeros(ds.n_groups) if b is None else b,
+                d=np.zeros(ds.n_groups) if d is None else d,
+                **self.opts,
+            )
+            beta_aug = res.betas[0].copy()
+            best.solver_info_ = {"n_iter": int(res.n_iter[0]), "converged": res.converged}
+            if not res.converged:
+                search._warn_unconverged(1, "the refit", self.opts)
+        best.coef_ = beta_aug[:p].copy()
+        best.intercept_ = float(beta_aug[p]) if self.intercept else 0.0
+        best.n_features_in_ = p
+        return best
 
 
 class LineSearchCV(BaseSearchCV):

@@ -135,3 +135,87 @@ def test_shard_units_partitions_and_balances():
     assert spans[0][0] == 0 and spans[-1][1] == 1_000_003
     assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
     assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _check_plan(unit_points, keys, world, lanes, fine=True):
+    from sparselm_amd.distributed import plan_lane_calls
+
+    plan = plan_lane_calls(unit_points, keys, world, lanes, fine=fine)
+    assert len(plan) == world
+    seen = {}
+    depth = []
+    for r, calls in enumerate(plan):
+        for call in calls:
+            assert 1 <= len(call) <= lanes
+            for lane in call:
+                assert len({keys[u] for u, _ in lane}) == 1  # pieces that share a lane share the key (row mask)
+                for u, idx in lane:
+                    assert len(idx) > 0
+                    for i in idx:
+                        assert (u, i) not in seen, "a path point was dealt twice"
+                        seen[(u, i)] = r
+            depth.append((r, max(sum(len(idx) for _, idx in lane) for lane in call)))
+    assert sorted(seen) == [(u, i) for u in range(len(unit_points)) for i in range(unit_points[u])]
+    assert plan == plan_lane_calls(unit_points, keys, world, lanes, fine=fine)  # deterministic: every rank computes the same
+    return plan, depth
+
+
+def test_lane_call_plan_covers_every_path_point_once():
+    # BASELINE config 4: 5 folds x 10 l1_ratio, 50 alphas each, sixteen lanes per call
+    keys = [f for f in range(5) for _ in range(10)]
+    passes = {}
+    for world in (1, 2, 3, 4, 8):
+        plan, depth = _check_plan([50] * 50, keys, world, 16)
+        per_rank = [sum(1 + d for r, d in depth if r == rank) for rank in range(world)]
+        passes[world] = max(per_rank)
+        assert max(per_rank) - min(per_rank) <= 1
+    # a call costs 1 + (points of its longest lane) passes: 8 ranks get within 5 % of an eighth of one rank's passes
+    assert passes[1] <= 163 and passes[8] <= 21 and passes[1] / passes[8] >= 7.6
+    assert passes[2] <= 86 and passes[4] <= 43
+    # on 8 ranks every lane holds 20 points: two pieces of 20 per path, and the 10 left over pair up inside their fold
+    plan, _ = _check_plan([50] * 50, keys, 8, 16)
+    sizes = sorted(sum(len(idx) for _, idx in lane) for calls in plan for call in calls for lane in call)
+    assert sizes == [20] * 125
+    joint = [lane for calls in plan for call in calls for lane in call if len(lane) > 1]
+    assert len(joint) == 25
+    for lane in joint:  # walked down one path and up the next: consecutive points stay neighbours
+        (u0, i0), (u1, i1) = lane
+        assert i0 == sorted(i0) and i1 == sorted(i1, reverse=True) and u0 != u1
+    # every piece is spread over the whole path: it starts near the top and ends near the bottom
+    for calls in plan:
+        for call in calls:
+            for lane in call:
+                for _, idx in lane:
+                    assert min(idx) <= 4 and max(idx) >= 45
+
+
+def test_lane_call_plan_odd_shapes():
+    rng = np.random.default_rng(0)
+    for _ in range(40):
+        n_units = int(rng.integers(1, 40))
+        pts = [int(k) for k in rng.integers(1, 60, n_units)]
+        keys = [int(k) for k in rng.integers(0, 3, n_units)]
+        world, lanes = int(rng.integers(1, 9)), int(rng.choice([1, 4, 6, 16]))
+        _check_plan(pts, keys, world, lanes)
+        plan, _ = _check_plan(pts, keys, world, lanes, fine=False)
+        assert all(len(lane) == 1 and lane[0][1] == list(range(pts[lane[0][0]]))
+                   for calls in plan for call in calls for lane in call)  # fine=False: whole paths only
+    with pytest.raises(ValueError):
+        _check_plan([3, 4], [0], 2, 4)
+
+
+def test_lane_points_brings_per_piece_secant_factors():
+    from sparselm_amd._engine import lane_points, path_extrapolation
+
+    al = np.geomspace(10.0, 0.01, 50)
+    up = np.c_[0.3 * al, 0.7 * al, 0 * al]
+    a, b = up[[0, 3, 5, 8, 10]], up[[44, 39, 34, 29]]
+    pts, gam = lane_points([a, b])
+    assert pts.shape == (9, 3) and gam.shape == (9,)
+    np.testing.assert_array_equal(pts, np.vstack([a, b]))
+    np.testing.assert_array_equal(gam[:5], path_extrapolation(a))
+    np.testing.assert_array_equal(gam[5:], path_extrapolation(b))
+    assert gam[0] == gam[1] == gam[5] == gam[6] == 0.0 and np.all(gam[[2, 3, 4, 7, 8]] > 0.0)
+    # exact for a piecewise-linear path: s_k = s_{k-1} + gamma (s_{k-1} - s_{k-2}) along the piece's own points
+    s = b[:, 0] / 0.3
+    np.testing.assert_allclose(s[2:], s[1:-1] + gam[7:] * (s[1:-1] - s[:-2]), rtol=1e-12)

@@ -382,3 +382,71 @@ def test_world_size_in_the_environment_without_a_process_group_means_one_rank(mo
     assert _gather(full, units) == full
     with pytest.raises(RuntimeError, match="not solved by any rank"):  # the check runs on the single-rank branch too
         _gather({units[0]: full[units[0]]}, units)
+
+
+def test_grids_over_non_penalty_parameters_leave_the_device_path():
+    """The device path sets the design, the groups and the preprocessing up once, from the base estimator: a grid that
+    varies anything but penalty parameters (standardize, fit_intercept, groups, ...) must go through the generic loop."""
+    from sparselm_amd.model import AdaptiveLasso, GroupLasso, SparseGroupLasso
+
+    groups = np.repeat(np.arange(4), 5)
+    ok = lambda est, grid: GridSearchCV(est, grid)._fast_path_ok({})  # noqa: E731
+    assert ok(SparseGroupLasso(groups=groups), {"alpha": [1.0, 0.1], "l1_ratio": [0.2, 0.8]})
+    assert ok(GroupLasso(groups=groups), [{"alpha": [1.0]}, {"alpha": [0.1], "group_weights": [np.ones(4)]}])
+    assert not ok(SparseGroupLasso(groups=groups), {"alpha": [1.0, 0.1], "standardize": [False, True]})
+    assert not ok(GroupLasso(groups=groups), {"alpha": [1.0, 0.1], "fit_intercept": [False, True]})
+    assert not ok(GroupLasso(groups=groups), {"alpha": [1.0], "groups": [groups, groups[::-1]]})
+    assert not ok(GroupLasso(groups=groups), [{"alpha": [1.0]}, {"alpha": [0.1], "standardize": [True]}])
+    assert not ok(GroupLasso(groups=groups), {"alpha": [1.0], "max_iter": [2, 3]})  # (not a parameter of the plain class's loop)
+    assert ok(AdaptiveLasso(), {"alpha": [1.0, 0.1], "max_iter": [2, 3], "eps": [1e-6, 1e-4]})
+    assert not ok(AdaptiveLasso(), {"alpha": [1.0, 0.1], "fit_intercept": [True]})
+
+
+@pytest.mark.gpu
+def test_the_shares_of_an_eight_rank_search_reproduce_the_one_rank_table(monkeypatch):
+    """Sixteen-lane searches deal path POINTS to the lane slots of all ranks (distributed.plan_lane_calls): pieces of
+    paths spread over the whole alpha range, short pieces of two paths walked one after the other in one lane.  The
+    eight shares of an 8-rank search, solved here one after the other, must tile the one-rank table exactly once and
+    reproduce it -- and the generic path's, fit by fit."""
+    monkeypatch.setenv("SLM_WS", "1")  # working set + split pass: sixteen lanes also for a problem of this size
+    rng = np.random.default_rng(5)
+    n, p, G = 3000, 120, 24
+    groups = rng.permutation(np.repeat(np.arange(G), p // G))
+    X = rng.standard_normal((n, p))
+    beta = np.zeros(p)
+    for g in rng.choice(G, 5, replace=False):
+        beta[groups == g] = rng.uniform(1.0, 4.0, p // G) * rng.choice([-1, 1], p // G)
+    y = X @ beta + 2.0 * rng.standard_normal(n)
+    grid = {"alpha": list(np.geomspace(3.0, 0.01, 21)), "l1_ratio": [0.2, 0.5, 0.8]}
+    cv = KFold(5, shuffle=True, random_state=0)
+    est = SparseGroupLasso(groups=groups, solver_options={"tol": 1e-11})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        search = GridSearchCV(est, grid, cv=cv)
+        one = search._device_cells(X, y, rank=0, world=1)
+        shares = [search._device_cells(X, y, rank=r, world=8) for r in range(8)]
+        fitted = GridSearchCV(est, grid, cv=cv).fit(X, y)
+        slow = SkGridSearchCV(est, {"alpha": grid["alpha"][::5], "l1_ratio": [0.5]}, cv=cv,
+                              scoring="neg_root_mean_squared_error").fit(X, y)
+    assert one.shape == (63, 5) and not np.isnan(one).any()
+    owners = np.sum([~np.isnan(s) for s in shares], axis=0)
+    assert np.all(owners == 1), "every (candidate, fold) cell belongs to exactly one rank"
+    assert all((~np.isnan(s)).sum() in range(36, 44) for s in shares)  # 315 fits over 8 ranks
+    merged = np.nansum(shares, axis=0)
+    np.testing.assert_allclose(merged, one, rtol=1e-8, atol=1e-10)
+    table = np.c_[tuple(fitted.cv_results_[f"split{f}_test_score"] for f in range(5))]
+    np.testing.assert_allclose(table, one, rtol=1e-8, atol=1e-10)
+    # the lanes of this search do hold pieces (not whole paths), and some hold pieces of two paths
+    from sparselm_amd.model_selection import _DeviceGrid
+
+    g = _DeviceGrid(search, X, y, None)
+    with g.open():
+        plan = g.plan(8)
+    lanes = [lane for calls in plan for call in calls for lane in call]
+    assert max(len(idx) for lane in lanes for _, idx in lane) < 21 and any(len(lane) > 1 for lane in lanes)
+    # an independent referee on a few cells: scikit-learn's loop around single fits
+    params = fitted.cv_results_["params"]
+    for q, sp in zip(slow.cv_results_["params"], range(len(slow.cv_results_["params"]))):
+        i = params.index(q)
+        for f in range(5):
+            assert merged[i, f] == pytest.approx(slow.cv_results_[f"split{f}_test_score"][sp], rel=1e-7)

@@ -37,10 +37,10 @@ class Mixed:
 
 
 def variant(which):
-    def run(self, ds, batches, run_batch, gidx, G, intercept):
+    def run(self, ds, batches, run_batch, grid):
         c = ds.clone()
-        if gidx is not None:
-            c.set_groups(np.append(gidx, G) if intercept else gidx, G + 1 if intercept else G)
+        if grid.gidx is not None:
+            grid._set_groups(c)
         try:
             target = {"copy": c, "solve_on_copy": Mixed(c, ds), "score_on_copy": Mixed(ds, c)}[which]
             return sum(run_batch(target, b) for b in batches)
