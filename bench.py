@@ -292,10 +292,10 @@ class Config4:
             self.unit_pts.append(np.c_[r * al, (1 - r) * al, 0 * al])
         self.lanes = _engine.MAX_LANES
 
-    def calls_of(self, world, rank):
+    def calls_of(self, world, rank, spread=True):
         from sparselm_amd import distributed as D
 
-        return D.plan_lane_calls([self.K] * len(self.units), [f for f, _ in self.units], world, self.lanes)[rank]
+        return D.plan_lane_calls([self.K] * len(self.units), [f for f, _ in self.units], world, self.lanes, spread=spread)[rank]
 
     def run_call(self, d, call, keep=None):
         from sparselm_amd import _engine

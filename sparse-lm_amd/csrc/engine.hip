@@ -369,6 +369,7 @@ struct slm_dataset {
   slm_engine* eng = nullptr;
   int64_t n = 0, p = 0, ld = 0, n_global = 0;
   double *X = nullptr, *y = nullptr, *rw = nullptr, *yzero = nullptr;
+  double rw_max = 1.0;  // largest row weight (1 without row weights; < 0: unknown -- weights handed over on the device)
   double* rw_lanes = nullptr;  // [kMaxLanes][n], allocated when a lane brings its own row weights
   double* rvec = nullptr;      // [n] residuals of the two-pass fallback
   // group structure (group-sorted permutation)
@@ -685,10 +686,15 @@ static int upload_row_weights(slm_dataset* ds, const double* rw_host) {
   ds->L_valid = false;
   if (!rw_host) {
     dfree(ds->rw);
+    ds->rw_max = 1.0;
     return SLM_OK;
   }
-  for (int64_t i = 0; i < ds->n; ++i)
+  double top = 0.0;
+  for (int64_t i = 0; i < ds->n; ++i) {
     if (!(rw_host[i] >= 0.0)) return fail(SLM_ERR_BAD_ARG, "row_weight[%lld] is negative or NaN", (long long)i);
+    top = std::max(top, rw_host[i]);
+  }
+  ds->rw_max = top;
   if (!ds->rw) SLM_TRY(dalloc(&ds->rw, ds->n));
   HIP_TRY(hipMemcpy(ds->rw, rw_host, sizeof(double) * ds->n, hipMemcpyHostToDevice));
   return SLM_OK;
@@ -758,6 +764,7 @@ extern "C" int slm_dataset_create_device(slm_engine* eng, const double* dX, int6
     e = hipMemcpyAsync(ds->y, dy, sizeof(double) * n, hipMemcpyDeviceToDevice, eng->stream);
   int rc = SLM_OK;
   if (e == hipSuccess && d_row_weight) {
+    ds->rw_max = -1.0;  // (not looked at on the host)
     rc = dalloc(&ds->rw, n);
     if (rc == SLM_OK)
       e = hipMemcpyAsync(ds->rw, d_row_weight, sizeof(double) * n, hipMemcpyDeviceToDevice, eng->stream);
@@ -785,6 +792,7 @@ extern "C" int slm_dataset_clone(slm_dataset* src, slm_engine* eng, slm_dataset*
   slm_dataset* ds = nullptr;
   SLM_TRY(slm_dataset_create_device(eng, src->X, src->n, src->p, src->ld, src->y, src->rw, &ds));
   ds->n_global = src->n_global;
+  ds->rw_max = src->rw_max;
   *out = ds;
   return SLM_OK;
 }
@@ -1561,6 +1569,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
 
   // ---- per-lane row weights / scaling -----------------------------------------------------------
   LaneSetup ls = default_lanes(ds, B);
+  double wmax[SLM_MAX_LANES];  // largest row weight of each lane (< 0: unknown)
+  for (int l = 0; l < kMaxLanes; ++l) wmax[l] = ds->rw ? ds->rw_max : 1.0;
   if (any_rw) {
     if (!ds->rw_lanes) SLM_TRY(dalloc(&ds->rw_lanes, (size_t)kMaxLanes * n));
     for (int l = 0; l < B; ++l) {
@@ -1572,12 +1582,17 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         for (int m = 0; m < l && same < 0; ++m)
           if (lanes[m].row_weight == w) same = m;
         if (same >= 0) {
+          wmax[l] = wmax[same];
           HIP_TRY(hipMemcpyAsync(dst, ds->rw_lanes + (size_t)same * n, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
           continue;
         }
-        for (int64_t i = 0; i < n; ++i)
+        double top = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
           if (!(w[i] >= 0.0) || !std::isfinite(w[i]))
             return fail(SLM_ERR_BAD_ARG, "lane %d: row_weight[%lld] is negative or not finite", l, (long long)i);
+          top = std::max(top, w[i]);
+        }
+        wmax[l] = top;
         HIP_TRY(hipMemcpyAsync(dst, w, sizeof(double) * n, hipMemcpyHostToDevice, s));
       } else if (ds->rw) {
         HIP_TRY(hipMemcpyAsync(dst, ds->rw, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
@@ -1600,6 +1615,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   double L[SLM_MAX_LANES];
   double lipschitz_ms = 0.0;
   bool L_on_device = false;  // the estimate stays on the device (no host round trip before the first pass)
+  double L_factor[SLM_MAX_LANES];  // ... and lane l uses L_factor[l] times it
+  for (int l = 0; l < kMaxLanes; ++l) L_factor[l] = 1.0;
   if (o.L > 0.0) {
     for (int l = 0; l < B; ++l) L[l] = o.L;
   } else {
@@ -1610,7 +1627,26 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     const bool sketch = ws_policy(ds, o.flags) == 2 && n >= 65536 && !getenv("SLM_NO_L_SKETCH");
     if (sketch && !(ds->L_valid && !(o.flags & SLM_FLAG_FRESH_L) && !any_rw && !custom_scale)) {
       const bool per_lane = any_rw || custom_scale;
-      if (!per_lane && !ds->rw) {
+      bool bounded = per_lane && !eng->sharded();
+      for (int l = 0; l < B && bounded; ++l) bounded = wmax[l] > 0.0;
+      if (bounded) {
+        // Lanes with their own row weights / scaling (CV folds: 0/1 masks with 1/n_train): ONE estimate, of the
+        // unweighted operator X_S^T X_S / |S|, and per lane the bound lambda_max(X^T W_l X) / n_l <= max(w_l) n / n_l
+        // times it -- 1.25 for the folds of a 5-fold split, whose own lambda_max is that of the whole matrix to a few
+        // per cent.  A step-size seed may be long by that much (it only shortens the first candidate step, and the
+        // sketch is already long by 2-3 x); what it must not cost is what the per-lane power iteration did: three split
+        // passes over the sketch for sixteen lanes, 0.9 ms of stream and a host round trip before every call of a grid.
+        // (row-sharded: the largest weight of THIS rank's rows would give every rank its own L -- the lanes' own
+        //  estimates, all-reduced like every gradient, stay in use there)
+        LaneSetup plain = default_lanes(ds, 1);
+        plain.rw = nullptr;
+        SLM_TRY(power_iteration(ds, plain, nullptr, kPowerItersSketch, sketch_rows(n)));
+        for (int l = 0; l < B; ++l) {
+          L[l] = 0.0;
+          L_factor[l] = wmax[l] * (double)ds->n_global / (ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global);
+        }
+        L_on_device = true;
+      } else if (!per_lane && !ds->rw) {
         // one operator for all lanes and no row weights that could blank the window: nothing on the host needs
         // the number -- the power steps are queued, seed_step_kernel writes L, the first inverse step and the
         // curvature floor into the control blocks, and the host goes on preparing the solve meanwhile
@@ -1745,6 +1781,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   if (L_on_device) {  // the power steps are still in flight: their result goes into the control blocks on the device
     SeedArgs sa;
     sa.ctl = ds->ctl; sa.lambda = ds->lambda; sa.n_lanes = B; sa.margin = 1.08;
+    for (int l = 0; l < kMaxLanes; ++l) sa.factor[l] = L_factor[l];
     hipLaunchKernelGGL(seed_step_kernel, dim3(1), dim3(64), 0, s, sa);
   }
   tr[0] = t_mark();

@@ -461,6 +461,7 @@ __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a)
   const unsigned mask = split_x_mask(a);
   if (mask == 0u) return;
   __shared__ double red[XZ_WAVES][SPLIT_LANES];
+  __shared__ double part[XZ_WAVES * XZ_T * 2 * 4 * 64];  // 64 KiB: the wavefronts' partial products of one step
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t b = blockIdx.x;
@@ -512,21 +513,39 @@ __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a)
     return;
   }
 
+  // Rows in tiles of 32 (a d2 load = two adjacent rows, sixteen lanes j = one 256-byte segment of a column of XT), the
+  // tiles dealt to the workgroups in contiguous, tile-aligned runs: every segment starts on a 256-byte boundary and no
+  // workgroup reads past its last tile.  (Until round 3 the blocks were the row-count-balanced ones of the other
+  // residual kernels -- 390 or 391 rows at n = 100k -- rounded OUT to 13 tiles from an arbitrary even row: PMC
+  // FETCH_SIZE 4.69 GB per launch for the 4.01 GB of XT, 0.75 ms at the 6.3 TB/s the memory system sustains;
+  // profiles/r03a_rowdot_counters.json.)
   const int j = lane & 15, q = lane >> 4;
-  const int64_t rbase = r0 & ~(int64_t)1;  // even: the 16-byte loads of XT stay aligned
-  const int64_t rend = r0 + nrows;
-  const int ntiles = (int)((rend - rbase + 31) >> 5);
+  const int64_t tiles_all = (a.n + 31) >> 5;
+  const int64_t tb = tiles_all / gridDim.x, tr = tiles_all % gridDim.x;
+  const int64_t t_lo = b * tb + (b < tr ? b : tr);
+  const int T = (int)(tb + (b < tr ? 1 : 0));
+  // A step = up to XZ_T adjacent tiles, taken by ALL wavefronts together: wavefront w contracts ITS quarter of the
+  // columns for every tile of the step, the four partial products meet in LDS and wavefront t finishes tile t.  (One
+  // wavefront per group of tiles, all columns -- the first layout -- left the wavefronts of a 13-tile block with 4, 4,
+  // 4 and 1 tiles; here a block's time is proportional to its tiles, and z is read once per step, not once per
+  // wavefront.)  Steps of equal size (13 tiles: 4 + 3 + 3 + 3), so that no step runs with a single tile's loads in flight.
+  const int nsteps = (T + XZ_T - 1) / XZ_T;
   const int ngroups = (int)(a.ld >> 4);
-  const double* zp = a.z + (int64_t)(j < a.n_lanes ? j : a.n_lanes - 1) * a.ld + 4 * q;
+  const int gb = ngroups / XZ_WAVES, gr = ngroups % XZ_WAVES;
+  const int g_lo = wave * gb + (wave < gr ? wave : gr);
+  const int g_n = gb + (wave < gr ? 1 : 0);
+  const double* zp = a.z + (int64_t)(j < a.n_lanes ? j : a.n_lanes - 1) * a.ld + 4 * q + 16 * (int64_t)g_lo;
   double loss[4] = {0.0, 0.0, 0.0, 0.0};  // of lane slots q, q + 4, q + 8, q + 12 over this lane's rows
-  for (int t0 = wave * XZ_T; t0 < ntiles; t0 += XZ_WAVES * XZ_T) {
-    const int nt = __builtin_amdgcn_readfirstlane(ntiles - t0 < XZ_T ? ntiles - t0 : XZ_T);
+  int t_at = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    const int nt = __builtin_amdgcn_readfirstlane(T / nsteps + (st < T % nsteps ? 1 : 0));
+    const int64_t row_s = 32 * (t_lo + t_at);  // first row of the step
     const double* xp[XZ_T];
 #pragma unroll
     for (int t = 0; t < XZ_T; ++t) {
-      int64_t rp = rbase + 32 * (int64_t)(t0 + t) + 2 * j;
-      if (rp > a.ldt - 2) rp = a.ldt - 2;  // (rows past the block are computed and dropped)
-      xp[t] = a.XT + (int64_t)(4 * q) * a.ldt + rp;
+      int64_t rp = row_s + 32 * (int64_t)t + 2 * j;
+      if (rp > a.ldt - 2) rp = a.ldt - 2;  // (rows past the matrix are computed and dropped)
+      xp[t] = a.XT + (int64_t)(4 * q + 16 * (int64_t)g_lo) * a.ldt + rp;
     }
     slm_d4 acc[XZ_T][2];
 #pragma unroll
@@ -554,28 +573,39 @@ __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a)
             acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[m], xv[m][t].y, acc[t][1], 0, 0, 0);
           }
     };
-    load(za, xa, 0);
-    for (int g = 0; g < ngroups; g += 2) {
-      if (g + 1 < ngroups) load(zb, xb, g + 1);
+    if (g_n > 0) load(za, xa, 0);
+    for (int g = 0; g < g_n; g += 2) {
+      if (g + 1 < g_n) load(zb, xb, g + 1);
       compute(za, xa);
-      if (g + 2 < ngroups) load(za, xa, g + 2);
-      if (g + 1 < ngroups) compute(zb, xb);
+      if (g + 2 < g_n) load(za, xa, g + 2);
+      if (g + 1 < g_n) compute(zb, xb);
     }
-    // result register r of lane l: lane slot (l >> 4) + 4 r, row 2 (l & 15) + e of the tile
+    // the partial products of this wavefront's columns: register r of accumulator (t, e) at [wave][t][e][r][lane]
 #pragma unroll
-    for (int t = 0; t < XZ_T; ++t) {
-      if (t >= nt) continue;
+    for (int t = 0; t < XZ_T; ++t)
+      if (t < nt) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[(((wave * XZ_T + t) * 2 + e) * 4 + r) * 64 + lane] = acc[t][e][r];
+      }
+    __syncthreads();
+    if (wave < nt) {  // wavefront t finishes tile t: result register r of lane l is lane slot (l >> 4) + 4 r, row 2 (l & 15) + e
+      const int t = wave;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int64_t row = rbase + 32 * (int64_t)(t0 + t) + 2 * j + e;
-        if (row < r0 || row >= rend) continue;
-        const double yi = a.y[row];
+        const int64_t row = row_s + 32 * (int64_t)t + 2 * j + e;
+        const bool in = row < a.n;
+        const double yi = a.y[in ? row : 0];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int l = q + 4 * r;
-          if ((mask >> l) & 1u) {
+          double v = 0.0;
+#pragma unroll
+          for (int w2 = 0; w2 < XZ_WAVES; ++w2) v += part[(((w2 * XZ_T + t) * 2 + e) * 4 + r) * 64 + lane];
+          if (in && ((mask >> l) & 1u)) {
             const double m = a.rw ? a.rw[(int64_t)l * a.rw_stride + row] : 1.0;
-            const double err = acc[t][e][r] - yi;
+            const double err = v - yi;
             const double res = err * m;
             a.R[row * SPLIT_RSTRIDE + l] = res;
             loss[r] = __builtin_fma(res, err, loss[r]);
@@ -583,6 +613,8 @@ __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a)
         }
       }
     }
+    __syncthreads();  // (the next step overwrites the partial products)
+    t_at += nt;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {

@@ -814,15 +814,19 @@ struct SeedArgs {
   const double* lambda;
   int n_lanes;
   double margin;
+  // lane l's operator is bounded by factor[l] times the one the estimate was taken on (lanes with their own row
+  // weights and 1/n scaling: max weight x n / n_l, see solve_core); 1 for lanes that share it
+  double factor[SLM_MAX_LANES];
 };
 __global__ void seed_step_kernel(SeedArgs a) {
   const int l = threadIdx.x;
   if (l >= a.n_lanes) return;
-  double L = a.lambda[0] * a.margin;
-  if (L <= 0.0) L = 1.0;  // X == 0
+  double L0 = a.lambda[0] * a.margin;
+  if (L0 <= 0.0) L0 = 1.0;  // X == 0
+  const double L = L0 * a.factor[l];
   a.ctl[l].L = L;
   a.ctl[l].ak = 1.25 * L;
-  a.ctl[l].Lhat = 0.5 * L;
+  a.ctl[l].Lhat = 0.5 * L0;
 }
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {

@@ -698,6 +698,7 @@ class Dataset:
         k_all = [int(np.asarray(spec["points"]).size // 3) for spec in lanes]
         beta_block = _host_pool.empty(sum(k_all) * self.p)
         gn_block = _host_pool.empty(sum(k_all) * G) if want_group_norms else None
+        infos_block = np.zeros(sum(k_all), dtype=_INFO_DTYPE)  # (one block: buffers that follow each other travel together)
         at = 0
         for l, spec in enumerate(lanes):
             pts = np.ascontiguousarray(spec["points"], dtype=np.float64).reshape(-1, 3)
@@ -718,8 +719,8 @@ class Dataset:
             rw = None if spec.get("row_weight") is None else _f64(spec["row_weight"], "row_weight", (self.n,))
             betas = beta_block[at * self.p : (at + K) * self.p].reshape(K, self.p)
             gn = gn_block[at * G : (at + K) * G].reshape(K, G) if want_group_norms else None
+            infos = infos_block[at : at + K]
             at += K
-            infos = np.zeros(K, dtype=_INFO_DTYPE)
             keep.append((cpts, a_, b_, d_, pen, b0, rw))
             clanes[l].pen = C.pointer(pen)
             clanes[l].points = _as(cpts, _PathPoint)

@@ -142,8 +142,18 @@ def _spread(sizes: Sequence[int]) -> list[list[int]]:
     return got
 
 
+def _chunks(sizes: Sequence[int]) -> list[list[int]]:
+    """The same pieces as contiguous ranges of the path (the first piece its top): every lane moves down the path one
+    point per pass, like a whole path would, but all pieces after the first start cold in the middle of the path."""
+    out, at = [], 0
+    for size in sizes:
+        out.append(list(range(at, at + size)))
+        at += size
+    return out
+
+
 def plan_lane_calls(unit_points: Sequence[int], unit_keys: Sequence[Any], world_size: int, lanes: int,
-                    fine: bool = True) -> list[list[list[list[tuple[int, list[int]]]]]]:
+                    fine: bool = True, spread: bool = True) -> list[list[list[list[tuple[int, list[int]]]]]]:
     """The calls every rank makes to solve a grid of warm-started paths, ``lanes`` lanes per call.
 
     ``unit_points[u]`` is the number of points of unit u's path (a unit: one (fold, other-parameters) pair of a
@@ -161,7 +171,8 @@ def plan_lane_calls(unit_points: Sequence[int], unit_keys: Sequence[Any], world_
     the path (`_spread`); the short pieces of units with the same key share lanes (first fit, decreasing), walked in
     alternating direction -- down one path, up the next -- so that consecutive points stay neighbours.  ``fine=False``
     (few lanes: the fused kernels without the working set, where a lane's cold start costs tens of passes) leaves
-    units whole.  Deterministic: every rank computes the same plan."""
+    units whole; ``spread=False`` cuts paths into contiguous ranges instead (`_chunks`; measurements).  Deterministic:
+    every rank computes the same plan."""
     n_units = len(unit_points)
     if len(unit_keys) != n_units:
         raise ValueError("one key per unit")
@@ -184,7 +195,7 @@ def plan_lane_calls(unit_points: Sequence[int], unit_keys: Sequence[Any], world_
         for u in rest:
             K = unit_points[u]
             sizes = [d] * (K // d) + ([K % d] if K % d else [])
-            for size, idx in zip(sizes, _spread(sizes)):
+            for size, idx in zip(sizes, _spread(sizes) if spread else _chunks(sizes)):
                 if size == d:
                     long_lanes.append((unit_keys[u], [(u, idx)]))
                 else:

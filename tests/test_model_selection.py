@@ -417,7 +417,7 @@ def test_the_shares_of_an_eight_rank_search_reproduce_the_one_rank_table(monkeyp
     for g in rng.choice(G, 5, replace=False):
         beta[groups == g] = rng.uniform(1.0, 4.0, p // G) * rng.choice([-1, 1], p // G)
     y = X @ beta + 2.0 * rng.standard_normal(n)
-    grid = {"alpha": list(np.geomspace(3.0, 0.01, 21)), "l1_ratio": [0.2, 0.5, 0.8]}
+    grid = {"alpha": list(np.geomspace(3.0, 0.01, 22)), "l1_ratio": [0.2, 0.5, 0.8]}
     cv = KFold(5, shuffle=True, random_state=0)
     est = SparseGroupLasso(groups=groups, solver_options={"tol": 1e-11})
     with warnings.catch_warnings():
@@ -426,12 +426,12 @@ def test_the_shares_of_an_eight_rank_search_reproduce_the_one_rank_table(monkeyp
         one = search._device_cells(X, y, rank=0, world=1)
         shares = [search._device_cells(X, y, rank=r, world=8) for r in range(8)]
         fitted = GridSearchCV(est, grid, cv=cv).fit(X, y)
-        slow = SkGridSearchCV(est, {"alpha": grid["alpha"][::5], "l1_ratio": [0.5]}, cv=cv,
+        slow = SkGridSearchCV(est, {"alpha": grid["alpha"][::7], "l1_ratio": [0.5]}, cv=cv,
                               scoring="neg_root_mean_squared_error").fit(X, y)
-    assert one.shape == (63, 5) and not np.isnan(one).any()
+    assert one.shape == (66, 5) and not np.isnan(one).any()
     owners = np.sum([~np.isnan(s) for s in shares], axis=0)
     assert np.all(owners == 1), "every (candidate, fold) cell belongs to exactly one rank"
-    assert all((~np.isnan(s)).sum() in range(36, 44) for s in shares)  # 315 fits over 8 ranks
+    assert all((~np.isnan(s)).sum() in range(39, 43) for s in shares)  # 330 fits over 8 ranks
     merged = np.nansum(shares, axis=0)
     np.testing.assert_allclose(merged, one, rtol=1e-8, atol=1e-10)
     table = np.c_[tuple(fitted.cv_results_[f"split{f}_test_score"] for f in range(5))]
@@ -443,7 +443,7 @@ def test_the_shares_of_an_eight_rank_search_reproduce_the_one_rank_table(monkeyp
     with g.open():
         plan = g.plan(8)
     lanes = [lane for calls in plan for call in calls for lane in call]
-    assert max(len(idx) for lane in lanes for _, idx in lane) < 21 and any(len(lane) > 1 for lane in lanes)
+    assert max(len(idx) for lane in lanes for _, idx in lane) == 3 and sum(len(lane) > 1 for lane in lanes) == 5
     # an independent referee on a few cells: scikit-learn's loop around single fits
     params = fitted.cv_results_["params"]
     for q, sp in zip(slow.cv_results_["params"], range(len(slow.cv_results_["params"]))):
