@@ -292,10 +292,10 @@ class Config4:
             self.unit_pts.append(np.c_[r * al, (1 - r) * al, 0 * al])
         self.lanes = _engine.MAX_LANES
 
-    def calls_of(self, world, rank, spread=True):
+    def calls_of(self, world, rank, **plan_options):
         from sparselm_amd import distributed as D
 
-        return D.plan_lane_calls([self.K] * len(self.units), [f for f, _ in self.units], world, self.lanes, spread=spread)[rank]
+        return D.plan_lane_calls([self.K] * len(self.units), [f for f, _ in self.units], world, self.lanes, **plan_options)[rank]
 
     def run_call(self, d, call, keep=None):
         from sparselm_amd import _engine
@@ -393,6 +393,137 @@ def leg_config4_grid(eng, rank, world, n, p, device_id=0, streams=3, emulate_wor
             c4.run(mine, n_streams)  # warm the copies
             out["seconds_streams"], _ = c4.run(mine, n_streams)
             out["streams"] = n_streams
+        return out
+    finally:
+        c4.close()
+
+
+def soak_case(seed, p):
+    """The law of tools/headline_soak.py: (coef, noise_sd, path floor as a fraction of alpha_max) of random dataset `seed`
+    -- 5...199 informative features of scale 1 or 100, noise 0.1 / 10 / 100, path down to 1e-3 / 1e-2 / 0.1 alpha_max."""
+    rng = np.random.default_rng(seed)
+    k = int(rng.integers(5, 200))
+    coef = np.zeros(p)
+    coef[rng.choice(p, k, replace=False)] = rng.choice([1.0, 100.0]) * rng.standard_normal(k)
+    noise = float(rng.choice([0.1, 10.0, 100.0]))
+    lo = float(rng.choice([1e-3, 1e-2, 0.1]))
+    return coef, noise, lo, k
+
+
+def leg_soak(eng, n, p, K, tol, lanes, seeds=range(4, 16)):
+    """The headline path on a DISTRIBUTION of datasets of the headline shape, not on the one the value is quoted on:
+    twelve seeds of `soak_case` (five of them noise-fitting paths whose ends outgrow the 512-column working set and
+    finish as plain steps on the sixteen-lane split pass).  Every path is checked against the plain four-lane
+    iteration of the same data (no working set, tol 1e-9)."""
+    from sparselm_amd import _engine
+
+    rows = []
+    for seed in seeds:
+        coef, noise, lo, k = soak_case(seed, p)
+        with eng.synthetic_dataset(n, p, seed=100 + seed, coef=coef, noise_sd=noise) as ds:
+            g0, _ = ds.gradient(None)
+            amax = float(np.max(np.abs(g0)))
+            pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, lo * amax, K)]
+            ds.solve_path(pts, tol=tol, lanes=lanes, flags=_engine.FLAG_FRESH_L)  # (one-off costs of a fresh dataset)
+            best = None
+            for _ in range(2):
+                eng.synchronize()
+                t0 = time.perf_counter()
+                r = ds.solve_path(pts, tol=tol, lanes=lanes, flags=_engine.FLAG_FRESH_L)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            q = ds.solve_path(pts, lanes=4, flags=_engine.FLAG_NO_WORKING_SET, tol=1e-9)
+            err = float(np.max(np.abs(r.betas - q.betas)) / max(float(np.max(np.abs(q.betas))), 1e-300))
+            rows.append({"seed": int(seed), "informative": k, "noise": noise, "floor": lo, "ms": 1e3 * best,
+                         "fits_per_s": K / best, "passes": int(r.grad_launches), "plain_passes": int(q.grad_launches),
+                         "nnz_last": int(np.count_nonzero(r.betas[-1])), "ws_columns": int(r.ws_columns),
+                         "converged": bool(r.converged and q.converged), "rel_inf_err_vs_plain": err})
+    return {"cases": rows}
+
+
+def leg_config3(eng, rank, world, n, p, tol, cpu_budget_s, steps=5):
+    """BASELINE config 3 (GroupLasso, 500 shuffled groups of 10, 50-alpha path) on the data law of `Config4`, timed on
+    the GPU; and -- rank 0 of a one-GPU run with a CPU budget -- an independent full-size referee for the group family:
+    the oracle's C twin (oracle/fista_ref.c, OpenMP) solves a prefix of that path, and one (fold, l1_ratio, alpha) cell
+    of config 4 from zero, on the downloaded (X, y); nothing of the engine enters its answer (its step size comes from
+    its own power iteration)."""
+    from sparselm_amd import _engine
+
+    c4 = Config4(eng, n, p)
+    try:
+        ds, G, groups, K = c4.ds, c4.G, c4.groups, c4.K
+        g0, _ = ds.gradient(None)
+        bmax = float(np.sqrt(np.bincount(groups, weights=g0 * g0, minlength=G)).max())
+        alphas = np.geomspace(bmax, 1e-3 * bmax, K)
+        pts = np.c_[0 * alphas, alphas, 0 * alphas]
+        for _ in range(2):
+            res = ds.solve_path(pts, tol=tol, lanes=16, flags=_engine.FLAG_FRESH_L)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = ds.solve_path(pts, tol=tol, lanes=16, flags=_engine.FLAG_FRESH_L)
+        eng.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out = {"fits_per_s": K / dt, "ms_per_path": 1e3 * dt, "passes": int(res.grad_launches), "converged": bool(res.converged),
+               "active_groups_last": int(np.sum(np.bincount(groups, weights=res.betas[-1] ** 2, minlength=G) > 0))}
+        if not (rank == 0 and world == 1 and cpu_budget_s > 0):
+            return out
+        # one cell of config 4 on the GPU: fold 2, l1_ratio 0.55, the path down to its 31st alpha
+        u = 2 * 10 + 5
+        f, ratio = c4.units[u]
+        cell_k = 30
+        cell = ds.solve_lanes([dict(points=c4.unit_pts[u][: cell_k + 1], row_weight=c4.masks[f], n_eff=int(c4.masks[f].sum()))],
+                              tol=tol)[0]
+        import oracle
+        from oracle import cref
+
+        X0, y = ds.download()
+        numa = cref.NumaMatrix(X0)
+        del X0
+        X = numa.array
+        gi = groups.astype(np.int32)
+
+        def twin_L(w):  # lambda_max(X^T W X) / n by the twin's own gradient: 8 power steps, 10 % margin
+            v = np.random.default_rng(0).standard_normal(p)
+            lam = 1.0
+            for _ in range(8):
+                v /= np.linalg.norm(v)
+                gv, _ = cref.gradient(X, 0.0 * y, v, w=w)
+                lam = float(np.linalg.norm(gv))
+                v = gv
+            return 1.1 * lam
+
+        L = twin_L(None)
+        beta, done, worst, iters = None, 0, 0.0, 0
+        t_start = time.perf_counter()
+        for k, alpha in enumerate(alphas):
+            if done >= 3 and time.perf_counter() - t_start > 0.6 * cpu_budget_s:
+                break
+            beta, it = cref.fista(X, y, 0.0, alpha, 0.0, gi, G, beta0=beta, L=L, tol=1e-9, max_iter=5000)
+            iters += abs(it)
+            done += 1
+            top = float(np.max(np.abs(beta)))
+            if k > 0 and top > 0:
+                worst = max(worst, float(np.max(np.abs(res.betas[k] - beta)) / top))
+        out["referee"] = {
+            "what": f"oracle/fista_ref.c (OpenMP, {cref.num_threads()} threads) on the downloaded data: the first {done} points of the "
+            f"GroupLasso path, warm-started, tol 1e-9 ({iters} gradients)",
+            "points_checked": done, "beta_rel_inf_err_gpu_vs_oracle": worst, "seconds": time.perf_counter() - t_start,
+        }
+        # the config-4 cell: minimise 1/(2 n_f) sum_i w_i e_i^2 + pen  ==  1/(2 n) sum_i w_i e_i^2 + (n_f / n) pen
+        w = c4.masks[f]
+        scale = float(w.sum()) / n
+        sa, sb, _ = c4.unit_pts[u][cell_k]
+        t_cell = time.perf_counter()
+        bc, it = cref.fista(X, y, scale * sa, scale * sb, 0.0, gi, G, L=twin_L(w), tol=1e-9, max_iter=3000, w=w)
+        top = float(np.max(np.abs(bc)))
+        out["referee_config4_cell"] = {
+            "what": f"SparseGroupLasso cell (fold {f}, l1_ratio {ratio:.2f}, alpha index {cell_k}) of config 4: the twin from zero "
+            f"on the fold's training rows ({abs(it)} gradients{'' if it > 0 else ', NOT converged'})",
+            "beta_rel_inf_err_gpu_vs_oracle": float(np.max(np.abs(cell.betas[cell_k] - bc)) / top) if top > 0 else None,
+            "nonzeros": int(np.count_nonzero(bc)), "seconds": time.perf_counter() - t_cell,
+        }
+        numa.__exit__()
         return out
     finally:
         c4.close()
@@ -723,6 +854,8 @@ def main():
 
         with Watchdog(args.extra_timeout, expire):
             for name, fn in (("config4_grid", lambda: leg_config4_grid(eng, rank, world, n, p, device_id)),
+                             ("config3_path", lambda: leg_config3(eng, rank, world, n, p, args.tol, args.cpu_budget)),
+                             ("soak", lambda: leg_soak(eng, n, p, K, args.tol, args.lanes) if rank == 0 else {}),
                              ("concurrent_paths", lambda: leg_concurrent_paths(eng, device_id, rank, n, p, K, args.tol, args.lanes)),
                              ("rowshard", lambda: leg_rowshard(eng, rank, world, args.rowshard_rows, args.rowshard_cols))):
                 try:
@@ -768,6 +901,33 @@ def main():
                             "points_imbalance_max_over_mean": max(q["points"] for q in sh) / (sum(q["points"] for q in sh) / len(sh)),
                             "seconds_imbalance_max_over_mean": worst / (sum(q["seconds"] for q in sh) / len(sh)),
                         }
+                elif name == "config3_path":
+                    legs[name] = {
+                        "what": "BASELINE config 3: GroupLasso, 500 shuffled groups x 10 features, 50-alpha warm-started path at "
+                        "n=100k p=5k, sixteen lanes, per rank; referee*: the oracle's C twin on the host cores (rank 0, one GPU)",
+                        "fits_per_s": [q["fits_per_s"] for q in parts], "ms_per_path": [q["ms_per_path"] for q in parts],
+                        "passes": parts[0]["passes"], "converged": all(q["converged"] for q in parts),
+                        "active_groups_last": parts[0]["active_groups_last"],
+                        **{k: v for k, v in parts[0].items() if k.startswith("referee")},
+                    }
+                elif name == "soak":
+                    cases = parts[0]["cases"]
+                    rate = sorted(c["fits_per_s"] for c in cases)
+                    dense = [c for c in cases if c["nnz_last"] > 512]
+                    legs[name] = {
+                        "what": "the headline path on twelve random datasets of the headline shape (seeds 4..15 of "
+                        "tools/headline_soak.py's law: 5..199 informative features, noise 0.1..100, path floor 1e-3..0.1 "
+                        "alpha_max), each checked against the plain four-lane iteration; never part of `value`",
+                        "median_fits_per_s": rate[len(rate) // 2], "worst_fits_per_s": rate[0], "best_fits_per_s": rate[-1],
+                        "paths_ending_above_512_nonzeros": len(dense),
+                        "passes": [c["passes"] for c in cases], "ms": [round(c["ms"], 2) for c in cases],
+                        "nnz_last": [c["nnz_last"] for c in cases],
+                        "worst_rel_inf_err_vs_plain_iteration": max(c["rel_inf_err_vs_plain"] for c in cases),
+                        "all_converged": all(c["converged"] for c in cases),
+                        "median_ms_dense_end": (sorted(c["ms"] for c in dense)[len(dense) // 2] if dense else None),
+                        "median_ms_sparse_end": sorted(c["ms"] for c in cases if c["nnz_last"] <= 512)[(len(cases) - len(dense)) // 2]
+                        if len(dense) < len(cases) else None,
+                    }
                 elif name == "concurrent_paths":
                     legs[name] = {
                         "what": "the headline path on three engines (streams) of ONE GPU at once, a dataset and a host thread "

@@ -26,6 +26,30 @@ __global__ __launch_bounds__(256) void transpose_f2c_kernel(const double* __rest
   }
 }
 
+// The column-major copy of X the working set gathers from and rowdot_mfma_kernel streams, in tiles of 32 rows:
+//   XT[((i >> 5) * ld + j) * 32 + (i & 31)] = X[i][j]
+// -- inside a tile of rows a column is 256 contiguous bytes (what a gather moves per request, what sixteen lanes of an
+// MFMA operand load cover), the columns of a tile follow each other (four columns = one KiB, a batch of sixteen = 4 KiB
+// per request group), and the tiles of a block of rows follow each other: every reader walks its part linearly.  As a
+// plain [ld][n] matrix (until round 3) the 256-byte pieces of consecutive columns lay 8 n bytes apart -- a new DRAM row
+// and, every third column, a new 2 MB page per piece.  Rows beyond n inside the last tile are written as zeros.
+// grid ((n + 31) / 32, (ld + 31) / 32).
+__global__ __launch_bounds__(256) void tile_columns_kernel(const double* __restrict__ X, int64_t n, int64_t ld,
+                                                           double* __restrict__ XT) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t i0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
+  for (int k = ty; k < 32; k += 8) {  // read: consecutive lanes walk columns j (contiguous in X)
+    const int64_t i = i0 + k, j = j0 + tx;
+    tile[k][tx] = (i < n && j < ld) ? X[i * ld + j] : 0.0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {  // write: consecutive lanes walk the 32 rows of the tile (contiguous in XT)
+    const int64_t j = j0 + k;
+    if (j < ld) XT[((int64_t)blockIdx.x * ld + j) * 32 + tx] = tile[tx][k];
+  }
+}
+
 // Row-major copy with different leading dimensions (device -> device), pad columns left untouched.
 __global__ __launch_bounds__(256) void copy_rows_kernel(const double* __restrict__ src, int64_t n,
                                                         int64_t p, int64_t lds_, double* __restrict__ dst,

@@ -384,8 +384,7 @@ struct slm_dataset {
   size_t sse_cap = 0;
   PathCtl h_stage[SLM_MAX_LANES];  // host staging of the control blocks of the solve in flight
   double* stop_words = nullptr;  // [STOP_WORDS] row-sharded mode: the vector the ranks all-reduce after every pass
-  double* XT = nullptr;  // column-major copy of X for the column gathers ([ld][ldt]), built on first use
-  int64_t ldt = 0;
+  double* XT = nullptr;  // column-major copy of X in tiles of 32 rows (tile_columns_kernel), built on first use
   bool XT_ready = false, XT_failed = false;
   int ws_sets = 0;  // Gram copies allocated
   // gradient launch, per lane count B = 1..kMaxLanes (index B-1); gk == nullptr => unsupported
@@ -967,8 +966,8 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
     hipLaunchKernelGGL(gk->fn, dim3(nblk), dim3(gk->W * 64), 0, s, a);
   } else {  // two-pass fallback (one lane; row weights shared)
     TwoPassArgs t;
-    t.X = ds->X; t.y = y; t.rw = ls.rw; t.z = ds->z; t.r = ds->rvec; t.partial = ds->partial;
-    t.loss_partial = ds->loss_partial; t.done = done; t.n = nr; t.ld = ds->ld;
+    t.X = ds->X; t.y = y; t.rw = ls.rw; t.z = a.z; t.r = ds->rvec; t.partial = a.partial;
+    t.loss_partial = a.loss_partial; t.done = done; t.n = nr; t.ld = ds->ld;
     t.rows_base = a.rows_base; t.rows_rem = a.rows_rem; t.p2 = a.p2;
     hipLaunchKernelGGL(rowdot_kernel, dim3(nblk), dim3(256), 0, s, t);
     const unsigned tiles = (unsigned)((a.p2 + 512 * kTwoPassC - 1) / (512 * kTwoPassC));
@@ -976,8 +975,8 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
   }
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
   ReduceArgs ra;
-  ra.partial = ds->partial;
-  ra.loss_partial = ds->loss_partial;
+  ra.partial = a.partial;
+  ra.loss_partial = a.loss_partial;
   ra.g = ds->g;
   ra.done = done;
   ra.nblk = nblk;
@@ -1010,7 +1009,6 @@ static void launch_rowdot(slm_dataset* ds, const SplitKernel* sk, int nblk, int 
   a.lane0 = 0;
   if ((!ring || sk->rowdot == nullptr) && ds->XT && ds->XT_ready) {
     a.XT = ds->XT;
-    a.ldt = ds->ldt;
     hipLaunchKernelGGL(rowdot_mfma_kernel, dim3(nblk), dim3(XZ_WAVES * 64), 0, s, a);
   } else if (sk->rowdot != nullptr) {
     hipLaunchKernelGGL(sk->rowdot, dim3(nblk, (B + ROWDOT_LANES - 1) / ROWDOT_LANES), dim3(sk->W * 64), 0, s, a);
@@ -1382,9 +1380,9 @@ extern "C" int slm_eval_sse(slm_dataset* ds, const double* Z, int32_t m, const d
 static int ensure_xt(slm_dataset* ds) {
   hipStream_t s = ds->eng->stream;
   const int64_t n = ds->n, ld = ds->ld;
+  const int64_t row_tiles = (n + 31) / 32;
   if (!ds->XT && !ds->XT_failed) {
-    ds->ldt = (n + 15) / 16 * 16;
-    if (hipMalloc((void**)&ds->XT, sizeof(double) * (size_t)ld * ds->ldt) != hipSuccess) {
+    if (hipMalloc((void**)&ds->XT, sizeof(double) * (size_t)ld * (size_t)row_tiles * 32) != hipSuccess) {
       (void)hipGetLastError();
       ds->XT = nullptr;
       ds->XT_failed = true;
@@ -1392,8 +1390,8 @@ static int ensure_xt(slm_dataset* ds) {
   }
   if (ds->XT && !ds->XT_ready) {
     ds->XT_ready = true;
-    const dim3 grid((unsigned)((ld + 31) / 32), (unsigned)((n + 31) / 32));
-    hipLaunchKernelGGL(transpose_f2c_kernel, grid, dim3(256), 0, s, (const double*)ds->X, ld, n, ds->XT, ds->ldt);
+    const dim3 grid((unsigned)row_tiles, (unsigned)((ld + 31) / 32));
+    hipLaunchKernelGGL(tile_columns_kernel, grid, dim3(256), 0, s, (const double*)ds->X, n, ld, ds->XT);
   }
   return SLM_OK;
 }
@@ -1439,7 +1437,7 @@ extern "C" int slm_eval_sse_sparse(slm_dataset* ds, const int32_t* cols, int32_t
   bail(hipMemcpyAsync(dZ, Zs, sizeof(double) * (size_t)m * n_cols, hipMemcpyHostToDevice, s));
   if (rc == SLM_OK) {
     GatherArgs ga;
-    ga.X = ds->X; ga.XT = ds->XT; ga.n = n; ga.ld = ds->ld; ga.ldt = ds->ldt;
+    ga.X = ds->X; ga.XT = ds->XT; ga.n = n; ga.ld = ds->ld;
     ga.idx = ds->ws_idx; ga.K = n_cols; ga.XW = ds->ws_XW;
     hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)std::min<int64_t>((n + 31) / 32, 1024), (unsigned)((n_cols + 31) / 32)),
                        dim3(256), 0, s, ga);
@@ -1651,6 +1649,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         // the number -- the power steps are queued, seed_step_kernel writes L, the first inverse step and the
         // curvature floor into the control blocks, and the host goes on preparing the solve meanwhile
         // (it used to wait for them: 0.2 ms of idle stream per path)
+        // (on a side stream beside the first pass, on vectors of its own, the seed saved nothing: the pass is bound by
+        //  the memory system, and the 0.4 GB the three power steps read through it come out of the same budget -- 4.26 ms
+        //  per path either way, profiles/r03a_seed_beside_ab.txt)
         SLM_TRY(power_iteration(ds, default_lanes(ds, 1), nullptr, kPowerItersSketch, sketch_rows(n)));
         for (int l = 0; l < B; ++l) L[l] = 0.0;
         L_on_device = true;
@@ -1879,7 +1880,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     wa.nt = getenv("SLM_NO_DIRECT") ? nullptr : ds->ws_nt;
     if (eng->sharded() && !ds->ws_Gx) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)ds->ws_sets * WS_KCAP * WS_KCAP));
     wa.Gx = eng->sharded() ? ds->ws_Gx : nullptr;  // row-sharded: Gram parts are summed over ranks before use
-    wa.X = ds->X; wa.XT = ds->XT; wa.ldt = ds->ldt; wa.n = n; wa.ld = ld;
+    wa.X = ds->X; wa.XT = ds->XT; wa.n = n; wa.ld = ld;
     wa.rw = ls.rw; wa.rw_stride = ls.rw_stride;
     for (int l = 0; l < kMaxLanes; ++l) {
       wa.set_of[l] = l < B ? set_of[l] : 0;

@@ -49,8 +49,7 @@ struct SplitArgs {
   int n_lanes;
   int lane0;  // rowdot_ring_kernel: first lane of this launch
   int xrows;  // xtr_mfma_kernel: rows per workgroup row (multiple of 8); partial is then [gridDim.y][SPLIT_LANES][ld]
-  const double* XT;  // rowdot_mfma_kernel: column-major copy of X, [ld][ldt]
-  int64_t ldt;
+  const double* XT;  // rowdot_mfma_kernel: column-major copy of X in tiles of 32 rows (tile_columns_kernel)
 };
 
 // which lanes take their residual from XW: live, flagged by ws_solve_kernel, and W still published
@@ -404,12 +403,27 @@ __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a
         acc[2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].y, rv[u], acc[2 * c + 1], 0, 0, 0);
       }
   };
-  if (nb > 0) load(xa, ra, 0);
-  for (int b = 0; b < nb; b += 2) {
-    if (b + 1 < nb) load(xb, rb, b + 1);
-    compute(xa, ra);
-    if (b + 2 < nb) load(xa, ra, b + 2);
-    if (b + 1 < nb) compute(xb, rb);
+  // (straight-line steady state, the odd batch peeled off: with `if (b + 1 < nb) load(...)` in the loop the compiler
+  //  had to wait at the first product of a batch as if the batch behind it had not been asked for -- vmcnt(1) with
+  //  ten loads just issued.  The exact counts changed nothing measurable here -- 0.587-0.618 ms either way on one box,
+  //  profiles/r03a_xtr_peel_ab.txt: the kernel waits for the memory system, not for its own waits -- but they are what
+  //  took rowdot_mfma_kernel, which has the same loop, from 0.69 to 0.60 ms)
+  if (nb > 0) {
+    load(xa, ra, 0);
+    const int pairs = (nb - 1) >> 1;
+    for (int k = 0; k < pairs; ++k) {
+      load(xb, rb, 2 * k + 1);
+      compute(xa, ra);
+      load(xa, ra, 2 * k + 2);
+      compute(xb, rb);
+    }
+    if ((nb - 1) & 1) {
+      load(xb, rb, nb - 1);
+      compute(xa, ra);
+      compute(xb, rb);
+    } else {
+      compute(xa, ra);
+    }
   }
   // the last rows of the block (fewer than 8): 4-row steps, rows past the end contribute R = 0
   for (int64_t row = r0 + (int64_t)nb * (4 * XTR_U); row < r1; row += 4) {
@@ -454,6 +468,63 @@ __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a
 // ---------------------------------------------------------------------------------------------
 constexpr int XZ_WAVES = 4;
 constexpr int XZ_T = 4;
+
+// One step of rowdot_mfma_kernel for one wavefront: NT adjacent tiles of 32 rows x this wavefront's g_n groups of 16
+// columns.  xt0: tile 0, first column of the wavefront, this lane's row pair (tile t: + 32 ld t doubles); zp: this lane's
+// four z values of the first group.  The partial products go to part[t][e][r][lane] (`mine` points at this lane).
+// Straight-line steady state -- two batches of a group each, the second in flight while the first is multiplied -- with
+// the odd batch peeled off, so that every wait is an exact count.
+template <int NT>
+__device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const double* zp, int g_n, double* mine) {
+  slm_d4 acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t][0] = acc[t][1] = slm_d4{0.0, 0.0, 0.0, 0.0};
+  slm_d4 za, zb;
+  d2 xa[4][NT], xb[4][NT];
+  auto load = [&](slm_d4& zv, d2(&xv)[4][NT], int g) {
+    zv = *reinterpret_cast<const slm_d4*>(zp + 16 * g);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const d2* src = reinterpret_cast<const d2*>(xt0 + (((int64_t)t * ld + 16 * g + m) << 5));
+        xv[m][t] = SLM_NT_LOADS ? __builtin_nontemporal_load(src) : *src;
+      }
+  };
+  auto compute = [&](const slm_d4& zv, d2(&xv)[4][NT]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[m], xv[m][t].x, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[m], xv[m][t].y, acc[t][1], 0, 0, 0);
+      }
+  };
+  if (g_n > 0) {
+    load(za, xa, 0);
+    const int pairs = (g_n - 1) >> 1;
+    for (int k = 0; k < pairs; ++k) {
+      load(zb, xb, 2 * k + 1);
+      compute(za, xa);
+      load(za, xa, 2 * k + 2);
+      compute(zb, xb);
+    }
+    if ((g_n - 1) & 1) {
+      load(zb, xb, g_n - 1);
+      compute(za, xa);
+      compute(zb, xb);
+    } else {
+      compute(za, xa);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[((t * 2 + e) * 4 + r) * 64] = acc[t][e][r];
+}
+
 
 __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 rows of the MFMA A operand");
@@ -540,55 +611,17 @@ __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a)
   for (int st = 0; st < nsteps; ++st) {
     const int nt = __builtin_amdgcn_readfirstlane(T / nsteps + (st < T % nsteps ? 1 : 0));
     const int64_t row_s = 32 * (t_lo + t_at);  // first row of the step
-    const double* xp[XZ_T];
-#pragma unroll
-    for (int t = 0; t < XZ_T; ++t) {
-      int64_t rp = row_s + 32 * (int64_t)t + 2 * j;
-      if (rp > a.ldt - 2) rp = a.ldt - 2;  // (rows past the matrix are computed and dropped)
-      xp[t] = a.XT + (int64_t)(4 * q + 16 * (int64_t)g_lo) * a.ldt + rp;
+    // (one instantiation per number of tiles: with `if (t < nt)` around the loads and products of a tile the compiler
+    //  could not count the loads in flight and put s_waitcnt vmcnt(0) before every pair of MFMAs -- the batch just
+    //  asked for included: no overlap of loads and products at all)
+    const double* xt0 = a.XT + (((t_lo + t_at) * a.ld + 4 * q + 16 * (int64_t)g_lo) << 5) + 2 * j;
+    double* mine = part + (size_t)wave * XZ_T * 2 * 4 * 64 + lane;
+    switch (nt) {
+      case 1: rowdot_step<1>(xt0, a.ld, zp, g_n, mine); break;
+      case 2: rowdot_step<2>(xt0, a.ld, zp, g_n, mine); break;
+      case 3: rowdot_step<3>(xt0, a.ld, zp, g_n, mine); break;
+      default: rowdot_step<4>(xt0, a.ld, zp, g_n, mine); break;
     }
-    slm_d4 acc[XZ_T][2];
-#pragma unroll
-    for (int t = 0; t < XZ_T; ++t) acc[t][0] = acc[t][1] = slm_d4{0.0, 0.0, 0.0, 0.0};
-    slm_d4 za, zb;
-    d2 xa[4][XZ_T], xb[4][XZ_T];
-    auto load = [&](slm_d4& zv, d2(&xv)[4][XZ_T], int g) {
-      zv = *reinterpret_cast<const slm_d4*>(zp + 16 * g);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int t = 0; t < XZ_T; ++t)
-          if (t < nt) {
-            const d2* src = reinterpret_cast<const d2*>(xp[t] + (int64_t)(16 * g + m) * a.ldt);
-            xv[m][t] = SLM_NT_LOADS ? __builtin_nontemporal_load(src) : *src;
-          }
-    };
-    auto compute = [&](const slm_d4& zv, d2(&xv)[4][XZ_T]) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int t = 0; t < XZ_T; ++t)
-          if (t < nt) {
-            acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[m], xv[m][t].x, acc[t][0], 0, 0, 0);
-            acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[m], xv[m][t].y, acc[t][1], 0, 0, 0);
-          }
-    };
-    if (g_n > 0) load(za, xa, 0);
-    for (int g = 0; g < g_n; g += 2) {
-      if (g + 1 < g_n) load(zb, xb, g + 1);
-      compute(za, xa);
-      if (g + 2 < g_n) load(za, xa, g + 2);
-      if (g + 1 < g_n) compute(zb, xb);
-    }
-    // the partial products of this wavefront's columns: register r of accumulator (t, e) at [wave][t][e][r][lane]
-#pragma unroll
-    for (int t = 0; t < XZ_T; ++t)
-      if (t < nt) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) part[(((wave * XZ_T + t) * 2 + e) * 4 + r) * 64 + lane] = acc[t][e][r];
-      }
     __syncthreads();
     if (wave < nt) {  // wavefront t finishes tile t: result register r of lane l is lane slot (l >> 4) + 4 r, row 2 (l & 15) + e
       const int t = wave;

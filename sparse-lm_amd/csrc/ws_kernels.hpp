@@ -115,8 +115,7 @@ struct WsArgs {
   double* Gx;      // row-sharded mode: [n_sets][WS_KCAP * WS_KCAP] staging, zeroed every pass, summed over
                    // ranks between ws_gram_reduce_kernel and ws_publish_kernel (nullptr otherwise)
   const double* X;
-  const double* XT;   // column-major copy of X ([p][ldt], built once per dataset): columns are contiguous
-  int64_t ldt;
+  const double* XT;   // column-major copy of X in tiles of 32 rows (tile_columns_kernel; built once per dataset)
   int64_t n, ld;
   const double* rw;   // row weights per set, or nullptr (all ones)
   int64_t rw_stride;
@@ -545,8 +544,8 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
 
 // ---------------------------------------------------------------------------------------------
 // (ii) gather the new columns: XW[i][k] = X[i][idx[k]] for k >= k_new (0 for padding positions).
-// Read from the column-major copy XT, where a column is contiguous, through a 32 x 32 LDS tile, so
-// reads and writes both move 256-byte segments.  (Gathering from the row-major X touches one 64-byte
+// Read from the column-major copy XT, where the 32 rows of a tile of a column are contiguous, through a 32 x 32 LDS
+// tile, so reads and writes both move 256-byte segments.  (Gathering from the row-major X touches one 64-byte
 // sector per element: 0.2 ms for 112 columns, 0.5 ms per 50-alpha path.)  grid (row tiles, 16 column
 // tiles of 32 starting at k_new); tiles beyond K return at once.
 // ---------------------------------------------------------------------------------------------
@@ -574,7 +573,7 @@ __global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
     for (int u = 0; u < 4; ++u) {  // read: lanes walk rows i (contiguous in XT)
       const int j = jcol[u];
       // (XT == nullptr: no memory for the column-major copy -- same tile, sector-granular reads from X)
-      v[u] = (j >= 0 && i < w.n) ? (w.XT ? w.XT[(int64_t)j * w.ldt + i] : w.X[i * w.ld + j]) : 0.0;
+      v[u] = (j >= 0 && i < w.n) ? (w.XT ? w.XT[((rt * w.ld + j) << 5) + tx] : w.X[i * w.ld + j]) : 0.0;
     }
     __syncthreads();  // the tile of the previous round has been written out
 #pragma unroll
@@ -1810,7 +1809,7 @@ constexpr int SSE_M = 16;
 struct GatherArgs {
   const double* X;
   const double* XT;  // nullptr: read the row-major X
-  int64_t n, ld, ldt;
+  int64_t n, ld;
   const int32_t* idx;  // [K] columns (all >= 0)
   int K;               // multiple of 16 is not required
   double* XW;          // [n][WS_KCAP]
@@ -1829,7 +1828,7 @@ __global__ __launch_bounds__(256) void gather_cols_kernel(GatherArgs w) {
       const int k = k0 + kk;
       const int j = k < w.K ? w.idx[k] : -1;
       const int64_t i = i0 + tx;
-      tile[kk][tx] = (j >= 0 && i < w.n) ? (w.XT ? w.XT[(int64_t)j * w.ldt + i] : w.X[i * w.ld + j]) : 0.0;
+      tile[kk][tx] = (j >= 0 && i < w.n) ? (w.XT ? w.XT[((rt * w.ld + j) << 5) + tx] : w.X[i * w.ld + j]) : 0.0;
     }
     __syncthreads();
     for (int ii = ty; ii < 32; ii += 8) {

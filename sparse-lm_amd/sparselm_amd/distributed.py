@@ -153,7 +153,7 @@ def _chunks(sizes: Sequence[int]) -> list[list[int]]:
 
 
 def plan_lane_calls(unit_points: Sequence[int], unit_keys: Sequence[Any], world_size: int, lanes: int,
-                    fine: bool = True, spread: bool = True) -> list[list[list[list[tuple[int, list[int]]]]]]:
+                    fine: bool = True, spread: bool = True, snake: bool = True) -> list[list[list[list[tuple[int, list[int]]]]]]:
     """The calls every rank makes to solve a grid of warm-started paths, ``lanes`` lanes per call.
 
     ``unit_points[u]`` is the number of points of unit u's path (a unit: one (fold, other-parameters) pair of a
@@ -171,8 +171,8 @@ def plan_lane_calls(unit_points: Sequence[int], unit_keys: Sequence[Any], world_
     the path (`_spread`); the short pieces of units with the same key share lanes (first fit, decreasing), walked in
     alternating direction -- down one path, up the next -- so that consecutive points stay neighbours.  ``fine=False``
     (few lanes: the fused kernels without the working set, where a lane's cold start costs tens of passes) leaves
-    units whole; ``spread=False`` cuts paths into contiguous ranges instead (`_chunks`; measurements).  Deterministic:
-    every rank computes the same plan."""
+    units whole; ``spread=False`` cuts paths into contiguous ranges instead (`_chunks`), ``snake=False`` walks every
+    piece of a shared lane from the top of its path (both: measurements).  Deterministic: every rank computes the same plan."""
     n_units = len(unit_points)
     if len(unit_keys) != n_units:
         raise ValueError("one key per unit")
@@ -211,7 +211,7 @@ def plan_lane_calls(unit_points: Sequence[int], unit_keys: Sequence[Any], world_
                 else:
                     bins.append((size, [(u, idx)]))
             for _, segs in bins:
-                segs = [(u, idx if k % 2 == 0 else idx[::-1]) for k, (u, idx) in enumerate(segs)]
+                segs = [(u, idx if (k % 2 == 0 or not snake) else idx[::-1]) for k, (u, idx) in enumerate(segs)]
                 packed.append((key, segs))
         if len(long_lanes) + len(packed) <= slots or d >= kmax:
             break

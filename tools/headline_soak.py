@@ -4,21 +4,18 @@ count, and agreement with the plain 4-lane iteration of the same data."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-sys.path.insert(0, os.path.join(ROOT, "sparse-lm_amd"))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "sparse-lm_amd")]
+from bench import soak_case  # (the law of the datasets: shared with bench.py's `soak` leg)
 from sparselm_amd import _engine
 eng = _engine.get_engine(0)
 n, p = 100000, 5000
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 worst, slow, bad = 0.0, 0, 0
 for seed in range(seeds):
-    rng = np.random.default_rng(seed)
-    k = int(rng.integers(5, 200))
-    coef = np.zeros(p); coef[rng.choice(p, k, replace=False)] = rng.choice([1.0, 100.0]) * rng.standard_normal(k)
-    noise = float(rng.choice([0.1, 10.0, 100.0]))
+    coef, noise, lo, k = soak_case(seed, p)
     with eng.synthetic_dataset(n, p, seed=100 + seed, coef=coef, noise_sd=noise) as ds:
         g0, _ = ds.gradient(None)
         amax = float(np.max(np.abs(g0)))
-        lo = float(rng.choice([1e-3, 1e-2, 0.1]))
         pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, lo * amax, 50)]
         t = time.perf_counter(); r = ds.solve_path(pts, lanes=16, flags=_engine.FLAG_FRESH_L); dt = (time.perf_counter() - t) * 1e3
         q = ds.solve_path(pts, lanes=4, flags=_engine.FLAG_NO_WORKING_SET, tol=1e-9)
