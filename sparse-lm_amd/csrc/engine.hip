@@ -27,6 +27,7 @@
 #include "tail_kernels.hpp"
 #include "ws_kernels.hpp"
 #include "split_kernels.hpp"
+#include "small_kernels.hpp"
 
 using namespace slm;
 
@@ -155,7 +156,8 @@ static const GradKernel kGradExtra[] = {
     SLM_GK(8, 8, 1, 1), SLM_GK(8, 5, 1, 2), SLM_GK(8, 5, 1, 3), SLM_GK(8, 4, 4, 2), SLM_GK(8, 6, 1, 2),
 };
 static const int kMaxTailE = 64;  // tail kernel instantiations cover p <= 1024 * 64
-static const int kProfStride = 2;  // SLM_FLAG_PROFILE times every 2nd gradient launch (a working-set path has ~6)
+static const int kProfStride = 3;  // SLM_FLAG_PROFILE times every 3rd gradient launch (a working-set path has ~5: two of them;
+                                   // an event pair costs ~12 us of stream around the launch it brackets)
 static const int64_t kMaxChunks = 64 * 8 * 10;  // largest row the fused kernel covers (p <= 10240)
 
 // Rows longer than the fused kernels cover: two-pass fallback (D = -1), one lane, any p.
@@ -1487,9 +1489,20 @@ static int ws_policy(const slm_dataset* ds, uint32_t flags) {
   const bool big = (double)ds->n * (double)ds->ld >= 67108864.0;  // 2^26 doubles = 512 MiB
   return (big || (flags & SLM_FLAG_WORKING_SET) || (env && env[0] == '1')) ? 2 : 1;
 }
+// The on-chip solver (small_kernels.hpp) takes a call when the caller allows it (SLM_FLAG_ON_CHIP), the Gram matrix
+// fits the LDS and nothing asks for a particular iteration of the general path.
+static bool small_ok(const slm_dataset* ds, uint32_t flags) {
+  if (!(flags & SLM_FLAG_ON_CHIP)) return false;
+  if (flags & (SLM_FLAG_NO_RESTART | SLM_FLAG_PROFILE | SLM_FLAG_FISTA_ONLY | SLM_FLAG_WORKING_SET | SLM_FLAG_NO_WORKING_SET))
+    return false;
+  if (const char* env = getenv("SLM_ON_CHIP"))
+    if (env[0] == '0') return false;
+  return ds->p <= SM_PMAX && (double)ds->n * (double)ds->ld <= 131072.0 && !ds->eng->sharded();
+}
 // most lanes one solve can run: the fused kernels' table, or the split pass's sixteen when the working
 // set is on from the start
 static int max_lanes_for(slm_dataset* ds, uint32_t flags) {
+  if (small_ok(ds, flags)) return kMaxLanes;  // a workgroup per lane
   if ((ws_policy(ds, flags) == 2 || (double)ds->n * (double)ds->ld >= 67108864.0) && split_usable(ds)) return SPLIT_LANES;
   int B = kMaxLanes;
   while (B > 1 && !ds->gk[B - 1]) --B;
@@ -1523,7 +1536,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // 10.9 ms per path against 250 columns and 10.3 ms with contiguous ranges.)
   const bool interleave = shared_path && ds->singleton && ws_policy(ds, opts ? opts->flags : 0u) == 2 &&
                           !getenv("SLM_NO_INTERLEAVE");
-  if (!split && !ds->gk[B - 1])
+  if (!split && !ds->gk[B - 1] && !small_ok(ds, opts ? opts->flags : 0u))
     return fail(SLM_ERR_UNSUPPORTED, "no %d-lane gradient kernel covers p = %lld", B, (long long)ds->p);
   if (split && B > ROWDOT_LANES) SLM_TRY(ensure_xt(ds));  // rowdot_mfma_kernel reads the column-major copy (optional)
   int64_t total_points = 0;
@@ -1609,14 +1622,15 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       custom_scale = true;
     }
 
+  const bool small = small_ok(ds, o.flags);
   // ---- Lipschitz constants -----------------------------------------------------------------------
   double L[SLM_MAX_LANES];
   double lipschitz_ms = 0.0;
   bool L_on_device = false;  // the estimate stays on the device (no host round trip before the first pass)
   double L_factor[SLM_MAX_LANES];  // ... and lane l uses L_factor[l] times it
   for (int l = 0; l < kMaxLanes; ++l) L_factor[l] = 1.0;
-  if (o.L > 0.0) {
-    for (int l = 0; l < B; ++l) L[l] = o.L;
+  if (o.L > 0.0 || small) {  // (the on-chip solver bounds its own steps from the Gram matrix)
+    for (int l = 0; l < B; ++l) L[l] = o.L > 0.0 ? o.L : 1.0;
   } else {
     const auto t0 = std::chrono::steady_clock::now();
     bool ran = false;
@@ -1819,6 +1833,113 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   ta.gn_out = any_gn ? ds->gn_out : nullptr;
   ta.infos = d_infos;
 
+  // results: lanes whose host buffers follow each other (the ranges of one shared path do) travel in one
+  // copy -- a device-to-host copy into pageable memory costs ~40 us before the first byte moves.  Queued on the
+  // solve's stream; the caller waits for it.
+  auto enqueue_result_copies = [&]() -> int {
+    int64_t at = 0;
+    for (int l = 0; l < B;) {
+      int l1 = l + 1;
+      int64_t pts = lanes[l].n_points;
+      const bool gn = lanes[l].group_norms_out != nullptr, inf = lanes[l].infos != nullptr;
+      while (l1 < B && lanes[l1].betas_out == lanes[l].betas_out + (size_t)pts * p &&
+             (lanes[l1].group_norms_out != nullptr) == gn && (lanes[l1].infos != nullptr) == inf &&
+             (!gn || lanes[l1].group_norms_out == lanes[l].group_norms_out + (size_t)pts * G) &&
+             (!inf || lanes[l1].infos == lanes[l].infos + pts)) {
+        pts += lanes[l1].n_points;
+        ++l1;
+      }
+      HIP_TRY(hipMemcpyAsync(lanes[l].betas_out, ds->betas_out + (size_t)at * p, sizeof(double) * (size_t)pts * p,
+                             hipMemcpyDeviceToHost, s));
+      if (gn)
+        HIP_TRY(hipMemcpyAsync(lanes[l].group_norms_out, ds->gn_out + (size_t)at * G, sizeof(double) * (size_t)pts * G,
+                               hipMemcpyDeviceToHost, s));
+      if (inf && !infos_in_snap)
+        HIP_TRY(hipMemcpyAsync(lanes[l].infos, ds->infos + at, sizeof(slm_point_info) * (size_t)pts,
+                               hipMemcpyDeviceToHost, s));
+      at += pts;
+      l = l1;
+    }
+    return SLM_OK;
+  };
+  // ---- problems that fit a workgroup: one launch for the whole call (small_kernels.hpp) -------------------------
+  if (small) {
+    SmallArgs sm;
+    memset(&sm, 0, sizeof(sm));
+    sm.t = ta;
+    sm.X = ds->X; sm.y = ds->y; sm.rw = ls.rw; sm.rw_stride = ls.rw_stride; sm.n = n;
+    for (int l = 0; l < kMaxLanes; ++l) sm.inv_n[l] = 1.0 / (ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global);
+    sm.max_iters = (int)std::min<int64_t>((int64_t)o.max_iter, 1500);  // (products per point; then the general path takes over)
+    sm.cold = (o.flags & SLM_FLAG_COLD_START) ? 1 : 0;
+    // LDS: the Gram matrix, three vectors, and the rest as the stage of the rows while the matrix is built
+    const size_t fixed = sizeof(double) * ((size_t)p * p + 3 * (size_t)p);
+    const size_t lds = (size_t)SM_LDS_BYTES;
+    sm.stage_doubles = (int)((lds - fixed - 64) / sizeof(double));
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_TRY(hipFuncSetAttribute((const void*)small_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(small_solve_kernel, dim3(B), dim3(SM_THREADS), lds, s, sm);
+    SLM_TRY(check_launch());
+    if (infos_in_snap) HIP_TRY(hipMemcpyAsync(&ds->hctl[0].c, ds->dctl, sizeof(DevCtl), hipMemcpyDeviceToHost, s));
+    else HIP_TRY(hipMemcpyAsync(&ds->hctl[0].c, ds->dctl, offsetof(DevCtl, infos), hipMemcpyDeviceToHost, s));
+    SLM_TRY(enqueue_result_copies());
+    HIP_TRY(hipStreamSynchronize(s));
+    const double t_small = t_mark();
+    const DevCtl& snap = ds->hctl[0].c;
+    bool nonfinite = false, unconverged = false;
+    int64_t at = 0, sweeps = 0;
+    std::vector<slm_point_info> far_infos;
+    if (!infos_in_snap) {  // (large calls: the records were fetched into the lanes' own arrays, or not asked for)
+      far_infos.resize((size_t)total_points);
+      HIP_TRY(hipMemcpy(far_infos.data(), ds->infos, sizeof(slm_point_info) * (size_t)total_points, hipMemcpyDeviceToHost));
+    }
+    const slm_point_info* all = infos_in_snap ? snap.infos : far_infos.data();
+    for (int l = 0; l < B; ++l) {
+      nonfinite = nonfinite || snap.lane[l].nonfinite;
+      sweeps += snap.lane[l].iter;
+      for (int k = 0; k < lanes[l].n_points; ++k) unconverged = unconverged || all[at + k].status == SLM_ERR_NOT_CONVERGED;
+      if (infos_in_snap && lanes[l].infos) memcpy(lanes[l].infos, snap.infos + at, sizeof(slm_point_info) * (size_t)lanes[l].n_points);
+      at += lanes[l].n_points;
+    }
+    if (nonfinite) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
+    if (unconverged) {
+      // the coordinate iteration did not settle some point within its sweeps (an ill-conditioned face): the general
+      // path, with its Newton steps, takes the call over from the start
+      slm_solve_opts again = o;
+      again.flags &= ~SLM_FLAG_ON_CHIP;
+      const int per_call = shared_path ? B : std::min(B, max_lanes_for(ds, again.flags));
+      if (per_call >= B) return solve_core(ds, lanes, n_lanes, &again, stats, shared_path);
+      // (more lanes than the general path serves at this p: a few calls)
+      slm_solve_stats sum, part;
+      memset(&sum, 0, sizeof(sum));
+      for (int l0 = 0; l0 < B; l0 += per_call) {
+        SLM_TRY(solve_core(ds, lanes + l0, std::min(per_call, B - l0), &again, &part, false));
+        sum.grad_launches += part.grad_launches;
+        sum.wall_ms += part.wall_ms;
+        sum.lipschitz_ms += part.lipschitz_ms;
+        sum.ws_builds += part.ws_builds; sum.ws_appends += part.ws_appends; sum.ws_refined += part.ws_refined;
+        sum.ws_misses += part.ws_misses; sum.ws_columns = std::max(sum.ws_columns, part.ws_columns);
+        sum.ws_inner_iters += part.ws_inner_iters; sum.ws_direct_steps += part.ws_direct_steps;
+      }
+      if (stats) *stats = sum;
+      return SLM_OK;
+    }
+    if (stats) {
+      memset(stats, 0, sizeof(*stats));
+      stats->grad_launches = 1;  // X is read once, for the Gram matrices
+      stats->ws_inner_iters = sweeps;
+      stats->wall_ms = t_mark();
+    }
+    if (const char* trc = getenv("SLM_TRACE"))
+      if (trc[0] == '2')
+        fprintf(stderr, "[slm] on-chip solve: row weights %.3f setup %.3f launched+synced %.3f end %.3f ms, %lld products; lane 0 in the kernel: "
+                "Gram %.3f, lambda_max %.3f, proximal steps %.3f, conjugate gradients %.3f, records %.3f ms\n", tr_rw, tr[0], t_small, t_mark(),
+                (long long)sweeps, snap.lane[0].hist[0], snap.lane[0].hist[1], snap.lane[0].hist[2], snap.lane[0].hist[3], snap.lane[0].hist[4]);
+    return SLM_OK;
+  }
+
   // ---- working-set refinement (ws_kernels.hpp) -----------------------------------------------------
   // Worth it when a pass over X costs more than the one-workgroup model solve that replaces several
   // of them; row-sharded datasets would need the Gram all-reduced (not built).
@@ -2018,40 +2139,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
     expected = 1 + most;
   }
-  // results: lanes whose host buffers follow each other (the ranges of one shared path do) travel in one
-  // copy -- a device-to-host copy into pageable memory costs ~40 us before the first byte moves.  Queued on the
-  // solve's stream; the caller waits for it.
-  auto enqueue_result_copies = [&]() -> int {
-    int64_t at = 0;
-    for (int l = 0; l < B;) {
-      int l1 = l + 1;
-      int64_t pts = lanes[l].n_points;
-      const bool gn = lanes[l].group_norms_out != nullptr, inf = lanes[l].infos != nullptr;
-      while (l1 < B && lanes[l1].betas_out == lanes[l].betas_out + (size_t)pts * p &&
-             (lanes[l1].group_norms_out != nullptr) == gn && (lanes[l1].infos != nullptr) == inf &&
-             (!gn || lanes[l1].group_norms_out == lanes[l].group_norms_out + (size_t)pts * G) &&
-             (!inf || lanes[l1].infos == lanes[l].infos + pts)) {
-        pts += lanes[l1].n_points;
-        ++l1;
-      }
-      HIP_TRY(hipMemcpyAsync(lanes[l].betas_out, ds->betas_out + (size_t)at * p, sizeof(double) * (size_t)pts * p,
-                             hipMemcpyDeviceToHost, s));
-      if (gn)
-        HIP_TRY(hipMemcpyAsync(lanes[l].group_norms_out, ds->gn_out + (size_t)at * G, sizeof(double) * (size_t)pts * G,
-                               hipMemcpyDeviceToHost, s));
-      if (inf && !infos_in_snap)
-        HIP_TRY(hipMemcpyAsync(lanes[l].infos, ds->infos + at, sizeof(slm_point_info) * (size_t)pts,
-                               hipMemcpyDeviceToHost, s));
-      at += pts;
-      l = l1;
-    }
-    return SLM_OK;
-  };
   int final_slot = 0;          // the snapshot in which the host saw `done`
   bool deferred = false;       // the refinement behind the last queued pass has not been queued yet
   while (!done) {
     {
-      const int this_chunk = expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(chunk, expected - enq) : 1);
+      // (a solve with an expected end queues all of its passes at once: launches behind the device-side stop flag return
+      //  at once, and every snapshot in between -- a copy, an event, 6 us of idle stream around them -- told the host
+      //  nothing it acts on)
+      const int this_chunk = expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(64, expected - enq) : 1);
       for (int i = 0; i < this_chunk; ++i) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && enq % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time

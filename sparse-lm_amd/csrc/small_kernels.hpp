@@ -1,0 +1,580 @@
+// On-chip solver for the problem sizes sparse-lm's own users run (the reference's tests: 25 x 20 and 25 x 30,
+// /root/reference/tests/conftest.py:17-19; its README example: 100 x 80, README.md:42-55): ONE launch per call,
+// one workgroup per lane, no pass over X after the first.
+//
+// The state machine of engine.hip spends a dozen launches per pass; below a few thousand matrix entries every one of
+// them is a 4-8 us kernel boundary around microseconds of work, and a fit costs 0.35-2.3 ms however little it
+// computes.  Here a lane's workgroup forms its Gram matrix G = X^T W X / n and c = X^T W y / n once (p <= 128: G
+// lives in LDS), and wavefront 0 then walks the lane's whole path on
+//
+//     1/2 b^T G b - c^T b + sum_j a_j |b_j| + sum_g b_g ||b_g||_2 + 1/2 sum_g d_g ||b_g||^2
+//
+// -- the reference's objective (model/_lasso.py:109-121 with the penalties of :99-107, :267-275, :627-639,
+// :795-811) up to the constant 1/(2n) y^T W y -- with every vector in registers (lane l holds positions l and l + 64
+// of the group-sorted order) and the matrix-vector product as the only loop: p LDS reads and fused multiply-adds per
+// lane, all lanes at once -- half a microsecond at p = 80.  (Coordinate descent, the first version, is a chain through
+// every coordinate: 300 cycles each on one wavefront, 10 us per sweep at p = 80 -- twenty products' worth.)
+//   * accelerated proximal gradient steps with the gradient-scheme restart (the iteration of SURVEY Appendix C) find the
+//     face of the minimiser;
+//   * once the sign pattern has stood still for a few steps and the point has no group norms, conjugate gradients on the
+//     face -- (G_AA + D) x = c_A - thr_A sign(x_A), warm-started, steps cut at the first sign change (that coordinate
+//     leaves the face) -- finish what the proximal steps would crawl along on an ill-conditioned face; the proximal
+//     steps that follow confirm the point or extend the face.
+// A point is accepted by the rule of the general path (fista_tail_kernel): KKT residual of the gradient point -- the
+// proximal-gradient mapping -- below tol * mu * ||b||, mu the smallest curvature <dq, dz> / <dz, dz> measured along the
+// steps (not trusted below 1e-6 lambda_max), with the same rounding floor.  A point that has not got there after
+// `max_iters` products is reported as SLM_ERR_NOT_CONVERGED and solve_core hands the call to the general path (whose
+// model solver has Newton steps): this kernel only has to be fast where it converges.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "grad_kernel.hpp"
+#include "tail_kernels.hpp"
+
+namespace slm {
+
+constexpr int SM_PMAX = 128;      // features: two positions per lane of the iterating wavefront
+constexpr int SM_THREADS = 256;   // four wavefronts build the Gram; wavefront 0 iterates
+constexpr int SM_STILL = 4;       // proximal steps with an unchanged sign pattern before conjugate gradients take over
+constexpr int SM_LDS_BYTES = 156 * 1024;  // of the 160 KiB of a CU
+
+struct SmallArgs {
+  TailArgs t;          // control blocks, path points, penalties, group structure, outputs -- as fista_tail_kernel uses them
+  const double* X;     // [n][ld]
+  const double* y;
+  const double* rw;    // row weights (nullptr: ones); lane l reads rw + l * rw_stride
+  int64_t rw_stride;
+  int64_t n;
+  double inv_n[SLM_MAX_LANES];
+  int max_iters;       // matrix-vector products per path point before the point is given up
+  int cold;            // SLM_FLAG_COLD_START: every point starts from zero
+  int stage_doubles;   // LDS left beside the Gram matrix and the vectors: the stage of the rows while G is built
+};
+
+__device__ __forceinline__ double sm_sum(double v) { return read_lane63(wave_sum_lane63(v)); }  // DPP scan, no LDS
+__device__ __forceinline__ double sm_min(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ void sm_lds_sync() {  // one wavefront: LDS writes before the reads that follow
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
+  extern __shared__ double sm_lds[];  // G [p][p], c [p], vz [p], vu [p], then the stage
+  const int lane_id = blockIdx.x;
+  PathCtl* ctl = a.t.ctl + lane_id;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = a.t.p, G = a.t.G;
+  double* Gs = sm_lds;
+  double* cs = Gs + p * p;
+  double* vz = cs + p;   // operand of the matrix-vector product
+  double* vu = vz + p;   // group norms of the proximal step
+  const int64_t voff = (int64_t)lane_id * a.t.ld;
+  const double* a0 = a.t.a0 + voff;
+  const double* b0 = a.t.b0 + voff;
+  const double* d0 = a.t.d0 + voff;
+  const double* rw = a.rw ? a.rw + (int64_t)lane_id * a.rw_stride : nullptr;
+  const double inv_n = a.inv_n[lane_id];
+  const int64_t n = a.n, ld = a.t.ld;
+  bool bad_setup = false;
+  const unsigned long long tk0 = wall_clock64();
+
+  // ---- Gram matrix of [X, y] (rows scaled by sqrt(w)) in the group-sorted order ---------------------------------
+  // G = X^T W X / n, c = X^T W y / n and y^T W y / n are the blocks of one symmetric matrix of p + 1 columns.  The rows
+  // are staged through LDS in chunks (what the Gram matrix leaves of it): all four
+  // wavefronts load a chunk coalesced, sqrt(w_i) applied once, then every thread accumulates its 4 x 4 blocks of the
+  // upper triangle from LDS.  (Straight from global memory every row cost each thread a dependent round trip: 0.25 ms
+  // for 400 x 100.)
+  __shared__ double yy_s;
+  {
+    const int P1 = p + 1;                 // the y column is position p
+    const int nb = (P1 + 3) >> 2;
+    const int ps = 4 * nb;                // row stride of the stage: whole blocks, zero beyond the y column
+    const int nblocks = nb * (nb + 1) / 2;
+    constexpr int MAXB = 3;  // blocks per thread (p + 1 <= 129: 33 x 34 / 2 = 561 blocks over 256 threads)
+    double acc[MAXB][4][4];
+    int bis[MAXB], bjs[MAXB];
+#pragma unroll
+    for (int r = 0; r < MAXB; ++r) {
+      const int blk = tid + r * SM_THREADS;
+      int bi = 0, rest = blk < nblocks ? blk : 0;  // row bi of the triangle holds nb - bi blocks
+      while (rest >= nb - bi) {
+        rest -= nb - bi;
+        ++bi;
+      }
+      bis[r] = blk < nblocks ? bi : -1;
+      bjs[r] = bi + rest;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[r][u][v] = 0.0;
+    }
+    const int rows_per_chunk = a.stage_doubles / ps;
+    double* stage = vu + p;
+    if (rows_per_chunk > 0) {
+      for (int64_t i0 = 0; i0 < n; i0 += rows_per_chunk) {
+        const int rows = (int)(n - i0 < rows_per_chunk ? n - i0 : rows_per_chunk);
+        __syncthreads();  // (the previous chunk has been consumed)
+        for (int r = wave; r < rows; r += SM_THREADS / 64) {  // a wavefront per row: lanes walk the positions
+          const int64_t i = i0 + r;
+          const double sw = rw ? sqrt(rw[i]) : 1.0;
+          const double* row = a.X + i * ld;
+          for (int sidx = lane; sidx < ps; sidx += 64) {
+            double v = 0.0;
+            if (sidx < p) v = row[a.t.order[sidx]] * sw;
+            else if (sidx == p) v = a.y[i] * sw;
+            stage[r * ps + sidx] = v;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MAXB; ++r) {
+          if (bis[r] < 0) continue;
+          const double* xs_p = stage + 4 * bis[r];
+          const double* xt_p = stage + 4 * bjs[r];
+          for (int rr = 0; rr < rows; ++rr) {
+            double xs[4], xt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              xs[u] = xs_p[rr * ps + u];
+              xt[u] = xt_p[rr * ps + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) acc[r][u][v] = __builtin_fma(xs[u], xt[v], acc[r][u][v]);
+          }
+        }
+      }
+    } else {  // (no room for a stage beside the Gram matrix: cannot happen for p <= SM_PMAX)
+      bad_setup = true;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MAXB; ++r) {
+      if (bis[r] < 0) continue;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int sp = 4 * bis[r] + u, tp = 4 * bjs[r] + v;
+          if (sp > tp || tp > p) continue;  // (upper triangle of the diagonal blocks; positions beyond the y column)
+          const double val = acc[r][u][v] * inv_n;
+          if (tp < p) {
+            Gs[sp * p + tp] = val;
+            Gs[tp * p + sp] = val;
+          } else if (sp < p) {
+            cs[sp] = val;
+          } else {
+            yy_s = val;
+          }
+        }
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;  // (no barrier below: wavefront 0 iterates on its own)
+  const double yy = yy_s;  // 1/n y^T W y: the constant of the loss
+  const unsigned long long tk1 = wall_clock64();
+  unsigned long long tk_it = 0, tk_cg = 0, tk_rec = 0;
+
+  // ---- per-position constants: lane l holds positions l and l + 64 ------------------------------------------
+  const int s0 = lane, s1 = lane + 64;
+  const bool on0 = s0 < p, on1 = s1 < p;
+  const bool wide = p > 64;
+  const int sc0 = on0 ? s0 : 0, sc1 = on1 ? s1 : 0;  // (lanes beyond p read column 0; what they accumulate is never used)
+  const int j0 = on0 ? a.t.order[s0] : 0, j1 = on1 ? a.t.order[s1] : 0;
+  const int g0 = a.t.singleton ? j0 : a.t.gid[j0], g1 = a.t.singleton ? j1 : a.t.gid[j1];
+  const double c0 = on0 ? cs[s0] : 0.0, c1 = on1 ? cs[s1] : 0.0;
+  const double A0 = on0 ? a0[j0] : 0.0, A1 = on1 ? a0[j1] : 0.0;
+  const double B0 = on0 ? b0[g0] : 0.0, B1 = on1 ? b0[g1] : 0.0;
+  const double D0 = on0 ? d0[g0] : 0.0, D1 = on1 ? d0[g1] : 0.0;
+  // first position / size of the group of each position (group-sorted order: groups are contiguous)
+  int gs0 = s0, gn0 = 1, gs1 = s1, gn1 = 1;
+  if (!a.t.singleton) {
+    if (on0) { gs0 = a.t.gstart[g0]; gn0 = a.t.gstart[g0 + 1] - gs0; }
+    if (on1) { gs1 = a.t.gstart[g1]; gn1 = a.t.gstart[g1 + 1] - gs1; }
+  }
+
+  // y = G v for the vector held as (v0, v1): v goes through LDS (every lane needs all of it), the rows of G are read
+  // along the lanes (symmetric: row m holds column m), two chains per half so that no product waits for the one before
+  auto matvec = [&](double v0, double v1, double& y0, double& y1) {
+    if (on0) vz[s0] = v0;
+    if (on1) vz[s1] = v1;
+    sm_lds_sync();
+    // (eight terms at a time, their sixteen or twenty-four loads asked for together, four chains per half: two terms at
+    //  a time the product spent two thirds of its time waiting for LDS round trips)
+    double e[4] = {0.0, 0.0, 0.0, 0.0}, f[4] = {0.0, 0.0, 0.0, 0.0};
+    int m = 0;
+    for (; m + 8 <= p; m += 8) {
+      double zv[8], ga[8], gb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        zv[u] = vz[m + u];
+        ga[u] = Gs[(m + u) * p + sc0];
+        gb[u] = wide ? Gs[(m + u) * p + sc1] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        e[u & 3] = __builtin_fma(ga[u], zv[u], e[u & 3]);
+        if (wide) f[u & 3] = __builtin_fma(gb[u], zv[u], f[u & 3]);
+      }
+    }
+    for (; m < p; ++m) {
+      const double za = vz[m];
+      e[m & 3] = __builtin_fma(Gs[m * p + sc0], za, e[m & 3]);
+      if (wide) f[m & 3] = __builtin_fma(Gs[m * p + sc1], za, f[m & 3]);
+    }
+    const double e0 = e[0] + e[2], e1 = e[1] + e[3], f0 = f[0] + f[2], f1 = f[1] + f[3];
+    y0 = e0 + e1;
+    y1 = f0 + f1;
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // lambda_max(G): twelve power steps from a fixed start, 5 % margin (the curvature test below repairs an under-estimate)
+  double L;
+  {
+    double v0 = on0 ? 1.0 + 0.37 * (double)(((unsigned)(s0 * 2654435761u) >> 24) & 0xffu) / 255.0 : 0.0;
+    double v1 = on1 ? 1.0 + 0.37 * (double)(((unsigned)(s1 * 2654435761u) >> 24) & 0xffu) / 255.0 : 0.0;
+    double lam = 0.0;
+    for (int it = 0; it < 12; ++it) {
+      double y0, y1;
+      matvec(v0, v1, y0, y1);
+      if (!on0) y0 = 0.0;
+      if (!on1) y1 = 0.0;
+      lam = sqrt(sm_sum(y0 * y0 + y1 * y1));
+      const double inv = lam > 0.0 ? 1.0 / lam : 0.0;
+      v0 = y0 * inv;
+      v1 = y1 * inv;
+    }
+    L = lam * 1.05;
+    if (!(L > 0.0)) L = 1.0;  // X == 0 (on the rows that count)
+  }
+
+  // ---- the lane's path ---------------------------------------------------------------------------------------
+  const int64_t po = ctl->pt_off;  // (0 when the lanes are ranges of one path: their point indices are global)
+  const slm_path_point* pts = a.t.pts + po;
+  double* betas_out = a.t.betas_out + po * p;
+  double* gn_out = a.t.gn_out ? a.t.gn_out + po * G : nullptr;
+  slm_point_info* infos = a.t.infos + po;
+  const int first = ctl->point, last = ctl->n_points;
+  const double tol = ctl->tol;
+  const unsigned long long tk2 = wall_clock64();
+  bool bad = false;
+  long long iters_all = 0;
+  if (bad_setup) {  // (nothing was built: every point goes to the general path)
+    for (int point = first + lane; point < last; point += 64) {
+      slm_point_info info;
+      memset(&info, 0, sizeof(info));
+      info.status = SLM_ERR_NOT_CONVERGED;
+      info.mode = 2;
+      infos[point] = info;
+    }
+    if (lane == 0) ctl->done = 1;
+    return;
+  }
+  // warm start of the first point (solve_setup_kernel left it in beta: zero, or the caller's beta0)
+  double x0 = on0 ? a.t.beta[voff + j0] : 0.0, x1 = on1 ? a.t.beta[voff + j1] : 0.0;
+  for (int point = first; point < last && !bad; ++point) {
+    const slm_path_point pt = pts[point];
+    const double pa0 = pt.sa * A0, pa1 = pt.sa * A1;
+    const double pb0 = pt.sb * B0, pb1 = pt.sb * B1;
+    const double pd0 = pt.sd * D0, pd1 = pt.sd * D1;
+    if (a.cold && point > first) x0 = x1 = 0.0;
+    // positions of real groups with a group term take part in a group norm; elsewhere b is a second l1 weight
+    const bool real0 = on0 && gn0 > 1 && pb0 != 0.0, real1 = on1 && gn1 > 1 && pb1 != 0.0;
+    const bool lasso_type = __ballot(real0 || real1) == 0ull;
+    const double thr0 = pa0 + (gn0 == 1 ? pb0 : 0.0), thr1 = pa1 + (gn1 == 1 ? pb1 : 0.0);
+    double Lp = L;  // the step bound of this point (raised by the curvature test)
+    // u = prox_t(v) of the point's penalty
+    auto prox = [&](double v0, double v1, double t, double& u0, double& u1) {
+      u0 = on0 ? soft(v0, t * thr0) : 0.0;
+      u1 = on1 ? soft(v1, t * thr1) : 0.0;
+      if (!lasso_type) {
+        if (on0) vu[s0] = u0;
+        if (on1) vu[s1] = u1;
+        sm_lds_sync();
+        if (real0) {
+          double ss = 0.0;
+          for (int m = 0; m < gn0; ++m) ss = __builtin_fma(vu[gs0 + m], vu[gs0 + m], ss);
+          const double nrm = sqrt(ss);
+          u0 *= nrm > 0.0 ? fmax(0.0, 1.0 - t * pb0 / nrm) : 0.0;
+        }
+        if (real1) {
+          double ss = 0.0;
+          for (int m = 0; m < gn1; ++m) ss = __builtin_fma(vu[gs1 + m], vu[gs1 + m], ss);
+          const double nrm = sqrt(ss);
+          u1 *= nrm > 0.0 ? fmax(0.0, 1.0 - t * pb1 / nrm) : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      u0 /= 1.0 + t * pd0;
+      u1 /= 1.0 + t * pd1;
+    };
+
+    double z0 = x0, z1 = x1, tk = 1.0;
+    double qz0 = 0.0, qz1 = 0.0;            // G z - c at the last gradient point
+    double zp0 = 0.0, zp1 = 0.0, qp0 = 0.0, qp1 = 0.0;  // ... and the one before (curvature along the step)
+    bool have_prev = false;
+    double mu_rq = 0.0, kkt = 0.0, bnorm = 0.0, gnorm = 0.0, resid = 0.0;
+    uint64_t pat_p = ~0ull, pat_n = ~0ull, pat_p1 = ~0ull, pat_n1 = ~0ull;
+    int still = 0, it = 0, cg_runs = 0;
+    bool conv = false;
+    // (a point with group norms has proximal steps only: it is given up -- to the general path -- sooner)
+    const int it_cap = lasso_type ? a.max_iters : (a.max_iters < 600 ? a.max_iters : 600);
+    while (it < it_cap && !conv) {
+      const unsigned long long tka = wall_clock64();
+      matvec(z0, z1, qz0, qz1);
+      ++it;
+      qz0 -= c0;
+      qz1 -= c1;
+      if (!on0) qz0 = 0.0;
+      if (!on1) qz1 = 0.0;
+      // curvature along the last move of the gradient point: a lower bound of the step bound, an estimate of mu
+      if (have_prev) {
+        const double dz0 = z0 - zp0, dz1 = z1 - zp1;
+        const double dd = sm_sum(dz0 * dz0 + dz1 * dz1);
+        if (dd > 0.0) {
+          const double dq = sm_sum(dz0 * (qz0 - qp0) + dz1 * (qz1 - qp1));
+          const double rq = dq / dd;
+          if (rq > Lp) Lp = 1.05 * rq;  // (the power steps under-estimated lambda_max)
+          if (rq > 0.0) mu_rq = mu_rq > 0.0 ? fmin(mu_rq, rq) : rq;
+        }
+      }
+      const double t = 1.0 / Lp;
+      double u0, u1;
+      prox(z0 - t * qz0, z1 - t * qz1, t, u0, u1);
+      // the proximal-gradient mapping at z: the KKT residual the point is accepted on
+      const double w0 = z0 - u0, w1 = z1 - u1;
+      const double s_kkt = sm_sum(w0 * w0 + w1 * w1), s_b = sm_sum(u0 * u0 + u1 * u1);
+      if ((it & 7) == 1) gnorm = sqrt(sm_sum(qz0 * qz0 + qz1 * qz1));  // (only the rounding floor uses it)
+      const double s_rs = sm_sum(w0 * (u0 - x0) + w1 * (u1 - x1));
+      kkt = sqrt(s_kkt) * Lp;
+      bnorm = sqrt(s_b);
+      resid = sqrt(s_kkt);
+      if (!(s_kkt == s_kkt) || !(s_b < 1e300)) {  // NaN / overflow
+        bad = true;
+        break;
+      }
+      double mu_eff = mu_rq > 0.0 ? fmin(mu_rq, Lp) : Lp;
+      mu_eff = fmax(mu_eff, kMuFloor * Lp);
+      conv = kkt <= fmax(tol * bnorm * mu_eff, kRoundFloor * (gnorm + Lp * bnorm));
+      // momentum with the gradient-scheme restart
+      const bool restart = s_rs > 0.0;
+      const double tk_new = restart ? 1.0 : 0.5 * (1.0 + sqrt(1.0 + 4.0 * tk * tk));
+      const double mom = restart ? 0.0 : (tk - 1.0) / tk_new;
+      zp0 = z0; zp1 = z1; qp0 = qz0; qp1 = qz1;
+      have_prev = true;
+      z0 = u0 + mom * (u0 - x0);
+      z1 = u1 + mom * (u1 - x1);
+      x0 = u0;
+      x1 = u1;
+      tk = tk_new;
+      // sign pattern of the iterate: unchanged for SM_STILL steps => the face is (probably) the minimiser's
+      const uint64_t np0 = __ballot(on0 && x0 > 0.0), nn0 = __ballot(on0 && x0 < 0.0);
+      const uint64_t np1 = __ballot(on1 && x1 > 0.0), nn1 = __ballot(on1 && x1 < 0.0);
+      still = (np0 == pat_p && nn0 == pat_n && np1 == pat_p1 && nn1 == pat_n1) ? still + 1 : 0;
+      pat_p = np0; pat_n = nn0; pat_p1 = np1; pat_n1 = nn1;
+      const unsigned long long tkb = wall_clock64();
+      tk_it += tkb - tka;
+
+      // ---- conjugate gradients on the face of the iterate (points without group norms) -------------------------
+      // (G_AA + D) x_A = c_A - thr_A sign(x_A): warm start x, residual r = -(q + thr sign(x) + d x) on A.  A step that
+      // would carry a coordinate across zero stops there; the coordinate leaves A and the iteration starts over on the
+      // smaller face.  Off A every vector is zero, so the products with the full G are products with G_AA.
+      if (lasso_type && !conv && still >= SM_STILL && cg_runs < 6 && (np0 | nn0 | np1 | nn1) != 0ull) {
+        ++cg_runs;
+        still = 0;
+        bool f0 = on0 && x0 != 0.0, f1 = on1 && x1 != 0.0;  // the face
+        double q0, q1;
+        matvec(x0, x1, q0, q1);
+        ++it;
+        q0 -= c0;
+        q1 -= c1;
+        int hits = 0;
+        const int face0 = __popcll(np0 | nn0) + __popcll(np1 | nn1);
+        const int cg_cap = 2 * face0 + 10;
+        double r0 = f0 ? -(q0 + copysign(thr0, x0) + pd0 * x0) : 0.0, r1 = f1 ? -(q1 + copysign(thr1, x1) + pd1 * x1) : 0.0;
+        double d0v = r0, d1v = r1;
+        double rr = sm_sum(r0 * r0 + r1 * r1);
+        const double rr_start = rr;
+        for (int k = 0; k < cg_cap && it < it_cap && rr > 0.0; ++k) {
+          double h0, h1;
+          matvec(d0v, d1v, h0, h1);
+          ++it;
+          h0 = f0 ? h0 + pd0 * d0v : 0.0;
+          h1 = f1 ? h1 + pd1 * d1v : 0.0;
+          const double dHd = sm_sum(d0v * h0 + d1v * h1), dd = sm_sum(d0v * d0v + d1v * d1v);
+          if (!(dd > 0.0)) break;
+          if (dHd > 0.0) mu_rq = mu_rq > 0.0 ? fmin(mu_rq, dHd / dd) : dHd / dd;
+          // the step to the minimiser along d (none: the face is flat along d -- go as far as the face allows)
+          double alpha = dHd > 1e-14 * Lp * dd ? rr / dHd : 1e300;
+          // ... and the step to the first sign change
+          const double lim0 = (f0 && d0v * x0 < 0.0) ? -x0 / d0v : 1e300;
+          const double lim1 = (f1 && d1v * x1 < 0.0) ? -x1 / d1v : 1e300;
+          const double amax = sm_min(fmin(lim0, lim1));
+          const bool hit = alpha >= amax;
+          if (hit) alpha = amax;
+          if (!(alpha < 1e299)) break;  // (flat and unbounded along d: nothing to gain)
+          x0 = f0 ? __builtin_fma(alpha, d0v, x0) : x0;
+          x1 = f1 ? __builtin_fma(alpha, d1v, x1) : x1;
+          q0 = __builtin_fma(alpha, h0 - (f0 ? pd0 * d0v : 0.0), q0);  // q follows x with the product just made: G d
+          q1 = __builtin_fma(alpha, h1 - (f1 ? pd1 * d1v : 0.0), q1);
+          if (hit) {
+            // the blocking coordinates land on zero and leave the face; conjugacy is lost: steepest descent restarts it
+            if (f0 && lim0 <= amax) { x0 = 0.0; f0 = false; }
+            if (f1 && lim1 <= amax) { x1 = 0.0; f1 = false; }
+            // (q was advanced with the full G d, whose rows off the face are garbage-free: d is zero there)
+            matvec(x0, x1, q0, q1);
+            ++it;
+            q0 -= c0;
+            q1 -= c1;
+            r0 = f0 ? -(q0 + copysign(thr0, x0) + pd0 * x0) : 0.0;
+            r1 = f1 ? -(q1 + copysign(thr1, x1) + pd1 * x1) : 0.0;
+            d0v = r0;
+            d1v = r1;
+            rr = sm_sum(r0 * r0 + r1 * r1);
+            if (++hits > face0) break;
+            continue;
+          }
+          r0 = f0 ? __builtin_fma(-alpha, h0, r0) : 0.0;
+          r1 = f1 ? __builtin_fma(-alpha, h1, r1) : 0.0;
+          const double rr_new = sm_sum(r0 * r0 + r1 * r1);
+          if (!(rr_new == rr_new)) {
+            bad = true;
+            break;
+          }
+          const double xn = sqrt(sm_sum(x0 * x0 + x1 * x1));
+          double mu_eff2 = mu_rq > 0.0 ? fmin(mu_rq, Lp) : Lp;
+          mu_eff2 = fmax(mu_eff2, kMuFloor * Lp);
+          // (a tenth of what the point is accepted on: the proximal steps that follow confirm it)
+          if (sqrt(rr_new) <= 0.1 * fmax(tol * xn * mu_eff2, kRoundFloor * (gnorm + Lp * xn)) || rr_new <= 1e-30 * rr_start) {
+            rr = rr_new;
+            break;
+          }
+          const double bt = rr_new / rr;
+          d0v = __builtin_fma(bt, d0v, r0);
+          d1v = __builtin_fma(bt, d1v, r1);
+          rr = rr_new;
+        }
+        if (bad) break;
+        z0 = x0; z1 = x1;   // the proximal steps go on from the face's minimiser, momentum and history afresh
+        tk = 1.0;
+        have_prev = false;
+        pat_p = pat_n = pat_p1 = pat_n1 = ~0ull;
+        tk_cg += wall_clock64() - tkb;
+      }
+    }
+    iters_all += it;
+    const unsigned long long tkc = wall_clock64();
+    // the reported point: the result of the last proximal step, with the gradient taken at it for the record
+    double q0, q1;
+    matvec(x0, x1, q0, q1);
+    q0 -= c0;
+    q1 -= c1;
+    const double be0 = x0, be1 = x1;
+    const double b2 = bnorm * bnorm, d2 = resid * resid;
+    const int sweep = it;
+    const double err_est = 0.0;
+    double mu_rep = mu_rq > 0.0 ? fmin(mu_rq, Lp) : Lp;
+    mu_rep = fmax(mu_rep, kMuFloor * Lp);
+    const double Lall = Lp;
+
+    // ---- the point's record: minimal-norm subgradient (the KKT residual), loss, group norms, coefficients --------
+    double kkt2 = 0.0;
+    {
+      // norm of every position's group (a group of one: the absolute value), and for the zero groups the norm of
+      // soft(q_g, a_g), which has to stay below b_g
+      double nr0 = fabs(be0), nr1 = fabs(be1), tn0 = 0.0, tn1 = 0.0;
+      if (!a.t.singleton && (!lasso_type || gn_out != nullptr)) {
+        if (on0) vu[s0] = be0;
+        if (on1) vu[s1] = be1;
+        sm_lds_sync();
+        if (on0 && gn0 > 1) {
+          double ss = 0.0;
+          for (int m = 0; m < gn0; ++m) ss = __builtin_fma(vu[gs0 + m], vu[gs0 + m], ss);
+          nr0 = sqrt(ss);
+        }
+        if (on1 && gn1 > 1) {
+          double ss = 0.0;
+          for (int m = 0; m < gn1; ++m) ss = __builtin_fma(vu[gs1 + m], vu[gs1 + m], ss);
+          nr1 = sqrt(ss);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (!lasso_type) {
+        if (on0) vu[s0] = soft(q0, pa0);
+        if (on1) vu[s1] = soft(q1, pa1);
+        sm_lds_sync();
+        if (real0 && nr0 == 0.0) {
+          double ss = 0.0;
+          for (int m = 0; m < gn0; ++m) ss = __builtin_fma(vu[gs0 + m], vu[gs0 + m], ss);
+          tn0 = sqrt(ss);
+        }
+        if (real1 && nr1 == 0.0) {
+          double ss = 0.0;
+          for (int m = 0; m < gn1; ++m) ss = __builtin_fma(vu[gs1 + m], vu[gs1 + m], ss);
+          tn1 = sqrt(ss);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      auto sub = [&](bool on, bool real, double q, double be, double thr, double pa, double pb, double pd, double nr, double tn,
+                     bool first_member) {
+        if (!on) return 0.0;
+        if (!real) {  // on its own: a group term of a group of one is part of the threshold
+          const double sm = q + pd * be;
+          return be != 0.0 ? sm + copysign(thr, be) : soft(sm, thr);
+        }
+        if (nr > 0.0) {  // smooth in the group term: gradient + b u / ||u|| + d u, l1 part by its minimal-norm element
+          const double sm = q + pd * be + pb * be / nr;
+          return be != 0.0 ? sm + copysign(pa, be) : soft(sm, pa);
+        }
+        return first_member ? fmax(0.0, tn - pb) : 0.0;  // zero group: counted once
+      };
+      const double r0 = sub(on0, real0, q0, be0, thr0, pa0, pb0, pd0, nr0, tn0, s0 == gs0);
+      const double r1 = sub(on1, real1, q1, be1, thr1, pa1, pb1, pd1, nr1, tn1, s1 == gs1);
+      kkt2 = sm_sum(r0 * r0 + r1 * r1);
+      if (gn_out != nullptr) {
+        if (on0 && s0 == gs0) gn_out[(int64_t)point * G + g0] = nr0;
+        if (on1 && s1 == gs1) gn_out[(int64_t)point * G + g1] = nr1;
+      }
+    }
+    const double loss = 0.5 * sm_sum(be0 * (q0 - c0) + be1 * (q1 - c1)) + 0.5 * yy;
+    if (on0) betas_out[(int64_t)point * p + j0] = be0;
+    if (on1) betas_out[(int64_t)point * p + j1] = be1;
+    if (lane == 0) {
+      slm_point_info info;
+      info.n_iter = sweep;
+      info.status = bad ? SLM_ERR_NON_FINITE : (conv ? SLM_OK : SLM_ERR_NOT_CONVERGED);
+      info.resid = sqrt(d2);
+      info.beta_norm = sqrt(b2);
+      info.loss = loss;
+      info.L = Lall;
+      info.mode = 2;  // on chip: proximal gradient steps and conjugate gradients on the Gram matrix
+      info.rejects = 0;
+      info.kkt = sqrt(kkt2);
+      info.mu = mu_rep;
+      infos[point] = info;
+    }
+    tk_rec += wall_clock64() - tkc;
+  }
+  if (lane == 0) {
+    ctl->total_iter = 1;  // X was read once
+    ctl->iter = (int32_t)(iters_all > 2000000000ll ? 2000000000ll : iters_all);
+    ctl->nonfinite = bad ? 1 : 0;
+    ctl->done = 1;
+    // (SLM_TRACE=2: where the kernel's time went, in ms -- the 100 MHz wall clock)
+    ctl->hist[0] = (double)(tk1 - tk0) * 1e-5;
+    ctl->hist[1] = (double)(tk2 - tk1) * 1e-5;
+    ctl->hist[2] = (double)tk_it * 1e-5;
+    ctl->hist[3] = (double)tk_cg * 1e-5;
+    ctl->hist[4] = (double)tk_rec * 1e-5;
+  }
+}
+
+}  // namespace slm

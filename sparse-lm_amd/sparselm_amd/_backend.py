@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _engine
 
-_KNOWN_OPTIONS = {"tol", "max_iter", "L", "restart", "check_every", "device"}
+_KNOWN_OPTIONS = {"tol", "max_iter", "L", "restart", "check_every", "device", "on_chip"}
 
 
 class DatasetCache:
@@ -164,7 +164,7 @@ class SolveProblem:
     def solve(self, a, b, d, beta0=None, want_group_norms=False):
         """One minimisation with penalty (a, b, d); returns (beta, group_norms or None, info)."""
         o = self.options
-        flags = 0 if o.get("restart", True) else _engine.FLAG_NO_RESTART
+        flags = solve_flags(o)
         res = self.ds.solve_path(
             [(1.0, 1.0, 1.0)],
             a=a,
@@ -238,6 +238,16 @@ def use_backend(backend):
         yield backend
     finally:
         _backend = old
+
+
+def solve_flags(options) -> int:
+    """Engine flags of a fit: ``restart=False`` is FISTA without the momentum restart; the on-chip solver for problems
+    that fit a workgroup (the reference's own sizes: one launch per call instead of a dozen per pass) unless
+    ``on_chip=False``."""
+    flags = 0 if options.get("restart", True) else _engine.FLAG_NO_RESTART
+    if options.get("on_chip", True):
+        flags |= _engine.FLAG_ON_CHIP
+    return flags
 
 
 def default_tol(n: int, p: int) -> float:

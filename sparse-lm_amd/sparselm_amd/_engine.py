@@ -39,9 +39,10 @@ FLAG_FRESH_L = 8
 FLAG_FISTA_ONLY = 16
 FLAG_WORKING_SET = 32  # force the Gram-assisted refinement even for small X
 FLAG_NO_WORKING_SET = 64
+FLAG_ON_CHIP = 128  # problems whose Gram matrix fits a workgroup: one launch per call (csrc/small_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 7  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 8  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -361,7 +362,7 @@ class PathResult:
     resid: np.ndarray
     beta_norm: np.ndarray
     loss: np.ndarray
-    mode: np.ndarray  # per point: 1 = spectral steps, 0 = FISTA
+    mode: np.ndarray  # per point: 1 = spectral steps, 0 = FISTA, 2 = on-chip coordinate descent
     L: float
     grad_launches: int
     grad_timed: int

@@ -370,7 +370,7 @@ class _DeviceGrid:
         ds = _engine.get_engine().dataset(Xd, self.y)
         if self.gidx is not None:
             self._set_groups(ds)
-        self.lanes = max(1, min(int(self.search.lanes), _engine.MAX_LANES, ds.max_lanes()))
+        self.lanes = max(1, min(int(self.search.lanes), _engine.MAX_LANES, ds.max_lanes(self.opts.get("flags", 0))))
         self._plan_world = None
         return ds
 
@@ -661,8 +661,7 @@ def _solver_options(est) -> dict:
         out["L"] = float(o["L"])
     if "check_every" in o:
         out["check_every"] = int(o["check_every"])
-    if not o.get("restart", True):
-        out["flags"] = _engine.FLAG_NO_RESTART
+    out["flags"] = _backend.solve_flags(o)
     return out
 
 
