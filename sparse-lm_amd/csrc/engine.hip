@@ -376,6 +376,7 @@ struct slm_dataset {
   double* rvec = nullptr;      // [n] residuals of the two-pass fallback
   // group structure (group-sorted permutation)
   int G = 0, singleton = 1, team = 1, max_group = 1;
+  std::vector<int32_t> h_gid;  // the group index as last set (empty: singleton groups) -- setting it again is free
   int *order = nullptr, *gid = nullptr, *gstart = nullptr;
   // working-set refinement (ws_kernels.hpp), allocated on first use
   WsCtl* ws_ctl = nullptr;  // (inside dctl)
@@ -385,6 +386,12 @@ struct slm_dataset {
   double *sse_Z = nullptr, *sse_part = nullptr;  // slm_eval_sse_sparse: coefficient block, partial sums
   size_t sse_cap = 0;
   PathCtl h_stage[SLM_MAX_LANES];  // host staging of the control blocks of the solve in flight
+  // page-locked staging of what the lanes of a call bring (penalty vectors, warm starts: [4][kMaxLanes][ld]; path points):
+  // one transfer per kind instead of one per lane and kind -- sixteen lanes x (a, warm start, points) were 48 transfers of a
+  // few hundred bytes, 0.25 ms of submissions before a 0.2 ms call of the on-chip solver
+  double* h_vec = nullptr;
+  slm_path_point* h_pts = nullptr;
+  int64_t h_pts_cap = 0;
   double* stop_words = nullptr;  // [STOP_WORDS] row-sharded mode: the vector the ranks all-reduce after every pass
   double* XT = nullptr;  // column-major copy of X in tiles of 32 rows (tile_columns_kernel), built on first use
   bool XT_ready = false, XT_failed = false;
@@ -557,6 +564,8 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
   dfree(ds->ws_nt); dfree(ds->stop_words); dfree(ds->sse_Z); dfree(ds->sse_part);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
+  if (ds->h_vec) (void)hipHostFree(ds->h_vec);
+  if (ds->h_pts) (void)hipHostFree(ds->h_pts);
   for (auto& e : ds->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : ds->prof) (void)hipEventDestroy(e);
@@ -883,9 +892,18 @@ extern "C" int slm_dataset_set_global_rows(slm_dataset* ds, int64_t n_global) {
 
 extern "C" int slm_dataset_set_groups(slm_dataset* ds, const int32_t* gid, int32_t n_groups) {
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  // (the estimators set the groups before every fit -- a cached dataset may carry another estimator's: the same
+  //  structure again costs nothing, where it used to cost four allocations and three blocking copies)
+  if (!gid && ds->singleton && ds->h_gid.empty()) return SLM_OK;
+  if (gid && !ds->singleton && n_groups == ds->G && ds->h_gid.size() == (size_t)ds->p &&
+      memcmp(ds->h_gid.data(), gid, sizeof(int32_t) * (size_t)ds->p) == 0)
+    return SLM_OK;
   HIP_TRY(hipSetDevice(ds->eng->device));
   HIP_TRY(hipStreamSynchronize(ds->eng->stream));
-  if (!gid) return set_singleton_groups(ds);
+  if (!gid) {
+    ds->h_gid.clear();
+    return set_singleton_groups(ds);
+  }
   const int p = (int)ds->p;
   if (n_groups <= 0 || n_groups > p)
     return fail(SLM_ERR_BAD_ARG, "n_groups = %d must be in [1, p = %d]", n_groups, p);
@@ -917,6 +935,7 @@ extern "C" int slm_dataset_set_groups(slm_dataset* ds, const int32_t* gid, int32
   ds->singleton = 0;
   ds->team = team;
   ds->max_group = max_size;
+  ds->h_gid.assign(gid, gid + p);
   return SLM_OK;
 }
 
@@ -1468,16 +1487,6 @@ extern "C" int slm_eval_sse_sparse(slm_dataset* ds, const int32_t* cols, int32_t
 // ------------------------------------------------------------------------------------------------
 // path solves
 // ------------------------------------------------------------------------------------------------
-// penalty weights handed over by the caller: validated, then queued for upload (the caller's buffer stays
-// valid for the whole call; solve_core synchronises once before it returns to anything that could free it)
-static int upload_weights(double* dst, const double* src, int64_t count, hipStream_t s) {
-  for (int64_t i = 0; i < count; ++i)
-    if (!(src[i] >= 0.0) || !std::isfinite(src[i]))
-      return fail(SLM_ERR_BAD_ARG, "penalty weights must be finite and >= 0 (index %lld)", (long long)i);
-  HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * count, hipMemcpyHostToDevice, s));
-  return SLM_OK;
-}
-
 // shared_path: the lanes are contiguous, ordered ranges of ONE path (slm_solve_path_lanes): global
 // point indices on the device and work stealing between lanes.
 // Working-set refinement policy (see solve_core): 0 = never, 1 = when a path point turns out hard
@@ -1723,6 +1732,20 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   su.infos_bytes = (int64_t)(sizeof(slm_point_info) * total_points);
   static_assert(sizeof(slm_point_info) % 8 == 0, "infos are zeroed in 8-byte words");
   su.ld = ld; su.p = p; su.G = G; su.n_lanes = B; su.max_lanes = kMaxLanes;
+  if (!ds->h_vec) {
+    hipError_t eh = hipHostMalloc((void**)&ds->h_vec, sizeof(double) * 4 * (size_t)kMaxLanes * (size_t)ld, hipHostMallocDefault);
+    if (eh != hipSuccess) return fail(SLM_ERR_OOM, "hipHostMalloc: %s", hipGetErrorString(eh));
+    memset(ds->h_vec, 0, sizeof(double) * 4 * (size_t)kMaxLanes * (size_t)ld);
+  }
+  if (total_points > ds->h_pts_cap) {
+    if (ds->h_pts) (void)hipHostFree(ds->h_pts);
+    ds->h_pts = nullptr;
+    ds->h_pts_cap = 0;
+    hipError_t eh = hipHostMalloc((void**)&ds->h_pts, sizeof(slm_path_point) * (size_t)total_points, hipHostMallocDefault);
+    if (eh != hipSuccess) return fail(SLM_ERR_OOM, "hipHostMalloc: %s", hipGetErrorString(eh));
+    ds->h_pts_cap = total_points;
+  }
+  int up_lo[4] = {kMaxLanes, kMaxLanes, kMaxLanes, kMaxLanes}, up_hi[4] = {-1, -1, -1, -1};  // lanes that bring a, b, d, beta0
   int64_t off = 0;
   bool same_pen = B > 1;
   for (int l = 1; l < B; ++l) same_pen = same_pen && lanes[l].pen == lanes[0].pen;
@@ -1740,19 +1763,21 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       else if (same_pen && l > 0) *mode[v] = 2;
       else {
         *mode[v] = 0;
-        SLM_TRY(upload_weights(dst[v], src[v], cnt[v], s));
+        for (int64_t i = 0; i < cnt[v]; ++i)
+          if (!(src[v][i] >= 0.0) || !std::isfinite(src[v][i]))
+            return fail(SLM_ERR_BAD_ARG, "penalty weights must be finite and >= 0 (index %lld)", (long long)i);
+        memcpy(ds->h_vec + ((size_t)v * kMaxLanes + l) * ld, src[v], sizeof(double) * cnt[v]);
+        up_lo[v] = std::min(up_lo[v], l);
+        up_hi[v] = std::max(up_hi[v], l);
       }
     }
-    if (l == 0 || ln.points != lanes[l - 1].points + lanes[l - 1].n_points) {  // (one copy per contiguous run)
-      int64_t run = ln.n_points;
-      for (int m = l + 1; m < B && lanes[m].points == lanes[m - 1].points + lanes[m - 1].n_points; ++m)
-        run += lanes[m].n_points;
-      HIP_TRY(hipMemcpyAsync(ds->pts + off, ln.points, sizeof(slm_path_point) * run, hipMemcpyHostToDevice, s));
-    }
+    memcpy(ds->h_pts + off, ln.points, sizeof(slm_path_point) * (size_t)ln.n_points);
     if (ln.beta0) {
       for (int64_t j = 0; j < p; ++j)
         if (!std::isfinite(ln.beta0[j])) return fail(SLM_ERR_BAD_ARG, "beta0[%lld] is not finite", (long long)j);
-      HIP_TRY(hipMemcpyAsync(ds->beta + (size_t)l * ld, ln.beta0, sizeof(double) * p, hipMemcpyHostToDevice, s));
+      memcpy(ds->h_vec + ((size_t)3 * kMaxLanes + l) * ld, ln.beta0, sizeof(double) * p);
+      up_lo[3] = std::min(up_lo[3], l);
+      up_hi[3] = std::max(up_hi[3], l);
       su.beta_mode[l] = 1;
     }
     h[l].n_points = ln.n_points;
@@ -1788,6 +1813,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     h[l].ak = 1.25 * L[l];  // a slightly short first step; the scheme measures its own curvature after it
     h[l].Lhat = 0.5 * L[l];  // a sure lower bound of lambda_max for the residual scaling
     off += ln.n_points;
+  }
+  {  // the staged rows, first to last lane that brings any (rows in between are filled by solve_setup_kernel afterwards)
+    double* dev[4] = {ds->a0, ds->b0, ds->d0, ds->beta};
+    for (int v = 0; v < 4; ++v)
+      if (up_hi[v] >= 0)
+        HIP_TRY(hipMemcpyAsync(dev[v] + (size_t)up_lo[v] * ld, ds->h_vec + ((size_t)v * kMaxLanes + up_lo[v]) * ld,
+                               sizeof(double) * (size_t)(up_hi[v] - up_lo[v] + 1) * ld, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ds->pts, ds->h_pts, sizeof(slm_path_point) * (size_t)total_points, hipMemcpyHostToDevice, s));
   }
   hipLaunchKernelGGL(solve_setup_kernel, dim3(128), dim3(256), 0, s, su);
   HIP_TRY(hipMemcpyAsync(ds->ctl, h, sizeof(PathCtl) * B, hipMemcpyHostToDevice, s));
@@ -1905,6 +1938,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
     if (nonfinite) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
     if (unconverged) {
+      if (const char* trc = getenv("SLM_TRACE"))
+        if (trc[0] == '2') fprintf(stderr, "[slm] on-chip solve gave a point up after %.3f ms (%lld products): the general path takes the call\n", t_small, (long long)sweeps);
       // the coordinate iteration did not settle some point within its sweeps (an ill-conditioned face): the general
       // path, with its Newton steps, takes the call over from the start
       slm_solve_opts again = o;

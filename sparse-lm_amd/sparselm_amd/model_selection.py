@@ -499,9 +499,15 @@ class _DeviceGrid:
                 local[(u, 0)] = (self.combos[c], f, np.full(len(self.combos[c]), search.error_score, dtype=float), 0.0)
             return 0
         dt = (time.perf_counter() - t_batch) / len(batch)
-        for u, (c, f), fit in zip(us, batch, fits):
-            sse = ds.eval_sse(fit["beta"][None, :], self.test_masks[f])
-            local[(u, 0)] = (self.combos[c], f, search._score_from_sse(sse, self.y[self.splits[f][1]]), dt)
+        # hold-out scores fold by fold: one scoring call for all the cells of the call that share a test mask
+        by_fold = defaultdict(list)
+        for k, (_, f) in enumerate(batch):
+            by_fold[f].append(k)
+        for f, ks in by_fold.items():
+            sse = ds.eval_sse(np.vstack([fits[k]["beta"] for k in ks]), self.test_masks[f])
+            sc = search._score_from_sse(sse, self.y[self.splits[f][1]])
+            for k, one in zip(ks, np.atleast_1d(sc)):
+                local[(us[k], 0)] = (self.combos[batch[k][0]], f, np.array([one]), dt)
         return sum(not i["converged"] for fit in fits for i in fit["infos"])
 
     def merge(self, cells):
