@@ -315,9 +315,9 @@ int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, const slm_path
                          slm_point_info* infos, slm_solve_stats* stats);
 
 /* ---- row-sharded mode (very tall X split by rows over ranks) ----------------------------------------
- * Every rank holds a block of rows and runs the whole state machine; per pass the ranks all-reduce the
- * lanes' gradients (ld + 16 doubles each), a 16-double stop vector, and -- in working-set solves -- the
- * staged Gram parts.  slm_dataset_center all-reduces the weighted sums and X^T w, so the global means are
+ * Every rank holds a block of rows and runs the whole state machine; per pass the ranks enter TWO all-reduces: the
+ * lanes' gradients (ld + 16 doubles each), and a 16-double stop vector -- in working-set solves riding behind the
+ * staged Gram parts in one buffer.  slm_dataset_center all-reduces the weighted sums and X^T w, so the global means are
  * subtracted.  HBM per rank: X plus, in working-set solves, its column-major copy (2 x 8 n p bytes). */
 #define SLM_COMM_ID_BYTES 128
 /* Rank 0 creates the id and distributes the 128 bytes to the other ranks out of band. */

@@ -424,16 +424,82 @@ struct slm_dataset {
   bool L_valid = false;
 };
 
+// Large device blocks (a dataset's X, its column-major copy, the gathered columns: gigabytes each) are recycled: a freed
+// block waits in a per-device list of its exact size, and the next dataset of that shape takes it instead of asking the
+// driver.  hipMalloc right behind the hipFree of such blocks stalled for SECONDS now and then (the soak over 96 datasets
+// of the headline shape, profiles/r02c_headline_soak.log: a 6-pass path in 2.4 s; 3.6 s in r02a) -- a fresh fit paying
+// three hundred times its solve.  At most kPoolIdleCap bytes wait per process; when the driver has no memory left the
+// waiting blocks are handed back and the allocation is tried again.  Nothing relies on a block's contents.
+static const size_t kPoolMinBytes = (size_t)64 << 20;
+static const size_t kPoolIdleCap = (size_t)48 << 30;
+struct DevicePool {
+  std::mutex m;
+  std::vector<std::pair<int, std::pair<size_t, void*>>> idle;  // (device, (bytes, block))
+  std::vector<std::pair<void*, std::pair<int, size_t>>> live;  // pooled blocks in use: block -> (device, bytes)
+  size_t idle_bytes = 0;
+};
+static DevicePool g_pool;
+
+static void pool_flush_locked() {
+  for (auto& e : g_pool.idle) (void)hipFree(e.second.second);
+  g_pool.idle.clear();
+  g_pool.idle_bytes = 0;
+}
+
+static hipError_t pool_malloc(void** out, size_t bytes) {
+  if (bytes < kPoolMinBytes) return hipMalloc(out, bytes);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_pool.m);
+  for (size_t i = 0; i < g_pool.idle.size(); ++i) {
+    if (g_pool.idle[i].first == dev && g_pool.idle[i].second.first == bytes) {
+      *out = g_pool.idle[i].second.second;
+      g_pool.idle.erase(g_pool.idle.begin() + (long)i);
+      g_pool.idle_bytes -= bytes;
+      g_pool.live.push_back({*out, {dev, bytes}});
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e == hipErrorOutOfMemory && !g_pool.idle.empty()) {
+    (void)hipGetLastError();
+    pool_flush_locked();
+    e = hipMalloc(out, bytes);
+  }
+  if (e == hipSuccess) g_pool.live.push_back({*out, {dev, bytes}});
+  return e;
+}
+
+static void pool_free(void* p) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool.m);
+    for (size_t i = 0; i < g_pool.live.size(); ++i) {
+      if (g_pool.live[i].first == p) {
+        const int dev = g_pool.live[i].second.first;
+        const size_t bytes = g_pool.live[i].second.second;
+        g_pool.live.erase(g_pool.live.begin() + (long)i);
+        if (g_pool.idle_bytes + bytes <= kPoolIdleCap && !getenv("SLM_NO_DEVICE_POOL")) {
+          g_pool.idle.push_back({dev, {bytes, p}});
+          g_pool.idle_bytes += bytes;
+          return;
+        }
+        break;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+
 template <typename T>
 static int dalloc(T** out, size_t count) {
   *out = nullptr;
   if (count == 0) count = 1;
-  HIP_TRY(hipMalloc((void**)out, count * sizeof(T)));
+  HIP_TRY(pool_malloc((void**)out, count * sizeof(T)));
   return SLM_OK;
 }
 template <typename T>
 static void dfree(T*& p) {
-  if (p) (void)hipFree(p);
+  if (p) pool_free(p);
   p = nullptr;
 }
 
@@ -520,6 +586,22 @@ extern "C" int slm_engine_destroy(slm_engine* eng) {
   (void)hipSetDevice(eng->device);
   if (eng->sharded()) (void)slm_comm_destroy(eng);
   if (eng->stream) (void)hipStreamDestroy(eng->stream);
+  {  // (the recycled blocks do not outlive the engines that could use them)
+    std::lock_guard<std::mutex> lk(g_pool.m);
+    bool other = false;
+    for (auto& e : g_pool.live) other = other || e.second.first == eng->device;
+    if (!other) {
+      for (size_t i = 0; i < g_pool.idle.size();) {
+        if (g_pool.idle[i].first == eng->device) {
+          (void)hipFree(g_pool.idle[i].second.second);
+          g_pool.idle_bytes -= g_pool.idle[i].second.first;
+          g_pool.idle.erase(g_pool.idle.begin() + (long)i);
+        } else {
+          ++i;
+        }
+      }
+    }
+  }
   delete eng;
   return SLM_OK;
 }
@@ -1403,7 +1485,7 @@ static int ensure_xt(slm_dataset* ds) {
   const int64_t n = ds->n, ld = ds->ld;
   const int64_t row_tiles = (n + 31) / 32;
   if (!ds->XT && !ds->XT_failed) {
-    if (hipMalloc((void**)&ds->XT, sizeof(double) * (size_t)ld * (size_t)row_tiles * 32) != hipSuccess) {
+    if (pool_malloc((void**)&ds->XT, sizeof(double) * (size_t)ld * (size_t)row_tiles * 32) != hipSuccess) {
       (void)hipGetLastError();
       ds->XT = nullptr;
       ds->XT_failed = true;
@@ -2018,7 +2100,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (ds->ws_sets < n_sets) {
       dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
       ds->ws_sets = 0;
-      if (eng->sharded()) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)n_sets * WS_KCAP * WS_KCAP));
+      if (eng->sharded()) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)n_sets * WS_KCAP * WS_KCAP + STOP_WORDS));
       SLM_TRY(dalloc(&ds->ws_part, (size_t)ws_nblk * n_sets * WS_KCAP * WS_KCAP));  // (ws_nblk depends on n only)
       SLM_TRY(dalloc(&ds->ws_G, (size_t)n_sets * WS_KCAP * WS_KCAP));
       ds->ws_sets = n_sets;
@@ -2034,7 +2116,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     wa.idx = ds->ws_idx; wa.pos = ds->ws_pos; wa.gs = ds->ws_gs; wa.gl = ds->ws_gl;
     wa.score = ds->ws_score; wa.XW = ds->ws_XW; wa.part = ds->ws_part; wa.Gm = ds->ws_G;
     wa.nt = getenv("SLM_NO_DIRECT") ? nullptr : ds->ws_nt;
-    if (eng->sharded() && !ds->ws_Gx) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)ds->ws_sets * WS_KCAP * WS_KCAP));
+    if (eng->sharded() && !ds->ws_Gx) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)ds->ws_sets * WS_KCAP * WS_KCAP + STOP_WORDS));
     wa.Gx = eng->sharded() ? ds->ws_Gx : nullptr;  // row-sharded: Gram parts are summed over ranks before use
     wa.X = ds->X; wa.XT = ds->XT; wa.n = n; wa.ld = ld;
     wa.rw = ls.rw; wa.rw_stride = ls.rw_stride;
@@ -2100,9 +2182,17 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     launch_tail(ta, s);
     if (shared_path && !interleave) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
     if (eng->sharded()) {  // the ranks agree on "finished" before anything acts on it
-      hipLaunchKernelGGL(stop_pack_kernel, dim3(1), dim3(64), 0, s, ta.gdone, ds->ctl, B, ds->stop_words);
-      if (ws_comm_rc == 0) ws_comm_rc = all_reduce_sum(eng, ds->stop_words, STOP_WORDS);
-      hipLaunchKernelGGL(stop_apply_kernel, dim3(1), dim3(64), 0, s, ta.gdone, ds->stop_words);
+      if (use_ws && wa.Gx) {
+        // working-set solves: the stop words ride behind the staged Gram parts, in the one all-reduce of the refinement
+        // (enqueue_refinement) -- two collectives per pass, not three.  Until then this pass's kernels see the flag of
+        // the pass before, which is what they would see on a rank that has not finished.
+        hipLaunchKernelGGL(stop_pack_kernel, dim3(1), dim3(64), 0, s, ta.gdone, ds->ctl, B,
+                           wa.Gx + (size_t)wa.n_sets * WS_KCAP * WS_KCAP);
+      } else {
+        hipLaunchKernelGGL(stop_pack_kernel, dim3(1), dim3(64), 0, s, ta.gdone, ds->ctl, B, ds->stop_words);
+        if (ws_comm_rc == 0) ws_comm_rc = all_reduce_sum(eng, ds->stop_words, STOP_WORDS);
+        hipLaunchKernelGGL(stop_apply_kernel, dim3(1), dim3(64), 0, s, ta.gdone, ds->stop_words);
+      }
     }
   };
   auto enqueue_refinement = [&]() {
@@ -2123,9 +2213,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       if (wa.Gx) {
         // one collective per pass on every rank whether or not a build is under way: the ranks run the
         // same state machine on the same all-reduced gradients, so they agree on when that is
-        if (ws_comm_rc == 0) ws_comm_rc = all_reduce_sum(eng, wa.Gx, (size_t)wa.n_sets * WS_KCAP * WS_KCAP);
+        const size_t gram_words = (size_t)wa.n_sets * WS_KCAP * WS_KCAP;
+        if (ws_comm_rc == 0) ws_comm_rc = all_reduce_sum(eng, wa.Gx, gram_words + STOP_WORDS);  // (+ the stop words: enqueue_tail)
         hipLaunchKernelGGL(ws_publish_kernel, dim3(WS_KCAP * WS_KCAP / 256, (unsigned)wa.n_sets), dim3(256), 0, s,
                            wa);
+        hipLaunchKernelGGL(stop_apply_kernel, dim3(1), dim3(64), 0, s, ta.gdone, wa.Gx + gram_words);
       }
       // the iteration alone, then -- for the lanes it left -- the solver with direct steps (ws_refine_lane)
       if (wa.one_solver && wa.nt) {
@@ -2518,7 +2610,7 @@ extern "C" int slm_comm_init_local(slm_engine** engines, int32_t n_ranks, double
   lc->refs = n_ranks;
   if (timeout_s > 0.0) lc->timeout_s = timeout_s;
   // the largest exchange is the staged working-set Gram of every lane set
-  lc->cap = (size_t)SLM_MAX_LANES * WS_KCAP * WS_KCAP;
+  lc->cap = (size_t)SLM_MAX_LANES * WS_KCAP * WS_KCAP + STOP_WORDS;
   const size_t tab_doubles = 2 * LocalComm::kMaxRanks;  // two pointer tables behind rank 0's staging areas
   hipError_t e = hipSuccess;
   for (int r = 0; r < n_ranks && e == hipSuccess; ++r) {

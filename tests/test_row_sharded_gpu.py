@@ -80,6 +80,9 @@ def test_local_ranks_reproduce_the_single_rank_path(n_ranks, flags):
     out, counts, infos = _run_ranks(n_ranks, work)
     assert infos == [(r, n_ranks) for r in range(n_ranks)]
     assert len(set(counts)) == 1 and counts[0] > 0  # every rank entered the same number of collectives
+    # two collectives per pass -- the gradients, then the stop vector (in working-set solves behind the staged Gram parts
+    # in one buffer) -- plus the gradient call above and the power steps of the step bound
+    assert counts[0] <= 2 * (out[0][1].grad_launches + 2) + 8, (counts[0], out[0][1].grad_launches)
     with _engine.get_engine(0).dataset(X, y) as ds:
         g_ref, _ = ds.gradient(None)
         ref = ds.solve_path(pts, tol=1e-10, flags=flags, lanes=2)
