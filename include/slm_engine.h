@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 8
+#define SLM_ABI_VERSION 9
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -313,6 +313,24 @@ int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, const slm_path
                          int32_t n_points, int32_t n_lanes, const slm_solve_opts* opts,
                          const double* beta0, double* betas_out, double* group_norms_out,
                          slm_point_info* infos, slm_solve_stats* stats);
+
+/*
+ * SparseGroupLasso(standardize=True) -- the reference's lambda1 ||b||_1 + lambda2 sum_g w_g ||X_g b_g||_2
+ * (src/sparselm/model/_lasso.py:616-639 with the standardised group norms of :249-252), which is no proximal penalty
+ * on b -- by operator splitting with ALL sweeps in one launch (small_split_kernels.hpp), for problems the on-chip solver
+ * takes (p <= 128, n * ld <= 131072, no row weights, not sharded, the groups' factors fitting LDS; otherwise
+ * SLM_ERR_UNSUPPORTED and the caller runs the sweeps itself over slm_solve_lanes, sparselm_amd/model/_split.py):
+ *   minimise 1/(2n)||X b - y||^2 + sum_j a[j] |b_j| + sum_g b[g] ||X_g b_g||_2 .
+ * Stops when the primal residual ||M b - gamma|| and the dual residual are below opts->tol relative to their scales
+ * (the rule of _split.py); the b-steps are solved to tol_inner (<= 0: min(tol, 1e-10)).  max_sweeps <= 0: 500.
+ * warm != 0 continues from the splitting variables of the previous call on this dataset (the re-weighting loop of the
+ * adaptive estimator) instead of rebuilding them from beta0.  info->n_iter = sweeps, info->rejects = matrix-vector
+ * products of the b-steps, info->kkt / info->mu = primal / dual residual, info->L = rho at exit, info->status =
+ * SLM_OK or SLM_ERR_NOT_CONVERGED (outputs are the last iterate).
+ */
+int slm_solve_standardized_sgl(slm_dataset* ds, const double* a, const double* b, const slm_solve_opts* opts,
+                               double tol_inner, int32_t max_sweeps, const double* beta0, int32_t warm,
+                               double* beta_out, double* group_norms_out, slm_point_info* info);
 
 /* ---- row-sharded mode (very tall X split by rows over ranks) ----------------------------------------
  * Every rank holds a block of rows and runs the whole state machine; per pass the ranks enter TWO all-reduces: the

@@ -28,6 +28,7 @@
 #include "ws_kernels.hpp"
 #include "split_kernels.hpp"
 #include "small_kernels.hpp"
+#include "small_split_kernels.hpp"
 
 using namespace slm;
 
@@ -392,6 +393,8 @@ struct slm_dataset {
   double* h_vec = nullptr;
   slm_path_point* h_pts = nullptr;
   int64_t h_pts_cap = 0;
+  double* split_state = nullptr;  // [3 ld + 2 + record] slm_solve_standardized_sgl: gamma, u, rho, valid; outputs
+  double* h_split = nullptr;      // its page-locked staging: a, b, warm start in; coefficients, group norms, record out
   double* stop_words = nullptr;  // [STOP_WORDS] row-sharded mode: the vector the ranks all-reduce after every pass
   double* XT = nullptr;  // column-major copy of X in tiles of 32 rows (tile_columns_kernel), built on first use
   bool XT_ready = false, XT_failed = false;
@@ -644,7 +647,8 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->pts); dfree(ds->betas_out); dfree(ds->gn_out); dfree(ds->infos);
   dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
   dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
-  dfree(ds->ws_nt); dfree(ds->stop_words); dfree(ds->sse_Z); dfree(ds->sse_part);
+  dfree(ds->ws_nt); dfree(ds->stop_words); dfree(ds->sse_Z); dfree(ds->sse_part); dfree(ds->split_state);
+  if (ds->h_split) (void)hipHostFree(ds->h_split);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   if (ds->h_vec) (void)hipHostFree(ds->h_vec);
   if (ds->h_pts) (void)hipHostFree(ds->h_pts);
@@ -2506,6 +2510,88 @@ extern "C" int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm
   lane.group_norms_out = group_norms_out;
   lane.infos = infos;
   return slm_solve_lanes(ds, &lane, 1, opts, stats);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SparseGroupLasso(standardize=True): the operator splitting on chip (small_split_kernels.hpp)
+// ------------------------------------------------------------------------------------------------
+extern "C" int slm_solve_standardized_sgl(slm_dataset* ds, const double* a, const double* b, const slm_solve_opts* opts,
+                                          double tol_inner, int32_t max_sweeps, const double* beta0, int32_t warm,
+                                          double* beta_out, double* group_norms_out, slm_point_info* info) {
+  if (!ds || !a || !b || !beta_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  slm_engine* eng = ds->eng;
+  HIP_TRY(hipSetDevice(eng->device));
+  hipStream_t s = eng->stream;
+  const int p = (int)ds->p, G = ds->G;
+  const int64_t ld = ds->ld;
+  const int gm = ds->max_group;
+  if (const char* env = getenv("SLM_ON_CHIP"))
+    if (env[0] == '0') return fail(SLM_ERR_UNSUPPORTED, "the on-chip solvers are switched off (SLM_ON_CHIP=0)");
+  if (eng->sharded() || ds->rw || p > SM_PMAX || (double)ds->n * (double)ld > 131072.0)
+    return fail(SLM_ERR_UNSUPPORTED, "the splitting runs on chip for unweighted, unsharded problems of p <= %d and n * ld <= 131072", SM_PMAX);
+  // LDS: Gram matrix, three vectors, the groups' Cholesky factors; what is left stages the rows of the build and
+  // then holds the partial products of three wavefronts
+  const size_t fixed = sizeof(double) * ((size_t)p * p + 3 * (size_t)p + (size_t)p * gm);
+  const size_t lds = (size_t)SM_LDS_BYTES;
+  const int64_t stage = fixed + 64 < lds ? (int64_t)((lds - fixed - 64) / sizeof(double)) : 0;
+  const int ps = 4 * ((p + 4) / 4);
+  if (stage < 3 * (int64_t)p || stage < 4 * (int64_t)ps)
+    return fail(SLM_ERR_UNSUPPORTED, "groups of up to %d columns at p = %d leave no room in LDS", gm, p);
+  const size_t rec_off = 3 * (size_t)ld + 2;  // state: gamma [ld], u [ld], rho, valid; then beta_out [ld]; then the record
+  const size_t n_state = rec_off + (sizeof(slm_point_info) + 7) / 8 + (size_t)ld;  // (+ group norms [ld])
+  const size_t n_host = 3 * (size_t)ld + n_state;
+  if (!ds->split_state) {
+    SLM_TRY(dalloc(&ds->split_state, n_state));
+    HIP_TRY(hipMemsetAsync(ds->split_state, 0, sizeof(double) * n_state, s));
+  }
+  if (!ds->h_split) {
+    hipError_t eh = hipHostMalloc((void**)&ds->h_split, sizeof(double) * n_host, hipHostMallocDefault);
+    if (eh != hipSuccess) return fail(SLM_ERR_OOM, "hipHostMalloc: %s", hipGetErrorString(eh));
+    memset(ds->h_split, 0, sizeof(double) * n_host);
+  }
+  // in: a | b | beta0 -> lane 0 of a0 | b0 | beta (one transfer each from the page-locked stage)
+  double* h = ds->h_split;
+  memcpy(h, a, sizeof(double) * p);
+  memcpy(h + ld, b, sizeof(double) * G);
+  if (beta0) memcpy(h + 2 * ld, beta0, sizeof(double) * p);
+  HIP_TRY(hipMemcpyAsync(ds->a0, h, sizeof(double) * p, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ds->b0, h + ld, sizeof(double) * G, hipMemcpyHostToDevice, s));
+  if (beta0) HIP_TRY(hipMemcpyAsync(ds->beta, h + 2 * ld, sizeof(double) * p, hipMemcpyHostToDevice, s));
+  SplitSglArgs k;
+  memset(&k, 0, sizeof(k));
+  k.X = ds->X; k.y = ds->y; k.rw = nullptr; k.n = ds->n; k.ld = ld; k.p = p; k.G = G; k.singleton = ds->singleton;
+  k.order = ds->order; k.gid = ds->gid; k.gstart = ds->gstart;
+  k.a = ds->a0; k.b = ds->b0; k.beta0 = beta0 ? ds->beta : nullptr;
+  k.state = ds->split_state;
+  k.beta_out = ds->split_state + 2 * ld + 2;
+  k.info = reinterpret_cast<slm_point_info*>(ds->split_state + rec_off);
+  k.gn_out = ds->split_state + rec_off + (sizeof(slm_point_info) + 7) / 8;
+  k.warm = warm ? 1 : 0;
+  k.tol = opts && opts->tol > 0 ? opts->tol : 1e-8;
+  k.tol_inner = tol_inner > 0 ? tol_inner : std::min(k.tol, 1e-10);
+  k.inv_n = 1.0 / (double)ds->n_global;
+  k.max_sweeps = max_sweeps > 0 ? max_sweeps : 500;
+  k.max_iters = opts && opts->max_iter > 0 ? (int)std::min<int64_t>(opts->max_iter, 4000) : 4000;
+  k.gmax = gm;
+  k.stage_doubles = (int)stage;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)small_stdsgl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(small_stdsgl_kernel, dim3(1), dim3(SM_THREADS), lds, s, k);
+  SLM_TRY(check_launch());
+  double* h_out = h + 3 * ld;  // a copy of everything behind gamma and u
+  const size_t out_off = 2 * (size_t)ld;
+  HIP_TRY(hipMemcpyAsync(h_out + out_off, ds->split_state + out_off, sizeof(double) * (n_state - out_off), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  slm_point_info rec;
+  memcpy(&rec, h_out + rec_off, sizeof(rec));
+  memcpy(beta_out, h_out + 2 * ld + 2, sizeof(double) * p);
+  if (group_norms_out) memcpy(group_norms_out, h_out + rec_off + (sizeof(slm_point_info) + 7) / 8, sizeof(double) * G);
+  if (info) *info = rec;
+  if (rec.status == SLM_ERR_NON_FINITE) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
+  return SLM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

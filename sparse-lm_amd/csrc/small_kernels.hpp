@@ -64,6 +64,109 @@ __device__ __forceinline__ void sm_lds_sync() {  // one wavefront: LDS writes be
   __builtin_amdgcn_wave_barrier();
 }
 
+// Gram matrix of [X, y] (rows scaled by sqrt(w)) in the group-sorted order, by all SM_THREADS threads of the workgroup:
+// Gs [p][p] = X^T W X / n, cs [p] = X^T W y / n, *yy_out = y^T W y / n (LDS).  `stage`: LDS scratch of stage_doubles.
+// Ends with a barrier.  Returns false when the stage holds not even one row.
+__device__ __forceinline__ bool sm_build_gram(const double* X, const double* y, const double* rw, int64_t n, int64_t ld, int p,
+                                              const int* order, double inv_n, int stage_doubles, double* Gs, double* cs,
+                                              double* stage, double* yy_out) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  bool ok = true;
+  // ---- Gram matrix of [X, y] (rows scaled by sqrt(w)) in the group-sorted order ---------------------------------
+  // G = X^T W X / n, c = X^T W y / n and y^T W y / n are the blocks of one symmetric matrix of p + 1 columns.  The rows
+  // are staged through LDS in chunks (what the Gram matrix leaves of it): all four
+  // wavefronts load a chunk coalesced, sqrt(w_i) applied once, then every thread accumulates its 4 x 4 blocks of the
+  // upper triangle from LDS.  (Straight from global memory every row cost each thread a dependent round trip: 0.25 ms
+  // for 400 x 100.)
+  {
+    const int P1 = p + 1;                 // the y column is position p
+    const int nb = (P1 + 3) >> 2;
+    const int ps = 4 * nb;                // row stride of the stage: whole blocks, zero beyond the y column
+    const int nblocks = nb * (nb + 1) / 2;
+    constexpr int MAXB = 3;  // blocks per thread (p + 1 <= 129: 33 x 34 / 2 = 561 blocks over 256 threads)
+    double acc[MAXB][4][4];
+    int bis[MAXB], bjs[MAXB];
+#pragma unroll
+    for (int r = 0; r < MAXB; ++r) {
+      const int blk = tid + r * SM_THREADS;
+      int bi = 0, rest = blk < nblocks ? blk : 0;  // row bi of the triangle holds nb - bi blocks
+      while (rest >= nb - bi) {
+        rest -= nb - bi;
+        ++bi;
+      }
+      bis[r] = blk < nblocks ? bi : -1;
+      bjs[r] = bi + rest;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[r][u][v] = 0.0;
+    }
+    const int rows_per_chunk = stage_doubles / ps;
+    if (rows_per_chunk > 0) {
+      for (int64_t i0 = 0; i0 < n; i0 += rows_per_chunk) {
+        const int rows = (int)(n - i0 < rows_per_chunk ? n - i0 : rows_per_chunk);
+        __syncthreads();  // (the previous chunk has been consumed)
+        for (int r = wave; r < rows; r += SM_THREADS / 64) {  // a wavefront per row: lanes walk the positions
+          const int64_t i = i0 + r;
+          const double sw = rw ? sqrt(rw[i]) : 1.0;
+          const double* row = X + i * ld;
+          for (int sidx = lane; sidx < ps; sidx += 64) {
+            double v = 0.0;
+            if (sidx < p) v = row[order[sidx]] * sw;
+            else if (sidx == p) v = y[i] * sw;
+            stage[r * ps + sidx] = v;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MAXB; ++r) {
+          if (bis[r] < 0) continue;
+          const double* xs_p = stage + 4 * bis[r];
+          const double* xt_p = stage + 4 * bjs[r];
+          for (int rr = 0; rr < rows; ++rr) {
+            double xs[4], xt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              xs[u] = xs_p[rr * ps + u];
+              xt[u] = xt_p[rr * ps + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) acc[r][u][v] = __builtin_fma(xs[u], xt[v], acc[r][u][v]);
+          }
+        }
+      }
+    } else {  // (no room for a stage beside the Gram matrix: cannot happen for p <= SM_PMAX)
+      ok = false;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MAXB; ++r) {
+      if (bis[r] < 0) continue;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int sp = 4 * bis[r] + u, tp = 4 * bjs[r] + v;
+          if (sp > tp || tp > p) continue;  // (upper triangle of the diagonal blocks; positions beyond the y column)
+          const double val = acc[r][u][v] * inv_n;
+          if (tp < p) {
+            Gs[sp * p + tp] = val;
+            Gs[tp * p + sp] = val;
+          } else if (sp < p) {
+            cs[sp] = val;
+          } else {
+            *yy_out = val;
+          }
+        }
+    }
+  }
+  __syncthreads();
+  return ok;
+}
+
 // this lane's part of y = G v over the rows m_lo..m_hi-1 of the (symmetric) matrix: eight terms at a time, their sixteen
 // or twenty-four loads asked for together, four chains per half (two terms at a time the product spent two thirds of its
 // time waiting for LDS round trips)
@@ -115,99 +218,8 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
   bool bad_setup = false;
   const unsigned long long tk0 = wall_clock64();
 
-  // ---- Gram matrix of [X, y] (rows scaled by sqrt(w)) in the group-sorted order ---------------------------------
-  // G = X^T W X / n, c = X^T W y / n and y^T W y / n are the blocks of one symmetric matrix of p + 1 columns.  The rows
-  // are staged through LDS in chunks (what the Gram matrix leaves of it): all four
-  // wavefronts load a chunk coalesced, sqrt(w_i) applied once, then every thread accumulates its 4 x 4 blocks of the
-  // upper triangle from LDS.  (Straight from global memory every row cost each thread a dependent round trip: 0.25 ms
-  // for 400 x 100.)
   __shared__ double yy_s;
-  {
-    const int P1 = p + 1;                 // the y column is position p
-    const int nb = (P1 + 3) >> 2;
-    const int ps = 4 * nb;                // row stride of the stage: whole blocks, zero beyond the y column
-    const int nblocks = nb * (nb + 1) / 2;
-    constexpr int MAXB = 3;  // blocks per thread (p + 1 <= 129: 33 x 34 / 2 = 561 blocks over 256 threads)
-    double acc[MAXB][4][4];
-    int bis[MAXB], bjs[MAXB];
-#pragma unroll
-    for (int r = 0; r < MAXB; ++r) {
-      const int blk = tid + r * SM_THREADS;
-      int bi = 0, rest = blk < nblocks ? blk : 0;  // row bi of the triangle holds nb - bi blocks
-      while (rest >= nb - bi) {
-        rest -= nb - bi;
-        ++bi;
-      }
-      bis[r] = blk < nblocks ? bi : -1;
-      bjs[r] = bi + rest;
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[r][u][v] = 0.0;
-    }
-    const int rows_per_chunk = a.stage_doubles / ps;
-    double* stage = vu + p;
-    if (rows_per_chunk > 0) {
-      for (int64_t i0 = 0; i0 < n; i0 += rows_per_chunk) {
-        const int rows = (int)(n - i0 < rows_per_chunk ? n - i0 : rows_per_chunk);
-        __syncthreads();  // (the previous chunk has been consumed)
-        for (int r = wave; r < rows; r += SM_THREADS / 64) {  // a wavefront per row: lanes walk the positions
-          const int64_t i = i0 + r;
-          const double sw = rw ? sqrt(rw[i]) : 1.0;
-          const double* row = a.X + i * ld;
-          for (int sidx = lane; sidx < ps; sidx += 64) {
-            double v = 0.0;
-            if (sidx < p) v = row[a.t.order[sidx]] * sw;
-            else if (sidx == p) v = a.y[i] * sw;
-            stage[r * ps + sidx] = v;
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < MAXB; ++r) {
-          if (bis[r] < 0) continue;
-          const double* xs_p = stage + 4 * bis[r];
-          const double* xt_p = stage + 4 * bjs[r];
-          for (int rr = 0; rr < rows; ++rr) {
-            double xs[4], xt[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              xs[u] = xs_p[rr * ps + u];
-              xt[u] = xt_p[rr * ps + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int v = 0; v < 4; ++v) acc[r][u][v] = __builtin_fma(xs[u], xt[v], acc[r][u][v]);
-          }
-        }
-      }
-    } else {  // (no room for a stage beside the Gram matrix: cannot happen for p <= SM_PMAX)
-      bad_setup = true;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < MAXB; ++r) {
-      if (bis[r] < 0) continue;
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int sp = 4 * bis[r] + u, tp = 4 * bjs[r] + v;
-          if (sp > tp || tp > p) continue;  // (upper triangle of the diagonal blocks; positions beyond the y column)
-          const double val = acc[r][u][v] * inv_n;
-          if (tp < p) {
-            Gs[sp * p + tp] = val;
-            Gs[tp * p + sp] = val;
-          } else if (sp < p) {
-            cs[sp] = val;
-          } else {
-            yy_s = val;
-          }
-        }
-    }
-  }
-  __syncthreads();
+  if (!sm_build_gram(a.X, a.y, rw, n, ld, p, a.t.order, inv_n, a.stage_doubles, Gs, cs, vu + p, &yy_s)) bad_setup = true;
   // Wavefront 0 iterates; the other three serve its matrix-vector products, a quarter of the rows of G each: they wait
   // at the barrier, multiply when the command word says so, leave when it says zero.
   __shared__ int sm_cmd;

@@ -42,7 +42,7 @@ FLAG_NO_WORKING_SET = 64
 FLAG_ON_CHIP = 128  # problems whose Gram matrix fits a workgroup: one launch per call (csrc/small_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 8  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 9  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -75,6 +75,7 @@ ABI_SYMBOLS = (
     "slm_solve_path",
     "slm_solve_lanes",
     "slm_solve_path_lanes",
+    "slm_solve_standardized_sgl",
     "slm_comm_unique_id",
     "slm_comm_init",
     "slm_comm_info",
@@ -255,6 +256,7 @@ def load_library():
             "slm_solve_path_lanes": [
                 vp, P(_PenaltyStruct), P(_PathPoint), i32, i32, P(_SolveOpts), vp, vp, vp, P(_PointInfo), P(_SolveStats),
             ],
+            "slm_solve_standardized_sgl": [vp, vp, vp, P(_SolveOpts), dbl, i32, vp, i32, vp, vp, P(_PointInfo)],
             "slm_comm_unique_id": [vp],
             "slm_comm_init": [vp, i32, i32, vp],
             "slm_comm_info": [vp, P(i32), P(i32)],
@@ -791,6 +793,28 @@ class Dataset:
             )
         )
         return _path_result(betas, gn, infos, K, stats)
+
+
+    def solve_standardized_sgl(self, a, b, beta0=None, warm=False, tol=1e-8, tol_inner=0.0, max_sweeps=0,
+                               max_iter=0, want_group_norms=False):
+        """``slm_solve_standardized_sgl``: the splitting for ``l1 + sum_g b_g ||X_g beta_g||_2`` with all sweeps in
+        one launch.  Returns ``(beta, group_norms or None, info)``; ``NotImplementedError`` when the problem is not
+        one the on-chip solver takes (the caller then runs the sweeps over ``solve_lanes``)."""
+        G = self.n_groups
+        a_ = _f64(np.broadcast_to(a, (self.p,)), "a")
+        b_ = _f64(np.broadcast_to(b, (G,)), "b")
+        b0 = None if beta0 is None else _f64(beta0, "beta0", (self.p,))
+        opts = _SolveOpts(float(tol), int(max_iter), 0, 0.0, 0)
+        beta = np.empty(self.p)
+        gn = np.empty(G) if want_group_norms else None
+        info = np.zeros(1, dtype=_INFO_DTYPE)
+        _check(
+            self._lib.slm_solve_standardized_sgl(
+                self._h, _ptr(a_), _ptr(b_), C.byref(opts), float(tol_inner), int(max_sweeps), _ptr(b0), int(bool(warm)),
+                _ptr(beta), _ptr(gn), _as(info, _PointInfo),
+            )
+        )
+        return beta, gn, info[0]
 
 
 class _HostPool:

@@ -43,7 +43,24 @@ class StandardizedSparseGroupProblem:
         self.n, self.p = X.shape
         self.G = int(n_groups)
         self.options = dict(options)
-        gidx = np.arange(self.p) if gidx is None else np.asarray(gidx)
+        self.gidx = np.arange(self.p) if gidx is None else np.asarray(gidx)
+        self.inner = None
+        self.blocks = None
+        # Problems the on-chip solver takes run ALL sweeps in one launch on the dataset of (X, y) itself
+        # (slm_solve_standardized_sgl, csrc/small_split_kernels.hpp); the sweeps below are the general route, and
+        # the A/B partner of that kernel (option ``on_chip=False``).
+        self.dev = None
+        self.dev_warm = False
+        if self.options.get("on_chip", True) is not False:
+            self.dev = get_backend().problem(self.X, self.y, gidx, self.G, self.options)
+            if not hasattr(getattr(self.dev, "ds", None), "solve_standardized_sgl"):  # (the tests' CPU stand-in)
+                self.dev.close()
+                self.dev = None
+        if self.dev is None:
+            self._host_setup()
+
+    def _host_setup(self):
+        X, gidx = self.X, self.gidx
         # M_g = S_g V_g^T of the thin SVD of X_g (rank-deficient groups keep rank(X_g) rows)
         blocks, r0 = [], 0
         for g in range(self.G):
@@ -60,7 +77,6 @@ class StandardizedSparseGroupProblem:
         for cols, Mg, lo, hi in blocks:
             self.M[lo:hi, cols] = Mg
         self.scale = np.sqrt((self.n + self.r) / self.n)  # the engine's loss is 1/(2 rows)
-        self.inner = None
         self.rho = 1.0 / self.n
         self.gamma = np.zeros(self.r)
         self.u = np.zeros(self.r)
@@ -95,11 +111,36 @@ class StandardizedSparseGroupProblem:
         v = self.M @ beta
         return np.array([np.linalg.norm(v[lo:hi]) for _, _, lo, hi in self.blocks])
 
+    def _solve_on_chip(self, a, b, beta0, want_group_norms, tol):
+        """All sweeps in one launch; ``None`` when the problem is not one the kernel takes, or it ran out of sweeps."""
+        o = self.options
+        try:
+            beta, gn, rec = self.dev.ds.solve_standardized_sgl(
+                a, b, beta0=beta0, warm=self.dev_warm, tol=tol, tol_inner=float(o["tol"]) if "tol" in o else min(tol, 1e-10),
+                max_sweeps=_MAX_SWEEPS, want_group_norms=want_group_norms,
+            )
+        except NotImplementedError:
+            return None
+        self.dev_warm = True
+        if int(rec["status"]) != 0:
+            return None
+        info = {"n_iter": int(rec["n_iter"]), "converged": True, "resid": float(rec["resid"]),
+                "inner_iterations": int(rec["rejects"]), "rho": float(rec["L"]), "on_chip": True}
+        return beta, gn, info
+
     def solve(self, a, b, d, beta0=None, want_group_norms=False):
         a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
         if d is not None and np.any(np.asarray(d) != 0.0):
             raise ValueError("the splitting for standardised sparse-group penalties carries no ridge term")
         tol = float(self.options.get("tol", default_tol(self.n, self.p)))
+        if self.dev is not None:
+            done = self._solve_on_chip(a, b, beta0, want_group_norms, tol)
+            if done is not None:
+                return done
+            self.dev.close()  # (not a problem for the kernel: the sweeps below take this and every later call)
+            self.dev = None
+        if self.blocks is None:
+            self._host_setup()
         zeros_g = np.zeros(self.p)  # (the inner problem has singleton groups: one entry per feature)
         beta = None if beta0 is None else np.asarray(beta0, dtype=np.float64)
         if beta is not None and not np.any(self.gamma) and not np.any(self.u):
@@ -150,6 +191,9 @@ class StandardizedSparseGroupProblem:
         return beta, (self.group_norms(beta) if want_group_norms else None), info
 
     def close(self):
+        if self.dev is not None:
+            self.dev.close()
+            self.dev = None
         if self.inner is not None:
             self.inner.close()
             self.inner = None

@@ -116,3 +116,90 @@ def test_randomised_cross_check_against_the_general_path():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "flagged 0" in out.stdout.splitlines()[-1]
+
+
+def test_standardized_sparse_group_splitting_in_one_launch(eng):
+    """slm_solve_standardized_sgl (csrc/small_split_kernels.hpp): l1 + sum_g b_g ||X_g beta_g||_2 -- the reference's
+    SparseGroupLasso(standardize=True), src/sparselm/model/_lasso.py:616-639 with the group norms of :249-252 -- with
+    all sweeps of the splitting on chip, against the oracle's primal-dual iteration and the optimality conditions of the
+    original problem; a rank-deficient group, groups in scattered order, an empty group, and the continuation of the
+    splitting variables the adaptive loop uses."""
+    rng = np.random.default_rng(5)
+    for n, p, G in ((100, 80, 10), (25, 30, 6), (400, 100, 25), (60, 128, 16)):
+        X = rng.standard_normal((n, p)) + 0.5 * rng.standard_normal((n, 1))
+        groups = rng.permutation(np.arange(p) % G)
+        cols = np.flatnonzero(groups == 0)
+        X[:, cols[-1]] = 2.0 * X[:, cols[0]]  # a rank-deficient group
+        beta = np.where(rng.random(p) < 0.25, rng.standard_normal(p), 0.0)
+        y = X @ beta + 0.2 * rng.standard_normal(n)
+        gidx, GG = oracle.group_index(groups, p)
+        a, b = 0.05 * rng.uniform(0.5, 1.5, p), 0.1 * rng.uniform(0.5, 1.5, GG)
+        with eng.dataset(X, y) as ds:
+            ds.set_groups(groups, GG)
+            coef, gn, rec = ds.solve_standardized_sgl(a, b, tol=1e-11, max_sweeps=5000, want_group_norms=True)
+            assert rec["status"] == 0 and rec["mode"] == 2
+            scale = np.max(np.abs(X.T @ y)) / n
+            ztol = 1e-9 * np.max(np.abs(coef))
+            assert oracle.kkt_standardized(X, y, a, b, gidx, GG, coef, zero_tol=ztol) < 1e-7 * scale
+            fit_norms = np.array([np.linalg.norm(X[:, gidx == g] @ coef[gidx == g]) for g in range(GG)])
+            np.testing.assert_allclose(gn, fit_norms, rtol=1e-9, atol=1e-12 * np.max(fit_norms))
+            assert np.all(coef[np.isin(gidx, np.flatnonzero(fit_norms == 0.0))] == 0.0)  # groups that are out: exact zeros
+            if n > p:
+                ref, info = oracle.standardized_sparse_group(X, y, a, b, gidx, GG)
+                assert info["converged"]
+                # (the duplicated column makes the split inside group 0 non-unique in the group norm; the l1 term picks it)
+                np.testing.assert_allclose(coef, ref, rtol=0, atol=1e-7 * np.max(np.abs(ref)))
+            # continuation: the same call again from its own splitting variables stops after a sweep or two
+            again, _, rec2 = ds.solve_standardized_sgl(a, b, beta0=coef, warm=True, tol=1e-11, max_sweeps=5000)
+            assert rec2["status"] == 0 and rec2["n_iter"] <= 3 and rec2["n_iter"] < rec["n_iter"]
+            np.testing.assert_allclose(again, coef, rtol=0, atol=1e-9 * np.max(np.abs(coef)))
+    # an empty group, singleton groups (then the group norm is ||x_j|| |b_j|: a weighted Lasso)
+    n, p = 50, 12
+    X = rng.standard_normal((n, p))
+    y = X[:, :3] @ np.array([2.0, -1.0, 0.5]) + 0.1 * rng.standard_normal(n)
+    with eng.dataset(X, y) as ds:
+        groups = np.array([0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 3, 3])
+        ds.set_groups(groups, 4)
+        coef, gn, rec = ds.solve_standardized_sgl(0.02 * np.ones(p), 0.1 * np.ones(4), tol=1e-11, want_group_norms=True)
+        assert rec["status"] == 0 and gn[1] == 0.0
+        assert oracle.kkt_standardized(X, y, 0.02, 0.1, groups, 4, coef) < 1e-8
+        ds.set_groups(None)
+        coef, _, rec = ds.solve_standardized_sgl(0.02 * np.ones(p), 0.1 * np.ones(p), tol=1e-11)
+        assert rec["status"] == 0
+        wl = 0.02 + 0.1 * np.linalg.norm(X, axis=0)
+        ref, _ = oracle.fista(X, y, wl, 0.0, 0.0, np.arange(p), p, tol=1e-14, max_iter=500000)
+        np.testing.assert_allclose(coef, ref, rtol=0, atol=1e-8 * np.max(np.abs(ref)))
+    # not for the kernel: too many features, row weights -> SLM_ERR_UNSUPPORTED (the estimator then runs the sweeps)
+    X = rng.standard_normal((40, 130))
+    with eng.dataset(X, X[:, 0]) as ds:
+        with pytest.raises(NotImplementedError):
+            ds.solve_standardized_sgl(np.ones(130), np.ones(130))
+    X = rng.standard_normal((40, 10))
+    with eng.dataset(X, X[:, 0], row_weight=np.linspace(0.5, 1.5, 40)) as ds:
+        with pytest.raises(NotImplementedError):
+            ds.solve_standardized_sgl(np.ones(10), np.ones(10))
+
+
+def test_standardized_estimator_takes_the_on_chip_route_and_agrees_with_the_sweeps(golden):
+    """SparseGroupLasso(standardize=True) / AdaptiveSparseGroupLasso through the estimator: on chip by default, the
+    host-driven sweeps of model/_split.py with on_chip=False -- same coefficients, same number of adaptive rounds."""
+    import warnings
+
+    from sparselm_amd.model import AdaptiveSparseGroupLasso, SparseGroupLasso
+
+    X, y, groups, gw = golden["grp_X"], golden["grp_y"], golden["grp_groups"], golden["grp_gw"]
+    fits = {}
+    for on_chip in (True, False):
+        opts = {"tol": 1e-11, "max_iter": 200000, "on_chip": on_chip}
+        m = SparseGroupLasso(groups=groups, alpha=0.4, l1_ratio=0.5, group_weights=gw, standardize=True, solver_options=opts).fit(X, y)
+        assert m.solver_info_["converged"] and bool(m.solver_info_.get("on_chip", False)) == on_chip
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            am = AdaptiveSparseGroupLasso(groups=groups, alpha=0.8, l1_ratio=0.4, group_weights=gw, standardize=True,
+                                          fit_intercept=True, solver_options=opts).fit(X, y)
+        fits[on_chip] = (m, am)
+    scale = np.max(np.abs(fits[False][0].coef_))
+    assert np.max(np.abs(fits[True][0].coef_ - fits[False][0].coef_)) < 1e-8 * scale
+    assert np.max(np.abs(fits[True][0].coef_ - golden["std_sgl_coef"])) < 1e-8 * scale
+    assert fits[True][1].n_iter_ == fits[False][1].n_iter_ == int(golden["std_ada_sgl_niter"])
+    assert np.max(np.abs(fits[True][1].coef_ - golden["std_ada_sgl_coef"])) < 1e-6 * np.max(np.abs(golden["std_ada_sgl_coef"]))
