@@ -209,8 +209,9 @@ typedef struct slm_path_point {
 #define SLM_FLAG_ON_CHIP 128u        /* the caller accepts the on-chip solver for problems whose Gram matrix fits a
                                         workgroup's LDS (p <= 128, n * ld <= 2^17 -- the sizes of the reference's own
                                         tests and README, tests/conftest.py:17-19, README.md:42-55): ONE launch per call,
-                                        a workgroup per lane, (block) coordinate descent on X^T W X / n.  Same minimiser
-                                        and the same meaning of `tol`; slm_point_info.mode is 2, n_iter counts sweeps,
+                                        a workgroup per lane, accelerated proximal steps + conjugate gradients / Anderson
+                                        acceleration on X^T W X / n held in LDS (small_kernels.hpp).  Same minimiser and the
+                                        same meaning of `tol`; slm_point_info.mode is 2, n_iter counts matrix-vector products,
                                         slm_solve_stats.grad_launches is 1.  Ignored together with the flags that ask for
                                         a particular iteration (1, 2, 16, 32, 64); a point it does not settle hands the
                                         call to the general path.  Up to SLM_MAX_LANES lanes whatever p.              */
@@ -232,8 +233,8 @@ typedef struct slm_point_info {
   double beta_norm;  /* ||beta||_2                                                       */
   double loss;       /* 1/(2n)||X z - y||_W^2 at the last gradient point                 */
   double L;          /* inverse step in use at exit (Lipschitz constant in FISTA mode)   */
-  int32_t mode;      /* 1 = spectral (Barzilai-Borwein) steps, 0 = FISTA (after fallback), 2 = on-chip
-                        coordinate descent (SLM_FLAG_ON_CHIP)                            */
+  int32_t mode;      /* 1 = spectral (Barzilai-Borwein) steps, 0 = FISTA (after fallback), 2 = the on-chip
+                        solver (SLM_FLAG_ON_CHIP)                            */
   int32_t rejects;   /* spectral candidates rejected so far in this solve                */
   double kkt;        /* KKT residual at exit: ||(z - prox_s(z - s grad f(z))) / s||_2 -- zero exactly at
                         the minimiser (the certificate SURVEY 8c-3 names; the reference's solver reports

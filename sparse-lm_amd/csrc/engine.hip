@@ -2026,7 +2026,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (unconverged) {
       if (const char* trc = getenv("SLM_TRACE"))
         if (trc[0] == '2') fprintf(stderr, "[slm] on-chip solve gave a point up after %.3f ms (%lld products): the general path takes the call\n", t_small, (long long)sweeps);
-      // the coordinate iteration did not settle some point within its sweeps (an ill-conditioned face): the general
+      // the on-chip iteration did not settle some point within its products (an ill-conditioned face): the general
       // path, with its Newton steps, takes the call over from the start
       slm_solve_opts again = o;
       again.flags &= ~SLM_FLAG_ON_CHIP;

@@ -364,7 +364,7 @@ class PathResult:
     resid: np.ndarray
     beta_norm: np.ndarray
     loss: np.ndarray
-    mode: np.ndarray  # per point: 1 = spectral steps, 0 = FISTA, 2 = on-chip coordinate descent
+    mode: np.ndarray  # per point: 1 = spectral steps, 0 = FISTA, 2 = the on-chip solver
     L: float
     grad_launches: int
     grad_timed: int
