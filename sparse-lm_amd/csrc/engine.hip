@@ -2054,10 +2054,18 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       stats->wall_ms = t_mark();
     }
     if (const char* trc = getenv("SLM_TRACE"))
-      if (trc[0] == '2')
-        fprintf(stderr, "[slm] on-chip solve: row weights %.3f setup %.3f launched+synced %.3f end %.3f ms, %lld products; lane 0 in the kernel: "
-                "Gram %.3f, lambda_max %.3f, proximal steps %.3f, conjugate gradients %.3f, records %.3f ms\n", tr_rw, tr[0], t_small, t_mark(),
-                (long long)sweeps, snap.lane[0].hist[0], snap.lane[0].hist[1], snap.lane[0].hist[2], snap.lane[0].hist[3], snap.lane[0].hist[4]);
+      if (trc[0] == '2') {
+        int sl = 0;  // the lane that took longest
+        double worst = -1.0;
+        for (int l = 0; l < B; ++l) {
+          const double t = snap.lane[l].hist[0] + snap.lane[l].hist[1] + snap.lane[l].hist[2] + snap.lane[l].hist[3] + snap.lane[l].hist[4];
+          if (t > worst) { worst = t; sl = l; }
+        }
+        fprintf(stderr, "[slm] on-chip solve: row weights %.3f setup %.3f launched+synced %.3f end %.3f ms, %lld products; slowest lane (%d of %d, %d points, "
+                "%d products, %d face solves) in the kernel: Gram %.3f, lambda_max %.3f, proximal steps %.3f, faces %.3f, records %.3f ms\n", tr_rw, tr[0],
+                t_small, t_mark(), (long long)sweeps, sl, B, lanes[sl].n_points, snap.lane[sl].iter, (int)snap.lane[sl].n_hist, snap.lane[sl].hist[0],
+                snap.lane[sl].hist[1], snap.lane[sl].hist[2], snap.lane[sl].hist[3], snap.lane[sl].hist[4]);
+      }
     return SLM_OK;
   }
 

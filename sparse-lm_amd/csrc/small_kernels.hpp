@@ -37,6 +37,7 @@ namespace slm {
 
 constexpr int SM_PMAX = 128;      // features: two positions per lane of the iterating wavefront
 constexpr int SM_THREADS = 256;   // four wavefronts build the Gram; wavefront 0 iterates
+constexpr int SM_FACE_ROUNDS = 1; // active-set rounds of a direct solve (more than one did not pay: see the direct block)
 constexpr int SM_STILL = 4;       // proximal steps with an unchanged sign pattern before conjugate gradients take over
 constexpr int SM_LDS_BYTES = 156 * 1024;  // of the 160 KiB of a CU
 
@@ -197,6 +198,195 @@ __device__ __forceinline__ void sm_partial(const double* Gs, const double* vz, i
   y1 = (f[0] + f[2]) + (f[1] + f[3]);
 }
 
+// value of lane k (uniform) of a wavefront's double
+__device__ __forceinline__ double sm_lane(double v, int k) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
+// LDS beside the Gram matrix that the direct solves on a face use: the positions of the face, the ridge terms of its
+// diagonal, the diagonal itself as gathered, the inverted pivots, and the factor (lower triangle, packed by rows: (i, j)
+// at i (i + 1) / 2 + j)
+constexpr int SM_FACE_HEAD = 64 + 3 * SM_PMAX;  // doubles in front of the factor: idx (as ints), add, dia, invd
+__device__ __forceinline__ int sm_face_cap(int free_doubles) {  // largest face whose factor fits
+  int m = 0;
+  while (m < SM_PMAX && (m + 1) * (m + 2) / 2 <= free_doubles - SM_FACE_HEAD) ++m;
+  return m;
+}
+
+__device__ __forceinline__ double sm_recip(double d) {  // 1 / d: the hardware's estimate and two Newton steps
+  double y = __builtin_amdgcn_rcp(d);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  return y;
+}
+
+// H = G_AA + diag(add) of the face A = idx[0..m) factored as L D L^T by the workgroup, right-looking in blocks of FOUR
+// columns, two barriers per block: F[i][c] (i > c) keeps u_ic = L[i][c] d_c, the diagonal keeps d_c, invd[c] = 1 / d_c.
+//   panel:  every thread factors the 4 x 4 diagonal block for itself (ten loads, four pivots); the thread of a row below
+//           it finishes that row's entries: u_i1 = a_i1 - L_i0 u_10, u_i2 = a_i2 - L_i0 u_20 - L_i1 u_21, ...
+//   update: F[i][j] -= sum_c u_ic invd_c u_jc behind the panel, a thread's columns' four terms kept in registers, all
+//           loads of a row ahead of its stores.  (The finished diagonal block is written here: nobody reads it any more.)
+// (One column per barrier, the first version, was a chain of dependent LDS round trips per column: 80 us for 80 unknowns.)
+// A pivot at rounding level (a column that depends on the ones before it: p > n, duplicated features) is dropped:
+// invd = 0, its unknown stays where it is.  `worker`: wavefront 0 -- which holds the iteration's state in its registers --
+// only keeps the barriers; the other three do the arithmetic.  Starts and ends with a barrier.
+__device__ __forceinline__ void sm_face_factor(const double* Gs, int p, const int* fidx, const double* fadd, int m, double* F,
+                                               double* fdia, double* invd, bool worker) {
+  constexpr int NB = SM_PMAX / 16;          // column batches of a thread in the update
+  constexpr int TW = SM_THREADS - 64;       // working threads
+  const int t = (int)threadIdx.x - 64;      // 0 .. TW-1 for the workers
+  const int ty = t >> 4, tx = t & 15;       // 12 x 16
+  if (worker) {
+    for (int i = ty; i < m; i += TW / 16) {
+      const int si = fidx[i], base = i * (i + 1) / 2;
+      for (int j = tx; j <= i; j += 16) {
+        const double v = Gs[si * p + fidx[j]] + (i == j ? fadd[i] : 0.0);
+        F[base + j] = v;
+        if (i == j) fdia[i] = v;
+      }
+    }
+  }
+  for (int k = 0; k < m; k += 4) {
+    __syncthreads();
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, u21 = 0.0, u31 = 0.0, u32 = 0.0;
+    const bool v1 = k + 1 < m, v2 = k + 2 < m, v3 = k + 3 < m;
+    const int r1 = v1 ? k + 1 : k, r2 = v2 ? k + 2 : k, r3 = v3 ? k + 3 : k;
+    const int bk1 = r1 * (r1 + 1) / 2, bk2 = r2 * (r2 + 1) / 2, bk3 = r3 * (r3 + 1) / 2;
+    if (worker) {
+      // ---- the 4 x 4 diagonal block (rows beyond m count as absent) ----
+      const int bk0 = k * (k + 1) / 2;
+      const double a00 = F[bk0 + k], a10 = F[bk1 + k], a11 = F[bk1 + r1], a20 = F[bk2 + k], a21 = F[bk2 + r1], a22 = F[bk2 + r2];
+      const double a30 = F[bk3 + k], a31 = F[bk3 + r1], a32 = F[bk3 + r2], a33 = F[bk3 + r3];
+      const double g0 = fdia[k], g1 = fdia[r1], g2 = fdia[r2], g3 = fdia[r3];
+      // this thread's row below the block
+      const int i = k + 4 + t;
+      const int bi = i * (i + 1) / 2;
+      double w0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+      if (i < m) {
+        w0 = F[bi + k];
+        x1 = F[bi + k + 1];
+        x2 = F[bi + k + 2];
+        x3 = F[bi + k + 3];
+      }
+      n0 = a00 > 1e-13 * g0 ? sm_recip(a00) : 0.0;
+      const double u10 = v1 ? a10 : 0.0, u20 = v2 ? a20 : 0.0, u30 = v3 ? a30 : 0.0;
+      const double l10 = u10 * n0, l20 = u20 * n0, l30 = u30 * n0;
+      d1 = __builtin_fma(-l10, u10, a11);
+      n1 = (v1 && d1 > 1e-13 * g1) ? sm_recip(d1) : 0.0;
+      u21 = v2 ? __builtin_fma(-l20, u10, a21) : 0.0;
+      u31 = v3 ? __builtin_fma(-l30, u10, a31) : 0.0;
+      const double l21 = u21 * n1, l31 = u31 * n1;
+      d2 = __builtin_fma(-l21, u21, __builtin_fma(-l20, u20, a22));
+      n2 = (v2 && d2 > 1e-13 * g2) ? sm_recip(d2) : 0.0;
+      u32 = v3 ? __builtin_fma(-l31, u21, __builtin_fma(-l30, u20, a32)) : 0.0;
+      const double l32 = u32 * n2;
+      d3 = __builtin_fma(-l32, u32, __builtin_fma(-l31, u31, __builtin_fma(-l30, u30, a33)));
+      n3 = (v3 && d3 > 1e-13 * g3) ? sm_recip(d3) : 0.0;
+      if (i < m) {
+        const double m0 = w0 * n0;
+        const double w1 = __builtin_fma(-m0, u10, x1);
+        const double m1 = w1 * n1;
+        const double w2 = __builtin_fma(-m1, u21, __builtin_fma(-m0, u20, x2));
+        const double m2 = w2 * n2;
+        const double w3 = __builtin_fma(-m2, u32, __builtin_fma(-m1, u31, __builtin_fma(-m0, u30, x3)));
+        F[bi + k + 1] = w1;  // (its own row: nobody else reads it before the barrier)
+        F[bi + k + 2] = w2;
+        F[bi + k + 3] = w3;
+      }
+    }
+    __syncthreads();
+    if (worker) {
+      if (t == 0) {  // the finished block and its pivots
+        invd[k] = n0;
+        if (v1) { invd[r1] = n1; F[bk1 + r1] = d1; }
+        if (v2) { invd[r2] = n2; F[bk2 + r1] = u21; F[bk2 + r2] = d2; }
+        if (v3) { invd[r3] = n3; F[bk3 + r1] = u31; F[bk3 + r2] = u32; F[bk3 + r3] = d3; }
+      }
+      // ---- update behind the panel: rows i = k + 4 + ty + 12 a, columns j = k + 4 + tx + 16 b <= i ----
+      const int jb = k + 4 + tx;
+      double cj[NB][4];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int j = jb + 16 * b;
+        const int bj = j * (j + 1) / 2 + k;
+        const bool on = j < m;
+        cj[b][0] = on ? F[bj] * n0 : 0.0;
+        cj[b][1] = on ? F[bj + 1] * n1 : 0.0;
+        cj[b][2] = on ? F[bj + 2] * n2 : 0.0;
+        cj[b][3] = on ? F[bj + 3] * n3 : 0.0;
+      }
+      for (int i = k + 4 + ty; i < m; i += TW / 16) {
+        const int base = i * (i + 1) / 2;
+        const double e0 = F[base + k], e1 = F[base + k + 1], e2 = F[base + k + 2], e3 = F[base + k + 3];
+        double f[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int j = jb + 16 * b;
+          f[b] = j <= i ? F[base + j] : 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int j = jb + 16 * b;
+          if (j <= i)
+            F[base + j] = __builtin_fma(-e3, cj[b][3], __builtin_fma(-e2, cj[b][2], __builtin_fma(-e1, cj[b][1], __builtin_fma(-e0, cj[b][0], f[b]))));
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// the two triangular solves with the factor above, on ONE wavefront: lane l holds unknowns l and l + 64 (w0, w1: the
+// right-hand side on entry, the solution on return).  The entries of L and the pivots a step needs do not depend on the
+// running vector: eight steps' worth are asked for together, the chain is a broadcast and two products per step.
+__device__ __forceinline__ void sm_face_solve(const double* F, const double* invd, int m, int lane, double& w0, double& w1) {
+  const int i0 = lane, i1 = lane + 64;
+  const bool h0 = i0 < m, h1 = i1 < m;
+  const double il0 = h0 ? invd[i0] : 0.0, il1 = h1 ? invd[i1] : 0.0;
+  const int b0 = i0 * (i0 + 1) / 2, b1 = i1 * (i1 + 1) / 2;
+  for (int k0 = 0; k0 < m; k0 += 8) {  // L w = rhs  (L[i][k] = F[i][k] invd[k])
+    double fa[8], fb[8], iv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      iv[u] = k < m ? invd[k] : 0.0;
+      fa[u] = (h0 && i0 > k) ? F[b0 + k] : 0.0;
+      fb[u] = (h1 && i1 > k) ? F[b1 + k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      if (k < m) {
+        const double ck = (k < 64 ? sm_lane(w0, k) : sm_lane(w1, k - 64)) * iv[u];
+        w0 = __builtin_fma(-fa[u], ck, w0);
+        w1 = __builtin_fma(-fb[u], ck, w1);
+      }
+    }
+  }
+  w0 *= il0;  // D
+  w1 *= il1;
+  for (int k0 = m - 1; k0 > 0; k0 -= 8) {  // L^T x = w
+    double fa[8], fb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 - u;
+      const int bk = k * (k + 1) / 2;
+      fa[u] = (k > 0 && i0 < k) ? F[bk + i0] * il0 : 0.0;
+      fb[u] = (k > 0 && h1 && i1 < k) ? F[bk + i1] * il1 : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 - u;
+      if (k > 0) {
+        const double xk = k < 64 ? sm_lane(w0, k) : sm_lane(w1, k - 64);
+        w0 = __builtin_fma(-fa[u], xk, w0);
+        w1 = __builtin_fma(-fb[u], xk, w1);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
   extern __shared__ double sm_lds[];  // G [p][p], c [p], vz [p], vu [p], then the stage
   const int lane_id = blockIdx.x;
@@ -222,8 +412,14 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
   if (!sm_build_gram(a.X, a.y, rw, n, ld, p, a.t.order, inv_n, a.stage_doubles, Gs, cs, vu + p, &yy_s)) bad_setup = true;
   // Wavefront 0 iterates; the other three serve its matrix-vector products, a quarter of the rows of G each: they wait
   // at the barrier, multiply when the command word says so, leave when it says zero.
-  __shared__ int sm_cmd;
+  __shared__ int sm_cmd, sm_m;
   double* pp = vu + p;  // [3][p]: the partial products of wavefronts 1..3 (the stage of the build is free now)
+  int* fidx = reinterpret_cast<int*>(pp + 3 * p);  // direct solves on a face (sm_face_factor)
+  double* fadd = pp + 3 * p + 64;
+  double* fdia = fadd + SM_PMAX;
+  double* invd = fdia + SM_PMAX;
+  double* Ff = invd + SM_PMAX;
+  const int face_cap = sm_face_cap(a.stage_doubles - 3 * p);
   const int mchunk = (((p + 3) >> 2) + 7) & ~7;
   if (wave != 0) {
     const int s0w = lane, s1w = lane + 64;
@@ -231,7 +427,12 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
     const int m_lo = wave * mchunk < p ? wave * mchunk : p, m_hi = (wave + 1) * mchunk < p ? (wave + 1) * mchunk : p;
     for (;;) {
       __syncthreads();
-      if (sm_cmd == 0) break;
+      const int cmd = sm_cmd;
+      if (cmd == 0) break;
+      if (cmd == 2) {
+        sm_face_factor(Gs, p, fidx, fadd, sm_m, Ff, fdia, invd, true);
+        continue;
+      }
       double y0, y1;
       sm_partial(Gs, vz, p, m_lo, m_hi, on0w ? s0w : 0, on1w ? s1w : 0, p > 64, y0, y1);
       if (on0w) pp[(wave - 1) * p + s0w] = y0;
@@ -310,6 +511,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
   const unsigned long long tk2 = wall_clock64();
   bool bad = false;
   long long iters_all = 0;
+  int face_solves = 0;  // direct solves on a face (SLM_TRACE=2)
   if (bad_setup) {  // (nothing was built: every point goes to the general path)
     for (int point = first + lane; point < last; point += 64) {
       slm_point_info info;
@@ -659,7 +861,10 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
       // (G_AA + D) x_A = c_A - thr_A sign(x_A): warm start x, residual r = -(q + thr sign(x) + d x) on A.  A step that
       // would carry a coordinate across zero stops there; the coordinate leaves A and the iteration starts over on the
       // smaller face.  Off A every vector is zero, so the products with the full G are products with G_AA.
-      if (lasso_type && !conv && still >= SM_STILL && cg_runs < 6 && (np0 | nn0 | np1 | nn1) != 0ull) {
+      const int face_now = __popcll(np0 | nn0) + __popcll(np1 | nn1);
+      const bool face_fits = face_now <= face_cap && face_now < (int)n;  // (more unknowns than rows: a singular face)
+      bool want_direct = false;
+      if (lasso_type && !conv && still >= SM_STILL && cg_runs < (face_fits ? 12 : 6) && face_now != 0) {
         ++cg_runs;
         still = 0;
         bool f0 = on0 && x0 != 0.0, f1 = on1 && x1 != 0.0;  // the face
@@ -670,7 +875,9 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
         q1 -= c1;
         int hits = 0;
         const int face0 = __popcll(np0 | nn0) + __popcll(np1 | nn1);
-        const int cg_cap = 2 * face0 + 10;
+        // (a face whose factor fits beside G gets a direct solve when these steps do not settle it soon)
+        const int cg_cap = face_fits ? (2 * face0 + 10 < 24 ? 2 * face0 + 10 : 24) : 2 * face0 + 10;
+        bool cg_done = false;
         double r0 = f0 ? -(q0 + copysign(thr0, x0) + pd0 * x0) : 0.0, r1 = f1 ? -(q1 + copysign(thr1, x1) + pd1 * x1) : 0.0;
         double d0v = r0, d1v = r1;
         double rr = sm_sum(r0 * r0 + r1 * r1);
@@ -727,6 +934,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
           // (a tenth of what the point is accepted on: the proximal steps that follow confirm it)
           if (sqrt(rr_new) <= 0.1 * fmax(tol * xn * mu_eff2, kRoundFloor * (gnorm + Lp * xn)) || rr_new <= 1e-30 * rr_start) {
             rr = rr_new;
+            cg_done = true;
             break;
           }
           const double bt = rr_new / rr;
@@ -735,11 +943,105 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
           rr = rr_new;
         }
         if (bad) break;
+        want_direct = face_fits && !cg_done && rr > 0.0;
         z0 = x0; z1 = x1;   // the proximal steps go on from the face's minimiser, momentum and history afresh
         tk = 1.0;
         have_prev = false;
         pat_p = pat_n = pat_p1 = pat_n1 = ~0ull;
         tk_cg += wall_clock64() - tkb;
+      }
+      if (want_direct) {
+        const unsigned long long tkd = wall_clock64();
+        // ---- direct solve on the face: (G_AA + D) x_A = c_A - thr_A s_A by an L D L^T factorisation the other three
+        // wavefronts work on (sm_face_factor), two triangular solves on this one -- for faces conjugate gradients have not
+        // settled in their steps (ill-conditioned G_AA: the nearly unpenalised small alphas of the reference's README grid).
+        // The iterate moves towards the face's minimiser t along the PROJECTED segment -- x + alpha (t - x) with every
+        // coordinate that would leave its sign held at zero -- for the first alpha of 1, 1/2, 1/4, ... at which the
+        // objective does not rise (one product each): many coordinates leave the face at once.  The proximal steps that
+        // follow confirm the point or extend the face.
+        // (SM_FACE_ROUNDS > 1 continues as an active-set method: coordinates at zero whose bound the gradient violates
+        //  join with the sign of -q_j and the larger face is solved again.  On the README's noise-free folds -- seventy of
+        //  eighty coefficients at rounding level, thresholds of 1e-8 against entries of 5e-5 in the inverse -- the rounds
+        //  flip subsets back and forth: 18-35 factorisations per point against 4-5 this way.  Stopping at the first sign
+        //  change and factoring again: a factorisation per coordinate.)
+        bool f0 = on0 && x0 != 0.0, f1 = on1 && x1 != 0.0;
+        double sg0 = f0 ? copysign(1.0, x0) : 0.0, sg1 = f1 ? copysign(1.0, x1) : 0.0;
+        // objective at v, with q = G v - c
+        auto objective = [&](double v0, double v1, double& g0, double& g1) {
+          matvec(v0, v1, g0, g1);
+          ++it;
+          const double Fv = sm_sum((on0 ? v0 * (0.5 * g0 - c0) + thr0 * fabs(v0) + 0.5 * pd0 * v0 * v0 : 0.0) +
+                                   (on1 ? v1 * (0.5 * g1 - c1) + thr1 * fabs(v1) + 0.5 * pd1 * v1 * v1 : 0.0));
+          g0 = on0 ? g0 - c0 : 0.0;
+          g1 = on1 ? g1 - c1 : 0.0;
+          return Fv;
+        };
+        double qx0, qx1;
+        double F_cur = objective(x0, x1, qx0, qx1);
+        bool any_move = false;
+        for (int round = 0; round < SM_FACE_ROUNDS; ++round) {
+          const uint64_t m0 = __ballot(f0), m1 = __ballot(f1);
+          const int n0 = __popcll(m0), m = n0 + __popcll(m1);
+          if (m == 0 || m > face_cap) break;
+          const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+          const int rk0 = __popcll(m0 & below), rk1 = n0 + __popcll(m1 & below);
+          if (f0) { fidx[rk0] = s0; fadd[rk0] = pd0; vu[rk0] = c0 - thr0 * sg0; }
+          if (f1) { fidx[rk1] = s1; fadd[rk1] = pd1; vu[rk1] = c1 - thr1 * sg1; }
+          if (lane == 0) { sm_m = m; sm_cmd = 2; }
+          __syncthreads();
+          sm_face_factor(Gs, p, fidx, fadd, m, Ff, fdia, invd, false);
+          ++face_solves;
+          // rank space: lane l holds unknowns l and l + 64 of the face
+          const int i0 = lane, i1 = lane + 64;
+          const bool h0 = i0 < m, h1 = i1 < m;
+          double w0 = h0 ? vu[i0] : 0.0, w1 = h1 ? vu[i1] : 0.0;
+          const double il0 = h0 ? invd[i0] : 0.0, il1 = h1 ? invd[i1] : 0.0;
+          sm_face_solve(Ff, invd, m, lane, w0, w1);
+          // (a dropped pivot left its unknown without an equation: it stays where it is)
+          __builtin_amdgcn_wave_barrier();
+          if (h0) vu[i0] = il0 != 0.0 ? w0 : 1e300;
+          if (h1) vu[i1] = il1 != 0.0 ? w1 : 1e300;
+          sm_lds_sync();
+          double t0 = f0 ? vu[rk0] : 0.0, t1 = f1 ? vu[rk1] : 0.0;
+          if (t0 == 1e300) t0 = x0;
+          if (t1 == 1e300) t1 = x1;
+          __builtin_amdgcn_wave_barrier();
+          if (!(sm_sum(t0 * t0 + t1 * t1) < 1e300)) break;  // (the factor went wrong: the proximal steps carry on)
+          bool moved = false, clipped = false;
+          double alpha = 1.0;
+          for (int tr = 0; tr < 6 && !moved; ++tr, alpha *= 0.5) {
+            double v0 = f0 ? __builtin_fma(alpha, t0 - x0, x0) : x0, v1 = f1 ? __builtin_fma(alpha, t1 - x1, x1) : x1;
+            const bool k0 = f0 && v0 * sg0 <= 0.0, k1 = f1 && v1 * sg1 <= 0.0;
+            if (k0) v0 = 0.0;
+            if (k1) v1 = 0.0;
+            double g0, g1;
+            const double Fv = objective(v0, v1, g0, g1);
+            if (Fv <= F_cur) {
+              x0 = v0; x1 = v1;
+              qx0 = g0; qx1 = g1;
+              F_cur = Fv;
+              moved = true;
+              clipped = __ballot(k0 || k1) != 0ull || tr > 0;
+            }
+          }
+          if (!moved) break;
+          any_move = true;
+          // the next face: what is non-zero, and the coordinates at zero whose bound the gradient violates
+          const double slack = 1e-9;
+          const bool a0 = on0 && x0 == 0.0 && fabs(qx0) > thr0 * (1.0 + slack) + 1e-14 * Lp * bnorm;
+          const bool a1 = on1 && x1 == 0.0 && fabs(qx1) > thr1 * (1.0 + slack) + 1e-14 * Lp * bnorm;
+          f0 = on0 && (x0 != 0.0 || a0);
+          f1 = on1 && (x1 != 0.0 || a1);
+          sg0 = x0 != 0.0 ? copysign(1.0, x0) : (a0 ? -copysign(1.0, qx0) : 0.0);
+          sg1 = x1 != 0.0 ? copysign(1.0, x1) : (a1 ? -copysign(1.0, qx1) : 0.0);
+          if (!clipped && __ballot(a0 || a1) == 0ull) break;  // the minimiser, as far as this arithmetic can tell
+        }
+        if (!any_move) cg_runs += 3;  // (no descent along the projected segment: leave the rest to the proximal steps)
+        z0 = x0; z1 = x1;
+        tk = 1.0;
+        have_prev = false;
+        pat_p = pat_n = pat_p1 = pat_n1 = ~0ull;
+        tk_cg += wall_clock64() - tkd;
       }
     }
     iters_all += it;
@@ -842,6 +1144,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
     ctl->nonfinite = bad ? 1 : 0;
     ctl->done = 1;
     // (SLM_TRACE=2: where the kernel's time went, in ms -- the 100 MHz wall clock)
+    ctl->n_hist = face_solves;
     ctl->hist[0] = (double)(tk1 - tk0) * 1e-5;
     ctl->hist[1] = (double)(tk2 - tk1) * 1e-5;
     ctl->hist[2] = (double)tk_it * 1e-5;
