@@ -2543,9 +2543,9 @@ extern "C" int slm_solve_standardized_sgl(slm_dataset* ds, const double* a, cons
   const size_t lds = (size_t)SM_LDS_BYTES;
   const int64_t stage = fixed + 64 < lds ? (int64_t)((lds - fixed - 64) / sizeof(double)) : 0;
   const int ps = 4 * ((p + 4) / 4);
-  if (stage < 3 * (int64_t)p || stage < 4 * (int64_t)ps)
+  if (stage < 3 * (int64_t)p + 512 || stage < 4 * (int64_t)ps)  // (512: the head of the b-step's direct solves)
     return fail(SLM_ERR_UNSUPPORTED, "groups of up to %d columns at p = %d leave no room in LDS", gm, p);
-  const size_t rec_off = 3 * (size_t)ld + 2;  // state: gamma [ld], u [ld], rho, valid; then beta_out [ld]; then the record
+  const size_t rec_off = 3 * (size_t)ld + 4;  // state: gamma [ld], u [ld], rho, valid, direct b-steps, factorisations; then beta_out [ld]; then the record
   const size_t n_state = rec_off + (sizeof(slm_point_info) + 7) / 8 + (size_t)ld;  // (+ group norms [ld])
   const size_t n_host = 3 * (size_t)ld + n_state;
   if (!ds->split_state) {
@@ -2571,7 +2571,7 @@ extern "C" int slm_solve_standardized_sgl(slm_dataset* ds, const double* a, cons
   k.order = ds->order; k.gid = ds->gid; k.gstart = ds->gstart;
   k.a = ds->a0; k.b = ds->b0; k.beta0 = beta0 ? ds->beta : nullptr;
   k.state = ds->split_state;
-  k.beta_out = ds->split_state + 2 * ld + 2;
+  k.beta_out = ds->split_state + 2 * ld + 4;
   k.info = reinterpret_cast<slm_point_info*>(ds->split_state + rec_off);
   k.gn_out = ds->split_state + rec_off + (sizeof(slm_point_info) + 7) / 8;
   k.warm = warm ? 1 : 0;
@@ -2595,7 +2595,11 @@ extern "C" int slm_solve_standardized_sgl(slm_dataset* ds, const double* a, cons
   HIP_TRY(hipStreamSynchronize(s));
   slm_point_info rec;
   memcpy(&rec, h_out + rec_off, sizeof(rec));
-  memcpy(beta_out, h_out + 2 * ld + 2, sizeof(double) * p);
+  memcpy(beta_out, h_out + 2 * ld + 4, sizeof(double) * p);
+  if (const char* trc = getenv("SLM_TRACE"))
+    if (trc[0] == '2')
+      fprintf(stderr, "[slm] standardised sparse-group splitting on chip: %d sweeps, %d products, %d b-steps by a direct solve, %d factorisations, rho %.3e\n",
+              rec.n_iter, rec.rejects, (int)h_out[2 * ld + 2], (int)h_out[2 * ld + 3], rec.L);
   if (group_norms_out) memcpy(group_norms_out, h_out + rec_off + (sizeof(slm_point_info) + 7) / 8, sizeof(double) * G);
   if (info) *info = rec;
   if (rec.status == SLM_ERR_NON_FINITE) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");

@@ -60,6 +60,11 @@ __device__ __forceinline__ double sm_min(double v) {
   for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
   return v;
 }
+__device__ __forceinline__ double sm_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
 __device__ __forceinline__ void sm_lds_sync() {  // one wavefront: LDS writes before the reads that follow
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -231,8 +236,11 @@ __device__ __forceinline__ double sm_recip(double d) {  // 1 / d: the hardware's
 // A pivot at rounding level (a column that depends on the ones before it: p > n, duplicated features) is dropped:
 // invd = 0, its unknown stays where it is.  `worker`: wavefront 0 -- which holds the iteration's state in its registers --
 // only keeps the barriers; the other three do the arithmetic.  Starts and ends with a barrier.
+// `fgrp` / `bd` (the splitting of small_split_kernels.hpp): entries of G inside a group -- fgrp[position] equal -- count
+// (1 + bd) times: the matrix is G + bd blockdiag(G_gg).
 __device__ __forceinline__ void sm_face_factor(const double* Gs, int p, const int* fidx, const double* fadd, int m, double* F,
-                                               double* fdia, double* invd, bool worker) {
+                                               double* fdia, double* invd, bool worker, const int* fgrp = nullptr,
+                                               double bd = 0.0) {
   constexpr int NB = SM_PMAX / 16;          // column batches of a thread in the update
   constexpr int TW = SM_THREADS - 64;       // working threads
   const int t = (int)threadIdx.x - 64;      // 0 .. TW-1 for the workers
@@ -241,7 +249,10 @@ __device__ __forceinline__ void sm_face_factor(const double* Gs, int p, const in
     for (int i = ty; i < m; i += TW / 16) {
       const int si = fidx[i], base = i * (i + 1) / 2;
       for (int j = tx; j <= i; j += 16) {
-        const double v = Gs[si * p + fidx[j]] + (i == j ? fadd[i] : 0.0);
+        const int sj = fidx[j];
+        double v = Gs[si * p + sj];
+        if (fgrp != nullptr && fgrp[si] == fgrp[sj]) v = __builtin_fma(bd, v, v);
+        if (i == j) v += fadd[i];
         F[base + j] = v;
         if (i == j) fdia[i] = v;
       }

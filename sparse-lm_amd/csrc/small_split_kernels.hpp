@@ -36,7 +36,7 @@ struct SplitSglArgs {
   double* beta_out;    // [p]
   double* gn_out;      // [G] ||X_g b_g||_2 (nullptr: not wanted)
   slm_point_info* info;  // [1]: n_iter = sweeps, rejects = matrix-vector products, resid = max(primal, dual residual)
-  double* state;       // [2 ld + 2]: gamma, u (group-sorted order), rho, valid -- kept with the dataset between calls
+  double* state;       // [2 ld + 4]: gamma, u (group-sorted order), rho, valid, direct b-steps, factorisations -- kept with the dataset
   int warm;            // continue from `state` (the re-weighting loop of the adaptive estimator)
   double tol, tol_inner, inv_n;
   int max_sweeps, max_iters, gmax, stage_doubles;
@@ -55,10 +55,18 @@ __global__ __launch_bounds__(SM_THREADS) void small_stdsgl_kernel(SplitSglArgs a
   double* vu = vz + p;
   double* Ll = vu + p;          // row r of a group's Cholesky factor L (L L^T = n G_gg) at position gs + r: [p][gm]
   double* stage = Ll + p * gm;  // the stage of the build; afterwards the partial products of wavefronts 1..3
-  __shared__ double yy_s;
-  __shared__ int sm_cmd;
+  __shared__ double yy_s, sm_bd;
+  __shared__ int sm_cmd, sm_m;
   const bool built = sm_build_gram(a.X, a.y, a.rw, a.n, a.ld, p, a.order, a.inv_n, a.stage_doubles, Gs, cs, stage, &yy_s);
   double* pp = stage;
+  // direct solves of the b-step on its face (sm_face_factor): group of every position, then the face's head and factor
+  int* gpos = reinterpret_cast<int*>(pp + 3 * p);
+  int* fidx = gpos + SM_PMAX;
+  double* fadd = pp + 3 * p + SM_PMAX;
+  double* fdia = fadd + SM_PMAX;
+  double* invd = fdia + SM_PMAX;
+  double* Ff = invd + SM_PMAX;
+  const int face_cap = sm_face_cap(a.stage_doubles - 3 * p - 64);
   const int mchunk = (((p + 3) >> 2) + 7) & ~7;
   if (wave != 0) {
     const int s0w = lane, s1w = lane + 64;
@@ -66,7 +74,12 @@ __global__ __launch_bounds__(SM_THREADS) void small_stdsgl_kernel(SplitSglArgs a
     const int m_lo = wave * mchunk < p ? wave * mchunk : p, m_hi = (wave + 1) * mchunk < p ? (wave + 1) * mchunk : p;
     for (;;) {
       __syncthreads();
-      if (sm_cmd == 0) break;
+      const int cmd = sm_cmd;
+      if (cmd == 0) break;
+      if (cmd == 2) {
+        sm_face_factor(Gs, p, fidx, fadd, sm_m, Ff, fdia, invd, true, gpos, sm_bd);
+        continue;
+      }
       double y0, y1;
       sm_partial(Gs, vz, p, m_lo, m_hi, on0w ? s0w : 0, on1w ? s1w : 0, p > 64, y0, y1);
       if (on0w) pp[(wave - 1) * p + s0w] = y0;
@@ -404,6 +417,76 @@ __global__ __launch_bounds__(SM_THREADS) void small_stdsgl_kernel(SplitSglArgs a
     return conv;
   };
 
+  // ---- the b-step by ONE direct solve where the face of the sweep before still holds ---------------------------------
+  // Between sweeps only the linear term moves; once the splitting has found the support, the b-step's minimiser keeps its
+  // face and its signs, and (G~_AA) t_A = c~_A - thr_A s_A gives it exactly: L D L^T of the face (sm_face_factor, kept as
+  // long as face and rho stand), two triangular solves, one product for the optimality conditions -- the gradient on the
+  // face below what the iteration's stopping rule asks (with the smallest pivot for the curvature), |q_j| <= thr_j off it,
+  // every sign kept.  Anything else leaves the sweep to the iteration above.
+  if (on0) gpos[s0] = g0;
+  if (on1) gpos[s1] = g1;
+  uint64_t fm0 = 0ull, fm1 = 0ull;  // the face the factor in LDS belongs to
+  double f_rho = -1.0;
+  int direct_hits = 0, face_factors = 0;
+  auto direct_b = [&](double ce0, double ce1) {
+    const bool f0 = on0 && x0 != 0.0, f1 = on1 && x1 != 0.0;
+    const uint64_t m0 = __ballot(f0), m1 = __ballot(f1);
+    const int n0 = __popcll(m0), m = n0 + __popcll(m1);
+    if (m == 0 || m > face_cap) return false;
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int rk0 = __popcll(m0 & below), rk1 = n0 + __popcll(m1 & below);
+    if (!(m0 == fm0 && m1 == fm1 && f_rho == rho_n)) {
+      if (f0) { fidx[rk0] = s0; fadd[rk0] = 0.0; }
+      if (f1) { fidx[rk1] = s1; fadd[rk1] = 0.0; }
+      if (lane == 0) { sm_m = m; sm_bd = rho_n; sm_cmd = 2; }
+      __syncthreads();
+      sm_face_factor(Gs, p, fidx, fadd, m, Ff, fdia, invd, false, gpos, rho_n);
+      fm0 = m0; fm1 = m1; f_rho = rho_n;
+      ++face_factors;
+    }
+    const int i0 = lane, i1 = lane + 64;
+    const bool h0 = i0 < m, h1 = i1 < m;
+    const double il0 = h0 ? invd[i0] : 1.0, il1 = h1 ? invd[i1] : 1.0;
+    if (__ballot((h0 && il0 == 0.0) || (h1 && il1 == 0.0)) != 0ull) return false;  // (a dropped pivot: a singular face)
+    const double mu_est = 1.0 / sm_max(fmax(h0 ? il0 : 0.0, h1 ? il1 : 0.0));      // the smallest pivot
+    double t0 = 0.0, t1 = 0.0, q0 = 0.0, q1 = 0.0;
+    double r0 = f0 ? ce0 - copysign(thr0, x0) : 0.0, r1 = f1 ? ce1 - copysign(thr1, x1) : 0.0;  // right-hand side, then residual
+    bool ok = false;
+    for (int pass = 0; pass < 2 && !ok; ++pass) {  // (the second pass: one step of iterative refinement)
+      __builtin_amdgcn_wave_barrier();
+      if (f0) vu[rk0] = r0;
+      if (f1) vu[rk1] = r1;
+      sm_lds_sync();
+      double w0 = h0 ? vu[i0] : 0.0, w1 = h1 ? vu[i1] : 0.0;
+      sm_face_solve(Ff, invd, m, lane, w0, w1);
+      __builtin_amdgcn_wave_barrier();
+      if (h0) vu[i0] = w0;
+      if (h1) vu[i1] = w1;
+      sm_lds_sync();
+      t0 += f0 ? vu[rk0] : 0.0;
+      t1 += f1 ? vu[rk1] : 0.0;
+      if (__ballot((f0 && !(t0 * x0 > 0.0)) || (f1 && !(t1 * x1 > 0.0))) != 0ull) return false;  // a sign would change (or NaN)
+      matvec(t0, t1, q0, q1);
+      ++products;
+      q0 = on0 ? q0 - ce0 : 0.0;
+      q1 = on1 ? q1 - ce1 : 0.0;
+      r0 = f0 ? -(q0 + copysign(thr0, x0)) : 0.0;
+      r1 = f1 ? -(q1 + copysign(thr1, x1)) : 0.0;
+      const double rn = sqrt(sm_sum(r0 * r0 + r1 * r1)), tn = sqrt(sm_sum(t0 * t0 + t1 * t1));
+      const double gn = sqrt(sm_sum(q0 * q0 + q1 * q1));
+      const double Lt = L * (1.0 + rho_n);
+      const double allow = fmax(0.1 * a.tol_inner * tn * fmax(mu_est, kMuFloor * Lt), kRoundFloor * (gn + Lt * tn));
+      const bool off0 = on0 && !f0 && fabs(q0) > thr0 + allow, off1 = on1 && !f1 && fabs(q1) > thr1 + allow;
+      if (__ballot(off0 || off1) != 0ull) return false;  // a coordinate off the face wants in
+      ok = rn <= allow;
+    }
+    if (!ok) return false;
+    x0 = t0;
+    x1 = t1;
+    ++direct_hits;
+    return true;
+  };
+
   // ---- the sweeps --------------------------------------------------------------------------------------------------
   int sweeps = 0;
   bool converged = false;
@@ -412,7 +495,8 @@ __global__ __launch_bounds__(SM_THREADS) void small_stdsgl_kernel(SplitSglArgs a
     rho_n = rho * nrows;
     double t0, t1;
     mul_L(gam0 - u0, gam1 - u1, t0, t1);
-    (void)inner(__builtin_fma(rho, t0, c0), __builtin_fma(rho, t1, c1), L * (1.0 + rho_n));  // (short of its tolerance: absorbed by the sweeps)
+    const double ce0 = __builtin_fma(rho, t0, c0), ce1 = __builtin_fma(rho, t1, c1);
+    if (!direct_b(ce0, ce1)) (void)inner(ce0, ce1, L * (1.0 + rho_n));  // (short of its tolerance: absorbed by the sweeps)
     if (bad) break;
     double v0, v1;
     mul_Lt(x0, x1, v0, v1);
@@ -480,6 +564,8 @@ __global__ __launch_bounds__(SM_THREADS) void small_stdsgl_kernel(SplitSglArgs a
     if (lane == 0) {
       a.state[2 * a.ld] = rho;
       a.state[2 * a.ld + 1] = bad ? 0.0 : 1.0;
+      a.state[2 * a.ld + 2] = (double)direct_hits;
+      a.state[2 * a.ld + 3] = (double)face_factors;
     }
   }
   const double loss = 0.5 * sm_sum((on0 ? x0 * (q0 - c0) : 0.0) + (on1 ? x1 * (q1 - c1) : 0.0)) + 0.5 * yy_s;
