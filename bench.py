@@ -266,7 +266,7 @@ class Config4:
 
     K = 50
 
-    def __init__(self, eng, n, p):
+    def __init__(self, eng, n, p, noise_sd=10.0):
         from sparselm_amd import _engine
 
         self.G = G = p // 10
@@ -275,7 +275,7 @@ class Config4:
         coef = np.zeros(p)
         for g in rng.choice(G, 25, replace=False):
             coef[groups == g] = 100.0 * rng.uniform(size=10)
-        self.ds = ds = eng.synthetic_dataset(n, p, seed=11, coef=coef, noise_sd=10.0)
+        self.ds = ds = eng.synthetic_dataset(n, p, seed=11, coef=coef, noise_sd=noise_sd)
         self.copies = [ds]
         ds.set_groups(groups, G)
         g0, _ = ds.gradient(None)
