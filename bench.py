@@ -291,6 +291,17 @@ class Config4:
             al = np.geomspace(amax, 1e-3 * amax, self.K)
             self.unit_pts.append(np.c_[r * al, (1 - r) * al, 0 * al])
         self.lanes = _engine.MAX_LANES
+        self.flags = 0  # solve flags of every call (build_covariance() adds FLAG_COVARIANCE)
+
+    def build_covariance(self):
+        """One Gram per fold on the first engine's dataset (slm_dataset_covariance); seconds spent."""
+        from sparselm_amd import _engine
+
+        t0 = time.perf_counter()
+        for m in self.masks:
+            self.ds.covariance(m, int(m.sum()))
+        self.flags |= _engine.FLAG_COVARIANCE
+        return time.perf_counter() - t0
 
     def calls_of(self, world, rank, **plan_options):
         from sparselm_amd import distributed as D
@@ -305,7 +316,7 @@ class Config4:
             pts, gam = _engine.lane_points([self.unit_pts[u][idx] for u, idx in lane])
             f = self.units[lane[0][0]][0]
             specs.append(dict(points=pts, extrap=gam, row_weight=self.masks[f], n_eff=int(self.masks[f].sum())))
-        out = d.solve_lanes(specs)
+        out = d.solve_lanes(specs, flags=self.flags)
         if not all(o.converged for o in out):
             raise RuntimeError("config 4: a path did not converge")
         if keep is not None:  # (unit, point) -> coefficients, for the checks
@@ -393,7 +404,39 @@ def leg_config4_grid(eng, rank, world, n, p, device_id=0, streams=3, emulate_wor
             c4.run(mine, n_streams)  # warm the copies
             out["seconds_streams"], _ = c4.run(mine, n_streams)
             out["streams"] = n_streams
+        # the rank's share from the Grams of the five folds (SLM_FLAG_COVARIANCE), the Grams' cost beside it
+        try:
+            out["covariance_build_s"] = c4.build_covariance()
+            c4.run(mine)
+            out["seconds_covariance"], out["passes_covariance"] = min(c4.run(mine) for _ in range(2))
+        except NotImplementedError as exc:
+            out["covariance_error"] = repr(exc)[:200]
         return out
+    finally:
+        c4.close()
+
+
+def leg_config4_dense(eng, n, p, noise_sd=100.0):
+    """Config 4's grid with noise 100 instead of 10: every path ends at thousands of non-zeros, the working set gives up
+    on a quarter of the points.  Over X (plain sixteen-lane passes there) and from the folds' Grams; the coefficient
+    vectors of the two runs against each other."""
+    c4 = Config4(eng, n, p, noise_sd=noise_sd)
+    try:
+        calls = c4.calls_of(1, 0)
+        keep_x, keep_c = {}, {}
+        for call in calls:
+            c4.run_call(c4.ds, call, keep_x)
+        seconds, passes = min(c4.run(calls) for _ in range(2))
+        nnz = sorted(int(np.count_nonzero(keep_x[(u, c4.K - 1)])) for u in range(len(c4.units)))
+        above = sum(int(np.count_nonzero(b)) > 512 for b in keep_x.values())
+        build = c4.build_covariance()
+        for call in calls:
+            c4.run_call(c4.ds, call, keep_c)
+        seconds_c, passes_c = min(c4.run(calls) for _ in range(2))
+        worst = max(float(np.max(np.abs(keep_c[k] - keep_x[k])) / max(float(np.max(np.abs(keep_x[k]))), 1e-300)) for k in keep_x)
+        return {"seconds": seconds, "passes": passes, "seconds_covariance": seconds_c, "passes_covariance": passes_c,
+                "covariance_build_s": build, "nnz_last_min_median_max": [nnz[0], nnz[len(nnz) // 2], nnz[-1]],
+                "points_above_512_nonzeros": above, "worst_rel_inf_diff": worst, "noise_sd": noise_sd}
     finally:
         c4.close()
 
@@ -854,6 +897,7 @@ def main():
 
         with Watchdog(args.extra_timeout, expire):
             for name, fn in (("config4_grid", lambda: leg_config4_grid(eng, rank, world, n, p, device_id)),
+                             ("config4_grid_dense_regime", lambda: leg_config4_dense(eng, n, p) if rank == 0 and world == 1 else {}),
                              ("config3_path", lambda: leg_config3(eng, rank, world, n, p, args.tol, args.cpu_budget)),
                              ("soak", lambda: leg_soak(eng, n, p, K, args.tol, args.lanes) if rank == 0 else {}),
                              ("concurrent_paths", lambda: leg_concurrent_paths(eng, device_id, rank, n, p, K, args.tol, args.lanes)),
@@ -884,6 +928,16 @@ def main():
                         "streams": parts[0].get("streams", 1), "calls_per_rank": [q["calls"] for q in parts],
                         "points_per_rank": pts, "passes_per_rank": [q["passes"] for q in parts],
                         "imbalance_max_over_mean": max(secs) / (sum(secs) / len(secs)),
+                        "covariance": ({
+                            "what": "the same share with SLM_FLAG_COVARIANCE: every pass reads the Gram of its fold (200 MB) "
+                            "instead of X; the five Grams are built once per dataset (slm_dataset_covariance: the BLAS "
+                            "library's dgemm, its load into the process included the first time) -- worth it when the search is "
+                            "repeated on the dataset, or its paths end dense (config4_grid_dense_regime)",
+                            "seconds_per_grid": max(q["seconds_covariance"] for q in parts),
+                            "fits_per_s": 2500.0 / max(q["seconds_covariance"] for q in parts),
+                            "build_s": max(q["covariance_build_s"] for q in parts),
+                            "passes_per_rank": [q["passes_covariance"] for q in parts],
+                        } if all("seconds_covariance" in q for q in parts) else {"error": parts[0].get("covariance_error")}),
                     }
                     if "emulated" in parts[0]:
                         em = parts[0]["emulated"]
@@ -900,6 +954,21 @@ def main():
                             "share_row_masks": [q["row_masks"] for q in sh], "full_grid_passes": parts[0]["passes"],
                             "points_imbalance_max_over_mean": max(q["points"] for q in sh) / (sum(q["points"] for q in sh) / len(sh)),
                             "seconds_imbalance_max_over_mean": worst / (sum(q["seconds"] for q in sh) / len(sh)),
+                        }
+                elif name == "config4_grid_dense_regime":
+                    q = parts[0]
+                    if q.get("seconds"):
+                        legs[name] = {
+                            "what": "config 4's grid with noise 100 (every path ends at thousands of non-zeros; the 512-column "
+                            "working set gives up on a quarter of the points and the lanes go on with plain sixteen-lane passes, "
+                            "two reads of X each), over X and from the folds' Grams (SLM_FLAG_COVARIANCE); one GPU, rank 0",
+                            "seconds_per_grid": q["seconds"], "fits_per_s": 2500.0 / q["seconds"], "passes": q["passes"],
+                            "covariance": {"seconds_per_grid": q["seconds_covariance"], "fits_per_s": 2500.0 / q["seconds_covariance"],
+                                           "passes": q["passes_covariance"], "build_s": q["covariance_build_s"],
+                                           "speedup": q["seconds"] / q["seconds_covariance"]},
+                            "nnz_last_min_median_max": q["nnz_last_min_median_max"],
+                            "points_above_512_nonzeros": q["points_above_512_nonzeros"],
+                            "worst_rel_inf_diff_covariance_vs_x": q["worst_rel_inf_diff"],
                         }
                 elif name == "config3_path":
                     legs[name] = {

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 9
+#define SLM_ABI_VERSION 10
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -216,6 +216,12 @@ typedef struct slm_path_point {
                                         a particular iteration (1, 2, 16, 32, 64); a point it does not settle hands the
                                         call to the general path.  Up to SLM_MAX_LANES lanes whatever p.              */
 
+#define SLM_FLAG_COVARIANCE 256u      /* passes take their gradients from the Grams of the call's row sets where
+                                        slm_dataset_covariance() has built every one of them: G z - c, 8 p^2 bytes per row
+                                        set and pass instead of a read of X (cov_kernels.hpp).  Same iteration, same
+                                        results to rounding; ignored where a Gram is missing, on row-sharded datasets and
+                                        for calls the on-chip solver takes                                            */
+
 typedef struct slm_solve_opts {
   double tol;          /* relative distance to the minimiser a point is accepted at: stop when the KKT
                           residual ||G(z)||_2 (prox-gradient mapping) <= tol * mu * ||beta||_2, mu the
@@ -332,6 +338,23 @@ int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, const slm_path
 int slm_solve_standardized_sgl(slm_dataset* ds, const double* a, const double* b, const slm_solve_opts* opts,
                                double tol_inner, int32_t max_sweeps, const double* beta0, int32_t warm,
                                double* beta_out, double* group_norms_out, slm_point_info* info);
+
+/*
+ * The Gram of a row set, for covariance passes (SLM_FLAG_COVARIANCE): G = X^T W X / n_eff, c = X^T W y / n_eff and
+ * y^T W y / n_eff, kept with the dataset (8 ld^2 bytes each) and found again by a fingerprint of the row weights and
+ * n_eff -- what a lane of slm_solve_lanes brings as (row_weight, n_eff).  row_weight: length n on the host, NULL = the
+ * dataset's own; n_eff <= 0 = the dataset's row count (the rule of slm_lane).  A 0/1 mask that leaves out at most half
+ * of the rows costs the Gram of the rows left out (the Gram of all rows is built once per dataset and kept); other
+ * weights cost a scaled copy of X and a full product.  The product is the BLAS library's dgemm (librocblas, loaded on
+ * first use: its own first call in a process takes 1-2 s).  Worth it when many solves share the row set: the ten
+ * l1_ratio rows x fifty alphas of a CV fold, the rounds of an Adaptive* grid.  Replaces nothing in the
+ * reference (cvxpy has no Gram form; scikit-learn's lasso_path(precompute=True) is the same idea on the host).
+ * SLM_ERR_UNSUPPORTED on row-sharded datasets and rows beyond the split pass's 10 240 columns.  New targets
+ * (slm_dataset_set_targets) drop the Grams built so far (they carry X^T W y); centring and new dataset row weights
+ * are expected BEFORE the first call.
+ */
+int slm_dataset_covariance(slm_dataset* ds, const double* row_weight, int64_t n_eff);
+int slm_dataset_covariance_count(slm_dataset* ds, int32_t* count_out);
 
 /* ---- row-sharded mode (very tall X split by rows over ranks) ----------------------------------------
  * Every rank holds a block of rows and runs the whole state machine; per pass the ranks enter TWO all-reduces: the

@@ -1,0 +1,138 @@
+// Covariance passes (SLM_FLAG_COVARIANCE): when many solves share a row set -- the ten l1_ratio rows x fifty alphas of a
+// CV fold, the re-weighting rounds of an Adaptive* grid -- the gradient of a pass, X^T W (X z - y) / n, is G z - c with
+// G = X^T W X / n and c = X^T W y / n kept per row set: 8 p^2 bytes (200 MB at p = 5 000) instead of the 4 GB of X per
+// pass for sixteen lanes.  The product G Z IS the second half of the split pass with G in the place of X and the lanes'
+// points in the place of the residuals (xtr_mfma_kernel on (G, Z[p][16])); what is here is the little around it:
+// packing Z, the finish g = G z - c with the loss 1/2 z^T G z - c^T z + 1/2 y^T W y / n, and the pieces of building G
+// (the product itself is the BLAS library's dgemm: a plain GEMM, loaded on first use).
+// The reference has no counterpart (cvxpy canonicalises X^T X-free conic forms, model/_base.py:414-467); scikit-learn's
+// `precompute=True` of lasso_path is the same idea on the host.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "split_kernels.hpp"
+
+namespace slm {
+
+// Z[j][l] = z_l[j] (lane-minor, the B operand of xtr_mfma_kernel); lane slots beyond n_lanes are zero
+__global__ __launch_bounds__(256) void cov_pack_kernel(const double* z, int64_t ld, int n_lanes, double* Z, const int* done) {
+  if (done != nullptr && *done != 0) return;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over ld * 16
+  if (e >= ld * SPLIT_RSTRIDE) return;
+  const int64_t j = e >> 4;
+  const int l = (int)(e & 15);
+  Z[e] = l < n_lanes ? z[(int64_t)l * ld + j] : 0.0;
+}
+
+struct CovFinishArgs {
+  const double* partial;  // [nblk][16][ld] of xtr_mfma_kernel
+  const double* c;        // [ld]
+  const double* z;        // [lanes][ld]
+  double* g;              // [lanes][ld + 16]
+  const int* done;
+  int nblk;
+  int64_t ld;
+  uint32_t lane_mask;     // lanes of THIS row set
+  double yy;              // y^T W y / n of the row set
+};
+
+// grid = (ld / 16, lanes): g_l[col] = sum_blk partial[blk][l][col] - c[col]   (fixed order: bit-identical run to run)
+__global__ __launch_bounds__(256) void cov_reduce_kernel(CovFinishArgs a) {
+  if (a.done != nullptr && *a.done != 0) return;
+  const int lane = blockIdx.y;
+  if (!((a.lane_mask >> lane) & 1u)) return;
+  __shared__ double lds[16][17];
+  const int tid = threadIdx.x, cl = tid & 15, slice = tid >> 4;
+  const int64_t col = (int64_t)blockIdx.x * 16 + cl;
+  double s = 0.0;
+  for (int b = slice; b < a.nblk; b += 16) s += a.partial[((int64_t)b * SPLIT_LANES + lane) * a.ld + col];
+  lds[slice][cl] = s;
+  __syncthreads();
+  if (slice == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += lds[k][cl];
+    a.g[(int64_t)lane * (a.ld + 16) + col] = t - a.c[col];
+  }
+}
+
+// grid = lanes, 256 threads: loss_l = 1/2 sum_j z_j (g_j - c_j) + 1/2 yy  (g = G z - c already), into g_l[ld]
+__global__ __launch_bounds__(256) void cov_loss_kernel(CovFinishArgs a) {
+  if (a.done != nullptr && *a.done != 0) return;
+  const int lane = blockIdx.x;
+  if (!((a.lane_mask >> lane) & 1u)) return;
+  __shared__ double red[256];
+  const double* z = a.z + (int64_t)lane * a.ld;
+  double* g = a.g + (int64_t)lane * (a.ld + 16);
+  double s = 0.0;
+  for (int64_t j = threadIdx.x; j < a.ld; j += 256) s = __builtin_fma(z[j], g[j] - a.c[j], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) g[a.ld] = 0.5 * red[0] + 0.5 * a.yy;
+}
+
+// ---- building a Gram ------------------------------------------------------------------------------------------------
+// fingerprint of a row-weight vector: two weighted sums with fixed pseudo-random multipliers, one workgroup, fixed order
+__global__ __launch_bounds__(1024) void cov_fingerprint_kernel(const double* w, int64_t n, double* out) {
+  __shared__ double r1[1024], r2[1024];
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const uint64_t h = (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull;
+    const double m1 = (double)((h >> 40) & 0xffffffull) * (1.0 / 16777216.0) + 0.5;
+    const double m2 = (double)((h >> 12) & 0xffffffull) * (1.0 / 16777216.0) + 0.5;
+    const double wi = w ? w[i] : 1.0;
+    s1 = __builtin_fma(wi, m1, s1);
+    s2 = __builtin_fma(wi, m2, s2);
+  }
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int k = 512; k >= 1; k >>= 1) {
+    if ((int)threadIdx.x < k) {
+      r1[threadIdx.x] += r1[threadIdx.x + k];
+      r2[threadIdx.x] += r2[threadIdx.x + k];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = r1[0];
+    out[1] = r2[0];
+  }
+}
+
+// T[r][:] = s_r * X[rows[r]][:]  (rows == nullptr: row r itself; scale == nullptr: 1)
+__global__ __launch_bounds__(256) void cov_rows_kernel(const double* X, int64_t ld, const int64_t* rows, const double* scale,
+                                                       int64_t n_rows, double* T) {
+  const int64_t r = blockIdx.x;
+  if (r >= n_rows) return;
+  const int64_t src = rows ? rows[r] : r;
+  const double s = scale ? sqrt(scale[src]) : 1.0;
+  const double2* in = reinterpret_cast<const double2*>(X + src * ld);
+  double2* out = reinterpret_cast<double2*>(T + r * ld);
+  for (int64_t j = threadIdx.x; j < ld / 2; j += 256) {
+    double2 v = in[j];
+    v.x *= s;
+    v.y *= s;
+    out[j] = v;
+  }
+}
+
+// G = (A - B) * s  (B == nullptr: G = A * s), element-wise over count doubles
+__global__ __launch_bounds__(256) void cov_combine_kernel(const double* A, const double* B, double s, int64_t count, double* G) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    G[i] = (A[i] - (B ? B[i] : 0.0)) * s;
+}
+
+// c = -g, yy = 2 loss from a standard pass at z = 0 (g = -X^T W y / n, loss = y^T W y / (2 n))
+__global__ __launch_bounds__(256) void cov_linear_kernel(const double* g, int64_t ld, double* c, double* yy_out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < ld) c[j] = -g[j];
+  if (j == 0) yy_out[0] = 2.0 * g[ld];
+}
+
+}  // namespace slm

@@ -29,6 +29,7 @@
 #include "split_kernels.hpp"
 #include "small_kernels.hpp"
 #include "small_split_kernels.hpp"
+#include "cov_kernels.hpp"
 
 using namespace slm;
 
@@ -99,6 +100,43 @@ static int load_rccl() {
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
     return fail(SLM_ERR_COMM, "librccl is missing required symbols");
   g_rccl.lib = lib;
+  return SLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The BLAS library's dgemm, loaded lazily: the one plain GEMM of the engine (X^T W X of a covariance pass's Gram)
+// ------------------------------------------------------------------------------------------------
+typedef void* rocblasHandle_t;
+struct RocblasApi {
+  void* lib = nullptr;
+  int (*Create)(rocblasHandle_t*) = nullptr;
+  int (*Destroy)(rocblasHandle_t) = nullptr;
+  int (*SetStream)(rocblasHandle_t, hipStream_t) = nullptr;
+  int (*Dgemm)(rocblasHandle_t, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*,
+               double*, int) = nullptr;
+};
+static RocblasApi g_blas;
+static const int kRocblasOpNone = 111, kRocblasOpTranspose = 112;
+
+static int fail(int code, const char* fmt, ...);
+static int load_rocblas() {
+  if (g_blas.lib) return SLM_OK;
+  const char* names[] = {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"};
+  void* lib = nullptr;
+  for (const char* nm : names) {
+    // (RTLD_LOCAL: a process that also holds another copy of the library -- PyTorch ships its own -- must not see this
+    //  one's symbols in place of its own)
+    lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(SLM_ERR_UNSUPPORTED, "cannot load librocblas (covariance passes need its dgemm): %s", dlerror());
+  g_blas.Create = (decltype(g_blas.Create))dlsym(lib, "rocblas_create_handle");
+  g_blas.Destroy = (decltype(g_blas.Destroy))dlsym(lib, "rocblas_destroy_handle");
+  g_blas.SetStream = (decltype(g_blas.SetStream))dlsym(lib, "rocblas_set_stream");
+  g_blas.Dgemm = (decltype(g_blas.Dgemm))dlsym(lib, "rocblas_dgemm");
+  if (!g_blas.Create || !g_blas.Destroy || !g_blas.SetStream || !g_blas.Dgemm)
+    return fail(SLM_ERR_UNSUPPORTED, "librocblas is missing required symbols");
+  g_blas.lib = lib;
   return SLM_OK;
 }
 
@@ -275,6 +313,7 @@ struct slm_engine {
   LocalComm* local = nullptr;
   int rank = 0, n_ranks = 1;
   long collectives = 0;  // all-reduces this engine has entered (diagnostics, slm_comm_info)
+  rocblasHandle_t blas = nullptr;  // covariance passes: created on first use
   bool sharded() const { return comm != nullptr || local != nullptr; }
 };
 
@@ -393,6 +432,15 @@ struct slm_dataset {
   double* h_vec = nullptr;
   slm_path_point* h_pts = nullptr;
   int64_t h_pts_cap = 0;
+  // covariance passes (cov_kernels.hpp): a Gram per row set, found again by the fingerprint of its row weights
+  struct CovEntry {
+    double *G = nullptr, *c = nullptr;
+    double yy = 0.0, n_eff = 0.0, fp1 = 0.0, fp2 = 0.0;
+  };
+  std::vector<CovEntry> cov;
+  double* cov_all = nullptr;  // X^T X of all rows, unscaled (the minuend of fold Grams), built on first use
+  double* cov_Z = nullptr;    // [ld][16] the lanes' points, lane-minor
+  double* cov_fp = nullptr;   // [2 * kMaxLanes + 2] fingerprints / scalars on their way to the host
   double* split_state = nullptr;  // [3 ld + 2 + record] slm_solve_standardized_sgl: gamma, u, rho, valid; outputs
   double* h_split = nullptr;      // its page-locked staging: a, b, warm start in; coefficients, group norms, record out
   double* stop_words = nullptr;  // [STOP_WORDS] row-sharded mode: the vector the ranks all-reduce after every pass
@@ -588,6 +636,8 @@ extern "C" int slm_engine_destroy(slm_engine* eng) {
   if (!eng) return SLM_OK;
   (void)hipSetDevice(eng->device);
   if (eng->sharded()) (void)slm_comm_destroy(eng);
+  // (the BLAS handle is left to the process: engines are destroyed at interpreter exit, when the library's own state may
+  //  already be gone)
   if (eng->stream) (void)hipStreamDestroy(eng->stream);
   {  // (the recycled blocks do not outlive the engines that could use them)
     std::lock_guard<std::mutex> lk(g_pool.m);
@@ -648,6 +698,8 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
   dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
   dfree(ds->ws_nt); dfree(ds->stop_words); dfree(ds->sse_Z); dfree(ds->sse_part); dfree(ds->split_state);
+  for (auto& e : ds->cov) { dfree(e.G); dfree(e.c); }
+  dfree(ds->cov_all); dfree(ds->cov_Z); dfree(ds->cov_fp);
   if (ds->h_split) (void)hipHostFree(ds->h_split);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   if (ds->h_vec) (void)hipHostFree(ds->h_vec);
@@ -965,6 +1017,9 @@ extern "C" int slm_dataset_set_targets(slm_dataset* ds, const double* y) {
   HIP_TRY(hipSetDevice(ds->eng->device));
   HIP_TRY(hipStreamSynchronize(ds->eng->stream));
   HIP_TRY(hipMemcpy(ds->y, y, sizeof(double) * ds->n, hipMemcpyHostToDevice));
+  // (the Grams of covariance passes carry X^T W y: gone with the old targets; the Gram of all rows depends on X alone)
+  for (auto& e : ds->cov) { dfree(e.G); dfree(e.c); }
+  ds->cov.clear();
   return SLM_OK;
 }
 
@@ -1179,6 +1234,56 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
   if (ds->eng->sharded())  // row-sharded: sum the gradients (and losses) of the row blocks over ranks
     SLM_TRY(all_reduce_sum(ds->eng, ds->g, (size_t)ls.B * (size_t)(ds->ld + 16)));
   return SLM_OK;
+}
+
+// The gradient of one pass from the Grams of the lanes' row sets (cov_kernels.hpp): g_l = G_s z_l - c_s, loss in g_l[ld].
+// `entry_of[l]`: the lane's entry of ds->cov.  One read of a 8 ld^2-byte Gram per row set of the call instead of X.
+static int enqueue_gradient_cov(slm_dataset* ds, int B, const int* entry_of, const int* done, hipEvent_t ev_start,
+                                hipEvent_t ev_stop) {
+  hipStream_t s = ds->eng->stream;
+  const int64_t ld = ds->ld;
+  hipLaunchKernelGGL(cov_pack_kernel, dim3((unsigned)((ld * SPLIT_RSTRIDE + 255) / 256)), dim3(256), 0, s, ds->z, ld, B, ds->cov_Z, done);
+  if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
+  bool seen[SLM_MAX_LANES] = {};
+  for (int l = 0; l < B; ++l) {
+    if (seen[l]) continue;
+    uint32_t mask = 0;
+    for (int m = l; m < B; ++m)
+      if (entry_of[m] == entry_of[l]) {
+        mask |= 1u << m;
+        seen[m] = true;
+      }
+    const slm_dataset::CovEntry& e = ds->cov[(size_t)entry_of[l]];
+    SplitArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = e.G; a.R = ds->cov_Z; a.partial = ds->partial; a.done = done;
+    a.n = ld; a.ld = ld; a.p2 = (int)(ld / 2); a.n_lanes = B;
+    const int xblk = launch_xtr(ds->eng->cus, a, s);
+    CovFinishArgs f;
+    f.partial = ds->partial; f.c = e.c; f.z = ds->z; f.g = ds->g; f.done = done; f.nblk = xblk; f.ld = ld;
+    f.lane_mask = mask; f.yy = e.yy;
+    hipLaunchKernelGGL(cov_reduce_kernel, dim3((unsigned)(ld / 16), (unsigned)B), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(cov_loss_kernel, dim3((unsigned)B), dim3(256), 0, s, f);
+  }
+  if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
+  return SLM_OK;
+}
+
+// fingerprints of row-weight vectors already on the device -> host (one small copy, one wait)
+static int cov_fingerprints(slm_dataset* ds, const double* const* w, int count, double* out /* [2 * count] */) {
+  hipStream_t s = ds->eng->stream;
+  if (!ds->cov_fp) SLM_TRY(dalloc(&ds->cov_fp, 2 * (size_t)kMaxLanes + 2));
+  for (int u = 0; u < count; ++u)
+    hipLaunchKernelGGL(cov_fingerprint_kernel, dim3(1), dim3(1024), 0, s, w[u], ds->n, ds->cov_fp + 2 * u);
+  HIP_TRY(hipMemcpyAsync(out, ds->cov_fp, sizeof(double) * 2 * (size_t)count, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return SLM_OK;
+}
+
+static int cov_find(const slm_dataset* ds, double fp1, double fp2, double n_eff) {
+  for (size_t i = 0; i < ds->cov.size(); ++i)
+    if (ds->cov[i].fp1 == fp1 && ds->cov[i].fp2 == fp2 && ds->cov[i].n_eff == n_eff) return (int)i;
+  return -1;
 }
 
 // E = features per thread of the one-workgroup-per-lane tail kernel (p <= 1024 * E).  Up to E = 8
@@ -1620,7 +1725,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   //  the fused kernel serves: measured on config 5's shape, one lane, 2.9 ms per pass against 2.4 ms fused)
   const bool wide = ds->sk != nullptr && ds->sk->rowdot == nullptr;
   const bool want_split = (ws_policy(ds, opts ? opts->flags : 0u) == 2 && !wide) ? (big_x || !ds->gk[B - 1]) : (big_x && !ds->gk[B - 1]);
-  const bool split = want_split && split_usable(ds);
+  // (covariance passes are a form of the split pass: the flag asks for it whatever the size, where Grams exist)
+  const bool want_cov = opts && (opts->flags & SLM_FLAG_COVARIANCE) && !ds->cov.empty() && !ds->eng->sharded();
+  const bool split = (want_split || want_cov) && split_usable(ds);
   // Shared path with the working set on from the start: the lanes take the points of the path in turn
   // (lane l: l, l + B, ...) instead of contiguous ranges.  Every lane then starts near alpha_max, where
   // the first working set (chosen from the gradient at zero) is enough, and all lanes move down the
@@ -1718,6 +1825,38 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
 
   const bool small = small_ok(ds, o.flags);
+  // ---- covariance passes: every row set of the call has its Gram (slm_dataset_covariance) --------------------------
+  int cov_entry[SLM_MAX_LANES] = {};
+  bool cov_on = false;
+  if (want_cov && split && !small) {
+    const double* wdev[SLM_MAX_LANES];
+    int uniq_of[SLM_MAX_LANES], first_lane[SLM_MAX_LANES], nu = 0;
+    for (int l = 0; l < B; ++l) {
+      int u = -1;
+      for (int m = 0; m < l && u < 0; ++m)
+        if (lanes[m].row_weight == lanes[l].row_weight && lanes[m].n_eff == lanes[l].n_eff) u = uniq_of[m];
+      if (u < 0) {
+        u = nu++;
+        first_lane[u] = l;
+        wdev[u] = ls.rw ? ls.rw + (int64_t)l * ls.rw_stride : nullptr;
+      }
+      uniq_of[l] = u;
+    }
+    double fp[2 * SLM_MAX_LANES];
+    SLM_TRY(cov_fingerprints(ds, wdev, nu, fp));
+    cov_on = true;
+    int entry_of_set[SLM_MAX_LANES];
+    for (int u = 0; u < nu && cov_on; ++u) {
+      const int l = first_lane[u];
+      const double ne = ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global;
+      entry_of_set[u] = cov_find(ds, fp[2 * u], fp[2 * u + 1], ne);
+      cov_on = entry_of_set[u] >= 0;
+    }
+    if (cov_on) {
+      for (int l = 0; l < B; ++l) cov_entry[l] = entry_of_set[uniq_of[l]];
+      if (!ds->cov_Z) SLM_TRY(dalloc(&ds->cov_Z, (size_t)ld * SPLIT_RSTRIDE));
+    }
+  }
   // ---- Lipschitz constants -----------------------------------------------------------------------
   double L[SLM_MAX_LANES];
   double lipschitz_ms = 0.0;
@@ -2184,6 +2323,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // the gradient of one pass: split pass (sixteen lane slots, residuals from the gathered columns where
   // possible) when the working set runs from the start, the fused kernel otherwise
   auto enqueue_pass_gradient = [&](hipEvent_t e0, hipEvent_t e1) -> int {
+    if (cov_on) return enqueue_gradient_cov(ds, B, cov_entry, done_flag, e0, e1);
     if (split) return enqueue_gradient_split(ds, ls, ds->y, done_flag, ds->ctl, &wa, e0, e1);
     return enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1);
   };
@@ -2464,6 +2604,131 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (tr[4] > 15.0 || trc[0] == '2')
       fprintf(stderr, "[slm] solve: row weights %.3f L %.3f setup %.3f sync %.3f prequeue %.3f loop %.3f end %.3f ms\n", tr_rw, tr[5], tr[0], tr[1], tr[2], tr[3], tr[4]);
   if (nonfinite) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
+  return SLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// covariance passes: the Gram of a row set
+// ------------------------------------------------------------------------------------------------
+extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight, int64_t n_eff_in) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  slm_engine* eng = ds->eng;
+  HIP_TRY(hipSetDevice(eng->device));
+  hipStream_t s = eng->stream;
+  if (eng->sharded()) return fail(SLM_ERR_UNSUPPORTED, "covariance passes are not built for row-sharded datasets");
+  if (!split_usable(ds)) return fail(SLM_ERR_UNSUPPORTED, "covariance passes ride on the split pass (rows of up to 10 240 columns)");
+  const int64_t n = ds->n, ld = ds->ld;
+  const double n_eff = n_eff_in > 0 ? (double)n_eff_in : (double)ds->n_global;
+  double* wown = nullptr;
+  struct Temps {
+    double *a = nullptr, *b = nullptr;
+    int64_t* rows = nullptr;
+    ~Temps() { dfree(a); dfree(b); dfree(rows); }
+  } tmp;
+  if (row_weight) {
+    SLM_TRY(dalloc(&tmp.a, (size_t)n));
+    wown = tmp.a;
+    HIP_TRY(hipMemcpyAsync(wown, row_weight, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  }
+  const double* wdev = row_weight ? wown : ds->rw;
+  double fp[2];
+  SLM_TRY(cov_fingerprints(ds, &wdev, 1, fp));
+  if (cov_find(ds, fp[0], fp[1], n_eff) >= 0) return SLM_OK;
+  SLM_TRY(load_rocblas());
+  if (!eng->blas) {
+    if (g_blas.Create(&eng->blas) != 0) return fail(SLM_ERR_HIP, "rocblas_create_handle failed");
+    if (g_blas.SetStream(eng->blas, s) != 0) return fail(SLM_ERR_HIP, "rocblas_set_stream failed");
+  }
+  // C = A^T A for the row-major rows x ld block A (read as the column-major ld x rows matrix it also is)
+  auto gram = [&](const double* A, int64_t rows, double* C) -> int {
+    const double one = 1.0, zero = 0.0;
+    const int st = g_blas.Dgemm(eng->blas, kRocblasOpNone, kRocblasOpTranspose, (int)ld, (int)ld, (int)rows, &one, A, (int)ld, A,
+                                (int)ld, &zero, C, (int)ld);
+    if (st != 0) return fail(SLM_ERR_HIP, "rocblas_dgemm failed (status %d)", st);
+    return SLM_OK;
+  };
+  auto ensure_all = [&]() -> int {
+    if (ds->cov_all) return SLM_OK;
+    SLM_TRY(dalloc(&ds->cov_all, (size_t)ld * ld));
+    return gram(ds->X, n, ds->cov_all);
+  };
+  // what kind of weights: none, a 0/1 mask (the Gram of all rows minus the Gram of the rows left out: a fifth of the
+  // work for a fold of five), or anything else (rows scaled by sqrt(w) into a copy)
+  std::vector<double> hw;
+  const double* w_host = row_weight;
+  if (!row_weight && ds->rw) {
+    hw.resize((size_t)n);
+    HIP_TRY(hipMemcpy(hw.data(), ds->rw, sizeof(double) * n, hipMemcpyDeviceToHost));
+    w_host = hw.data();
+  }
+  bool binary = true;
+  std::vector<int64_t> zeros;
+  if (w_host)
+    for (int64_t i = 0; i < n; ++i) {
+      if (w_host[i] == 0.0) zeros.push_back(i);
+      else if (w_host[i] != 1.0) binary = false;
+    }
+  slm_dataset::CovEntry e;
+  e.n_eff = n_eff; e.fp1 = fp[0]; e.fp2 = fp[1];
+  SLM_TRY(dalloc(&e.G, (size_t)ld * ld));
+  SLM_TRY(dalloc(&e.c, (size_t)ld));
+  const unsigned cgrid = (unsigned)std::min<int64_t>(4096, (ld * ld + 255) / 256);
+  int rc = SLM_OK;
+  if (!w_host || (binary && (int64_t)zeros.size() * 2 <= n)) {
+    rc = ensure_all();
+    if (rc == SLM_OK && !zeros.empty()) {
+      rc = dalloc(&tmp.rows, zeros.size());
+      if (rc == SLM_OK) rc = dalloc(&tmp.b, zeros.size() * (size_t)ld);
+      if (rc == SLM_OK) {
+        HIP_TRY(hipMemcpyAsync(tmp.rows, zeros.data(), sizeof(int64_t) * zeros.size(), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(cov_rows_kernel, dim3((unsigned)zeros.size()), dim3(256), 0, s, ds->X, ld, tmp.rows, nullptr,
+                           (int64_t)zeros.size(), tmp.b);
+        rc = gram(tmp.b, (int64_t)zeros.size(), e.G);
+      }
+    }
+    if (rc == SLM_OK)
+      hipLaunchKernelGGL(cov_combine_kernel, dim3(cgrid), dim3(256), 0, s, ds->cov_all, zeros.empty() ? nullptr : e.G, 1.0 / n_eff,
+                         ld * ld, e.G);
+  } else {
+    rc = dalloc(&tmp.b, (size_t)n * (size_t)ld);
+    if (rc == SLM_OK) {
+      hipLaunchKernelGGL(cov_rows_kernel, dim3((unsigned)n), dim3(256), 0, s, ds->X, ld, nullptr, wdev, n, tmp.b);
+      rc = gram(tmp.b, n, e.G);
+    }
+    if (rc == SLM_OK) hipLaunchKernelGGL(cov_combine_kernel, dim3(cgrid), dim3(256), 0, s, e.G, nullptr, 1.0 / n_eff, ld * ld, e.G);
+  }
+  // c = X^T W y / n and y^T W y / n: a standard pass at z = 0
+  if (rc == SLM_OK) {
+    LaneSetup ls = default_lanes(ds, 1);
+    ls.rw = wdev;
+    ls.rw_stride = 0;
+    ls.n_eff[0] = n_eff;
+    HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * ld, s));
+    if (ds->gk[0]) rc = enqueue_gradient(ds, ls, ds->y, nullptr, nullptr, nullptr);
+    else rc = enqueue_gradient_split(ds, ls, ds->y, nullptr, nullptr, nullptr, nullptr, nullptr);
+  }
+  if (rc == SLM_OK) {
+    hipLaunchKernelGGL(cov_linear_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ds->g, ld, e.c, ds->cov_fp);
+    rc = check_launch();
+  }
+  if (rc == SLM_OK) {
+    hipError_t he = hipMemcpyAsync(&e.yy, ds->cov_fp, sizeof(double), hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    if (he != hipSuccess) rc = fail(SLM_ERR_HIP, "covariance build: %s", hipGetErrorString(he));
+  }
+  if (rc != SLM_OK) {
+    (void)hipStreamSynchronize(s);
+    dfree(e.G);
+    dfree(e.c);
+    return rc;
+  }
+  ds->cov.push_back(e);
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_covariance_count(slm_dataset* ds, int32_t* count_out) {
+  if (!ds || !count_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  *count_out = (int32_t)ds->cov.size();
   return SLM_OK;
 }
 

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _engine
 
-_KNOWN_OPTIONS = {"tol", "max_iter", "L", "restart", "check_every", "device", "on_chip"}
+_KNOWN_OPTIONS = {"tol", "max_iter", "L", "restart", "check_every", "device", "on_chip", "covariance"}
 
 
 class DatasetCache:

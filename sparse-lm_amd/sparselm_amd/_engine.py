@@ -40,9 +40,10 @@ FLAG_FISTA_ONLY = 16
 FLAG_WORKING_SET = 32  # force the Gram-assisted refinement even for small X
 FLAG_NO_WORKING_SET = 64
 FLAG_ON_CHIP = 128  # problems whose Gram matrix fits a workgroup: one launch per call (csrc/small_kernels.hpp)
+FLAG_COVARIANCE = 256  # passes from the Grams of the call's row sets (Dataset.covariance; csrc/cov_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 9  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 10  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -76,6 +77,8 @@ ABI_SYMBOLS = (
     "slm_solve_lanes",
     "slm_solve_path_lanes",
     "slm_solve_standardized_sgl",
+    "slm_dataset_covariance",
+    "slm_dataset_covariance_count",
     "slm_comm_unique_id",
     "slm_comm_init",
     "slm_comm_info",
@@ -257,6 +260,8 @@ def load_library():
                 vp, P(_PenaltyStruct), P(_PathPoint), i32, i32, P(_SolveOpts), vp, vp, vp, P(_PointInfo), P(_SolveStats),
             ],
             "slm_solve_standardized_sgl": [vp, vp, vp, P(_SolveOpts), dbl, i32, vp, i32, vp, vp, P(_PointInfo)],
+            "slm_dataset_covariance": [vp, vp, i64],
+            "slm_dataset_covariance_count": [vp, P(i32)],
             "slm_comm_unique_id": [vp],
             "slm_comm_init": [vp, i32, i32, vp],
             "slm_comm_info": [vp, P(i32), P(i32)],
@@ -794,6 +799,18 @@ class Dataset:
         )
         return _path_result(betas, gn, infos, K, stats)
 
+
+    def covariance(self, row_weight=None, n_eff=0):
+        """``slm_dataset_covariance``: build (or find) the Gram of the row set ``(row_weight, n_eff)`` -- what a lane
+        brings as ``row_weight`` / ``n_eff`` -- so that solves with ``FLAG_COVARIANCE`` take their gradients from it
+        instead of reading X.  Worth it when many solves share the row set (a fold of a large grid)."""
+        rw = None if row_weight is None else _f64(row_weight, "row_weight", (self.n,))
+        _check(self._lib.slm_dataset_covariance(self._h, _ptr(rw), int(n_eff)))
+
+    def covariance_count(self) -> int:
+        out = C.c_int32()
+        _check(self._lib.slm_dataset_covariance_count(self._h, C.byref(out)))
+        return int(out.value)
 
     def solve_standardized_sgl(self, a, b, beta0=None, warm=False, tol=1e-8, tol_inner=0.0, max_sweeps=0,
                                max_iter=0, want_group_norms=False):

@@ -302,6 +302,9 @@ class GridSearchCV(_GridSearchCV):
         return self.best_estimator_.predict(X)
 
 
+from ._backend import normalise_options  # noqa: E402
+
+
 class _DeviceGrid:
     """One device-resident search: the grid laid out as units, the dataset, the calls of a rank's share.
 
@@ -429,10 +432,38 @@ class _DeviceGrid:
             self.cells = [(u, idx[0]) for calls in self._plan for call in calls for lane in call for u, idx in lane]
         return self._plan
 
+    def covariance(self, ds, calls):
+        """Covariance passes for this share (``solver_options={"covariance": True | False | "auto"}``, default "auto"):
+        the Gram of every fold's training rows is built once (``Dataset.covariance``: the Gram of all rows minus the
+        fold's test rows) and every pass of the share reads 8 p^2 bytes per fold instead of X.  "auto" asks whether the
+        passes the share is expected to take over X -- one per path point and sixteen lanes, at the HBM rate -- cost
+        more than twice the Grams (2 n p^2 flops at the matrix cores' fp64 rate for all rows, a fifth of that per fold):
+        true for grids of tens of thousands of fits on a large X, not for BASELINE config 4's 2 500, whose 163 passes
+        cost 0.10 s against 0.16 s of Grams (the grid then runs in 0.064 s instead of 0.147 s: worth asking for when
+        the search is repeated, or when its paths end dense -- DESIGN section 8)."""
+        want = normalise_options(self.est.solver_options).get("covariance", "auto")
+        if want is False or self.adaptive:
+            return False
+        n, p = ds.n, ds.p
+        if want == "auto":
+            points = sum(len(idx) for call in calls for lane in call for _, idx in lane)
+            over_x = 1.1 * points / max(self.lanes, 1) * (8.0 * n * p / 6.5e12)
+            grams = (1.0 + 0.25 * self.n_splits) * 2.0 * n * p * p / 60e12
+            if n * p < (1 << 26) or over_x < 2.0 * grams:
+                return False
+        try:
+            for m in self.train_masks:
+                ds.covariance(m, int(m.sum()))
+        except (NotImplementedError, MemoryError):
+            return False
+        return True
+
     def solve_share(self, ds, rank, world):
         """(cells of rank `rank`, number of solves that stopped short of the tolerance)"""
         calls = self.plan(world)[rank]
         local = {}
+        if self.covariance(ds, calls):
+            self.opts["flags"] = self.opts.get("flags", 0) | _engine.FLAG_COVARIANCE
         run = self._run_adaptive if self.adaptive else self._run_call
         unconverged = self.search._run_batches(ds, calls, lambda d, call: run(d, call, local), self)
         return local, unconverged

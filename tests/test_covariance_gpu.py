@@ -1,0 +1,102 @@
+"""Covariance passes (SLM_FLAG_COVARIANCE, csrc/cov_kernels.hpp): gradients from the Gram of a row set instead of a
+read of X -- for the many solves of a CV grid that share a fold (the reference's loop over candidates x folds,
+/root/reference/src/sparselm/model_selection.py:304-323).  Same iteration, same results."""
+
+import numpy as np
+import pytest
+
+from sparselm_amd import _engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return _engine.get_engine(0)
+
+
+def _problem(n, p, seed=0):
+    rng = np.random.default_rng(seed)
+    G = p // 10
+    groups = rng.permutation(np.repeat(np.arange(G), 10))
+    coef = np.zeros(p)
+    for g in rng.choice(G, 6, replace=False):
+        coef[groups == g] = 10.0 * rng.uniform(size=10)
+    X = rng.standard_normal((n, p))
+    y = X @ coef + 5.0 * rng.standard_normal(n)
+    return X, y, groups, G, rng
+
+
+def test_sixteen_lane_calls_from_the_grams_of_their_folds(eng):
+    """Sixteen lanes -- five CV folds as row masks with their own 1/n, sparse-group paths of twelve points -- over X and
+    from the folds' Grams: the same passes, the same coefficients to rounding; a Gram is found again by the content of
+    its row weights (another array with the same values), general weights and the dataset's own rows work too, new
+    targets drop what was built."""
+    n, p = 6000, 400
+    X, y, groups, G, rng = _problem(n, p)
+    folds = rng.permutation(n) % 5
+    masks = [(folds != f).astype(float) for f in range(5)]
+    with eng.dataset(X, y) as ds:
+        ds.set_groups(groups, G)
+        g0, _ = ds.gradient(None)
+        amax = float(np.max(np.abs(g0)))
+        al = np.geomspace(amax, 1e-2 * amax, 12)
+        pts = np.c_[0.5 * al, 0.5 * al, 0 * al]
+        specs = [dict(points=pts * (1.0 + 0.1 * (l // 5)), row_weight=masks[l % 5], n_eff=int(masks[l % 5].sum())) for l in range(16)]
+        base = _engine.FLAG_WORKING_SET
+        ref = ds.solve_lanes(specs, tol=1e-10, flags=base)
+        # the flag without Grams changes nothing
+        same = ds.solve_lanes(specs, tol=1e-10, flags=base | _engine.FLAG_COVARIANCE)
+        assert all(np.array_equal(a.betas, b.betas) for a, b in zip(ref, same))
+        for m in masks:
+            ds.covariance(m, int(m.sum()))
+        assert ds.covariance_count() == 5
+        ds.covariance(masks[3].copy(), int(masks[3].sum()))  # same content, another array: found, not built again
+        assert ds.covariance_count() == 5
+        cov = ds.solve_lanes(specs, tol=1e-10, flags=base | _engine.FLAG_COVARIANCE)
+        for a, b in zip(ref, cov):
+            assert a.converged and b.converged and a.grad_launches == b.grad_launches
+            np.testing.assert_allclose(b.betas, a.betas, rtol=0, atol=1e-9 * np.max(np.abs(a.betas)))
+            np.testing.assert_allclose(b.loss, a.loss, rtol=1e-9)
+        # a call with a row set that has no Gram runs over X (on the split pass, which the flag asks for: equal to rounding)
+        other = (rng.permutation(n) % 3 != 0).astype(float)
+        mixed = specs[:3] + [dict(points=pts, row_weight=other, n_eff=int(other.sum()))]
+        a = ds.solve_lanes(mixed, tol=1e-10, flags=base)
+        b = ds.solve_lanes(mixed, tol=1e-10, flags=base | _engine.FLAG_COVARIANCE)
+        for u, v in zip(a, b):
+            np.testing.assert_allclose(v.betas, u.betas, rtol=0, atol=1e-9 * np.max(np.abs(u.betas)))
+        # general weights, and all rows with the dataset's 1/n
+        w = rng.uniform(0.5, 1.5, n)
+        ds.covariance(w, 0)
+        ds.covariance(None, 0)
+        assert ds.covariance_count() == 7
+        for rw in (w, None):
+            three = [dict(points=pts, row_weight=rw), dict(points=1.3 * pts, row_weight=rw), dict(points=0.8 * pts, row_weight=rw)]
+            a = ds.solve_lanes(three, tol=1e-10, flags=base)
+            b = ds.solve_lanes(three, tol=1e-10, flags=base | _engine.FLAG_COVARIANCE)
+            for u, v in zip(a, b):
+                assert u.converged and v.converged
+                np.testing.assert_allclose(v.betas, u.betas, rtol=0, atol=1e-9 * np.max(np.abs(u.betas)))
+        ds.set_targets(2.0 * y)
+        assert ds.covariance_count() == 0
+
+
+def test_grid_search_from_the_folds_grams(eng):
+    """GridSearchCV(SparseGroupLasso) with solver_options covariance=True / False: the same table of scores and the same
+    choice ("auto" does not ask for Grams on a grid this small)."""
+    from sparselm_amd.model import SparseGroupLasso
+    from sparselm_amd.model_selection import GridSearchCV
+
+    n, p = 3000, 200
+    X, y, groups, G, _ = _problem(n, p, seed=3)
+    grid = {"alpha": np.geomspace(2.0, 0.05, 8), "l1_ratio": [0.2, 0.5, 0.8]}
+    out = {}
+    for cov in (False, True, "auto"):
+        opts = {"tol": 1e-10, "covariance": cov, "on_chip": False}
+        gs = GridSearchCV(SparseGroupLasso(groups=groups, solver_options=opts), grid, cv=4).fit(X, y)
+        out[cov] = gs
+    np.testing.assert_allclose(out[True].cv_results_["mean_test_score"], out[False].cv_results_["mean_test_score"], rtol=1e-8)
+    np.testing.assert_array_equal(out["auto"].cv_results_["mean_test_score"], out[False].cv_results_["mean_test_score"])
+    assert out[True].best_params_ == out[False].best_params_
+    np.testing.assert_allclose(out[True].best_estimator_.coef_, out[False].best_estimator_.coef_, rtol=0,
+                               atol=1e-8 * np.max(np.abs(out[False].best_estimator_.coef_)))

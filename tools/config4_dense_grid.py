@@ -32,6 +32,19 @@ over = np.array([sum(np.count_nonzero(keep[(u, k)]) > 512 for k in range(c4.K)) 
 print(f"config 4, noise {noise:g}: {dt:.3f} s per 2500-fit grid ({warm:.3f} s the first time), passes per call {passes} = {sum(passes)} in all; "
       f"non-zeros at the last alpha {nnz.min()}..{nnz.max()} (median {int(np.median(nnz))}); path points above 512 non-zeros: "
       f"{int(over.sum())} of 2500, in {int((over > 0).sum())} of 50 units", flush=True)
+# the same grid from the Grams of its five folds
+keep_x = keep
+t0 = time.perf_counter()
+t_build = c4.build_covariance()
+keep_c = {}
+passes_c = [c4.run_call(c4.ds, call, keep_c) for call in calls]
+t0 = time.perf_counter()
+passes_c = [c4.run_call(c4.ds, call) for call in calls]
+dt_c = time.perf_counter() - t0
+worst = max(float(np.max(np.abs(keep_c[k] - keep_x[k])) / max(np.max(np.abs(keep_x[k])), 1e-300)) for k in keep_x)
+print(f"  with covariance passes (SLM_FLAG_COVARIANCE): five fold Grams built in {t_build:.3f} s (the BLAS library's first call in the process "
+      f"included), then {dt_c:.3f} s per grid, passes per call {passes_c} = {sum(passes_c)}; worst difference of a coefficient vector "
+      f"to the run over X {worst:.2e} (relative to its largest entry)", flush=True)
 c4.close()
 
 # the parts of a covariance route, measured on this box
