@@ -350,8 +350,8 @@ int slm_solve_standardized_sgl(slm_dataset* ds, const double* a, const double* b
  * l1_ratio rows x fifty alphas of a CV fold, the rounds of an Adaptive* grid.  Replaces nothing in the
  * reference (cvxpy has no Gram form; scikit-learn's lasso_path(precompute=True) is the same idea on the host).
  * SLM_ERR_UNSUPPORTED on row-sharded datasets and rows beyond the split pass's 10 240 columns.  New targets
- * (slm_dataset_set_targets) drop the Grams built so far (they carry X^T W y); centring and new dataset row weights
- * are expected BEFORE the first call.
+ * (slm_dataset_set_targets) and centring (slm_dataset_center) drop the Grams built so far.  At most sixteen Grams are
+ * kept per dataset; the oldest goes first.
  */
 int slm_dataset_covariance(slm_dataset* ds, const double* row_weight, int64_t n_eff);
 int slm_dataset_covariance_count(slm_dataset* ds, int32_t* count_out);

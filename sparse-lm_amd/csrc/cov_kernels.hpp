@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "split_kernels.hpp"
+#include "ws_kernels.hpp"
 
 namespace slm {
 
@@ -74,6 +75,45 @@ __global__ __launch_bounds__(256) void cov_loss_kernel(CovFinishArgs a) {
     __syncthreads();
   }
   if (threadIdx.x == 0) g[a.ld] = 0.5 * red[0] + 0.5 * a.yy;
+}
+
+// The working set's Gram under covariance passes: G_WW is a sub-matrix of the row set's Gram -- no gathered columns, no
+// product over the rows.  Stands in for ws_gather_kernel + ws_gram_kernel + ws_gram_reduce_kernel with the latter's grid
+// ((WS_TILES^2, n_sets)) and protocol: the new tile rows and, mirrored, the matching columns of the old part; the last
+// workgroup publishes the Gram.
+struct CovSets {
+  const double* G[SLM_MAX_LANES];  // per SET of the working set (WsArgs::set_of): the row set's Gram, [ld][ld]
+};
+
+__global__ __launch_bounds__(256) void ws_gram_cov_kernel(WsArgs w, CovSets cs) {
+  WsCtl* ws = w.ws;
+  if (!ws->building) return;
+  const int K = ws->K;
+  const int row_lo = (ws->k_new >> 4) << 4;
+  const int set = blockIdx.y;
+  const int tile = blockIdx.x, I = tile / WS_TILES, J = tile % WS_TILES;
+  const int tiles = K >> 4, I_lo = row_lo >> 4;
+  if (I < I_lo || I >= tiles || J >= tiles) return;  // (only the working tiles take part in the count below)
+  const int i = 16 * I + (threadIdx.x >> 4), j = 16 * J + (threadIdx.x & 15);
+  {
+    const int fi = w.idx[i], fj = w.idx[j];  // (padding positions: -1)
+    const double s = (fi >= 0 && fj >= 0) ? cs.G[set][(int64_t)fi * w.ld + fj] : 0.0;
+    double* Gs = w.Gm + (int64_t)set * (WS_KCAP * WS_KCAP);
+    Gs[i * WS_KCAP + j] = s;
+    if (j < row_lo) Gs[j * WS_KCAP + i] = s;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = (tiles - I_lo) * tiles * (int)gridDim.y;
+    if (atomicAdd(&ws->counter, 1) + 1 == total) {
+      ws->counter = 0;
+      ws->request = 0;
+      ws->valid = 1;
+      __threadfence();
+      ws->building = 0;
+    }
+  }
 }
 
 // ---- building a Gram ------------------------------------------------------------------------------------------------

@@ -1410,6 +1410,10 @@ extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
   HIP_TRY(hipSetDevice(ds->eng->device));
   hipStream_t s = ds->eng->stream;
+  // (X and y change in place: the Grams of covariance passes, the Gram of all rows included, go with the old values)
+  for (auto& e : ds->cov) { dfree(e.G); dfree(e.c); }
+  ds->cov.clear();
+  dfree(ds->cov_all);
   const int64_t n = ds->n, p = ds->p, ld = ds->ld;
   // sum w, sum w y -- of ALL rows: a row-sharded dataset adds its ranks' sums here and its ranks' X_r^T w_r
   // in the gradient launch below (one all-reduce each), so every rank subtracts the global means
@@ -2355,6 +2359,13 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         hipLaunchKernelGGL(ws_score_kernel, dim3((unsigned)((items + bs - 1) / bs)), dim3(bs), 0, s, ta, wa);
       }
       hipLaunchKernelGGL(ws_select_kernel, dim3(1), dim3(WS_THREADS), 0, s, ta, wa);
+      if (cov_on) {
+        // covariance passes: the working set's Gram is a sub-matrix of the row set's (no gathered columns, no product
+        // over the rows; nothing reads XW in this mode -- the residuals of a pass are not formed at all)
+        CovSets cs;
+        for (int st = 0; st < kMaxLanes; ++st) cs.G[st] = st < wa.n_sets ? ds->cov[(size_t)cov_entry[wa.set_lane[st]]].G : nullptr;
+        hipLaunchKernelGGL(ws_gram_cov_kernel, dim3(WS_TILES * WS_TILES, (unsigned)wa.n_sets), dim3(256), 0, s, wa, cs);
+      } else {
       hipLaunchKernelGGL(ws_gather_kernel, dim3((unsigned)std::min<int64_t>((n + 31) / 32, 1024), WS_KCAP / 32), dim3(256), 0, s, wa);
       hipLaunchKernelGGL(ws_gram_kernel, dim3((unsigned)wa.nblk, (unsigned)wa.n_sets, 1), dim3(WS_GRAM_THREADS), 0, s,
                          wa);
@@ -2362,6 +2373,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         (void)hipMemsetAsync(wa.Gx, 0, sizeof(double) * (size_t)wa.n_sets * WS_KCAP * WS_KCAP, s);
       hipLaunchKernelGGL(ws_gram_reduce_kernel, dim3(WS_TILES * WS_TILES, (unsigned)wa.n_sets), dim3(256),
                          0, s, wa);
+      }
       if (wa.Gx) {
         // one collective per pass on every rank whether or not a build is under way: the ranks run the
         // same state machine on the same all-reduced gradients, so they agree on when that is
@@ -2721,6 +2733,13 @@ extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight,
     dfree(e.G);
     dfree(e.c);
     return rc;
+  }
+  // (at most sixteen Grams per dataset -- 3.2 GB at p = 5 000 -- the oldest goes first: searches with fresh CV splits on a
+  //  cached dataset would otherwise pile them up)
+  if (ds->cov.size() >= 16) {
+    dfree(ds->cov.front().G);
+    dfree(ds->cov.front().c);
+    ds->cov.erase(ds->cov.begin());
   }
   ds->cov.push_back(e);
   return SLM_OK;

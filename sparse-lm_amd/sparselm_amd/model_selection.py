@@ -439,7 +439,7 @@ class _DeviceGrid:
         passes the share is expected to take over X -- one per path point and sixteen lanes, at the HBM rate -- cost
         more than twice the Grams (2 n p^2 flops at the matrix cores' fp64 rate for all rows, a fifth of that per fold):
         true for grids of tens of thousands of fits on a large X, not for BASELINE config 4's 2 500, whose 163 passes
-        cost 0.10 s against 0.16 s of Grams (the grid then runs in 0.064 s instead of 0.147 s: worth asking for when
+        cost 0.10 s against 0.16 s of Grams (the grid then runs in 0.054 s instead of 0.147 s: worth asking for when
         the search is repeated, or when its paths end dense -- DESIGN section 8)."""
         want = normalise_options(self.est.solver_options).get("covariance", "auto")
         if want is False or self.adaptive:
