@@ -100,3 +100,25 @@ def test_grid_search_from_the_folds_grams(eng):
     assert out[True].best_params_ == out[False].best_params_
     np.testing.assert_allclose(out[True].best_estimator_.coef_, out[False].best_estimator_.coef_, rtol=0,
                                atol=1e-8 * np.max(np.abs(out[False].best_estimator_.coef_)))
+
+
+def test_adaptive_grid_search_from_the_folds_grams(eng):
+    """GridSearchCV(AdaptiveLasso): every cell is a loop of re-weighted solves on its fold -- with covariance=True all of
+    them read the fold's Gram; same scores, same number of re-weighting rounds in the refit."""
+    import warnings
+
+    from sparselm_amd.model import AdaptiveLasso
+    from sparselm_amd.model_selection import GridSearchCV
+
+    n, p = 2500, 160
+    X, y, _, _, _ = _problem(n, p, seed=5)
+    grid = {"alpha": np.geomspace(1.0, 0.02, 6)}
+    out = {}
+    for cov in (False, True):
+        opts = {"tol": 1e-10, "covariance": cov, "on_chip": False}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out[cov] = GridSearchCV(AdaptiveLasso(fit_intercept=True, solver_options=opts), grid, cv=3).fit(X, y)
+    np.testing.assert_allclose(out[True].cv_results_["mean_test_score"], out[False].cv_results_["mean_test_score"], rtol=1e-7)
+    assert out[True].best_params_ == out[False].best_params_
+    assert out[True].best_estimator_.n_iter_ == out[False].best_estimator_.n_iter_
