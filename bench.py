@@ -441,6 +441,45 @@ def leg_config4_dense(eng, n, p, noise_sd=100.0):
         c4.close()
 
 
+def leg_config1_small():
+    """BASELINE config 1 and the reference's own problem sizes through the estimators (what its users run: README.md:42-55,
+    tests/conftest.py:17-19): the on-chip solvers' territory.  Times include everything a user's call includes."""
+    import warnings
+
+    from sklearn.datasets import make_regression
+    from sparselm_amd.model import AdaptiveLasso, Lasso, SparseGroupLasso
+    from sparselm_amd.model_selection import GridSearchCV
+
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X, y = make_regression(n_samples=100, n_features=80, n_informative=10, random_state=0)
+        grid = {"alpha": np.logspace(-8, 2, 10)}
+        GridSearchCV(AdaptiveLasso(fit_intercept=False), grid).fit(X, y)
+        t = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            gs = GridSearchCV(AdaptiveLasso(fit_intercept=False), grid).fit(X, y)
+            t.append(time.perf_counter() - t0)
+        out["readme_grid_ms"] = 1e3 * sorted(t)[len(t) // 2]
+        out["readme_grid_best_alpha"] = float(gs.best_params_["alpha"])
+        Xs, ys = make_regression(n_samples=25, n_features=30, n_informative=10, random_state=1)
+        Lasso(alpha=0.1).fit(Xs, ys)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            m = Lasso(alpha=0.1).fit(Xs, ys)
+        out["lasso_fit_25x30_ms"] = 1e3 * (time.perf_counter() - t0) / 50
+        out["lasso_fit_converged"] = bool(m.solver_info_["converged"])
+        groups = np.arange(80) // 8
+        SparseGroupLasso(groups=groups, alpha=0.5, standardize=True, fit_intercept=True).fit(X, y)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            m = SparseGroupLasso(groups=groups, alpha=0.5, standardize=True, fit_intercept=True).fit(X, y)
+        out["standardized_sgl_fit_100x80_ms"] = 1e3 * (time.perf_counter() - t0) / 5
+        out["standardized_sgl_sweeps"] = int(m.solver_info_["n_iter"])
+    return out
+
+
 def soak_case(seed, p):
     """The law of tools/headline_soak.py: (coef, noise_sd, path floor as a fraction of alpha_max) of random dataset `seed`
     -- 5...199 informative features of scale 1 or 100, noise 0.1 / 10 / 100, path down to 1e-3 / 1e-2 / 0.1 alpha_max."""
@@ -900,6 +939,8 @@ def main():
                              ("config4_grid_dense_regime", lambda: leg_config4_dense(eng, n, p) if rank == 0 and world == 1 else {}),
                              ("config3_path", lambda: leg_config3(eng, rank, world, n, p, args.tol, args.cpu_budget)),
                              ("soak", lambda: leg_soak(eng, n, p, K, args.tol, args.lanes) if rank == 0 else {}),
+                             # (every rank: with a process group up, GridSearchCV shards the search over the ranks and gathers)
+                             ("config1_small", lambda: leg_config1_small()),
                              ("concurrent_paths", lambda: leg_concurrent_paths(eng, device_id, rank, n, p, K, args.tol, args.lanes)),
                              ("rowshard", lambda: leg_rowshard(eng, rank, world, args.rowshard_rows, args.rowshard_cols))):
                 try:
@@ -996,6 +1037,14 @@ def main():
                         "median_ms_dense_end": (sorted(c["ms"] for c in dense)[len(dense) // 2] if dense else None),
                         "median_ms_sparse_end": sorted(c["ms"] for c in cases if c["nnz_last"] <= 512)[(len(cases) - len(dense)) // 2]
                         if len(dense) < len(cases) else None,
+                    }
+                elif name == "config1_small":
+                    legs[name] = {
+                        "what": "BASELINE config 1 (the reference's README example: GridSearchCV(AdaptiveLasso), 10 alphas x 5 folds + "
+                        "refit, make_regression(100, 80)) and two fits of the reference's own sizes through the estimators, on the "
+                        "one-workgroup solvers (small_kernels.hpp, small_split_kernels.hpp); wall time of the user's call on rank 0 (with "
+                        "more than one rank the grid search is sharded over the ranks and gathered through torch.distributed)",
+                        **{k: v for k, v in parts[0].items() if k != "ok"},
                     }
                 elif name == "concurrent_paths":
                     legs[name] = {
