@@ -1325,7 +1325,17 @@ static int check_launch() {
 // magnitude (it measures curvature along its own steps) and FISTA's curvature guard repairs an
 // under-estimate, so a handful of passes is enough; slm_dataset_lipschitz() asks for more.
 static const int kPowerItersSolve = 2;
-static const int kPowerItersSketch = 3;  // on a thirty-second of the rows (working-set solves)
+// Power steps on the sketch (a thirty-second of the rows) for working-set solves: ONE.  The sketch's lambda_max is 2-3 x the
+// whole matrix's, and one step from the fixed start lands at about half of the sketch's: closer to the truth than three
+// steps' estimate, 80 us cheaper per solve (a launch chain of nine), and these solves only use L for a first candidate
+// and for fallback steps whose curvature guard repairs an under-estimate.  Round 3, same box, alternating: headline
+// 4.17-4.25 ms with three steps, 4.13-4.16 with two, 4.09-4.12 with one; passes of the headline, configs 3 / 4 and the
+// sparse-regime soak paths unchanged, dense-regime soak paths -3 ... +3 passes of 24-60 (SLM_L_SKETCH_ITERS).
+static const int kPowerItersSketchDefault = 1;
+static int sketch_iters() {
+  if (const char* e = getenv("SLM_L_SKETCH_ITERS")) return std::max(1, std::min(16, atoi(e)));
+  return kPowerItersSketchDefault;
+}
 static const int kPowerItersQuery = 16;
 // (a thirty-second of the rows: the bound is looser than from a sixteenth -- lambda_max of a sketch grows as it
 // shrinks -- and nothing downstream noticed down to a sixty-fourth, SLM_L_SKETCH_DIV; three steps on
@@ -1890,7 +1900,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         //  estimates, all-reduced like every gradient, stay in use there)
         LaneSetup plain = default_lanes(ds, 1);
         plain.rw = nullptr;
-        SLM_TRY(power_iteration(ds, plain, nullptr, kPowerItersSketch, sketch_rows(n)));
+        SLM_TRY(power_iteration(ds, plain, nullptr, sketch_iters(), sketch_rows(n)));
         for (int l = 0; l < B; ++l) {
           L[l] = 0.0;
           L_factor[l] = wmax[l] * (double)ds->n_global / (ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global);
@@ -1904,11 +1914,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         // (on a side stream beside the first pass, on vectors of its own, the seed saved nothing: the pass is bound by
         //  the memory system, and the 0.4 GB the three power steps read through it come out of the same budget -- 4.26 ms
         //  per path either way, profiles/r03a_seed_beside_ab.txt)
-        SLM_TRY(power_iteration(ds, default_lanes(ds, 1), nullptr, kPowerItersSketch, sketch_rows(n)));
+        SLM_TRY(power_iteration(ds, default_lanes(ds, 1), nullptr, sketch_iters(), sketch_rows(n)));
         for (int l = 0; l < B; ++l) L[l] = 0.0;
         L_on_device = true;
       } else {
-      SLM_TRY(power_iteration(ds, per_lane ? ls : default_lanes(ds, 1), L, kPowerItersSketch, sketch_rows(n)));
+      SLM_TRY(power_iteration(ds, per_lane ? ls : default_lanes(ds, 1), L, sketch_iters(), sketch_rows(n)));
       // A lane whose row weights vanish on the window (scikit-learn's default cv = unshuffled KFold: the first
       // fold's training mask is zero on the first n / k rows) measured nothing there: all rows, then.
       bool blank = false;
