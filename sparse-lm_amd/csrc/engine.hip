@@ -1703,6 +1703,18 @@ static int ws_policy(const slm_dataset* ds, uint32_t flags) {
   const bool big = (double)ds->n * (double)ds->ld >= 67108864.0;  // 2^26 doubles = 512 MiB
   return (big || (flags & SLM_FLAG_WORKING_SET) || (env && env[0] == '1')) ? 2 : 1;
 }
+// kernels that ask for more dynamic LDS than the default limit: the attribute is per device
+static int allow_big_lds(const void* fn, int device) {
+  static std::mutex m;
+  static std::vector<std::pair<const void*, int>> done;
+  std::lock_guard<std::mutex> lk(m);
+  for (auto& d : done)
+    if (d.first == fn && d.second == device) return SLM_OK;
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES));
+  done.push_back({fn, device});
+  return SLM_OK;
+}
+
 // The on-chip solver (small_kernels.hpp) takes a call when the caller allows it (SLM_FLAG_ON_CHIP), the Gram matrix
 // fits the LDS and nothing asks for a particular iteration of the general path.
 static bool small_ok(const slm_dataset* ds, uint32_t flags) {
@@ -2147,11 +2159,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     const size_t fixed = sizeof(double) * ((size_t)p * p + 3 * (size_t)p);
     const size_t lds = (size_t)SM_LDS_BYTES;
     sm.stage_doubles = (int)((lds - fixed - 64) / sizeof(double));
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIP_TRY(hipFuncSetAttribute((const void*)small_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES));
-      attr_set = true;
-    }
+    SLM_TRY(allow_big_lds((const void*)small_solve_kernel, eng->device));
     hipLaunchKernelGGL(small_solve_kernel, dim3(B), dim3(SM_THREADS), lds, s, sm);
     SLM_TRY(check_launch());
     if (infos_in_snap) HIP_TRY(hipMemcpyAsync(&ds->hctl[0].c, ds->dctl, sizeof(DevCtl), hipMemcpyDeviceToHost, s));
@@ -2876,11 +2884,7 @@ extern "C" int slm_solve_standardized_sgl(slm_dataset* ds, const double* a, cons
   k.max_iters = opts && opts->max_iter > 0 ? (int)std::min<int64_t>(opts->max_iter, 4000) : 4000;
   k.gmax = gm;
   k.stage_doubles = (int)stage;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)small_stdsgl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS_BYTES));
-    attr_set = true;
-  }
+  SLM_TRY(allow_big_lds((const void*)small_stdsgl_kernel, eng->device));
   hipLaunchKernelGGL(small_stdsgl_kernel, dim3(1), dim3(SM_THREADS), lds, s, k);
   SLM_TRY(check_launch());
   double* h_out = h + 3 * ld;  // a copy of everything behind gamma and u
