@@ -2700,6 +2700,16 @@ extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight,
     }
   slm_dataset::CovEntry e;
   e.n_eff = n_eff; e.fp1 = fp[0]; e.fp2 = fp[1];
+  struct EntryGuard {  // (whichever way this function is left before the entry is filed, its blocks go back)
+    slm_dataset::CovEntry* e;
+    hipStream_t s;
+    ~EntryGuard() {
+      if (!e) return;
+      (void)hipStreamSynchronize(s);
+      dfree(e->G);
+      dfree(e->c);
+    }
+  } guard{&e, s};
   SLM_TRY(dalloc(&e.G, (size_t)ld * ld));
   SLM_TRY(dalloc(&e.c, (size_t)ld));
   const unsigned cgrid = (unsigned)std::min<int64_t>(4096, (ld * ld + 255) / 256);
@@ -2746,12 +2756,8 @@ extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight,
     if (he == hipSuccess) he = hipStreamSynchronize(s);
     if (he != hipSuccess) rc = fail(SLM_ERR_HIP, "covariance build: %s", hipGetErrorString(he));
   }
-  if (rc != SLM_OK) {
-    (void)hipStreamSynchronize(s);
-    dfree(e.G);
-    dfree(e.c);
-    return rc;
-  }
+  if (rc != SLM_OK) return rc;
+  guard.e = nullptr;
   // (at most sixteen Grams per dataset -- 3.2 GB at p = 5 000 -- the oldest goes first: searches with fresh CV splits on a
   //  cached dataset would otherwise pile them up)
   if (ds->cov.size() >= 16) {
