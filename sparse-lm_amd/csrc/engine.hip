@@ -1736,6 +1736,32 @@ static int max_lanes_for(slm_dataset* ds, uint32_t flags) {
 }
 
 static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, const slm_solve_opts* opts,
+                      slm_solve_stats* stats, bool shared_path);
+
+// A call the on-chip solver was offered, on the general path: in as many calls as that path needs for the lane count
+// (sixteen workgroups take sixteen lanes whatever p; the fused kernels' table stops earlier).
+static int solve_without_chip(slm_dataset* ds, const slm_lane* lanes, int32_t B, const slm_solve_opts& o, slm_solve_stats* stats,
+                              bool shared_path) {
+  slm_solve_opts again = o;
+  again.flags &= ~SLM_FLAG_ON_CHIP;
+  const int per_call = shared_path ? B : std::min<int>(B, max_lanes_for(ds, again.flags));
+  if (per_call >= B) return solve_core(ds, lanes, B, &again, stats, shared_path);
+  slm_solve_stats sum, part;
+  memset(&sum, 0, sizeof(sum));
+  for (int l0 = 0; l0 < B; l0 += per_call) {
+    SLM_TRY(solve_core(ds, lanes + l0, std::min(per_call, B - l0), &again, &part, false));
+    sum.grad_launches += part.grad_launches;
+    sum.wall_ms += part.wall_ms;
+    sum.lipschitz_ms += part.lipschitz_ms;
+    sum.ws_builds += part.ws_builds; sum.ws_appends += part.ws_appends; sum.ws_refined += part.ws_refined;
+    sum.ws_misses += part.ws_misses; sum.ws_columns = std::max(sum.ws_columns, part.ws_columns);
+    sum.ws_inner_iters += part.ws_inner_iters; sum.ws_direct_steps += part.ws_direct_steps;
+  }
+  if (stats) *stats = sum;
+  return SLM_OK;
+}
+
+static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, const slm_solve_opts* opts,
                       slm_solve_stats* stats, bool shared_path) {
   if (!ds || !lanes) return fail(SLM_ERR_BAD_ARG, "NULL argument");
   if (n_lanes < 1 || n_lanes > kMaxLanes)
@@ -2184,29 +2210,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       at += lanes[l].n_points;
     }
     if (nonfinite) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
-    if (unconverged) {
+    if (unconverged && getenv("SLM_ON_CHIP_NO_FALLBACK") == nullptr) {  // (the variable: diagnostics -- the on-chip records as they are)
       if (const char* trc = getenv("SLM_TRACE"))
         if (trc[0] == '2') fprintf(stderr, "[slm] on-chip solve gave a point up after %.3f ms (%lld products): the general path takes the call\n", t_small, (long long)sweeps);
       // the on-chip iteration did not settle some point within its products (an ill-conditioned face): the general
       // path, with its Newton steps, takes the call over from the start
-      slm_solve_opts again = o;
-      again.flags &= ~SLM_FLAG_ON_CHIP;
-      const int per_call = shared_path ? B : std::min(B, max_lanes_for(ds, again.flags));
-      if (per_call >= B) return solve_core(ds, lanes, n_lanes, &again, stats, shared_path);
-      // (more lanes than the general path serves at this p: a few calls)
-      slm_solve_stats sum, part;
-      memset(&sum, 0, sizeof(sum));
-      for (int l0 = 0; l0 < B; l0 += per_call) {
-        SLM_TRY(solve_core(ds, lanes + l0, std::min(per_call, B - l0), &again, &part, false));
-        sum.grad_launches += part.grad_launches;
-        sum.wall_ms += part.wall_ms;
-        sum.lipschitz_ms += part.lipschitz_ms;
-        sum.ws_builds += part.ws_builds; sum.ws_appends += part.ws_appends; sum.ws_refined += part.ws_refined;
-        sum.ws_misses += part.ws_misses; sum.ws_columns = std::max(sum.ws_columns, part.ws_columns);
-        sum.ws_inner_iters += part.ws_inner_iters; sum.ws_direct_steps += part.ws_direct_steps;
-      }
-      if (stats) *stats = sum;
-      return SLM_OK;
+      return solve_without_chip(ds, lanes, B, o, stats, shared_path);
     }
     if (stats) {
       memset(stats, 0, sizeof(*stats));

@@ -212,7 +212,7 @@ __device__ __forceinline__ double sm_lane(double v, int k) {
 // LDS beside the Gram matrix that the direct solves on a face use: the positions of the face, the ridge terms of its
 // diagonal, the diagonal itself as gathered, the inverted pivots, and the factor (lower triangle, packed by rows: (i, j)
 // at i (i + 1) / 2 + j)
-constexpr int SM_FACE_HEAD = 64 + 3 * SM_PMAX;  // doubles in front of the factor: idx (as ints), add, dia, invd
+constexpr int SM_FACE_HEAD = 128 + 4 * SM_PMAX;  // doubles in front of the factor: idx, group of a position (ints), add, dia, invd, gv
 __device__ __forceinline__ int sm_face_cap(int free_doubles) {  // largest face whose factor fits
   int m = 0;
   while (m < SM_PMAX && (m + 1) * (m + 2) / 2 <= free_doubles - SM_FACE_HEAD) ++m;
@@ -237,10 +237,12 @@ __device__ __forceinline__ double sm_recip(double d) {  // 1 / d: the hardware's
 // invd = 0, its unknown stays where it is.  `worker`: wavefront 0 -- which holds the iteration's state in its registers --
 // only keeps the barriers; the other three do the arithmetic.  Starts and ends with a barrier.
 // `fgrp` / `bd` (the splitting of small_split_kernels.hpp): entries of G inside a group -- fgrp[position] equal -- count
-// (1 + bd) times: the matrix is G + bd blockdiag(G_gg).
+// (1 + bd) times: the matrix is G + bd blockdiag(G_gg).  `fgv` (Newton steps on faces with group norms): inside a group
+// the entry (i, j) also loses fgv[i] fgv[j] -- the rank-one part of the Hessian of b ||x_g||, with fgv = x sqrt(b / ||x_g||^3)
+// and b / ||x_g|| in the diagonal term `fadd`.
 __device__ __forceinline__ void sm_face_factor(const double* Gs, int p, const int* fidx, const double* fadd, int m, double* F,
                                                double* fdia, double* invd, bool worker, const int* fgrp = nullptr,
-                                               double bd = 0.0) {
+                                               double bd = 0.0, const double* fgv = nullptr) {
   constexpr int NB = SM_PMAX / 16;          // column batches of a thread in the update
   constexpr int TW = SM_THREADS - 64;       // working threads
   const int t = (int)threadIdx.x - 64;      // 0 .. TW-1 for the workers
@@ -251,7 +253,10 @@ __device__ __forceinline__ void sm_face_factor(const double* Gs, int p, const in
       for (int j = tx; j <= i; j += 16) {
         const int sj = fidx[j];
         double v = Gs[si * p + sj];
-        if (fgrp != nullptr && fgrp[si] == fgrp[sj]) v = __builtin_fma(bd, v, v);
+        if (fgrp != nullptr && fgrp[si] == fgrp[sj]) {
+          v = __builtin_fma(bd, v, v);
+          if (fgv != nullptr) v = __builtin_fma(-fgv[i], fgv[j], v);
+        }
         if (i == j) v += fadd[i];
         F[base + j] = v;
         if (i == j) fdia[i] = v;
@@ -423,13 +428,15 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
   if (!sm_build_gram(a.X, a.y, rw, n, ld, p, a.t.order, inv_n, a.stage_doubles, Gs, cs, vu + p, &yy_s)) bad_setup = true;
   // Wavefront 0 iterates; the other three serve its matrix-vector products, a quarter of the rows of G each: they wait
   // at the barrier, multiply when the command word says so, leave when it says zero.
-  __shared__ int sm_cmd, sm_m;
+  __shared__ int sm_cmd, sm_m, sm_grp;
   double* pp = vu + p;  // [3][p]: the partial products of wavefronts 1..3 (the stage of the build is free now)
   int* fidx = reinterpret_cast<int*>(pp + 3 * p);  // direct solves on a face (sm_face_factor)
-  double* fadd = pp + 3 * p + 64;
+  int* gpos = fidx + SM_PMAX;                      // group of every position (Newton steps on faces with group norms)
+  double* fadd = pp + 3 * p + 128;
   double* fdia = fadd + SM_PMAX;
   double* invd = fdia + SM_PMAX;
-  double* Ff = invd + SM_PMAX;
+  double* fgv = invd + SM_PMAX;
+  double* Ff = fgv + SM_PMAX;
   const int face_cap = sm_face_cap(a.stage_doubles - 3 * p);
   const int mchunk = (((p + 3) >> 2) + 7) & ~7;
   if (wave != 0) {
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
       const int cmd = sm_cmd;
       if (cmd == 0) break;
       if (cmd == 2) {
-        sm_face_factor(Gs, p, fidx, fadd, sm_m, Ff, fdia, invd, true);
+        sm_face_factor(Gs, p, fidx, fadd, sm_m, Ff, fdia, invd, true, sm_grp ? gpos : nullptr, 0.0, sm_grp ? fgv : nullptr);
         continue;
       }
       double y0, y1;
@@ -463,6 +470,8 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
   const int sc0 = on0 ? s0 : 0, sc1 = on1 ? s1 : 0;  // (lanes beyond p read column 0; what they accumulate is never used)
   const int j0 = on0 ? a.t.order[s0] : 0, j1 = on1 ? a.t.order[s1] : 0;
   const int g0 = a.t.singleton ? j0 : a.t.gid[j0], g1 = a.t.singleton ? j1 : a.t.gid[j1];
+  if (on0) gpos[s0] = g0;
+  if (on1) gpos[s1] = g1;
   const double c0 = on0 ? cs[s0] : 0.0, c1 = on1 ? cs[s1] : 0.0;
   const double A0 = on0 ? a0[j0] : 0.0, A1 = on1 ? a0[j1] : 0.0;
   const double B0 = on0 ? b0[g0] : 0.0, B1 = on1 ? b0[g1] : 0.0;
@@ -664,8 +673,113 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
 #pragma unroll
         for (int k = 0; k < SM_AA; ++k) M[i][k] = 0.0;
       }
+      // Newton steps on the face of the iterate (its non-zero coordinates; groups at zero stay out): on the face the
+      // objective is smooth -- gradient q + thr s + d x + b x / ||x_g||, Hessian G_AA + diag(d + b / ||x_g||) minus the
+      // rank-one b x_g x_g^T / ||x_g||^3 of every group -- and one L D L^T of that Hessian (sm_face_factor) gives the step the
+      // mixing of proximal steps needs tens of products for, or never finds (p > n with groups: the reference's own
+      // fixture spent its 320 products and went to the general path).  Taken along the projected segment (coordinates
+      // that would change sign held at zero) at the first of 1, 1/2, 1/4, ... that lowers the objective; the proximal
+      // steps between two Newton steps move groups in and out of the face.
+      int newton_left = 8, next_newton = it + 24;
+      auto newton = [&]() {
+        const bool f0 = on0 && y0 != 0.0, f1 = on1 && y1 != 0.0;
+        const uint64_t m0 = __ballot(f0), m1 = __ballot(f1);
+        const int n0 = __popcll(m0), m = n0 + __popcll(m1);
+        if (m == 0 || m > face_cap) return false;
+        // norms of the groups of y
+        if (on0) vu[s0] = y0;
+        if (on1) vu[s1] = y1;
+        sm_lds_sync();
+        double nr0 = 0.0, nr1 = 0.0;
+        if (real0 && f0) {
+          double ss = 0.0;
+          for (int mm = 0; mm < gn0; ++mm) ss = __builtin_fma(vu[gs0 + mm], vu[gs0 + mm], ss);
+          nr0 = sqrt(ss);
+        }
+        if (real1 && f1) {
+          double ss = 0.0;
+          for (int mm = 0; mm < gn1; ++mm) ss = __builtin_fma(vu[gs1 + mm], vu[gs1 + mm], ss);
+          nr1 = sqrt(ss);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double bn0 = (real0 && nr0 > 0.0) ? pb0 / nr0 : 0.0, bn1 = (real1 && nr1 > 0.0) ? pb1 / nr1 : 0.0;
+        const double gr0 = f0 ? qy0 + copysign(thr0, y0) + (pd0 + bn0) * y0 : 0.0;
+        const double gr1 = f1 ? qy1 + copysign(thr1, y1) + (pd1 + bn1) * y1 : 0.0;
+        const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        const int rk0 = __popcll(m0 & below), rk1 = n0 + __popcll(m1 & below);
+        if (f0) { fidx[rk0] = s0; fadd[rk0] = pd0 + bn0; fgv[rk0] = nr0 > 0.0 ? y0 * sqrt(bn0) / nr0 : 0.0; vu[rk0] = -gr0; }
+        if (f1) { fidx[rk1] = s1; fadd[rk1] = pd1 + bn1; fgv[rk1] = nr1 > 0.0 ? y1 * sqrt(bn1) / nr1 : 0.0; vu[rk1] = -gr1; }
+        if (lane == 0) { sm_m = m; sm_grp = 1; sm_cmd = 2; }
+        __syncthreads();
+        sm_face_factor(Gs, p, fidx, fadd, m, Ff, fdia, invd, false, gpos, 0.0, fgv);
+        ++face_solves;
+        const int i0 = lane, i1 = lane + 64;
+        const bool h0 = i0 < m, h1 = i1 < m;
+        double w0 = h0 ? vu[i0] : 0.0, w1 = h1 ? vu[i1] : 0.0;
+        sm_face_solve(Ff, invd, m, lane, w0, w1);
+        __builtin_amdgcn_wave_barrier();
+        if (h0) vu[i0] = w0;
+        if (h1) vu[i1] = w1;
+        sm_lds_sync();
+        const double d0 = f0 ? vu[rk0] : 0.0, d1 = f1 ? vu[rk1] : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        const double dn = sm_sum(d0 * d0 + d1 * d1);
+        if (!(dn < 1e300) || !(dn > 0.0)) return false;
+        const double g_old = sm_sum(gr0 * gr0 + gr1 * gr1);
+        double alpha = 1.0;
+        for (int tr = 0; tr < 6; ++tr, alpha *= 0.5) {
+          double v0 = f0 ? __builtin_fma(alpha, d0, y0) : y0, v1 = f1 ? __builtin_fma(alpha, d1, y1) : y1;
+          const bool k0 = f0 && v0 * y0 <= 0.0, k1 = f1 && v1 * y1 <= 0.0;
+          if (k0) v0 = 0.0;
+          if (k1) v1 = 0.0;
+          double qv0, qv1;
+          matvec(v0, v1, qv0, qv1);
+          ++it;
+          qv0 = on0 ? qv0 - c0 : 0.0;
+          qv1 = on1 ? qv1 - c1 : 0.0;
+          const double Fv = 0.5 * sm_sum(v0 * (qv0 - c0) + v1 * (qv1 - c1)) + penalty(v0, v1);
+          // Close to the minimiser a step that still halves the gradient changes the objective by less than its rounding
+          // noise (the error enters F squared): such a step -- full, nothing clipped -- is judged by the face's gradient
+          bool by_gradient = false;
+          if (!(Fv < Fy) && tr == 0 && __ballot(k0 || k1) == 0ull && Fv <= Fy + 1e-12 * fabs(Fy)) {
+            // (penalty() left the image of v in vu)
+            double nv0 = 0.0, nv1 = 0.0;
+            if (real0 && f0) {
+              double ss = 0.0;
+              for (int mm = 0; mm < gn0; ++mm) ss = __builtin_fma(vu[gs0 + mm], vu[gs0 + mm], ss);
+              nv0 = sqrt(ss);
+            }
+            if (real1 && f1) {
+              double ss = 0.0;
+              for (int mm = 0; mm < gn1; ++mm) ss = __builtin_fma(vu[gs1 + mm], vu[gs1 + mm], ss);
+              nv1 = sqrt(ss);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double e0 = f0 ? qv0 + copysign(thr0, v0) + (pd0 + ((real0 && nv0 > 0.0) ? pb0 / nv0 : 0.0)) * v0 : 0.0;
+            const double e1 = f1 ? qv1 + copysign(thr1, v1) + (pd1 + ((real1 && nv1 > 0.0) ? pb1 / nv1 : 0.0)) * v1 : 0.0;
+            by_gradient = sm_sum(e0 * e0 + e1 * e1) < 0.25 * g_old;
+          }
+          if (Fv < Fy || by_gradient) {
+            y0 = v0; y1 = v1; qy0 = qv0; qy1 = qv1; Fy = Fv;
+            x0 = y0; x1 = y1;
+            return true;
+          }
+        }
+        return false;
+      };
       while (it < it_cap && !conv) {
         const unsigned long long tka = wall_clock64();
+        // (the Newton steps are spent and the point still has not settled -- a group sliding towards zero, where the
+        //  curvature b / ||x_g|| of its norm blows up and the steps shrink: nearly unpenalised p > n fits of the adaptive
+        //  estimators' later rounds -- the general path's model solver is the better place for it)
+        if (newton_left == 0 && it >= next_newton) break;
+        if (newton_left > 0 && it >= next_newton) {
+          --newton_left;
+          const bool moved = newton();
+          next_newton = it + (moved ? 6 : 40);
+          tk_cg += wall_clock64() - tka;
+          if (moved) nh = 0;  // (the mixing's history belongs to the point left behind)
+        }
         const double t = 1.0 / Lp;
         double g0v, g1v;
         prox(y0 - t * qy0, y1 - t * qy1, t, g0v, g1v);
@@ -998,7 +1112,7 @@ __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
           const int rk0 = __popcll(m0 & below), rk1 = n0 + __popcll(m1 & below);
           if (f0) { fidx[rk0] = s0; fadd[rk0] = pd0; vu[rk0] = c0 - thr0 * sg0; }
           if (f1) { fidx[rk1] = s1; fadd[rk1] = pd1; vu[rk1] = c1 - thr1 * sg1; }
-          if (lane == 0) { sm_m = m; sm_cmd = 2; }
+          if (lane == 0) { sm_m = m; sm_grp = 0; sm_cmd = 2; }
           __syncthreads();
           sm_face_factor(Gs, p, fidx, fadd, m, Ff, fdia, invd, false);
           ++face_solves;

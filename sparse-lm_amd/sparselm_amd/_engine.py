@@ -308,7 +308,9 @@ def _f64(arr, name, shape=None):
 
 
 def _ptr(a):
-    return None if a is None else a.ctypes.data_as(C.c_void_p)
+    # (the address as an int: what a c_void_p argument or field takes; `ctypes.data_as` costs twice as much, and a
+    #  sixteen-lane call asks eighty times)
+    return None if a is None else a.ctypes.data
 
 
 _extrap_cache: dict = {}  # bytes of the points -> secant factors (the folds and rows of a grid walk the same path)
@@ -719,7 +721,10 @@ class Dataset:
 
             def vec(name, size):
                 v = spec.get(name)
-                return None if v is None else _f64(np.broadcast_to(v, (size,)), name)
+                if v is None:
+                    return None
+                v = np.asarray(v)
+                return _f64(v if v.shape == (size,) else np.broadcast_to(v, (size,)), name)
 
             a_, b_, d_ = vec("a", self.p), vec("b", G), vec("d", G)
             pen = _PenaltyStruct(_ptr(a_), _ptr(b_), _ptr(d_))

@@ -1,0 +1,24 @@
+import os, sys, warnings
+import numpy as np
+sys.path.insert(0, "/root/repo/sparse-lm_amd")
+from sklearn.datasets import make_regression
+from sparselm_amd import _engine
+warnings.simplefilter("ignore")
+X, y = make_regression(n_samples=25, n_features=30, n_informative=10, random_state=1)
+Xc = X - X.mean(0); yc = y - y.mean()
+groups = np.arange(30) // 5
+eng = _engine.get_engine(0)
+alpha, eps = 0.1, 1e-8
+with eng.dataset(Xc, yc) as ds:
+    ds.set_groups(groups, 6)
+    b = alpha * np.ones(6)
+    for rnd in range(3):
+        ref = ds.solve_path([(0.0, 1.0, 0.0)], b=b, tol=1e-10, want_group_norms=True)
+        os.environ["SLM_ON_CHIP_NO_FALLBACK"] = "1"
+        r = ds.solve_path([(0.0, 1.0, 0.0)], b=b, tol=1e-10, flags=_engine.FLAG_ON_CHIP, want_group_norms=True)
+        del os.environ["SLM_ON_CHIP_NO_FALLBACK"]
+        print(f"round {rnd}: b = {np.array2string(b, precision=3)}")
+        print(f"   general: conv {ref.converged} passes {ref.grad_launches} gn {np.array2string(ref.group_norms[0], precision=4)}")
+        print(f"   on chip: conv {r.converged} products {r.n_iter[0]} kkt {r.kkt[0]:.3e} resid {r.resid[0]:.3e} mu {r.mu[0]:.3e} L {r.L:.3e} "
+              f"diff {np.max(np.abs(r.betas[0]-ref.betas[0]))/np.max(np.abs(ref.betas[0])):.2e} gn {np.array2string(r.group_norms[0], precision=4)}")
+        b = alpha * alpha / (ref.group_norms[0] + eps)
