@@ -19,7 +19,11 @@
 //   * once the sign pattern has stood still for a few steps and the point has no group norms, conjugate gradients on the
 //     face -- (G_AA + D) x = c_A - thr_A sign(x_A), warm-started, steps cut at the first sign change (that coordinate
 //     leaves the face) -- finish what the proximal steps would crawl along on an ill-conditioned face; the proximal
-//     steps that follow confirm the point or extend the face.
+//     steps that follow confirm the point or extend the face;
+//   * faces those do not settle in 24 steps get a direct solve: L D L^T of the face's matrix by wavefronts 1-3
+//     (sm_face_factor), two triangular solves on wavefront 0 (sm_face_solve), a projected line search;
+//   * points with group norms mix their proximal steps (Anderson acceleration) and take Newton steps on the face of the
+//     iterate with the same factorisation (the group norms' curvature added to the Gram block).
 // A point is accepted by the rule of the general path (fista_tail_kernel): KKT residual of the gradient point -- the
 // proximal-gradient mapping -- below tol * mu * ||b||, mu the smallest curvature <dq, dz> / <dz, dz> measured along the
 // steps (not trusted below 1e-6 lambda_max), with the same rounding floor.  A point that has not got there after
