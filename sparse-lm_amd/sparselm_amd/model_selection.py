@@ -87,6 +87,43 @@ def select_best_index_onestd(results, refit_metric="score"):
     return int(eligible[np.argmin(np.abs(mean[eligible] - target))])
 
 
+class _DatasetLease:
+    """The device dataset of a search, kept across the searches of a `LineSearchCV`: every line is a `GridSearchCV` on
+    the same (X, y), and opening a dataset per line uploaded X once per line (4 GB at the BASELINE shape: as long as the
+    line's search itself).  The lease opens it at the first line and closes it when the line search ends; what was built on
+    it in between -- the column copy of the split pass, the Grams of covariance passes -- stays."""
+
+    def __init__(self, repeats=1):
+        self.ds, self.key, self.repeats = None, None, int(repeats)
+
+    def get(self, grid):
+        key = (id(grid.X_in), id(grid.y_in), grid.intercept, grid.X.shape)
+        if self.ds is None or self.key != key:
+            self.close()
+            self.ds, self.key = grid.open(), key
+        else:
+            grid.adopt(self.ds)
+        return self.ds
+
+    def close(self):
+        if self.ds is not None:
+            self.ds.close()
+            self.ds, self.key = None, None
+
+
+class _Borrowed:
+    """`with` wrapper that leaves the dataset open (the lease closes it)."""
+
+    def __init__(self, ds):
+        self.ds = ds
+
+    def __enter__(self):
+        return self.ds
+
+    def __exit__(self, *exc):
+        return False
+
+
 class GridSearchCV(_GridSearchCV):
     """Exhaustive search over a parameter grid with optional one-standard-error selection.
 
@@ -194,7 +231,8 @@ class GridSearchCV(_GridSearchCV):
         rank, world = D.active_world()
         grid = _DeviceGrid(self, X, y, groups)
         t0 = time.perf_counter()
-        with grid.open() as ds:
+        lease = getattr(self, "_lease", None)
+        with (_Borrowed(lease.get(grid)) if lease is not None else grid.open()) as ds:
             local, unconverged = grid.solve_share(ds, rank, world)
             scores, fit_time = grid.merge(_gather(local, grid.cells, world))
             if unconverged:
@@ -316,6 +354,7 @@ class _DeviceGrid:
     def __init__(self, search, X, y, groups):
         est = search.estimator
         self.search, self.est = search, est
+        self.X_in, self.y_in = X, y  # (the caller's objects: what a lease recognises the next line's data by)
         X, y, groups = indexable(X, y, groups)
         self.X = X = np.asarray(X, dtype=np.float64)
         self.y = y = np.asarray(y, dtype=np.float64)
@@ -373,6 +412,16 @@ class _DeviceGrid:
         ds = _engine.get_engine().dataset(Xd, self.y)
         if self.gidx is not None:
             self._set_groups(ds)
+        self.lanes = max(1, min(int(self.search.lanes), _engine.MAX_LANES, ds.max_lanes(self.opts.get("flags", 0))))
+        self._plan_world = None
+        return ds
+
+    def adopt(self, ds):
+        """`open()` for a dataset another search of the same data has opened (a `_DatasetLease`)."""
+        if self.gidx is not None:
+            self._set_groups(ds)
+        else:
+            ds.set_groups(None)
         self.lanes = max(1, min(int(self.search.lanes), _engine.MAX_LANES, ds.max_lanes(self.opts.get("flags", 0))))
         self._plan_world = None
         return ds
@@ -449,6 +498,9 @@ class _DeviceGrid:
             points = sum(len(idx) for call in calls for lane in call for _, idx in lane)
             if self.adaptive:  # every cell is a loop of re-weighted solves, each a few passes
                 points *= 2 * max(1, int(getattr(self.est, "max_iter", 1)))
+            lease = getattr(self.search, "_lease", None)
+            if lease is not None:  # (a line search: the Grams serve the lines still to come)
+                points *= max(1, lease.repeats)
             over_x = 1.1 * points / max(self.lanes, 1) * (8.0 * n * p / 6.5e12)
             grams = (1.0 + 0.25 * self.n_splits) * 2.0 * n * p * p / 60e12
             if n * p < (1 << 26) or over_x < 2.0 * grams:
@@ -652,6 +704,17 @@ class LineSearchCV(BaseSearchCV):
         n_iter = self.n_iter if (self.n_iter is not None and self.n_iter > 0) else 2 * n_params
         history = []
         best = None
+        lease = _DatasetLease()
+        try:
+            self._fit_lines(X, y, groups, fit_params, n_iter, n_params, methods, history, best, lease)
+        finally:
+            lease.close()
+        self.history_ = history
+        for attr in (v for v in vars(history[-1]) if v.endswith("_") and not v.startswith("__")):
+            setattr(self, attr, getattr(history[-1], attr))
+        return self
+
+    def _fit_lines(self, X, y, groups, fit_params, n_iter, n_params, methods, history, best, lease):
         for i in range(n_iter):
             pid = i % n_params
             last = [values[0] if best is None else best[name] for name, values in self.param_grid]
@@ -672,13 +735,14 @@ class LineSearchCV(BaseSearchCV):
                 error_score=self.error_score,
                 return_train_score=self.return_train_score,
             )
-            search.fit(X, y, groups=groups, **fit_params)
+            lease.repeats = n_iter - i  # the lines still to come on this dataset, this one included
+            search._lease = lease
+            try:
+                search.fit(X, y, groups=groups, **fit_params)
+            finally:
+                del search._lease  # (a private attribute: not a constructor parameter, gone before anyone clones the search)
             best = deepcopy(search.best_params_)
             history.append(search)
-        self.history_ = history
-        for attr in (v for v in vars(history[-1]) if v.endswith("_") and not v.startswith("__")):
-            setattr(self, attr, getattr(history[-1], attr))
-        return self
 
     def _run_search(self, evaluate_candidates):
         """Unused: every line is its own GridSearchCV."""

@@ -450,3 +450,35 @@ def test_the_shares_of_an_eight_rank_search_reproduce_the_one_rank_table(monkeyp
         i = params.index(q)
         for f in range(5):
             assert merged[i, f] == pytest.approx(slow.cv_results_[f"split{f}_test_score"][sp], rel=1e-7)
+
+
+@pytest.mark.gpu
+def test_line_search_keeps_one_device_dataset_for_all_its_lines(monkeypatch):
+    """LineSearchCV (reference model_selection.py:427-707) runs one GridSearchCV per line on the same (X, y): the device
+    dataset is opened once and lent to every line (`_DatasetLease`), and the lines give what stand-alone searches give."""
+    from sparselm_amd import model_selection as ms
+    from sparselm_amd.model import SparseGroupLasso
+
+    rng = np.random.default_rng(11)
+    n, p = 600, 60
+    X = rng.standard_normal((n, p))
+    groups = np.arange(p) // 5
+    coef = np.where(groups < 3, rng.standard_normal(p), 0.0)
+    y = X @ coef + 0.5 * rng.standard_normal(n)
+    grid = [("alpha", list(np.geomspace(1.0, 0.02, 6))), ("l1_ratio", [0.2, 0.5, 0.8])]
+    opened = []
+    real_open = ms._DeviceGrid.open
+    monkeypatch.setattr(ms._DeviceGrid, "open", lambda self: (opened.append(1), real_open(self))[1])
+    est = SparseGroupLasso(groups=groups, fit_intercept=True, solver_options={"tol": 1e-10})
+    line = ms.LineSearchCV(est, grid, cv=3, n_iter=4).fit(X, y)
+    assert len(opened) == 1 and len(line.history_) == 4
+    # the same lines as stand-alone searches
+    best = {"alpha": grid[0][1][0], "l1_ratio": grid[1][1][0]}
+    for i, search in enumerate(line.history_):
+        name, values = grid[i % 2]
+        alone = ms.GridSearchCV(est, {k: (list(values) if k == name else [v]) for k, v in best.items()}, cv=3, refit=line.refit).fit(X, y)
+        np.testing.assert_allclose(search.cv_results_["mean_test_score"], alone.cv_results_["mean_test_score"], rtol=1e-9)
+        assert search.best_params_ == alone.best_params_
+        best = dict(alone.best_params_)
+    assert len(opened) == 1 + 4
+    assert line.best_params_ == best
