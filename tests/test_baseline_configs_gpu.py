@@ -229,6 +229,21 @@ def test_config4_full_size_cells_are_kkt_certified(eng):
         # the four lanes of a unit are one warm-started path: denser towards its end
         nnz = [(o.betas != 0).sum(axis=1) for o in out[:4]]
         assert nnz[3][-1] >= nnz[0][-1]
+        # the same call from the Grams of its two folds (covariance passes, csrc/cov_kernels.hpp): same passes, the same
+        # coefficients to the tolerance, and the cells certified OVER X -- the Grams never enter the check
+        for f in (0, 3):
+            mask = (folds != f).astype(float)
+            ds.covariance(mask, int(mask.sum()))
+        assert ds.covariance_count() == 2
+        cov = ds.solve_lanes(specs, flags=_engine.FLAG_COVARIANCE)
+        assert all(o.converged for o in cov) and abs(cov[0].grad_launches - out[0].grad_launches) <= 2
+        for lane in (0, 7, 12, 15):
+            f, r, al, mask = cells[lane]
+            scale = np.max(np.abs(out[lane].betas))
+            assert np.max(np.abs(cov[lane].betas - out[lane].betas)) < 1e-6 * scale
+            k = len(al) - 1
+            kkt = _kkt_of_cell(ds, cov[lane].betas[k], mask, int(mask.sum()), r * al[k] * np.ones(P), (1 - r) * al[k] * np.ones(G), gidx, G)
+            assert kkt / 0.45 < 1e-6 * max(np.max(np.abs(cov[lane].betas[k])), 1e-300), (lane, kkt)
 
 
 def test_config5_per_rank_share_full_size_with_lanes(eng):
