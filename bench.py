@@ -367,11 +367,15 @@ class Config4:
             c.set_groups(self.groups, self.G)
             self.copies.append(c)
 
-    def close(self):
+    def drop_streams(self):
         for c in self.copies[1:]:
             e = c.engine
             c.close()
             e.close()
+        self.copies = self.copies[:1]
+
+    def close(self):
+        self.drop_streams()
         self.ds.close()
 
 
@@ -409,6 +413,11 @@ def leg_config4_grid(eng, rank, world, n, p, device_id=0, streams=3, emulate_wor
             out["covariance_build_s"] = c4.build_covariance()
             c4.run(mine)
             out["seconds_covariance"], out["passes_covariance"] = min(c4.run(mine) for _ in range(2))
+            if n_streams > 1:  # copies made now share the Grams (slm_dataset_clone)
+                c4.drop_streams()
+                c4.add_streams(n_streams)
+                c4.run(mine, n_streams)
+                out["seconds_covariance_streams"] = min(c4.run(mine, n_streams)[0] for _ in range(2))
         except NotImplementedError as exc:
             out["covariance_error"] = repr(exc)[:200]
         return out
@@ -978,6 +987,8 @@ def main():
                             "fits_per_s": 2500.0 / max(q["seconds_covariance"] for q in parts),
                             "build_s": max(q["covariance_build_s"] for q in parts),
                             "passes_per_rank": [q["passes_covariance"] for q in parts],
+                            "seconds_per_grid_streams": (max(q["seconds_covariance_streams"] for q in parts)
+                                                         if all("seconds_covariance_streams" in q for q in parts) else None),
                         } if all("seconds_covariance" in q for q in parts) else {"error": parts[0].get("covariance_error")}),
                     }
                     if "emulated" in parts[0]:

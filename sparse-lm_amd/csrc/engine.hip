@@ -16,6 +16,7 @@
 #include <cmath>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -407,6 +408,8 @@ struct HostCtl {  // pinned snapshot the host polls
   DevCtl c;
 };
 
+static void pool_free(void* p);
+
 struct slm_dataset {
   slm_engine* eng = nullptr;
   int64_t n = 0, p = 0, ld = 0, n_global = 0;
@@ -433,12 +436,23 @@ struct slm_dataset {
   slm_path_point* h_pts = nullptr;
   int64_t h_pts_cap = 0;
   // covariance passes (cov_kernels.hpp): a Gram per row set, found again by the fingerprint of its row weights
-  struct CovEntry {
+  // (the blocks are shared with the copies of a dataset on further engines of its device -- slm_dataset_clone: the
+  //  streams of a grid search -- and go back when the last holder lets go)
+  struct CovBlocks {
     double *G = nullptr, *c = nullptr;
+    ~CovBlocks() {
+      if (G) pool_free(G);
+      if (c) pool_free(c);
+    }
+  };
+  struct CovEntry {
+    std::shared_ptr<CovBlocks> hold;
+    double *G = nullptr, *c = nullptr;  // = hold->G, hold->c
     double yy = 0.0, n_eff = 0.0, fp1 = 0.0, fp2 = 0.0;
   };
   std::vector<CovEntry> cov;
-  double* cov_all = nullptr;  // X^T X of all rows, unscaled (the minuend of fold Grams), built on first use
+  std::shared_ptr<CovBlocks> cov_all_hold;
+  double* cov_all = nullptr;  // X^T X of all rows, unscaled (the minuend of fold Grams), built on first use (= cov_all_hold->G)
   double* cov_Z = nullptr;    // [ld][16] the lanes' points, lane-minor
   double* cov_fp = nullptr;   // [2 * kMaxLanes + 2] fingerprints / scalars on their way to the host
   double* split_state = nullptr;  // [3 ld + 2 + record] slm_solve_standardized_sgl: gamma, u, rho, valid; outputs
@@ -698,8 +712,10 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
   dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
   dfree(ds->ws_nt); dfree(ds->stop_words); dfree(ds->sse_Z); dfree(ds->sse_part); dfree(ds->split_state);
-  for (auto& e : ds->cov) { dfree(e.G); dfree(e.c); }
-  dfree(ds->cov_all); dfree(ds->cov_Z); dfree(ds->cov_fp);
+  ds->cov.clear();
+  ds->cov_all_hold.reset();
+  ds->cov_all = nullptr;
+  dfree(ds->cov_Z); dfree(ds->cov_fp);
   if (ds->h_split) (void)hipHostFree(ds->h_split);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   if (ds->h_vec) (void)hipHostFree(ds->h_vec);
@@ -941,6 +957,10 @@ extern "C" int slm_dataset_clone(slm_dataset* src, slm_engine* eng, slm_dataset*
   SLM_TRY(slm_dataset_create_device(eng, src->X, src->n, src->p, src->ld, src->y, src->rw, &ds));
   ds->n_global = src->n_global;
   ds->rw_max = src->rw_max;
+  // the Grams of covariance passes built so far are shared, not copied (same device, read-only)
+  ds->cov = src->cov;
+  ds->cov_all_hold = src->cov_all_hold;
+  ds->cov_all = src->cov_all;
   *out = ds;
   return SLM_OK;
 }
@@ -1018,7 +1038,6 @@ extern "C" int slm_dataset_set_targets(slm_dataset* ds, const double* y) {
   HIP_TRY(hipStreamSynchronize(ds->eng->stream));
   HIP_TRY(hipMemcpy(ds->y, y, sizeof(double) * ds->n, hipMemcpyHostToDevice));
   // (the Grams of covariance passes carry X^T W y: gone with the old targets; the Gram of all rows depends on X alone)
-  for (auto& e : ds->cov) { dfree(e.G); dfree(e.c); }
   ds->cov.clear();
   return SLM_OK;
 }
@@ -1421,9 +1440,9 @@ extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y
   HIP_TRY(hipSetDevice(ds->eng->device));
   hipStream_t s = ds->eng->stream;
   // (X and y change in place: the Grams of covariance passes, the Gram of all rows included, go with the old values)
-  for (auto& e : ds->cov) { dfree(e.G); dfree(e.c); }
   ds->cov.clear();
-  dfree(ds->cov_all);
+  ds->cov_all_hold.reset();
+  ds->cov_all = nullptr;
   const int64_t n = ds->n, p = ds->p, ld = ds->ld;
   // sum w, sum w y -- of ALL rows: a row-sharded dataset adds its ranks' sums here and its ranks' X_r^T w_r
   // in the gradient launch below (one all-reduce each), so every rank subtracts the global means
@@ -2688,7 +2707,11 @@ extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight,
   };
   auto ensure_all = [&]() -> int {
     if (ds->cov_all) return SLM_OK;
-    SLM_TRY(dalloc(&ds->cov_all, (size_t)ld * ld));
+    double* all = nullptr;
+    SLM_TRY(dalloc(&all, (size_t)ld * ld));
+    ds->cov_all_hold = std::make_shared<slm_dataset::CovBlocks>();
+    ds->cov_all_hold->G = all;
+    ds->cov_all = all;
     return gram(ds->X, n, ds->cov_all);
   };
   // what kind of weights: none, a 0/1 mask (the Gram of all rows minus the Gram of the rows left out: a fifth of the
@@ -2769,11 +2792,10 @@ extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight,
   guard.e = nullptr;
   // (at most sixteen Grams per dataset -- 3.2 GB at p = 5 000 -- the oldest goes first: searches with fresh CV splits on a
   //  cached dataset would otherwise pile them up)
-  if (ds->cov.size() >= 16) {
-    dfree(ds->cov.front().G);
-    dfree(ds->cov.front().c);
-    ds->cov.erase(ds->cov.begin());
-  }
+  if (ds->cov.size() >= 16) ds->cov.erase(ds->cov.begin());
+  e.hold = std::make_shared<slm_dataset::CovBlocks>();
+  e.hold->G = e.G;
+  e.hold->c = e.c;
   ds->cov.push_back(e);
   return SLM_OK;
 }

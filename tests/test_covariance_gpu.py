@@ -122,3 +122,31 @@ def test_adaptive_grid_search_from_the_folds_grams(eng):
     np.testing.assert_allclose(out[True].cv_results_["mean_test_score"], out[False].cv_results_["mean_test_score"], rtol=1e-7)
     assert out[True].best_params_ == out[False].best_params_
     assert out[True].best_estimator_.n_iter_ == out[False].best_estimator_.n_iter_
+
+
+def test_copies_on_further_engines_share_the_grams(eng):
+    """slm_dataset_clone hands the Grams built so far to the copy (same device, read-only, freed with the last holder): the
+    streams of a grid search read them too.  The copy outlives the original."""
+    n, p = 4000, 240
+    X, y, groups, G, rng = _problem(n, p, seed=9)
+    mask = (rng.permutation(n) % 4 != 0).astype(float)
+    ds = eng.dataset(X, y)
+    ds.set_groups(groups, G)
+    g0, _ = ds.gradient(None)
+    al = np.geomspace(float(np.max(np.abs(g0))), 0.01 * float(np.max(np.abs(g0))), 8)
+    specs = [dict(points=np.c_[0.5 * al, 0.5 * al, 0 * al] * s, row_weight=mask, n_eff=int(mask.sum())) for s in (1.0, 1.2, 0.9)]
+    ref = ds.solve_lanes(specs, tol=1e-10, flags=_engine.FLAG_WORKING_SET)
+    ds.covariance(mask, int(mask.sum()))
+    other = _engine.Engine(0)
+    try:
+        copy = ds.clone(other)
+        copy.set_groups(groups, G)
+        assert copy.covariance_count() == 1
+        ds.close()  # the copy keeps the blocks alive
+        out = copy.solve_lanes(specs, tol=1e-10, flags=_engine.FLAG_WORKING_SET | _engine.FLAG_COVARIANCE)
+        for a, b in zip(ref, out):
+            assert b.converged
+            np.testing.assert_allclose(b.betas, a.betas, rtol=0, atol=1e-9 * np.max(np.abs(a.betas)))
+        copy.close()
+    finally:
+        other.close()
