@@ -482,3 +482,43 @@ def test_line_search_keeps_one_device_dataset_for_all_its_lines(monkeypatch):
         best = dict(alone.best_params_)
     assert len(opened) == 1 + 4
     assert line.best_params_ == best
+
+
+def test_covariance_auto_weighs_the_passes_against_the_grams():
+    """`_DeviceGrid.covariance` (solver_options covariance="auto"): Grams are asked for when the share's expected passes over
+    X cost more than twice the Grams -- not for BASELINE config 4's 2 500 fits, for twenty times as many, and for config 4
+    when a line search has many lines to come; False / True are obeyed; a dataset that cannot build them says no."""
+    from types import SimpleNamespace
+
+    from sparselm_amd import model_selection as ms
+
+    built = []
+
+    class FakeDataset:
+        n, p = 100_000, 5_000
+
+        def covariance(self, mask, n_eff):
+            built.append(n_eff)
+
+    def grid(option, points, adaptive=False, lease=None, lanes=16):
+        g = ms._DeviceGrid.__new__(ms._DeviceGrid)
+        g.est = SimpleNamespace(solver_options={"covariance": option}, max_iter=5)
+        g.search = SimpleNamespace(**({"_lease": lease} if lease is not None else {}))
+        g.adaptive, g.lanes, g.n_splits = adaptive, lanes, 5
+        g.train_masks = [np.ones(4)] * 5
+        calls = [[[(0, list(range(points)))]]]
+        return g, calls
+
+    for option, points, kw, want in (("auto", 2500, {}, False), ("auto", 50_000, {}, True), (False, 50_000, {}, False), (True, 100, {}, True),
+                                     ("auto", 2500, {"lease": SimpleNamespace(repeats=8)}, True), ("auto", 2500, {"adaptive": True}, True)):
+        built.clear()
+        g, calls = grid(option, points, **kw)
+        assert g.covariance(FakeDataset(), calls) is want, (option, points, kw)
+        assert len(built) == (5 if want else 0)
+
+    class Refusing(FakeDataset):
+        def covariance(self, mask, n_eff):
+            raise NotImplementedError("row-sharded")
+
+    g, calls = grid(True, 100)
+    assert g.covariance(Refusing(), calls) is False
