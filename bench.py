@@ -980,8 +980,8 @@ def main():
                         "imbalance_max_over_mean": max(secs) / (sum(secs) / len(secs)),
                         "covariance": ({
                             "what": "the same share with SLM_FLAG_COVARIANCE: every pass reads the Gram of its fold (200 MB) "
-                            "instead of X; the five Grams are built once per dataset (slm_dataset_covariance: the BLAS "
-                            "library's dgemm, its load into the process included the first time) -- worth it when the search is "
+                            "instead of X; the five Grams are built once per dataset (slm_dataset_covariance: cov_syrk_kernel on the "
+                            "matrix cores, all rows once, then a fold's test rows each) -- worth it when the search is "
                             "repeated on the dataset, or its paths end dense (config4_grid_dense_regime)",
                             "seconds_per_grid": max(q["seconds_covariance"] for q in parts),
                             "fits_per_s": 2500.0 / max(q["seconds_covariance"] for q in parts),

@@ -3,8 +3,8 @@
 // G = X^T W X / n and c = X^T W y / n kept per row set: 8 p^2 bytes (200 MB at p = 5 000) instead of the 4 GB of X per
 // pass for sixteen lanes.  The product G Z IS the second half of the split pass with G in the place of X and the lanes'
 // points in the place of the residuals (xtr_mfma_kernel on (G, Z[p][16])); what is here is the little around it:
-// packing Z, the finish g = G z - c with the loss 1/2 z^T G z - c^T z + 1/2 y^T W y / n, and the pieces of building G
-// (the product itself is the BLAS library's dgemm: a plain GEMM, loaded on first use).
+// packing Z, the finish g = G z - c with the loss 1/2 z^T G z - c^T z + 1/2 y^T W y / n, and building G: the product
+// itself (cov_syrk_kernel, on the matrix cores) and the pieces around it.
 // The reference has no counterpart (cvxpy canonicalises X^T X-free conic forms, model/_base.py:414-467); scikit-learn's
 // `precompute=True` of lasso_path is the same idea on the host.
 #pragma once
@@ -173,6 +173,103 @@ __global__ __launch_bounds__(256) void cov_linear_kernel(const double* g, int64_
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j < ld) c[j] = -g[j];
   if (j == 0) yy_out[0] = 2.0 * g[ld];
+}
+
+// ---- the Gram product itself: C = A^T A for the row-major rows x ld block A, on v_mfma_f64_16x16x4_f64 -------------------
+// One workgroup per 128 x 128 tile of the LOWER triangle (tile rows bi >= tile columns bj; the mirror is written with it),
+// four wavefronts as 2 x 2, each a 64 x 64 sub-tile = 4 x 4 result tiles (64 doubles of accumulators per lane).  The
+// contraction runs over the rows of A, four per MFMA: A[i][k] = A_[r + k][i0 + i] and B[k][j] = A_[r + k][j0 + j] are the
+// SAME access -- lane l reads element (row r + (l >> 4), column base + (l & 15)): four rows x 128 contiguous bytes per
+// load instruction -- so both operands come straight from the matrix, no transposed copy, no LDS.  COV_DEPTH steps of loads
+// are in flight ahead of the products (plain register ring, the loop fully unrolled over the ring).  2 rows ld^2 flops on the
+// lower triangle: 2.5 TFLOP at 100 000 x 5 000 -- the matrix cores' fp64 rate bounds it (78 TFLOP/s peak: 32 ms).
+// (Until this kernel the product was the BLAS library's dgemm, 76 ms warm -- and 8-13 s for its first call in a process on
+//  a freshly booted box, while its code objects came off the disk.)
+constexpr int COV_TILE = 128;
+#ifndef SLM_COV_DEPTH
+#define SLM_COV_DEPTH 4
+#endif
+constexpr int COV_DEPTH = SLM_COV_DEPTH;
+
+__global__ __launch_bounds__(256) void cov_syrk_kernel(const double* A, int64_t rows, int64_t ld, double* C) {
+  // tile pair of this workgroup: linear index over the lower triangle, row by row
+  const int nt = (int)((ld + COV_TILE - 1) / COV_TILE);
+  int bi = 0, rest = (int)blockIdx.x;
+  while (rest > bi) {
+    rest -= bi + 1;
+    ++bi;
+  }
+  const int bj = rest;  // bj <= bi
+  (void)nt;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wi = wave >> 1, wj = wave & 1;
+  const int kq = lane >> 4, i16 = lane & 15;
+  const int64_t i0 = (int64_t)bi * COV_TILE + 64 * wi, j0 = (int64_t)bj * COV_TILE + 64 * wj;
+  // columns of this lane's operand elements (clamped inside the matrix: what they bring is never stored)
+  int64_t ca[4], cb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int64_t a_ = i0 + 16 * t + i16, b_ = j0 + 16 * t + i16;
+    ca[t] = a_ < ld ? a_ : ld - 1;
+    cb[t] = b_ < ld ? b_ : ld - 1;
+  }
+  slm_d4 acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = slm_d4{0.0, 0.0, 0.0, 0.0};
+  double ra[COV_DEPTH][4], rb[COV_DEPTH][4];
+  const int64_t steps = (rows + 3) / 4;
+  auto load = [&](int slot, int64_t step) {
+    const int64_t r = step * 4 + kq;
+    const bool ok = r < rows;
+    const double* row = A + (ok ? r : 0) * ld;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ra[slot][t] = ok ? row[ca[t]] : 0.0;
+      rb[slot][t] = ok ? row[cb[t]] : 0.0;
+    }
+  };
+  auto compute = [&](int slot) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[slot][u], rb[slot][v], acc[u][v], 0, 0, 0);
+  };
+#pragma unroll
+  for (int d = 0; d < COV_DEPTH; ++d) load(d, d < steps ? d : steps - 1);  // (steps >= 1)
+  int64_t s = 0;
+  for (; s + COV_DEPTH <= steps - COV_DEPTH; s += COV_DEPTH) {  // whole rings with a full ring behind them
+#pragma unroll
+    for (int d = 0; d < COV_DEPTH; ++d) {
+      compute(d);
+      load(d, s + COV_DEPTH + d);
+    }
+  }
+  for (; s < steps; ++s) {  // the rest: no more loads beyond the end
+    const int slot = (int)(s % COV_DEPTH);
+    // (the ring's slot index has to be a constant for the arrays to stay in registers)
+#pragma unroll
+    for (int d = 0; d < COV_DEPTH; ++d)
+      if (slot == d) {
+        compute(d);
+        if (s + COV_DEPTH < steps) load(d, s + COV_DEPTH);
+      }
+  }
+  // result register q of lane l of tile (u, v): D[i = (l >> 4) + 4 q][j = l & 15]
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t gi = i0 + 16 * u + kq + 4 * q, gj = j0 + 16 * v + i16;
+        if (gi < ld && gj < ld) {
+          const double val = acc[u][v][q];
+          if (bi != bj || gj <= gi) C[gi * ld + gj] = val;          // the lower triangle (diagonal tiles: their own lower half)
+          if (bi != bj || gj < gi) C[gj * ld + gi] = val;           // ... and its mirror
+        }
+      }
 }
 
 }  // namespace slm

@@ -2692,13 +2692,27 @@ extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight,
   double fp[2];
   SLM_TRY(cov_fingerprints(ds, &wdev, 1, fp));
   if (cov_find(ds, fp[0], fp[1], n_eff) >= 0) return SLM_OK;
-  SLM_TRY(load_rocblas());
-  if (!eng->blas) {
-    if (g_blas.Create(&eng->blas) != 0) return fail(SLM_ERR_HIP, "rocblas_create_handle failed");
-    if (g_blas.SetStream(eng->blas, s) != 0) return fail(SLM_ERR_HIP, "rocblas_set_stream failed");
+  // the product: cov_syrk_kernel; SLM_COV_BLAS=1: the BLAS library's dgemm instead (A/B runs, tests)
+  const char* blas_env = getenv("SLM_COV_BLAS");
+  const bool use_blas = blas_env && blas_env[0] == '1';
+  if (use_blas) {
+    SLM_TRY(load_rocblas());
+    if (!eng->blas) {
+      if (g_blas.Create(&eng->blas) != 0) return fail(SLM_ERR_HIP, "rocblas_create_handle failed");
+      if (g_blas.SetStream(eng->blas, s) != 0) return fail(SLM_ERR_HIP, "rocblas_set_stream failed");
+    }
   }
   // C = A^T A for the row-major rows x ld block A (read as the column-major ld x rows matrix it also is)
   auto gram = [&](const double* A, int64_t rows, double* C) -> int {
+    if (!use_blas) {
+      if (rows < 1) {
+        HIP_TRY(hipMemsetAsync(C, 0, sizeof(double) * (size_t)ld * ld, s));
+        return SLM_OK;
+      }
+      const int nt = (int)((ld + COV_TILE - 1) / COV_TILE);
+      hipLaunchKernelGGL(cov_syrk_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, s, A, rows, ld, C);
+      return check_launch();
+    }
     const double one = 1.0, zero = 0.0;
     const int st = g_blas.Dgemm(eng->blas, kRocblasOpNone, kRocblasOpTranspose, (int)ld, (int)ld, (int)rows, &one, A, (int)ld, A,
                                 (int)ld, &zero, C, (int)ld);

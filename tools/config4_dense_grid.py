@@ -42,8 +42,7 @@ t0 = time.perf_counter()
 passes_c = [c4.run_call(c4.ds, call) for call in calls]
 dt_c = time.perf_counter() - t0
 worst = max(float(np.max(np.abs(keep_c[k] - keep_x[k])) / max(np.max(np.abs(keep_x[k])), 1e-300)) for k in keep_x)
-print(f"  with covariance passes (SLM_FLAG_COVARIANCE): five fold Grams built in {t_build:.3f} s (the BLAS library's first call in the process "
-      f"included), then {dt_c:.3f} s per grid, passes per call {passes_c} = {sum(passes_c)}; worst difference of a coefficient vector "
+print(f"  with covariance passes (SLM_FLAG_COVARIANCE): five fold Grams built in {t_build:.3f} s, then {dt_c:.3f} s per grid, passes per call {passes_c} = {sum(passes_c)}; worst difference of a coefficient vector "
       f"to the run over X {worst:.2e} (relative to its largest entry)", flush=True)
 c4.close()
 

@@ -31,3 +31,19 @@ with warnings.catch_warnings():
         print(json.dumps({"rep": rep, "streams": streams, "seconds": round(dt, 3), "search_seconds": round(gs.search_time_, 3), "fits": 2500, "fits_per_s": round(2500 / dt, 1),
                           "best": {k: float(v) for k, v in gs.best_params_.items()}, "best_score": float(gs.best_score_),
                           "nnz_groups": int(np.sum(np.bincount(groups, weights=gs.best_estimator_.coef_ != 0) > 0))}), flush=True)
+    # the same search from the folds' Grams (solver_options covariance=True): the Grams' build is part of the search time
+    for rep, streams in enumerate((1, 1, 3)):
+        t0 = time.perf_counter()
+        gs2 = GridSearchCV(SparseGroupLasso(groups=groups, solver_options={"covariance": True}), grid,
+                           cv=KFold(5, shuffle=True, random_state=0), streams=streams).fit(X, y)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"covariance": True, "rep": rep, "streams": streams, "seconds": round(dt, 3), "search_seconds": round(gs2.search_time_, 3),
+                          "best": {k: float(v) for k, v in gs2.best_params_.items()},
+                          "scores_vs_over_x": float(np.max(np.abs(gs2.cv_results_["mean_test_score"] - gs.cv_results_["mean_test_score"])))}), flush=True)
+    # a line search over the two parameters (reference model_selection.py:427-707): four lines on ONE device dataset
+    from sparselm_amd.model_selection import LineSearchCV
+    t0 = time.perf_counter()
+    ls = LineSearchCV(SparseGroupLasso(groups=groups), [("alpha", grid["alpha"]), ("l1_ratio", grid["l1_ratio"])],
+                      cv=KFold(5, shuffle=True, random_state=0), n_iter=4).fit(X, y)
+    print(json.dumps({"line_search": True, "lines": 4, "seconds": round(time.perf_counter() - t0, 3),
+                      "line_search_seconds": [round(h.search_time_, 3) for h in ls.history_], "best": {k: float(v) for k, v in ls.best_params_.items()}}), flush=True)
