@@ -346,7 +346,7 @@ int slm_solve_standardized_sgl(slm_dataset* ds, const double* a, const double* b
  * dataset's own; n_eff <= 0 = the dataset's row count (the rule of slm_lane).  A 0/1 mask that leaves out at most half
  * of the rows costs the Gram of the rows left out (the Gram of all rows is built once per dataset and kept); other
  * weights cost a scaled copy of X and a full product.  The product is cov_syrk_kernel (fp64 matrix cores, the lower
- * triangle: 65 ms for all rows at 100 000 x 5 000, 14 ms for a fold's test rows).  Worth it when many solves share the row set: the ten
+ * triangle: 50 ms for all rows at 100 000 x 5 000, 11 ms for a fold's test rows).  Worth it when many solves share the row set: the ten
  * l1_ratio rows x fifty alphas of a CV fold, the rounds of an Adaptive* grid.  Replaces nothing in the
  * reference (cvxpy has no Gram form; scikit-learn's lasso_path(precompute=True) is the same idea on the host).
  * SLM_ERR_UNSUPPORTED on row-sharded datasets and rows beyond the split pass's 10 240 columns.  New targets

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void cov_linear_kernel(const double* g, int64_
 }
 
 // ---- the Gram product itself: C = A^T A for the row-major rows x ld block A, on v_mfma_f64_16x16x4_f64 -------------------
-// One workgroup per 128 x 128 tile of the LOWER triangle (tile rows bi >= tile columns bj; the mirror is written with it),
+// One workgroup per 128 x 128 (or 96 x 96) tile of the LOWER triangle (tile rows bi >= tile columns bj; the mirror is written with it),
 // four wavefronts as 2 x 2, each a 64 x 64 sub-tile = 4 x 4 result tiles (64 doubles of accumulators per lane).  The
 // contraction runs over the rows of A, four per MFMA: A[i][k] = A_[r + k][i0 + i] and B[k][j] = A_[r + k][j0 + j] are the
 // SAME access -- lane l reads element (row r + (l >> 4), column base + (l & 15)): four rows x 128 contiguous bytes per
@@ -185,56 +185,59 @@ __global__ __launch_bounds__(256) void cov_linear_kernel(const double* g, int64_
 // lower triangle: 2.5 TFLOP at 100 000 x 5 000 -- the matrix cores' fp64 rate bounds it (78 TFLOP/s peak: 32 ms).
 // (Until this kernel the product was the BLAS library's dgemm, 76 ms warm -- and 8-13 s for its first call in a process on
 //  a freshly booted box, while its code objects came off the disk.)
-constexpr int COV_TILE = 128;
 #ifndef SLM_COV_DEPTH
 #define SLM_COV_DEPTH 4
 #endif
 constexpr int COV_DEPTH = SLM_COV_DEPTH;
 
+// NT: result tiles per side of a wavefront's sub-tile (4: 128 x 128 per workgroup, 3: 96 x 96).  The smaller tile costs a
+// third more loads per product and wins where it fills the CUs' rounds better: 820 tiles of 128 at ld = 5 008 are four rounds
+// of 256 workgroups with the last round almost empty, 1 431 tiles of 96 are six rounds of 56 % the work each (cov_tile_for).
+template <int NT>
 __global__ __launch_bounds__(256) void cov_syrk_kernel(const double* A, int64_t rows, int64_t ld, double* C) {
+  constexpr int COV_TILE = 32 * NT;
+  constexpr int SUB = 16 * NT;  // a wavefront's sub-tile
   // tile pair of this workgroup: linear index over the lower triangle, row by row
-  const int nt = (int)((ld + COV_TILE - 1) / COV_TILE);
   int bi = 0, rest = (int)blockIdx.x;
   while (rest > bi) {
     rest -= bi + 1;
     ++bi;
   }
   const int bj = rest;  // bj <= bi
-  (void)nt;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int wi = wave >> 1, wj = wave & 1;
   const int kq = lane >> 4, i16 = lane & 15;
-  const int64_t i0 = (int64_t)bi * COV_TILE + 64 * wi, j0 = (int64_t)bj * COV_TILE + 64 * wj;
+  const int64_t i0 = (int64_t)bi * COV_TILE + SUB * wi, j0 = (int64_t)bj * COV_TILE + SUB * wj;
   // columns of this lane's operand elements (clamped inside the matrix: what they bring is never stored)
-  int64_t ca[4], cb[4];
+  int64_t ca[NT], cb[NT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < NT; ++t) {
     const int64_t a_ = i0 + 16 * t + i16, b_ = j0 + 16 * t + i16;
     ca[t] = a_ < ld ? a_ : ld - 1;
     cb[t] = b_ < ld ? b_ : ld - 1;
   }
-  slm_d4 acc[4][4];
+  slm_d4 acc[NT][NT];
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < NT; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) acc[u][v] = slm_d4{0.0, 0.0, 0.0, 0.0};
-  double ra[COV_DEPTH][4], rb[COV_DEPTH][4];
+    for (int v = 0; v < NT; ++v) acc[u][v] = slm_d4{0.0, 0.0, 0.0, 0.0};
+  double ra[COV_DEPTH][NT], rb[COV_DEPTH][NT];
   const int64_t steps = (rows + 3) / 4;
   auto load = [&](int slot, int64_t step) {
     const int64_t r = step * 4 + kq;
     const bool ok = r < rows;
     const double* row = A + (ok ? r : 0) * ld;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
       ra[slot][t] = ok ? row[ca[t]] : 0.0;
       rb[slot][t] = ok ? row[cb[t]] : 0.0;
     }
   };
   auto compute = [&](int slot) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < NT; ++u)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[slot][u], rb[slot][v], acc[u][v], 0, 0, 0);
+      for (int v = 0; v < NT; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[slot][u], rb[slot][v], acc[u][v], 0, 0, 0);
   };
 #pragma unroll
   for (int d = 0; d < COV_DEPTH; ++d) load(d, d < steps ? d : steps - 1);  // (steps >= 1)
@@ -258,9 +261,9 @@ __global__ __launch_bounds__(256) void cov_syrk_kernel(const double* A, int64_t 
   }
   // result register q of lane l of tile (u, v): D[i = (l >> 4) + 4 q][j = l & 15]
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < NT; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < NT; ++v)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int64_t gi = i0 + 16 * u + kq + 4 * q, gj = j0 + 16 * v + i16;
@@ -270,6 +273,21 @@ __global__ __launch_bounds__(256) void cov_syrk_kernel(const double* A, int64_t 
           if (bi != bj || gj < gi) C[gj * ld + gi] = val;           // ... and its mirror
         }
       }
+}
+
+// the tile size that costs the fewest rounds x tile area on `cus` compute units (one workgroup per CU at a time)
+static inline int cov_tile_for(int64_t ld, int cus) {
+  double best = 0.0;
+  int pick = 4;
+  for (int nt : {4, 3}) {
+    const int64_t t = 32 * nt, n = (ld + t - 1) / t, tiles = n * (n + 1) / 2;
+    const double cost = (double)((tiles + cus - 1) / cus) * (double)(t * t) * (nt == 3 ? 1.06 : 1.0);  // (more loads per product)
+    if (best == 0.0 || cost < best) {
+      best = cost;
+      pick = nt;
+    }
+  }
+  return pick;
 }
 
 }  // namespace slm

@@ -2709,8 +2709,12 @@ extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight,
         HIP_TRY(hipMemsetAsync(C, 0, sizeof(double) * (size_t)ld * ld, s));
         return SLM_OK;
       }
-      const int nt = (int)((ld + COV_TILE - 1) / COV_TILE);
-      hipLaunchKernelGGL(cov_syrk_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, s, A, rows, ld, C);
+      int side = cov_tile_for(ld, eng->cus);
+      if (const char* e = getenv("SLM_COV_TILE")) side = atoi(e) == 3 ? 3 : 4;  // (A/B runs: 96 or 128 columns per workgroup)
+      const int nt = (int)((ld + 32 * side - 1) / (32 * side));
+      const dim3 grid((unsigned)(nt * (nt + 1) / 2));
+      if (side == 3) hipLaunchKernelGGL(cov_syrk_kernel<3>, grid, dim3(256), 0, s, A, rows, ld, C);
+      else hipLaunchKernelGGL(cov_syrk_kernel<4>, grid, dim3(256), 0, s, A, rows, ld, C);
       return check_launch();
     }
     const double one = 1.0, zero = 0.0;
