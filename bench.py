@@ -298,8 +298,7 @@ class Config4:
         from sparselm_amd import _engine
 
         t0 = time.perf_counter()
-        for m in self.masks:
-            self.ds.covariance(m, int(m.sum()))
+        self.ds.covariance_folds(self.masks, [int(m.sum()) for m in self.masks])
         self.flags |= _engine.FLAG_COVARIANCE
         return time.perf_counter() - t0
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 10
+#define SLM_ABI_VERSION 11
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -354,6 +354,10 @@ int slm_solve_standardized_sgl(slm_dataset* ds, const double* a, const double* b
  * kept per dataset; the oldest goes first.
  */
 int slm_dataset_covariance(slm_dataset* ds, const double* row_weight, int64_t n_eff);
+/* The folds of a K-fold split at once: count (row_weight, n_eff) pairs.  When the masks' zeros are a partition of the rows
+ * -- the test rows of K folds -- the Gram of all rows is the sum of the test rows' Grams and is never formed from X: K
+ * products over n / K rows each.  Anything else is built mask by mask, as by slm_dataset_covariance. */
+int slm_dataset_covariance_folds(slm_dataset* ds, const double* const* row_weights, const int64_t* n_effs, int32_t count);
 int slm_dataset_covariance_count(slm_dataset* ds, int32_t* count_out);
 
 /* ---- row-sharded mode (very tall X split by rows over ranks) ----------------------------------------

@@ -168,6 +168,11 @@ __global__ __launch_bounds__(256) void cov_combine_kernel(const double* A, const
     G[i] = (A[i] - (B ? B[i] : 0.0)) * s;
 }
 
+// G += A, element-wise over count doubles
+__global__ __launch_bounds__(256) void cov_accumulate_kernel(const double* A, int64_t count, double* G) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) G[i] += A[i];
+}
+
 // c = -g, yy = 2 loss from a standard pass at z = 0 (g = -X^T W y / n, loss = y^T W y / (2 n))
 __global__ __launch_bounds__(256) void cov_linear_kernel(const double* g, int64_t ld, double* c, double* yy_out) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;

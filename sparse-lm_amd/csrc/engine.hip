@@ -2668,70 +2668,147 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
 // ------------------------------------------------------------------------------------------------
 // covariance passes: the Gram of a row set
 // ------------------------------------------------------------------------------------------------
-extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight, int64_t n_eff_in) {
+// C = A^T A for the row-major rows x ld block A: cov_syrk_kernel; SLM_COV_BLAS=1: the BLAS library's dgemm instead (A/B runs)
+static int cov_gram(slm_dataset* ds, const double* A, int64_t rows, double* C) {
+  slm_engine* eng = ds->eng;
+  hipStream_t s = eng->stream;
+  const int64_t ld = ds->ld;
+  const char* blas_env = getenv("SLM_COV_BLAS");
+  if (!(blas_env && blas_env[0] == '1')) {
+    if (rows < 1) {
+      HIP_TRY(hipMemsetAsync(C, 0, sizeof(double) * (size_t)ld * ld, s));
+      return SLM_OK;
+    }
+    int side = cov_tile_for(ld, eng->cus);
+    if (const char* e = getenv("SLM_COV_TILE")) side = atoi(e) == 3 ? 3 : 4;  // (A/B runs: 96 or 128 columns per workgroup)
+    const int nt = (int)((ld + 32 * side - 1) / (32 * side));
+    const dim3 grid((unsigned)(nt * (nt + 1) / 2));
+    if (side == 3) hipLaunchKernelGGL(cov_syrk_kernel<3>, grid, dim3(256), 0, s, A, rows, ld, C);
+    else hipLaunchKernelGGL(cov_syrk_kernel<4>, grid, dim3(256), 0, s, A, rows, ld, C);
+    return check_launch();
+  }
+  SLM_TRY(load_rocblas());
+  if (!eng->blas) {
+    if (g_blas.Create(&eng->blas) != 0) return fail(SLM_ERR_HIP, "rocblas_create_handle failed");
+    if (g_blas.SetStream(eng->blas, s) != 0) return fail(SLM_ERR_HIP, "rocblas_set_stream failed");
+  }
+  const double one = 1.0, zero = 0.0;
+  const int st = g_blas.Dgemm(eng->blas, kRocblasOpNone, kRocblasOpTranspose, (int)ld, (int)ld, (int)rows, &one, A, (int)ld, A, (int)ld,
+                              &zero, C, (int)ld);
+  if (st != 0) return fail(SLM_ERR_HIP, "rocblas_dgemm failed (status %d)", st);
+  return SLM_OK;
+}
+
+// the Gram of the rows `rows_host[0..count)` of X (gathered into a block of its own), unscaled, into C
+static int cov_gram_of_rows(slm_dataset* ds, const std::vector<int64_t>& rows_host, double* C) {
+  hipStream_t s = ds->eng->stream;
+  const int64_t ld = ds->ld;
+  if (rows_host.empty()) {
+    HIP_TRY(hipMemsetAsync(C, 0, sizeof(double) * (size_t)ld * ld, s));
+    return SLM_OK;
+  }
+  int64_t* rows = nullptr;
+  double* block = nullptr;
+  int rc = dalloc(&rows, rows_host.size());
+  if (rc == SLM_OK) rc = dalloc(&block, rows_host.size() * (size_t)ld);
+  if (rc == SLM_OK) {
+    hipError_t he = hipMemcpyAsync(rows, rows_host.data(), sizeof(int64_t) * rows_host.size(), hipMemcpyHostToDevice, s);
+    if (he != hipSuccess) rc = fail(SLM_ERR_HIP, "covariance build: %s", hipGetErrorString(he));
+  }
+  if (rc == SLM_OK) {
+    hipLaunchKernelGGL(cov_rows_kernel, dim3((unsigned)rows_host.size()), dim3(256), 0, s, ds->X, ld, rows, nullptr,
+                       (int64_t)rows_host.size(), block);
+    rc = cov_gram(ds, block, (int64_t)rows_host.size(), C);
+  }
+  (void)hipStreamSynchronize(s);  // (the staging blocks go back below; the index list is host memory of the caller)
+  dfree(rows);
+  dfree(block);
+  return rc;
+}
+
+// files the entry of a row set whose scaled Gram G is ready: c = X^T W y / n and y^T W y / n from a standard pass at z = 0.
+// Takes G over (it goes back to the pool if anything fails).
+static int cov_file_entry(slm_dataset* ds, const double* wdev, double n_eff, const double fp[2], double* G) {
+  hipStream_t s = ds->eng->stream;
+  const int64_t ld = ds->ld;
+  slm_dataset::CovEntry e;
+  e.n_eff = n_eff; e.fp1 = fp[0]; e.fp2 = fp[1];
+  e.G = G;
+  struct EntryGuard {  // (whichever way this function is left before the entry is filed, its blocks go back)
+    slm_dataset::CovEntry* e;
+    hipStream_t s;
+    ~EntryGuard() {
+      if (!e) return;
+      (void)hipStreamSynchronize(s);
+      dfree(e->G);
+      dfree(e->c);
+    }
+  } guard{&e, s};
+  SLM_TRY(dalloc(&e.c, (size_t)ld));
+  LaneSetup ls = default_lanes(ds, 1);
+  ls.rw = wdev;
+  ls.rw_stride = 0;
+  ls.n_eff[0] = n_eff;
+  HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * ld, s));
+  if (ds->gk[0]) SLM_TRY(enqueue_gradient(ds, ls, ds->y, nullptr, nullptr, nullptr));
+  else SLM_TRY(enqueue_gradient_split(ds, ls, ds->y, nullptr, nullptr, nullptr, nullptr, nullptr));
+  hipLaunchKernelGGL(cov_linear_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ds->g, ld, e.c, ds->cov_fp);
+  SLM_TRY(check_launch());
+  HIP_TRY(hipMemcpyAsync(&e.yy, ds->cov_fp, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  guard.e = nullptr;
+  // (at most sixteen Grams per dataset -- 3.2 GB at p = 5 000 -- the oldest goes first: searches with fresh CV splits on a
+  //  cached dataset would otherwise pile them up)
+  if (ds->cov.size() >= 16) ds->cov.erase(ds->cov.begin());
+  e.hold = std::make_shared<slm_dataset::CovBlocks>();
+  e.hold->G = e.G;
+  e.hold->c = e.c;
+  ds->cov.push_back(e);
+  return SLM_OK;
+}
+
+static int cov_checks(slm_dataset* ds) {
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  if (ds->eng->sharded()) return fail(SLM_ERR_UNSUPPORTED, "covariance passes are not built for row-sharded datasets");
+  if (!split_usable(ds)) return fail(SLM_ERR_UNSUPPORTED, "covariance passes ride on the split pass (rows of up to 10 240 columns)");
+  return SLM_OK;
+}
+
+static int cov_ensure_all(slm_dataset* ds) {
+  if (ds->cov_all) return SLM_OK;
+  double* all = nullptr;
+  SLM_TRY(dalloc(&all, (size_t)ds->ld * ds->ld));
+  ds->cov_all_hold = std::make_shared<slm_dataset::CovBlocks>();
+  ds->cov_all_hold->G = all;
+  ds->cov_all = all;
+  return cov_gram(ds, ds->X, ds->n, ds->cov_all);
+}
+
+extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight, int64_t n_eff_in) {
+  SLM_TRY(cov_checks(ds));
   slm_engine* eng = ds->eng;
   HIP_TRY(hipSetDevice(eng->device));
   hipStream_t s = eng->stream;
-  if (eng->sharded()) return fail(SLM_ERR_UNSUPPORTED, "covariance passes are not built for row-sharded datasets");
-  if (!split_usable(ds)) return fail(SLM_ERR_UNSUPPORTED, "covariance passes ride on the split pass (rows of up to 10 240 columns)");
   const int64_t n = ds->n, ld = ds->ld;
   const double n_eff = n_eff_in > 0 ? (double)n_eff_in : (double)ds->n_global;
-  double* wown = nullptr;
   struct Temps {
     double *a = nullptr, *b = nullptr;
-    int64_t* rows = nullptr;
-    ~Temps() { dfree(a); dfree(b); dfree(rows); }
+    hipStream_t s;
+    ~Temps() {
+      (void)hipStreamSynchronize(s);
+      dfree(a);
+      dfree(b);
+    }
   } tmp;
+  tmp.s = s;
   if (row_weight) {
     SLM_TRY(dalloc(&tmp.a, (size_t)n));
-    wown = tmp.a;
-    HIP_TRY(hipMemcpyAsync(wown, row_weight, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(tmp.a, row_weight, sizeof(double) * n, hipMemcpyHostToDevice, s));
   }
-  const double* wdev = row_weight ? wown : ds->rw;
+  const double* wdev = row_weight ? tmp.a : ds->rw;
   double fp[2];
   SLM_TRY(cov_fingerprints(ds, &wdev, 1, fp));
   if (cov_find(ds, fp[0], fp[1], n_eff) >= 0) return SLM_OK;
-  // the product: cov_syrk_kernel; SLM_COV_BLAS=1: the BLAS library's dgemm instead (A/B runs, tests)
-  const char* blas_env = getenv("SLM_COV_BLAS");
-  const bool use_blas = blas_env && blas_env[0] == '1';
-  if (use_blas) {
-    SLM_TRY(load_rocblas());
-    if (!eng->blas) {
-      if (g_blas.Create(&eng->blas) != 0) return fail(SLM_ERR_HIP, "rocblas_create_handle failed");
-      if (g_blas.SetStream(eng->blas, s) != 0) return fail(SLM_ERR_HIP, "rocblas_set_stream failed");
-    }
-  }
-  // C = A^T A for the row-major rows x ld block A (read as the column-major ld x rows matrix it also is)
-  auto gram = [&](const double* A, int64_t rows, double* C) -> int {
-    if (!use_blas) {
-      if (rows < 1) {
-        HIP_TRY(hipMemsetAsync(C, 0, sizeof(double) * (size_t)ld * ld, s));
-        return SLM_OK;
-      }
-      int side = cov_tile_for(ld, eng->cus);
-      if (const char* e = getenv("SLM_COV_TILE")) side = atoi(e) == 3 ? 3 : 4;  // (A/B runs: 96 or 128 columns per workgroup)
-      const int nt = (int)((ld + 32 * side - 1) / (32 * side));
-      const dim3 grid((unsigned)(nt * (nt + 1) / 2));
-      if (side == 3) hipLaunchKernelGGL(cov_syrk_kernel<3>, grid, dim3(256), 0, s, A, rows, ld, C);
-      else hipLaunchKernelGGL(cov_syrk_kernel<4>, grid, dim3(256), 0, s, A, rows, ld, C);
-      return check_launch();
-    }
-    const double one = 1.0, zero = 0.0;
-    const int st = g_blas.Dgemm(eng->blas, kRocblasOpNone, kRocblasOpTranspose, (int)ld, (int)ld, (int)rows, &one, A, (int)ld, A,
-                                (int)ld, &zero, C, (int)ld);
-    if (st != 0) return fail(SLM_ERR_HIP, "rocblas_dgemm failed (status %d)", st);
-    return SLM_OK;
-  };
-  auto ensure_all = [&]() -> int {
-    if (ds->cov_all) return SLM_OK;
-    double* all = nullptr;
-    SLM_TRY(dalloc(&all, (size_t)ld * ld));
-    ds->cov_all_hold = std::make_shared<slm_dataset::CovBlocks>();
-    ds->cov_all_hold->G = all;
-    ds->cov_all = all;
-    return gram(ds->X, n, ds->cov_all);
-  };
   // what kind of weights: none, a 0/1 mask (the Gram of all rows minus the Gram of the rows left out: a fifth of the
   // work for a fold of five), or anything else (rows scaled by sqrt(w) into a copy)
   std::vector<double> hw;
@@ -2748,73 +2825,107 @@ extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight,
       if (w_host[i] == 0.0) zeros.push_back(i);
       else if (w_host[i] != 1.0) binary = false;
     }
-  slm_dataset::CovEntry e;
-  e.n_eff = n_eff; e.fp1 = fp[0]; e.fp2 = fp[1];
-  struct EntryGuard {  // (whichever way this function is left before the entry is filed, its blocks go back)
-    slm_dataset::CovEntry* e;
-    hipStream_t s;
-    ~EntryGuard() {
-      if (!e) return;
-      (void)hipStreamSynchronize(s);
-      dfree(e->G);
-      dfree(e->c);
-    }
-  } guard{&e, s};
-  SLM_TRY(dalloc(&e.G, (size_t)ld * ld));
-  SLM_TRY(dalloc(&e.c, (size_t)ld));
+  double* G = nullptr;
+  SLM_TRY(dalloc(&G, (size_t)ld * ld));
   const unsigned cgrid = (unsigned)std::min<int64_t>(4096, (ld * ld + 255) / 256);
   int rc = SLM_OK;
   if (!w_host || (binary && (int64_t)zeros.size() * 2 <= n)) {
-    rc = ensure_all();
-    if (rc == SLM_OK && !zeros.empty()) {
-      rc = dalloc(&tmp.rows, zeros.size());
-      if (rc == SLM_OK) rc = dalloc(&tmp.b, zeros.size() * (size_t)ld);
-      if (rc == SLM_OK) {
-        HIP_TRY(hipMemcpyAsync(tmp.rows, zeros.data(), sizeof(int64_t) * zeros.size(), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(cov_rows_kernel, dim3((unsigned)zeros.size()), dim3(256), 0, s, ds->X, ld, tmp.rows, nullptr,
-                           (int64_t)zeros.size(), tmp.b);
-        rc = gram(tmp.b, (int64_t)zeros.size(), e.G);
-      }
-    }
+    rc = cov_ensure_all(ds);
+    if (rc == SLM_OK && !zeros.empty()) rc = cov_gram_of_rows(ds, zeros, G);
     if (rc == SLM_OK)
-      hipLaunchKernelGGL(cov_combine_kernel, dim3(cgrid), dim3(256), 0, s, ds->cov_all, zeros.empty() ? nullptr : e.G, 1.0 / n_eff,
-                         ld * ld, e.G);
+      hipLaunchKernelGGL(cov_combine_kernel, dim3(cgrid), dim3(256), 0, s, ds->cov_all, zeros.empty() ? nullptr : G, 1.0 / n_eff,
+                         ld * ld, G);
   } else {
     rc = dalloc(&tmp.b, (size_t)n * (size_t)ld);
     if (rc == SLM_OK) {
       hipLaunchKernelGGL(cov_rows_kernel, dim3((unsigned)n), dim3(256), 0, s, ds->X, ld, nullptr, wdev, n, tmp.b);
-      rc = gram(tmp.b, n, e.G);
+      rc = cov_gram(ds, tmp.b, n, G);
     }
-    if (rc == SLM_OK) hipLaunchKernelGGL(cov_combine_kernel, dim3(cgrid), dim3(256), 0, s, e.G, nullptr, 1.0 / n_eff, ld * ld, e.G);
+    if (rc == SLM_OK) hipLaunchKernelGGL(cov_combine_kernel, dim3(cgrid), dim3(256), 0, s, G, nullptr, 1.0 / n_eff, ld * ld, G);
   }
-  // c = X^T W y / n and y^T W y / n: a standard pass at z = 0
-  if (rc == SLM_OK) {
-    LaneSetup ls = default_lanes(ds, 1);
-    ls.rw = wdev;
-    ls.rw_stride = 0;
-    ls.n_eff[0] = n_eff;
-    HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * ld, s));
-    if (ds->gk[0]) rc = enqueue_gradient(ds, ls, ds->y, nullptr, nullptr, nullptr);
-    else rc = enqueue_gradient_split(ds, ls, ds->y, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc != SLM_OK) {
+    (void)hipStreamSynchronize(s);
+    dfree(G);
+    return rc;
   }
-  if (rc == SLM_OK) {
-    hipLaunchKernelGGL(cov_linear_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ds->g, ld, e.c, ds->cov_fp);
-    rc = check_launch();
+  return cov_file_entry(ds, wdev, n_eff, fp, G);
+}
+
+// The folds of a K-fold split at once.  Their test rows are a partition of the rows, so the Gram of ALL rows is the sum of
+// the test rows' Grams: K products over n / K rows each -- one pass' worth of products in all -- instead of that plus a
+// product over all n rows.  Anything that is not such a partition (masks that overlap or leave rows out, weights that
+// are not 0/1, a Gram of all rows that exists already) is built mask by mask (slm_dataset_covariance).
+extern "C" int slm_dataset_covariance_folds(slm_dataset* ds, const double* const* row_weights, const int64_t* n_effs, int32_t count) {
+  SLM_TRY(cov_checks(ds));
+  if (!row_weights || !n_effs || count < 1 || count > kMaxLanes) return fail(SLM_ERR_BAD_ARG, "between 1 and %d row sets", kMaxLanes);
+  slm_engine* eng = ds->eng;
+  HIP_TRY(hipSetDevice(eng->device));
+  hipStream_t s = eng->stream;
+  const int64_t n = ds->n, ld = ds->ld;
+  // a partition of the rows by the masks' zeros?
+  bool partition = count >= 2 && ds->cov_all == nullptr && ds->cov.empty();
+  std::vector<std::vector<int64_t>> zeros((size_t)count);
+  if (partition) {
+    std::vector<unsigned char> seen((size_t)n, 0);
+    for (int f = 0; f < count && partition; ++f) {
+      const double* w = row_weights[f];
+      partition = w != nullptr && n_effs[f] > 0;
+      for (int64_t i = 0; i < n && partition; ++i) {
+        if (w[i] == 0.0) {
+          partition = !seen[(size_t)i];
+          seen[(size_t)i] = 1;
+          zeros[(size_t)f].push_back(i);
+        } else if (w[i] != 1.0) {
+          partition = false;
+        }
+      }
+    }
+    for (int64_t i = 0; i < n && partition; ++i) partition = seen[(size_t)i] != 0;
   }
-  if (rc == SLM_OK) {
-    hipError_t he = hipMemcpyAsync(&e.yy, ds->cov_fp, sizeof(double), hipMemcpyDeviceToHost, s);
-    if (he == hipSuccess) he = hipStreamSynchronize(s);
-    if (he != hipSuccess) rc = fail(SLM_ERR_HIP, "covariance build: %s", hipGetErrorString(he));
+  if (!partition) {
+    for (int f = 0; f < count; ++f) SLM_TRY(slm_dataset_covariance(ds, row_weights[f], n_effs[f]));
+    return SLM_OK;
   }
-  if (rc != SLM_OK) return rc;
-  guard.e = nullptr;
-  // (at most sixteen Grams per dataset -- 3.2 GB at p = 5 000 -- the oldest goes first: searches with fresh CV splits on a
-  //  cached dataset would otherwise pile them up)
-  if (ds->cov.size() >= 16) ds->cov.erase(ds->cov.begin());
-  e.hold = std::make_shared<slm_dataset::CovBlocks>();
-  e.hold->G = e.G;
-  e.hold->c = e.c;
-  ds->cov.push_back(e);
+  struct Blocks {
+    std::vector<double*> G, w;
+    hipStream_t s;
+    ~Blocks() {
+      (void)hipStreamSynchronize(s);
+      for (double* b : G) dfree(b);
+      for (double* b : w) dfree(b);
+    }
+  } blk;
+  blk.s = s;
+  blk.G.assign((size_t)count, nullptr);
+  blk.w.assign((size_t)count, nullptr);
+  const unsigned cgrid = (unsigned)std::min<int64_t>(4096, (ld * ld + 255) / 256);
+  // the test rows' Grams, summed into the Gram of all rows as they come
+  double* all = nullptr;
+  SLM_TRY(dalloc(&all, (size_t)ld * ld));
+  ds->cov_all_hold = std::make_shared<slm_dataset::CovBlocks>();
+  ds->cov_all_hold->G = all;
+  for (int f = 0; f < count; ++f) {
+    SLM_TRY(dalloc(&blk.G[(size_t)f], (size_t)ld * ld));
+    SLM_TRY(dalloc(&blk.w[(size_t)f], (size_t)n));
+    HIP_TRY(hipMemcpyAsync(blk.w[(size_t)f], row_weights[f], sizeof(double) * n, hipMemcpyHostToDevice, s));
+    SLM_TRY(cov_gram_of_rows(ds, zeros[(size_t)f], blk.G[(size_t)f]));
+    // all = G_0 (f = 0), all += G_f: (A - B) * s with B = -... : two steps keep the kernel as it is
+    if (f == 0) HIP_TRY(hipMemcpyAsync(all, blk.G[0], sizeof(double) * (size_t)ld * ld, hipMemcpyDeviceToDevice, s));
+    else hipLaunchKernelGGL(cov_accumulate_kernel, dim3(cgrid), dim3(256), 0, s, blk.G[(size_t)f], ld * ld, all);
+  }
+  SLM_TRY(check_launch());
+  ds->cov_all = all;
+  for (int f = 0; f < count; ++f) {
+    const double n_eff = (double)n_effs[f];
+    const double* wdev = blk.w[(size_t)f];
+    double fp[2];
+    SLM_TRY(cov_fingerprints(ds, &wdev, 1, fp));
+    if (cov_find(ds, fp[0], fp[1], n_eff) >= 0) continue;  // (the same mask twice)
+    double* G = blk.G[(size_t)f];
+    hipLaunchKernelGGL(cov_combine_kernel, dim3(cgrid), dim3(256), 0, s, ds->cov_all, G, 1.0 / n_eff, ld * ld, G);
+    blk.G[(size_t)f] = nullptr;  // (the entry takes it over)
+    SLM_TRY(cov_file_entry(ds, wdev, n_eff, fp, G));
+  }
   return SLM_OK;
 }
 

@@ -43,7 +43,7 @@ FLAG_ON_CHIP = 128  # problems whose Gram matrix fits a workgroup: one launch pe
 FLAG_COVARIANCE = 256  # passes from the Grams of the call's row sets (Dataset.covariance; csrc/cov_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 10  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 11  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -78,6 +78,7 @@ ABI_SYMBOLS = (
     "slm_solve_path_lanes",
     "slm_solve_standardized_sgl",
     "slm_dataset_covariance",
+    "slm_dataset_covariance_folds",
     "slm_dataset_covariance_count",
     "slm_comm_unique_id",
     "slm_comm_init",
@@ -261,6 +262,7 @@ def load_library():
             ],
             "slm_solve_standardized_sgl": [vp, vp, vp, P(_SolveOpts), dbl, i32, vp, i32, vp, vp, P(_PointInfo)],
             "slm_dataset_covariance": [vp, vp, i64],
+            "slm_dataset_covariance_folds": [vp, vp, vp, i32],
             "slm_dataset_covariance_count": [vp, P(i32)],
             "slm_comm_unique_id": [vp],
             "slm_comm_init": [vp, i32, i32, vp],
@@ -811,6 +813,16 @@ class Dataset:
         instead of reading X.  Worth it when many solves share the row set (a fold of a large grid)."""
         rw = None if row_weight is None else _f64(row_weight, "row_weight", (self.n,))
         _check(self._lib.slm_dataset_covariance(self._h, _ptr(rw), int(n_eff)))
+
+    def covariance_folds(self, row_weights, n_effs):
+        """``slm_dataset_covariance_folds``: the Grams of the training sets of a K-fold split at once -- where the test rows
+        partition the rows, the Gram of all rows is the sum of the test rows' Grams and is never formed from X."""
+        rws = [_f64(w, "row_weight", (self.n,)) for w in row_weights]
+        if not 1 <= len(rws) <= MAX_LANES:
+            raise ValueError(f"between 1 and {MAX_LANES} row sets")
+        ptrs = (C.c_void_p * len(rws))(*[w.ctypes.data for w in rws])
+        ne = (C.c_int64 * len(rws))(*[int(v) for v in n_effs])
+        _check(self._lib.slm_dataset_covariance_folds(self._h, ptrs, ne, len(rws)))
 
     def covariance_count(self) -> int:
         out = C.c_int32()

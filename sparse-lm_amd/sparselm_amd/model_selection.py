@@ -483,13 +483,13 @@ class _DeviceGrid:
 
     def covariance(self, ds, calls):
         """Covariance passes for this share (``solver_options={"covariance": True | False | "auto"}``, default "auto"):
-        the Gram of every fold's training rows is built once (``Dataset.covariance``: the Gram of all rows minus the
-        fold's test rows) and every pass of the share reads 8 p^2 bytes per fold instead of X.  "auto" asks whether the
-        passes the share is expected to take over X -- one per path point and sixteen lanes, at the HBM rate -- cost
-        more than twice the Grams (2 n p^2 flops at the matrix cores' fp64 rate for all rows, a fifth of that per fold):
-        true for grids of tens of thousands of fits on a large X, not for BASELINE config 4's 2 500, whose 163 passes
-        cost 0.10 s against 0.16 s of Grams (the grid then runs in 0.054 s instead of 0.147 s: worth asking for when
-        the search is repeated, or when its paths end dense -- DESIGN section 8)."""
+        the Gram of every fold's training rows is built once (``Dataset.covariance_folds``: where the folds' test rows
+        partition the rows -- K-fold -- the Gram of all rows is the sum of the test rows' Grams, one triangle product over n
+        rows in all) and every pass of the share reads 8 p^2 bytes per fold instead of X.  "auto" asks whether what the
+        share's passes save -- one per path point and sixteen lanes; a read of X at the HBM rate against a read of the
+        Gram -- exceeds the Grams by a margin: true for BASELINE config 4 on one GPU (2 500 fits: 0.147 s over X, 0.065 s
+        of Grams + 0.055 s from them), not for its eighth on one of eight ranks (22 passes), nor for splits that are no
+        partition unless the grid is several times larger."""
         want = normalise_options(self.est.solver_options).get("covariance", "auto")
         if want is False:
             return False
@@ -501,13 +501,20 @@ class _DeviceGrid:
             lease = getattr(self.search, "_lease", None)
             if lease is not None:  # (a line search: the Grams serve the lines still to come)
                 points *= max(1, lease.repeats)
-            over_x = 1.1 * points / max(self.lanes, 1) * (8.0 * n * p / 6.5e12)
-            grams = (1.0 + 0.25 * self.n_splits) * 2.0 * n * p * p / 60e12
-            if n * p < (1 << 26) or over_x < 2.0 * grams:
+            passes = 1.1 * points / max(self.lanes, 1)
+            saved = passes * (8.0 * n * p / 6.5e12 - 8.0 * p * p / 5.0e12)
+            tests = getattr(self, "test_masks", None)
+            partition = bool(tests) and len(tests) == self.n_splits and bool(np.all(np.sum(tests, axis=0) == 1.0))
+            triangle = 1.3 * n * p * p / 50e12  # X^T X on the matrix cores (its lower triangle), set-up included
+            grams = triangle if partition else triangle * (1.0 + float(np.mean([1.0 - np.mean(m) for m in self.train_masks])) * self.n_splits)
+            if n * p < (1 << 26) or saved < 1.15 * grams:
                 return False
         try:
-            for m in self.train_masks:
-                ds.covariance(m, int(m.sum()))
+            if len(self.train_masks) <= _engine.MAX_LANES and hasattr(ds, "covariance_folds"):
+                ds.covariance_folds(self.train_masks, [int(m.sum()) for m in self.train_masks])
+            else:
+                for m in self.train_masks:
+                    ds.covariance(m, int(m.sum()))
         except (NotImplementedError, MemoryError):
             return False
         return True

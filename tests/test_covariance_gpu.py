@@ -150,3 +150,42 @@ def test_copies_on_further_engines_share_the_grams(eng):
         copy.close()
     finally:
         other.close()
+
+
+def test_the_folds_of_a_split_at_once(eng):
+    """slm_dataset_covariance_folds: the test rows of a K-fold split partition the rows, so the Gram of all rows is the sum of
+    their Grams -- same entries as mask by mask (found again by either call), same solves; masks that are no partition fall
+    back to the mask-by-mask build."""
+    n, p = 5000, 300
+    X, y, groups, G, rng = _problem(n, p, seed=4)
+    folds = rng.permutation(n) % 4
+    masks = [(folds != f).astype(float) for f in range(4)]
+    nes = [int(m.sum()) for m in masks]
+    with eng.dataset(X, y) as a, eng.dataset(X, y) as b:
+        for ds in (a, b):
+            ds.set_groups(groups, G)
+        a.covariance_folds(masks, nes)
+        assert a.covariance_count() == 4
+        a.covariance(masks[2], nes[2])  # found, not built again
+        assert a.covariance_count() == 4
+        for m, ne in zip(masks, nes):
+            b.covariance(m, ne)
+        g0, _ = a.gradient(None)
+        al = np.geomspace(float(np.max(np.abs(g0))), 0.02 * float(np.max(np.abs(g0))), 8)
+        specs = [dict(points=np.c_[0.4 * al, 0.6 * al, 0 * al] * (1 + 0.1 * (l // 4)), row_weight=masks[l % 4], n_eff=nes[l % 4]) for l in range(12)]
+        flags = _engine.FLAG_WORKING_SET | _engine.FLAG_COVARIANCE
+        ra, rb = a.solve_lanes(specs, tol=1e-10, flags=flags), b.solve_lanes(specs, tol=1e-10, flags=flags)
+        ref = a.solve_lanes(specs, tol=1e-10, flags=_engine.FLAG_WORKING_SET)
+        for u, v, w in zip(ra, rb, ref):
+            assert u.converged and v.converged
+            scale = np.max(np.abs(w.betas))
+            assert np.max(np.abs(u.betas - v.betas)) < 1e-9 * scale and np.max(np.abs(u.betas - w.betas)) < 1e-9 * scale
+    # no partition: overlapping test rows, and a weight that is not 0/1
+    with eng.dataset(X, y) as ds:
+        odd = [masks[0], (rng.permutation(n) % 3 != 0).astype(float), rng.uniform(0.5, 1.5, n)]
+        ds.covariance_folds(odd, [int(odd[0].sum()), int(odd[1].sum()), n])
+        assert ds.covariance_count() == 3
+        one = [dict(points=[(0.1, 0.0, 0.0)], row_weight=odd[2], n_eff=n)]
+        u = ds.solve_lanes(one, tol=1e-10, flags=_engine.FLAG_WORKING_SET)[0]
+        v = ds.solve_lanes(one, tol=1e-10, flags=_engine.FLAG_WORKING_SET | _engine.FLAG_COVARIANCE)[0]
+        np.testing.assert_allclose(v.betas, u.betas, rtol=0, atol=1e-9 * np.max(np.abs(u.betas)))

@@ -485,9 +485,10 @@ def test_line_search_keeps_one_device_dataset_for_all_its_lines(monkeypatch):
 
 
 def test_covariance_auto_weighs_the_passes_against_the_grams():
-    """`_DeviceGrid.covariance` (solver_options covariance="auto"): Grams are asked for when the share's expected passes over
-    X cost more than twice the Grams -- not for BASELINE config 4's 2 500 fits, for twenty times as many, and for config 4
-    when a line search has many lines to come; False / True are obeyed; a dataset that cannot build them says no."""
+    """`_DeviceGrid.covariance` (solver_options covariance="auto"): Grams are asked for when what the share's passes save
+    exceeds them -- for BASELINE config 4's 2 500 fits on a K-fold split (whose test rows partition the rows: one triangle
+    product in all), not for an eighth of it (a rank of eight), not for the same grid on a split that is no partition unless
+    a line search has lines to come; False / True are obeyed; a dataset that cannot build them says no."""
     from types import SimpleNamespace
 
     from sparselm_amd import model_selection as ms
@@ -500,17 +501,21 @@ def test_covariance_auto_weighs_the_passes_against_the_grams():
         def covariance(self, mask, n_eff):
             built.append(n_eff)
 
-    def grid(option, points, adaptive=False, lease=None, lanes=16):
+    def grid(option, points, adaptive=False, lease=None, lanes=16, kfold=True):
         g = ms._DeviceGrid.__new__(ms._DeviceGrid)
         g.est = SimpleNamespace(solver_options={"covariance": option}, max_iter=5)
         g.search = SimpleNamespace(**({"_lease": lease} if lease is not None else {}))
         g.adaptive, g.lanes, g.n_splits = adaptive, lanes, 5
-        g.train_masks = [np.ones(4)] * 5
+        fold = np.arange(10) % 5
+        g.test_masks = [(fold == f).astype(float) for f in range(5)] if kfold else [(np.arange(10) < 2).astype(float)] * 5
+        g.train_masks = [1.0 - t for t in g.test_masks]
         calls = [[[(0, list(range(points)))]]]
         return g, calls
 
-    for option, points, kw, want in (("auto", 2500, {}, False), ("auto", 50_000, {}, True), (False, 50_000, {}, False), (True, 100, {}, True),
-                                     ("auto", 2500, {"lease": SimpleNamespace(repeats=8)}, True), ("auto", 2500, {"adaptive": True}, True)):
+    for option, points, kw, want in (("auto", 2500, {}, True), ("auto", 320, {}, False), ("auto", 2500, {"kfold": False}, False),
+                                     ("auto", 50_000, {"kfold": False}, True), (False, 50_000, {}, False), (True, 100, {}, True),
+                                     ("auto", 2500, {"lease": SimpleNamespace(repeats=8), "kfold": False}, True),
+                                     ("auto", 600, {"adaptive": True}, True)):
         built.clear()
         g, calls = grid(option, points, **kw)
         assert g.covariance(FakeDataset(), calls) is want, (option, points, kw)
