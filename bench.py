@@ -980,11 +980,13 @@ def main():
                         "covariance": ({
                             "what": "the same share with SLM_FLAG_COVARIANCE: every pass reads the Gram of its fold (200 MB) "
                             "instead of X; the five Grams are built once per dataset (slm_dataset_covariance: cov_syrk_kernel on the "
-                            "matrix cores, all rows once, then a fold's test rows each) -- worth it when the search is "
+                            "matrix cores; the test rows of the folds partition the rows, so all five cost one triangle product) -- worth it when "
+                            "build_s + seconds_per_grid beats the grid over X, as here, or the search is "
                             "repeated on the dataset, or its paths end dense (config4_grid_dense_regime)",
                             "seconds_per_grid": max(q["seconds_covariance"] for q in parts),
                             "fits_per_s": 2500.0 / max(q["seconds_covariance"] for q in parts),
                             "build_s": max(q["covariance_build_s"] for q in parts),
+                            "seconds_build_plus_one_grid": max(q["covariance_build_s"] + q["seconds_covariance"] for q in parts),
                             "passes_per_rank": [q["passes_covariance"] for q in parts],
                             "seconds_per_grid_streams": (max(q["seconds_covariance_streams"] for q in parts)
                                                          if all("seconds_covariance_streams" in q for q in parts) else None),
