@@ -165,6 +165,14 @@ class SolveProblem:
         """One minimisation with penalty (a, b, d); returns (beta, group_norms or None, info)."""
         o = self.options
         flags = solve_flags(o)
+        if o.get("covariance") is True:
+            # asked for by name (a single fit never takes it by itself: the Gram of all rows costs about eighty passes
+            # over X): worth it for re-weighting loops with many rounds, refits on a cached dataset, dense solutions
+            try:
+                self.ds.covariance(None, 0)  # (found again in microseconds once built)
+                flags |= _engine.FLAG_COVARIANCE
+            except NotImplementedError:
+                pass
         res = self.ds.solve_path(
             [(1.0, 1.0, 1.0)],
             a=a,

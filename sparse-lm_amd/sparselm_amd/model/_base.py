@@ -36,7 +36,9 @@ class ProxRegressor(RegressorMixin, BaseEstimator):
             solution is accepted at (KKT residual <= tol * mu * ||coef||, mu the strong-convexity estimate of
             the active face; default 1e-10 below 2^26 matrix entries, 1e-8 above: ``_backend.default_tol``),
             ``max_iter`` (10000), ``L`` (Lipschitz constant, default estimated), ``restart`` (True),
-            ``check_every``, ``device``.
+            ``check_every``, ``device``, ``on_chip`` (False: never the one-workgroup solvers), ``covariance`` (True: passes
+            from the Gram of the rows instead of X -- built once per device dataset; "auto", the default, lets a
+            ``GridSearchCV`` decide and a single fit decline).
 
     Attributes:
         coef_ (ndarray of shape (n_features,)), intercept_ (float), solver_info_ (dict).

@@ -189,3 +189,17 @@ def test_the_folds_of_a_split_at_once(eng):
         u = ds.solve_lanes(one, tol=1e-10, flags=_engine.FLAG_WORKING_SET)[0]
         v = ds.solve_lanes(one, tol=1e-10, flags=_engine.FLAG_WORKING_SET | _engine.FLAG_COVARIANCE)[0]
         np.testing.assert_allclose(v.betas, u.betas, rtol=0, atol=1e-9 * np.max(np.abs(u.betas)))
+
+
+def test_a_single_fit_from_the_gram_when_asked(eng):
+    """solver_options={"covariance": True} on an estimator: the fit's passes read the Gram of the (cached) device dataset;
+    same coefficients as the default fit."""
+    from sparselm_amd.model import AdaptiveLasso, Lasso
+
+    n, p = 3000, 250
+    X, y, _, _, _ = _problem(n, p, seed=8)
+    for cls, kw in ((Lasso, dict(alpha=0.3)), (AdaptiveLasso, dict(alpha=0.3, max_iter=4))):
+        a = cls(fit_intercept=True, solver_options={"tol": 1e-10, "on_chip": False}, **kw).fit(X, y)
+        b = cls(fit_intercept=True, solver_options={"tol": 1e-10, "on_chip": False, "covariance": True}, **kw).fit(X, y)
+        np.testing.assert_allclose(b.coef_, a.coef_, rtol=0, atol=1e-8 * np.max(np.abs(a.coef_)))
+        np.testing.assert_allclose(b.intercept_, a.intercept_, rtol=1e-8)
