@@ -491,7 +491,7 @@ class _DeviceGrid:
         of Grams + 0.055 s from them), not for its eighth on one of eight ranks (22 passes), nor for splits that are no
         partition unless the grid is several times larger."""
         want = normalise_options(self.est.solver_options).get("covariance", "auto")
-        if want is False:
+        if want is False or len(self.train_masks) > _engine.MAX_LANES:  # (a dataset keeps sixteen Grams)
             return False
         n, p = ds.n, ds.p
         if want == "auto":
