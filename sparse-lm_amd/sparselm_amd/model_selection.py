@@ -496,13 +496,18 @@ class _DeviceGrid:
         n, p = ds.n, ds.p
         if want == "auto":
             points = sum(len(idx) for call in calls for lane in call for _, idx in lane)
-            if self.adaptive:  # every cell is a loop of re-weighted solves, each a few passes
-                points *= 2 * max(1, int(getattr(self.est, "max_iter", 1)))
+            reads = 1.0  # reads of X per pass
+            if self.adaptive:
+                # every cell is a loop of re-weighted solves, each about four passes, and their warm starts take their
+                # residuals from X too: two reads per pass (measured, 60 cells x 5 rounds at 100 000 x 5 000: 0.186 s of
+                # solves over X, 0.061 s from the Grams -- tools/adaptive_grid_big.py)
+                points *= 4 * max(1, int(getattr(self.est, "max_iter", 1)))
+                reads = 2.0
             lease = getattr(self.search, "_lease", None)
             if lease is not None:  # (a line search: the Grams serve the lines still to come)
                 points *= max(1, lease.repeats)
             passes = 1.1 * points / max(self.lanes, 1)
-            saved = passes * (8.0 * n * p / 6.5e12 - 8.0 * p * p / 5.0e12)
+            saved = passes * (reads * 8.0 * n * p / 6.5e12 - 8.0 * p * p / 5.0e12)
             tests = getattr(self, "test_masks", None)
             partition = bool(tests) and len(tests) == self.n_splits and bool(np.all(np.sum(tests, axis=0) == 1.0))
             triangle = 1.3 * n * p * p / 50e12  # X^T X on the matrix cores (its lower triangle), set-up included

@@ -515,7 +515,7 @@ def test_covariance_auto_weighs_the_passes_against_the_grams():
     for option, points, kw, want in (("auto", 2500, {}, True), ("auto", 320, {}, False), ("auto", 2500, {"kfold": False}, False),
                                      ("auto", 50_000, {"kfold": False}, True), (False, 50_000, {}, False), (True, 100, {}, True),
                                      ("auto", 2500, {"lease": SimpleNamespace(repeats=8), "kfold": False}, True),
-                                     ("auto", 600, {"adaptive": True}, True)):
+                                     ("auto", 60, {"adaptive": True}, True), ("auto", 10, {"adaptive": True}, False)):
         built.clear()
         g, calls = grid(option, points, **kw)
         assert g.covariance(FakeDataset(), calls) is want, (option, points, kw)
