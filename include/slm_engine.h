@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 11
+#define SLM_ABI_VERSION 12
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -358,7 +358,25 @@ int slm_dataset_covariance(slm_dataset* ds, const double* row_weight, int64_t n_
  * -- the test rows of K folds -- the Gram of all rows is the sum of the test rows' Grams and is never formed from X: K
  * products over n / K rows each.  Anything else is built mask by mask, as by slm_dataset_covariance. */
 int slm_dataset_covariance_folds(slm_dataset* ds, const double* const* row_weights, const int64_t* n_effs, int32_t count);
+/* The same in two steps.  _begin queues the products on the engine's stream and returns (*started_out = 0 and nothing queued
+ * when the masks are no such partition: use slm_dataset_covariance then); _finish forms the Grams and files them.  Between the
+ * two the caller may queue other work -- and a REPLICA (slm_dataset_set_replicated) on an engine with a communicator enters
+ * its collective in _finish only: _begin builds the parts of this rank's n_ranks-th of the rows ([X_f^T X_f | X_f^T y_f |
+ * y_f . y_f] of every fold's test rows among them: 1 / n_ranks of the products), _finish sums each part over the ranks (one
+ * all-reduce of ld^2 + ld + 16 doubles per fold on a second stream, part f under way while part f + 1 is still being
+ * multiplied) -- the grid mode's only collective (SURVEY 8e-1 has none; the reference dispatches whole fits,
+ * src/sparselm/model_selection.py:273,304-323).  Every rank must call both with the same masks. */
+int slm_dataset_covariance_folds_begin(slm_dataset* ds, const double* const* row_weights, const int64_t* n_effs, int32_t count,
+                                       int32_t* started_out);
+int slm_dataset_covariance_folds_finish(slm_dataset* ds);
 int slm_dataset_covariance_count(slm_dataset* ds, int32_t* count_out);
+/* Diagnostic (tests): Gram `index` (oldest first) to the host -- G_out p x p (C-order), c_out length p (either may be NULL),
+ * scalars_out = {y^T W y / n_eff, n_eff, the two fingerprint sums of the row weights}. */
+int slm_dataset_covariance_download(slm_dataset* ds, int32_t index, double* G_out, double* c_out, double scalars_out[4]);
+/* On an engine with a communicator a dataset is a row block of one tall matrix (the row-sharded mode below) unless it is
+ * marked as a replica: every rank then holds ALL rows, solves its own lanes without any per-pass collective (grid mode), and
+ * the communicator only carries the folds' Grams (slm_dataset_covariance_folds). */
+int slm_dataset_set_replicated(slm_dataset* ds, int32_t replicated);
 
 /* ---- row-sharded mode (very tall X split by rows over ranks) ----------------------------------------
  * Every rank holds a block of rows and runs the whole state machine; per pass the ranks enter TWO all-reduces: the

@@ -180,6 +180,50 @@ __global__ __launch_bounds__(256) void cov_linear_kernel(const double* g, int64_
   if (j == 0) yy_out[0] = 2.0 * g[ld];
 }
 
+// ---- the folds of a K-fold split, built from gathered blocks of their test rows (engine.hip, cov_folds_begin) ----------
+// R[i][0] = y[rows[i]], the other fifteen lane slots zero: the B operand of xtr_mfma_kernel for X_block^T y_block
+__global__ __launch_bounds__(256) void cov_targets_kernel(const double* y, const int64_t* rows, int64_t m, double* R) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over m * 16
+  if (e >= m * SPLIT_RSTRIDE) return;
+  const int64_t i = e >> 4;
+  R[e] = (e & 15) == 0 ? y[rows ? rows[i] : i] : 0.0;
+}
+
+// t[col] = sum_blk partial[blk][lane 0][col], fixed order; grid = ld / 256 (+1)
+__global__ __launch_bounds__(256) void cov_xty_kernel(const double* partial, int nblk, int64_t ld, double* t) {
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (col >= ld) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * SPLIT_LANES * ld + col];
+  t[col] = s;
+}
+
+// out[0] = sum_i y[rows[i]]^2 (one workgroup, fixed order), out[1..15] = 0
+__global__ __launch_bounds__(1024) void cov_yy_kernel(const double* y, const int64_t* rows, int64_t m, double* out) {
+  __shared__ double red[1024];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < m; i += 1024) {
+    const double v = y[rows ? rows[i] : i];
+    s = __builtin_fma(v, v, s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 512; k >= 1; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x < 16) out[threadIdx.x] = threadIdx.x == 0 ? red[0] : 0.0;
+}
+
+// S[i] = sum_f parts[f * stride + i], f in fixed order, over len doubles
+__global__ __launch_bounds__(256) void cov_sum_kernel(const double* parts, int count, int64_t stride, int64_t len, double* S) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
+    double t = parts[i];
+    for (int f = 1; f < count; ++f) t += parts[(int64_t)f * stride + i];
+    S[i] = t;
+  }
+}
+
 // ---- the Gram product itself: C = A^T A for the row-major rows x ld block A, on v_mfma_f64_16x16x4_f64 -------------------
 // One workgroup per 128 x 128 (or 96 x 96) tile of the LOWER triangle (tile rows bi >= tile columns bj; the mirror is written with it),
 // four wavefronts as 2 x 2, each a 64 x 64 sub-tile = 4 x 4 result tiles (64 doubles of accumulators per lane).  The

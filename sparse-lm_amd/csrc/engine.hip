@@ -314,6 +314,10 @@ struct slm_engine {
   LocalComm* local = nullptr;
   int rank = 0, n_ranks = 1;
   long collectives = 0;  // all-reduces this engine has entered (diagnostics, slm_comm_info)
+  // a second stream for collectives that run beside the solve stream's kernels (the folds' Grams of a replicated
+  // dataset: part f is summed over the ranks while part f + 1 is still being built), made on first use
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ev = nullptr;
   rocblasHandle_t blas = nullptr;  // covariance passes: created on first use
   bool sharded() const { return comm != nullptr || local != nullptr; }
 };
@@ -337,18 +341,9 @@ static bool local_meet(LocalComm* lc, int phase, long round) {
   return lc->cv.wait_for(lk, std::chrono::duration<double>(lc->timeout_s), [&] { return lc->arrived[phase] >= want; });
 }
 
-// sum `count` doubles at `buf` (device) over the ranks, in place, on the engine's stream
-static int all_reduce_sum(slm_engine* eng, double* buf, size_t count) {
-  hipStream_t s = eng->stream;
-  eng->collectives += 1;
-  if (eng->comm) {
-    const int e = g_rccl.AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, eng->comm, s);
-    if (e != 0) return fail(SLM_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "rccl error");
-    return SLM_OK;
-  }
+// one round of the in-process exchange: count <= lc->cap doubles
+static int local_all_reduce_round(slm_engine* eng, double* buf, size_t count, hipStream_t s) {
   LocalComm* lc = eng->local;
-  if (!lc) return SLM_OK;
-  if (count > lc->cap) return fail(SLM_ERR_COMM, "in-process all-reduce of %zu doubles exceeds the staging area (%zu)", count, lc->cap);
   const int r = eng->rank;
   const long round = lc->round_of[r]++;
   const int par = (int)(round & 1);
@@ -376,6 +371,22 @@ static int all_reduce_sum(slm_engine* eng, double* buf, size_t count) {
   // (the `consumed` events of this round must exist before any rank waits on them two rounds from now)
   if (!local_meet(lc, 1, round))
     return fail(SLM_ERR_COMM, "in-process all-reduce %ld: a rank did not finish within %.0f s", round, lc->timeout_s);
+  return SLM_OK;
+}
+
+// sum `count` doubles at `buf` (device) over the ranks, in place, on stream `s` (nullptr: the engine's own).  The
+// in-process communicator moves buffers beyond its staging area in rounds (the folds' Grams: 25 M doubles each).
+static int all_reduce_sum(slm_engine* eng, double* buf, size_t count, hipStream_t s = nullptr) {
+  if (!s) s = eng->stream;
+  eng->collectives += 1;
+  if (eng->comm) {
+    const int e = g_rccl.AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, eng->comm, s);
+    if (e != 0) return fail(SLM_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "rccl error");
+    return SLM_OK;
+  }
+  LocalComm* lc = eng->local;
+  if (!lc) return SLM_OK;
+  for (size_t at = 0; at < count; at += lc->cap) SLM_TRY(local_all_reduce_round(eng, buf + at, std::min(lc->cap, count - at), s));
   return SLM_OK;
 }
 
@@ -413,6 +424,10 @@ static void pool_free(void* p);
 struct slm_dataset {
   slm_engine* eng = nullptr;
   int64_t n = 0, p = 0, ld = 0, n_global = 0;
+  // On an engine with a communicator a dataset is a row block of one tall matrix (every pass all-reduces its gradients),
+  // unless it is marked as a REPLICA (slm_dataset_set_replicated: grid mode -- every rank holds all rows and solves its own
+  // lanes; the communicator then only carries the folds' Grams, each rank building the part of an n_ranks-th of the rows)
+  bool replicated = false;
   double *X = nullptr, *y = nullptr, *rw = nullptr, *yzero = nullptr;
   double rw_max = 1.0;  // largest row weight (1 without row weights; < 0: unknown -- weights handed over on the device)
   double* rw_lanes = nullptr;  // [kMaxLanes][n], allocated when a lane brings its own row weights
@@ -451,6 +466,8 @@ struct slm_dataset {
     double yy = 0.0, n_eff = 0.0, fp1 = 0.0, fp2 = 0.0;
   };
   std::vector<CovEntry> cov;
+  struct CovPending;          // a fold build between slm_dataset_covariance_folds_begin and _finish
+  CovPending* cov_pend = nullptr;
   std::shared_ptr<CovBlocks> cov_all_hold;
   double* cov_all = nullptr;  // X^T X of all rows, unscaled (the minuend of fold Grams), built on first use (= cov_all_hold->G)
   double* cov_Z = nullptr;    // [ld][16] the lanes' points, lane-minor
@@ -488,6 +505,8 @@ struct slm_dataset {
   int L_iters = 0;
   bool L_valid = false;
 };
+
+static inline bool row_sharded(const slm_dataset* ds) { return ds->eng->sharded() && !ds->replicated; }
 
 // Large device blocks (a dataset's X, its column-major copy, the gathered columns: gigabytes each) are recycled: a freed
 // block waits in a per-device list of its exact size, and the next dataset of that shape takes it instead of asking the
@@ -652,6 +671,8 @@ extern "C" int slm_engine_destroy(slm_engine* eng) {
   if (eng->sharded()) (void)slm_comm_destroy(eng);
   // (the BLAS handle is left to the process: engines are destroyed at interpreter exit, when the library's own state may
   //  already be gone)
+  if (eng->comm_ev) (void)hipEventDestroy(eng->comm_ev);
+  if (eng->comm_stream) (void)hipStreamDestroy(eng->comm_stream);
   if (eng->stream) (void)hipStreamDestroy(eng->stream);
   {  // (the recycled blocks do not outlive the engines that could use them)
     std::lock_guard<std::mutex> lk(g_pool.m);
@@ -700,6 +721,7 @@ extern "C" int slm_engine_device_info(slm_engine* eng, int64_t out[6], char* nam
 // ------------------------------------------------------------------------------------------------
 // dataset
 // ------------------------------------------------------------------------------------------------
+static void cov_pending_drop(slm_dataset* ds);
 static void dataset_free(slm_dataset* ds) {
   if (!ds) return;
   dfree(ds->X); dfree(ds->y); dfree(ds->rw); dfree(ds->yzero); dfree(ds->rw_lanes); dfree(ds->rvec);
@@ -712,6 +734,7 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
   dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
   dfree(ds->ws_nt); dfree(ds->stop_words); dfree(ds->sse_Z); dfree(ds->sse_part); dfree(ds->split_state);
+  cov_pending_drop(ds);
   ds->cov.clear();
   ds->cov_all_hold.reset();
   ds->cov_all = nullptr;
@@ -1020,6 +1043,7 @@ extern "C" int slm_dataset_download(slm_dataset* ds, double* X_out, double* y_ou
 }
 
 extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y_mean_out);
+static void cov_pending_drop(slm_dataset* ds);
 
 extern "C" int slm_dataset_set_row_weights(slm_dataset* ds, const double* row_weight) {
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
@@ -1038,6 +1062,7 @@ extern "C" int slm_dataset_set_targets(slm_dataset* ds, const double* y) {
   HIP_TRY(hipStreamSynchronize(ds->eng->stream));
   HIP_TRY(hipMemcpy(ds->y, y, sizeof(double) * ds->n, hipMemcpyHostToDevice));
   // (the Grams of covariance passes carry X^T W y: gone with the old targets; the Gram of all rows depends on X alone)
+  cov_pending_drop(ds);
   ds->cov.clear();
   return SLM_OK;
 }
@@ -1170,7 +1195,7 @@ static int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* 
     ra.loss_scale[l] = 0.5 / ne;
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(ds->ld / 16 + 1), B), dim3(256), 0, s, ra);
-  if (ds->eng->sharded())  // also with one rank: keeps the RCCL path exercised on a single GPU
+  if (row_sharded(ds))  // also with one rank: keeps the RCCL path exercised on a single GPU
     SLM_TRY(all_reduce_sum(ds->eng, ds->g, (size_t)B * (size_t)(ds->ld + 16)));
   return SLM_OK;
 }
@@ -1250,7 +1275,7 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
     ra.loss_scale[l] = 0.5 / ne;
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(ds->ld / 16 + 1), ls.B), dim3(256), 0, s, ra);
-  if (ds->eng->sharded())  // row-sharded: sum the gradients (and losses) of the row blocks over ranks
+  if (row_sharded(ds))  // row-sharded: sum the gradients (and losses) of the row blocks over ranks
     SLM_TRY(all_reduce_sum(ds->eng, ds->g, (size_t)ls.B * (size_t)(ds->ld + 16)));
   return SLM_OK;
 }
@@ -1440,6 +1465,7 @@ extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y
   HIP_TRY(hipSetDevice(ds->eng->device));
   hipStream_t s = ds->eng->stream;
   // (X and y change in place: the Grams of covariance passes, the Gram of all rows included, go with the old values)
+  cov_pending_drop(ds);
   ds->cov.clear();
   ds->cov_all_hold.reset();
   ds->cov_all = nullptr;
@@ -1448,7 +1474,7 @@ extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y
   // in the gradient launch below (one all-reduce each), so every rank subtracts the global means
   // (reference model/_base.py:216-222 on the whole matrix)
   hipLaunchKernelGGL(weighted_sums_kernel, dim3(1), dim3(1024), 0, s, ds->y, ds->rw, n, ds->lambda);
-  if (ds->eng->sharded()) SLM_TRY(all_reduce_sum(ds->eng, ds->lambda, 2));
+  if (row_sharded(ds)) SLM_TRY(all_reduce_sum(ds->eng, ds->lambda, 2));
   double sums[2] = {0.0, 0.0};
   HIP_TRY(hipMemcpyAsync(sums, ds->lambda, sizeof(double) * 2, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1742,7 +1768,7 @@ static bool small_ok(const slm_dataset* ds, uint32_t flags) {
     return false;
   if (const char* env = getenv("SLM_ON_CHIP"))
     if (env[0] == '0') return false;
-  return ds->p <= SM_PMAX && (double)ds->n * (double)ds->ld <= 131072.0 && !ds->eng->sharded();
+  return ds->p <= SM_PMAX && (double)ds->n * (double)ds->ld <= 131072.0 && !row_sharded(ds);
 }
 // most lanes one solve can run: the fused kernels' table, or the split pass's sixteen when the working
 // set is on from the start
@@ -1797,7 +1823,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   const bool wide = ds->sk != nullptr && ds->sk->rowdot == nullptr;
   const bool want_split = (ws_policy(ds, opts ? opts->flags : 0u) == 2 && !wide) ? (big_x || !ds->gk[B - 1]) : (big_x && !ds->gk[B - 1]);
   // (covariance passes are a form of the split pass: the flag asks for it whatever the size, where Grams exist)
-  const bool want_cov = opts && (opts->flags & SLM_FLAG_COVARIANCE) && !ds->cov.empty() && !ds->eng->sharded();
+  const bool want_cov = opts && (opts->flags & SLM_FLAG_COVARIANCE) && !ds->cov.empty() && !row_sharded(ds);
   const bool split = (want_split || want_cov) && split_usable(ds);
   // Shared path with the working set on from the start: the lanes take the points of the path in turn
   // (lane l: l, l + B, ...) instead of contiguous ranges.  Every lane then starts near alpha_max, where
@@ -1830,6 +1856,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     any_gn = any_gn || ln.group_norms_out != nullptr;
   }
   slm_engine* eng = ds->eng;
+  const bool sharded = row_sharded(ds);  // (a replica on an engine with a communicator -- grid mode -- is not)
   HIP_TRY(hipSetDevice(eng->device));
   hipStream_t s = eng->stream;
   // Uploads from the caller's buffers and from the dataset's staging area are asynchronous: whichever way this
@@ -1944,7 +1971,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     const bool sketch = ws_policy(ds, o.flags) == 2 && n >= 65536 && !getenv("SLM_NO_L_SKETCH");
     if (sketch && !(ds->L_valid && !(o.flags & SLM_FLAG_FRESH_L) && !any_rw && !custom_scale)) {
       const bool per_lane = any_rw || custom_scale;
-      bool bounded = per_lane && !eng->sharded();
+      bool bounded = per_lane && !sharded;
       for (int l = 0; l < B && bounded; ++l) bounded = wmax[l] > 0.0;
       if (bounded) {
         // Lanes with their own row weights / scaling (CV folds: 0/1 masks with 1/n_train): ONE estimate, of the
@@ -2137,7 +2164,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   ta.ctl = ds->ctl;
   ta.gdone = reinterpret_cast<int*>(ds->gctl);
   ta.n_lanes = B;
-  ta.done_slot = eng->sharded() ? 3 : 0;
+  ta.done_slot = sharded ? 3 : 0;
   ta.steal = (shared_path && !interleave) ? 1 : 0;  // interleaved lanes are balanced by construction
   ta.pts = ds->pts;
   ta.p = (int)p;
@@ -2271,9 +2298,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     const int pol = ws_policy(ds, o.flags);
     use_ws = pol == 2;
     // (row-sharded: the switch would change the collectives of a pass on the strength of one rank's state)
-    ws_late = pol == 1 && !eng->sharded();
+    ws_late = pol == 1 && !sharded;
   }
-  if (eng->sharded() && !ds->stop_words) SLM_TRY(dalloc(&ds->stop_words, STOP_WORDS));
+  if (sharded && !ds->stop_words) SLM_TRY(dalloc(&ds->stop_words, STOP_WORDS));
   auto ws_setup = [&](bool late) -> int {
     // lanes with the same row weights (same host pointer: the folds of a CV grid) and the same 1/n
     // scaling share one Gram
@@ -2301,7 +2328,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (ds->ws_sets < n_sets) {
       dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
       ds->ws_sets = 0;
-      if (eng->sharded()) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)n_sets * WS_KCAP * WS_KCAP + STOP_WORDS));
+      if (sharded) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)n_sets * WS_KCAP * WS_KCAP + STOP_WORDS));
       SLM_TRY(dalloc(&ds->ws_part, (size_t)ws_nblk * n_sets * WS_KCAP * WS_KCAP));  // (ws_nblk depends on n only)
       SLM_TRY(dalloc(&ds->ws_G, (size_t)n_sets * WS_KCAP * WS_KCAP));
       ds->ws_sets = n_sets;
@@ -2317,8 +2344,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     wa.idx = ds->ws_idx; wa.pos = ds->ws_pos; wa.gs = ds->ws_gs; wa.gl = ds->ws_gl;
     wa.score = ds->ws_score; wa.XW = ds->ws_XW; wa.part = ds->ws_part; wa.Gm = ds->ws_G;
     wa.nt = getenv("SLM_NO_DIRECT") ? nullptr : ds->ws_nt;
-    if (eng->sharded() && !ds->ws_Gx) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)ds->ws_sets * WS_KCAP * WS_KCAP + STOP_WORDS));
-    wa.Gx = eng->sharded() ? ds->ws_Gx : nullptr;  // row-sharded: Gram parts are summed over ranks before use
+    if (sharded && !ds->ws_Gx) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)ds->ws_sets * WS_KCAP * WS_KCAP + STOP_WORDS));
+    wa.Gx = sharded ? ds->ws_Gx : nullptr;  // row-sharded: Gram parts are summed over ranks before use
     wa.X = ds->X; wa.XT = ds->XT; wa.n = n; wa.ld = ld;
     wa.rw = ls.rw; wa.rw_stride = ls.rw_stride;
     for (int l = 0; l < kMaxLanes; ++l) {
@@ -2362,7 +2389,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     // (row-sharded: a rank that fell back on its own would stop entering the per-pass Gram all-reduce while its peers
     //  still do -- mismatched collectives, which RCCL answers with a hang: no memory for the working set is an error
     //  there, reported by the rank that ran out, and the caller frees memory or passes SLM_FLAG_NO_WORKING_SET on all)
-    if (rc == SLM_ERR_OOM && !split && !eng->sharded()) {
+    if (rc == SLM_ERR_OOM && !split && !sharded) {
       ws_release();
       use_ws = false;
     } else if (rc != SLM_OK) {
@@ -2383,7 +2410,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   auto enqueue_tail = [&]() {
     launch_tail(ta, s);
     if (shared_path && !interleave) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
-    if (eng->sharded()) {  // the ranks agree on "finished" before anything acts on it
+    if (sharded) {  // the ranks agree on "finished" before anything acts on it
       if (use_ws && wa.Gx) {
         // working-set solves: the stop words ride behind the staged Gram parts, in the one all-reduce of the refinement
         // (enqueue_refinement) -- two collectives per pass, not three.  Until then this pass's kernels see the flag of
@@ -2501,7 +2528,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         ++enq;
         // behind the pass the solve is expected to end with, the six launches of the refinement would only find
         // out that there is nothing left to refine (30 us): they follow once the snapshot says otherwise
-        deferred = expected > 0 && enq == expected && !eng->sharded();
+        deferred = expected > 0 && enq == expected && !sharded;
         if (!deferred) enqueue_refinement();
       }
       SLM_TRY(check_launch());
@@ -2570,7 +2597,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   HIP_TRY(hipStreamSynchronize(s));
   tr[3] = t_mark();
   const DevCtl& snap = ds->hctl[final_slot].c;  // (nothing in the block changes after `done`)
-  if (eng->sharded() && snap.g.diverged)
+  if (sharded && snap.g.diverged)
     return fail(SLM_ERR_COMM, "row-sharded solve aborted: the ranks' solver states differ (different arguments on "
                 "different ranks, or an all-reduce that is not bit-identical on every rank)");
   const PathCtl* fin = snap.lane;
@@ -2769,7 +2796,7 @@ static int cov_file_entry(slm_dataset* ds, const double* wdev, double n_eff, con
 
 static int cov_checks(slm_dataset* ds) {
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
-  if (ds->eng->sharded()) return fail(SLM_ERR_UNSUPPORTED, "covariance passes are not built for row-sharded datasets");
+  if (row_sharded(ds)) return fail(SLM_ERR_UNSUPPORTED, "covariance passes are not built for row-sharded datasets (replicas: slm_dataset_set_replicated)");
   if (!split_usable(ds)) return fail(SLM_ERR_UNSUPPORTED, "covariance passes ride on the split pass (rows of up to 10 240 columns)");
   return SLM_OK;
 }
@@ -2778,10 +2805,16 @@ static int cov_ensure_all(slm_dataset* ds) {
   if (ds->cov_all) return SLM_OK;
   double* all = nullptr;
   SLM_TRY(dalloc(&all, (size_t)ds->ld * ds->ld));
+  const int rc = cov_gram(ds, ds->X, ds->n, all);
+  if (rc != SLM_OK) {  // (published only once the product is under way: a failed one must not stand in as the minuend)
+    (void)hipStreamSynchronize(ds->eng->stream);
+    dfree(all);
+    return rc;
+  }
   ds->cov_all_hold = std::make_shared<slm_dataset::CovBlocks>();
   ds->cov_all_hold->G = all;
   ds->cov_all = all;
-  return cov_gram(ds, ds->X, ds->n, ds->cov_all);
+  return SLM_OK;
 }
 
 extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight, int64_t n_eff_in) {
@@ -2853,18 +2886,43 @@ extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight,
 
 // The folds of a K-fold split at once.  Their test rows are a partition of the rows, so the Gram of ALL rows is the sum of
 // the test rows' Grams: K products over n / K rows each -- one pass' worth of products in all -- instead of that plus a
-// product over all n rows.  Anything that is not such a partition (masks that overlap or leave rows out, weights that
-// are not 0/1, a Gram of all rows that exists already) is built mask by mask (slm_dataset_covariance).
-extern "C" int slm_dataset_covariance_folds(slm_dataset* ds, const double* const* row_weights, const int64_t* n_effs, int32_t count) {
-  SLM_TRY(cov_checks(ds));
-  if (!row_weights || !n_effs || count < 1 || count > kMaxLanes) return fail(SLM_ERR_BAD_ARG, "between 1 and %d row sets", kMaxLanes);
-  slm_engine* eng = ds->eng;
-  HIP_TRY(hipSetDevice(eng->device));
-  hipStream_t s = eng->stream;
-  const int64_t n = ds->n, ld = ds->ld;
-  // a partition of the rows by the masks' zeros?
+// product over all n rows.  The same sums give the linear terms: X^T W_f y = (sum_g t_g - t_f) with t_g = X_g^T y_g of fold
+// g's test rows (xtr_mfma_kernel on the gathered block and its targets), and y^T W_f y alike -- no pass over X at all.
+// Part f = [Gram of the test rows | t_f | y_f . y_f] is one stretch of `stride` doubles of one block, so that
+//   * a REPLICA on an engine with a communicator (grid mode: slm_dataset_set_replicated) builds the parts from ITS n_ranks-th
+//     of the rows only and the ranks sum them -- one all-reduce per part, on the engine's second stream, entered as soon as
+//     the part is built while the next one is still being multiplied;
+//   * everything behind the parts -- (all - part_f) / n_f, the entries -- is the same with and without ranks.
+// Anything that is not such a partition (masks that overlap or leave rows out, weights that are not 0/1, Grams that exist
+// already) is built mask by mask (slm_dataset_covariance), by every rank for itself.
+struct slm_dataset::CovPending {
+  double *big = nullptr, *all = nullptr;  // [count][stride] parts; [stride] their sum
+  size_t stride = 0;
+  int count = 0;
+  std::vector<double> n_eff, fp;          // per fold; fingerprints of the masks [2 * count]
+  double *block = nullptr, *R16 = nullptr;  // staging of a fold's test rows and their targets (freed by finish)
+  int64_t* rows = nullptr;                // the folds' test-row indices, one list after the other
+  hipEvent_t built[SLM_MAX_LANES] = {};   // part f is complete on the engine's stream
+};
+
+static void cov_pending_drop(slm_dataset* ds) {
+  slm_dataset::CovPending* q = ds->cov_pend;
+  if (!q) return;
+  (void)hipStreamSynchronize(ds->eng->stream);
+  if (ds->eng->comm_stream) (void)hipStreamSynchronize(ds->eng->comm_stream);
+  dfree(q->big); dfree(q->all); dfree(q->block); dfree(q->R16); dfree(q->rows);
+  for (auto& e : q->built)
+    if (e) (void)hipEventDestroy(e);
+  delete q;
+  ds->cov_pend = nullptr;
+}
+
+// 1: the zeros of the masks partition the rows (zeros[f] = test rows of fold f), 0: they do not
+static int cov_partition(const slm_dataset* ds, const double* const* row_weights, const int64_t* n_effs, int count,
+                         std::vector<std::vector<int64_t>>& zeros) {
+  const int64_t n = ds->n;
   bool partition = count >= 2 && ds->cov_all == nullptr && ds->cov.empty();
-  std::vector<std::vector<int64_t>> zeros((size_t)count);
+  zeros.assign((size_t)count, {});
   if (partition) {
     std::vector<unsigned char> seen((size_t)n, 0);
     for (int f = 0; f < count && partition; ++f) {
@@ -2882,49 +2940,202 @@ extern "C" int slm_dataset_covariance_folds(slm_dataset* ds, const double* const
     }
     for (int64_t i = 0; i < n && partition; ++i) partition = seen[(size_t)i] != 0;
   }
-  if (!partition) {
-    for (int f = 0; f < count; ++f) SLM_TRY(slm_dataset_covariance(ds, row_weights[f], n_effs[f]));
-    return SLM_OK;
+  return partition ? 1 : 0;
+}
+
+// queues the parts of this rank's rows on the engine's stream; *started = 0 when the masks are no partition (nothing queued)
+static int cov_folds_begin(slm_dataset* ds, const double* const* row_weights, const int64_t* n_effs, int32_t count, int* started) {
+  *started = 0;
+  SLM_TRY(cov_checks(ds));
+  if (!row_weights || !n_effs || count < 1 || count > kMaxLanes) return fail(SLM_ERR_BAD_ARG, "between 1 and %d row sets", kMaxLanes);
+  if (ds->cov_pend) return fail(SLM_ERR_BAD_ARG, "a fold build is already under way on this dataset (finish it first)");
+  slm_engine* eng = ds->eng;
+  HIP_TRY(hipSetDevice(eng->device));
+  hipStream_t s = eng->stream;
+  const int64_t n = ds->n, ld = ds->ld;
+  std::vector<std::vector<int64_t>> zeros;
+  if (!cov_partition(ds, row_weights, n_effs, count, zeros)) return SLM_OK;
+  // this rank's rows: all of them, or -- a replica among ranks -- a contiguous n_ranks-th
+  int64_t lo = 0, hi = n;
+  if (ds->replicated && eng->sharded()) {
+    const int64_t base = n / eng->n_ranks, rem = n % eng->n_ranks;
+    lo = eng->rank * base + std::min<int64_t>(eng->rank, rem);
+    hi = lo + base + (eng->rank < rem ? 1 : 0);
   }
-  struct Blocks {
-    std::vector<double*> G, w;
-    hipStream_t s;
-    ~Blocks() {
-      (void)hipStreamSynchronize(s);
-      for (double* b : G) dfree(b);
-      for (double* b : w) dfree(b);
-    }
-  } blk;
-  blk.s = s;
-  blk.G.assign((size_t)count, nullptr);
-  blk.w.assign((size_t)count, nullptr);
-  const unsigned cgrid = (unsigned)std::min<int64_t>(4096, (ld * ld + 255) / 256);
-  // the test rows' Grams, summed into the Gram of all rows as they come
-  double* all = nullptr;
-  SLM_TRY(dalloc(&all, (size_t)ld * ld));
-  ds->cov_all_hold = std::make_shared<slm_dataset::CovBlocks>();
-  ds->cov_all_hold->G = all;
+  std::vector<int64_t> rows_host, first((size_t)count + 1, 0);
+  int64_t most = 1;
   for (int f = 0; f < count; ++f) {
-    SLM_TRY(dalloc(&blk.G[(size_t)f], (size_t)ld * ld));
-    SLM_TRY(dalloc(&blk.w[(size_t)f], (size_t)n));
-    HIP_TRY(hipMemcpyAsync(blk.w[(size_t)f], row_weights[f], sizeof(double) * n, hipMemcpyHostToDevice, s));
-    SLM_TRY(cov_gram_of_rows(ds, zeros[(size_t)f], blk.G[(size_t)f]));
-    // all = G_0 (f = 0), all += G_f: (A - B) * s with B = -... : two steps keep the kernel as it is
-    if (f == 0) HIP_TRY(hipMemcpyAsync(all, blk.G[0], sizeof(double) * (size_t)ld * ld, hipMemcpyDeviceToDevice, s));
-    else hipLaunchKernelGGL(cov_accumulate_kernel, dim3(cgrid), dim3(256), 0, s, blk.G[(size_t)f], ld * ld, all);
+    for (int64_t i : zeros[(size_t)f])
+      if (i >= lo && i < hi) rows_host.push_back(i);
+    first[(size_t)f + 1] = (int64_t)rows_host.size();
+    most = std::max(most, first[(size_t)f + 1] - first[(size_t)f]);
+  }
+  slm_dataset::CovPending* q = new slm_dataset::CovPending();
+  ds->cov_pend = q;
+  struct Guard {  // (whichever way this function is left before the parts are queued, the blocks go back)
+    slm_dataset* ds;
+    ~Guard() { if (ds) cov_pending_drop(ds); }
+  } guard{ds};
+  q->count = count;
+  q->stride = (size_t)ld * ld + (size_t)ld + 16;
+  q->n_eff.resize((size_t)count);
+  q->fp.resize(2 * (size_t)count);
+  // fingerprints of the masks first (the one wait of this function; the products are queued behind it)
+  {
+    double* wdev = nullptr;
+    SLM_TRY(dalloc(&wdev, (size_t)count * n));
+    int rc = SLM_OK;
+    const double* wp[SLM_MAX_LANES];
+    for (int f = 0; f < count && rc == SLM_OK; ++f) {
+      q->n_eff[(size_t)f] = (double)n_effs[f];
+      wp[f] = wdev + (size_t)f * n;
+      if (hipMemcpyAsync(wdev + (size_t)f * n, row_weights[f], sizeof(double) * n, hipMemcpyHostToDevice, s) != hipSuccess)
+        rc = fail(SLM_ERR_HIP, "covariance build: upload of a mask failed");
+    }
+    if (rc == SLM_OK) rc = cov_fingerprints(ds, wp, count, q->fp.data());
+    (void)hipStreamSynchronize(s);
+    dfree(wdev);
+    SLM_TRY(rc);
+  }
+  SLM_TRY(dalloc(&q->big, (size_t)count * q->stride));
+  SLM_TRY(dalloc(&q->all, q->stride));
+  SLM_TRY(dalloc(&q->block, (size_t)most * (size_t)ld));
+  SLM_TRY(dalloc(&q->R16, (size_t)most * SPLIT_RSTRIDE));
+  SLM_TRY(dalloc(&q->rows, std::max<size_t>(1, rows_host.size())));
+  if (!rows_host.empty())
+    HIP_TRY(hipMemcpyAsync(q->rows, rows_host.data(), sizeof(int64_t) * rows_host.size(), hipMemcpyHostToDevice, s));
+  int side = cov_tile_for(ld, eng->cus);
+  if (const char* e = getenv("SLM_COV_TILE")) side = atoi(e) == 3 ? 3 : 4;  // (A/B runs: 96 or 128 columns per workgroup)
+  const int nt = (int)((ld + 32 * side - 1) / (32 * side));
+  const dim3 sgrid((unsigned)(nt * (nt + 1) / 2));
+  for (int f = 0; f < count; ++f) {
+    double* part = q->big + (size_t)f * q->stride;
+    const int64_t m = first[(size_t)f + 1] - first[(size_t)f];
+    if (m < 1) {  // (none of the fold's test rows are among this rank's)
+      HIP_TRY(hipMemsetAsync(part, 0, sizeof(double) * q->stride, s));
+    } else {
+      const int64_t* rows = q->rows + first[(size_t)f];
+      hipLaunchKernelGGL(cov_rows_kernel, dim3((unsigned)m), dim3(256), 0, s, ds->X, ld, rows, nullptr, m, q->block);
+      if (side == 3) hipLaunchKernelGGL(cov_syrk_kernel<3>, sgrid, dim3(256), 0, s, q->block, m, ld, part);
+      else hipLaunchKernelGGL(cov_syrk_kernel<4>, sgrid, dim3(256), 0, s, q->block, m, ld, part);
+      // t_f = X_f^T y_f: the second half of the split pass on (block, [y_f, 0 ...])
+      hipLaunchKernelGGL(cov_targets_kernel, dim3((unsigned)((m * SPLIT_RSTRIDE + 255) / 256)), dim3(256), 0, s, ds->y, rows, m, q->R16);
+      SplitArgs a;
+      memset(&a, 0, sizeof(a));
+      a.X = q->block; a.R = q->R16; a.partial = ds->partial; a.n = m; a.ld = ld; a.p2 = (int)(ld / 2); a.n_lanes = 1;
+      const int xblk = launch_xtr(eng->cus, a, s);
+      hipLaunchKernelGGL(cov_xty_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ds->partial, xblk, ld, part + (size_t)ld * ld);
+      hipLaunchKernelGGL(cov_yy_kernel, dim3(1), dim3(1024), 0, s, ds->y, rows, m, part + (size_t)ld * ld + ld);
+    }
+    HIP_TRY(hipEventCreateWithFlags(&q->built[f], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(q->built[f], s));
   }
   SLM_TRY(check_launch());
-  ds->cov_all = all;
-  for (int f = 0; f < count; ++f) {
-    const double n_eff = (double)n_effs[f];
-    const double* wdev = blk.w[(size_t)f];
-    double fp[2];
-    SLM_TRY(cov_fingerprints(ds, &wdev, 1, fp));
-    if (cov_find(ds, fp[0], fp[1], n_eff) >= 0) continue;  // (the same mask twice)
-    double* G = blk.G[(size_t)f];
-    hipLaunchKernelGGL(cov_combine_kernel, dim3(cgrid), dim3(256), 0, s, ds->cov_all, G, 1.0 / n_eff, ld * ld, G);
-    blk.G[(size_t)f] = nullptr;  // (the entry takes it over)
-    SLM_TRY(cov_file_entry(ds, wdev, n_eff, fp, G));
+  guard.ds = nullptr;
+  *started = 1;
+  return SLM_OK;
+}
+
+// sums the parts over the ranks (replicas among ranks), forms the folds' Grams and files the entries
+static int cov_folds_finish(slm_dataset* ds) {
+  slm_dataset::CovPending* q = ds->cov_pend;
+  if (!q) return fail(SLM_ERR_BAD_ARG, "no fold build is under way on this dataset");
+  slm_engine* eng = ds->eng;
+  HIP_TRY(hipSetDevice(eng->device));
+  hipStream_t s = eng->stream;
+  const int64_t ld = ds->ld;
+  struct Guard {
+    slm_dataset* ds;
+    ~Guard() { cov_pending_drop(ds); }
+  } guard{ds};
+  if (ds->replicated && eng->sharded()) {
+    if (!eng->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&eng->comm_stream, hipStreamNonBlocking));
+    if (!eng->comm_ev) HIP_TRY(hipEventCreateWithFlags(&eng->comm_ev, hipEventDisableTiming));
+    hipStream_t cs = eng->comm_stream;
+    for (int f = 0; f < q->count; ++f) {
+      HIP_TRY(hipStreamWaitEvent(cs, q->built[f], 0));
+      SLM_TRY(all_reduce_sum(eng, q->big + (size_t)f * q->stride, q->stride, cs));
+    }
+    HIP_TRY(hipEventRecord(eng->comm_ev, cs));
+    HIP_TRY(hipStreamWaitEvent(s, eng->comm_ev, 0));
+  }
+  const unsigned cgrid = (unsigned)std::min<int64_t>(4096, ((int64_t)q->stride + 255) / 256);
+  hipLaunchKernelGGL(cov_sum_kernel, dim3(cgrid), dim3(256), 0, s, q->big, q->count, (int64_t)q->stride, (int64_t)q->stride, q->all);
+  for (int f = 0; f < q->count; ++f) {
+    double* part = q->big + (size_t)f * q->stride;
+    hipLaunchKernelGGL(cov_combine_kernel, dim3(cgrid), dim3(256), 0, s, q->all, part, 1.0 / q->n_eff[(size_t)f], (int64_t)q->stride, part);
+  }
+  SLM_TRY(check_launch());
+  double yy[SLM_MAX_LANES] = {};
+  for (int f = 0; f < q->count; ++f)
+    HIP_TRY(hipMemcpyAsync(&yy[f], q->big + (size_t)f * q->stride + (size_t)ld * ld + ld, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  // the entries share the block of the parts; the sum stays as the Gram of all rows (its first ld^2 doubles)
+  auto hold = std::make_shared<slm_dataset::CovBlocks>();
+  hold->G = q->big;
+  q->big = nullptr;
+  ds->cov_all_hold = std::make_shared<slm_dataset::CovBlocks>();
+  ds->cov_all_hold->G = q->all;
+  ds->cov_all = q->all;
+  q->all = nullptr;
+  for (int f = 0; f < q->count; ++f) {
+    if (cov_find(ds, q->fp[2 * (size_t)f], q->fp[2 * (size_t)f + 1], q->n_eff[(size_t)f]) >= 0) continue;  // (the same mask twice)
+    slm_dataset::CovEntry e;
+    e.hold = hold;
+    e.G = hold->G + (size_t)f * q->stride;
+    e.c = e.G + (size_t)ld * ld;
+    e.yy = yy[f];
+    e.n_eff = q->n_eff[(size_t)f];
+    e.fp1 = q->fp[2 * (size_t)f];
+    e.fp2 = q->fp[2 * (size_t)f + 1];
+    if (ds->cov.size() >= 16) ds->cov.erase(ds->cov.begin());
+    ds->cov.push_back(e);
+  }
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_covariance_folds_begin(slm_dataset* ds, const double* const* row_weights, const int64_t* n_effs, int32_t count,
+                                                  int32_t* started_out) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  int started = 0;
+  SLM_TRY(cov_folds_begin(ds, row_weights, n_effs, count, &started));
+  if (started_out) *started_out = started;
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_covariance_folds_finish(slm_dataset* ds) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  return cov_folds_finish(ds);
+}
+
+extern "C" int slm_dataset_covariance_folds(slm_dataset* ds, const double* const* row_weights, const int64_t* n_effs, int32_t count) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  int started = 0;
+  SLM_TRY(cov_folds_begin(ds, row_weights, n_effs, count, &started));
+  if (started) return cov_folds_finish(ds);
+  for (int f = 0; f < count; ++f) SLM_TRY(slm_dataset_covariance(ds, row_weights[f], n_effs[f]));
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_set_replicated(slm_dataset* ds, int32_t replicated) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  ds->replicated = replicated != 0;
+  ds->L_valid = false;
+  return SLM_OK;
+}
+
+// Diagnostic: entry `index` (oldest first) of the Grams kept with the dataset, to the host
+extern "C" int slm_dataset_covariance_download(slm_dataset* ds, int32_t index, double* G_out, double* c_out, double scalars_out[4]) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  if (index < 0 || index >= (int32_t)ds->cov.size()) return fail(SLM_ERR_BAD_ARG, "Gram %d of %d", index, (int)ds->cov.size());
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  HIP_TRY(hipStreamSynchronize(ds->eng->stream));
+  const slm_dataset::CovEntry& e = ds->cov[(size_t)index];
+  const int64_t p = ds->p, ld = ds->ld;
+  if (G_out) HIP_TRY(hipMemcpy2D(G_out, sizeof(double) * p, e.G, sizeof(double) * ld, sizeof(double) * p, (size_t)p, hipMemcpyDeviceToHost));
+  if (c_out) HIP_TRY(hipMemcpy(c_out, e.c, sizeof(double) * p, hipMemcpyDeviceToHost));
+  if (scalars_out) {
+    scalars_out[0] = e.yy; scalars_out[1] = e.n_eff; scalars_out[2] = e.fp1; scalars_out[3] = e.fp2;
   }
   return SLM_OK;
 }
@@ -3003,7 +3214,7 @@ extern "C" int slm_solve_standardized_sgl(slm_dataset* ds, const double* a, cons
   const int gm = ds->max_group;
   if (const char* env = getenv("SLM_ON_CHIP"))
     if (env[0] == '0') return fail(SLM_ERR_UNSUPPORTED, "the on-chip solvers are switched off (SLM_ON_CHIP=0)");
-  if (eng->sharded() || ds->rw || p > SM_PMAX || (double)ds->n * (double)ld > 131072.0)
+  if (row_sharded(ds) || ds->rw || p > SM_PMAX || (double)ds->n * (double)ld > 131072.0)
     return fail(SLM_ERR_UNSUPPORTED, "the splitting runs on chip for unweighted, unsharded problems of p <= %d and n * ld <= 131072", SM_PMAX);
   // LDS: Gram matrix, three vectors, the groups' Cholesky factors; what is left stages the rows of the build and
   // then holds the partial products of three wavefronts

@@ -43,7 +43,7 @@ FLAG_ON_CHIP = 128  # problems whose Gram matrix fits a workgroup: one launch pe
 FLAG_COVARIANCE = 256  # passes from the Grams of the call's row sets (Dataset.covariance; csrc/cov_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 11  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 12  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -79,7 +79,11 @@ ABI_SYMBOLS = (
     "slm_solve_standardized_sgl",
     "slm_dataset_covariance",
     "slm_dataset_covariance_folds",
+    "slm_dataset_covariance_folds_begin",
+    "slm_dataset_covariance_folds_finish",
     "slm_dataset_covariance_count",
+    "slm_dataset_covariance_download",
+    "slm_dataset_set_replicated",
     "slm_comm_unique_id",
     "slm_comm_init",
     "slm_comm_info",
@@ -263,7 +267,11 @@ def load_library():
             "slm_solve_standardized_sgl": [vp, vp, vp, P(_SolveOpts), dbl, i32, vp, i32, vp, vp, P(_PointInfo)],
             "slm_dataset_covariance": [vp, vp, i64],
             "slm_dataset_covariance_folds": [vp, vp, vp, i32],
+            "slm_dataset_covariance_folds_begin": [vp, vp, vp, i32, P(i32)],
+            "slm_dataset_covariance_folds_finish": [vp],
             "slm_dataset_covariance_count": [vp, P(i32)],
+            "slm_dataset_covariance_download": [vp, i32, vp, vp, vp],
+            "slm_dataset_set_replicated": [vp, i32],
             "slm_comm_unique_id": [vp],
             "slm_comm_init": [vp, i32, i32, vp],
             "slm_comm_info": [vp, P(i32), P(i32)],
@@ -823,6 +831,36 @@ class Dataset:
         ptrs = (C.c_void_p * len(rws))(*[w.ctypes.data for w in rws])
         ne = (C.c_int64 * len(rws))(*[int(v) for v in n_effs])
         _check(self._lib.slm_dataset_covariance_folds(self._h, ptrs, ne, len(rws)))
+
+    def covariance_folds_begin(self, row_weights, n_effs) -> bool:
+        """First half of ``covariance_folds``: queues the products of THIS rank's rows (all rows without a communicator)
+        and returns; False when the masks are no K-fold partition (nothing queued: use ``covariance``)."""
+        rws = [_f64(w, "row_weight", (self.n,)) for w in row_weights]
+        if not 1 <= len(rws) <= MAX_LANES:
+            raise ValueError(f"between 1 and {MAX_LANES} row sets")
+        ptrs = (C.c_void_p * len(rws))(*[w.ctypes.data for w in rws])
+        ne = (C.c_int64 * len(rws))(*[int(v) for v in n_effs])
+        started = C.c_int32()
+        _check(self._lib.slm_dataset_covariance_folds_begin(self._h, ptrs, ne, len(rws), C.byref(started)))
+        return bool(started.value)
+
+    def covariance_folds_finish(self):
+        """Second half: a replica among ranks sums the parts over the ranks here (the grid mode's one collective), then the
+        folds' Grams are formed and filed."""
+        _check(self._lib.slm_dataset_covariance_folds_finish(self._h))
+
+    def covariance_download(self, index: int):
+        """(G, c, {yy, n_eff, fp}) of Gram ``index`` (oldest first): diagnostics and tests."""
+        G = np.empty((self.p, self.p))
+        c = np.empty(self.p)
+        sc = np.empty(4)
+        _check(self._lib.slm_dataset_covariance_download(self._h, int(index), _ptr(G), _ptr(c), _ptr(sc)))
+        return G, c, {"yy": float(sc[0]), "n_eff": float(sc[1]), "fingerprint": (float(sc[2]), float(sc[3]))}
+
+    def set_replicated(self, replicated: bool = True):
+        """On an engine with a communicator: this dataset holds ALL rows (grid mode), not a row block -- no per-pass
+        collective; the communicator only carries the folds' Grams (``covariance_folds``)."""
+        _check(self._lib.slm_dataset_set_replicated(self._h, int(bool(replicated))))
 
     def covariance_count(self) -> int:
         out = C.c_int32()
