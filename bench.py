@@ -401,6 +401,10 @@ def leg_config4_grid(eng, rank, world, n, p, device_id=0, streams=3, emulate_wor
                 shares.append({"seconds": sec, "passes": pas, "lanes": [len(c) for c in calls], "points": points(calls),
                                "row_masks": [len({c4.units[u][0] for lane in c for u, _ in lane}) for c in calls]})
             out["emulated"] = {"world": emulate_world, "shares": shares}
+            try:
+                out["emulated"]["shared_grams"] = emulate_shared_grams(device_id, n, p, emulate_world)
+            except Exception as exc:  # noqa: BLE001 -- the leg over X stands on its own
+                out["emulated"]["shared_grams"] = {"error": repr(exc)[:300]}
         n_streams = min(streams, len(mine))
         if n_streams > 1:
             c4.add_streams(n_streams)
@@ -422,6 +426,79 @@ def leg_config4_grid(eng, rank, world, n, p, device_id=0, streams=3, emulate_wor
         return out
     finally:
         c4.close()
+
+
+def emulate_shared_grams(device_id, n, p, world):
+    """The grid of config 4 as `world` ranks run it WITH the folds' Grams built together: every rank a
+    replica of (X, y) on an engine of an in-process communicator of this GPU.  Timed per rank, one rank at a time (on a
+    node every rank has its own GPU): (A) the parts of its `world`-th of the rows (`covariance_folds_begin`), (C) its share
+    solved from the Grams; (B) the exchange and the folds' Grams (`covariance_folds_finish`) run on all ranks at once --
+    the collective needs them all -- and are charged 1 / world of their wall time each (bandwidth-bound work of `world`
+    ranks sharing one HBM).  An xGMI ring is modelled beside the in-process exchange, never instead of it."""
+    from sparselm_amd import _engine
+
+    engines = [_engine.Engine(device_id) for _ in range(world)]
+    c4s = []
+    try:
+        for e in engines:  # (before the communicator exists: Config4 evaluates a gradient, which a row block would all-reduce)
+            c4s.append(Config4(e, n, p))
+        _engine.init_local_comm(engines, timeout_s=60.0)
+        for c in c4s:
+            c.ds.set_replicated(True)
+            c.flags |= _engine.FLAG_COVARIANCE
+        masks, n_effs = c4s[0].masks, [int(m.sum()) for m in c4s[0].masks]
+
+        def all_ranks(fn):
+            errors = []
+
+            def run(r):
+                try:
+                    fn(r)
+                except BaseException as exc:  # noqa: BLE001
+                    errors.append(exc)
+
+            threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+            for e in engines:
+                e.synchronize()
+            t0 = time.perf_counter()
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            for e in engines:
+                e.synchronize()
+            if errors:
+                raise errors[0]
+            return time.perf_counter() - t0
+
+        build, finish_wall = [0.0] * world, 0.0
+        for rep in range(2):  # (the first round pays the allocations: a fresh process's one-off)
+            for c in c4s:
+                c.ds.covariance_clear()
+            for r, c in enumerate(c4s):
+                engines[r].synchronize()
+                t0 = time.perf_counter()
+                if not c.ds.covariance_folds_begin(masks, n_effs):
+                    raise RuntimeError("the folds of config 4 are a partition")
+                engines[r].synchronize()
+                build[r] = time.perf_counter() - t0
+            finish_wall = all_ranks(lambda r: c4s[r].ds.covariance_folds_finish())
+        shares = []
+        for r, c in enumerate(c4s):
+            calls = c.calls_of(world, r)
+            c.run(calls)
+            sec, pas = min(c.run(calls) for _ in range(3))
+            shares.append({"build_s": build[r], "solve_s": sec, "passes": pas})
+        ld = c4s[0].ds.ld
+        # per fold: the packed lower triangle (rounded up to 16 doubles), X_f^T y_f and y_f . y_f (cov_folds_begin)
+        exchange_bytes = 8.0 * len(masks) * ((ld * (ld + 1) // 2 + 15) // 16 * 16 + ld + 16)
+        return {"world": world, "shares": shares, "finish_wall_s_all_ranks_on_one_gpu": finish_wall,
+                "exchange_bytes_per_rank": exchange_bytes, "collectives_per_rank": engines[0].comm_collectives() // 2}
+    finally:
+        for c in c4s:
+            c.close()
+        for e in engines:
+            e.close()
 
 
 def leg_config4_dense(eng, n, p, noise_sd=100.0):
@@ -741,6 +818,7 @@ def main():
     ap.add_argument("--no-ws", action="store_true", help="disable the working-set refinement (A/B runs)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-4 grid and row-sharded legs")
+    ap.add_argument("--legs", default="", help="comma-separated names of the extra legs to run (default: all)")
     ap.add_argument("--extra-timeout", type=float, default=240.0, help="hard limit (s) on the extra legs")
     ap.add_argument("--rowshard-rows", type=int, default=125_000, help="rows per rank of the row-sharded leg")
     ap.add_argument("--rowshard-cols", type=int, default=10_000)
@@ -951,6 +1029,8 @@ def main():
                              ("config1_small", lambda: leg_config1_small()),
                              ("concurrent_paths", lambda: leg_concurrent_paths(eng, device_id, rank, n, p, K, args.tol, args.lanes)),
                              ("rowshard", lambda: leg_rowshard(eng, rank, world, args.rowshard_rows, args.rowshard_cols))):
+                if args.legs and name not in args.legs.split(","):
+                    continue
                 try:
                     with StdoutToStderr():
                         mine = {"ok": True, **fn()}
@@ -1008,6 +1088,39 @@ def main():
                             "points_imbalance_max_over_mean": max(q["points"] for q in sh) / (sum(q["points"] for q in sh) / len(sh)),
                             "seconds_imbalance_max_over_mean": worst / (sum(q["seconds"] for q in sh) / len(sh)),
                         }
+                        sg = em.get("shared_grams") or {}
+                        if "shares" in sg:
+                            e8 = legs["config4_grid_emulated_world8"]
+                            w8 = em["world"]
+                            exch = sg["finish_wall_s_all_ranks_on_one_gpu"] / w8
+                            per = [q["build_s"] + exch + q["solve_s"] for q in sg["shares"]]
+                            # an xGMI ring all-reduce of the same bytes: 2 (N - 1) / N x bytes / bus bandwidth
+                            xgmi_busbw = 300e9
+                            ring = 2.0 * (w8 - 1) / w8 * sg["exchange_bytes_per_rank"] / xgmi_busbw
+                            per_ring = [q["build_s"] + max(exch, ring) + q["solve_s"] for q in sg["shares"]]
+                            cov = legs[name]["covariance"]
+                            best_one = min(max(secs), cov.get("seconds_build_plus_one_grid", float("inf")))
+                            e8["shared_grams"] = {
+                                "what": "the same 8 ranks with the folds' Grams built TOGETHER: every rank (a replica on an engine of an "
+                                "in-process communicator of this GPU) builds the parts of its eighth of the rows (build_s, timed alone), the "
+                                "ranks sum them and form the Grams (all at once on this one GPU: charged wall / 8 each = exchange_s), and "
+                                "solves its share from the Grams (solve_s, timed alone); share = build + exchange + solve.  "
+                                "*_xgmi_ring: the exchange replaced by max(measured, a modelled ring all-reduce of the same bytes at "
+                                f"{xgmi_busbw / 1e9:.0f} GB/s bus bandwidth) -- a model, stated, not a measurement",
+                                "build_s": [q["build_s"] for q in sg["shares"]], "solve_s": [q["solve_s"] for q in sg["shares"]],
+                                "share_passes": [q["passes"] for q in sg["shares"]], "exchange_s": exch,
+                                "exchange_bytes_per_rank": sg["exchange_bytes_per_rank"], "collectives_per_rank": sg["collectives_per_rank"],
+                                "share_seconds": per, "max_share_s": max(per),
+                                "speedup_vs_one_gpu_over_x": max(secs) / max(per),
+                                "speedup_vs_best_one_gpu": best_one / max(per),
+                                "best_one_gpu_s": best_one,
+                                "best_one_gpu_is": "Grams built + one grid from them" if best_one < max(secs) else "the grid over X",
+                                "xgmi_ring_model_s": ring, "max_share_s_xgmi_ring": max(per_ring),
+                                "speedup_vs_one_gpu_over_x_xgmi_ring": max(secs) / max(per_ring),
+                                "speedup_vs_best_one_gpu_xgmi_ring": best_one / max(per_ring),
+                            }
+                        elif sg:
+                            legs["config4_grid_emulated_world8"]["shared_grams"] = sg
                 elif name == "config4_grid_dense_regime":
                     q = parts[0]
                     if q.get("seconds"):

@@ -370,6 +370,8 @@ int slm_dataset_covariance_folds_begin(slm_dataset* ds, const double* const* row
                                        int32_t* started_out);
 int slm_dataset_covariance_folds_finish(slm_dataset* ds);
 int slm_dataset_covariance_count(slm_dataset* ds, int32_t* count_out);
+/* Drops every Gram built so far (and a build under way): the memory goes back, later solves run over X. */
+int slm_dataset_covariance_clear(slm_dataset* ds);
 /* Diagnostic (tests): Gram `index` (oldest first) to the host -- G_out p x p (C-order), c_out length p (either may be NULL),
  * scalars_out = {y^T W y / n_eff, n_eff, the two fingerprint sums of the row weights}. */
 int slm_dataset_covariance_download(slm_dataset* ds, int32_t index, double* G_out, double* c_out, double scalars_out[4]);

@@ -117,9 +117,15 @@ __global__ __launch_bounds__(256) void ws_gram_cov_kernel(WsArgs w, CovSets cs) 
 }
 
 // ---- building a Gram ------------------------------------------------------------------------------------------------
-// fingerprint of a row-weight vector: two weighted sums with fixed pseudo-random multipliers, one workgroup, fixed order
-__global__ __launch_bounds__(1024) void cov_fingerprint_kernel(const double* w, int64_t n, double* out) {
+// fingerprint of a row-weight vector: two weighted sums with fixed pseudo-random multipliers, one workgroup per vector
+// (grid = vectors: they run side by side), fixed order
+struct CovFpArgs {
+  const double* w[SLM_MAX_LANES];
+};
+__global__ __launch_bounds__(1024) void cov_fingerprint_kernel(CovFpArgs fa, int64_t n, double* out_all) {
   __shared__ double r1[1024], r2[1024];
+  const double* w = fa.w[blockIdx.x];
+  double* out = out_all + 2 * blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += 1024) {
     const uint64_t h = (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull;
@@ -160,6 +166,18 @@ __global__ __launch_bounds__(256) void cov_rows_kernel(const double* X, int64_t 
     v.y *= s;
     out[j] = v;
   }
+}
+
+// the same into a block padded with rows of zeros: T[r][:] = X[rows[r]][:] for r < n_rows, 0 for n_rows <= r < gridDim.x
+__global__ __launch_bounds__(256) void cov_rows_pad_kernel(const double* X, int64_t ld, const int64_t* rows, int64_t n_rows, double* T) {
+  const int64_t r = blockIdx.x;
+  double2* out = reinterpret_cast<double2*>(T + r * ld);
+  if (r >= n_rows) {
+    for (int64_t j = threadIdx.x; j < ld / 2; j += 256) out[j] = double2{0.0, 0.0};
+    return;
+  }
+  const double2* in = reinterpret_cast<const double2*>(X + rows[r] * ld);
+  for (int64_t j = threadIdx.x; j < ld / 2; j += 256) out[j] = in[j];
 }
 
 // G = (A - B) * s  (B == nullptr: G = A * s), element-wise over count doubles
@@ -221,6 +239,159 @@ __global__ __launch_bounds__(256) void cov_sum_kernel(const double* parts, int c
     double t = parts[i];
     for (int f = 1; f < count; ++f) t += parts[(int64_t)f * stride + i];
     S[i] = t;
+  }
+}
+
+// ---- the folds' parts as PACKED lower triangles -------------------------------------------------------------------------
+// P[i (i + 1) / 2 + j], j <= i < ld: half the bytes of the square in everything that follows the products -- the ranks' sum,
+// the folds' sum, (all - part) / n -- until cov_unpack_kernel writes the square a pass reads.
+__host__ __device__ inline int64_t cov_tri(int64_t i, int64_t j) { return i * (i + 1) / 2 + j; }
+
+// C = A^T A of up to sixteen row blocks in ONE launch, a 64 x 128 result tile per WAVEFRONT: 32 accumulator tiles = 256
+// registers, the whole AGPR half of a one-wave-per-SIMD budget, so a 4-row step is 32 products for six 16-byte loads per lane
+// -- 4 rows x 256 contiguous bytes per instruction, the two doubles of a lane feeding the even / odd column tile as in
+// xtr_mfma_kernel -- 3 bytes per lane and product where the 48 x 48 sub-tiles of cov_syrk_kernel<3> move 5.3, and it was the
+// memory system, not the matrix pipe, that held that kernel at 44-50 TFLOP/s.  (96 x 96 would be 2.7 bytes, but its 288
+// accumulator registers do not fit the 256 AGPRs: 568 spills.)  Wavefronts are independent (no LDS, no barrier): grid =
+// (tiles / 4, blocks), and the batch is what fills the chip to the last round -- the 1 600 tiles of one fold at ld = 5 008
+// are 1.6 rounds of 1 024 wavefronts, the 8 000 of five folds 7.8.  Tile (bi, bj): rows 64 bi.. of the result (first
+// operand), columns 128 bj.. (second); kept when it touches the lower triangle, 128 bj <= 64 bi + 63 -- block rows 2 m and
+// 2 m + 1 have m + 1 tiles each.  Operand index i of column tile u = 2 c + e stands for matrix column base + 32 c + 2 i + e.
+struct SyrkBatch {
+  const double* A[SLM_MAX_LANES];  // row-major blocks, leading dimension ld
+  int64_t rows[SLM_MAX_LANES];
+  double* P[SLM_MAX_LANES];        // packed lower triangles
+};
+constexpr int SYRK_TI = 64, SYRK_TJ = 128;  // a wavefront's tile: rows x columns of the result
+constexpr int SYRK_NU = SYRK_TI / 16, SYRK_NV = SYRK_TJ / 16;
+constexpr int SYRK_R = 2;  // 4-row steps per register set (two sets: one multiplied, one in flight)
+
+// rows a block of `rows` rows must hold (zeros behind the data): whole rings of steps, and the ring loaded past the end
+static inline int64_t cov_syrk_padded_rows(int64_t rows) {
+  const int64_t steps = (rows + 3) / 4, rounds = (steps + 2 * SYRK_R - 1) / (2 * SYRK_R);
+  return 4 * (2 * SYRK_R * rounds + SYRK_R);
+}
+
+static inline int cov_syrk_tiles(int64_t ld) {
+  const int64_t nbi = (ld + SYRK_TI - 1) / SYRK_TI;
+  int64_t t = 0;
+  for (int64_t bi = 0; bi < nbi; ++bi) t += bi / 2 + 1;
+  return (int)t;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void cov_syrk_packed_kernel(SyrkBatch b, int64_t ld, int n_tiles) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int tile = (int)blockIdx.x * 4 + wave;
+  if (tile >= n_tiles) return;
+  int m = 0;  // pair of block rows: m (m + 1) tiles lie before it
+  while ((m + 1) * (m + 2) <= tile) ++m;
+  const int r = tile - m * (m + 1);
+  const int bi = 2 * m + (r >= m + 1 ? 1 : 0), bj = r >= m + 1 ? r - (m + 1) : r;
+  const double* A = b.A[blockIdx.y];
+  const int64_t rows = b.rows[blockIdx.y];
+  double* P = b.P[blockIdx.y];
+  const int kq = lane >> 4, i16 = lane & 15;
+  const int64_t i0 = (int64_t)bi * SYRK_TI, j0 = (int64_t)bj * SYRK_TJ;
+  int64_t ca[SYRK_NU / 2], cb[SYRK_NV / 2];  // (columns past the row re-read its last pair: what they bring is never stored)
+#pragma unroll
+  for (int c = 0; c < SYRK_NU / 2; ++c) {
+    const int64_t a_ = i0 + 32 * c + 2 * i16;
+    ca[c] = a_ < ld - 2 ? a_ : ld - 2;
+  }
+#pragma unroll
+  for (int c = 0; c < SYRK_NV / 2; ++c) {
+    const int64_t b_ = j0 + 32 * c + 2 * i16;
+    cb[c] = b_ < ld - 2 ? b_ : ld - 2;
+  }
+  slm_d4 acc[SYRK_NU][SYRK_NV];
+#pragma unroll
+  for (int u = 0; u < SYRK_NU; ++u)
+#pragma unroll
+    for (int v = 0; v < SYRK_NV; ++v) acc[u][v] = slm_d4{0.0, 0.0, 0.0, 0.0};
+  // two register sets of SYRK_R steps each: one is multiplied while the other's loads are in flight (the loads of a set are
+  // issued BEFORE the products of the other in program order, so every wait is an exact count -- written as one ring with
+  // the load behind each product, the compiler hoisted all loads to the top of the body and consumed them in the same
+  // iteration).  No test on the row: the block is padded with rows of zeros (cov_syrk_padded_rows), so every load, the
+  // ones past the end included, is a plain load; a select on the loaded value made every load wait for itself.
+  d2 xa[SYRK_R][SYRK_NU / 2], ya[SYRK_R][SYRK_NV / 2], xb[SYRK_R][SYRK_NU / 2], yb[SYRK_R][SYRK_NV / 2];
+  const int64_t steps = (rows + 3) / 4;
+  auto load = [&](d2(&x)[SYRK_R][SYRK_NU / 2], d2(&y)[SYRK_R][SYRK_NV / 2], int64_t step) {
+#pragma unroll
+    for (int t = 0; t < SYRK_R; ++t) {
+      const double* row = A + ((step + t) * 4 + kq) * ld;
+#pragma unroll
+      for (int c = 0; c < SYRK_NU / 2; ++c) x[t][c] = *reinterpret_cast<const d2*>(row + ca[c]);
+#pragma unroll
+      for (int c = 0; c < SYRK_NV / 2; ++c) y[t][c] = *reinterpret_cast<const d2*>(row + cb[c]);
+    }
+  };
+  auto compute = [&](d2(&x)[SYRK_R][SYRK_NU / 2], d2(&y)[SYRK_R][SYRK_NV / 2]) {
+#pragma unroll
+    for (int t = 0; t < SYRK_R; ++t)
+#pragma unroll
+      for (int u = 0; u < SYRK_NU; ++u) {
+        const double au = (u & 1) ? x[t][u >> 1].y : x[t][u >> 1].x;
+#pragma unroll
+        for (int v = 0; v < SYRK_NV; ++v)
+          acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(au, (v & 1) ? y[t][v >> 1].y : y[t][v >> 1].x, acc[u][v], 0, 0, 0);
+      }
+  };
+  load(xa, ya, 0);
+  for (int64_t s = 0; s < steps; s += 2 * SYRK_R) {
+    load(xb, yb, s + SYRK_R);
+    __builtin_amdgcn_sched_barrier(0);  // (the loads stay ahead of the products they are to hide behind)
+    compute(xa, ya);
+    __builtin_amdgcn_sched_barrier(0);
+    load(xa, ya, s + 2 * SYRK_R);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(xb, yb);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // result register q of lane l of tile (u, v): D[i = (l >> 4) + 4 q][j = l & 15]
+#pragma unroll
+  for (int u = 0; u < SYRK_NU; ++u)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t gi = i0 + 32 * (u >> 1) + 2 * (kq + 4 * q) + (u & 1);
+      if (gi >= ld) continue;
+      double* prow = P + gi * (gi + 1) / 2;
+#pragma unroll
+      for (int v = 0; v < SYRK_NV; ++v) {
+        const int64_t gj = j0 + 32 * (v >> 1) + 2 * i16 + (v & 1);
+        if (gj <= gi) prow[gj] = acc[u][v][q];  // (gj <= gi < ld)
+      }
+    }
+}
+
+// G = (A - B) * scale from packed triangles to the square, mirrored (B == nullptr: G = A * scale).  One 32 x 32 tile of the
+// lower triangle per workgroup: rows of the packed tile are read in 256-byte stretches, the mirror goes through LDS.
+__global__ __launch_bounds__(256) void cov_unpack_kernel(const double* A, const double* B, double scale, int64_t ld, double* G) {
+  int bi = 0, rest = (int)blockIdx.x;
+  while (rest > bi) {
+    rest -= bi + 1;
+    ++bi;
+  }
+  const int bj = rest;
+  __shared__ double t[32][33];
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;  // 8 rows per sweep
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + 8 * k;
+    const int64_t gi = 32LL * bi + r, gj = 32LL * bj + c;
+    double v = 0.0;
+    if (gi < ld && gj <= gi) {
+      const int64_t at = cov_tri(gi, gj);
+      v = (A[at] - (B ? B[at] : 0.0)) * scale;
+      G[gi * ld + gj] = v;
+    }
+    t[r][c] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + 8 * k;  // row of the mirrored tile = column of the original
+    const int64_t gi = 32LL * bj + r, gj = 32LL * bi + c;  // element (gi, gj) = original (gj, gi)
+    if (gj < ld && gi < gj) G[gi * ld + gj] = t[c][r];  // strictly above the diagonal
   }
 }
 

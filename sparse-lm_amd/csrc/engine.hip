@@ -1317,8 +1317,10 @@ static int enqueue_gradient_cov(slm_dataset* ds, int B, const int* entry_of, con
 static int cov_fingerprints(slm_dataset* ds, const double* const* w, int count, double* out /* [2 * count] */) {
   hipStream_t s = ds->eng->stream;
   if (!ds->cov_fp) SLM_TRY(dalloc(&ds->cov_fp, 2 * (size_t)kMaxLanes + 2));
-  for (int u = 0; u < count; ++u)
-    hipLaunchKernelGGL(cov_fingerprint_kernel, dim3(1), dim3(1024), 0, s, w[u], ds->n, ds->cov_fp + 2 * u);
+  CovFpArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  for (int u = 0; u < count; ++u) fa.w[u] = w[u];
+  hipLaunchKernelGGL(cov_fingerprint_kernel, dim3((unsigned)count), dim3(1024), 0, s, fa, ds->n, ds->cov_fp);
   HIP_TRY(hipMemcpyAsync(out, ds->cov_fp, sizeof(double) * 2 * (size_t)count, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return SLM_OK;
@@ -2896,13 +2898,14 @@ extern "C" int slm_dataset_covariance(slm_dataset* ds, const double* row_weight,
 // Anything that is not such a partition (masks that overlap or leave rows out, weights that are not 0/1, Grams that exist
 // already) is built mask by mask (slm_dataset_covariance), by every rank for itself.
 struct slm_dataset::CovPending {
-  double *big = nullptr, *all = nullptr;  // [count][stride] parts; [stride] their sum
-  size_t stride = 0;
+  double *big = nullptr, *all = nullptr;  // [count][stride] parts; [stride] their sum -- packed triangle | t | y.y, see cov_folds_begin
+  size_t stride = 0, tri = 0;             // doubles per part; of which the packed triangle (rounded up to 16)
   int count = 0;
-  std::vector<double> n_eff, fp;          // per fold; fingerprints of the masks [2 * count]
-  double *block = nullptr, *R16 = nullptr;  // staging of a fold's test rows and their targets (freed by finish)
+  std::vector<double> n_eff;              // per fold
+  double *block = nullptr, *R16 = nullptr, *wdev = nullptr;  // staging: the folds' test rows (padded), targets, the masks
   int64_t* rows = nullptr;                // the folds' test-row indices, one list after the other
-  hipEvent_t built[SLM_MAX_LANES] = {};   // part f is complete on the engine's stream
+  hipEvent_t built = nullptr;             // the parts are complete on the engine's stream
+  hipEvent_t uploaded = nullptr;          // the caller's masks have left the host
 };
 
 static void cov_pending_drop(slm_dataset* ds) {
@@ -2910,9 +2913,9 @@ static void cov_pending_drop(slm_dataset* ds) {
   if (!q) return;
   (void)hipStreamSynchronize(ds->eng->stream);
   if (ds->eng->comm_stream) (void)hipStreamSynchronize(ds->eng->comm_stream);
-  dfree(q->big); dfree(q->all); dfree(q->block); dfree(q->R16); dfree(q->rows);
-  for (auto& e : q->built)
-    if (e) (void)hipEventDestroy(e);
+  dfree(q->big); dfree(q->all); dfree(q->block); dfree(q->R16); dfree(q->rows); dfree(q->wdev);
+  if (q->built) (void)hipEventDestroy(q->built);
+  if (q->uploaded) (void)hipEventDestroy(q->uploaded);
   delete q;
   ds->cov_pend = nullptr;
 }
@@ -2943,7 +2946,9 @@ static int cov_partition(const slm_dataset* ds, const double* const* row_weights
   return partition ? 1 : 0;
 }
 
-// queues the parts of this rank's rows on the engine's stream; *started = 0 when the masks are no partition (nothing queued)
+// Queues the parts of this rank's rows on the engine's stream and returns without waiting for anything; *started = 0 when
+// the masks are no partition (nothing queued).  Part f, `stride` doubles: the PACKED lower triangle of X_f^T X_f (test rows of
+// fold f among this rank's; cov_syrk_packed_kernel, all folds in one launch), then t_f = X_f^T y_f [ld] and y_f . y_f [16].
 static int cov_folds_begin(slm_dataset* ds, const double* const* row_weights, const int64_t* n_effs, int32_t count, int* started) {
   *started = 0;
   SLM_TRY(cov_checks(ds));
@@ -2962,13 +2967,15 @@ static int cov_folds_begin(slm_dataset* ds, const double* const* row_weights, co
     lo = eng->rank * base + std::min<int64_t>(eng->rank, rem);
     hi = lo + base + (eng->rank < rem ? 1 : 0);
   }
-  std::vector<int64_t> rows_host, first((size_t)count + 1, 0);
+  std::vector<int64_t> rows_host, first((size_t)count + 1, 0), at_row((size_t)count + 1, 0);
   int64_t most = 1;
   for (int f = 0; f < count; ++f) {
     for (int64_t i : zeros[(size_t)f])
       if (i >= lo && i < hi) rows_host.push_back(i);
     first[(size_t)f + 1] = (int64_t)rows_host.size();
-    most = std::max(most, first[(size_t)f + 1] - first[(size_t)f]);
+    const int64_t m = first[(size_t)f + 1] - first[(size_t)f];
+    most = std::max(most, m);
+    at_row[(size_t)f + 1] = at_row[(size_t)f] + cov_syrk_padded_rows(m);  // (the fold's rows in the block, zeros behind them)
   }
   slm_dataset::CovPending* q = new slm_dataset::CovPending();
   ds->cov_pend = q;
@@ -2977,60 +2984,67 @@ static int cov_folds_begin(slm_dataset* ds, const double* const* row_weights, co
     ~Guard() { if (ds) cov_pending_drop(ds); }
   } guard{ds};
   q->count = count;
-  q->stride = (size_t)ld * ld + (size_t)ld + 16;
+  q->tri = ((size_t)ld * (size_t)(ld + 1) / 2 + 15) / 16 * 16;
+  q->stride = q->tri + (size_t)ld + 16;
   q->n_eff.resize((size_t)count);
-  q->fp.resize(2 * (size_t)count);
-  // fingerprints of the masks first (the one wait of this function; the products are queued behind it)
+  // the masks go to the device for their fingerprints (read back by cov_folds_finish: nothing here waits)
+  SLM_TRY(dalloc(&q->wdev, (size_t)count * n));
   {
-    double* wdev = nullptr;
-    SLM_TRY(dalloc(&wdev, (size_t)count * n));
-    int rc = SLM_OK;
-    const double* wp[SLM_MAX_LANES];
-    for (int f = 0; f < count && rc == SLM_OK; ++f) {
+    CovFpArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    for (int f = 0; f < count; ++f) {
       q->n_eff[(size_t)f] = (double)n_effs[f];
-      wp[f] = wdev + (size_t)f * n;
-      if (hipMemcpyAsync(wdev + (size_t)f * n, row_weights[f], sizeof(double) * n, hipMemcpyHostToDevice, s) != hipSuccess)
-        rc = fail(SLM_ERR_HIP, "covariance build: upload of a mask failed");
+      fa.w[f] = q->wdev + (size_t)f * n;
+      HIP_TRY(hipMemcpyAsync(q->wdev + (size_t)f * n, row_weights[f], sizeof(double) * n, hipMemcpyHostToDevice, s));
     }
-    if (rc == SLM_OK) rc = cov_fingerprints(ds, wp, count, q->fp.data());
-    (void)hipStreamSynchronize(s);
-    dfree(wdev);
-    SLM_TRY(rc);
+    if (!ds->cov_fp) SLM_TRY(dalloc(&ds->cov_fp, 2 * (size_t)kMaxLanes + 2));
+    hipLaunchKernelGGL(cov_fingerprint_kernel, dim3((unsigned)count), dim3(1024), 0, s, fa, n, ds->cov_fp);
   }
   SLM_TRY(dalloc(&q->big, (size_t)count * q->stride));
   SLM_TRY(dalloc(&q->all, q->stride));
-  SLM_TRY(dalloc(&q->block, (size_t)most * (size_t)ld));
+  SLM_TRY(dalloc(&q->block, (size_t)at_row[(size_t)count] * (size_t)ld));
   SLM_TRY(dalloc(&q->R16, (size_t)most * SPLIT_RSTRIDE));
   SLM_TRY(dalloc(&q->rows, std::max<size_t>(1, rows_host.size())));
   if (!rows_host.empty())
     HIP_TRY(hipMemcpyAsync(q->rows, rows_host.data(), sizeof(int64_t) * rows_host.size(), hipMemcpyHostToDevice, s));
-  int side = cov_tile_for(ld, eng->cus);
-  if (const char* e = getenv("SLM_COV_TILE")) side = atoi(e) == 3 ? 3 : 4;  // (A/B runs: 96 or 128 columns per workgroup)
-  const int nt = (int)((ld + 32 * side - 1) / (32 * side));
-  const dim3 sgrid((unsigned)(nt * (nt + 1) / 2));
+  // (host memory -- the caller's masks, the row list -- is borrowed for the duration of the call only: the uploads sit at the
+  //  head of the stream and are long through when everything behind them has been queued; that, not the products, is waited for)
+  HIP_TRY(hipEventCreateWithFlags(&q->uploaded, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(q->uploaded, s));
+  SyrkBatch sb;
+  memset(&sb, 0, sizeof(sb));
   for (int f = 0; f < count; ++f) {
-    double* part = q->big + (size_t)f * q->stride;
     const int64_t m = first[(size_t)f + 1] - first[(size_t)f];
-    if (m < 1) {  // (none of the fold's test rows are among this rank's)
-      HIP_TRY(hipMemsetAsync(part, 0, sizeof(double) * q->stride, s));
-    } else {
-      const int64_t* rows = q->rows + first[(size_t)f];
-      hipLaunchKernelGGL(cov_rows_kernel, dim3((unsigned)m), dim3(256), 0, s, ds->X, ld, rows, nullptr, m, q->block);
-      if (side == 3) hipLaunchKernelGGL(cov_syrk_kernel<3>, sgrid, dim3(256), 0, s, q->block, m, ld, part);
-      else hipLaunchKernelGGL(cov_syrk_kernel<4>, sgrid, dim3(256), 0, s, q->block, m, ld, part);
-      // t_f = X_f^T y_f: the second half of the split pass on (block, [y_f, 0 ...])
-      hipLaunchKernelGGL(cov_targets_kernel, dim3((unsigned)((m * SPLIT_RSTRIDE + 255) / 256)), dim3(256), 0, s, ds->y, rows, m, q->R16);
-      SplitArgs a;
-      memset(&a, 0, sizeof(a));
-      a.X = q->block; a.R = q->R16; a.partial = ds->partial; a.n = m; a.ld = ld; a.p2 = (int)(ld / 2); a.n_lanes = 1;
-      const int xblk = launch_xtr(eng->cus, a, s);
-      hipLaunchKernelGGL(cov_xty_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ds->partial, xblk, ld, part + (size_t)ld * ld);
-      hipLaunchKernelGGL(cov_yy_kernel, dim3(1), dim3(1024), 0, s, ds->y, rows, m, part + (size_t)ld * ld + ld);
+    double* blk = q->block + (size_t)at_row[(size_t)f] * (size_t)ld;
+    hipLaunchKernelGGL(cov_rows_pad_kernel, dim3((unsigned)(at_row[(size_t)f + 1] - at_row[(size_t)f])), dim3(256), 0, s, ds->X, ld,
+                       q->rows + first[(size_t)f], m, blk);
+    sb.A[f] = blk;
+    sb.rows[f] = m;
+    sb.P[f] = q->big + (size_t)f * q->stride;
+  }
+  const int n_tiles = cov_syrk_tiles(ld);
+  hipLaunchKernelGGL(cov_syrk_packed_kernel, dim3((unsigned)((n_tiles + 3) / 4), (unsigned)count), dim3(256), 0, s, sb, ld, n_tiles);
+  for (int f = 0; f < count; ++f) {
+    double* lin = q->big + (size_t)f * q->stride + q->tri;  // t_f [ld], then y_f . y_f [16]
+    const int64_t m = first[(size_t)f + 1] - first[(size_t)f];
+    if (m < 1) {
+      HIP_TRY(hipMemsetAsync(lin, 0, sizeof(double) * ((size_t)ld + 16), s));
+      continue;
     }
-    HIP_TRY(hipEventCreateWithFlags(&q->built[f], hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(q->built[f], s));
+    const int64_t* rows = q->rows + first[(size_t)f];
+    // t_f = X_f^T y_f: the second half of the split pass on (block, [y_f, 0 ...])
+    hipLaunchKernelGGL(cov_targets_kernel, dim3((unsigned)((m * SPLIT_RSTRIDE + 255) / 256)), dim3(256), 0, s, ds->y, rows, m, q->R16);
+    SplitArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = sb.A[f]; a.R = q->R16; a.partial = ds->partial; a.n = m; a.ld = ld; a.p2 = (int)(ld / 2); a.n_lanes = 1;
+    const int xblk = launch_xtr(eng->cus, a, s);
+    hipLaunchKernelGGL(cov_xty_kernel, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, ds->partial, xblk, ld, lin);
+    hipLaunchKernelGGL(cov_yy_kernel, dim3(1), dim3(1024), 0, s, ds->y, rows, m, lin + ld);
   }
   SLM_TRY(check_launch());
+  HIP_TRY(hipEventCreateWithFlags(&q->built, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(q->built, s));
+  HIP_TRY(hipEventSynchronize(q->uploaded));
   guard.ds = nullptr;
   *started = 1;
   return SLM_OK;
@@ -3046,48 +3060,70 @@ static int cov_folds_finish(slm_dataset* ds) {
   const int64_t ld = ds->ld;
   struct Guard {
     slm_dataset* ds;
-    ~Guard() { cov_pending_drop(ds); }
+    double* full = nullptr;
+    ~Guard() {
+      cov_pending_drop(ds);  // (waits for the stream)
+      dfree(full);
+    }
   } guard{ds};
   if (ds->replicated && eng->sharded()) {
+    // on the engine's second stream (RCCL's kernels then never sit between two kernels of a solve on this stream)
     if (!eng->comm_stream) HIP_TRY(hipStreamCreateWithFlags(&eng->comm_stream, hipStreamNonBlocking));
     if (!eng->comm_ev) HIP_TRY(hipEventCreateWithFlags(&eng->comm_ev, hipEventDisableTiming));
     hipStream_t cs = eng->comm_stream;
-    for (int f = 0; f < q->count; ++f) {
-      HIP_TRY(hipStreamWaitEvent(cs, q->built[f], 0));
-      SLM_TRY(all_reduce_sum(eng, q->big + (size_t)f * q->stride, q->stride, cs));
-    }
+    HIP_TRY(hipStreamWaitEvent(cs, q->built, 0));
+    for (int f = 0; f < q->count; ++f) SLM_TRY(all_reduce_sum(eng, q->big + (size_t)f * q->stride, q->stride, cs));
     HIP_TRY(hipEventRecord(eng->comm_ev, cs));
     HIP_TRY(hipStreamWaitEvent(s, eng->comm_ev, 0));
   }
   const unsigned cgrid = (unsigned)std::min<int64_t>(4096, ((int64_t)q->stride + 255) / 256);
   hipLaunchKernelGGL(cov_sum_kernel, dim3(cgrid), dim3(256), 0, s, q->big, q->count, (int64_t)q->stride, (int64_t)q->stride, q->all);
+  // the squares a pass reads: G_f = (all - part_f) / n_f mirrored out of the packed triangles, c_f and y^T W_f y behind it
+  const size_t fstride = (size_t)ld * ld + (size_t)ld + 16;
+  SLM_TRY(dalloc(&guard.full, (size_t)q->count * fstride));
+  double* all_sq = nullptr;
+  SLM_TRY(dalloc(&all_sq, (size_t)ld * ld));
+  const int64_t nt32 = (ld + 31) / 32;
+  const dim3 ugrid((unsigned)(nt32 * (nt32 + 1) / 2));
   for (int f = 0; f < q->count; ++f) {
-    double* part = q->big + (size_t)f * q->stride;
-    hipLaunchKernelGGL(cov_combine_kernel, dim3(cgrid), dim3(256), 0, s, q->all, part, 1.0 / q->n_eff[(size_t)f], (int64_t)q->stride, part);
+    const double* part = q->big + (size_t)f * q->stride;
+    double* Gf = guard.full + (size_t)f * fstride;
+    const double sc = 1.0 / q->n_eff[(size_t)f];
+    hipLaunchKernelGGL(cov_unpack_kernel, ugrid, dim3(256), 0, s, q->all, part, sc, ld, Gf);
+    hipLaunchKernelGGL(cov_combine_kernel, dim3((unsigned)((ld + 16 + 255) / 256)), dim3(256), 0, s, q->all + q->tri, part + q->tri, sc,
+                       (int64_t)ld + 16, Gf + (size_t)ld * ld);
   }
-  SLM_TRY(check_launch());
-  double yy[SLM_MAX_LANES] = {};
-  for (int f = 0; f < q->count; ++f)
-    HIP_TRY(hipMemcpyAsync(&yy[f], q->big + (size_t)f * q->stride + (size_t)ld * ld + ld, sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  // the entries share the block of the parts; the sum stays as the Gram of all rows (its first ld^2 doubles)
+  hipLaunchKernelGGL(cov_unpack_kernel, ugrid, dim3(256), 0, s, q->all, (const double*)nullptr, 1.0, ld, all_sq);
+  double yy[SLM_MAX_LANES] = {}, fp[2 * SLM_MAX_LANES] = {};
+  int rc = check_launch();
+  hipError_t he = hipSuccess;
+  for (int f = 0; f < q->count && he == hipSuccess; ++f)
+    he = hipMemcpyAsync(&yy[f], guard.full + (size_t)f * fstride + (size_t)ld * ld + ld, sizeof(double), hipMemcpyDeviceToHost, s);
+  if (he == hipSuccess) he = hipMemcpyAsync(fp, ds->cov_fp, sizeof(double) * 2 * (size_t)q->count, hipMemcpyDeviceToHost, s);
+  if (he == hipSuccess) he = hipStreamSynchronize(s);
+  if (rc == SLM_OK && he != hipSuccess) rc = fail(SLM_ERR_HIP, "covariance build: %s", hipGetErrorString(he));
+  if (rc != SLM_OK) {
+    (void)hipStreamSynchronize(s);
+    dfree(all_sq);
+    return rc;
+  }
+  // the entries share the block of the squares; the Gram of all rows stays for later single masks
   auto hold = std::make_shared<slm_dataset::CovBlocks>();
-  hold->G = q->big;
-  q->big = nullptr;
+  hold->G = guard.full;
+  guard.full = nullptr;
   ds->cov_all_hold = std::make_shared<slm_dataset::CovBlocks>();
-  ds->cov_all_hold->G = q->all;
-  ds->cov_all = q->all;
-  q->all = nullptr;
+  ds->cov_all_hold->G = all_sq;
+  ds->cov_all = all_sq;
   for (int f = 0; f < q->count; ++f) {
-    if (cov_find(ds, q->fp[2 * (size_t)f], q->fp[2 * (size_t)f + 1], q->n_eff[(size_t)f]) >= 0) continue;  // (the same mask twice)
+    if (cov_find(ds, fp[2 * f], fp[2 * f + 1], q->n_eff[(size_t)f]) >= 0) continue;  // (the same mask twice)
     slm_dataset::CovEntry e;
     e.hold = hold;
-    e.G = hold->G + (size_t)f * q->stride;
+    e.G = hold->G + (size_t)f * fstride;
     e.c = e.G + (size_t)ld * ld;
     e.yy = yy[f];
     e.n_eff = q->n_eff[(size_t)f];
-    e.fp1 = q->fp[2 * (size_t)f];
-    e.fp2 = q->fp[2 * (size_t)f + 1];
+    e.fp1 = fp[2 * f];
+    e.fp2 = fp[2 * f + 1];
     if (ds->cov.size() >= 16) ds->cov.erase(ds->cov.begin());
     ds->cov.push_back(e);
   }
@@ -3114,6 +3150,17 @@ extern "C" int slm_dataset_covariance_folds(slm_dataset* ds, const double* const
   SLM_TRY(cov_folds_begin(ds, row_weights, n_effs, count, &started));
   if (started) return cov_folds_finish(ds);
   for (int f = 0; f < count; ++f) SLM_TRY(slm_dataset_covariance(ds, row_weights[f], n_effs[f]));
+  return SLM_OK;
+}
+
+extern "C" int slm_dataset_covariance_clear(slm_dataset* ds) {
+  if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  HIP_TRY(hipStreamSynchronize(ds->eng->stream));
+  cov_pending_drop(ds);
+  ds->cov.clear();
+  ds->cov_all_hold.reset();
+  ds->cov_all = nullptr;
   return SLM_OK;
 }
 

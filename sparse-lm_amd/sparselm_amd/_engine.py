@@ -82,6 +82,7 @@ ABI_SYMBOLS = (
     "slm_dataset_covariance_folds_begin",
     "slm_dataset_covariance_folds_finish",
     "slm_dataset_covariance_count",
+    "slm_dataset_covariance_clear",
     "slm_dataset_covariance_download",
     "slm_dataset_set_replicated",
     "slm_comm_unique_id",
@@ -270,6 +271,7 @@ def load_library():
             "slm_dataset_covariance_folds_begin": [vp, vp, vp, i32, P(i32)],
             "slm_dataset_covariance_folds_finish": [vp],
             "slm_dataset_covariance_count": [vp, P(i32)],
+            "slm_dataset_covariance_clear": [vp],
             "slm_dataset_covariance_download": [vp, i32, vp, vp, vp],
             "slm_dataset_set_replicated": [vp, i32],
             "slm_comm_unique_id": [vp],
@@ -861,6 +863,10 @@ class Dataset:
         """On an engine with a communicator: this dataset holds ALL rows (grid mode), not a row block -- no per-pass
         collective; the communicator only carries the folds' Grams (``covariance_folds``)."""
         _check(self._lib.slm_dataset_set_replicated(self._h, int(bool(replicated))))
+
+    def covariance_clear(self):
+        """Drop every Gram built so far (later solves run over X)."""
+        _check(self._lib.slm_dataset_covariance_clear(self._h))
 
     def covariance_count(self) -> int:
         out = C.c_int32()

@@ -102,6 +102,46 @@ def gather_results(local: dict[int, Any], n_units: int) -> list[Any] | None:
     return [merged[i] for i in range(n_units)]
 
 
+_grid_engines: dict = {}
+
+
+def grid_engine(rank: int, world_size: int):
+    """The engine grid-mode searches of this process use among ``world_size`` ranks: a further engine (stream) on the
+    rank's device with an RCCL communicator over all ranks, made once per process.  Datasets opened on it are marked as
+    REPLICAS (``Dataset.set_replicated``): every rank holds all rows and solves its own lanes with no per-pass
+    collective; the communicator carries one thing, the folds' Grams summed from the ranks' row blocks
+    (``Dataset.covariance_folds``).  The per-process default engine stays without a communicator, so ordinary fits are
+    untouched.  Returns ``None`` when the communicator cannot be formed on every rank (several ranks on one GPU: RCCL
+    refuses) -- the ranks agree on that through the process group -- and the search then runs without sharded Grams."""
+    import torch
+    import torch.distributed as dist
+
+    from . import _engine
+
+    key = (os.getpid(), int(world_size))
+    if key in _grid_engines:
+        return _grid_engines[key]
+    eng = _engine.Engine(_engine.get_engine().device_id)
+    ok = 1
+    try:
+        init_row_sharding(eng, rank, world_size)
+        ok = int(eng.comm_ranks() == world_size)
+    except Exception:  # noqa: BLE001 -- whatever went wrong, the ranks settle it together below
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    if dist.get_backend() == "nccl" and torch.cuda.is_available():
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        try:
+            eng.close()
+        except Exception:  # noqa: BLE001
+            pass
+        eng = None
+    _grid_engines[key] = eng
+    return eng
+
+
 def init_row_sharding(engine, rank: int | None = None, world_size: int | None = None) -> None:
     """Create the engine's RCCL communicator: rank 0 makes the unique id, everybody receives it
     through torch.distributed, then all ranks enter ``slm_comm_init`` together."""
@@ -119,8 +159,11 @@ def init_row_sharding(engine, rank: int | None = None, world_size: int | None = 
         buf = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             buf = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).clone()
+        on_gpu = dist.get_backend() == "nccl" and torch.cuda.is_available()  # (that backend moves device tensors only)
+        if on_gpu:
+            buf = buf.cuda()
         dist.broadcast(buf, src=0)
-        uid = bytes(buf.tolist())
+        uid = bytes(buf.cpu().tolist())
     engine.comm_init(rank, world_size, uid)
 
 

@@ -229,7 +229,9 @@ class GridSearchCV(_GridSearchCV):
     # ---- device-resident fast path ------------------------------------------------------------------
     def _fit_device(self, X, y, groups):
         rank, world = D.active_world()
-        grid = _DeviceGrid(self, X, y, groups)
+        # among several ranks the search runs on an engine of its own that carries a communicator for the folds' Grams
+        # (None where RCCL cannot form the group: the search then goes without sharded Grams)
+        grid = _DeviceGrid(self, X, y, groups, engine=D.grid_engine(rank, world) if world > 1 else None)
         t0 = time.perf_counter()
         lease = getattr(self, "_lease", None)
         with (_Borrowed(lease.get(grid)) if lease is not None else grid.open()) as ds:
@@ -256,11 +258,13 @@ class GridSearchCV(_GridSearchCV):
         self.search_time_ = time.perf_counter() - t0
         return self
 
-    def _device_cells(self, X, y, groups=None, rank=0, world=1):
+    def _device_cells(self, X, y, groups=None, rank=0, world=1, engine=None):
         """The (candidate, fold) scores rank ``rank`` of a ``world``-rank search computes, as a (candidates x folds)
         array with NaN in the cells of the other ranks -- the share `_fit_device` would solve in that process, without a
-        process group (tests; `bench.py`'s emulated multi-rank legs)."""
-        grid = _DeviceGrid(self, X, y, groups)
+        process group (tests; `bench.py`'s emulated multi-rank legs).  ``engine``: the rank's engine when the ranks are
+        the engines of an in-process communicator (``_engine.init_local_comm``; one thread per rank must then call this
+        at the same time: the folds' Grams are a collective)."""
+        grid = _DeviceGrid(self, X, y, groups, engine=engine)
         with grid.open() as ds:
             local, _ = grid.solve_share(ds, rank, world)
         scores = np.full((len(grid.candidates), grid.n_splits), np.nan)
@@ -351,9 +355,10 @@ class _DeviceGrid:
     `distributed.plan_lane_calls`; what every rank reports back are *cells*: (unit, first point) -> (candidate
     indices, fold, scores, seconds per fit)."""
 
-    def __init__(self, search, X, y, groups):
+    def __init__(self, search, X, y, groups, engine=None):
         est = search.estimator
         self.search, self.est = search, est
+        self.engine = engine  # None: the per-process default engine
         self.X_in, self.y_in = X, y  # (the caller's objects: what a lease recognises the next line's data by)
         X, y, groups = indexable(X, y, groups)
         self.X = X = np.asarray(X, dtype=np.float64)
@@ -409,7 +414,10 @@ class _DeviceGrid:
     def open(self):
         n = self.X.shape[0]
         Xd = np.hstack([self.X, np.ones((n, 1))]) if self.intercept else self.X
-        ds = _engine.get_engine().dataset(Xd, self.y)
+        eng = self.engine if self.engine is not None else _engine.get_engine()
+        ds = eng.dataset(Xd, self.y)
+        if eng.comm_ranks() > 1:  # grid mode among ranks: every rank holds all rows
+            ds.set_replicated(True)
         if self.gidx is not None:
             self._set_groups(ds)
         self.lanes = max(1, min(int(self.search.lanes), _engine.MAX_LANES, ds.max_lanes(self.opts.get("flags", 0))))
@@ -481,19 +489,28 @@ class _DeviceGrid:
             self.cells = [(u, idx[0]) for calls in self._plan for call in calls for lane in call for u, idx in lane]
         return self._plan
 
-    def covariance(self, ds, calls):
-        """Covariance passes for this share (``solver_options={"covariance": True | False | "auto"}``, default "auto"):
+    def covariance(self, ds, calls, world=1):
+        """Covariance passes for this search (``solver_options={"covariance": True | False | "auto"}``, default "auto"):
         the Gram of every fold's training rows is built once (``Dataset.covariance_folds``: where the folds' test rows
         partition the rows -- K-fold -- the Gram of all rows is the sum of the test rows' Grams, one triangle product over n
-        rows in all) and every pass of the share reads 8 p^2 bytes per fold instead of X.  "auto" asks whether what the
-        share's passes save -- one per path point and sixteen lanes; a read of X at the HBM rate against a read of the
-        Gram -- exceeds the Grams by a margin: true for BASELINE config 4 on one GPU (2 500 fits: 0.147 s over X, 0.065 s
-        of Grams + 0.055 s from them), not for its eighth on one of eight ranks (22 passes), nor for splits that are no
-        partition unless the grid is several times larger."""
+        rows in all) and every pass of a share reads 8 p^2 bytes per fold instead of X.  Among ranks (a replica on an
+        engine with a communicator) every rank builds the parts of its ``world``-th of the rows and the ranks sum them: the
+        decision is taken from ``calls``, the LARGEST share of the plan, so that every rank takes the same one (the build is
+        a collective).  "auto" asks whether what the passes of the largest share save -- one per path point and sixteen
+        lanes; a read of X at the HBM rate, and in a grid cut into pieces the dearer appends to the working set, against a
+        read of the Gram -- exceeds the Grams by a margin: true for BASELINE config 4 on one GPU (2 500 fits: 0.147 s over
+        X, 0.065 s of Grams + 0.055 s from them) and, with the build shared, for its eighth on one of eight ranks; not for
+        splits that are no partition unless the grid is several times larger."""
         want = normalise_options(self.est.solver_options).get("covariance", "auto")
         if want is False or len(self.train_masks) > _engine.MAX_LANES:  # (a dataset keeps sixteen Grams)
             return False
         n, p = ds.n, ds.p
+        eng = getattr(ds, "engine", None)
+        shared = world > 1 and eng is not None and eng.comm_ranks() == world  # the ranks build the Grams together
+        n_effs = [int(m.sum()) for m in self.train_masks]
+        if want == "auto" and hasattr(ds, "covariance_count") and ds.covariance_count() >= self.n_splits:
+            # (a leased dataset: an earlier line of the search built them -- the entries are found by their fingerprints)
+            want = True
         if want == "auto":
             points = sum(len(idx) for call in calls for lane in call for _, idx in lane)
             reads = 1.0  # reads of X per pass
@@ -503,6 +520,8 @@ class _DeviceGrid:
                 # solves over X, 0.061 s from the Grams -- tools/adaptive_grid_big.py)
                 points *= 4 * max(1, int(getattr(self.est, "max_iter", 1)))
                 reads = 2.0
+            elif world > 1:
+                reads = 1.5  # pieces of paths append k times the columns per pass: 1.18 ms against 0.90 ms
             lease = getattr(self.search, "_lease", None)
             if lease is not None:  # (a line search: the Grams serve the lines still to come)
                 points *= max(1, lease.repeats)
@@ -512,15 +531,22 @@ class _DeviceGrid:
             partition = bool(tests) and len(tests) == self.n_splits and bool(np.all(np.sum(tests, axis=0) == 1.0))
             triangle = 1.3 * n * p * p / 50e12  # X^T X on the matrix cores (its lower triangle), set-up included
             grams = triangle if partition else triangle * (1.0 + float(np.mean([1.0 - np.mean(m) for m in self.train_masks])) * self.n_splits)
+            if shared and partition:
+                # a world-th of the products, plus the exchange: n_splits packed triangles at ~150 GB/s per rank
+                grams = triangle / world + self.n_splits * 4.0 * p * p / 150e9
             if n * p < (1 << 26) or saved < 1.15 * grams:
                 return False
         try:
             if len(self.train_masks) <= _engine.MAX_LANES and hasattr(ds, "covariance_folds"):
-                ds.covariance_folds(self.train_masks, [int(m.sum()) for m in self.train_masks])
+                ds.covariance_folds(self.train_masks, n_effs)
             else:
                 for m in self.train_masks:
                     ds.covariance(m, int(m.sum()))
-        except (NotImplementedError, MemoryError):
+        except NotImplementedError:  # (a matter of the shape: every rank gets the same answer, before any collective)
+            return False
+        except MemoryError:
+            if shared:
+                raise  # (the other ranks are inside the collective: nothing to fall back to on one rank's say-so)
             return False
         return True
 
@@ -528,7 +554,8 @@ class _DeviceGrid:
         """(cells of rank `rank`, number of solves that stopped short of the tolerance)"""
         calls = self.plan(world)[rank]
         local = {}
-        if self.covariance(ds, calls):
+        largest = max(self.plan(world), key=lambda cs: sum(len(idx) for call in cs for lane in call for _, idx in lane))
+        if self.covariance(ds, largest, world):
             self.opts["flags"] = self.opts.get("flags", 0) | _engine.FLAG_COVARIANCE
         run = self._run_adaptive if self.adaptive else self._run_call
         unconverged = self.search._run_batches(ds, calls, lambda d, call: run(d, call, local), self)

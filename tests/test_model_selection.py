@@ -453,6 +453,59 @@ def test_the_shares_of_an_eight_rank_search_reproduce_the_one_rank_table(monkeyp
 
 
 @pytest.mark.gpu
+def test_an_eight_rank_search_with_the_folds_grams_built_together(monkeypatch):
+    """Grid mode with the folds' Grams: the eight ranks of a search -- eight engines of an in-process communicator, a
+    thread each, every one with a replica of (X, y) -- build the Grams of the five folds together (every rank the parts of
+    its eighth of the rows, one sum over the ranks per fold) and solve their shares from them; the merged table is the
+    one-rank table over X."""
+    import threading
+
+    from sparselm_amd import _engine
+
+    monkeypatch.setenv("SLM_WS", "1")
+    rng = np.random.default_rng(6)
+    n, p, G = 2400, 96, 16
+    groups = rng.permutation(np.repeat(np.arange(G), p // G))
+    X = rng.standard_normal((n, p))
+    beta = np.zeros(p)
+    for g in rng.choice(G, 4, replace=False):
+        beta[groups == g] = rng.uniform(1.0, 4.0, p // G) * rng.choice([-1, 1], p // G)
+    y = X @ beta + 2.0 * rng.standard_normal(n)
+    grid = {"alpha": list(np.geomspace(3.0, 0.01, 20)), "l1_ratio": [0.3, 0.7]}
+    cv = KFold(5, shuffle=True, random_state=0)
+    world = 8
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        one = GridSearchCV(SparseGroupLasso(groups=groups, solver_options={"tol": 1e-11, "covariance": False}), grid, cv=cv)._device_cells(X, y)
+        engines = [_engine.Engine(0) for _ in range(world)]
+        shares, errors, counts = [None] * world, [], [None] * world
+        try:
+            _engine.init_local_comm(engines, timeout_s=120.0)
+
+            def work(r):
+                try:
+                    est = SparseGroupLasso(groups=groups, solver_options={"tol": 1e-11, "covariance": True})
+                    shares[r] = GridSearchCV(est, grid, cv=cv)._device_cells(X, y, rank=r, world=world, engine=engines[r])
+                    counts[r] = engines[r].comm_collectives()
+                except BaseException as exc:  # noqa: BLE001
+                    errors.append(exc)
+
+            threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            for e in engines:
+                e.close()
+    assert not errors, errors[:1]
+    assert counts == [5] * world  # one sum per fold, nothing per pass
+    owners = np.sum([~np.isnan(s) for s in shares], axis=0)
+    assert np.all(owners == 1)
+    np.testing.assert_allclose(np.nansum(shares, axis=0), one, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.gpu
 def test_line_search_keeps_one_device_dataset_for_all_its_lines(monkeypatch):
     """LineSearchCV (reference model_selection.py:427-707) runs one GridSearchCV per line on the same (X, y): the device
     dataset is opened once and lent to every line (`_DatasetLease`), and the lines give what stand-alone searches give."""
@@ -527,3 +580,16 @@ def test_covariance_auto_weighs_the_passes_against_the_grams():
 
     g, calls = grid(True, 100)
     assert g.covariance(Refusing(), calls) is False
+
+    # a rank of eight: no for its eighth of config 4 on its own, yes when the ranks build the Grams together (a replica on
+    # an engine with a communicator over all of them: an eighth of the products each, plus the exchange)
+    class Shared(FakeDataset):
+        engine = SimpleNamespace(comm_ranks=lambda: 8)
+
+        def covariance_folds(self, masks, n_effs):
+            built.extend(n_effs)
+
+    built.clear()
+    g, calls = grid("auto", 320)
+    assert g.covariance(FakeDataset(), calls, 8) is False and not built
+    assert g.covariance(Shared(), calls, 8) is True and len(built) == 5
