@@ -26,6 +26,142 @@ __global__ __launch_bounds__(256) void cov_pack_kernel(const double* z, int64_t 
   Z[e] = l < n_lanes ? z[(int64_t)l * ld + j] : 0.0;
 }
 
+// The product of a covariance pass, partial[by][l][col] = sum_{row in block by} Z[row][l] G[row][col]: xtr_mfma_kernel's loop
+// (same operands, same layouts: G in the place of X, the lanes' points Z[ld][16] in the place of the residuals), with one
+// more way to run.  A point the model solver produced is zero outside the working set W (PathCtl::zsup, what lets the
+// split pass form residuals from the gathered columns), so when EVERY live lane's point is such a point only the K <= 512
+// rows of G listed in `idx` can contribute: the workgroups then read those rows (a.xrows_ws of the list each: indices first,
+// then all loads of the block at once) -- 8 K ld bytes, 12 MB at K = 300, instead of the 200 MB of G, 8-10 us instead of 37
+// per row set and pass.  Plain steps (zsup = 0), a working set under construction, or no working set at all: every row.
+__global__ __launch_bounds__(XTR_WAVES * 64, 2) void cov_gz_mfma_kernel(SplitArgs a) {
+  if (a.done != nullptr && *a.done != 0) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+  {  // XCD-aware tile order, as in xtr_mfma_kernel
+    const int total = (int)(gridDim.x * gridDim.y), lin = bx + (int)gridDim.x * by;
+    const int xcd = lin & 7, slot = lin >> 3, base = total >> 3, rem = total & 7;
+    const int m = xcd * base + (xcd < rem ? xcd : rem) + slot;
+    bx = m % (int)gridDim.x;
+    by = m / (int)gridDim.x;
+  }
+  const int col0 = (bx * XTR_WAVES + wave) * XTR_CW;
+  const int ld = (int)a.ld;
+  if (col0 >= ld) return;  // (no barrier below)
+  const int kq = lane >> 4, i16 = lane & 15;
+  int coff[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = col0 + 32 * c + 2 * i16;
+    coff[c] = col < ld - 2 ? col : ld - 2;
+  }
+  slm_d4 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = slm_d4{0.0, 0.0, 0.0, 0.0};
+  bool listed = false;
+  if (a.ctl != nullptr && a.ws != nullptr && a.xrows_ws > 0) {
+    unsigned live, on_ws;
+    split_masks(a, live, on_ws);
+    listed = live != 0u && live == on_ws && (int64_t)a.xrows_ws * (int64_t)gridDim.y >= (int64_t)a.ws->K;
+  }
+  if (listed) {
+    const int K = a.ws->K;
+    const int k0 = by * a.xrows_ws;
+    // the rows of this block: indices first (one round trip), then every load of the block (a.xrows_ws <= 32: eight steps)
+    int rows[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int k = k0 + 4 * t + kq;
+      rows[t] = (4 * t < a.xrows_ws && k < K) ? a.idx[k] : -1;
+    }
+    d2 xv[8][4];
+    double rv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int64_t r = rows[t] >= 0 ? rows[t] : 0;  // (a row that is not there multiplies row 0 by zero)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xv[t][c] = *reinterpret_cast<const d2*>(a.X + r * a.ld + coff[c]);
+      rv[t] = a.R[r * SPLIT_RSTRIDE + i16];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const double z = rows[t] >= 0 ? rv[t] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t][c].x, z, acc[2 * c], 0, 0, 0);
+        acc[2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t][c].y, z, acc[2 * c + 1], 0, 0, 0);
+      }
+    }
+  } else {
+    const int64_t r0 = (int64_t)by * a.xrows;
+    const int64_t r1 = r0 + a.xrows < a.n ? r0 + a.xrows : a.n;
+    const int nb = r1 > r0 ? (int)((r1 - r0) / (4 * XTR_U)) : 0;  // full batches
+    const double* xp = a.X + (r0 + kq) * a.ld;
+    const double* rp = a.R + (r0 + kq) * SPLIT_RSTRIDE + i16;
+    d2 xa[XTR_U][4], xb[XTR_U][4];
+    double ra[XTR_U], rb[XTR_U];
+    auto load = [&](d2(&xv)[XTR_U][4], double(&rv)[XTR_U], int b) {
+      const double* xq = xp + (int64_t)b * (4 * XTR_U) * a.ld;
+      const double* rq = rp + (int64_t)b * (4 * XTR_U) * SPLIT_RSTRIDE;
+#pragma unroll
+      for (int u = 0; u < XTR_U; ++u) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xv[u][c] = *reinterpret_cast<const d2*>(xq + (int64_t)u * 4 * a.ld + coff[c]);
+        rv[u] = rq[u * 4 * SPLIT_RSTRIDE];
+      }
+    };
+    auto compute = [&](d2(&xv)[XTR_U][4], double(&rv)[XTR_U]) {
+#pragma unroll
+      for (int u = 0; u < XTR_U; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].x, rv[u], acc[2 * c], 0, 0, 0);
+          acc[2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].y, rv[u], acc[2 * c + 1], 0, 0, 0);
+        }
+    };
+    if (nb > 0) {
+      load(xa, ra, 0);
+      const int pairs = (nb - 1) >> 1;
+      for (int k = 0; k < pairs; ++k) {
+        load(xb, rb, 2 * k + 1);
+        compute(xa, ra);
+        load(xa, ra, 2 * k + 2);
+        compute(xb, rb);
+      }
+      if ((nb - 1) & 1) {
+        load(xb, rb, nb - 1);
+        compute(xa, ra);
+        compute(xb, rb);
+      } else {
+        compute(xa, ra);
+      }
+    }
+    for (int64_t row = r0 + (int64_t)nb * (4 * XTR_U); row < r1; row += 4) {
+      const bool ok = row + kq < r1;
+      const int64_t rr = ok ? row + kq : r1 - 1;
+      const double rv = ok ? a.R[rr * SPLIT_RSTRIDE + i16] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const d2 x = *reinterpret_cast<const d2*>(a.X + rr * a.ld + coff[c]);
+        acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, rv, acc[2 * c], 0, 0, 0);
+        acc[2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, rv, acc[2 * c + 1], 0, 0, 0);
+      }
+    }
+  }
+  if (i16 < SPLIT_LANES) {  // tile 2c+e holds columns col0 + 32 c + 2 i + e
+    double* out = a.partial + ((int64_t)by * SPLIT_LANES + i16) * a.ld;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = col0 + 32 * c + 2 * (kq + 4 * r) + e;
+          if (col < ld) out[col] = acc[2 * c + e][r];
+        }
+  }
+}
+
 struct CovFinishArgs {
   const double* partial;  // [nblk][16][ld] of xtr_mfma_kernel
   const double* c;        // [ld]

@@ -252,6 +252,21 @@ static int launch_xtr(int cus, SplitArgs& a, hipStream_t s) {
   return yb;
 }
 
+// the product of a covariance pass (cov_gz_mfma_kernel): xtr_mfma_kernel's grid; when only the working set's rows are read a
+// workgroup row takes the next multiple of four of WS_KCAP / row blocks list entries (at most 32: eight steps in registers)
+static int launch_cov_gz(int cus, SplitArgs& a, hipStream_t s) {
+  const int xb = (int)((a.ld + XTR_CB - 1) / XTR_CB);
+  const int64_t want = std::max<int64_t>(1, xtr_max_row_blocks(cus, a.ld) / 2);
+  int64_t rows = (a.n + want - 1) / want;
+  rows = (rows + 7) / 8 * 8;
+  const int yb = (int)((a.n + rows - 1) / rows);  // <= want
+  a.xrows = (int)rows;
+  const int per = ((WS_KCAP + yb - 1) / yb + 3) / 4 * 4;
+  a.xrows_ws = (a.ctl != nullptr && per <= 32) ? per : 0;
+  hipLaunchKernelGGL(cov_gz_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+  return yb;
+}
+
 static const GradKernel* pick_grad_kernel(int64_t p2, int B) {
   if (p2 > kMaxChunks) return B == 1 ? &kGradTwoPass : nullptr;
   // LDS-ring variants: measured flat in B (0.60-0.61 ms for B = 1..4 at p = 5000) where the register
@@ -1283,7 +1298,7 @@ static int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const do
 // The gradient of one pass from the Grams of the lanes' row sets (cov_kernels.hpp): g_l = G_s z_l - c_s, loss in g_l[ld].
 // `entry_of[l]`: the lane's entry of ds->cov.  One read of a 8 ld^2-byte Gram per row set of the call instead of X.
 static int enqueue_gradient_cov(slm_dataset* ds, int B, const int* entry_of, const int* done, hipEvent_t ev_start,
-                                hipEvent_t ev_stop) {
+                                hipEvent_t ev_stop, const PathCtl* ctl = nullptr, const WsArgs* wa = nullptr) {
   hipStream_t s = ds->eng->stream;
   const int64_t ld = ds->ld;
   hipLaunchKernelGGL(cov_pack_kernel, dim3((unsigned)((ld * SPLIT_RSTRIDE + 255) / 256)), dim3(256), 0, s, ds->z, ld, B, ds->cov_Z, done);
@@ -1302,7 +1317,9 @@ static int enqueue_gradient_cov(slm_dataset* ds, int B, const int* entry_of, con
     memset(&a, 0, sizeof(a));
     a.X = e.G; a.R = ds->cov_Z; a.partial = ds->partial; a.done = done;
     a.n = ld; a.ld = ld; a.p2 = (int)(ld / 2); a.n_lanes = B;
-    const int xblk = launch_xtr(ds->eng->cus, a, s);
+    // (points the model solver produced are zero outside the working set: only its rows of G are read then)
+    if (ctl && wa && wa->ws && !getenv("SLM_COV_ALL_ROWS")) { a.ctl = ctl; a.ws = wa->ws; a.idx = wa->idx; }
+    const int xblk = launch_cov_gz(ds->eng->cus, a, s);
     CovFinishArgs f;
     f.partial = ds->partial; f.c = e.c; f.z = ds->z; f.g = ds->g; f.done = done; f.nblk = xblk; f.ld = ld;
     f.lane_mask = mask; f.yy = e.yy;
@@ -2402,7 +2419,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // the gradient of one pass: split pass (sixteen lane slots, residuals from the gathered columns where
   // possible) when the working set runs from the start, the fused kernel otherwise
   auto enqueue_pass_gradient = [&](hipEvent_t e0, hipEvent_t e1) -> int {
-    if (cov_on) return enqueue_gradient_cov(ds, B, cov_entry, done_flag, e0, e1);
+    if (cov_on) return enqueue_gradient_cov(ds, B, cov_entry, done_flag, e0, e1, ds->ctl, use_ws ? &wa : nullptr);
     if (split) return enqueue_gradient_split(ds, ls, ds->y, done_flag, ds->ctl, &wa, e0, e1);
     return enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1);
   };

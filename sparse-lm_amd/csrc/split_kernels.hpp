@@ -49,6 +49,7 @@ struct SplitArgs {
   int n_lanes;
   int lane0;  // rowdot_ring_kernel: first lane of this launch
   int xrows;  // xtr_mfma_kernel: rows per workgroup row (multiple of 8); partial is then [gridDim.y][SPLIT_LANES][ld]
+  int xrows_ws;  // cov_gz_mfma_kernel: listed rows per workgroup row when only the working set's rows are read (multiple of 4, <= 32)
   const double* XT;  // rowdot_mfma_kernel: column-major copy of X in tiles of 32 rows (tile_columns_kernel)
 };
 
