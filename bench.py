@@ -608,6 +608,44 @@ def leg_soak(eng, n, p, K, tol, lanes, seeds=range(4, 16)):
     return {"cases": rows}
 
 
+def leg_plain(eng, rank, n, p, K, tol, steps=3):
+    """The headline path WITHOUT the working set, so that the kernel's contribution can be told from the algorithm's:
+    `plain_fista` -- accelerated proximal gradient with restarts (the iteration the north star names), four lanes on the fused
+    one-read kernel; `plain_spectral_16` -- the engine's spectral steps on sixteen lanes, whose pass is two reads of X
+    (rowdot_mfma_kernel, then xtr_mfma_kernel).  Per gradient unit (one pass for all its lanes) the roofline fraction is
+    charged ONE W = 8 (n p + 2 n + 2 p lanes) bytes, as SURVEY 8(d) charges it, over the whole time between two passes."""
+    from sparselm_amd import _engine
+
+    coef = make_coef(p, 50, seed=0)
+    out = {}
+    with eng.synthetic_dataset(n, p, seed=1000 + rank, coef=coef, noise_sd=10.0) as ds:
+        g0, _ = ds.gradient(None)
+        amax = float(np.max(np.abs(g0)))
+        points = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-3 * amax, K)]
+        for name, lanes, flags in (("plain_fista", 4, _engine.FLAG_FISTA_ONLY | _engine.FLAG_NO_WORKING_SET),
+                                   ("plain_spectral_16", 16, _engine.FLAG_NO_WORKING_SET)):
+            flags |= _engine.FLAG_FRESH_L | _engine.FLAG_PROFILE
+            ds.solve_path(points, tol=tol, flags=flags, lanes=lanes)
+            eng.synchronize()
+            t0 = time.perf_counter()
+            kernel_ms, timed, passes = 0.0, 0, 0
+            for _ in range(steps):
+                res = ds.solve_path(points, tol=tol, flags=flags, lanes=lanes)
+                kernel_ms += res.grad_ms_total
+                timed += res.grad_timed
+                passes += res.grad_launches
+            eng.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            W = 8.0 * (n * p + 2 * n + 2 * p * lanes)
+            unit_ms = 1e3 * dt / (passes / steps)
+            out[name] = {"fits_per_s": K / dt, "ms_per_path": 1e3 * dt, "passes": passes // steps, "lanes": lanes,
+                         "converged": bool(res.converged), "gradient_unit_ms": unit_ms,
+                         "roofline_frac_per_unit_one_W": W / (unit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_ms_by_hip_events": kernel_ms / max(1, timed),
+                         "kernel_timed": "the fused one-read kernel" if lanes <= 4 else "xtr_mfma_kernel only (the second of the pass's two reads)"}
+    return out
+
+
 def leg_config3(eng, rank, world, n, p, tol, cpu_budget_s, steps=5):
     """BASELINE config 3 (GroupLasso, 500 shuffled groups of 10, 50-alpha path) on the data law of `Config4`, timed on
     the GPU; and -- rank 0 of a one-GPU run with a CPU budget -- an independent full-size referee for the group family:
@@ -783,7 +821,7 @@ def leg_rowshard(eng, rank, world, n_rank, p, reps=2):
             eng.synchronize()
             dt = time.perf_counter() - t0
             out = {"seconds_per_fit": dt, "passes": passes, "converged": bool(res.converged),
-                   "active_groups": int(np.sum(res.group_norms[0] > 0)), "rccl_ranks": comm_ranks,
+                   "active_groups": int(np.sum(res.group_norms[0] > 0)), "rccl_ranks": comm_ranks, "device": eng.device_id,
                    "beta_checksum": float(np.sum(beta * np.arange(1, p + 1)))}
         return out
     finally:
@@ -1025,6 +1063,7 @@ def main():
                              ("config4_grid_dense_regime", lambda: leg_config4_dense(eng, n, p) if rank == 0 and world == 1 else {}),
                              ("config3_path", lambda: leg_config3(eng, rank, world, n, p, args.tol, args.cpu_budget)),
                              ("soak", lambda: leg_soak(eng, n, p, K, args.tol, args.lanes) if rank == 0 else {}),
+                             ("plain_iteration", lambda: leg_plain(eng, rank, n, p, K, args.tol) if rank == 0 else {}),
                              # (every rank: with a process group up, GridSearchCV shards the search over the ranks and gathers)
                              ("config1_small", lambda: leg_config1_small()),
                              ("concurrent_paths", lambda: leg_concurrent_paths(eng, device_id, rank, n, p, K, args.tol, args.lanes)),
@@ -1163,6 +1202,12 @@ def main():
                         "median_ms_sparse_end": sorted(c["ms"] for c in cases if c["nnz_last"] <= 512)[(len(cases) - len(dense)) // 2]
                         if len(dense) < len(cases) else None,
                     }
+                elif name == "plain_iteration":
+                    legs["plain_fista"] = {"what": "the headline path by plain FISTA with restarts, no working set, four lanes on the "
+                                           "fused one-read kernel: what the kernel alone buys", **parts[0].get("plain_fista", {})}
+                    legs["plain_spectral_16"] = {"what": "the headline path by the engine's spectral steps without the working set, "
+                                                 "sixteen lanes, two reads of X per pass (the regime of paths that end above 512 "
+                                                 "non-zeros)", **parts[0].get("plain_spectral_16", {})}
                 elif name == "config1_small":
                     legs[name] = {
                         "what": "BASELINE config 1 (the reference's README example: GridSearchCV(AdaptiveLasso), 10 alphas x 5 folds + "
@@ -1191,6 +1236,8 @@ def main():
                         "fits_per_s": 1.0 / max(secs), "seconds_per_fit": max(secs), "seconds_per_rank": secs,
                         "passes": parts[0]["passes"], "passes_agree": len({q["passes"] for q in parts}) == 1,
                         "rccl_ranks": parts[0]["rccl_ranks"], "converged": all(q["converged"] for q in parts),
+                        # non-zero: the ranks sit on distinct devices and RCCL still did not join them all (a failure, loud)
+                        "status": int(len({q["device"] for q in parts}) == world and any(q["rccl_ranks"] != world for q in parts)),
                         "active_groups": parts[0]["active_groups"],
                         "ranks_hold_identical_coefficients": max(sums) == min(sums),
                         "rows_per_s": world * args.rowshard_rows * parts[0]["passes"] / max(secs),

@@ -212,3 +212,28 @@ def test_grams_summed_from_the_row_blocks_of_the_ranks(eng, n, p, world):
     finally:
         for e in engines:
             e.close()
+
+
+def _run_tool(name, *args):
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    return subprocess.run([sys.executable, os.path.join(root, "tools", name), *args], capture_output=True, text=True, timeout=900)
+
+
+def test_randomised_cross_check_of_covariance_passes():
+    """tools/covariance_fuzz.py: 60 random calls (penalty kinds, group sizes, 1-16 lanes, folds / general weights / no
+    weights as row sets, per-lane 1/n, warm starts, p > n, with and without the working set) solved over X and from the
+    Grams of their row sets."""
+    out = _run_tool("covariance_fuzz.py", "60", "1")
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "flagged 0" in out.stdout.splitlines()[-1]
+
+
+def test_odd_shapes_through_the_on_chip_solvers_and_the_grams():
+    """tools/edge_cases.py: one to three features, two rows, one group over everything, p = 128, one-point paths on sixteen
+    lanes -- on chip, through the splitting, and from Grams -- each against the general path."""
+    out = _run_tool("edge_cases.py")
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "edge cases done" in out.stdout.splitlines()[-1]
