@@ -104,43 +104,6 @@ static int load_rccl() {
   return SLM_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// The BLAS library's dgemm, loaded lazily: the one plain GEMM of the engine (X^T W X of a covariance pass's Gram)
-// ------------------------------------------------------------------------------------------------
-typedef void* rocblasHandle_t;
-struct RocblasApi {
-  void* lib = nullptr;
-  int (*Create)(rocblasHandle_t*) = nullptr;
-  int (*Destroy)(rocblasHandle_t) = nullptr;
-  int (*SetStream)(rocblasHandle_t, hipStream_t) = nullptr;
-  int (*Dgemm)(rocblasHandle_t, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*,
-               double*, int) = nullptr;
-};
-static RocblasApi g_blas;
-static const int kRocblasOpNone = 111, kRocblasOpTranspose = 112;
-
-static int fail(int code, const char* fmt, ...);
-static int load_rocblas() {
-  if (g_blas.lib) return SLM_OK;
-  const char* names[] = {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"};
-  void* lib = nullptr;
-  for (const char* nm : names) {
-    // (RTLD_LOCAL: a process that also holds another copy of the library -- PyTorch ships its own -- must not see this
-    //  one's symbols in place of its own)
-    lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-    if (lib) break;
-  }
-  if (!lib) return fail(SLM_ERR_UNSUPPORTED, "cannot load librocblas (covariance passes need its dgemm): %s", dlerror());
-  g_blas.Create = (decltype(g_blas.Create))dlsym(lib, "rocblas_create_handle");
-  g_blas.Destroy = (decltype(g_blas.Destroy))dlsym(lib, "rocblas_destroy_handle");
-  g_blas.SetStream = (decltype(g_blas.SetStream))dlsym(lib, "rocblas_set_stream");
-  g_blas.Dgemm = (decltype(g_blas.Dgemm))dlsym(lib, "rocblas_dgemm");
-  if (!g_blas.Create || !g_blas.Destroy || !g_blas.SetStream || !g_blas.Dgemm)
-    return fail(SLM_ERR_UNSUPPORTED, "librocblas is missing required symbols");
-  g_blas.lib = lib;
-  return SLM_OK;
-}
-
 #define RCCL_TRY(expr)                                                                      \
   do {                                                                                      \
     int e__ = (expr);                                                                       \
@@ -333,7 +296,6 @@ struct slm_engine {
   // dataset: part f is summed over the ranks while part f + 1 is still being built), made on first use
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ev = nullptr;
-  rocblasHandle_t blas = nullptr;  // covariance passes: created on first use
   bool sharded() const { return comm != nullptr || local != nullptr; }
 };
 
@@ -527,10 +489,19 @@ static inline bool row_sharded(const slm_dataset* ds) { return ds->eng->sharded(
 // block waits in a per-device list of its exact size, and the next dataset of that shape takes it instead of asking the
 // driver.  hipMalloc right behind the hipFree of such blocks stalled for SECONDS now and then (the soak over 96 datasets
 // of the headline shape, profiles/r02c_headline_soak.log: a 6-pass path in 2.4 s; 3.6 s in r02a) -- a fresh fit paying
-// three hundred times its solve.  At most kPoolIdleCap bytes wait per process; when the driver has no memory left the
+// three hundred times its solve.  At most pool_idle_cap() bytes wait per process; when the driver has no memory left the
 // waiting blocks are handed back and the allocation is tried again.  Nothing relies on a block's contents.
 static const size_t kPoolMinBytes = (size_t)64 << 20;
-static const size_t kPoolIdleCap = (size_t)48 << 30;
+// idle blocks kept per process: 16 GB unless SLM_DEVICE_POOL_GB says otherwise (0 turns the pool off) -- a block idle here is
+// memory no other allocator on the GPU can have (another rank sharing the device, torch, RCCL's buffers): enough for the two
+// or three blocks of the largest dataset shape seen lately, not a standing reservation
+static size_t pool_idle_cap() {
+  static const size_t cap = [] {
+    if (const char* e = getenv("SLM_DEVICE_POOL_GB")) return (size_t)(std::max(0.0, atof(e)) * (double)((size_t)1 << 30));
+    return (size_t)16 << 30;
+  }();
+  return cap;
+}
 struct DevicePool {
   std::mutex m;
   std::vector<std::pair<int, std::pair<size_t, void*>>> idle;  // (device, (bytes, block))
@@ -577,7 +548,13 @@ static void pool_free(void* p) {
         const int dev = g_pool.live[i].second.first;
         const size_t bytes = g_pool.live[i].second.second;
         g_pool.live.erase(g_pool.live.begin() + (long)i);
-        if (g_pool.idle_bytes + bytes <= kPoolIdleCap && !getenv("SLM_NO_DEVICE_POOL")) {
+        if (!getenv("SLM_NO_DEVICE_POOL") && bytes <= pool_idle_cap()) {
+          // (over the cap: the blocks that have waited longest go back to the driver first)
+          while (g_pool.idle_bytes + bytes > pool_idle_cap() && !g_pool.idle.empty()) {
+            (void)hipFree(g_pool.idle.front().second.second);
+            g_pool.idle_bytes -= g_pool.idle.front().second.first;
+            g_pool.idle.erase(g_pool.idle.begin());
+          }
           g_pool.idle.push_back({dev, {bytes, p}});
           g_pool.idle_bytes += bytes;
           return;
@@ -684,8 +661,6 @@ extern "C" int slm_engine_destroy(slm_engine* eng) {
   if (!eng) return SLM_OK;
   (void)hipSetDevice(eng->device);
   if (eng->sharded()) (void)slm_comm_destroy(eng);
-  // (the BLAS handle is left to the process: engines are destroyed at interpreter exit, when the library's own state may
-  //  already be gone)
   if (eng->comm_ev) (void)hipEventDestroy(eng->comm_ev);
   if (eng->comm_stream) (void)hipStreamDestroy(eng->comm_stream);
   if (eng->stream) (void)hipStreamDestroy(eng->stream);
@@ -2714,35 +2689,23 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
 // ------------------------------------------------------------------------------------------------
 // covariance passes: the Gram of a row set
 // ------------------------------------------------------------------------------------------------
-// C = A^T A for the row-major rows x ld block A: cov_syrk_kernel; SLM_COV_BLAS=1: the BLAS library's dgemm instead (A/B runs)
+// C = A^T A for the row-major rows x ld block A (cov_syrk_kernel: the square with its mirror, for one row set at a time;
+// the folds of a K-fold split go through cov_syrk_packed_kernel, cov_folds_begin)
 static int cov_gram(slm_dataset* ds, const double* A, int64_t rows, double* C) {
   slm_engine* eng = ds->eng;
   hipStream_t s = eng->stream;
   const int64_t ld = ds->ld;
-  const char* blas_env = getenv("SLM_COV_BLAS");
-  if (!(blas_env && blas_env[0] == '1')) {
-    if (rows < 1) {
-      HIP_TRY(hipMemsetAsync(C, 0, sizeof(double) * (size_t)ld * ld, s));
-      return SLM_OK;
-    }
-    int side = cov_tile_for(ld, eng->cus);
-    if (const char* e = getenv("SLM_COV_TILE")) side = atoi(e) == 3 ? 3 : 4;  // (A/B runs: 96 or 128 columns per workgroup)
-    const int nt = (int)((ld + 32 * side - 1) / (32 * side));
-    const dim3 grid((unsigned)(nt * (nt + 1) / 2));
-    if (side == 3) hipLaunchKernelGGL(cov_syrk_kernel<3>, grid, dim3(256), 0, s, A, rows, ld, C);
-    else hipLaunchKernelGGL(cov_syrk_kernel<4>, grid, dim3(256), 0, s, A, rows, ld, C);
-    return check_launch();
+  if (rows < 1) {
+    HIP_TRY(hipMemsetAsync(C, 0, sizeof(double) * (size_t)ld * ld, s));
+    return SLM_OK;
   }
-  SLM_TRY(load_rocblas());
-  if (!eng->blas) {
-    if (g_blas.Create(&eng->blas) != 0) return fail(SLM_ERR_HIP, "rocblas_create_handle failed");
-    if (g_blas.SetStream(eng->blas, s) != 0) return fail(SLM_ERR_HIP, "rocblas_set_stream failed");
-  }
-  const double one = 1.0, zero = 0.0;
-  const int st = g_blas.Dgemm(eng->blas, kRocblasOpNone, kRocblasOpTranspose, (int)ld, (int)ld, (int)rows, &one, A, (int)ld, A, (int)ld,
-                              &zero, C, (int)ld);
-  if (st != 0) return fail(SLM_ERR_HIP, "rocblas_dgemm failed (status %d)", st);
-  return SLM_OK;
+  int side = cov_tile_for(ld, eng->cus);
+  if (const char* e = getenv("SLM_COV_TILE")) side = atoi(e) == 3 ? 3 : 4;  // (A/B runs, tests: 96 or 128 columns per workgroup)
+  const int nt = (int)((ld + 32 * side - 1) / (32 * side));
+  const dim3 grid((unsigned)(nt * (nt + 1) / 2));
+  if (side == 3) hipLaunchKernelGGL(cov_syrk_kernel<3>, grid, dim3(256), 0, s, A, rows, ld, C);
+  else hipLaunchKernelGGL(cov_syrk_kernel<4>, grid, dim3(256), 0, s, A, rows, ld, C);
+  return check_launch();
 }
 
 // the Gram of the rows `rows_host[0..count)` of X (gathered into a block of its own), unscaled, into C

@@ -51,7 +51,10 @@ class StandardizedSparseGroupProblem:
         # the A/B partner of that kernel (option ``on_chip=False``).
         self.dev = None
         self.dev_warm = False
-        if self.options.get("on_chip", True) is not False:
+        # (only where that kernel can take the problem -- p <= 128 and n * ld <= 2^17, the rule of slm_solve_standardized_sgl:
+        #  for anything larger a device dataset opened here would be an upload of X, learned to be useless at the first solve)
+        ld = (self.p + 15) // 16 * 16
+        if self.options.get("on_chip", True) is not False and self.p <= 128 and self.n * ld <= 131072:
             self.dev = get_backend().problem(self.X, self.y, gidx, self.G, self.options)
             if not hasattr(getattr(self.dev, "ds", None), "solve_standardized_sgl"):  # (the tests' CPU stand-in)
                 self.dev.close()

@@ -373,14 +373,14 @@ class _DeviceGrid:
         # clone / get_params / inspect.signature cost was a quarter of the search)
         seen = set()
         for params in candidates:
-            fresh = [k for k, v in params.items() if (k, repr(v)) not in seen]
+            fresh = [k for k, v in params.items() if (k, _value_key(v)) not in seen]
             if fresh:
-                seen.update((k, repr(v)) for k, v in params.items())
+                seen.update((k, _value_key(v)) for k, v in params.items())
                 clone(est).set_params(**params)._validate_params(X, y)
         # units: (non-alpha params, fold) -> one warm-started alpha path
         by_combo = defaultdict(list)
         for ci, params in enumerate(candidates):
-            key = tuple(sorted((k, repr(v)) for k, v in params.items() if k != "alpha"))
+            key = tuple(sorted((k, _value_key(v)) for k, v in params.items() if k != "alpha"))
             by_combo[key].append(ci)
         self.adaptive = isinstance(est, AdaptiveLasso)
         if self.adaptive:  # every (candidate, fold) is its own re-weighting loop: no shared alpha path
@@ -786,6 +786,20 @@ class LineSearchCV(BaseSearchCV):
     def _run_search(self, evaluate_candidates):
         """Unused: every line is its own GridSearchCV."""
         return
+
+
+def _value_key(v):
+    """What two grid values must share to count as the same value: the CONTENT of arrays (`repr` elides the middle of an
+    array of more than a thousand entries -- two `group_weights` candidates that differ only there would be one unit,
+    solved and scored with the first one's penalty), `repr` for everything else."""
+    if isinstance(v, (np.ndarray, list, tuple)):
+        try:
+            a = np.asarray(v)
+            if a.dtype != object:
+                return ("array", a.dtype.str, a.shape, a.tobytes())
+        except (ValueError, TypeError):
+            pass
+    return repr(v)
 
 
 def _solver_options(est) -> dict:

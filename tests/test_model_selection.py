@@ -593,3 +593,24 @@ def test_covariance_auto_weighs_the_passes_against_the_grams():
     g, calls = grid("auto", 320)
     assert g.covariance(FakeDataset(), calls, 8) is False and not built
     assert g.covariance(Shared(), calls, 8) is True and len(built) == 5
+
+
+def test_grid_values_are_told_apart_by_content_not_by_repr():
+    """Two `group_weights` candidates of more than a thousand entries that differ only where numpy's repr elides the array
+    are two units of the device grid, not one (each is solved with its own penalty)."""
+    from sparselm_amd.model import GroupLasso
+    from sparselm_amd.model_selection import _DeviceGrid, _value_key
+
+    p = 1200
+    w1 = np.ones(p)
+    w2 = np.ones(p)
+    w2[600] = 2.0
+    assert repr(w1) == repr(w2) and _value_key(w1) != _value_key(w2)
+    assert _value_key(0.5) == _value_key(0.5) and _value_key([1.0, 2.0]) == _value_key(np.array([1.0, 2.0]))
+    rng = np.random.default_rng(0)
+    X, y = rng.standard_normal((40, p)), rng.standard_normal(40)
+    search = GridSearchCV(GroupLasso(groups=np.arange(p)), {"alpha": [1.0, 0.5], "group_weights": [w1, w2]}, cv=KFold(2))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        grid = _DeviceGrid(search, X, y, None)
+    assert len(grid.combos) == 2 and sorted(len(c) for c in grid.combos) == [2, 2]
