@@ -1324,9 +1324,9 @@ static int cov_find(const slm_dataset* ds, double fp1, double fp2, double n_eff)
   return -1;
 }
 
-// E = features per thread of the one-workgroup-per-lane tail kernel (p <= 1024 * E).  Up to E = 8
-// everything stays in registers; the larger instantiations (long-row fallback) spill to scratch,
-// which is irrelevant next to a two-pass gradient over a matrix that wide.
+// E = features per thread of the one-workgroup-per-lane tail kernel (p <= 1024 * E).  Up to E = 6 everything a thread
+// needs of its features stays in registers; rows of more than 6 144 columns take the streaming form of the same kernel,
+// which keeps nothing per feature across a workgroup sum and so needs no scratch memory at any p.
 static void launch_tail(const TailArgs& ta, hipStream_t s) {
   const int E = (ta.p + TAIL_THREADS - 1) / TAIL_THREADS;
   const dim3 grid(ta.n_lanes);
@@ -1338,14 +1338,7 @@ static void launch_tail(const TailArgs& ta, hipStream_t s) {
     case 4: SLM_TAIL_LAUNCH(4); break;
     case 5: SLM_TAIL_LAUNCH(5); break;
     case 6: SLM_TAIL_LAUNCH(6); break;
-    case 7: SLM_TAIL_LAUNCH(7); break;
-    case 8: SLM_TAIL_LAUNCH(8); break;
-    case 9: SLM_TAIL_LAUNCH(9); break;
-    case 10: SLM_TAIL_LAUNCH(10); break;
-    default:
-      if (E <= 16) SLM_TAIL_LAUNCH(16);
-      else if (E <= 32) SLM_TAIL_LAUNCH(32);
-      else SLM_TAIL_LAUNCH(64);
+    default: hipLaunchKernelGGL(fista_tail_stream_kernel, grid, dim3(TAIL_THREADS), 0, s, ta);
   }
 #undef SLM_TAIL_LAUNCH
 }
@@ -2446,8 +2439,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         // same state machine on the same all-reduced gradients, so they agree on when that is
         const size_t gram_words = (size_t)wa.n_sets * WS_KCAP * WS_KCAP;
         if (ws_comm_rc == 0) ws_comm_rc = all_reduce_sum(eng, wa.Gx, gram_words + STOP_WORDS);  // (+ the stop words: enqueue_tail)
-        hipLaunchKernelGGL(ws_publish_kernel, dim3(WS_KCAP * WS_KCAP / 256, (unsigned)wa.n_sets), dim3(256), 0, s,
-                           wa);
+        hipLaunchKernelGGL(ws_publish_kernel, dim3(WS_PUBLISH_BLOCKS, (unsigned)wa.n_sets), dim3(256), 0, s, wa);
         hipLaunchKernelGGL(stop_apply_kernel, dim3(1), dim3(64), 0, s, ta.gdone, wa.Gx + gram_words);
       }
       // the iteration alone, then -- for the lanes it left -- the solver with direct steps (ws_refine_lane)

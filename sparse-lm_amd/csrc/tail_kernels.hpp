@@ -239,17 +239,28 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   double* us = US_IN_LDS ? us_lds : a.uscratch;
 
   // ---- phase 0: per-feature loads (independent of the control block) ---------------------------
-  // (kept to the minimum that must live across the reductions: 1024 threads => 128 VGPRs)
-  double zj[E], gj[E], bo[E], gpv[E];
+  // (kept to the minimum that must live across the reductions: 1024 threads => 128 VGPRs.  Up to six features per
+  //  thread the base point and its gradient stay in registers too; beyond -- p > 6144, BASELINE config 5's 10 000 --
+  //  they are read where they are used, once more from the L2 in the branches that need them again: with all four
+  //  vectors and the two results in registers a thread of E = 10 needs 120 of its 128 for them alone, and what did
+  //  not fit went to scratch memory, 20 ... 544 bytes per thread, whose dirty lines are written back at the end of
+  //  every call of this kernel)
+  constexpr bool KEEP = E <= 6;
+  double zj[E], gj[E], bo[KEEP ? E : 1], gpv[KEEP ? E : 1];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int j = tid + e * TAIL_THREADS;
     const int jj = j < p ? j : 0;
     zj[e] = a.z[jj];
     gj[e] = a.g[jj];
-    bo[e] = a.beta[jj];
-    gpv[e] = a.gprev[jj];
+    if (KEEP) {
+      bo[KEEP ? e : 0] = a.beta[jj];
+      gpv[KEEP ? e : 0] = a.gprev[jj];
+    }
   }
+  // base point / its gradient of feature slot e (jj: the slot's feature, clamped)
+  auto BO = [&](int e, int jj) -> double { return KEEP ? bo[KEEP ? e : 0] : a.beta[jj]; };
+  auto GPV = [&](int e, int jj) -> double { return KEEP ? gpv[KEEP ? e : 0] : a.gprev[jj]; };
 
   // uniform snapshot of the control block (read-only until the final single-thread update)
   const int point = ctl->point;
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
 
   // outcome of this call, filled by either scheme
   double u[E];   // next point z (candidate / extrapolated point), or the reported solution when finalize
-  double nb[E];  // new beta when !finalize
+  double(&nb)[E] = zj;  // new beta when !finalize: takes over the registers of z once the sums over z are done
   bool finalize = false, conv = false, nonfinite = false;
   double resid = 0.0, bnorm = 0.0;
   double kkt = 0.0, mu_eff = 0.0, new_mu_rq = mu_rq_old;
@@ -357,8 +368,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     double s[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      if (tid + e * TAIL_THREADS < p) {
-        const double dz = zj[e] - bo[e], dg = gj[e] - gpv[e];
+      const int j = tid + e * TAIL_THREADS;
+      if (j < p) {
+        const double dz = zj[e] - BO(e, j), dg = gj[e] - GPV(e, j);
         s[0] = __builtin_fma(dz, dz, s[0]);
         s[1] = __builtin_fma(dz, dg, s[1]);
         s[2] = __builtin_fma(dg, dg, s[2]);
@@ -431,40 +443,28 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     // base point and its gradient after the decision; (zprev, gprev) = (base, its gradient) stays a
     // consistent pair for the FISTA curvature guard should this lane fall back
     const double step = 1.0 / new_ak;
-    // (E <= 8, i.e. p <= 8192: two loops rather than `accept ? zj[e] : bo[e]` in one.  The compiler turns that
-    // into a choice between the ADDRESSES of the arrays, which puts all four of them in scratch memory -- sixteen
-    // stores, thirty loads and their lines to write back at the end of every call.  Beyond, the arrays do not fit
-    // the 128 registers of a thread anyway, and scratch arrays are the cheaper way of not fitting.)
-    if (E <= 8 && accept) {
+    // (two loops under one test rather than `accept ? zj[e] : bo[e]` in one: the compiler turns that into a choice
+    // between the ADDRESSES of the arrays, which puts them in scratch memory -- sixteen stores, thirty loads and their
+    // lines to write back at the end of every call.  nb IS zj from here on: an accepted candidate is the new base
+    // as it stands, a rejected one is overwritten by the old base)
+    if (accept) {
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int j = tid + e * TAIL_THREADS;
-        nb[e] = zj[e];
         if (j < p) {
           a.gprev[j] = gj[e];
           a.zprev[j] = nb[e];
         }
         u[e] = nb[e] - step * gj[e];
       }
-    } else if (E <= 8) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const int j = tid + e * TAIL_THREADS;
-        nb[e] = bo[e];
-        if (j < p) a.zprev[j] = nb[e];
-        u[e] = nb[e] - step * gpv[e];
-      }
     } else {
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int j = tid + e * TAIL_THREADS;
-        nb[e] = accept ? zj[e] : bo[e];
-        const double gb = accept ? gj[e] : gpv[e];
-        if (j < p) {
-          if (accept) a.gprev[j] = gb;
-          a.zprev[j] = nb[e];
-        }
-        u[e] = nb[e] - step * gb;
+        const int jj = j < p ? j : 0;
+        nb[e] = BO(e, jj);
+        if (j < p) a.zprev[j] = nb[e];
+        u[e] = nb[e] - step * GPV(e, jj);
       }
     }
     const bool fallback = !nonfinite && (new_rejects >= BB_REJECT_LIMIT || iter + 1 > BB_POINT_LIMIT);
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     for (int e = 0; e < E; ++e) {
       const int j = tid + e * TAIL_THREADS;
       if (j < p) {
-        const double dg = gj[e] - gpv[e], dzz = zj[e] - a.zprev[j];
+        const double dg = gj[e] - GPV(e, j), dzz = zj[e] - a.zprev[j];
         s[3] = __builtin_fma(dg, dg, s[3]);
         s[4] = __builtin_fma(dzz, dzz, s[4]);
         s[8] = __builtin_fma(dg, dzz, s[8]);
@@ -537,12 +537,13 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     prox_inplace(u, step, nullptr);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      if (tid + e * TAIL_THREADS < p) {
+      const int j = tid + e * TAIL_THREADS;
+      if (j < p) {
         const double bn = u[e];
         const double dz = bn - zj[e];
         s[0] = __builtin_fma(dz, dz, s[0]);
         s[1] = __builtin_fma(bn, bn, s[1]);
-        s[2] = __builtin_fma(-dz, bn - bo[e], s[2]);
+        s[2] = __builtin_fma(-dz, bn - BO(e, j), s[2]);
         if (!isfinite(bn)) s[6] += 1.0;
       }
     }
@@ -574,14 +575,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     finalize = nonfinite || conv || hit_max;
     new_t = l_bad ? 1.0 : t_new;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const double bn = u[e];
+    for (int e = 0; e < E; ++e) {  // (z is spent: nb takes its registers)
+      const int j = tid + e * TAIL_THREADS;
+      const double bn = u[e], bold = BO(e, j < p ? j : 0);
       if (l_bad) {
-        nb[e] = bo[e];  // step rejected: beta unchanged, momentum dropped
-        u[e] = bo[e];
+        nb[e] = bold;  // step rejected: beta unchanged, momentum dropped
+        u[e] = bold;
       } else {
         nb[e] = bn;
-        if (!finalize) u[e] = bn + mom * (bn - bo[e]);  // next extrapolated point
+        if (!finalize) u[e] = bn + mom * (bn - bold);  // next extrapolated point
       }
     }
   }
@@ -676,6 +678,393 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     } else {
       ctl->iter = iter + 1;
       atomicMax(&a.gdone[2], iter + 1);  // GlobalCtl::hard: lets the host give a hard problem the working set
+      ctl->t = new_t;
+      ctl->have_base = new_have_base;
+      ctl->n_hist = new_n_hist;
+      ctl->pen_z = new_pen_z;
+      ctl->mu_rq = new_mu_rq;
+#pragma unroll
+      for (int k = 0; k < BB_HIST; ++k) ctl->hist[k] = hist[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same kernel for rows of more than 6 144 columns (BASELINE config 5: p = 10 000), STREAMING: nothing per feature
+// lives in registers across a workgroup sum.  A thread of fista_tail_kernel<E> carries 6 E doubles (z, g, base, its
+// gradient, the new point, the new base) through three sums; from E = 7 on that is more than the 128 registers 1 024
+// threads leave each other, and what did not fit went to scratch memory -- 20 ... 544 bytes per thread from E = 7 to 10,
+// kilobytes beyond -- whose dirty lines the next kernel boundary has to write back ("Kernel
+// boundaries").  Here every phase walks the features (j = tid, tid + 1024, ...: the order, and therefore every sum, is
+// that of the register kernel), reads what it needs from the L2-resident vectors and leaves its result in the feature
+// image `us` (LDS up to 16 384 features, the per-lane global scratch beyond); the image is the candidate point, the
+// base point is zprev (which the decision phase writes anyway).  Same arithmetic, same state machine, any p.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArgs a) {
+  __shared__ double red[9][TAIL_WAVES];
+  constexpr int US_LDS = 16 * TAIL_THREADS;
+  __shared__ double us_lds[US_LDS];
+  const int lane_id = blockIdx.x;
+  PathCtl* ctl = a.ctl + lane_id;
+  if (ctl->done != 0 || ctl->idle != 0 || a.gdone[0] != 0) return;
+  const int tid = threadIdx.x;
+  const int p = a.p, G = a.G;
+  {  // rebase every per-lane pointer
+    const int64_t off = (int64_t)lane_id * a.ld;
+    a.beta += off; a.z += off; a.zprev += off; a.gprev += off;
+    a.a0 += off; a.b0 += off; a.d0 += off;
+    a.g += (int64_t)lane_id * (a.ld + 16);
+    a.gscale += (int64_t)lane_id * G;
+    a.uscratch += off;
+    const int64_t po = ctl->pt_off;
+    a.pts += po;
+    a.betas_out += po * p;
+    a.infos += po;
+    if (a.gn_out != nullptr) a.gn_out += po * G;
+  }
+  double* us = p <= US_LDS ? us_lds : a.uscratch;
+
+  const int point = ctl->point;
+  const int iter = ctl->iter;
+  const double L = ctl->L;
+  const double t_old = ctl->t;
+  const double tol = ctl->tol;
+  const uint32_t flags = ctl->flags;
+  const int64_t total_iter = ctl->total_iter;
+  const int n_points = ctl->n_points;
+  const int pt_lo = ctl->pt_lo;
+  const int max_iter = ctl->max_iter;
+  const int mode = ctl->mode;
+  const int have_base = ctl->have_base;
+  const int rejects = ctl->rejects;
+  const int n_hist = ctl->n_hist;
+  const double ak_old = ctl->ak;
+  const double Lhat_old = ctl->Lhat;
+  const double pen_z = ctl->pen_z;
+  const double mu_ws = ctl->mu;
+  const double mu_rq_old = ctl->mu_rq;
+  double hist[BB_HIST];
+#pragma unroll
+  for (int k = 0; k < BB_HIST; ++k) hist[k] = ctl->hist[k];
+  const slm_path_point pt = a.pts[point];
+  const double loss_z = a.g[a.ld];
+  const bool group_pen = (pt.sb != 0.0) || (pt.sd != 0.0);
+  const bool cold = (flags & SLM_FLAG_COLD_START) != 0;
+  const bool hit_max = (iter + 1 >= max_iter);
+  const double bnorm_floor = 1e-10 * sqrt(2.0 * fmax(loss_z, 0.0) / fmax(L, Lhat_old));
+
+  // the image us[] holds v; on return it holds prox_{step * penalty}(v).  pen (nullable): thread-partial penalty value
+  // of the result, accumulated in the order of fista_tail_kernel's prox_inplace
+  auto prox_image = [&](double step, double* pen) {
+#pragma unroll 4
+    for (int j = tid; j < p; j += TAIL_THREADS) {
+      double uu = soft(us[j], step * pt.sa * a.a0[j]);
+      if (group_pen && a.singleton) {
+        const double nrm = fabs(uu);
+        const double sc = nrm > 0.0 ? fmax(0.0, 1.0 - step * pt.sb * a.b0[j] / nrm) : 0.0;
+        uu *= sc / (1.0 + step * pt.sd * a.d0[j]);
+        if (pen) *pen += pt.sb * a.b0[j] * fabs(uu) + 0.5 * pt.sd * a.d0[j] * uu * uu;
+      }
+      us[j] = uu;
+    }
+    if (group_pen && !a.singleton) {
+      __syncthreads();
+      for_each_group_sumsq(us, a.order, a.gstart, G, a.team, [&](int g, double ss) {
+        const double nrm = sqrt(ss);
+        const double sc = (nrm > 0.0 ? fmax(0.0, 1.0 - step * pt.sb * a.b0[g] / nrm) : 0.0) /
+                          (1.0 + step * pt.sd * a.d0[g]);
+        a.gscale[g] = sc;
+        if (pen) {
+          const double nc = nrm * sc;
+          *pen += pt.sb * a.b0[g] * nc + 0.5 * pt.sd * a.d0[g] * nc * nc;
+        }
+      });
+      __syncthreads();
+#pragma unroll 4
+      for (int j = tid; j < p; j += TAIL_THREADS) us[j] *= a.gscale[a.gid[j]];
+    }
+    if (pen && pt.sa != 0.0) {
+#pragma unroll 4
+      for (int j = tid; j < p; j += TAIL_THREADS) *pen += pt.sa * a.a0[j] * fabs(us[j]);
+    }
+  };
+
+  bool finalize = false, conv = false, nonfinite = false;
+  double resid = 0.0, bnorm = 0.0;
+  double kkt = 0.0, mu_eff = 0.0, new_mu_rq = mu_rq_old;
+  int new_mode = mode, new_have_base = have_base, new_rejects = rejects, new_n_hist = n_hist;
+  double new_t = t_old, new_L = L, new_ak = ak_old, new_Lhat = Lhat_old, new_pen_z = pen_z;
+  bool did_restart = false, l_bad = false;
+  // how the last phase finds the new base point and the next point of feature j:
+  //   mode 1: base = zprev[j], next = us[j] (the candidate; the base itself on the switch to FISTA: us holds it then)
+  //   mode 0: base / next from us[j] (the proximal point) and beta[j], see below
+  double mom = 0.0;
+
+  if (mode == 1) {
+    double s[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+    for (int j = tid; j < p; j += TAIL_THREADS) {
+      const double z = a.z[j], g = a.g[j];
+      const double dz = z - a.beta[j], dg = g - a.gprev[j];
+      s[0] = __builtin_fma(dz, dz, s[0]);
+      s[1] = __builtin_fma(dz, dg, s[1]);
+      s[2] = __builtin_fma(dg, dg, s[2]);
+      if (!isfinite(g)) s[3] += 1.0;
+      s[5] = __builtin_fma(g, g, s[5]);
+    }
+    if (!have_base) {
+#pragma unroll 2
+      for (int j = tid; j < p; j += TAIL_THREADS) {
+        const double az = fabs(a.z[j]);
+        s[4] += pt.sa * a.a0[j] * az;
+        if (group_pen && a.singleton) s[4] += pt.sb * a.b0[j] * az + 0.5 * pt.sd * a.d0[j] * az * az;
+      }
+      if (group_pen && !a.singleton) {
+        for (int j = tid; j < p; j += TAIL_THREADS) us[j] = a.z[j];
+        __syncthreads();
+        for_each_group_sumsq(us, a.order, a.gstart, G, a.team, [&](int g, double ss) {
+          s[4] += pt.sb * a.b0[g] * sqrt(ss) + 0.5 * pt.sd * a.d0[g] * ss;
+        });
+      }
+    }
+    block_sum<6>(s, red);
+    const double Fz = loss_z + (have_base ? pen_z : s[4]);
+    nonfinite = s[3] > 0.0 || !isfinite(Fz);
+    bool accept;
+    if (!have_base) {
+      accept = true;
+      new_n_hist = 0;
+    } else {
+      double fmax_hist = hist[0];
+#pragma unroll
+      for (int k = 1; k < BB_HIST; ++k)
+        if (k < n_hist) fmax_hist = fmax(fmax_hist, hist[k]);
+      accept = Fz <= fmax_hist - 0.5 * BB_SIGMA * ak_old * s[0];
+      if (accept) {
+        if (s[0] > 0.0) {
+          new_Lhat = fmax(Lhat_old, sqrt(s[2] / s[0]));
+          new_ak = s[1] > 0.0 ? s[1] / s[0] : new_Lhat;
+        }
+        new_ak = fmin(fmax(new_ak, 1e-6 * new_Lhat), 1e6 * new_Lhat);
+        if (s[1] > 0.0 && s[0] * new_Lhat * new_Lhat > 1e-20 * s[5] && s[2] > 1e-20 * s[5])
+          new_mu_rq = mu_rq_old > 0.0 ? fmin(mu_rq_old, new_ak) : new_ak;
+      } else {
+        new_ak = fmin(2.0 * ak_old, 1e6 * Lhat_old);
+        new_rejects = rejects + 1;
+      }
+    }
+    if (accept) {
+      if (new_n_hist < BB_HIST) {
+#pragma unroll
+        for (int k = 0; k < BB_HIST; ++k)
+          if (k == new_n_hist) hist[k] = Fz;
+        new_n_hist += 1;
+      } else {
+#pragma unroll
+        for (int k = 0; k + 1 < BB_HIST; ++k) hist[k] = hist[k + 1];
+        hist[BB_HIST - 1] = Fz;
+      }
+      new_have_base = 1;
+    }
+    const double step = 1.0 / new_ak;
+    const bool fallback = !nonfinite && (new_rejects >= BB_REJECT_LIMIT || iter + 1 > BB_POINT_LIMIT);
+    __syncthreads();  // (the image may still be read by the group sums above)
+    // base point (-> zprev) and its gradient (-> gprev) after the decision; the image gets base - step * gradient,
+    // or, on the switch to FISTA, the base itself
+    if (accept) {
+#pragma unroll 2
+      for (int j = tid; j < p; j += TAIL_THREADS) {
+        const double z = a.z[j], g = a.g[j];
+        a.gprev[j] = g;
+        a.zprev[j] = z;
+        us[j] = fallback ? z : z - step * g;
+      }
+    } else {
+#pragma unroll 2
+      for (int j = tid; j < p; j += TAIL_THREADS) {
+        const double b = a.beta[j];
+        a.zprev[j] = b;
+        us[j] = fallback ? b : b - step * a.gprev[j];
+      }
+    }
+    if (fallback) {
+      new_mode = 0;
+      new_t = 1.0;
+      new_L = fmax(L, new_Lhat);
+      finalize = hit_max;
+      if (finalize) {
+        double q[1] = {0.0};
+#pragma unroll 4
+        for (int j = tid; j < p; j += TAIL_THREADS) q[0] = __builtin_fma(us[j], us[j], q[0]);
+        block_sum<1>(q, red);
+        bnorm = sqrt(q[0]);
+        resid = sqrt(s[0]);
+      }
+    } else {
+      double pen_c = 0.0;
+      prox_image(step, &pen_c);
+      double q[4] = {0, 0, pen_c, 0};
+#pragma unroll 4
+      for (int j = tid; j < p; j += TAIL_THREADS) {
+        const double c = us[j];
+        const double dc = c - a.zprev[j];
+        q[0] = __builtin_fma(dc, dc, q[0]);
+        q[1] = __builtin_fma(c, c, q[1]);
+        if (!isfinite(c)) q[3] += 1.0;
+      }
+      block_sum<4>(q, red);
+      nonfinite = nonfinite || q[3] > 0.0 || !isfinite(q[0]) || !isfinite(q[1]);
+      new_pen_z = q[2];
+      resid = sqrt(q[0]) * fmax(1.0, new_ak / new_Lhat);
+      bnorm = sqrt(q[1]);
+      kkt = sqrt(q[0]) * new_ak;
+      mu_eff = fmin(new_ak, new_Lhat);
+      if (new_mu_rq > 0.0) mu_eff = fmin(mu_eff, new_mu_rq);
+      if (mu_ws > 0.0) mu_eff = fmin(mu_eff, mu_ws);
+      mu_eff = fmax(mu_eff, kMuFloor * new_Lhat);
+      conv = kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[5]) + new_Lhat * bnorm));
+      finalize = nonfinite || conv || hit_max;
+    }
+  } else {
+    // ================= FISTA scheme =================================================================
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const double step = 1.0 / L;
+#pragma unroll 2
+    for (int j = tid; j < p; j += TAIL_THREADS) {
+      const double z = a.z[j], g = a.g[j];
+      const double dg = g - a.gprev[j], dzz = z - a.zprev[j];
+      s[3] = __builtin_fma(dg, dg, s[3]);
+      s[4] = __builtin_fma(dzz, dzz, s[4]);
+      s[8] = __builtin_fma(dg, dzz, s[8]);
+      s[5] = __builtin_fma(z, z, s[5]);
+      s[7] = __builtin_fma(g, g, s[7]);
+      a.gprev[j] = g;
+      a.zprev[j] = z;
+      us[j] = z - step * g;
+    }
+    prox_image(step, nullptr);
+#pragma unroll 2
+    for (int j = tid; j < p; j += TAIL_THREADS) {
+      const double bn = us[j];
+      const double dz = bn - a.z[j];
+      s[0] = __builtin_fma(dz, dz, s[0]);
+      s[1] = __builtin_fma(bn, bn, s[1]);
+      s[2] = __builtin_fma(-dz, bn - a.beta[j], s[2]);
+      if (!isfinite(bn)) s[6] += 1.0;
+    }
+    block_sum<9>(s, red);
+    nonfinite = s[6] > 0.0 || !isfinite(s[0]) || !isfinite(s[1]) || !isfinite(loss_z);
+    if (total_iter > 0 && s[4] > 1e-12 * s[5] && s[4] > 0.0) {
+      const double curv = sqrt(s[3] / s[4]);
+      if (curv > L * (1.0 + 1e-9)) {
+        l_bad = true;
+        new_L = 1.02 * curv;
+      }
+      if (s[8] > 0.0 && s[3] > 1e-20 * s[7]) new_mu_rq = mu_rq_old > 0.0 ? fmin(mu_rq_old, s[8] / s[4]) : s[8] / s[4];
+    }
+    did_restart = !(flags & SLM_FLAG_NO_RESTART) && s[2] > 0.0;
+    const double t_use = did_restart ? 1.0 : t_old;
+    const double t_new = 0.5 * (1.0 + sqrt(1.0 + 4.0 * t_use * t_use));
+    mom = (t_use - 1.0) / t_new;
+    resid = sqrt(s[0]);
+    bnorm = sqrt(s[1]);
+    kkt = resid * L;
+    mu_eff = mu_ws > 0.0 ? fmin(mu_ws, L) : L;
+    if (new_mu_rq > 0.0) mu_eff = fmin(mu_eff, new_mu_rq);
+    mu_eff = fmax(mu_eff, kMuFloor * L);
+    conv = !l_bad && (kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[7]) + L * bnorm)));
+    finalize = nonfinite || conv || hit_max;
+    new_t = l_bad ? 1.0 : t_new;
+  }
+
+  // ---- state update --------------------------------------------------------------------------
+  double extrap = 0.0;
+  const int stride = ctl->stride > 1 ? ctl->stride : 1;
+  if (finalize && !cold && !nonfinite && stride == 1 && point - pt_lo >= 1 && point + 1 < n_points)
+    extrap = a.pts[point + 1].extrap;
+  const int tail_pt = ctl->tail_pt;
+  const bool walk_end = point + stride >= n_points;
+  const bool range_end = finalize && !nonfinite && walk_end && (tail_pt < 0 || point == tail_pt);
+  const bool goes_idle = range_end && a.steal;
+#pragma unroll 2
+  for (int j = tid; j < p; j += TAIL_THREADS) {
+    double nbv, uu;  // new base, next point (or the reported solution)
+    if (mode == 1) {
+      nbv = a.zprev[j];
+      uu = us[j];
+    } else {
+      const double bn = us[j], bold = a.beta[j];
+      if (l_bad) {
+        nbv = bold;
+        uu = bold;
+      } else {
+        nbv = bn;
+        uu = finalize ? bn : bn + mom * (bn - bold);
+      }
+    }
+    if (finalize) {
+      a.betas_out[(int64_t)point * p + j] = uu;
+      double nxt = (cold || goes_idle) ? 0.0 : uu;
+      if (extrap != 0.0) nxt = uu + extrap * (uu - a.betas_out[(int64_t)(point - 1) * p + j]);
+      a.beta[j] = nxt;
+      a.z[j] = nxt;
+      us[j] = uu;  // (the group norms below read the reported solution)
+    } else {
+      a.beta[j] = nbv;
+      a.z[j] = uu;
+    }
+  }
+  if (finalize && a.gn_out != nullptr) {
+    __syncthreads();
+    double* gn = a.gn_out + (int64_t)point * G;
+    for_each_group_sumsq(us, a.order, a.gstart, G, a.team, [&](int g, double ss) { gn[g] = sqrt(ss); });
+  }
+
+  // ---- control block (as in fista_tail_kernel) ---------------------------------------------------
+  if (tid == 0) {
+    ctl->zzero = 0;
+    ctl->total_iter = total_iter + 1;
+    ctl->L = new_L;
+    ctl->mode = new_mode;
+    ctl->rejects = new_rejects;
+    ctl->ak = new_ak;
+    ctl->Lhat = new_Lhat;
+    if (l_bad) ctl->l_bumps += 1;
+    if (did_restart) ctl->restarts += 1;
+    if (finalize) {
+      slm_point_info info;
+      info.n_iter = iter + 1;
+      info.status = (conv && !nonfinite) ? SLM_OK : (nonfinite ? SLM_ERR_NON_FINITE : SLM_ERR_NOT_CONVERGED);
+      info.resid = resid;
+      info.beta_norm = bnorm;
+      info.loss = loss_z;
+      info.L = new_mode == 1 ? new_ak : new_L;
+      info.mode = new_mode;
+      info.rejects = new_rejects;
+      info.kkt = kkt;
+      info.mu = mu_eff;
+      a.infos[point] = info;
+      ctl->mu = 0.0;
+      ctl->mu_rq = 0.0;
+      ctl->iter = 0;
+      ctl->t = 1.0;
+      ctl->have_base = 0;
+      ctl->n_hist = 0;
+      ctl->pen_z = 0.0;
+      ctl->point = (walk_end && tail_pt >= 0 && point != tail_pt) ? tail_pt : point + stride;
+      if (nonfinite) {
+        ctl->nonfinite = 1;
+        ctl->done = 1;
+        a.gdone[a.done_slot] = 1;
+      } else if (goes_idle) {
+        ctl->idle = 1;
+      } else if (range_end) {
+        ctl->done = 1;
+        if (atomicAdd(&a.gdone[1], 1) + 1 == a.n_lanes) a.gdone[a.done_slot] = 1;
+      }
+    } else {
+      ctl->iter = iter + 1;
+      atomicMax(&a.gdone[2], iter + 1);
       ctl->t = new_t;
       ctl->have_base = new_have_base;
       ctl->n_hist = new_n_hist;

@@ -793,19 +793,22 @@ __global__ __launch_bounds__(256) void ws_gram_reduce_kernel(WsArgs w) {
 }
 
 // Row-sharded mode: after the all-reduce of the staging matrix, move the new rows / columns into the
-// Gram and publish it.  grid (WS_KCAP * WS_KCAP / 256, n_sets).
+// Gram and publish it.  grid (WS_PUBLISH_BLOCKS, n_sets): a workgroup walks its share of the K x K corner (as 1 024
+// workgroups over the whole 512 x 512 matrix, each with its turn at the one counter, the kernel took 62 us).
+constexpr int WS_PUBLISH_BLOCKS = 64;
 __global__ __launch_bounds__(256) void ws_publish_kernel(WsArgs w) {
   WsCtl* ws = w.ws;
   if (!ws->building || !ws->staged) return;
   const int K = ws->K;
   const int row_lo = (ws->k_new >> 4) << 4;
   const int set = blockIdx.y;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const int i = e / WS_KCAP, j = e % WS_KCAP;
-  if (i < K && j < K && (i >= row_lo || j >= row_lo)) {
-    const int64_t at = (int64_t)set * (WS_KCAP * WS_KCAP) + e;
-    w.Gm[at] = w.Gx[at];
-  }
+  // rows of the corner, WS_KCAP doubles apart; a wavefront moves 64 consecutive columns of one row
+  for (int i = blockIdx.x; i < K; i += gridDim.x)
+    for (int j = threadIdx.x; j < K; j += 256)
+      if (i >= row_lo || j >= row_lo) {
+        const int64_t at = (int64_t)set * (WS_KCAP * WS_KCAP) + (int64_t)i * WS_KCAP + j;
+        w.Gm[at] = w.Gx[at];
+      }
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
