@@ -15,19 +15,42 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "sparselm_amd", "_lib")
 OUT = os.path.join(OUT_DIR, "libslm_hip.so")
+BINDING = os.path.join(OUT_DIR, "_slm_binding.so")  # pybind11 module over the C ABI (csrc/binding.cpp): host code only
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXX = os.environ.get("CXX", "g++")
 
 
-def _stale() -> bool:
-    if not os.path.exists(OUT):
+def _stale(out=OUT, deps=None) -> bool:
+    if not os.path.exists(out):
         return True
-    deps = glob.glob(os.path.join(CSRC, "*")) + [os.path.join(HERE, "..", "include", "slm_engine.h")]
+    if deps is None:
+        deps = [d for d in glob.glob(os.path.join(CSRC, "*")) if not d.endswith("binding.cpp")]
+    deps = list(deps) + [os.path.join(HERE, "..", "include", "slm_engine.h")]
     newest = max(os.path.getmtime(d) for d in deps)
-    return newest > os.path.getmtime(OUT)
+    return newest > os.path.getmtime(out)
+
+
+def build_binding(force: bool = False) -> str:
+    """The compiled Python binding of the hot calls (pybind11, g++): links against libslm_hip.so next to it."""
+    src = os.path.join(CSRC, "binding.cpp")
+    if not force and not _stale(BINDING, [src, OUT]):
+        return BINDING
+    import sysconfig
+
+    import pybind11
+
+    cmd = [
+        CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+        f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}",
+        src, "-o", BINDING, f"-L{OUT_DIR}", "-lslm_hip", "-Wl,-rpath,$ORIGIN",
+    ]
+    subprocess.run(cmd, check=True)
+    return BINDING
 
 
 def build(force: bool = False, extra_flags=()) -> str:
     if not force and not _stale():
+        build_binding(False)
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
     cmd = [
@@ -44,6 +67,7 @@ def build(force: bool = False, extra_flags=()) -> str:
         "-ldl",
     ]
     subprocess.run(cmd, check=True)
+    build_binding(True)
     return OUT
 
 

@@ -1338,7 +1338,11 @@ static void launch_tail(const TailArgs& ta, hipStream_t s) {
     case 4: SLM_TAIL_LAUNCH(4); break;
     case 5: SLM_TAIL_LAUNCH(5); break;
     case 6: SLM_TAIL_LAUNCH(6); break;
-    default: hipLaunchKernelGGL(fista_tail_stream_kernel, grid, dim3(TAIL_THREADS), 0, s, ta);
+    case 7: hipLaunchKernelGGL(fista_tail_stream_kernel<7>, grid, dim3(TAIL_THREADS), 0, s, ta); break;
+    case 8: hipLaunchKernelGGL(fista_tail_stream_kernel<8>, grid, dim3(TAIL_THREADS), 0, s, ta); break;
+    case 9: hipLaunchKernelGGL(fista_tail_stream_kernel<9>, grid, dim3(TAIL_THREADS), 0, s, ta); break;
+    case 10: hipLaunchKernelGGL(fista_tail_stream_kernel<10>, grid, dim3(TAIL_THREADS), 0, s, ta); break;
+    default: hipLaunchKernelGGL(fista_tail_stream_kernel<0>, grid, dim3(TAIL_THREADS), 0, s, ta);
   }
 #undef SLM_TAIL_LAUNCH
 }

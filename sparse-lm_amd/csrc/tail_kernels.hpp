@@ -166,18 +166,36 @@ __device__ __forceinline__ void for_each_group_sumsq(const double* src, const in
   const int tid = threadIdx.x;
   const int nteams = TAIL_THREADS / team;
   const int my_team = tid / team, tl = tid % team;
-  for (int g0 = 0; g0 < G; g0 += nteams) {  // trip count is uniform across the workgroup
-    const int g = g0 + my_team;
-    double s = 0.0;
-    if (g < G) {
-      const int k1 = gstart[g + 1];
-      for (int k = gstart[g] + tl; k < k1; k += team) {
-        const double x = src[order[k]];
-        s = __builtin_fma(x, x, s);
+  // Four rounds of groups at a time, each step of a round for all four before the next step: a round is a chain of
+  // three dependent loads (group bounds -> feature index -> value), and one round after the other the 500 groups of
+  // BASELINE config 3 / 4 were eight such chains per sweep, 25 us of a 40 us call.
+  constexpr int R = 4;
+  for (int g0 = 0; g0 < G; g0 += R * nteams) {  // trip count is uniform across the workgroup
+    int g[R], k[R], k1[R], j[R];
+    double s[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      g[u] = g0 + u * nteams + my_team;
+      const bool in = g[u] < G;
+      k[u] = in ? gstart[g[u]] + tl : 0;
+      k1[u] = in ? gstart[g[u] + 1] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) j[u] = k[u] < k1[u] ? order[k[u]] : -1;
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const double x = j[u] >= 0 ? src[j[u]] : 0.0;
+      s[u] = x * x;
+      for (int kk = k[u] + team; kk < k1[u]; kk += team) {  // (groups larger than a team)
+        const double y = src[order[kk]];
+        s[u] = __builtin_fma(y, y, s[u]);
       }
     }
-    for (int off = team >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (g < G && tl == 0) fn(g, s);
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      for (int off = team >> 1; off >= 1; off >>= 1) s[u] += __shfl_xor(s[u], off, 64);
+      if (g[u] < G && tl == 0) fn(g[u], s[u]);
+    }
   }
 }
 
@@ -700,6 +718,23 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
 // image `us` (LDS up to 16 384 features, the per-lane global scratch beyond); the image is the candidate point, the
 // base point is zprev (which the decision phase writes anyway).  Same arithmetic, same state machine, any p.
 // ---------------------------------------------------------------------------------------------
+// E > 0: p <= 1024 E, every walk over the features is E unrolled steps of straight-line code -- loads from a clamped index,
+// sums and stores predicated -- so that the loads of a phase are all in flight at once (as runtime loops a phase was ten
+// dependent round trips: 100 us per call at p = 10 000 against 25); E = 0: runtime loops, any p.
+template <int E, typename F>
+__device__ __forceinline__ void tail_for(int tid, int p, F f) {
+  if constexpr (E > 0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = tid + e * TAIL_THREADS;
+      f(j < p ? j : 0, j < p);
+    }
+  } else {
+    for (int j = tid; j < p; j += TAIL_THREADS) f(j, true);
+  }
+}
+
+template <int E>
 __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArgs a) {
   __shared__ double red[9][TAIL_WAVES];
   constexpr int US_LDS = 16 * TAIL_THREADS;
@@ -756,17 +791,16 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
   // the image us[] holds v; on return it holds prox_{step * penalty}(v).  pen (nullable): thread-partial penalty value
   // of the result, accumulated in the order of fista_tail_kernel's prox_inplace
   auto prox_image = [&](double step, double* pen) {
-#pragma unroll 4
-    for (int j = tid; j < p; j += TAIL_THREADS) {
+    tail_for<E>(tid, p, [&](int j, bool ok) {
       double uu = soft(us[j], step * pt.sa * a.a0[j]);
       if (group_pen && a.singleton) {
         const double nrm = fabs(uu);
         const double sc = nrm > 0.0 ? fmax(0.0, 1.0 - step * pt.sb * a.b0[j] / nrm) : 0.0;
         uu *= sc / (1.0 + step * pt.sd * a.d0[j]);
-        if (pen) *pen += pt.sb * a.b0[j] * fabs(uu) + 0.5 * pt.sd * a.d0[j] * uu * uu;
+        if (pen && ok) *pen += pt.sb * a.b0[j] * fabs(uu) + 0.5 * pt.sd * a.d0[j] * uu * uu;
       }
-      us[j] = uu;
-    }
+      if (ok) us[j] = uu;
+    });
     if (group_pen && !a.singleton) {
       __syncthreads();
       for_each_group_sumsq(us, a.order, a.gstart, G, a.team, [&](int g, double ss) {
@@ -780,12 +814,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
         }
       });
       __syncthreads();
-#pragma unroll 4
-      for (int j = tid; j < p; j += TAIL_THREADS) us[j] *= a.gscale[a.gid[j]];
+      tail_for<E>(tid, p, [&](int j, bool ok) {
+        const double v = us[j] * a.gscale[a.gid[j]];
+        if (ok) us[j] = v;
+      });
     }
     if (pen && pt.sa != 0.0) {
-#pragma unroll 4
-      for (int j = tid; j < p; j += TAIL_THREADS) *pen += pt.sa * a.a0[j] * fabs(us[j]);
+      tail_for<E>(tid, p, [&](int j, bool ok) {
+        if (ok) *pen += pt.sa * a.a0[j] * fabs(us[j]);
+      });
     }
   };
 
@@ -802,25 +839,30 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
 
   if (mode == 1) {
     double s[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll 2
-    for (int j = tid; j < p; j += TAIL_THREADS) {
+    tail_for<E>(tid, p, [&](int j, bool ok) {
       const double z = a.z[j], g = a.g[j];
       const double dz = z - a.beta[j], dg = g - a.gprev[j];
-      s[0] = __builtin_fma(dz, dz, s[0]);
-      s[1] = __builtin_fma(dz, dg, s[1]);
-      s[2] = __builtin_fma(dg, dg, s[2]);
-      if (!isfinite(g)) s[3] += 1.0;
-      s[5] = __builtin_fma(g, g, s[5]);
-    }
-    if (!have_base) {
-#pragma unroll 2
-      for (int j = tid; j < p; j += TAIL_THREADS) {
-        const double az = fabs(a.z[j]);
-        s[4] += pt.sa * a.a0[j] * az;
-        if (group_pen && a.singleton) s[4] += pt.sb * a.b0[j] * az + 0.5 * pt.sd * a.d0[j] * az * az;
+      if (ok) {
+        s[0] = __builtin_fma(dz, dz, s[0]);
+        s[1] = __builtin_fma(dz, dg, s[1]);
+        s[2] = __builtin_fma(dg, dg, s[2]);
+        if (!isfinite(g)) s[3] += 1.0;
+        s[5] = __builtin_fma(g, g, s[5]);
       }
+    });
+    if (!have_base) {
+      tail_for<E>(tid, p, [&](int j, bool ok) {
+        const double az = fabs(a.z[j]);
+        if (ok) {
+          s[4] += pt.sa * a.a0[j] * az;
+          if (group_pen && a.singleton) s[4] += pt.sb * a.b0[j] * az + 0.5 * pt.sd * a.d0[j] * az * az;
+        }
+      });
       if (group_pen && !a.singleton) {
-        for (int j = tid; j < p; j += TAIL_THREADS) us[j] = a.z[j];
+        tail_for<E>(tid, p, [&](int j, bool ok) {
+          const double z = a.z[j];
+          if (ok) us[j] = z;
+        });
         __syncthreads();
         for_each_group_sumsq(us, a.order, a.gstart, G, a.team, [&](int g, double ss) {
           s[4] += pt.sb * a.b0[g] * sqrt(ss) + 0.5 * pt.sd * a.d0[g] * ss;
@@ -872,20 +914,22 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
     // base point (-> zprev) and its gradient (-> gprev) after the decision; the image gets base - step * gradient,
     // or, on the switch to FISTA, the base itself
     if (accept) {
-#pragma unroll 2
-      for (int j = tid; j < p; j += TAIL_THREADS) {
+      tail_for<E>(tid, p, [&](int j, bool ok) {
         const double z = a.z[j], g = a.g[j];
-        a.gprev[j] = g;
-        a.zprev[j] = z;
-        us[j] = fallback ? z : z - step * g;
-      }
+        if (ok) {
+          a.gprev[j] = g;
+          a.zprev[j] = z;
+          us[j] = fallback ? z : z - step * g;
+        }
+      });
     } else {
-#pragma unroll 2
-      for (int j = tid; j < p; j += TAIL_THREADS) {
-        const double b = a.beta[j];
-        a.zprev[j] = b;
-        us[j] = fallback ? b : b - step * a.gprev[j];
-      }
+      tail_for<E>(tid, p, [&](int j, bool ok) {
+        const double b = a.beta[j], gp = a.gprev[j];
+        if (ok) {
+          a.zprev[j] = b;
+          us[j] = fallback ? b : b - step * gp;
+        }
+      });
     }
     if (fallback) {
       new_mode = 0;
@@ -894,8 +938,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
       finalize = hit_max;
       if (finalize) {
         double q[1] = {0.0};
-#pragma unroll 4
-        for (int j = tid; j < p; j += TAIL_THREADS) q[0] = __builtin_fma(us[j], us[j], q[0]);
+        tail_for<E>(tid, p, [&](int j, bool ok) {
+          if (ok) q[0] = __builtin_fma(us[j], us[j], q[0]);
+        });
         block_sum<1>(q, red);
         bnorm = sqrt(q[0]);
         resid = sqrt(s[0]);
@@ -904,14 +949,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
       double pen_c = 0.0;
       prox_image(step, &pen_c);
       double q[4] = {0, 0, pen_c, 0};
-#pragma unroll 4
-      for (int j = tid; j < p; j += TAIL_THREADS) {
+      tail_for<E>(tid, p, [&](int j, bool ok) {
         const double c = us[j];
         const double dc = c - a.zprev[j];
-        q[0] = __builtin_fma(dc, dc, q[0]);
-        q[1] = __builtin_fma(c, c, q[1]);
-        if (!isfinite(c)) q[3] += 1.0;
-      }
+        if (ok) {
+          q[0] = __builtin_fma(dc, dc, q[0]);
+          q[1] = __builtin_fma(c, c, q[1]);
+          if (!isfinite(c)) q[3] += 1.0;
+        }
+      });
       block_sum<4>(q, red);
       nonfinite = nonfinite || q[3] > 0.0 || !isfinite(q[0]) || !isfinite(q[1]);
       new_pen_z = q[2];
@@ -929,29 +975,31 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
     // ================= FISTA scheme =================================================================
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const double step = 1.0 / L;
-#pragma unroll 2
-    for (int j = tid; j < p; j += TAIL_THREADS) {
+    tail_for<E>(tid, p, [&](int j, bool ok) {
       const double z = a.z[j], g = a.g[j];
       const double dg = g - a.gprev[j], dzz = z - a.zprev[j];
-      s[3] = __builtin_fma(dg, dg, s[3]);
-      s[4] = __builtin_fma(dzz, dzz, s[4]);
-      s[8] = __builtin_fma(dg, dzz, s[8]);
-      s[5] = __builtin_fma(z, z, s[5]);
-      s[7] = __builtin_fma(g, g, s[7]);
-      a.gprev[j] = g;
-      a.zprev[j] = z;
-      us[j] = z - step * g;
-    }
+      if (ok) {
+        s[3] = __builtin_fma(dg, dg, s[3]);
+        s[4] = __builtin_fma(dzz, dzz, s[4]);
+        s[8] = __builtin_fma(dg, dzz, s[8]);
+        s[5] = __builtin_fma(z, z, s[5]);
+        s[7] = __builtin_fma(g, g, s[7]);
+        a.gprev[j] = g;
+        a.zprev[j] = z;
+        us[j] = z - step * g;
+      }
+    });
     prox_image(step, nullptr);
-#pragma unroll 2
-    for (int j = tid; j < p; j += TAIL_THREADS) {
+    tail_for<E>(tid, p, [&](int j, bool ok) {
       const double bn = us[j];
-      const double dz = bn - a.z[j];
-      s[0] = __builtin_fma(dz, dz, s[0]);
-      s[1] = __builtin_fma(bn, bn, s[1]);
-      s[2] = __builtin_fma(-dz, bn - a.beta[j], s[2]);
-      if (!isfinite(bn)) s[6] += 1.0;
-    }
+      const double dz = bn - a.z[j], db = bn - a.beta[j];
+      if (ok) {
+        s[0] = __builtin_fma(dz, dz, s[0]);
+        s[1] = __builtin_fma(bn, bn, s[1]);
+        s[2] = __builtin_fma(-dz, db, s[2]);
+        if (!isfinite(bn)) s[6] += 1.0;
+      }
+    });
     block_sum<9>(s, red);
     nonfinite = s[6] > 0.0 || !isfinite(s[0]) || !isfinite(s[1]) || !isfinite(loss_z);
     if (total_iter > 0 && s[4] > 1e-12 * s[5] && s[4] > 0.0) {
@@ -986,22 +1034,23 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
   const bool walk_end = point + stride >= n_points;
   const bool range_end = finalize && !nonfinite && walk_end && (tail_pt < 0 || point == tail_pt);
   const bool goes_idle = range_end && a.steal;
-#pragma unroll 2
-  for (int j = tid; j < p; j += TAIL_THREADS) {
+  tail_for<E>(tid, p, [&](int j, bool ok) {
     double nbv, uu;  // new base, next point (or the reported solution)
+    const double image = us[j];
     if (mode == 1) {
       nbv = a.zprev[j];
-      uu = us[j];
+      uu = image;
     } else {
-      const double bn = us[j], bold = a.beta[j];
+      const double bold = a.beta[j];
       if (l_bad) {
         nbv = bold;
         uu = bold;
       } else {
-        nbv = bn;
-        uu = finalize ? bn : bn + mom * (bn - bold);
+        nbv = image;
+        uu = finalize ? image : image + mom * (image - bold);
       }
     }
+    if (!ok) return;
     if (finalize) {
       a.betas_out[(int64_t)point * p + j] = uu;
       double nxt = (cold || goes_idle) ? 0.0 : uu;
@@ -1013,7 +1062,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
       a.beta[j] = nbv;
       a.z[j] = uu;
     }
-  }
+  });
   if (finalize && a.gn_out != nullptr) {
     __syncthreads();
     double* gn = a.gn_out + (int64_t)point * G;

@@ -15,7 +15,6 @@ import ctypes as C
 import os
 import threading
 import weakref
-from dataclasses import dataclass
 
 import numpy as np
 
@@ -290,6 +289,32 @@ def load_library():
         return lib
 
 
+_binding = None  # the compiled binding of the hot calls (csrc/binding.cpp), False when it is not to be used
+
+
+def load_binding():
+    """The pybind11 module over the hot calls (``slm_solve_lanes``, ``slm_solve_path_lanes``, ``slm_dataset_create``), or
+    None: built next to the engine by ``sparse-lm_amd/build.py``; ``SLM_NO_BINDING=1`` (A/B runs, the ABI tests) and a library
+    taken from ``SLM_HIP_LIBRARY`` (the module is linked against the one in ``_lib``) leave every call to ctypes."""
+    global _binding
+    if _binding is None:
+        lib = load_library()
+        path = os.path.join(_LIB_DIR, "_slm_binding.so")
+        if os.environ.get("SLM_NO_BINDING") or os.environ.get("SLM_HIP_LIBRARY") or not os.path.exists(path):
+            _binding = False
+        else:
+            import importlib.util
+
+            spec = importlib.util.spec_from_file_location("_slm_binding", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() != lib.slm_abi_version() or mod.info_record_bytes() != _INFO_DTYPE.itemsize:
+                raise EngineError(f"{path} does not match libslm_hip.so: rebuild with `python sparse-lm_amd/build.py --force`")
+            mod.set_error_types(EngineError, NonFiniteError)
+            _binding = mod
+    return _binding or None
+
+
 def _check(rc: int):
     if rc == SLM_OK:
         return
@@ -374,63 +399,55 @@ def lane_points(segments) -> tuple[np.ndarray, np.ndarray]:
     return np.vstack(pts), np.concatenate([path_extrapolation(s) for s in pts])
 
 
-@dataclass
+_STATS_FIELDS = ("grad_launches", "grad_timed", "grad_ms_total", "wall_ms", "lipschitz_ms", "ws_builds", "ws_appends",
+                 "ws_refined", "ws_misses", "ws_columns", "ws_inner_iters", "ws_direct_steps")
+
+
 class PathResult:
-    betas: np.ndarray  # (n_points, p)
-    group_norms: np.ndarray | None  # (n_points, G)
-    n_iter: np.ndarray  # (n_points,)
-    status: np.ndarray  # (n_points,) SLM_OK or SLM_ERR_NOT_CONVERGED
-    resid: np.ndarray
-    beta_norm: np.ndarray
-    loss: np.ndarray
-    mode: np.ndarray  # per point: 1 = spectral steps, 0 = FISTA, 2 = the on-chip solver
-    L: float
-    grad_launches: int
-    grad_timed: int
-    grad_ms_total: float
-    wall_ms: float
-    lipschitz_ms: float
-    ws_builds: int = 0  # working sets selected from scratch during the solve (0: refinement not used)
-    ws_appends: int = 0  # times columns were appended to the working set
-    ws_refined: int = 0
-    ws_misses: int = 0
-    ws_columns: int = 0  # columns in the working set at the end
-    ws_inner_iters: int = 0  # proximal-gradient iterations of the model solver
-    ws_direct_steps: int = 0  # direct (Cholesky) steps of the model solver
-    kkt: np.ndarray | None = None  # (n_points,) KKT residual ||G(z)||_2 at exit
-    mu: np.ndarray | None = None  # (n_points,) strong-convexity estimate the point was accepted with
+    """The solutions of one lane's path.  ``betas`` (n_points, p) and ``group_norms`` (n_points, G) or None are views of the
+    call's result blocks; the per-point records and the call's statistics are read where they are asked for (a
+    sixteen-lane call used to build 160 small arrays nobody looked at):
+
+    ``n_iter``, ``status`` (SLM_OK or SLM_ERR_NOT_CONVERGED), ``resid``, ``beta_norm``, ``loss``, ``mode`` (1 = spectral
+    steps, 0 = FISTA, 2 = the on-chip solver), ``kkt`` (KKT residual at exit), ``mu`` (strong-convexity estimate the point
+    was accepted with): arrays of n_points; ``L``: inverse step at the last point; ``converged``; and the statistics of the
+    call, shared by its lanes: ``grad_launches``, ``grad_timed``, ``grad_ms_total``, ``wall_ms``, ``lipschitz_ms``,
+    ``ws_builds`` (working sets selected from scratch; 0: refinement not used), ``ws_appends``, ``ws_refined``,
+    ``ws_misses``, ``ws_columns`` (columns in the working set at the end), ``ws_inner_iters``, ``ws_direct_steps``."""
+
+    __slots__ = ("betas", "group_norms", "_infos", "_stats")
+
+    def __init__(self, betas, group_norms, infos, stats):
+        self.betas, self.group_norms, self._infos, self._stats = betas, group_norms, infos, stats
+
+    n_iter = property(lambda self: self._infos["n_iter"].astype(np.int64))
+    status = property(lambda self: self._infos["status"].astype(np.int64))
+    resid = property(lambda self: self._infos["resid"].copy())
+    beta_norm = property(lambda self: self._infos["beta_norm"].copy())
+    loss = property(lambda self: self._infos["loss"].copy())
+    mode = property(lambda self: self._infos["mode"].astype(np.int64))
+    kkt = property(lambda self: self._infos["kkt"].copy())
+    mu = property(lambda self: self._infos["mu"].copy())
+    L = property(lambda self: float(self._infos["L"][-1]))
 
     @property
     def converged(self) -> bool:
-        return bool(np.all(self.status == SLM_OK))
+        return not self._infos["status"].any()  # (SLM_OK == 0)
+
+    def __getattr__(self, name):  # the call's statistics
+        try:
+            v = self._stats[_STATS_FIELDS.index(name)]
+        except ValueError:
+            raise AttributeError(name) from None
+        return float(v) if name in ("grad_ms_total", "wall_ms", "lipschitz_ms") else int(v)
+
+
+def _stats_tuple(stats) -> tuple:
+    return tuple(getattr(stats, f) for f in _STATS_FIELDS)
 
 
 def _path_result(betas, gn, infos, K, stats) -> PathResult:
-    return PathResult(
-        betas=betas,
-        group_norms=gn,
-        n_iter=infos["n_iter"].astype(np.int64),
-        status=infos["status"].astype(np.int64),
-        resid=infos["resid"].copy(),
-        beta_norm=infos["beta_norm"].copy(),
-        loss=infos["loss"].copy(),
-        mode=infos["mode"].astype(np.int64),
-        L=float(infos["L"][K - 1]),
-        grad_launches=int(stats.grad_launches),
-        grad_timed=int(stats.grad_timed),
-        grad_ms_total=float(stats.grad_ms_total),
-        wall_ms=float(stats.wall_ms),
-        lipschitz_ms=float(stats.lipschitz_ms),
-        ws_builds=int(stats.ws_builds),
-        ws_appends=int(stats.ws_appends),
-        ws_refined=int(stats.ws_refined),
-        ws_misses=int(stats.ws_misses),
-        ws_columns=int(stats.ws_columns),
-        ws_inner_iters=int(stats.ws_inner_iters),
-        ws_direct_steps=int(stats.ws_direct_steps),
-        kkt=infos["kkt"].copy(),
-        mu=infos["mu"].copy(),
-    )
+    return PathResult(betas, gn, infos, stats if isinstance(stats, tuple) else _stats_tuple(stats))
 
 
 _live_engines: "weakref.WeakSet[Engine]" = weakref.WeakSet()
@@ -496,6 +513,9 @@ class Engine:
             rs, cs = p, 1
         elif X.flags.f_contiguous:
             rs, cs = 1, n
+        b = load_binding()
+        if b is not None:
+            return Dataset(self, C.c_void_p(b.dataset_create(self._h.value, X, y, rw)), n, p)
         h = C.c_void_p()
         _check(self._lib.slm_dataset_create(self._h, _ptr(X), n, p, rs, cs, _ptr(y), _ptr(rw), C.byref(h)))
         return Dataset(self, h, n, p)
@@ -712,6 +732,17 @@ class Dataset:
         if not (1 <= nl <= MAX_LANES):
             raise ValueError(f"between 1 and {MAX_LANES} lanes, got {nl}")
         G = self.n_groups
+        b = load_binding()
+        if b is not None:  # the compiled binding marshals the lanes itself
+            betas, gnb, inf, ks, st = b.solve_lanes(self._h.value, list(lanes), self.n, self.p, G, float(tol), int(max_iter),
+                                                    int(check_every), float(L), int(flags), bool(want_group_norms),
+                                                    bool(extrapolate), _host_pool.empty)
+            infos, out, at, p = inf.view(_INFO_DTYPE), [], 0, self.p
+            for K in ks:
+                out.append(PathResult(betas[at * p : (at + K) * p].reshape(K, p),
+                                      gnb[at * G : (at + K) * G].reshape(K, G) if want_group_norms else None, infos[at : at + K], st))
+                at += K
+            return out
         keep = []  # keep every buffer alive for the duration of the call
         clanes = (_Lane * nl)()
         outs = []
@@ -796,6 +827,12 @@ class Dataset:
             return self.solve_lanes([dict(points=pts, beta0=beta0, **common)], **kw)[0]
         # shared path: the engine splits it into `lanes` ranges and balances them by work stealing
         G = self.n_groups
+        bnd = load_binding()
+        if bnd is not None:
+            betas, gnb, inf, st = bnd.solve_path_lanes(self._h.value, pts, self.p, G, a, b, d, beta0, int(lanes), float(tol),
+                                                       int(max_iter), int(check_every), float(L), int(flags),
+                                                       bool(want_group_norms), bool(extrapolate), _host_pool.empty)
+            return PathResult(betas.reshape(K, self.p), gnb.reshape(K, G) if want_group_norms else None, inf.view(_INFO_DTYPE), st)
         gam = path_extrapolation(pts) if extrapolate else np.zeros(K)
         cpts = _points_block(pts, gam)
         a_ = None if a is None else _f64(np.broadcast_to(a, (self.p,)), "a")
