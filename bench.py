@@ -83,18 +83,27 @@ PRIMING_PATHS = 3  # untimed solves of the path right after the dataset is made 
 
 
 def measured_traffic(n, p, lanes, kernel):
-    """HBM bytes per gradient launch from the committed PMC passes (profiles/roofline_traffic.json,
-    produced by tools/summarize_prof.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`), or
-    None when no counter run exists for this (n, p) AND this kernel: the figure is a committed measurement, not
-    one of this run, so it is only quoted for the kernel it was taken on."""
+    """(HBM bytes per gradient launch, note) from the committed PMC passes (profiles/roofline_traffic.json, written by
+    tools/update_roofline_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`).  The figure is a committed
+    measurement, not one of this run: it is quoted only for the (n, p, lanes) and the kernel it was taken on, and only while
+    the kernel's source file is the one the counters were taken on (its SHA-256 is recorded with them) -- otherwise None
+    and the reason."""
+    import hashlib
+
     try:
         with open(os.path.join(ROOT, "profiles", "roofline_traffic.json")) as f:
             t = json.load(f)
-        if t["workload"] == {"n": n, "p": p, "lanes": lanes} and kernel in t["kernel"]:
-            return t["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+        if t["workload"] != {"n": n, "p": p, "lanes": lanes} or kernel not in t["kernel"]:
+            return None, "no counter run for this workload and kernel"
+        on = t.get("taken_on") or {}
+        src = os.path.join(ROOT, on.get("kernel_source", ""))
+        if not on.get("kernel_source_sha256") or not os.path.isfile(src):
+            return None, "the counter run does not record the kernel source it was taken on"
+        if hashlib.sha256(open(src, "rb").read()).hexdigest() != on["kernel_source_sha256"]:
+            return None, f"{on['kernel_source']} has changed since the counters were taken (commit {on.get('commit', '?')[:12]}): re-collect"
+        return t["hbm_bytes_per_launch"], f"PMC passes of commit {on.get('commit', '?')[:12]}, {t.get('source')}"
+    except (OSError, KeyError, ValueError) as exc:
+        return None, f"profiles/roofline_traffic.json unreadable: {exc!r}"
 
 
 def make_coef(p, n_informative, seed):
@@ -1020,8 +1029,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(n, p, lanes_used, "xtr_mfma_kernel" if split else "grad_fused_kernel"),
+                "traffic": measured_traffic(n, p, lanes_used, "xtr_mfma_kernel" if split else "grad_fused_kernel")[0],
                 "traffic_unit": "HBM bytes per launch (PMC, profiles/roofline_traffic.json)",
+                "traffic_note": measured_traffic(n, p, lanes_used, "xtr_mfma_kernel" if split else "grad_fused_kernel")[1],
                 "kernel": (f"xtr_mfma_kernel (X^T R of the split pass on the matrix cores, lanes={lanes_used})" if split
                            else f"grad_fused_kernel (lanes={lanes_used})"),
                 "avg_kernel_ms": t_grad_ms,
