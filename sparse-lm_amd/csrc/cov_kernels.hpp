@@ -17,7 +17,7 @@
 namespace slm {
 
 // Z[j][l] = z_l[j] (lane-minor, the B operand of xtr_mfma_kernel); lane slots beyond n_lanes are zero
-__global__ __launch_bounds__(256) void cov_pack_kernel(const double* z, int64_t ld, int n_lanes, double* Z, const int* done) {
+static __global__ __launch_bounds__(256) void cov_pack_kernel(const double* z, int64_t ld, int n_lanes, double* Z, const int* done) {
   if (done != nullptr && *done != 0) return;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over ld * 16
   if (e >= ld * SPLIT_RSTRIDE) return;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void cov_pack_kernel(const double* z, int64_t 
 // rows of G listed in `idx` can contribute: the workgroups then read those rows (a.xrows_ws of the list each: indices first,
 // then all loads of the block at once) -- 8 K ld bytes, 12 MB at K = 300, instead of the 200 MB of G, 8-10 us instead of 37
 // per row set and pass.  Plain steps (zsup = 0), a working set under construction, or no working set at all: every row.
-__global__ __launch_bounds__(XTR_WAVES * 64, 2) void cov_gz_mfma_kernel(SplitArgs a) {
+static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void cov_gz_mfma_kernel(SplitArgs a) {
   if (a.done != nullptr && *a.done != 0) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -175,7 +175,7 @@ struct CovFinishArgs {
 };
 
 // grid = (ld / 16, lanes): g_l[col] = sum_blk partial[blk][l][col] - c[col]   (fixed order: bit-identical run to run)
-__global__ __launch_bounds__(256) void cov_reduce_kernel(CovFinishArgs a) {
+static __global__ __launch_bounds__(256) void cov_reduce_kernel(CovFinishArgs a) {
   if (a.done != nullptr && *a.done != 0) return;
   const int lane = blockIdx.y;
   if (!((a.lane_mask >> lane) & 1u)) return;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void cov_reduce_kernel(CovFinishArgs a) {
 }
 
 // grid = lanes, 256 threads: loss_l = 1/2 sum_j z_j (g_j - c_j) + 1/2 yy  (g = G z - c already), into g_l[ld]
-__global__ __launch_bounds__(256) void cov_loss_kernel(CovFinishArgs a) {
+static __global__ __launch_bounds__(256) void cov_loss_kernel(CovFinishArgs a) {
   if (a.done != nullptr && *a.done != 0) return;
   const int lane = blockIdx.x;
   if (!((a.lane_mask >> lane) & 1u)) return;
@@ -221,7 +221,7 @@ struct CovSets {
   const double* G[SLM_MAX_LANES];  // per SET of the working set (WsArgs::set_of): the row set's Gram, [ld][ld]
 };
 
-__global__ __launch_bounds__(256) void ws_gram_cov_kernel(WsArgs w, CovSets cs) {
+static __global__ __launch_bounds__(256) void ws_gram_cov_kernel(WsArgs w, CovSets cs) {
   WsCtl* ws = w.ws;
   if (!ws->building) return;
   const int K = ws->K;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void ws_gram_cov_kernel(WsArgs w, CovSets cs) 
 struct CovFpArgs {
   const double* w[SLM_MAX_LANES];
 };
-__global__ __launch_bounds__(1024) void cov_fingerprint_kernel(CovFpArgs fa, int64_t n, double* out_all) {
+static __global__ __launch_bounds__(1024) void cov_fingerprint_kernel(CovFpArgs fa, int64_t n, double* out_all) {
   __shared__ double r1[1024], r2[1024];
   const double* w = fa.w[blockIdx.x];
   double* out = out_all + 2 * blockIdx.x;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(1024) void cov_fingerprint_kernel(CovFpArgs fa, int
 }
 
 // T[r][:] = s_r * X[rows[r]][:]  (rows == nullptr: row r itself; scale == nullptr: 1)
-__global__ __launch_bounds__(256) void cov_rows_kernel(const double* X, int64_t ld, const int64_t* rows, const double* scale,
+static __global__ __launch_bounds__(256) void cov_rows_kernel(const double* X, int64_t ld, const int64_t* rows, const double* scale,
                                                        int64_t n_rows, double* T) {
   const int64_t r = blockIdx.x;
   if (r >= n_rows) return;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void cov_rows_kernel(const double* X, int64_t 
 }
 
 // the same into a block padded with rows of zeros: T[r][:] = X[rows[r]][:] for r < n_rows, 0 for n_rows <= r < gridDim.x
-__global__ __launch_bounds__(256) void cov_rows_pad_kernel(const double* X, int64_t ld, const int64_t* rows, int64_t n_rows, double* T) {
+static __global__ __launch_bounds__(256) void cov_rows_pad_kernel(const double* X, int64_t ld, const int64_t* rows, int64_t n_rows, double* T) {
   const int64_t r = blockIdx.x;
   double2* out = reinterpret_cast<double2*>(T + r * ld);
   if (r >= n_rows) {
@@ -317,18 +317,18 @@ __global__ __launch_bounds__(256) void cov_rows_pad_kernel(const double* X, int6
 }
 
 // G = (A - B) * s  (B == nullptr: G = A * s), element-wise over count doubles
-__global__ __launch_bounds__(256) void cov_combine_kernel(const double* A, const double* B, double s, int64_t count, double* G) {
+static __global__ __launch_bounds__(256) void cov_combine_kernel(const double* A, const double* B, double s, int64_t count, double* G) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
     G[i] = (A[i] - (B ? B[i] : 0.0)) * s;
 }
 
 // G += A, element-wise over count doubles
-__global__ __launch_bounds__(256) void cov_accumulate_kernel(const double* A, int64_t count, double* G) {
+static __global__ __launch_bounds__(256) void cov_accumulate_kernel(const double* A, int64_t count, double* G) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) G[i] += A[i];
 }
 
 // c = -g, yy = 2 loss from a standard pass at z = 0 (g = -X^T W y / n, loss = y^T W y / (2 n))
-__global__ __launch_bounds__(256) void cov_linear_kernel(const double* g, int64_t ld, double* c, double* yy_out) {
+static __global__ __launch_bounds__(256) void cov_linear_kernel(const double* g, int64_t ld, double* c, double* yy_out) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j < ld) c[j] = -g[j];
   if (j == 0) yy_out[0] = 2.0 * g[ld];
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void cov_linear_kernel(const double* g, int64_
 
 // ---- the folds of a K-fold split, built from gathered blocks of their test rows (engine.hip, cov_folds_begin) ----------
 // R[i][0] = y[rows[i]], the other fifteen lane slots zero: the B operand of xtr_mfma_kernel for X_block^T y_block
-__global__ __launch_bounds__(256) void cov_targets_kernel(const double* y, const int64_t* rows, int64_t m, double* R) {
+static __global__ __launch_bounds__(256) void cov_targets_kernel(const double* y, const int64_t* rows, int64_t m, double* R) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over m * 16
   if (e >= m * SPLIT_RSTRIDE) return;
   const int64_t i = e >> 4;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void cov_targets_kernel(const double* y, const
 }
 
 // t[col] = sum_blk partial[blk][lane 0][col], fixed order; grid = ld / 256 (+1)
-__global__ __launch_bounds__(256) void cov_xty_kernel(const double* partial, int nblk, int64_t ld, double* t) {
+static __global__ __launch_bounds__(256) void cov_xty_kernel(const double* partial, int nblk, int64_t ld, double* t) {
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (col >= ld) return;
   double s = 0.0;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void cov_xty_kernel(const double* partial, int
 }
 
 // out[0] = sum_i y[rows[i]]^2 (one workgroup, fixed order), out[1..15] = 0
-__global__ __launch_bounds__(1024) void cov_yy_kernel(const double* y, const int64_t* rows, int64_t m, double* out) {
+static __global__ __launch_bounds__(1024) void cov_yy_kernel(const double* y, const int64_t* rows, int64_t m, double* out) {
   __shared__ double red[1024];
   double s = 0.0;
   for (int64_t i = threadIdx.x; i < m; i += 1024) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(1024) void cov_yy_kernel(const double* y, const int
 }
 
 // S[i] = sum_f parts[f * stride + i], f in fixed order, over len doubles
-__global__ __launch_bounds__(256) void cov_sum_kernel(const double* parts, int count, int64_t stride, int64_t len, double* S) {
+static __global__ __launch_bounds__(256) void cov_sum_kernel(const double* parts, int count, int64_t stride, int64_t len, double* S) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (int64_t)gridDim.x * 256) {
     double t = parts[i];
     for (int f = 1; f < count; ++f) t += parts[(int64_t)f * stride + i];
@@ -415,7 +415,7 @@ static inline int cov_syrk_tiles(int64_t ld) {
   return (int)t;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void cov_syrk_packed_kernel(SyrkBatch b, int64_t ld, int n_tiles) {
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void cov_syrk_packed_kernel(SyrkBatch b, int64_t ld, int n_tiles) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int tile = (int)blockIdx.x * 4 + wave;
   if (tile >= n_tiles) return;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // G = (A - B) * scale from packed triangles to the square, mirrored (B == nullptr: G = A * scale).  One 32 x 32 tile of the
 // lower triangle per workgroup: rows of the packed tile are read in 256-byte stretches, the mirror goes through LDS.
-__global__ __launch_bounds__(256) void cov_unpack_kernel(const double* A, const double* B, double scale, int64_t ld, double* G) {
+static __global__ __launch_bounds__(256) void cov_unpack_kernel(const double* A, const double* B, double scale, int64_t ld, double* G) {
   int bi = 0, rest = (int)blockIdx.x;
   while (rest > bi) {
     rest -= bi + 1;

@@ -9,7 +9,7 @@
 namespace slm {
 
 // F-order (column-major, leading dimension = n) -> padded row-major.  32x32 LDS tile.
-__global__ __launch_bounds__(256) void transpose_f2c_kernel(const double* __restrict__ src, int64_t n,
+static __global__ __launch_bounds__(256) void transpose_f2c_kernel(const double* __restrict__ src, int64_t n,
                                                             int64_t p, double* __restrict__ dst,
                                                             int64_t ld) {
   __shared__ double tile[32][33];
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void transpose_f2c_kernel(const double* __rest
 // plain [ld][n] matrix (until round 3) the 256-byte pieces of consecutive columns lay 8 n bytes apart -- a new DRAM row
 // and, every third column, a new 2 MB page per piece.  Rows beyond n inside the last tile are written as zeros.
 // grid ((n + 31) / 32, (ld + 31) / 32).
-__global__ __launch_bounds__(256) void tile_columns_kernel(const double* __restrict__ X, int64_t n, int64_t ld,
+static __global__ __launch_bounds__(256) void tile_columns_kernel(const double* __restrict__ X, int64_t n, int64_t ld,
                                                            double* __restrict__ XT) {
   __shared__ double tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void tile_columns_kernel(const double* __restr
 }
 
 // Row-major copy with different leading dimensions (device -> device), pad columns left untouched.
-__global__ __launch_bounds__(256) void copy_rows_kernel(const double* __restrict__ src, int64_t n,
+static __global__ __launch_bounds__(256) void copy_rows_kernel(const double* __restrict__ src, int64_t n,
                                                         int64_t p, int64_t lds_, double* __restrict__ dst,
                                                         int64_t ld) {
   const int64_t total = n * p;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const double* __restrict
 }
 
 // lane 0's copy of a per-lane vector -> lanes 1 .. n_lanes-1 (stride ld)
-__global__ __launch_bounds__(256) void broadcast_lanes_kernel(double* v, int64_t count, int64_t ld, int n_lanes) {
+static __global__ __launch_bounds__(256) void broadcast_lanes_kernel(double* v, int64_t count, int64_t ld, int n_lanes) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;
        e += (int64_t)gridDim.x * blockDim.x) {
     const double x = v[e];
@@ -84,7 +84,7 @@ struct SetupArgs {
   unsigned char a_mode[16], b_mode[16], d_mode[16], beta_mode[16];
 };
 
-__global__ __launch_bounds__(256) void solve_setup_kernel(SetupArgs s) {
+static __global__ __launch_bounds__(256) void solve_setup_kernel(SetupArgs s) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int64_t e = t0; e < (int64_t)s.max_lanes * s.ld; e += stride) {
@@ -113,14 +113,14 @@ __global__ __launch_bounds__(256) void solve_setup_kernel(SetupArgs s) {
   for (int64_t e = t0; e < s.infos_bytes / 8; e += stride) q[e] = 0ull;
 }
 
-__global__ __launch_bounds__(256) void fill_kernel(double* dst, int64_t count, double value) {
+static __global__ __launch_bounds__(256) void fill_kernel(double* dst, int64_t count, double value) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;
        e += (int64_t)gridDim.x * blockDim.x)
     dst[e] = value;
 }
 
 // sums[0] = sum_i w_i, sums[1] = sum_i w_i y_i   (one workgroup; w == nullptr => ones)
-__global__ __launch_bounds__(1024) void weighted_sums_kernel(const double* __restrict__ y,
+static __global__ __launch_bounds__(1024) void weighted_sums_kernel(const double* __restrict__ y,
                                                              const double* __restrict__ w, int64_t n,
                                                              double* __restrict__ sums) {
   __shared__ double red[2][TAIL_WAVES];
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(1024) void weighted_sums_kernel(const double* __res
 }
 
 // X[i][j] -= xmean[j] (j < p only: pad columns stay zero), y[i] -= ymean
-__global__ __launch_bounds__(256) void center_kernel(double* __restrict__ X, double* __restrict__ y, int64_t n,
+static __global__ __launch_bounds__(256) void center_kernel(double* __restrict__ X, double* __restrict__ y, int64_t n,
                                                      int64_t p, int64_t ld, const double* __restrict__ xmean,
                                                      double ymean) {
   const int64_t chunks = ld / 2;
@@ -171,7 +171,7 @@ __device__ __forceinline__ void normal_pair(uint64_t key, uint64_t ctr, double& 
 
 // X_ij ~ N(0,1) keyed by (seed, global row, column pair): independent of the launch geometry and of
 // how rows are sharded over ranks.
-__global__ __launch_bounds__(256) void synth_x_kernel(double* __restrict__ X, int64_t n, int64_t p,
+static __global__ __launch_bounds__(256) void synth_x_kernel(double* __restrict__ X, int64_t n, int64_t p,
                                                       int64_t ld, uint64_t seed, int64_t row_offset) {
   const int64_t pairs = (p + 1) / 2;
   const int64_t total = n * pairs;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void synth_x_kernel(double* __restrict__ X, in
 }
 
 // y_i = x_i . coef + noise_sd * N(0,1): one wavefront per row.
-__global__ __launch_bounds__(256) void synth_y_kernel(const double* __restrict__ X, int64_t n, int64_t p,
+static __global__ __launch_bounds__(256) void synth_y_kernel(const double* __restrict__ X, int64_t n, int64_t p,
                                                       int64_t ld, const double* __restrict__ coef,
                                                       double noise_sd, uint64_t seed,
                                                       int64_t row_offset, double* __restrict__ y) {

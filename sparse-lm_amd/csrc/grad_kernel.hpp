@@ -444,7 +444,7 @@ struct TwoPassArgs {
   int p2;
 };
 
-__global__ __launch_bounds__(256) void rowdot_kernel(TwoPassArgs a) {
+static __global__ __launch_bounds__(256) void rowdot_kernel(TwoPassArgs a) {
   if (a.done != nullptr && *a.done != 0) return;
   __shared__ double lsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -558,7 +558,7 @@ struct ReduceArgs {
 };
 
 // grid = (ld/16 + 1, n_lanes)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceArgs a) {
+static __global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceArgs a) {
   if (a.done != nullptr && *a.done != 0) return;
   __shared__ double lds[16][17];
   const int tid = threadIdx.x;

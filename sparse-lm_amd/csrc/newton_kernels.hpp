@@ -249,7 +249,7 @@ __device__ __forceinline__ double nt_lambda_min(const double* F, const double* D
   return lam;
 }
 
-__global__ __launch_bounds__(TAIL_THREADS) void dense_spd_solve_kernel(DenseSolveArgs a) {
+static __global__ __launch_bounds__(TAIL_THREADS) void dense_spd_solve_kernel(DenseSolveArgs a) {
   __shared__ NtShared sh;
   __shared__ double v[NT_MAXT * NT_B];
   __shared__ double red[1][TAIL_WAVES];

@@ -407,7 +407,7 @@ __device__ __forceinline__ void sm_face_solve(const double* F, const double* inv
   }
 }
 
-__global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
+static __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArgs a) {
   extern __shared__ double sm_lds[];  // G [p][p], c [p], vz [p], vu [p], then the stage
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.t.ctl + lane_id;

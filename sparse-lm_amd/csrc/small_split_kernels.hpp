@@ -44,7 +44,7 @@ struct SplitSglArgs {
 
 constexpr double SS_RELAX = 1.6;
 
-__global__ __launch_bounds__(SM_THREADS) void small_stdsgl_kernel(SplitSglArgs a) {
+static __global__ __launch_bounds__(SM_THREADS) void small_stdsgl_kernel(SplitSglArgs a) {
   extern __shared__ double sm_lds[];  // G [p][p], c [p], vz [p], vu [p], L [p][gmax], then the stage
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -345,7 +345,7 @@ constexpr int XTR_CW = 128;                    // columns per wavefront
 constexpr int XTR_CB = XTR_WAVES * XTR_CW;     // columns per workgroup
 constexpr int XTR_U = 2;                       // 4-row steps per batch
 
-__global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a) {
+static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a) {
   static_assert(SPLIT_RSTRIDE == 16 && SPLIT_LANES <= 16, "a row of R is the 16-wide B operand");
   if (a.done != nullptr && *a.done != 0) return;
   const int lane = threadIdx.x & 63;
@@ -527,7 +527,7 @@ __device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const
 }
 
 
-__global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a) {
+static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 rows of the MFMA A operand");
   if (a.done != nullptr && *a.done != 0) return;
   const unsigned mask = split_x_mask(a);
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a)
 constexpr int RM_WAVES = 8;   // (4: 30.6 us per pass on the headline path, 8 or 16: 26.6 us -- six 16-row tiles per wavefront were a chain of six)
 constexpr int RM_U = 4;  // 16-position groups per batch (two batches in flight)
 
-__global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) {
+static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 columns of the MFMA B operand");
   if (a.done != nullptr && *a.done != 0) return;
   const unsigned mask = split_ws_mask(a);

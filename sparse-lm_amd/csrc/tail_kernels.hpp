@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
 // in index order; each takes the upper half of the points the busiest lane has not started
 // (keeping at least one for the victim) and starts cold; with nothing left to take it retires.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void steal_kernel(TailArgs a) {
+static __global__ __launch_bounds__(256) void steal_kernel(TailArgs a) {
   if (a.gdone[0] != 0) return;
   __shared__ int took[SLM_MAX_LANES];
   if (threadIdx.x == 0) {
@@ -1186,7 +1186,7 @@ constexpr int STOP_WORDS = 16;
 // this rank's control blocks (path point, passes on it, mode, done of every lane): if the ranks' states are the
 // same, n sum(c^2) == (sum c)^2 exactly (all terms are integers below 2^53); if not, the solve is over -- its
 // ranks no longer iterate on one problem -- and every rank reports it (gdone[4]) after the same pass.
-__global__ void stop_pack_kernel(const int* gdone, const PathCtl* ctl, int n_lanes, double* words) {
+static __global__ void stop_pack_kernel(const int* gdone, const PathCtl* ctl, int n_lanes, double* words) {
   if (threadIdx.x < STOP_WORDS) words[threadIdx.x] = 0.0;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1204,7 +1204,7 @@ __global__ void stop_pack_kernel(const int* gdone, const PathCtl* ctl, int n_lan
     words[3] = (double)c * (double)c;
   }
 }
-__global__ void stop_apply_kernel(int* gdone, const double* words) {
+static __global__ void stop_apply_kernel(int* gdone, const double* words) {
   if (threadIdx.x != 0) return;
   const double n = words[1];
   if (!(n >= 1.0)) return;
@@ -1229,7 +1229,7 @@ struct PowerArgs {
 };
 
 // one workgroup per lane
-__global__ __launch_bounds__(TAIL_THREADS) void power_step_kernel(PowerArgs a) {
+static __global__ __launch_bounds__(TAIL_THREADS) void power_step_kernel(PowerArgs a) {
   __shared__ double red[1][TAIL_WAVES];
   a.g += (int64_t)blockIdx.x * (a.ld + 16);
   a.v += (int64_t)blockIdx.x * a.ld;
@@ -1256,7 +1256,7 @@ struct SeedArgs {
   // weights and 1/n scaling: max weight x n / n_l, see solve_core); 1 for lanes that share it
   double factor[SLM_MAX_LANES];
 };
-__global__ void seed_step_kernel(SeedArgs a) {
+static __global__ void seed_step_kernel(SeedArgs a) {
   const int l = threadIdx.x;
   if (l >= a.n_lanes) return;
   double L0 = a.lambda[0] * a.margin;
@@ -1275,7 +1275,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 }
 
 // Deterministic start vector for the power iteration: unit-norm hash noise.
-__global__ __launch_bounds__(TAIL_THREADS) void power_init_kernel(double* v, int p, int64_t ld) {
+static __global__ __launch_bounds__(TAIL_THREADS) void power_init_kernel(double* v, int p, int64_t ld) {
   __shared__ double red[1][TAIL_WAVES];
   v += (int64_t)blockIdx.x * ld;  // one workgroup per lane, same start vector
   double s[1] = {0.0};

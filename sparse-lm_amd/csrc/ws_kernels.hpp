@@ -134,7 +134,7 @@ struct WsArgs {
 };
 
 // state of a fresh solve (the block is zeroed first): a build is requested, no lane has been refined yet
-__global__ void ws_ctl_init_kernel(WsCtl* ws, int max_builds) {
+static __global__ void ws_ctl_init_kernel(WsCtl* ws, int max_builds) {
   if (threadIdx.x == 0) {
     ws->request = 1;
     ws->max_builds = max_builds;
@@ -176,7 +176,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[16]*/, in
 // the path there).  Features that would enter by then are taken now; later ones are appended when
 // their time comes.  (Inside the one-workgroup select kernel this sweep cost 45-60 us per pass.)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
+static __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
   WsCtl* ws = w.ws;
   if (a.gdone[0] != 0 || ws->disabled) return;
   const bool had_w = ws->valid != 0;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
 // APPENDED (their columns and Gram rows are all that has to be produced); a fresh selection is made
 // at the start of a solve and when the appended set would exceed WS_KCAP.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArgs w) {
+static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArgs w) {
   __shared__ double red[2][TAIL_WAVES];
   __shared__ int wave_tot[TAIL_WAVES];
   WsCtl* ws = w.ws;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArg
 // sector per element: 0.2 ms for 112 columns, 0.5 ms per 50-alpha path.)  grid (row tiles, 16 column
 // tiles of 32 starting at k_new); tiles beyond K return at once.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
+static __global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
   if (!w.ws->building) return;
   const int K = w.ws->K;
   const int k0 = w.ws->k_new + 32 * (int)blockIdx.y;
@@ -602,7 +602,7 @@ typedef double ws_d4 __attribute__((ext_vector_type(4)));
 constexpr int WS_GRAM_THREADS = 512;
 constexpr int WS_GRAM_ZCHUNKS = 4;  // slices of a row block: 4 column quarters x this many chunks of tile rows
 
-__global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
+static __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
   if (!w.ws->building) return;
   __shared__ ws_d4 comb[2][16][64];  // 64 KiB: row-split appends fold their four parts through here
   const int K = w.ws->K;
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(WS_GRAM_THREADS) void ws_gram_kernel(WsArgs w) {
 // fixed-order sum of the partial Grams, scaled by 1/n_set: the new tile rows and, mirrored, the
 // matching columns of the old part.  One workgroup per 16x16 tile (grid (WS_TILES^2, n_sets)); the
 // last workgroup publishes the Gram.
-__global__ __launch_bounds__(256) void ws_gram_reduce_kernel(WsArgs w) {
+static __global__ __launch_bounds__(256) void ws_gram_reduce_kernel(WsArgs w) {
   WsCtl* ws = w.ws;
   if (!ws->building) return;
   const int K = ws->K;
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void ws_gram_reduce_kernel(WsArgs w) {
 // Gram and publish it.  grid (WS_PUBLISH_BLOCKS, n_sets): a workgroup walks its share of the K x K corner (as 1 024
 // workgroups over the whole 512 x 512 matrix, each with its turn at the one counter, the kernel took 62 us).
 constexpr int WS_PUBLISH_BLOCKS = 64;
-__global__ __launch_bounds__(256) void ws_publish_kernel(WsArgs w) {
+static __global__ __launch_bounds__(256) void ws_publish_kernel(WsArgs w) {
   WsCtl* ws = w.ws;
   if (!ws->building || !ws->staged) return;
   const int K = ws->K;
@@ -1818,7 +1818,7 @@ struct GatherArgs {
   double* XW;          // [n][WS_KCAP]
 };
 
-__global__ __launch_bounds__(256) void gather_cols_kernel(GatherArgs w) {
+static __global__ __launch_bounds__(256) void gather_cols_kernel(GatherArgs w) {
   const int k0 = 32 * (int)blockIdx.y;
   if (k0 >= w.K) return;
   __shared__ double tile[32][33];
@@ -1852,7 +1852,7 @@ struct SseArgs {
   int K, m;          // m <= SSE_M vectors in this launch
 };
 
-__global__ __launch_bounds__(256) void sse_sparse_kernel(SseArgs a) {
+static __global__ __launch_bounds__(256) void sse_sparse_kernel(SseArgs a) {
   extern __shared__ double zs[];  // [K][SSE_M]
   __shared__ double wsum[4][SSE_M];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

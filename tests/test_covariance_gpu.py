@@ -83,7 +83,8 @@ def test_sixteen_lane_calls_from_the_grams_of_their_folds(eng):
 
 def test_grid_search_from_the_folds_grams(eng):
     """GridSearchCV(SparseGroupLasso) with solver_options covariance=True / False: the same table of scores and the same
-    choice ("auto" does not ask for Grams on a grid this small)."""
+    choice.  "auto" does not ask for Grams on a grid this small -- but takes the ones an earlier search left on the dataset
+    (the searches of one (X, y) share a device dataset through the cache: found by content)."""
     from sparselm_amd.model import SparseGroupLasso
     from sparselm_amd.model_selection import GridSearchCV
 
@@ -91,12 +92,14 @@ def test_grid_search_from_the_folds_grams(eng):
     X, y, groups, G, _ = _problem(n, p, seed=3)
     grid = {"alpha": np.geomspace(2.0, 0.05, 8), "l1_ratio": [0.2, 0.5, 0.8]}
     out = {}
-    for cov in (False, True, "auto"):
-        opts = {"tol": 1e-10, "covariance": cov, "on_chip": False}
+    for cov in (False, "auto", True, "auto again"):
+        opts = {"tol": 1e-10, "covariance": "auto" if isinstance(cov, str) else cov, "on_chip": False}
         gs = GridSearchCV(SparseGroupLasso(groups=groups, solver_options=opts), grid, cv=4).fit(X, y)
         out[cov] = gs
     np.testing.assert_allclose(out[True].cv_results_["mean_test_score"], out[False].cv_results_["mean_test_score"], rtol=1e-8)
     np.testing.assert_array_equal(out["auto"].cv_results_["mean_test_score"], out[False].cv_results_["mean_test_score"])
+    # (the Grams of the third search are on the cached dataset: the fourth reads them -- bit for bit the third's table)
+    np.testing.assert_array_equal(out["auto again"].cv_results_["mean_test_score"], out[True].cv_results_["mean_test_score"])
     assert out[True].best_params_ == out[False].best_params_
     np.testing.assert_allclose(out[True].best_estimator_.coef_, out[False].best_estimator_.coef_, rtol=0,
                                atol=1e-8 * np.max(np.abs(out[False].best_estimator_.coef_)))

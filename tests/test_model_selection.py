@@ -522,6 +522,9 @@ def test_line_search_keeps_one_device_dataset_for_all_its_lines(monkeypatch):
     opened = []
     real_open = ms._DeviceGrid.open
     monkeypatch.setattr(ms._DeviceGrid, "open", lambda self: (opened.append(1), real_open(self))[1])
+    cached = []  # stand-alone searches go through the device dataset cache (same content: found again, not uploaded)
+    real_cached = ms._DeviceGrid.open_cached
+    monkeypatch.setattr(ms._DeviceGrid, "open_cached", lambda self: (cached.append(1), real_cached(self))[1])
     est = SparseGroupLasso(groups=groups, fit_intercept=True, solver_options={"tol": 1e-10})
     line = ms.LineSearchCV(est, grid, cv=3, n_iter=4).fit(X, y)
     assert len(opened) == 1 and len(line.history_) == 4
@@ -533,7 +536,7 @@ def test_line_search_keeps_one_device_dataset_for_all_its_lines(monkeypatch):
         np.testing.assert_allclose(search.cv_results_["mean_test_score"], alone.cv_results_["mean_test_score"], rtol=1e-9)
         assert search.best_params_ == alone.best_params_
         best = dict(alone.best_params_)
-    assert len(opened) == 1 + 4
+    assert len(opened) == 1 and len(cached) == 4  # the line search opened ONE dataset; each stand-alone search asked the cache
     assert line.best_params_ == best
 
 
