@@ -1,5 +1,6 @@
 #!/bin/bash
-# The profile set of a round: run on the GPU box from the repository root as `bash tools/r04_profile.sh <tag>` (e.g. r04a).
+# The profile set of a round, collection: run on the GPU box from the repository root as `bash tools/r04_profile.sh <tag>` (e.g. r04b);
+# everything lands under gpurun_out/ (the only directory that travels back); tools/r04_condense.sh <tag> then writes profiles/<tag>_*.
 # Every rocprofv3 run has the program itself after `--`; counters run in passes of their own.
 set -o pipefail
 TAG=${1:-r04a}
@@ -15,13 +16,4 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d 
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_t_fetch -- python3 $R/tools/r04_targets.py grams grid config5 > /dev/null 2>&1 && echo targets fetch ok
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_t_write -- python3 $R/tools/r04_targets.py grams grid config5 > /dev/null 2>&1 && echo targets write ok
 cd $R
-python tools/summarize_prof.py $TAG
-T=$(find gpurun_out/prof_t_stats -name "*kernel_stats.csv" | head -1); cp $T profiles/${TAG}_targets_kernel_stats.csv
-K=$(find gpurun_out/prof_t_stats -name "*kernel_trace.csv" | head -1); python tools/kernel_table.py $K > profiles/${TAG}_targets_kernel_table.txt
-cp gpurun_out/${TAG}_targets.log profiles/${TAG}_targets.log
-cp gpurun_out/${TAG}_bench_under_rocprof.log profiles/${TAG}_bench_under_rocprof.log
-python tools/summarize_counters.py prof_t_mfma ${TAG}_targets_mfma_counters "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/r04_targets.py grams grid"
-python tools/summarize_counters.py prof_t_fetch ${TAG}_targets_fetch "rocprofv3 --pmc FETCH_SIZE -- python3 tools/r04_targets.py grams grid config5 (KiB per dispatch; double for 16-byte-per-lane loads, MI355X_MICROARCH.md)"
-python tools/summarize_counters.py prof_t_write ${TAG}_targets_write "rocprofv3 --pmc WRITE_SIZE -- python3 tools/r04_targets.py grams grid config5 (KiB per dispatch)"
-P=$(find gpurun_out/prof_stats -name "*kernel_trace.csv" | head -1); python tools/path_timeline.py $P 9 1 > profiles/${TAG}_path_timeline.txt 2>/dev/null || true
-ls -la profiles/${TAG}_*
+echo collected: run tools/r04_condense.sh $TAG where gpurun_out/ has been merged back
