@@ -72,3 +72,56 @@ def test_host_pool_falls_back_to_numpy_memory():
     big[:] = 1.0
     pool.pid = -1  # "another process"
     assert pool.empty(1 << 16).flags.owndata
+
+
+def test_roofline_traffic_is_quoted_only_for_the_source_it_was_taken_on(tmp_path, monkeypatch):
+    """bench.measured_traffic: the committed PMC figure goes into the bench line only for the workload and kernel it was
+    taken on and only while the kernel's source file still has the recorded SHA-256 (the GPU box has no .git to ask)."""
+    import hashlib
+    import json
+    import os
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, root)
+    import bench
+
+    value, note = bench.measured_traffic(100_000, 5_000, 16, "xtr_mfma_kernel")
+    recorded = json.load(open(os.path.join(root, "profiles", "roofline_traffic.json")))
+    src = os.path.join(root, recorded["taken_on"]["kernel_source"])
+    if hashlib.sha256(open(src, "rb").read()).hexdigest() == recorded["taken_on"]["kernel_source_sha256"]:
+        assert value == recorded["hbm_bytes_per_launch"] and "PMC passes of commit" in note
+    else:
+        assert value is None and "has changed" in note
+    assert bench.measured_traffic(100_000, 5_000, 4, "xtr_mfma_kernel")[0] is None  # another workload
+    assert bench.measured_traffic(100_000, 5_000, 16, "grad_fused_kernel")[0] is None  # another kernel
+    # a changed source file: the figure is withheld, with the reason
+    fake = tmp_path / "repo"
+    (fake / "profiles").mkdir(parents=True)
+    (fake / "k.hpp").write_text("// edited\n")
+    rec = dict(recorded, taken_on=dict(recorded["taken_on"], kernel_source="k.hpp"))
+    (fake / "profiles" / "roofline_traffic.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(fake))
+    value, note = bench.measured_traffic(100_000, 5_000, 16, "xtr_mfma_kernel")
+    assert value is None and "has changed" in note
+
+
+def test_compiled_binding_loads_and_agrees_with_python_on_the_secant_factors():
+    """The pybind11 module loads without a GPU (it only links the engine), reports the ABI it was built against, and its
+    secant factors of a path -- computed in C++ for the hot calls -- are those of `_engine.path_extrapolation`."""
+    import numpy as np
+
+    from sparselm_amd import _engine
+
+    b = _engine.load_binding()
+    assert b is not None, "build it: python sparse-lm_amd/build.py"
+    assert b.abi_version() == _engine.ABI_VERSION and b.info_record_bytes() == _engine._INFO_DTYPE.itemsize
+    rng = np.random.default_rng(0)
+    for K in (1, 2, 3, 10, 50):
+        al = np.geomspace(1, 1e-3, K)
+        for pts in (np.c_[al, 0 * al, 0 * al], np.c_[0.3 * al, 0.7 * al, 0 * al], np.c_[al, al[::-1], 0 * al], rng.uniform(size=(K, 3)),
+                    np.c_[al, al, al] * np.r_[np.ones(K // 2), np.ones(K - K // 2)][:, None]):
+            pts = np.ascontiguousarray(pts)
+            np.testing.assert_allclose(b.path_extrapolation(pts), _engine._path_extrapolation(pts), rtol=1e-13, atol=0)
+    with __import__("pytest").raises(ValueError):
+        b.path_extrapolation(np.zeros(4))

@@ -670,3 +670,56 @@ def test_results_come_in_recycled_page_locked_blocks():
             del os.environ["SLM_NO_HOST_POOL"]
         assert plain.betas.flags.owndata or plain.betas.base is not None
         np.testing.assert_array_equal(plain.betas, first)
+
+
+def test_compiled_binding_and_ctypes_give_the_same_bits():
+    """The pybind11 module (csrc/binding.cpp) marshals the hot calls itself; with SLM_NO_BINDING=1 the same calls go through
+    ctypes.  Same engine, same arguments: the same coefficients bit for bit -- lanes with masks, warm starts, scalar and
+    vector penalties, group norms, a shared path, its own secant factors against Python's."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, "sparse-lm_amd")
+from sparselm_amd import _engine
+rng = np.random.default_rng(3)
+n, p = 900, 70
+X = rng.standard_normal((n, p)); y = X[:, :5] @ rng.uniform(1, 3, 5) + rng.standard_normal(n)
+groups = np.arange(p) // 5
+eng = _engine.get_engine(0)
+out = {"binding": _engine.load_binding() is not None}
+with eng.dataset(np.asfortranarray(X), y) as ds:
+    ds.set_groups(groups, p // 5)
+    g0, _ = ds.gradient(None)
+    amax = float(np.max(np.abs(g0)))
+    al = np.geomspace(amax, 0.02 * amax, 7)
+    mask = (rng.permutation(n) % 4 != 0).astype(float)
+    lanes = [dict(points=np.c_[al, 0 * al, 0 * al]),
+             dict(points=np.c_[0.3 * al, 0.7 * al, 0.1 + 0 * al], row_weight=mask, n_eff=int(mask.sum()), a=rng.uniform(0.5, 1.5, p)),
+             dict(points=[(0.0, 0.4 * amax, 0.0)], b=2.0, beta0=0.01 * rng.standard_normal(p), row_weight=mask, n_eff=int(mask.sum()))]
+    res = ds.solve_lanes(lanes, tol=1e-10, want_group_norms=True)
+    shared = ds.solve_path(np.c_[al, 0 * al, 0 * al], tol=1e-10, lanes=4, flags=_engine.FLAG_WORKING_SET)
+    h = hashlib.sha256()
+    for r in res + [shared]:
+        h.update(np.ascontiguousarray(r.betas).tobytes())
+        if r.group_norms is not None:
+            h.update(np.ascontiguousarray(r.group_norms).tobytes())
+        h.update(r.n_iter.tobytes())
+    out["digest"] = h.hexdigest()
+    out["converged"] = all(r.converged for r in res) and shared.converged
+    out["passes"] = [int(r.grad_launches) for r in res + [shared]]
+print(json.dumps(out))
+'''
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    got = {}
+    for name, env in (("binding", {}), ("ctypes", {"SLM_NO_BINDING": "1"})):
+        run = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        got[name] = json.loads(run.stdout.strip().splitlines()[-1])
+    assert got["binding"]["binding"] is True and got["ctypes"]["binding"] is False
+    assert got["binding"]["converged"] and got["ctypes"]["converged"]
+    assert got["binding"]["digest"] == got["ctypes"]["digest"] and got["binding"]["passes"] == got["ctypes"]["passes"]
