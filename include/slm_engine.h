@@ -214,7 +214,7 @@ typedef struct slm_path_point {
                                         same meaning of `tol`; slm_point_info.mode is 2, n_iter counts matrix-vector products,
                                         slm_solve_stats.grad_launches is 1.  Ignored together with the flags that ask for
                                         a particular iteration (1, 2, 16, 32, 64); a point it does not settle hands the
-                                        call to the general path.  Up to SLM_MAX_LANES lanes whatever p.              */
+                                        call to the general path.  Up to SLM_MAX_CELLS lanes whatever p.              */
 
 #define SLM_FLAG_COVARIANCE 256u      /* passes take their gradients from the Grams of the call's row sets where
                                         slm_dataset_covariance() has built every one of them: G z - c, 8 p^2 bytes per row
@@ -292,6 +292,11 @@ int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point
  * matrix cores for SLM_MAX_LANES lanes per read of X.  slm_dataset_max_lanes() tells.
  */
 #define SLM_MAX_LANES 16
+/* ... and of a call the on-chip solver takes (SLM_FLAG_ON_CHIP on a dataset of p <= 128, n * ld <= 2^17): a workgroup per
+ * lane, so the cells of a small grid search -- (candidate, fold) pairs, 50 in the reference's README example -- go in ONE
+ * call.  slm_dataset_max_lanes() tells which of the two limits applies; a point the kernel does not settle sends the call
+ * to the general path in chunks of SLM_MAX_LANES. */
+#define SLM_MAX_CELLS 64
 typedef struct slm_lane {
   const slm_penalty* pen;         /* NULL => all-ones base vectors                              */
   const slm_path_point* points;   /* this lane's warm-started path                              */

@@ -131,7 +131,7 @@ py::array info_bytes(int64_t count) {
 py::tuple solve_lanes(uintptr_t ds, const py::list& specs, int64_t n, int64_t p, int64_t G, double tol, int max_iter, int check_every,
                       double L, uint32_t flags, bool want_gn, bool extrapolate, const py::object& alloc) {
   const int nl = (int)specs.size();
-  if (nl < 1 || nl > SLM_MAX_LANES) throw py::value_error("between 1 and " + std::to_string(SLM_MAX_LANES) + " lanes, got " + std::to_string(nl));
+  if (nl < 1 || nl > SLM_MAX_CELLS) throw py::value_error("between 1 and " + std::to_string(SLM_MAX_CELLS) + " lanes, got " + std::to_string(nl));
   Keep keep;
   std::vector<slm_lane> lanes((size_t)nl);
   std::vector<slm_penalty> pens((size_t)nl);

@@ -81,7 +81,7 @@ struct SetupArgs {
   int64_t infos_bytes;
   int64_t ld, p, G;
   int n_lanes, max_lanes;
-  unsigned char a_mode[16], b_mode[16], d_mode[16], beta_mode[16];
+  unsigned char a_mode[SLM_MAX_CELLS], b_mode[SLM_MAX_CELLS], d_mode[SLM_MAX_CELLS], beta_mode[SLM_MAX_CELLS];
 };
 
 static __global__ __launch_bounds__(256) void solve_setup_kernel(SetupArgs s) {

@@ -366,7 +366,7 @@ int set_singleton_groups(slm_dataset* ds) {
   SLM_TRY(dalloc(&ds->order, p));
   SLM_TRY(dalloc(&ds->gid, p));
   SLM_TRY(dalloc(&ds->gstart, p + 1));
-  SLM_TRY(dalloc(&ds->gscale, (size_t)kMaxLanes * p));
+  SLM_TRY(dalloc(&ds->gscale, (size_t)ds->lane_cap * p));
   HIP_TRY(hipMemcpy(ds->order, ident.data(), sizeof(int) * p, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ds->gid, ident.data(), sizeof(int) * p, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ds->gstart, start.data(), sizeof(int) * (p + 1), hipMemcpyHostToDevice));
@@ -425,7 +425,8 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
 
   int rc = SLM_OK;
   auto A = [&](int r) { if (rc == SLM_OK) rc = r; };
-  const size_t ML = kMaxLanes;
+  ds->lane_cap = (p <= SM_PMAX && (double)n * (double)ld <= 131072.0) ? kMaxCells : kMaxLanes;
+  const size_t ML = (size_t)ds->lane_cap;
   A(dalloc(&ds->X, (size_t)n * ld));
   A(dalloc(&ds->y, n));
   A(dalloc(&ds->yzero, n));
@@ -719,7 +720,7 @@ extern "C" int slm_dataset_set_groups(slm_dataset* ds, const int32_t* gid, int32
   SLM_TRY(dalloc(&ds->order, p));
   SLM_TRY(dalloc(&ds->gid, p));
   SLM_TRY(dalloc(&ds->gstart, n_groups + 1));
-  SLM_TRY(dalloc(&ds->gscale, (size_t)kMaxLanes * n_groups));
+  SLM_TRY(dalloc(&ds->gscale, (size_t)ds->lane_cap * n_groups));
   HIP_TRY(hipMemcpy(ds->order, order.data(), sizeof(int) * p, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ds->gid, gid, sizeof(int) * p, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ds->gstart, start.data(), sizeof(int) * (n_groups + 1), hipMemcpyHostToDevice));

@@ -147,6 +147,7 @@ struct slm_engine {
 int all_reduce_sum(slm_engine* eng, double* buf, size_t count, hipStream_t s = nullptr);
 
 static const int kMaxLanes = SLM_MAX_LANES;
+static const int kMaxCells = SLM_MAX_CELLS;  // lanes of a call the on-chip solver takes (slm_dataset::lane_cap)
 
 // Control words shared by all lanes of a solve.
 struct GlobalCtl {
@@ -168,7 +169,7 @@ static const int kSnapInfos = 64;
 struct DevCtl {
   GlobalCtl g;
   WsCtl ws;  // (next to g: one fill clears both at the start of a solve)
-  PathCtl lane[SLM_MAX_LANES];
+  PathCtl lane[SLM_MAX_CELLS];
   slm_point_info infos[kSnapInfos];  // the per-point records of solves of up to kSnapInfos points ride along
 };
 struct HostCtl {  // pinned snapshot the host polls
@@ -184,6 +185,9 @@ struct slm_dataset {
   // unless it is marked as a REPLICA (slm_dataset_set_replicated: grid mode -- every rank holds all rows and solves its own
   // lanes; the communicator then only carries the folds' Grams, each rank building the part of an n_ranks-th of the rows)
   bool replicated = false;
+  // lanes the per-lane buffers are laid out for: SLM_MAX_LANES, or SLM_MAX_CELLS on datasets the on-chip solver can take
+  // (p <= 128, n * ld <= 2^17: the buffers are tiny there, and a small grid search has more cells than sixteen)
+  int lane_cap = SLM_MAX_LANES;
   double *X = nullptr, *y = nullptr, *rw = nullptr, *yzero = nullptr;
   double rw_max = 1.0;  // largest row weight (1 without row weights; < 0: unknown -- weights handed over on the device)
   double* rw_lanes = nullptr;  // [kMaxLanes][n], allocated when a lane brings its own row weights
@@ -199,7 +203,7 @@ struct slm_dataset {
   double* ws_nt = nullptr;  // [kMaxLanes][NT_SCRATCH] factors of the model solver's direct steps
   double *sse_Z = nullptr, *sse_part = nullptr;  // slm_eval_sse_sparse: coefficient block, partial sums
   size_t sse_cap = 0;
-  PathCtl h_stage[SLM_MAX_LANES];  // host staging of the control blocks of the solve in flight
+  PathCtl h_stage[SLM_MAX_CELLS];  // host staging of the control blocks of the solve in flight
   // page-locked staging of what the lanes of a call bring (penalty vectors, warm starts: [4][kMaxLanes][ld]; path points):
   // one transfer per kind instead of one per lane and kind -- sixteen lanes x (a, warm start, points) were 48 transfers of a
   // few hundred bytes, 0.25 ms of submissions before a 0.2 ms call of the on-chip solver
@@ -287,7 +291,7 @@ struct LaneSetup {
   int B = 1;
   const double* rw = nullptr;  // device row weights handed to the kernel
   int64_t rw_stride = 0;
-  double n_eff[SLM_MAX_LANES] = {};
+  double n_eff[SLM_MAX_CELLS] = {};
 };
 LaneSetup default_lanes(slm_dataset* ds, int B);
 int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done, hipEvent_t ev_start, hipEvent_t ev_stop,

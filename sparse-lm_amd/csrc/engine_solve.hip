@@ -142,7 +142,7 @@ LaneSetup default_lanes(slm_dataset* ds, int B) {
   ls.B = B;
   ls.rw = ds->rw;
   ls.rw_stride = 0;
-  for (int l = 0; l < kMaxLanes; ++l) ls.n_eff[l] = (double)ds->n_global;
+  for (int l = 0; l < kMaxCells; ++l) ls.n_eff[l] = (double)ds->n_global;
   return ls;
 }
 
@@ -774,7 +774,7 @@ static bool small_ok(const slm_dataset* ds, uint32_t flags) {
 // most lanes one solve can run: the fused kernels' table, or the split pass's sixteen when the working
 // set is on from the start
 static int max_lanes_for(slm_dataset* ds, uint32_t flags) {
-  if (small_ok(ds, flags)) return kMaxLanes;  // a workgroup per lane
+  if (small_ok(ds, flags)) return ds->lane_cap;  // a workgroup per lane
   if ((ws_policy(ds, flags) == 2 || (double)ds->n * (double)ds->ld >= 67108864.0) && split_usable(ds)) return SPLIT_LANES;
   int B = kMaxLanes;
   while (B > 1 && !ds->gk[B - 1]) --B;
@@ -810,8 +810,12 @@ static int solve_without_chip(slm_dataset* ds, const slm_lane* lanes, int32_t B,
 static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, const slm_solve_opts* opts,
                       slm_solve_stats* stats, bool shared_path) {
   if (!ds || !lanes) return fail(SLM_ERR_BAD_ARG, "NULL argument");
-  if (n_lanes < 1 || n_lanes > kMaxLanes)
-    return fail(SLM_ERR_BAD_ARG, "n_lanes must be in [1, %d] (got %d)", kMaxLanes, n_lanes);
+  {
+    // sixteen lanes; the on-chip solver, a workgroup per lane, takes SLM_MAX_CELLS (what it does not settle comes back here
+    // through solve_without_chip in chunks of sixteen)
+    const int cap = small_ok(ds, opts ? opts->flags : 0u) ? ds->lane_cap : kMaxLanes;
+    if (n_lanes < 1 || n_lanes > cap) return fail(SLM_ERR_BAD_ARG, "n_lanes must be in [1, %d] (got %d)", cap, n_lanes);
+  }
   const int B = n_lanes;
   // the split pass costs four launches where the fused kernel costs one: take it when X is large (the
   // accumulate-only stream is then all that matters) or when only it has enough lanes
@@ -822,7 +826,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   //  second full read, of the column-major copy -- the split pass is worth it there only for more lanes than
   //  the fused kernel serves: measured on config 5's shape, one lane, 2.9 ms per pass against 2.4 ms fused)
   const bool wide = ds->sk != nullptr && ds->sk->rowdot == nullptr;
-  const bool want_split = (ws_policy(ds, opts ? opts->flags : 0u) == 2 && !wide) ? (big_x || !ds->gk[B - 1]) : (big_x && !ds->gk[B - 1]);
+  // (the fused kernels' table stops at SLM_MAX_LANES; calls of more lanes exist on the on-chip route only)
+  const GradKernel* gk_B = B <= kMaxLanes ? ds->gk[B - 1] : nullptr;
+  const bool want_split = (ws_policy(ds, opts ? opts->flags : 0u) == 2 && !wide) ? (big_x || !gk_B) : (big_x && !gk_B);
   // (covariance passes are a form of the split pass: the flag asks for it whatever the size, where Grams exist)
   const bool want_cov = opts && (opts->flags & SLM_FLAG_COVARIANCE) && !ds->cov.empty() && !row_sharded(ds);
   const bool split = (want_split || want_cov) && split_usable(ds);
@@ -836,7 +842,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // 10.9 ms per path against 250 columns and 10.3 ms with contiguous ranges.)
   const bool interleave = shared_path && ds->singleton && ws_policy(ds, opts ? opts->flags : 0u) == 2 &&
                           !getenv("SLM_NO_INTERLEAVE");
-  if (!split && !ds->gk[B - 1] && !small_ok(ds, opts ? opts->flags : 0u))
+  if (!split && !gk_B && !small_ok(ds, opts ? opts->flags : 0u))
     return fail(SLM_ERR_UNSUPPORTED, "no %d-lane gradient kernel covers p = %lld", B, (long long)ds->p);
   if (split && B > ROWDOT_LANES) SLM_TRY(ensure_xt(ds));  // rowdot_mfma_kernel reads the column-major copy (optional)
   int64_t total_points = 0;
@@ -881,10 +887,10 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
 
   // ---- per-lane row weights / scaling -----------------------------------------------------------
   LaneSetup ls = default_lanes(ds, B);
-  double wmax[SLM_MAX_LANES];  // largest row weight of each lane (< 0: unknown)
-  for (int l = 0; l < kMaxLanes; ++l) wmax[l] = ds->rw ? ds->rw_max : 1.0;
+  double wmax[SLM_MAX_CELLS];  // largest row weight of each lane (< 0: unknown)
+  for (int l = 0; l < kMaxCells; ++l) wmax[l] = ds->rw ? ds->rw_max : 1.0;
   if (any_rw) {
-    if (!ds->rw_lanes) SLM_TRY(dalloc(&ds->rw_lanes, (size_t)kMaxLanes * n));
+    if (!ds->rw_lanes) SLM_TRY(dalloc(&ds->rw_lanes, (size_t)ds->lane_cap * n));
     for (int l = 0; l < B; ++l) {
       double* dst = ds->rw_lanes + (size_t)l * n;
       if (lanes[l].row_weight) {
@@ -925,11 +931,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
 
   const bool small = small_ok(ds, o.flags);
   // ---- covariance passes: every row set of the call has its Gram (slm_dataset_covariance) --------------------------
-  int cov_entry[SLM_MAX_LANES] = {};
+  int cov_entry[SLM_MAX_CELLS] = {};
   bool cov_on = false;
   if (want_cov && split && !small) {
-    const double* wdev[SLM_MAX_LANES];
-    int uniq_of[SLM_MAX_LANES], first_lane[SLM_MAX_LANES], nu = 0;
+    const double* wdev[SLM_MAX_CELLS];
+    int uniq_of[SLM_MAX_CELLS], first_lane[SLM_MAX_CELLS], nu = 0;
     for (int l = 0; l < B; ++l) {
       int u = -1;
       for (int m = 0; m < l && u < 0; ++m)
@@ -957,11 +963,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
   }
   // ---- Lipschitz constants -----------------------------------------------------------------------
-  double L[SLM_MAX_LANES];
+  double L[SLM_MAX_CELLS];
   double lipschitz_ms = 0.0;
   bool L_on_device = false;  // the estimate stays on the device (no host round trip before the first pass)
-  double L_factor[SLM_MAX_LANES];  // ... and lane l uses L_factor[l] times it
-  for (int l = 0; l < kMaxLanes; ++l) L_factor[l] = 1.0;
+  double L_factor[SLM_MAX_CELLS];  // ... and lane l uses L_factor[l] times it
+  for (int l = 0; l < kMaxCells; ++l) L_factor[l] = 1.0;
   if (o.L > 0.0 || small) {  // (the on-chip solver bounds its own steps from the Gram matrix)
     for (int l = 0; l < B; ++l) L[l] = o.L > 0.0 ? o.L : 1.0;
   } else {
@@ -1055,11 +1061,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   su.infos = reinterpret_cast<unsigned char*>(d_infos);
   su.infos_bytes = (int64_t)(sizeof(slm_point_info) * total_points);
   static_assert(sizeof(slm_point_info) % 8 == 0, "infos are zeroed in 8-byte words");
-  su.ld = ld; su.p = p; su.G = G; su.n_lanes = B; su.max_lanes = kMaxLanes;
+  su.ld = ld; su.p = p; su.G = G; su.n_lanes = B; su.max_lanes = ds->lane_cap;
   if (!ds->h_vec) {
-    hipError_t eh = hipHostMalloc((void**)&ds->h_vec, sizeof(double) * 4 * (size_t)kMaxLanes * (size_t)ld, hipHostMallocDefault);
+    hipError_t eh = hipHostMalloc((void**)&ds->h_vec, sizeof(double) * 4 * (size_t)ds->lane_cap * (size_t)ld, hipHostMallocDefault);
     if (eh != hipSuccess) return fail(SLM_ERR_OOM, "hipHostMalloc: %s", hipGetErrorString(eh));
-    memset(ds->h_vec, 0, sizeof(double) * 4 * (size_t)kMaxLanes * (size_t)ld);
+    memset(ds->h_vec, 0, sizeof(double) * 4 * (size_t)ds->lane_cap * (size_t)ld);
   }
   if (total_points > ds->h_pts_cap) {
     if (ds->h_pts) (void)hipHostFree(ds->h_pts);
@@ -1069,7 +1075,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (eh != hipSuccess) return fail(SLM_ERR_OOM, "hipHostMalloc: %s", hipGetErrorString(eh));
     ds->h_pts_cap = total_points;
   }
-  int up_lo[4] = {kMaxLanes, kMaxLanes, kMaxLanes, kMaxLanes}, up_hi[4] = {-1, -1, -1, -1};  // lanes that bring a, b, d, beta0
+  const size_t cap = (size_t)ds->lane_cap;
+  int up_lo[4] = {ds->lane_cap, ds->lane_cap, ds->lane_cap, ds->lane_cap}, up_hi[4] = {-1, -1, -1, -1};  // lanes that bring a, b, d, beta0
   int64_t off = 0;
   bool same_pen = B > 1;
   for (int l = 1; l < B; ++l) same_pen = same_pen && lanes[l].pen == lanes[0].pen;
@@ -1090,7 +1097,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         for (int64_t i = 0; i < cnt[v]; ++i)
           if (!(src[v][i] >= 0.0) || !std::isfinite(src[v][i]))
             return fail(SLM_ERR_BAD_ARG, "penalty weights must be finite and >= 0 (index %lld)", (long long)i);
-        memcpy(ds->h_vec + ((size_t)v * kMaxLanes + l) * ld, src[v], sizeof(double) * cnt[v]);
+        memcpy(ds->h_vec + ((size_t)v * cap + l) * ld, src[v], sizeof(double) * cnt[v]);
         up_lo[v] = std::min(up_lo[v], l);
         up_hi[v] = std::max(up_hi[v], l);
       }
@@ -1099,7 +1106,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (ln.beta0) {
       for (int64_t j = 0; j < p; ++j)
         if (!std::isfinite(ln.beta0[j])) return fail(SLM_ERR_BAD_ARG, "beta0[%lld] is not finite", (long long)j);
-      memcpy(ds->h_vec + ((size_t)3 * kMaxLanes + l) * ld, ln.beta0, sizeof(double) * p);
+      memcpy(ds->h_vec + ((size_t)3 * cap + l) * ld, ln.beta0, sizeof(double) * p);
       up_lo[3] = std::min(up_lo[3], l);
       up_hi[3] = std::max(up_hi[3], l);
       su.beta_mode[l] = 1;
@@ -1142,7 +1149,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     double* dev[4] = {ds->a0, ds->b0, ds->d0, ds->beta};
     for (int v = 0; v < 4; ++v)
       if (up_hi[v] >= 0)
-        HIP_TRY(hipMemcpyAsync(dev[v] + (size_t)up_lo[v] * ld, ds->h_vec + ((size_t)v * kMaxLanes + up_lo[v]) * ld,
+        HIP_TRY(hipMemcpyAsync(dev[v] + (size_t)up_lo[v] * ld, ds->h_vec + ((size_t)v * cap + up_lo[v]) * ld,
                                sizeof(double) * (size_t)(up_hi[v] - up_lo[v] + 1) * ld, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ds->pts, ds->h_pts, sizeof(slm_path_point) * (size_t)total_points, hipMemcpyHostToDevice, s));
   }
@@ -1225,7 +1232,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     memset(&sm, 0, sizeof(sm));
     sm.t = ta;
     sm.X = ds->X; sm.y = ds->y; sm.rw = ls.rw; sm.rw_stride = ls.rw_stride; sm.n = n;
-    for (int l = 0; l < kMaxLanes; ++l) sm.inv_n[l] = 1.0 / (ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global);
+    for (int l = 0; l < kMaxCells; ++l) sm.inv_n[l] = 1.0 / (ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global);
     sm.max_iters = (int)std::min<int64_t>((int64_t)o.max_iter, 1500);  // (products per point; then the general path takes over)
     sm.cold = (o.flags & SLM_FLAG_COLD_START) ? 1 : 0;
     // LDS: the Gram matrix, three vectors, and the rest as the stage of the rows while the matrix is built

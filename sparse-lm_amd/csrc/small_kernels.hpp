@@ -52,7 +52,7 @@ struct SmallArgs {
   const double* rw;    // row weights (nullptr: ones); lane l reads rw + l * rw_stride
   int64_t rw_stride;
   int64_t n;
-  double inv_n[SLM_MAX_LANES];
+  double inv_n[SLM_MAX_CELLS];
   int max_iters;       // matrix-vector products per path point before the point is given up
   int cold;            // SLM_FLAG_COLD_START: every point starts from zero
   int stage_doubles;   // LDS left beside the Gram matrix and the vectors: the stage of the rows while G is built
@@ -991,7 +991,7 @@ static __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArg
       // would carry a coordinate across zero stops there; the coordinate leaves A and the iteration starts over on the
       // smaller face.  Off A every vector is zero, so the products with the full G are products with G_AA.
       const int face_now = __popcll(np0 | nn0) + __popcll(np1 | nn1);
-      const bool face_fits = face_now <= face_cap && face_now < (int)n;  // (more unknowns than rows: a singular face)
+      const bool face_fits = face_now <= face_cap && face_now <= (int)n;  // (more unknowns than rows: a singular face)
       bool want_direct = false;
       if (lasso_type && !conv && still >= SM_STILL && cg_runs < (face_fits ? 12 : 6) && face_now != 0) {
         ++cg_runs;

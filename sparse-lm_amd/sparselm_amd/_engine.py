@@ -167,6 +167,7 @@ class _Lane(C.Structure):
 
 
 MAX_LANES = 16
+MAX_CELLS = 64  # SLM_MAX_CELLS: lanes of a call the on-chip solver takes (Dataset.max_lanes tells which limit applies)
 
 # numpy views of the two per-point structs (no per-point Python objects on the way in or out)
 _INFO_DTYPE = np.dtype(
@@ -729,8 +730,8 @@ class Dataset:
         the points).  Returns one ``PathResult`` per lane (shared timing fields).
         """
         nl = len(lanes)
-        if not (1 <= nl <= MAX_LANES):
-            raise ValueError(f"between 1 and {MAX_LANES} lanes, got {nl}")
+        if not (1 <= nl <= MAX_CELLS):
+            raise ValueError(f"between 1 and {MAX_CELLS} lanes, got {nl}")
         G = self.n_groups
         b = load_binding()
         if b is not None:  # the compiled binding marshals the lanes itself

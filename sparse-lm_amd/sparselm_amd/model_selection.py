@@ -151,8 +151,9 @@ class GridSearchCV(_GridSearchCV):
         opt_selection_method (str): "max_score" (default) or "one_std_score".
         scoring: default "neg_root_mean_squared_error" (reference :166).
         n_jobs, refit, cv, verbose, pre_dispatch, error_score, return_train_score: as scikit-learn.
-        lanes (int): (fold, grid-row) units solved per pass over X on the fast path (1..16, default
-            16; the engine falls back to fewer where no kernel variant serves that many).
+        lanes (int | None): (fold, grid-row) units solved per call on the fast path.  None (default): as many as the dataset
+            takes -- sixteen per pass over a large X, up to 64 cells per launch where the on-chip solver applies (the
+            reference's README search: its 50 (candidate, fold) cells in ONE call per re-weighting round); an int caps it.
         streams (int): engines (HIP streams) of the device the batches of the fast path are dealt to (default 1).
             Every further stream works on a device-to-device copy of the dataset, from its own host thread: the
             launches between the passes of one batch run beside the passes over X of another (the counterpart of
@@ -177,7 +178,7 @@ class GridSearchCV(_GridSearchCV):
         pre_dispatch="2*n_jobs",
         error_score=np.nan,
         return_train_score=False,
-        lanes=16,
+        lanes=None,
         streams=1,
     ):
         super().__init__(
@@ -437,7 +438,7 @@ class _DeviceGrid:
             ds.set_replicated(True)
         if self.gidx is not None:
             self._set_groups(ds)
-        self.lanes = max(1, min(int(self.search.lanes), _engine.MAX_LANES, ds.max_lanes(self.opts.get("flags", 0))))
+        self.lanes = self._lanes_for(ds)
         self._plan_world = None
         return ds
 
@@ -460,9 +461,13 @@ class _DeviceGrid:
             self._set_groups(ds)
         else:
             ds.set_groups(None)
-        self.lanes = max(1, min(int(self.search.lanes), _engine.MAX_LANES, ds.max_lanes(self.opts.get("flags", 0))))
+        self.lanes = self._lanes_for(ds)
         self._plan_world = None
         return ds
+
+    def _lanes_for(self, ds):
+        cap = ds.max_lanes(self.opts.get("flags", 0))
+        return cap if self.search.lanes is None else max(1, min(int(self.search.lanes), cap))
 
     def _set_groups(self, ds):
         ds.set_groups(np.append(self.gidx, self.G) if self.intercept else self.gidx, self.G + 1 if self.intercept else self.G)
@@ -591,6 +596,26 @@ class _DeviceGrid:
         unconverged = self.search._run_batches(ds, calls, lambda d, call: run(d, call, local), self)
         return local, unconverged
 
+    def _holdout_sse(self, ds, betas, f):
+        """Squared hold-out error of the coefficient vectors `betas` (rows; with the intercept's coefficient last when the
+        device copy carries the column of ones) on fold f's test rows.  On the device for matrices of any size
+        (`slm_eval_sse_sparse` / `slm_eval_sse` with the test mask) -- except the reference's own sizes, where a device call
+        (0.09 ms) costs more than the product on the host: there `X[test] @ betas.T` in numpy."""
+        n, p = self.X.shape
+        if n * (p + 16) > 131072:
+            return ds.eval_sse(betas, self.test_masks[f])
+        cache = self.__dict__.setdefault("_test_rows", {})
+        if f not in cache:
+            test = self.splits[f][1]
+            cache[f] = (np.ascontiguousarray(self.X[test]), self.y[test])
+        Xt, yt = cache[f]
+        B = np.atleast_2d(betas)
+        pred = Xt @ B[:, :p].T
+        if self.intercept:
+            pred = pred + B[:, p][None, :]
+        r = pred - yt[:, None]
+        return np.einsum("ij,ij->j", r, r)
+
     def _run_call(self, ds, call, local):
         """One call of the engine for the lanes of `call` on dataset `ds` (this stream's copy); scores go into `local`."""
         search, cands = self.search, self.candidates
@@ -628,7 +653,7 @@ class _DeviceGrid:
                 by_fold[self.units[u][1]].append((u, idx, res.betas[at : at + len(idx)]))
                 at += len(idx)
         for f, parts in by_fold.items():
-            sse = ds.eval_sse(np.vstack([b for _, _, b in parts]), self.test_masks[f])
+            sse = self._holdout_sse(ds, np.vstack([b for _, _, b in parts]), f)
             sc = search._score_from_sse(sse, self.y[self.splits[f][1]])
             at = 0
             for u, idx, _ in parts:
@@ -666,7 +691,7 @@ class _DeviceGrid:
         for k, (_, f) in enumerate(batch):
             by_fold[f].append(k)
         for f, ks in by_fold.items():
-            sse = ds.eval_sse(np.vstack([fits[k]["beta"] for k in ks]), self.test_masks[f])
+            sse = self._holdout_sse(ds, np.vstack([fits[k]["beta"] for k in ks]), f)
             sc = search._score_from_sse(sse, self.y[self.splits[f][1]])
             for k, one in zip(ks, np.atleast_1d(sc)):
                 local[(us[k], 0)] = (self.combos[batch[k][0]], f, np.array([one]), dt)

@@ -63,7 +63,7 @@ def test_paths_folds_and_warm_starts_in_one_launch(eng):
     fold = rng.integers(0, 16, n)
     specs = [dict(points=pts, row_weight=(fold != f).astype(float), n_eff=int(np.sum(fold != f))) for f in range(16)]
     with eng.dataset(X, y) as ds:
-        assert ds.max_lanes(_engine.FLAG_ON_CHIP) == 16 and ds.max_lanes() < 16
+        assert ds.max_lanes(_engine.FLAG_ON_CHIP) == _engine.MAX_CELLS == 64 and ds.max_lanes() < 16
         chip = ds.solve_lanes(specs, tol=1e-11, flags=_engine.FLAG_ON_CHIP)
         for spec, r in zip(specs, chip):
             ref = ds.solve_lanes([spec], tol=1e-11)[0]
@@ -107,6 +107,42 @@ def test_what_does_not_fit_or_does_not_settle_takes_the_general_path(eng):
         bad[3, 2] = np.inf
         with eng.dataset(bad, y) as ds:
             ds.solve_path([(0.1, 0.0, 0.0)], flags=_engine.FLAG_ON_CHIP)
+
+
+def test_fifty_cells_in_one_launch(eng):
+    """More lanes than sixteen on the on-chip route (SLM_MAX_CELLS: the (candidate, fold) cells of a small grid search -- the
+    reference's README example has fifty): ONE launch, a workgroup per cell; the same coefficients as sixteen at a time; a
+    call the general path has to take (flags that ask for its iteration) still stops at sixteen lanes."""
+    rng = np.random.default_rng(2)
+    n, p = 100, 80
+    X = rng.standard_normal((n, p))
+    y = X[:, :8] @ rng.uniform(1, 3, 8) + 0.3 * rng.standard_normal(n)
+    amax = np.max(np.abs(X.T @ y)) / n
+    fold = rng.integers(0, 5, n)
+    specs = []
+    for c in range(10):
+        for f in range(5):
+            w = (fold != f).astype(float)
+            specs.append(dict(points=[(amax * 0.6 ** c, 0.0, 0.0)], a=rng.uniform(0.5, 1.5, p), row_weight=w, n_eff=int(w.sum()),
+                              beta0=(0.01 * rng.standard_normal(p) if c % 3 == 0 else None)))
+    with eng.dataset(X, y) as ds:
+        one = ds.solve_lanes(specs, tol=1e-11, flags=_engine.FLAG_ON_CHIP)
+        assert len(one) == 50 and all(r.converged and r.mode[0] == 2 for r in one) and one[0].grad_launches == 1
+        for k0 in range(0, 50, 16):
+            part = ds.solve_lanes(specs[k0 : k0 + 16], tol=1e-11, flags=_engine.FLAG_ON_CHIP)
+            for a, b in zip(one[k0 : k0 + 16], part):
+                assert np.array_equal(a.betas, b.betas)
+        ref = ds.solve_lanes(specs[:3], tol=1e-11)
+        for a, b in zip(one[:3], ref):
+            np.testing.assert_allclose(a.betas, b.betas, rtol=0, atol=1e-8 * np.max(np.abs(b.betas)))
+        with pytest.raises(ValueError):
+            ds.solve_lanes(specs[:17], tol=1e-11, flags=_engine.FLAG_ON_CHIP | _engine.FLAG_FISTA_ONLY)
+        with pytest.raises(ValueError):
+            ds.solve_lanes(specs + specs[:15], tol=1e-11, flags=_engine.FLAG_ON_CHIP)
+    # a dataset the on-chip solver does not take keeps the sixteen
+    Xb = rng.standard_normal((300, 130))
+    with eng.dataset(Xb, Xb[:, 0]) as big:
+        assert big.max_lanes(_engine.FLAG_ON_CHIP) <= 16
 
 
 def test_randomised_cross_check_against_the_general_path():

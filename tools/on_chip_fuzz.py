@@ -44,7 +44,7 @@ for case in range(n_cases):
         specs = [dict(points=pts, a=a, b=b, beta0=warm, row_weight=(fold != f).astype(float), n_eff=int(np.sum(fold != f))) for f in range(nl)]
         if rng.random() < 0.3:
             specs = [dict(points=pts, a=a, b=b, beta0=warm)]
-        assert ds.max_lanes(_engine.FLAG_ON_CHIP) == 16
+        assert ds.max_lanes(_engine.FLAG_ON_CHIP) == _engine.MAX_CELLS
         t0 = time.perf_counter(); R1 = ds.solve_lanes(specs, tol=tol, max_iter=100000, flags=_engine.FLAG_ON_CHIP); t_chip += time.perf_counter() - t0
         t0 = time.perf_counter(); R0 = [ds.solve_lanes([s], tol=tol, max_iter=300000)[0] for s in specs]; t_gen += time.perf_counter() - t0
     on_chip = all(np.all(r.mode == 2) for r in R1)
