@@ -75,8 +75,14 @@ static __global__ __launch_bounds__(256) void broadcast_lanes_kernel(double* v, 
 // fills, copies and broadcasts, each a dependent 4-8 us step on the stream: 0.15 ms per solve).  Per lane l and
 // vector (a, b, d): mode 0 = the host uploaded it (leave it), 1 = fill with 1.0, 2 = copy lane 0's.
 // beta_mode: 0 = zero, 1 = the host uploaded a warm start.  z <- beta, zprev = gprev = 0.
+// carry != 0 (a "carried start", solve_core): every lane starts where the dataset's last solve left it -- the point
+// zprev, whose gradient gprev and loss the tail kernels kept -- and g receives that gradient: the first step of the
+// solve needs no pass over the data.
 struct SetupArgs {
   double *beta, *z, *zprev, *gprev, *a0, *b0, *d0;
+  double* g;              // [n_lanes][ld + 16], written when carry != 0
+  int carry;
+  double carry_loss[SLM_MAX_LANES];
   unsigned char* infos;   // zeroed: infos_bytes bytes (multiple of 8)
   int64_t infos_bytes;
   int64_t ld, p, G;
@@ -92,6 +98,11 @@ static __global__ __launch_bounds__(256) void solve_setup_kernel(SetupArgs s) {
     const int64_t j = e - (int64_t)l * s.ld;
     double bv = 0.0;
     if (l < s.n_lanes && s.beta_mode[l] == 1 && j < s.p) bv = s.beta[e];
+    if (s.carry && l < s.n_lanes) {
+      bv = j < s.p ? s.zprev[e] : 0.0;
+      s.g[(int64_t)l * (s.ld + 16) + j] = j < s.p ? s.gprev[e] : 0.0;
+      if (j == 0) s.g[(int64_t)l * (s.ld + 16) + s.ld] = s.carry_loss[l];
+    }
     s.beta[e] = bv;
     s.z[e] = bv;
     s.zprev[e] = 0.0;

@@ -480,6 +480,7 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
 
 static int upload_row_weights(slm_dataset* ds, const double* rw_host) {
   ds->L_valid = false;
+  ds->carry_valid = false;
   if (!rw_host) {
     dfree(ds->rw);
     ds->rw_max = 1.0;
@@ -669,6 +670,7 @@ extern "C" int slm_dataset_set_targets(slm_dataset* ds, const double* y) {
   HIP_TRY(hipSetDevice(ds->eng->device));
   HIP_TRY(hipStreamSynchronize(ds->eng->stream));
   HIP_TRY(hipMemcpy(ds->y, y, sizeof(double) * ds->n, hipMemcpyHostToDevice));
+  ds->carry_valid = false;
   // (the Grams of covariance passes carry X^T W y: gone with the old targets; the Gram of all rows depends on X alone)
   cov_pending_drop(ds);
   ds->cov.clear();
@@ -680,6 +682,7 @@ extern "C" int slm_dataset_set_global_rows(slm_dataset* ds, int64_t n_global) {
   if (n_global < 1) return fail(SLM_ERR_BAD_ARG, "n_global must be positive (got %lld)", (long long)n_global);
   ds->n_global = n_global;
   ds->L_valid = false;
+  ds->carry_valid = false;
   return SLM_OK;
 }
 

@@ -264,6 +264,18 @@ struct slm_dataset {
   double L = 0.0;
   int L_iters = 0;
   bool L_valid = false;
+  // Carried start (solve_core): what the last solve left on the device -- per lane the point zprev, its gradient gprev
+  // and its loss -- described on the host so that the next solve can tell whether it starts exactly there.
+  struct CarryLane {
+    int64_t n_eff = 0;
+    bool has_rw = false;
+    double fp[2] = {0.0, 0.0};  // checksums of the lane's row weights (has_rw)
+    double loss = 0.0;
+  };
+  bool carry_valid = false;
+  int carry_lanes = 0;
+  CarryLane carry_lane[SLM_MAX_LANES];
+  std::vector<double> carry_out;  // [carry_lanes][p]: the solutions the last solve reported
 };
 
 static inline bool row_sharded(const slm_dataset* ds) { return ds->eng->sharded() && !ds->replicated; }

@@ -499,6 +499,7 @@ extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y
   HIP_TRY(hipStreamSynchronize(s));
   if (y_mean_out) *y_mean_out = ymean;
   ds->L_valid = false;
+  ds->carry_valid = false;
   ds->XT_ready = false;  // X changed in place: the column-major copy is rebuilt on next use
   return SLM_OK;
 }
@@ -889,6 +890,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   LaneSetup ls = default_lanes(ds, B);
   double wmax[SLM_MAX_CELLS];  // largest row weight of each lane (< 0: unknown)
   for (int l = 0; l < kMaxCells; ++l) wmax[l] = ds->rw ? ds->rw_max : 1.0;
+  double rw_fp[SLM_MAX_CELLS][2] = {};  // two checksums of each lane's row weights (carried starts, below)
   if (any_rw) {
     if (!ds->rw_lanes) SLM_TRY(dalloc(&ds->rw_lanes, (size_t)ds->lane_cap * n));
     for (int l = 0; l < B; ++l) {
@@ -901,16 +903,22 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
           if (lanes[m].row_weight == w) same = m;
         if (same >= 0) {
           wmax[l] = wmax[same];
+          rw_fp[l][0] = rw_fp[same][0];
+          rw_fp[l][1] = rw_fp[same][1];
           HIP_TRY(hipMemcpyAsync(dst, ds->rw_lanes + (size_t)same * n, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
           continue;
         }
-        double top = 0.0;
+        double top = 0.0, f0 = 0.0, f1 = 0.0;
         for (int64_t i = 0; i < n; ++i) {
           if (!(w[i] >= 0.0) || !std::isfinite(w[i]))
             return fail(SLM_ERR_BAD_ARG, "lane %d: row_weight[%lld] is negative or not finite", l, (long long)i);
           top = std::max(top, w[i]);
+          f0 += w[i];
+          f1 += w[i] * (double)(((uint32_t)i * 2654435761u) >> 8);  // (position-dependent; no chain beside the sums')
         }
         wmax[l] = top;
+        rw_fp[l][0] = f0;
+        rw_fp[l][1] = f1;
         HIP_TRY(hipMemcpyAsync(dst, w, sizeof(double) * n, hipMemcpyHostToDevice, s));
       } else if (ds->rw) {
         HIP_TRY(hipMemcpyAsync(dst, ds->rw, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
@@ -1049,11 +1057,36 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     SLM_TRY(dalloc(&ds->gn_out, (size_t)total_points * G));
     ds->cap_gn = total_points * G;
   }
+  // ---- carried start ---------------------------------------------------------------------------------------------
+  // A solve that starts where the dataset's last solve ended -- every lane's warm start IS the solution that solve
+  // reported for the lane, over the same rows with the same weights -- already has what its first step needs on the
+  // device: the tail kernels keep the last point whose gradient they saw (zprev), that gradient (gprev) and its loss.
+  // The penalty may differ (the gradient is that of the smooth part): the rounds of an Adaptive* estimator
+  // (reference: model/_adaptive_lasso.py:142-178 re-solves the same problem with new weights), the refit of a search,
+  // repeated fits with warm_start.  The solve then starts at zprev -- the point the reported solution is one proximal
+  // step of converged length away from -- and its first pass over the data is not run: 9 -> 7 passes for BASELINE
+  // config 5.  Decided on the host from the caller's arrays alone, so the ranks of a row-sharded solve agree.
+  bool carry = false;
+  if (ds->carry_valid && !small && !shared_path && B <= ds->carry_lanes && !(o.flags & SLM_FLAG_COLD_START) &&
+      getenv("SLM_NO_CARRY") == nullptr) {
+    carry = true;
+    for (int l = 0; l < B && carry; ++l) {
+      const slm_dataset::CarryLane& c = ds->carry_lane[l];
+      carry = lanes[l].beta0 != nullptr && lanes[l].n_eff == c.n_eff && (lanes[l].row_weight != nullptr) == c.has_rw &&
+              (!c.has_rw || (rw_fp[l][0] == c.fp[0] && rw_fp[l][1] == c.fp[1])) &&
+              memcmp(lanes[l].beta0, ds->carry_out.data() + (size_t)l * p, sizeof(double) * (size_t)p) == 0;
+    }
+  }
+  ds->carry_valid = false;  // (this solve rewrites the state; it describes its own end below)
   PathCtl* h = ds->h_stage;  // (lives as long as the dataset: the upload below is asynchronous)
   memset(h, 0, sizeof(ds->h_stage));
   SetupArgs su;
   memset(&su, 0, sizeof(su));
   su.beta = ds->beta; su.z = ds->z; su.zprev = ds->zprev; su.gprev = ds->gprev;
+  su.g = ds->g;
+  su.carry = carry ? 1 : 0;
+  if (carry)
+    for (int l = 0; l < B; ++l) su.carry_loss[l] = ds->carry_lane[l].loss;
   su.a0 = ds->a0; su.b0 = ds->b0; su.d0 = ds->d0;
   // (small solves keep their per-point records inside the control block: one blocking copy less at the end)
   const bool infos_in_snap = total_points <= kSnapInfos;
@@ -1106,9 +1139,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (ln.beta0) {
       for (int64_t j = 0; j < p; ++j)
         if (!std::isfinite(ln.beta0[j])) return fail(SLM_ERR_BAD_ARG, "beta0[%lld] is not finite", (long long)j);
-      memcpy(ds->h_vec + ((size_t)3 * cap + l) * ld, ln.beta0, sizeof(double) * p);
-      up_lo[3] = std::min(up_lo[3], l);
-      up_hi[3] = std::max(up_hi[3], l);
+      if (!carry) {  // (a carried start takes the point from the device)
+        memcpy(ds->h_vec + ((size_t)3 * cap + l) * ld, ln.beta0, sizeof(double) * p);
+        up_lo[3] = std::min(up_lo[3], l);
+        up_hi[3] = std::max(up_hi[3], l);
+      }
       su.beta_mode[l] = 1;
     }
     h[l].n_points = ln.n_points;
@@ -1530,7 +1565,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
           e0 = ds->prof[2 * slot_id];
           e1 = ds->prof[2 * slot_id + 1];
         }
-        SLM_TRY(enqueue_pass_gradient(e0, e1));
+        if (!(carry && enq == 0)) SLM_TRY(enqueue_pass_gradient(e0, e1));  // (a carried start has its first gradient)
         enqueue_tail();
         ++enq;
         // behind the pass the solve is expected to end with, the six launches of the refinement would only find
@@ -1622,7 +1657,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     nonfinite = nonfinite || fin[l].nonfinite;
   }
   if (stats) {
-    stats->grad_launches = passes;  // launches that did work (every launch serves all lanes)
+    stats->grad_launches = passes - (carry ? 1 : 0);  // launches that did work (every launch serves all lanes)
     stats->grad_ms_total = 0.0;
     stats->grad_timed = 0;
     if (profile) {
@@ -1696,6 +1731,20 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (tr[4] > 15.0 || trc[0] == '2')
       fprintf(stderr, "[slm] solve: row weights %.3f L %.3f setup %.3f sync %.3f prequeue %.3f loop %.3f end %.3f ms\n", tr_rw, tr[5], tr[0], tr[1], tr[2], tr[3], tr[4]);
   if (nonfinite) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
+  if (!shared_path && !(o.flags & SLM_FLAG_COLD_START) && B <= kMaxLanes) {  // where the solve ended (carried starts, above)
+    ds->carry_out.resize((size_t)B * (size_t)p);
+    for (int l = 0; l < B; ++l) {
+      memcpy(ds->carry_out.data() + (size_t)l * p, lanes[l].betas_out + (size_t)(lanes[l].n_points - 1) * p, sizeof(double) * (size_t)p);
+      slm_dataset::CarryLane& c = ds->carry_lane[l];
+      c.n_eff = lanes[l].n_eff;
+      c.has_rw = lanes[l].row_weight != nullptr;
+      c.fp[0] = rw_fp[l][0];
+      c.fp[1] = rw_fp[l][1];
+      c.loss = fin[l].loss_base;
+    }
+    ds->carry_lanes = B;
+    ds->carry_valid = true;
+  }
   return SLM_OK;
 }
 

@@ -65,6 +65,8 @@ struct PathCtl {
   int32_t tail_pt;     // interleaved lanes: one more point after the lane's regular walk, or -1 (the points beyond
                        // the last full band of a shared path go to the lanes that have just solved their neighbours)
   int32_t pad2_;
+  double loss_base;    // smooth loss at zprev, the point whose gradient gprev holds: with them a later solve that starts
+                       // where this one ended needs no pass over the data for its first step (solve_core, "carried start")
 };
 
 constexpr int BB_HIST = 5;
@@ -374,6 +376,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
   double kkt = 0.0, mu_eff = 0.0, new_mu_rq = mu_rq_old;
   // control-block updates
   int new_mode = mode, new_have_base = have_base, new_rejects = rejects, new_n_hist = n_hist;
+  double new_loss_base = ctl->loss_base;
   double new_t = t_old, new_L = L, new_ak = ak_old, new_Lhat = Lhat_old, new_pen_z = pen_z;
   bool did_restart = false, l_bad = false;
 
@@ -457,6 +460,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
         hist[BB_HIST - 1] = Fz;
       }
       new_have_base = 1;
+      new_loss_base = loss_z;
     }
     // base point and its gradient after the decision; (zprev, gprev) = (base, its gradient) stays a
     // consistent pair for the FISTA curvature guard should this lane fall back
@@ -537,6 +541,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     //  s[7] = ||g||^2   s[8] = <g - gprev, z - zprev>
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const double step = 1.0 / L;
+    new_loss_base = loss_z;  // (zprev = z below)
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int j = tid + e * TAIL_THREADS;
@@ -660,6 +665,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     ctl->rejects = new_rejects;
     ctl->ak = new_ak;
     ctl->Lhat = new_Lhat;
+    ctl->loss_base = new_loss_base;
     if (l_bad) ctl->l_bumps += 1;
     if (did_restart) ctl->restarts += 1;
     if (finalize) {
@@ -830,6 +836,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
   double resid = 0.0, bnorm = 0.0;
   double kkt = 0.0, mu_eff = 0.0, new_mu_rq = mu_rq_old;
   int new_mode = mode, new_have_base = have_base, new_rejects = rejects, new_n_hist = n_hist;
+  double new_loss_base = ctl->loss_base;
   double new_t = t_old, new_L = L, new_ak = ak_old, new_Lhat = Lhat_old, new_pen_z = pen_z;
   bool did_restart = false, l_bad = false;
   // how the last phase finds the new base point and the next point of feature j:
@@ -907,6 +914,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
         hist[BB_HIST - 1] = Fz;
       }
       new_have_base = 1;
+      new_loss_base = loss_z;
     }
     const double step = 1.0 / new_ak;
     const bool fallback = !nonfinite && (new_rejects >= BB_REJECT_LIMIT || iter + 1 > BB_POINT_LIMIT);
@@ -975,6 +983,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
     // ================= FISTA scheme =================================================================
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const double step = 1.0 / L;
+    new_loss_base = loss_z;  // (zprev = z below)
     tail_for<E>(tid, p, [&](int j, bool ok) {
       const double z = a.z[j], g = a.g[j];
       const double dg = g - a.gprev[j], dzz = z - a.zprev[j];
@@ -1078,6 +1087,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
     ctl->rejects = new_rejects;
     ctl->ak = new_ak;
     ctl->Lhat = new_Lhat;
+    ctl->loss_base = new_loss_base;
     if (l_bad) ctl->l_bumps += 1;
     if (did_restart) ctl->restarts += 1;
     if (finalize) {

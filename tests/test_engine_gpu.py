@@ -723,3 +723,90 @@ print(json.dumps(out))
     assert got["binding"]["binding"] is True and got["ctypes"]["binding"] is False
     assert got["binding"]["converged"] and got["ctypes"]["converged"]
     assert got["binding"]["digest"] == got["ctypes"]["digest"] and got["binding"]["passes"] == got["ctypes"]["passes"]
+
+
+# ---- carried starts (solve_core): a solve that starts where the last one ended skips its first pass over the data -----
+def _reweighted_sequence(ds, a1, a2, alpha, tweak=None, **kw):
+    """Two solves the way an Adaptive* estimator issues them: the second starts at the first's solution with new
+    penalty weights.  `tweak(beta0, ds)` may disturb the hand-over.  Returns (second result, passes of the second)."""
+    first = ds.solve_lanes([dict(points=[(alpha, 0, 0)], a=a1, **kw)], tol=1e-10, max_iter=100000)[0]
+    beta0 = first.betas[-1].copy()
+    if tweak is not None:
+        beta0 = tweak(beta0, ds)
+    second = ds.solve_lanes([dict(points=[(alpha, 0, 0)], a=a2, beta0=beta0, **kw)], tol=1e-10, max_iter=100000)[0]
+    assert first.converged and second.converged
+    return second, second.grad_launches
+
+
+def test_carried_start_skips_the_first_pass_and_gives_the_same_solution(eng, monkeypatch):
+    rng = np.random.default_rng(77)
+    n, p = 3000, 700
+    X = rng.standard_normal((n, p))
+    coef = np.where(rng.random(p) < 0.05, rng.standard_normal(p) * 3, 0.0)
+    y = X @ coef + 0.5 * rng.standard_normal(n)
+    alpha = 0.05 * np.max(np.abs(X.T @ y)) / n
+    a1 = np.ones(p)
+    a2 = 1.0 / (np.abs(rng.standard_normal(p)) + 0.3)
+    with eng.dataset(X, y) as ds:
+        carried, k_carried = _reweighted_sequence(ds, a1, a2, alpha)
+    monkeypatch.setenv("SLM_NO_CARRY", "1")
+    with eng.dataset(X, y) as ds:
+        plain, k_plain = _reweighted_sequence(ds, a1, a2, alpha)
+    monkeypatch.delenv("SLM_NO_CARRY")
+    assert k_carried == k_plain - 1, (k_carried, k_plain)
+    want, _ = oracle.fista(X, y, alpha * a2, 0.0, 0.0, np.arange(p), p, tol=1e-13)
+    assert rel_inf(carried.betas[-1], want) < 1e-7
+    assert rel_inf(plain.betas[-1], want) < 1e-7
+    assert rel_inf(carried.betas[-1], plain.betas[-1]) < 1e-7
+
+    # a warm start that is NOT the solver's own last solution, other rows, or other targets: the pass is run
+    def one_ulp(b, ds):
+        b[np.argmax(np.abs(b))] *= 1.0 + 2.3e-16
+        return b
+
+    def new_targets(b, ds):
+        ds.set_targets(y + 1e-3)
+        return b
+
+    for tweak, yy in ((one_ulp, y), (new_targets, y + 1e-3)):
+        with eng.dataset(X, y) as ds:
+            res, k = _reweighted_sequence(ds, a1, a2, alpha, tweak=tweak)
+        assert k == k_plain, (tweak.__name__, k, k_plain)
+        want, _ = oracle.fista(X, yy, alpha * a2, 0.0, 0.0, np.arange(p), p, tol=1e-13)
+        assert rel_inf(res.betas[-1], want) < 1e-7
+
+
+def test_carried_start_tells_row_weights_by_content(eng, monkeypatch):
+    rng = np.random.default_rng(78)
+    n, p = 2500, 600
+    X = rng.standard_normal((n, p))
+    y = X[:, :20] @ rng.standard_normal(20) + 0.3 * rng.standard_normal(n)
+    alpha = 0.05 * np.max(np.abs(X.T @ y)) / n
+    a1, a2 = np.ones(p), 1.0 / (np.abs(rng.standard_normal(p)) + 0.3)
+    masks = [(np.arange(n) % 5 != f).astype(float) for f in (0, 1)]
+    n_tr = int(masks[0].sum())
+
+    def run(second_mask_of):
+        mask = masks[0].copy()
+        with eng.dataset(X, y) as ds:
+            first = ds.solve_lanes([dict(points=[(alpha, 0, 0)], a=a1, row_weight=mask, n_eff=n_tr)], tol=1e-10)[0]
+            w2 = second_mask_of(mask)
+            return ds.solve_lanes([dict(points=[(alpha, 0, 0)], a=a2, row_weight=w2, n_eff=n_tr, beta0=first.betas[-1])], tol=1e-10)[0]
+
+    def same_content(mask):  # another array with the same rows: carried
+        return mask.copy()
+
+    def same_array_other_rows(mask):  # a loop over folds that reuses its buffer: NOT carried
+        mask[:] = masks[1]
+        return mask
+
+    got = {f.__name__: run(f) for f in (same_content, same_array_other_rows)}
+    monkeypatch.setenv("SLM_NO_CARRY", "1")
+    plain = {f.__name__: run(f) for f in (same_content, same_array_other_rows)}
+    monkeypatch.delenv("SLM_NO_CARRY")
+    assert got["same_content"].grad_launches == plain["same_content"].grad_launches - 1
+    assert got["same_array_other_rows"].grad_launches == plain["same_array_other_rows"].grad_launches
+    for name, f in (("same_content", 0), ("same_array_other_rows", 1)):
+        tr = masks[f] > 0
+        want, _ = oracle.fista(X[tr], y[tr], alpha * a2, 0.0, 0.0, np.arange(p), p, tol=1e-13)
+        assert rel_inf(got[name].betas[-1], want) < 1e-7, name
