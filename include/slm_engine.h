@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 12
+#define SLM_ABI_VERSION 13
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -311,6 +311,30 @@ typedef struct slm_lane {
 
 int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes,
                     const slm_solve_opts* opts, slm_solve_stats* stats);
+/*
+ * The re-weighting loop of the Adaptive* estimators inside ONE call (reference: AdaptiveLasso._solve,
+ * src/sparselm/model/_adaptive_lasso.py:206-232 -- solve, renew the penalty weights from the solution, :364-374 for the
+ * group norms, stop when the weights no longer move or after max_iter solves; the reference re-enters cvxpy once per
+ * round).  Lane l's points are its rounds (n_points = max_iter, normally all (1, 1, 1)): after round k the weights become
+ *     a_j <- coef_scale * (numerator / (|beta_j| + eps))            j < n_coef     (coef_scale != 0)
+ *     b_g <- group_scale[g] * (numerator / (||beta_g||_2 + eps))    g < n_group    (group_scale != NULL)
+ * -- the default update functions of the reference, operation for operation -- and the rounds end once the 2-norm of the
+ * change of the weights is <= tol.  betas_out / group_norms_out / infos hold one row per round; rounds that were not run
+ * have infos[k].n_iter == 0 and mode == 3, and rounds_out[l] says how many were.  Only for problems the on-chip solver
+ * takes (the reference-sized ones): SLM_ERR_UNSUPPORTED otherwise, or when a round was not settled on chip -- the
+ * caller then runs the loop itself over slm_solve_lanes, which is what it did before this call existed.
+ */
+typedef struct slm_reweight {
+  double coef_scale;
+  const double* group_scale;   /* length n_group, nullable */
+  double numerator;
+  double eps;
+  double tol;
+  int32_t n_coef;              /* leading coefficients that carry adaptive weights (an intercept column stays out) */
+  int32_t n_group;
+} slm_reweight;
+int slm_solve_lanes_reweighted(slm_dataset* ds, const slm_lane* lanes, const slm_reweight* rules, int32_t n_lanes,
+                               const slm_solve_opts* opts, slm_solve_stats* stats, int32_t* rounds_out);
 /* How many lanes one slm_solve_lanes call on this dataset can take with these solve flags (callers
  * size their batches of CV folds / grid rows with it instead of probing for SLM_ERR_UNSUPPORTED). */
 int slm_dataset_max_lanes(slm_dataset* ds, uint32_t flags, int32_t* max_lanes_out);

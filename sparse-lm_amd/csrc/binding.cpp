@@ -128,9 +128,13 @@ py::array info_bytes(int64_t count) {
 // slm_solve_lanes: `specs` is the list of lane dicts of Dataset.solve_lanes; `alloc(n)` hands out a float64 block of n
 // entries (the binding's page-locked result pool).  Returns (betas block, group-norm block or None, records as bytes,
 // points per lane, stats).
-py::tuple solve_lanes(uintptr_t ds, const py::list& specs, int64_t n, int64_t p, int64_t G, double tol, int max_iter, int check_every,
-                      double L, uint32_t flags, bool want_gn, bool extrapolate, const py::object& alloc) {
+// `reweighted`: every spec carries "reweight" = (coef_scale, group_scale or None, numerator, eps, tol, n_coef, n_group) and the
+// call is slm_solve_lanes_reweighted; the tuple then ends with the rounds run per lane.
+py::tuple solve_lanes_any(uintptr_t ds, const py::list& specs, int64_t n, int64_t p, int64_t G, double tol, int max_iter, int check_every,
+                          double L, uint32_t flags, bool want_gn, bool extrapolate, const py::object& alloc, bool reweighted) {
   const int nl = (int)specs.size();
+  std::vector<slm_reweight> rules(reweighted ? (size_t)nl : 0);
+  std::vector<int32_t> rounds(reweighted ? (size_t)nl : 0, 0);
   if (nl < 1 || nl > SLM_MAX_CELLS) throw py::value_error("between 1 and " + std::to_string(SLM_MAX_CELLS) + " lanes, got " + std::to_string(nl));
   Keep keep;
   std::vector<slm_lane> lanes((size_t)nl);
@@ -168,6 +172,20 @@ py::tuple solve_lanes(uintptr_t ds, const py::list& specs, int64_t n, int64_t p,
     ln.n_eff = ne.is_none() ? 0 : ne.cast<int64_t>();
     ks[(size_t)l] = K;
     total += K;
+    if (reweighted) {
+      const py::object rw = dict_get(spec, "reweight");
+      if (rw.is_none()) throw py::value_error("lane " + std::to_string(l) + ": no re-weighting rule");
+      const py::tuple t = rw.cast<py::tuple>();
+      if (t.size() != 7) throw py::value_error("reweight = (coef_scale, group_scale, numerator, eps, tol, n_coef, n_group)");
+      slm_reweight& r = rules[(size_t)l];
+      r.coef_scale = t[0].cast<double>();
+      r.n_coef = t[5].cast<int32_t>();
+      r.n_group = t[6].cast<int32_t>();
+      r.group_scale = vector_arg(t[1], r.n_group, "group_scale", keep);
+      r.numerator = t[2].cast<double>();
+      r.eps = t[3].cast<double>();
+      r.tol = t[4].cast<double>();
+    }
   }
   py::array betas = alloc(total * p).cast<py::array>();
   py::object gn_obj = py::none();
@@ -194,12 +212,26 @@ py::tuple solve_lanes(uintptr_t ds, const py::list& specs, int64_t n, int64_t p,
   int rc;
   {
     py::gil_scoped_release nogil;
-    rc = slm_solve_lanes(reinterpret_cast<slm_dataset*>(ds), lanes.data(), nl, &opts, &st);
+    rc = reweighted ? slm_solve_lanes_reweighted(reinterpret_cast<slm_dataset*>(ds), lanes.data(), rules.data(), nl, &opts, &st, rounds.data())
+                    : slm_solve_lanes(reinterpret_cast<slm_dataset*>(ds), lanes.data(), nl, &opts, &st);
   }
   check(rc);
   py::list kl;
   for (int64_t k : ks) kl.append(k);
-  return py::make_tuple(betas, gn_obj, infos, kl, stats_tuple(st));
+  if (!reweighted) return py::make_tuple(betas, gn_obj, infos, kl, stats_tuple(st));
+  py::list rl;
+  for (int32_t r : rounds) rl.append(r);
+  return py::make_tuple(betas, gn_obj, infos, kl, stats_tuple(st), rl);
+}
+
+py::tuple solve_lanes(uintptr_t ds, const py::list& specs, int64_t n, int64_t p, int64_t G, double tol, int max_iter, int check_every,
+                      double L, uint32_t flags, bool want_gn, bool extrapolate, const py::object& alloc) {
+  return solve_lanes_any(ds, specs, n, p, G, tol, max_iter, check_every, L, flags, want_gn, extrapolate, alloc, false);
+}
+
+py::tuple solve_lanes_reweighted(uintptr_t ds, const py::list& specs, int64_t n, int64_t p, int64_t G, double tol, int max_iter,
+                                 int check_every, double L, uint32_t flags, bool want_gn, const py::object& alloc) {
+  return solve_lanes_any(ds, specs, n, p, G, tol, max_iter, check_every, L, flags, want_gn, false, alloc, true);
 }
 
 // slm_solve_path_lanes: one path walked by `n_lanes` lanes.  Returns (betas, group norms or None, records as bytes, stats).
@@ -277,6 +309,7 @@ PYBIND11_MODULE(_slm_binding, m) {
   m.def("abi_version", []() { return slm_abi_version(); });
   m.def("info_record_bytes", []() { return (int)sizeof(slm_point_info); });
   m.def("solve_lanes", &solve_lanes);
+  m.def("solve_lanes_reweighted", &solve_lanes_reweighted);
   m.def("solve_path_lanes", &solve_path_lanes);
   m.def("dataset_create", &dataset_create);
   m.def("path_extrapolation", [](const arr_d& pts) {

@@ -783,7 +783,7 @@ static int max_lanes_for(slm_dataset* ds, uint32_t flags) {
 }
 
 static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, const slm_solve_opts* opts,
-                      slm_solve_stats* stats, bool shared_path);
+                      slm_solve_stats* stats, bool shared_path, const slm_reweight* rules = nullptr, int32_t* rounds_out = nullptr);
 
 // A call the on-chip solver was offered, on the general path: in as many calls as that path needs for the lane count
 // (sixteen workgroups take sixteen lanes whatever p; the fused kernels' table stops earlier).
@@ -809,8 +809,24 @@ static int solve_without_chip(slm_dataset* ds, const slm_lane* lanes, int32_t B,
 }
 
 static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, const slm_solve_opts* opts,
-                      slm_solve_stats* stats, bool shared_path) {
+                      slm_solve_stats* stats, bool shared_path, const slm_reweight* rules, int32_t* rounds_out) {
   if (!ds || !lanes) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  if (rules) {
+    // re-weighted rounds run inside the on-chip kernel, nowhere else: other problems keep their loop on the caller's side
+    if (!rounds_out) return fail(SLM_ERR_BAD_ARG, "rounds_out is NULL");
+    if (shared_path || !small_ok(ds, opts ? opts->flags : 0u))
+      return fail(SLM_ERR_UNSUPPORTED, "re-weighted rounds need a problem the on-chip solver takes (p <= %d, n * ld <= 131072)", SM_PMAX);
+    for (int l = 0; l < n_lanes && l < SLM_MAX_CELLS; ++l) {
+      const slm_reweight& r = rules[l];
+      if (!(r.eps >= 0.0) || !(r.tol >= 0.0) || !std::isfinite(r.coef_scale) || !std::isfinite(r.numerator) || !std::isfinite(r.eps) ||
+          r.n_coef < 0 || r.n_coef > ds->p || r.n_group < 0 || r.n_group > ds->G)
+        return fail(SLM_ERR_BAD_ARG, "lane %d: bad re-weighting rule", l);
+      if (r.group_scale)
+        for (int g = 0; g < r.n_group; ++g)
+          if (!(r.group_scale[g] >= 0.0) || !std::isfinite(r.group_scale[g]))
+            return fail(SLM_ERR_BAD_ARG, "lane %d: group_scale[%d] is negative or not finite", l, g);
+    }
+  }
   {
     // sixteen lanes; the on-chip solver, a workgroup per lane, takes SLM_MAX_CELLS (what it does not settle comes back here
     // through solve_without_chip in chunks of sixteen)
@@ -1175,6 +1191,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       h[l].n_points = (int32_t)(off + ln.n_points);
     }
     h[l].zzero = ln.beta0 ? 0 : 1;
+    if (rules) {
+      const slm_reweight& r = rules[l];
+      h[l].rw_coef = r.coef_scale; h[l].rw_numer = r.numerator; h[l].rw_eps = r.eps; h[l].rw_tol = r.tol;
+      h[l].rw_ncoef = r.n_coef; h[l].rw_ngroup = r.n_group;
+      h[l].rw_on = (r.coef_scale != 0.0 ? 1 : 0) | (r.group_scale ? 2 : 0);
+      if (r.group_scale)  // (gscale: the general path's scratch for group factors, free on chip; pageable source: staged by the runtime)
+        HIP_TRY(hipMemcpyAsync(ds->gscale + (size_t)l * G, r.group_scale, sizeof(double) * (size_t)r.n_group, hipMemcpyHostToDevice, s));
+    }
     h[l].mode = (o.flags & SLM_FLAG_FISTA_ONLY) ? 0 : 1;
     h[l].ak = 1.25 * L[l];  // a slightly short first step; the scheme measures its own curvature after it
     h[l].Lhat = 0.5 * L[l];  // a sure lower bound of lambda_max for the residual scaling
@@ -1299,6 +1323,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       at += lanes[l].n_points;
     }
     if (nonfinite) return fail(SLM_ERR_NON_FINITE, "non-finite iterate (diverged or non-finite data)");
+    if (rules) {
+      // a round the kernel did not settle ends the lane's rounds there: the caller runs its own loop (over slm_solve_lanes,
+      // whose general path takes what the chip gives up) -- nothing half-done is handed back
+      if (unconverged) return fail(SLM_ERR_UNSUPPORTED, "a re-weighted round was not settled on chip");
+      for (int l = 0; l < B; ++l) rounds_out[l] = snap.lane[l].rounds;
+    }
     if (unconverged && getenv("SLM_ON_CHIP_NO_FALLBACK") == nullptr) {  // (the variable: diagnostics -- the on-chip records as they are)
       if (const char* trc = getenv("SLM_TRACE"))
         if (trc[0] == '2') fprintf(stderr, "[slm] on-chip solve gave a point up after %.3f ms (%lld products): the general path takes the call\n", t_small, (long long)sweeps);
@@ -1757,6 +1787,12 @@ extern "C" int slm_dataset_max_lanes(slm_dataset* ds, uint32_t flags, int32_t* m
 extern "C" int slm_solve_lanes(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes,
                                const slm_solve_opts* opts, slm_solve_stats* stats) {
   return solve_core(ds, lanes, n_lanes, opts, stats, false);
+}
+
+extern "C" int slm_solve_lanes_reweighted(slm_dataset* ds, const slm_lane* lanes, const slm_reweight* rules, int32_t n_lanes,
+                                          const slm_solve_opts* opts, slm_solve_stats* stats, int32_t* rounds_out) {
+  if (!rules) return fail(SLM_ERR_BAD_ARG, "rules is NULL");
+  return solve_core(ds, lanes, n_lanes, opts, stats, false, rules, rounds_out);
 }
 
 extern "C" int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,

@@ -477,8 +477,9 @@ static __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArg
   if (on0) gpos[s0] = g0;
   if (on1) gpos[s1] = g1;
   const double c0 = on0 ? cs[s0] : 0.0, c1 = on1 ? cs[s1] : 0.0;
-  const double A0 = on0 ? a0[j0] : 0.0, A1 = on1 ? a0[j1] : 0.0;
-  const double B0 = on0 ? b0[g0] : 0.0, B1 = on1 ? b0[g1] : 0.0;
+  // (not const: the rounds of a re-weighted lane renew them, see the end of the point loop)
+  double A0 = on0 ? a0[j0] : 0.0, A1 = on1 ? a0[j1] : 0.0;
+  double B0 = on0 ? b0[g0] : 0.0, B1 = on1 ? b0[g1] : 0.0;
   const double D0 = on0 ? d0[g0] : 0.0, D1 = on1 ? d0[g1] : 0.0;
   // first position / size of the group of each position (group-sorted order: groups are contiguous)
   int gs0 = s0, gn0 = 1, gs1 = s1, gn1 = 1;
@@ -536,6 +537,12 @@ static __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArg
   bool bad = false;
   long long iters_all = 0;
   int face_solves = 0;  // direct solves on a face (SLM_TRACE=2)
+  // re-weighted rounds (PathCtl::rw_*): the points of the lane are the solves of an Adaptive* estimator's loop
+  const int rw_on = ctl->rw_on;
+  const double rw_coef = ctl->rw_coef, rw_numer = ctl->rw_numer, rw_eps = ctl->rw_eps, rw_tol = ctl->rw_tol;
+  const int rw_ncoef = ctl->rw_ncoef, rw_ngroup = ctl->rw_ngroup;
+  const double* rw_gscale = a.t.gscale + (int64_t)lane_id * G;
+  int rounds = 0;
   if (bad_setup) {  // (nothing was built: every point goes to the general path)
     for (int point = first + lane; point < last; point += 64) {
       slm_point_info info;
@@ -1190,11 +1197,12 @@ static __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArg
 
     // ---- the point's record: minimal-norm subgradient (the KKT residual), loss, group norms, coefficients --------
     double kkt2 = 0.0;
+    double nr0 = fabs(be0), nr1 = fabs(be1);
     {
       // norm of every position's group (a group of one: the absolute value), and for the zero groups the norm of
       // soft(q_g, a_g), which has to stay below b_g
-      double nr0 = fabs(be0), nr1 = fabs(be1), tn0 = 0.0, tn1 = 0.0;
-      if (!a.t.singleton && (!lasso_type || gn_out != nullptr)) {
+      double tn0 = 0.0, tn1 = 0.0;
+      if (!a.t.singleton && (!lasso_type || gn_out != nullptr || (rw_on & 2))) {
         if (on0) vu[s0] = be0;
         if (on1) vu[s1] = be1;
         sm_lds_sync();
@@ -1264,10 +1272,41 @@ static __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArg
       info.mu = mu_rep;
       infos[point] = info;
     }
+    // ---- a re-weighted lane: the next round's weights from this round's solution ---------------------------------
+    // (the loop of AdaptiveLasso._solve, reference model/_adaptive_lasso.py:206-232: solve, renew the weights from the
+    //  solution -- :364-374 for the group norms --, stop when they no longer move; here without leaving the kernel.  The
+    //  expressions are the host loop's own, operation for operation: scale * (numerator / (|x| + eps)))
+    if (rw_on && !bad) {
+      ++rounds;
+      double nA0 = A0, nA1 = A1, nB0 = B0, nB1 = B1;
+      if (rw_on & 1) {
+        if (on0 && j0 < rw_ncoef) nA0 = rw_coef * (rw_numer / (fabs(be0) + rw_eps));
+        if (on1 && j1 < rw_ncoef) nA1 = rw_coef * (rw_numer / (fabs(be1) + rw_eps));
+      }
+      if (rw_on & 2) {
+        if (on0 && g0 < rw_ngroup) nB0 = rw_gscale[g0] * (rw_numer / (nr0 + rw_eps));
+        if (on1 && g1 < rw_ngroup) nB1 = rw_gscale[g1] * (rw_numer / (nr1 + rw_eps));
+      }
+      // (a group's weight counts once: at its first member)
+      const double dA0 = nA0 - A0, dA1 = nA1 - A1, dB0 = (on0 && s0 == gs0) ? nB0 - B0 : 0.0, dB1 = (on1 && s1 == gs1) ? nB1 - B1 : 0.0;
+      const double moved = sqrt(sm_sum((dA0 * dA0 + dA1 * dA1) + (dB0 * dB0 + dB1 * dB1)));
+      A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
+      if (!conv || moved <= rw_tol) {  // settled -- or a round that did not: the caller's own loop takes the lane (solve_core)
+        for (int k = point + 1 + lane; k < last; k += 64) {
+          slm_point_info skipped;
+          memset(&skipped, 0, sizeof(skipped));
+          skipped.mode = 3;  // a round that was not run
+          infos[k] = skipped;
+        }
+        tk_rec += wall_clock64() - tkc;
+        break;
+      }
+    }
     tk_rec += wall_clock64() - tkc;
   }
   release_helpers();
   if (lane == 0) {
+    ctl->rounds = rounds;
     ctl->total_iter = 1;  // X was read once
     ctl->iter = (int32_t)(iters_all > 2000000000ll ? 2000000000ll : iters_all);
     ctl->nonfinite = bad ? 1 : 0;

@@ -67,6 +67,15 @@ struct PathCtl {
   int32_t pad2_;
   double loss_base;    // smooth loss at zprev, the point whose gradient gprev holds: with them a later solve that starts
                        // where this one ended needs no pass over the data for its first step (solve_core, "carried start")
+  // re-weighted rounds on chip (slm_solve_lanes_reweighted, small_kernels.hpp): the lane's points are the rounds of an
+  // Adaptive* estimator; after each the kernel renews the penalty weights from the solution
+  double rw_coef;      // a_j <- rw_coef * (rw_numer / (|beta_j| + rw_eps)) for j < rw_ncoef   (rw_on & 1)
+  double rw_numer;     // b_g <- gscale[g] * (rw_numer / (||beta_g|| + rw_eps)) for g < rw_ngroup   (rw_on & 2)
+  double rw_eps;
+  double rw_tol;       // the rounds end when the weights moved by no more than this (2-norm)
+  int32_t rw_ncoef, rw_ngroup;
+  int32_t rw_on;
+  int32_t rounds;      // out: rounds run
 };
 
 constexpr int BB_HIST = 5;

@@ -9,6 +9,7 @@ implementation without touching product code.
 
 from __future__ import annotations
 
+import os
 import warnings
 from contextlib import contextmanager
 
@@ -205,6 +206,27 @@ class SolveProblem:
         # (copies: an estimator's coef_ must not keep a block of the engine's page-locked result pool alive)
         gn = None if res.group_norms is None else res.group_norms[0].copy()
         return res.betas[0].copy(), gn, info
+
+    def solve_rounds(self, a, b, d, rule, rounds, beta0=None, cold=False):
+        """The re-weighting rounds of an Adaptive* fit in ONE launch (``Dataset.solve_lanes_reweighted``; ``rule`` as
+        ``AdaptiveLasso._reweight_rule`` gives it): ``(beta, group_norms, infos)`` of the last round run, one info per
+        round -- or ``None`` where that does not apply (not a problem for the on-chip solver, a round that did not settle
+        there, ``covariance=True``): the caller then loops over ``solve``."""
+        o = self.options
+        flags = solve_flags(o)
+        if not (flags & _engine.FLAG_ON_CHIP) or o.get("covariance") is True or os.environ.get("SLM_HOST_ROUNDS"):
+            return None
+        if cold:
+            flags |= _engine.FLAG_COLD_START
+        try:
+            (res,), (r,) = self.ds.solve_lanes_reweighted(
+                [dict(points=np.ones((int(rounds), 3)), a=a, b=b, d=d, beta0=beta0, reweight=rule)],
+                tol=float(o.get("tol", default_tol(self.ds.n, self.ds.p))), max_iter=int(o.get("max_iter", 10000)), flags=flags)
+        except NotImplementedError:
+            return None
+        infos = [{"n_iter": int(res.n_iter[k]), "converged": True, "resid": float(res.resid[k]), "L": float(res._infos["L"][k]),
+                  "loss": float(res.loss[k]), "wall_ms": res.wall_ms} for k in range(r)]
+        return res.betas[r - 1].copy(), res.group_norms[r - 1].copy(), infos
 
     def set_targets(self, y):
         """New targets on the same design (problems opened with ``cache=False`` only: a cached dataset is

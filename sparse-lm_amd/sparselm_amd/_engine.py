@@ -42,7 +42,7 @@ FLAG_ON_CHIP = 128  # problems whose Gram matrix fits a workgroup: one launch pe
 FLAG_COVARIANCE = 256  # passes from the Grams of the call's row sets (Dataset.covariance; csrc/cov_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 12  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 13  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -74,6 +74,7 @@ ABI_SYMBOLS = (
     "slm_dense_spd_solve",
     "slm_solve_path",
     "slm_solve_lanes",
+    "slm_solve_lanes_reweighted",
     "slm_solve_path_lanes",
     "slm_solve_standardized_sgl",
     "slm_dataset_covariance",
@@ -163,6 +164,18 @@ class _Lane(C.Structure):
         ("betas_out", C.c_void_p),
         ("group_norms_out", C.c_void_p),
         ("infos", C.POINTER(_PointInfo)),
+    ]
+
+
+class _Reweight(C.Structure):
+    _fields_ = [
+        ("coef_scale", C.c_double),
+        ("group_scale", C.c_void_p),
+        ("numerator", C.c_double),
+        ("eps", C.c_double),
+        ("tol", C.c_double),
+        ("n_coef", C.c_int32),
+        ("n_group", C.c_int32),
     ]
 
 
@@ -262,6 +275,7 @@ def load_library():
                 P(_SolveStats),
             ],
             "slm_solve_lanes": [vp, P(_Lane), i32, P(_SolveOpts), P(_SolveStats)],
+            "slm_solve_lanes_reweighted": [vp, P(_Lane), P(_Reweight), i32, P(_SolveOpts), P(_SolveStats), P(i32)],
             "slm_solve_path_lanes": [
                 vp, P(_PenaltyStruct), P(_PathPoint), i32, i32, P(_SolveOpts), vp, vp, vp, P(_PointInfo), P(_SolveStats),
             ],
@@ -721,6 +735,7 @@ class Dataset:
         flags: int = 0,
         want_group_norms: bool = False,
         extrapolate: bool = True,
+        _reweighted: bool = False,
     ) -> list:
         """Solve up to MAX_LANES independent warm-started paths on ONE pass over X per iteration.
 
@@ -735,15 +750,21 @@ class Dataset:
         G = self.n_groups
         b = load_binding()
         if b is not None:  # the compiled binding marshals the lanes itself
-            betas, gnb, inf, ks, st = b.solve_lanes(self._h.value, list(lanes), self.n, self.p, G, float(tol), int(max_iter),
-                                                    int(check_every), float(L), int(flags), bool(want_group_norms),
-                                                    bool(extrapolate), _host_pool.empty)
+            rounds = None
+            if _reweighted:
+                betas, gnb, inf, ks, st, rounds = b.solve_lanes_reweighted(
+                    self._h.value, list(lanes), self.n, self.p, G, float(tol), int(max_iter), int(check_every), float(L),
+                    int(flags), bool(want_group_norms), _host_pool.empty)
+            else:
+                betas, gnb, inf, ks, st = b.solve_lanes(self._h.value, list(lanes), self.n, self.p, G, float(tol), int(max_iter),
+                                                        int(check_every), float(L), int(flags), bool(want_group_norms),
+                                                        bool(extrapolate), _host_pool.empty)
             infos, out, at, p = inf.view(_INFO_DTYPE), [], 0, self.p
             for K in ks:
                 out.append(PathResult(betas[at * p : (at + K) * p].reshape(K, p),
                                       gnb[at * G : (at + K) * G].reshape(K, G) if want_group_norms else None, infos[at : at + K], st))
                 at += K
-            return out
+            return (out, [int(r) for r in rounds]) if _reweighted else out
         keep = []  # keep every buffer alive for the duration of the call
         clanes = (_Lane * nl)()
         outs = []
@@ -791,8 +812,27 @@ class Dataset:
             outs.append((betas, gn, infos, K))
         opts = _SolveOpts(float(tol), int(max_iter), int(check_every), float(L), int(flags))
         stats = _SolveStats()
+        if _reweighted:
+            rules, rounds = (_Reweight * nl)(), (C.c_int32 * nl)()
+            for l, spec in enumerate(lanes):
+                coef_scale, group_scale, numerator, eps, rtol, n_coef, n_group = spec["reweight"]
+                gsc = None if group_scale is None else _f64(np.broadcast_to(np.asarray(group_scale), (int(n_group),)), "group_scale")
+                keep.append(gsc)
+                rules[l] = _Reweight(float(coef_scale), _ptr(gsc), float(numerator), float(eps), float(rtol), int(n_coef), int(n_group))
+            _check(self._lib.slm_solve_lanes_reweighted(self._h, clanes, rules, nl, C.byref(opts), C.byref(stats), rounds))
+            return [_path_result(betas, gn, infos, K, stats) for betas, gn, infos, K in outs], [int(r) for r in rounds]
         _check(self._lib.slm_solve_lanes(self._h, clanes, nl, C.byref(opts), C.byref(stats)))
         return [_path_result(betas, gn, infos, K, stats) for betas, gn, infos, K in outs]
+
+    def solve_lanes_reweighted(self, lanes, tol: float = 1e-8, max_iter: int = 10000, flags: int = 0, want_group_norms: bool = True):
+        """The re-weighting loops of Adaptive* estimators inside one launch (``slm_solve_lanes_reweighted``): every lane dict
+        has ``points`` = its rounds (``max_iter`` rows, normally all ones) and ``reweight`` = ``(coef_scale, group_scale or
+        None, numerator, eps, tol, n_coef, n_group)``.  Returns ``(results, rounds)``: one ``PathResult`` per lane with a row
+        per round, and the number of rounds each lane ran (its last solution is row ``rounds - 1``).
+        ``NotImplementedError`` when the problem is not one the on-chip solver takes, or a round did not settle there: the
+        caller then loops over ``solve_lanes`` itself."""
+        return self.solve_lanes(lanes, tol=tol, max_iter=max_iter, flags=int(flags) | FLAG_ON_CHIP, want_group_norms=want_group_norms,
+                                extrapolate=False, _reweighted=True)
 
     def solve_path(
         self,

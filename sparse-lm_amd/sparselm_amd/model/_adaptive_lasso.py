@@ -124,6 +124,15 @@ class AdaptiveLasso(Lasso):
 
     _needs_group_norms = False
 
+    def _reweight_rule(self, p, G):
+        """The default weight update in the engine's terms -- ``(coef_scale, group_scale, numerator, eps, tol, n_coef,
+        n_group)`` of ``slm_solve_lanes_reweighted``: new ``a_j = coef_scale * (numerator / (|b_j| + eps))``, new ``b_g =
+        group_scale[g] * (numerator / (||b_g|| + eps))``, the operations of ``_updated_weights`` in its order -- or
+        ``None`` with a user's ``update_function``, which only the host loop can call.  After ``_adaptive_setup``."""
+        if self.update_function is not None:
+            return None
+        return (float(self.alpha), None, float(self.alpha), float(self.eps), float(self.tol), int(p), 0)
+
     # ---- the re-weighting loop ---------------------------------------------------------------
     def _solve(self, X, y, solver_options, *args, **kwargs):
         """Counterpart of AdaptiveLasso._solve (reference _adaptive_lasso.py:206-232)."""
@@ -139,7 +148,17 @@ class AdaptiveLasso(Lasso):
         infos = []
         self.n_iter_ = 0
         try:
-            for i in range(self.max_iter):
+            # reference-sized problems with the default update function: every round inside one launch
+            solve_rounds = getattr(problem, "solve_rounds", None)
+            rule = self._reweight_rule(p, G) if solve_rounds is not None and self.max_iter >= 1 else None
+            if rule is not None:
+                a, b, d = self._weights_to_penalty(weights, p, G)
+                got = solve_rounds(a, b, np.zeros(G) if dz.ridge_absorbed else d, rule, self.max_iter, beta0=warm, cold=not self.warm_start)
+                if got is not None:
+                    beta, group_norms, infos = got
+                    self.n_iter_ = len(infos)
+                    weights = self._updated_weights(beta, group_norms)
+            for i in range(self.max_iter if beta is None else 0):
                 a, b, d = self._weights_to_penalty(weights, p, G)
                 if dz.ridge_absorbed:
                     d = np.zeros(G)
@@ -212,6 +231,11 @@ class AdaptiveGroupLasso(AdaptiveLasso, GroupLasso):
     def _updated_weights(self, beta, group_norms):
         update = self._get_update_function()
         return (self.alpha * self._gw) * np.asarray(update(group_norms, self.eps), dtype=np.float64)
+
+    def _reweight_rule(self, p, G):
+        if self.update_function is not None:
+            return None
+        return (0.0, self.alpha * self._gw, float(self.alpha), float(self.eps), float(self.tol), 0, int(G))
 
 
 class AdaptiveOverlapGroupLasso(AdaptiveGroupLasso, OverlapGroupLasso):
@@ -333,6 +357,12 @@ class AdaptiveSparseGroupLasso(AdaptiveLasso, SparseGroupLasso):
         coef_w = lam1 * np.asarray(update(beta, self.eps), dtype=np.float64)
         group_w = (lam2 * self._gw) * np.asarray(update(group_norms, self.eps), dtype=np.float64)
         return np.concatenate((group_w, coef_w))
+
+    def _reweight_rule(self, p, G):
+        if self.update_function is not None:
+            return None
+        lam1, lam2 = self._lambdas()
+        return (float(lam1), lam2 * self._gw, float(self.alpha), float(self.eps), float(self.tol), int(p), int(G))
 
     @property
     def adaptive_group_weights_(self):

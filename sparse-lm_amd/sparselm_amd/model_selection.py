@@ -33,6 +33,7 @@ fit; sample weights, custom scorers, grids without ``alpha``) runs through sciki
 from __future__ import annotations
 
 import numbers
+import os
 import time
 import warnings
 from collections import defaultdict
@@ -678,7 +679,7 @@ class _DeviceGrid:
         t_batch = time.perf_counter()
         try:
             fits = _adaptive_lanes(ds, ests, self.X, [self.train_masks[f] for _, f in batch],
-                                   [len(self.splits[f][0]) for _, f in batch], self.opts, self.with_intercept)
+                                   [len(self.splits[f][0]) for _, f in batch], self.opts, self.with_intercept, want_weights=False)
         except _engine.NonFiniteError:
             if search.error_score == "raise":
                 raise
@@ -895,7 +896,39 @@ def _solve_lanes_with_fallback(ds, specs, opts):
         return _solve_lanes_with_fallback(ds, specs[:half], opts) + _solve_lanes_with_fallback(ds, specs[half:], opts)
 
 
-def _adaptive_lanes(ds, ests, X, row_weights, n_effs, opts, with_intercept):
+def _adaptive_lanes_on_chip(ds, ests, st, p, row_weights, n_effs, opts, with_intercept, want_weights):
+    """The loops of ``_adaptive_lanes`` inside one launch (``Dataset.solve_lanes_reweighted``): for reference-sized
+    problems and the default update function -- every round used to be a call of its own, 0.5 ms of launch, wait and
+    numpy per round of a 5 ms search.  ``None`` when this is not such a case (the rule is a user's function, the
+    estimators differ in ``warm_start``, the problem is not one the on-chip solver takes, a round did not settle there):
+    the caller's loop runs as before."""
+    if not hasattr(ds, "solve_lanes_reweighted") or os.environ.get("SLM_HOST_ROUNDS"):
+        return None
+    rules = [e._reweight_rule(p, s["G"]) for e, s in zip(ests, st)]
+    if any(r is None for r in rules) or len({bool(e.warm_start) for e in ests}) != 1:
+        return None
+    flags = int(opts.get("flags", 0))
+    if not ests[0].warm_start:
+        flags |= _engine.FLAG_COLD_START
+    specs = []
+    for e, s, rule, rw, ne in zip(ests, st, rules, row_weights, n_effs):
+        a, b, d = with_intercept(*e._weights_to_penalty(s["w"], p, s["G"]), s["G"])
+        specs.append(dict(points=np.ones((int(e.max_iter), 3)), a=a, b=b, d=d, row_weight=rw, n_eff=ne, reweight=rule))
+    try:
+        results, rounds = ds.solve_lanes_reweighted(specs, tol=opts.get("tol", 1e-8), max_iter=opts.get("max_iter", 10000), flags=flags)
+    except NotImplementedError:
+        return None
+    fits = []
+    for e, s, res, r in zip(ests, st, results, rounds):
+        beta = res.betas[r - 1].copy()
+        fit = dict(beta=beta, n_iter=r, infos=[{"n_iter": int(res.n_iter[k]), "converged": True} for k in range(r)])
+        if want_weights:
+            fit["weights"] = e._updated_weights(beta[:p], res.group_norms[r - 1][: s["G"]])
+        fits.append(fit)
+    return fits
+
+
+def _adaptive_lanes(ds, ests, X, row_weights, n_effs, opts, with_intercept, want_weights=True):
     """The re-weighting loops of several Adaptive* estimators side by side: outer iteration k of every
     estimator is ONE call with one lane per estimator (each lane its own weight vectors, row mask and warm
     start), so X is read once per inner iteration for all of them.  Same loop semantics as
@@ -912,6 +945,9 @@ def _adaptive_lanes(ds, ests, X, row_weights, n_effs, opts, with_intercept):
             raise ValueError("max_iter=0 performs no solve; coef_ would be undefined")
         _, G, w = e._adaptive_setup(X)
         st.append(dict(G=G, w=w, prev=w.copy(), beta=None, n_iter=0, done=False, infos=[]))
+    on_chip = _adaptive_lanes_on_chip(ds, ests, st, p, row_weights, n_effs, opts, with_intercept, want_weights)
+    if on_chip is not None:
+        return on_chip
     for it in range(max(e.max_iter for e in ests)):
         live = [i for i, e in enumerate(ests) if not st[i]["done"] and it < e.max_iter]
         if not live:

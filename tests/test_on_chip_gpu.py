@@ -239,3 +239,145 @@ def test_standardized_estimator_takes_the_on_chip_route_and_agrees_with_the_swee
     assert np.max(np.abs(fits[True][0].coef_ - golden["std_sgl_coef"])) < 1e-8 * scale
     assert fits[True][1].n_iter_ == fits[False][1].n_iter_ == int(golden["std_ada_sgl_niter"])
     assert np.max(np.abs(fits[True][1].coef_ - golden["std_ada_sgl_coef"])) < 1e-6 * np.max(np.abs(golden["std_ada_sgl_coef"]))
+
+
+# ---- re-weighted rounds inside the launch (slm_solve_lanes_reweighted) ----------------------------------------------------
+def _host_rounds(ds, spec, rule, rounds, tol):
+    """The loop the kernel replaces, over solve_lanes: (betas per round, rounds run)."""
+    coef_scale, group_scale, numer, eps, rtol, n_coef, n_group = rule
+    a, b = np.array(spec["a"], dtype=float), np.array(spec["b"], dtype=float)
+    beta, out = None, []
+    for _ in range(rounds):
+        res = ds.solve_lanes([dict(points=[(1.0, 1.0, 1.0)], a=a, b=b, d=spec["d"], beta0=beta, row_weight=spec.get("row_weight"),
+                                   n_eff=spec.get("n_eff"))], tol=tol, want_group_norms=True, flags=_engine.FLAG_ON_CHIP)[0]
+        assert res.converged
+        if res.mode[0] != 2:  # the chip gave the round up (the general path solved it): the launch of all rounds refuses too
+            return None, 0
+        beta = res.betas[0].copy()
+        out.append(beta)
+        na, nb = a.copy(), b.copy()
+        if coef_scale != 0.0:
+            na[:n_coef] = coef_scale * (numer / (np.abs(beta[:n_coef]) + eps))
+        if group_scale is not None:
+            nb[:n_group] = np.asarray(group_scale) * (numer / (res.group_norms[0][:n_group] + eps))
+        moved = np.sqrt(np.sum((na - a) ** 2) + np.sum((nb - b) ** 2))
+        a, b = na, nb
+        if moved <= rtol:
+            break
+    return out, len(out)
+
+
+def test_re_weighted_rounds_in_one_launch_are_the_host_loop_bit_for_bit(eng):
+    rng = np.random.default_rng(5)
+    n, p, G = 100, 80, 8
+    X = rng.standard_normal((n, p))
+    coef = np.zeros(p)
+    coef[rng.choice(p, 10, replace=False)] = rng.uniform(1, 5, 10)
+    y = X @ coef + 0.5 * rng.standard_normal(n)
+    groups = rng.permutation(np.arange(p) % G)
+    gw = rng.uniform(0.5, 2.0, G)
+    mask = (np.arange(n) % 5 != 2).astype(float)
+    tol = 1e-10
+    cases = []  # (groups, spec, rule, rounds)
+    for alpha in (1e-3, 0.3, 3.0):
+        cases.append((None, dict(a=alpha * np.ones(p), b=np.zeros(p), d=np.zeros(p)), (alpha, None, alpha, 1e-6, 1e-10, p, 0), 3))
+        cases.append((groups, dict(a=np.zeros(p), b=alpha * np.ones(G), d=np.zeros(G)), (0.0, alpha * gw, alpha, 1e-6, 1e-10, 0, G), 4))
+        cases.append((groups, dict(a=0.3 * alpha * np.ones(p), b=0.7 * alpha * np.ones(G), d=0.1 * np.ones(G), row_weight=mask, n_eff=int(mask.sum())),
+                      (0.3 * alpha, 0.7 * alpha * gw, alpha, 1e-6, 1e-10, p, G), 3))
+    # rounds that end early: the weights of an all-zero solution do not move after the second round
+    cases.append((None, dict(a=50.0 * np.ones(p), b=np.zeros(p), d=np.zeros(p)), (50.0, None, 50.0, 1e-6, 1e-10, p, 0), 5))
+    refused = 0
+    with eng.dataset(X, y) as ds:
+        for grp, spec, rule, rounds in cases:
+            ds.set_groups(grp, None if grp is None else G)
+            want, r_want = _host_rounds(ds, spec, rule, rounds, tol)
+            if want is None:
+                with pytest.raises(NotImplementedError):
+                    ds.solve_lanes_reweighted([dict(points=np.ones((rounds, 3)), reweight=rule, **spec)], tol=tol)
+                refused += 1
+                continue
+            (res,), (r,) = ds.solve_lanes_reweighted([dict(points=np.ones((rounds, 3)), reweight=rule, **spec)], tol=tol)
+            assert r == r_want, (rule, r, r_want)
+            for k in range(r):
+                np.testing.assert_array_equal(res.betas[k], want[k])
+                assert res.mode[k] == 2 and res.n_iter[k] > 0
+            for k in range(r, rounds):
+                assert res.mode[k] == 3 and res.n_iter[k] == 0
+        assert r_want < 5  # (the last case did end early)
+        assert refused <= 3, refused
+        # many lanes, each its own rule and number of rounds, in one launch
+        ds.set_groups(None, None)
+        alphas = np.geomspace(0.02, 5.0, 40)
+        specs = [dict(points=np.ones((2 + i % 3, 3)), a=al * np.ones(p), b=np.zeros(p), d=np.zeros(p), reweight=(al, None, al, 1e-6, 1e-10, p, 0))
+                 for i, al in enumerate(alphas)]
+        results, rounds = ds.solve_lanes_reweighted(specs, tol=tol)
+        assert results[0].grad_launches == 1
+        for i in (0, 7, 22, 39):
+            want, r_want = _host_rounds(ds, specs[i], specs[i]["reweight"], 2 + i % 3, tol)
+            assert want is not None and rounds[i] == r_want
+            np.testing.assert_array_equal(results[i].betas[rounds[i] - 1], want[-1])
+
+
+def test_re_weighted_rounds_are_refused_where_the_chip_does_not_apply(eng):
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((300, 200))
+    y = rng.standard_normal(300)
+    with eng.dataset(X, y) as ds:  # p > 128: the caller keeps its loop
+        with pytest.raises(NotImplementedError):
+            ds.solve_lanes_reweighted([dict(points=np.ones((3, 3)), a=np.ones(200), reweight=(1.0, None, 1.0, 1e-6, 1e-10, 200, 0))])
+    X = rng.standard_normal((40, 30))
+    y = rng.standard_normal(40)
+    with eng.dataset(X, y) as ds:
+        with pytest.raises(ValueError):
+            ds.solve_lanes_reweighted([dict(points=np.ones((3, 3)), a=np.ones(30), reweight=(1.0, None, 1.0, -1.0, 1e-10, 30, 0))])
+        with pytest.raises(ValueError):
+            ds.solve_lanes_reweighted([dict(points=np.ones((3, 3)), a=np.ones(30), reweight=(1.0, None, 1.0, 1e-6, 1e-10, 31, 0))])
+
+
+@pytest.mark.parametrize("kind", ["lasso", "group", "sparse_group", "ridged", "overlap"])
+def test_adaptive_searches_with_rounds_on_chip_equal_the_host_loop(kind, monkeypatch):
+    """GridSearchCV over the Adaptive* estimators at the README's size: rounds inside the launch against the loop of calls
+    (SLM_HOST_ROUNDS=1) -- the same scores, the same refit."""
+    from sklearn.datasets import make_regression
+
+    from sparselm_amd import model
+    from sparselm_amd.model_selection import GridSearchCV
+
+    X, y = make_regression(n_samples=100, n_features=60, n_informative=10, random_state=3)
+    groups = np.arange(60) % 12
+    est = {
+        "lasso": lambda: model.AdaptiveLasso(fit_intercept=True),
+        "group": lambda: model.AdaptiveGroupLasso(groups=groups, group_weights=np.linspace(0.5, 2.0, 12)),
+        "sparse_group": lambda: model.AdaptiveSparseGroupLasso(groups=groups, l1_ratio=0.4, max_iter=4),
+        "ridged": lambda: model.AdaptiveRidgedGroupLasso(groups=groups, delta=(0.5,), fit_intercept=True),
+        "overlap": lambda: model.AdaptiveOverlapGroupLasso(group_list=[[g, (g + 1) % 12] for g in groups], max_iter=2),
+    }[kind]
+    grid = {"alpha": np.logspace(-3, 1, 6)}
+    import warnings
+
+    calls = []
+    inner = _engine.Dataset.solve_lanes_reweighted
+
+    def counted(self, lanes, **kw):
+        out = inner(self, lanes, **kw)
+        calls.append(len(lanes))
+        return out
+
+    monkeypatch.setattr(_engine.Dataset, "solve_lanes_reweighted", counted)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        on_chip = GridSearchCV(est(), grid, cv=4).fit(X, y)
+        # the 6 x 4 cells in one launch, the refit in another (the overlap estimator duplicates columns on the host: its
+        # search goes cell by cell through fit, a launch per fit where the duplicated columns' rounds settle on chip)
+        if kind == "overlap":
+            assert calls and set(calls) == {1}, calls
+        else:
+            assert calls == [24, 1], calls
+        n_calls = len(calls)
+        monkeypatch.setenv("SLM_HOST_ROUNDS", "1")
+        host = GridSearchCV(est(), grid, cv=4).fit(X, y)
+        assert len(calls) == n_calls
+    np.testing.assert_array_equal(on_chip.cv_results_["mean_test_score"], host.cv_results_["mean_test_score"])
+    np.testing.assert_array_equal(on_chip.best_estimator_.coef_, host.best_estimator_.coef_)
+    np.testing.assert_array_equal(on_chip.best_estimator_.adaptive_weights_, host.best_estimator_.adaptive_weights_)
+    assert on_chip.best_estimator_.n_iter_ == host.best_estimator_.n_iter_
