@@ -125,3 +125,40 @@ def test_compiled_binding_loads_and_agrees_with_python_on_the_secant_factors():
             np.testing.assert_allclose(b.path_extrapolation(pts), _engine._path_extrapolation(pts), rtol=1e-13, atol=0)
     with __import__("pytest").raises(ValueError):
         b.path_extrapolation(np.zeros(4))
+
+
+def test_reweight_rules_are_the_estimators_updates_in_the_engines_terms():
+    """``_reweight_rule`` hands ``slm_solve_lanes_reweighted`` the default weight update of each Adaptive* estimator: the
+    kernel's expression, scale * (numerator / (|x| + eps)), evaluated here in numpy, gives ``_updated_weights`` bit for bit."""
+    from sparselm_amd import model
+
+    rng = np.random.default_rng(3)
+    n, p, G = 30, 24, 6
+    X = rng.standard_normal((n, p))
+    groups = np.arange(p) % G
+    gw = rng.uniform(0.5, 2.0, G)
+    beta = rng.standard_normal(p) * (rng.random(p) < 0.6)
+    ests = [
+        model.AdaptiveLasso(alpha=0.37, eps=1e-5),
+        model.AdaptiveGroupLasso(groups=groups, alpha=0.21, group_weights=gw),
+        model.AdaptiveSparseGroupLasso(groups=groups, alpha=0.8, l1_ratio=0.3, group_weights=gw, eps=1e-4),
+        model.AdaptiveRidgedGroupLasso(groups=groups, alpha=1.3, delta=(0.5,), group_weights=gw),
+    ]
+    for est in ests:
+        gidx, GG, w0 = est._adaptive_setup(X)
+        gn = np.abs(beta) if gidx is None else np.sqrt(np.bincount(gidx, weights=beta**2, minlength=GG))
+        coef_scale, group_scale, numer, eps, tol, n_coef, n_group = est._reweight_rule(p, GG)
+        assert eps == est.eps and tol == est.tol
+        a0, b0, _ = est._weights_to_penalty(w0, p, GG)
+        a = np.array(a0, dtype=float)
+        b = np.array(b0, dtype=float)
+        if coef_scale != 0.0:
+            a[:n_coef] = coef_scale * (numer / (np.abs(beta[:n_coef]) + eps))
+        if group_scale is not None:
+            b[:n_group] = np.asarray(group_scale) * (numer / (gn[:n_group] + eps))
+        want_a, want_b, _ = est._weights_to_penalty(est._updated_weights(beta, gn), p, GG)
+        np.testing.assert_array_equal(a, want_a)
+        np.testing.assert_array_equal(b, want_b)
+    custom = model.AdaptiveLasso(update_function=lambda b, eps: 1.0 / (np.abs(b) + eps))
+    custom._adaptive_setup(X)
+    assert custom._reweight_rule(p, p) is None
