@@ -810,3 +810,16 @@ def test_carried_start_tells_row_weights_by_content(eng, monkeypatch):
         tr = masks[f] > 0
         want, _ = oracle.fista(X[tr], y[tr], alpha * a2, 0.0, 0.0, np.arange(p), p, tol=1e-13)
         assert rel_inf(got[name].betas[-1], want) < 1e-7, name
+
+
+def test_randomised_call_sequences_with_and_without_carried_starts():
+    """tools/carry_fuzz.py: sequences of calls on one dataset (penalties, warm starts, row masks, targets, lane counts and
+    flags changing as estimators and searches change them) with carried starts against the same calls without."""
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "carry_fuzz.py"), "0", "1", "2", "3", "4", "5"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "0 calls more than a pass worse" in out.stdout
