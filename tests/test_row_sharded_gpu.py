@@ -124,6 +124,51 @@ def test_group_penalty_with_working_set_across_two_ranks():
         np.testing.assert_allclose(res.group_norms, ref.group_norms, rtol=0, atol=1e-8 * np.max(ref.group_norms))
 
 
+@pytest.mark.parametrize("flags", [0, _engine.FLAG_WORKING_SET])
+def test_re_weighted_solves_across_two_ranks_carry_their_start(flags, monkeypatch):
+    """The rounds of an adaptive group estimator on a row-sharded dataset: each re-weighted solve starts where the one
+    before ended and leaves out its first pass -- and the all-reduce that goes with it -- on every rank alike (the
+    decision is made from the caller's arrays, which the ranks share)."""
+    X, y = _problem(2600, 150, seed=11)
+    n = len(y)
+    groups = np.repeat(np.arange(30), 5)
+    c = X.T @ y / n
+    alpha = 0.05 * np.max(np.sqrt(np.bincount(groups, weights=c * c)))
+
+    def rounds(ds):
+        ds.set_groups(groups, 30)
+        b, beta, out, passes = alpha * np.ones(30), None, [], []
+        for _ in range(3):
+            res = ds.solve_path([(0.0, 1.0, 0.0)], b=b, beta0=beta, tol=1e-10, flags=flags, want_group_norms=True)
+            assert res.converged
+            beta = res.betas[0].copy()
+            b = alpha * (alpha / (res.group_norms[0] + 1e-6))
+            out.append(beta)
+            passes.append(res.grad_launches)
+        return out, passes
+
+    def work(r, eng):
+        lo, hi = row_range(n, r, 2)
+        with eng.dataset(X[lo:hi], y[lo:hi]) as ds:
+            ds.set_global_rows(n)
+            return rounds(ds)
+
+    out, counts, _ = _run_ranks(2, work)
+    assert counts[0] == counts[1]
+    monkeypatch.setenv("SLM_NO_CARRY", "1")
+    plain, plain_counts, _ = _run_ranks(2, work)
+    monkeypatch.delenv("SLM_NO_CARRY")
+    with _engine.get_engine(0).dataset(X, y) as ds:
+        ref, _ = rounds(ds)
+    (b0, k0), (b1, k1) = out
+    assert k0 == k1 and k0[0] == plain[0][1][0]
+    assert all(a == b - 1 for a, b in zip(k0[1:], plain[0][1][1:])), (k0, plain[0][1])
+    assert counts[0] < plain_counts[0]  # (fewer collectives, too)
+    for k in range(3):
+        assert np.array_equal(b0[k], b1[k])
+        assert np.max(np.abs(b0[k] - ref[k])) <= 1e-7 * np.max(np.abs(ref[k]))
+
+
 def test_centring_a_row_sharded_dataset_subtracts_the_global_means():
     X, y = _problem(1999, 61, seed=3)
     n = len(y)
