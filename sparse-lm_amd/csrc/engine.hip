@@ -442,7 +442,7 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
   A(dalloc(&ds->a0, ML * ld));
   A(dalloc(&ds->b0, ML * ld));
   A(dalloc(&ds->d0, ML * ld));
-  A(dalloc(&ds->lambda, ML));
+  A(dalloc(&ds->lambda, ML + 1));  // (+ 1: the kept sketch estimate, slm_dataset::sketch_valid)
   A(dalloc(&ds->dctl, 1));
   if (rc == SLM_OK) {  // (addresses only: nothing is read through the device pointer here)
     ds->ctl = ds->dctl->lane;
@@ -480,6 +480,7 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
 
 static int upload_row_weights(slm_dataset* ds, const double* rw_host) {
   ds->L_valid = false;
+  ds->sketch_valid = false;
   ds->carry_valid = false;
   if (!rw_host) {
     dfree(ds->rw);
@@ -682,6 +683,7 @@ extern "C" int slm_dataset_set_global_rows(slm_dataset* ds, int64_t n_global) {
   if (n_global < 1) return fail(SLM_ERR_BAD_ARG, "n_global must be positive (got %lld)", (long long)n_global);
   ds->n_global = n_global;
   ds->L_valid = false;
+  ds->sketch_valid = false;
   ds->carry_valid = false;
   return SLM_OK;
 }

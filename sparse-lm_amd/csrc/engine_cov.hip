@@ -466,6 +466,7 @@ extern "C" int slm_dataset_set_replicated(slm_dataset* ds, int32_t replicated) {
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
   ds->replicated = replicated != 0;
   ds->L_valid = false;
+  ds->sketch_valid = false;
   ds->carry_valid = false;
   return SLM_OK;
 }

@@ -264,6 +264,7 @@ struct slm_dataset {
   double L = 0.0;
   int L_iters = 0;
   bool L_valid = false;
+  bool sketch_valid = false;  // lambda[lane_cap] holds the sketch's estimate for the dataset's own rows and weights (solve_core)
   // Carried start (solve_core): what the last solve left on the device -- per lane the point zprev, its gradient gprev
   // and its loss -- described on the host so that the next solve can tell whether it starts exactly there.
   struct CarryLane {

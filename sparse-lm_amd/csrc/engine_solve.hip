@@ -499,6 +499,7 @@ extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y
   HIP_TRY(hipStreamSynchronize(s));
   if (y_mean_out) *y_mean_out = ymean;
   ds->L_valid = false;
+  ds->sketch_valid = false;
   ds->carry_valid = false;
   ds->XT_ready = false;  // X changed in place: the column-major copy is rebuilt on next use
   return SLM_OK;
@@ -990,6 +991,15 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   double L[SLM_MAX_CELLS];
   double lipschitz_ms = 0.0;
   bool L_on_device = false;  // the estimate stays on the device (no host round trip before the first pass)
+  bool L_kept = false;       // ... in the dataset's kept slot (lambda[lane_cap]) rather than in lane 0's
+  // the sketch's estimate for the dataset's own rows and weights, computed once and kept on the device
+  auto kept_sketch = [&]() -> int {
+    if (ds->sketch_valid && !(o.flags & SLM_FLAG_FRESH_L) && getenv("SLM_NO_SKETCH_CACHE") == nullptr) return SLM_OK;
+    SLM_TRY(power_iteration(ds, default_lanes(ds, 1), nullptr, sketch_iters(), sketch_rows(ds->n)));
+    HIP_TRY(hipMemcpyAsync(ds->lambda + ds->lane_cap, ds->lambda, sizeof(double), hipMemcpyDeviceToDevice, eng->stream));
+    ds->sketch_valid = true;
+    return SLM_OK;
+  };
   double L_factor[SLM_MAX_CELLS];  // ... and lane l uses L_factor[l] times it
   for (int l = 0; l < kMaxCells; ++l) L_factor[l] = 1.0;
   if (o.L > 0.0 || small) {  // (the on-chip solver bounds its own steps from the Gram matrix)
@@ -1015,7 +1025,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         //  estimates, all-reduced like every gradient, stay in use there)
         LaneSetup plain = default_lanes(ds, 1);
         plain.rw = nullptr;
-        SLM_TRY(power_iteration(ds, plain, nullptr, sketch_iters(), sketch_rows(n)));
+        if (ds->rw) {  // (not the dataset's own operator: not kept)
+          SLM_TRY(power_iteration(ds, plain, nullptr, sketch_iters(), sketch_rows(n)));
+        } else {
+          SLM_TRY(kept_sketch());
+          L_kept = true;
+        }
         for (int l = 0; l < B; ++l) {
           L[l] = 0.0;
           L_factor[l] = wmax[l] * (double)ds->n_global / (ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global);
@@ -1029,7 +1044,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         // (on a side stream beside the first pass, on vectors of its own, the seed saved nothing: the pass is bound by
         //  the memory system, and the 0.4 GB the three power steps read through it come out of the same budget -- 4.26 ms
         //  per path either way, profiles/r03a_seed_beside_ab.txt)
-        SLM_TRY(power_iteration(ds, default_lanes(ds, 1), nullptr, sketch_iters(), sketch_rows(n)));
+        // (the estimate belongs to the dataset -- its rows, its weights, nothing of the call: kept on the device beside the
+        //  lanes' values, like the bound of the full power iteration is kept on the host (estimate_lipschitz); 45 us of
+        //  four launches per solve otherwise)
+        SLM_TRY(kept_sketch());
+        L_kept = true;
         for (int l = 0; l < B; ++l) L[l] = 0.0;
         L_on_device = true;
       } else {
@@ -1218,7 +1237,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   HIP_TRY(hipMemsetAsync(ds->dctl, 0, offsetof(DevCtl, lane), s));  // stop words and working-set counters
   if (L_on_device) {  // the power steps are still in flight: their result goes into the control blocks on the device
     SeedArgs sa;
-    sa.ctl = ds->ctl; sa.lambda = ds->lambda; sa.n_lanes = B; sa.margin = 1.08;
+    sa.ctl = ds->ctl; sa.lambda = L_kept ? ds->lambda + ds->lane_cap : ds->lambda; sa.n_lanes = B; sa.margin = 1.08;
     for (int l = 0; l < kMaxLanes; ++l) sa.factor[l] = L_factor[l];
     hipLaunchKernelGGL(seed_step_kernel, dim3(1), dim3(64), 0, s, sa);
   }
@@ -1575,6 +1594,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
     expected = 1 + most;
   }
+  bool results_queued = false, results_final = false;  // the result copies were queued early / and hold the final state
   int final_slot = 0;          // the snapshot in which the host saw `done`
   bool deferred = false;       // the refinement behind the last queued pass has not been queued yet
   while (!done) {
@@ -1614,6 +1634,13 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     // gets a few more passes polled this way, then the pipelined polls.
     const bool at_end = expected > 0 && enq >= expected && enq < expected + 4;
     HIP_TRY(hipEventRecord(ds->ev[slot], s));
+    // behind the pass the solve is expected to end with, the results set off at once: when it does end there they are
+    // under way while the host still reads the snapshot (37 us of idle stream per path); when it does not, they are
+    // fetched again at the real end
+    if (expected > 0 && enq == expected && !results_queued) {
+      SLM_TRY(enqueue_result_copies());
+      results_queued = true;
+    }
     pending[slot] = true;
     const int other = slot ^ 1;
     if (at_end) {
@@ -1635,6 +1662,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       if (ds->hctl[slot].c.g.done) {
         done = true;
         final_slot = slot;
+        results_final = results_queued && enq == expected;  // (queued behind exactly this pass)
       } else if (deferred) {  // the solve goes on: what was held back, then the next pass
         enqueue_refinement();
         deferred = false;
@@ -1665,7 +1693,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       return fail(SLM_ERR_HIP, "internal error: path state machine did not terminate");
     }
   }
-  SLM_TRY(enqueue_result_copies());
+  if (!results_final) SLM_TRY(enqueue_result_copies());
   HIP_TRY(hipStreamSynchronize(s));
   tr[3] = t_mark();
   const DevCtl& snap = ds->hctl[final_slot].c;  // (nothing in the block changes after `done`)
