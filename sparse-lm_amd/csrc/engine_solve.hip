@@ -1251,6 +1251,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   ta.gdone = reinterpret_cast<int*>(ds->gctl);
   ta.n_lanes = B;
   ta.done_slot = sharded ? 3 : 0;
+  ta.provisional = 0;
   ta.steal = (shared_path && !interleave) ? 1 : 0;  // interleaved lanes are balanced by construction
   ta.pts = ds->pts;
   ta.p = (int)p;
@@ -1516,6 +1517,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       }
     }
   };
+  bool fix_start = false;  // the refinement being queued follows the pass on the row sample (sample start, below)
   auto enqueue_refinement = [&]() {
     if (use_ws) {
       {
@@ -1532,6 +1534,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         hipLaunchKernelGGL(ws_gram_cov_kernel, dim3(WS_TILES * WS_TILES, (unsigned)wa.n_sets), dim3(256), 0, s, wa, cs);
       } else {
       hipLaunchKernelGGL(ws_gather_kernel, dim3((unsigned)std::min<int64_t>((n + 31) / 32, 1024), WS_KCAP / 32), dim3(256), 0, s, wa);
+      if (fix_start) {  // the exact gradient at zero on W, from the gathered columns (ws_kernels.hpp (ii-b))
+        XtyArgs xa;
+        xa.ws = wa.ws; xa.idx = wa.idx; xa.XW = wa.XW; xa.y = ds->y; xa.part = ds->partial; xa.g = ds->g; xa.gprev = ds->gprev; xa.z = ds->z;
+        xa.ctl = ds->ctl; xa.done = done_flag; xa.n = n; xa.ld = ld; xa.inv_n = 1.0 / (double)ds->n_global; xa.n_lanes = B;
+        xa.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(2 * eng->cus, n / 64));
+        hipLaunchKernelGGL(ws_xty_partial_kernel, dim3((unsigned)xa.nblk), dim3(512), 0, s, xa);
+        hipLaunchKernelGGL(ws_xty_apply_kernel, dim3(WS_KCAP / 128), dim3(512), 0, s, xa);
+      }
       hipLaunchKernelGGL(ws_gram_kernel, dim3((unsigned)wa.nblk, (unsigned)wa.n_sets, 1), dim3(WS_GRAM_THREADS), 0, s,
                          wa);
       if (wa.Gx)  // (zero where this pass builds nothing, so the unconditional all-reduce below is harmless)
@@ -1594,6 +1604,25 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
     expected = 1 + most;
   }
+  // ---- sample start ------------------------------------------------------------------------------------------------
+  // A cold path on the interleaved lanes used to open with a pass over X for the gradient at zero, of which the solve
+  // uses two things: the choice of the first working set, and -- on it -- the exact linear term of the model.  The choice
+  // needs the ranking of |X_j^T y|, which an eighth of the rows gives (a feature that enters on the first band of alphas
+  // stands far above the sampling noise); the linear term on W is X_W^T y, one read of the gathered columns.  So the path
+  // opens on the first n / 8 rows (70 us instead of 570), nothing is accepted on that estimate (TailArgs::provisional),
+  // the model of the first refinement is exact on W, and the first pass over ALL of X already verifies the first band:
+  // 4 passes per 50-alpha path instead of 5.  What the sample ranks wrongly the verification finds (a miss: the columns
+  // are appended and the point is verified again, as after any pass) -- rows in an order that makes their head
+  // unrepresentative cost a pass, not a digit.  SLM_NO_SAMPLE_START=1 opens on all rows.
+  int64_t n_sample = 0;
+  {
+    bool cold = true;
+    for (int l = 0; l < B; ++l) cold = cold && lanes[l].beta0 == nullptr;
+    if (cold && shared_path && interleave && use_ws && !ws_late && !sharded && !cov_on && split && !any_rw && !ds->rw &&
+        !custom_scale && expected > 0 && o.max_iter >= 4 && n >= 65536 && getenv("SLM_NO_SAMPLE_START") == nullptr)
+      n_sample = n / 8;
+  }
+  const int64_t prof_off = n_sample > 0 ? 1 : 0;  // (the pass on the sample is no launch of the roofline's kernel on X)
   bool results_queued = false, results_final = false;  // the result copies were queued early / and hold the final state
   int final_slot = 0;          // the snapshot in which the host saw `done`
   bool deferred = false;       // the refinement behind the last queued pass has not been queued yet
@@ -1605,8 +1634,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       const int this_chunk = expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(64, expected - enq) : 1);
       for (int i = 0; i < this_chunk; ++i) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (profile && enq % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time
-          const int64_t slot_id = enq / kProfStride;
+        if (profile && enq >= prof_off && (enq - prof_off) % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time
+          const int64_t slot_id = (enq - prof_off) / kProfStride;
           while ((int64_t)ds->prof.size() < 2 * (slot_id + 1)) {
             hipEvent_t ev;
             HIP_TRY(hipEventCreate(&ev));
@@ -1615,13 +1644,25 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
           e0 = ds->prof[2 * slot_id];
           e1 = ds->prof[2 * slot_id + 1];
         }
-        if (!(carry && enq == 0)) SLM_TRY(enqueue_pass_gradient(e0, e1));  // (a carried start has its first gradient)
-        enqueue_tail();
+        const bool sample_pass = n_sample > 0 && enq == 0;
+        if (sample_pass) {
+          LaneSetup part = ls;
+          for (int l = 0; l < kMaxLanes; ++l) part.n_eff[l] = (double)ds->n_global * (double)n_sample / (double)n;
+          SLM_TRY(enqueue_gradient_split(ds, part, ds->y, done_flag, ds->ctl, &wa, nullptr, nullptr, n_sample));
+          TailArgs first = ta;
+          first.provisional = 1;
+          launch_tail(first, s);
+        } else {
+          if (!(carry && enq == 0)) SLM_TRY(enqueue_pass_gradient(e0, e1));  // (a carried start has its first gradient)
+          enqueue_tail();
+        }
+        fix_start = sample_pass;
         ++enq;
         // behind the pass the solve is expected to end with, the six launches of the refinement would only find
         // out that there is nothing left to refine (30 us): they follow once the snapshot says otherwise
         deferred = expected > 0 && enq == expected && !sharded;
         if (!deferred) enqueue_refinement();
+        fix_start = false;
       }
       SLM_TRY(check_launch());
       if (ws_comm_rc != 0) return ws_comm_rc;  // (all_reduce_sum has set the message)
@@ -1715,14 +1756,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     nonfinite = nonfinite || fin[l].nonfinite;
   }
   if (stats) {
-    stats->grad_launches = passes - (carry ? 1 : 0);  // launches that did work (every launch serves all lanes)
+    stats->grad_launches = passes - (carry ? 1 : 0) - prof_off;  // launches over the data that did work (every launch serves all lanes)
     stats->grad_ms_total = 0.0;
     stats->grad_timed = 0;
     if (profile) {
       double tot = 0.0;
       int64_t cnt = 0;
       // iterations 0, kProfStride, 2 kProfStride, ... below `passes` did real work and were timed
-      for (int64_t k = 0; k * kProfStride < passes && 2 * k + 1 < (int64_t)ds->prof.size(); ++k) {
+      for (int64_t k = 0; k * kProfStride < passes - prof_off && 2 * k + 1 < (int64_t)ds->prof.size(); ++k) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ds->prof[2 * k], ds->prof[2 * k + 1]) == hipSuccess) {
           tot += ms;

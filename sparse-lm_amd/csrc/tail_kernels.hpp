@@ -107,6 +107,9 @@ struct TailArgs {
                               // the ranks have all-reduced, so that every rank stops after the same pass
                               // (and enters the same number of collectives) whatever its own state says
   int n_lanes;
+  int provisional;            // 1 => the gradient of this call is an estimate (the first call of a path that opens on a row
+                              // sample, solve_core "sample start"): it steers the step and the working set, and no point
+                              // is accepted on it
   int steal;                  // 1 => all lanes walk ONE path: an idle lane takes over the upper half of
                               //      the points the busiest lane has not reached yet (cold start)
   const slm_path_point* pts;  // concatenated over lanes
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       if (mu_ws > 0.0) mu_eff = fmin(mu_eff, mu_ws);
       mu_eff = fmax(mu_eff, kMuFloor * new_Lhat);
       // (second term: a prox step at the rounding level of the gradient itself cannot be improved)
-      conv = kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[5]) + new_Lhat * bnorm));
+      conv = !a.provisional && kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[5]) + new_Lhat * bnorm));
       finalize = nonfinite || conv || hit_max;
     }
   } else {
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
     mu_eff = mu_ws > 0.0 ? fmin(mu_ws, L) : L;
     if (new_mu_rq > 0.0) mu_eff = fmin(mu_eff, new_mu_rq);
     mu_eff = fmax(mu_eff, kMuFloor * L);
-    conv = !l_bad && (kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[7]) + L * bnorm)));
+    conv = !a.provisional && !l_bad && (kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[7]) + L * bnorm)));
     finalize = nonfinite || conv || hit_max;
     new_t = l_bad ? 1.0 : t_new;
 #pragma unroll
@@ -985,7 +988,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
       if (new_mu_rq > 0.0) mu_eff = fmin(mu_eff, new_mu_rq);
       if (mu_ws > 0.0) mu_eff = fmin(mu_eff, mu_ws);
       mu_eff = fmax(mu_eff, kMuFloor * new_Lhat);
-      conv = kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[5]) + new_Lhat * bnorm));
+      conv = !a.provisional && kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[5]) + new_Lhat * bnorm));
       finalize = nonfinite || conv || hit_max;
     }
   } else {
@@ -1038,7 +1041,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
     mu_eff = mu_ws > 0.0 ? fmin(mu_ws, L) : L;
     if (new_mu_rq > 0.0) mu_eff = fmin(mu_eff, new_mu_rq);
     mu_eff = fmax(mu_eff, kMuFloor * L);
-    conv = !l_bad && (kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[7]) + L * bnorm)));
+    conv = !a.provisional && !l_bad && (kkt <= fmax(tol * fmax(bnorm, bnorm_floor) * mu_eff, kRoundFloor * (sqrt(s[7]) + L * bnorm)));
     finalize = nonfinite || conv || hit_max;
     new_t = l_bad ? 1.0 : t_new;
   }

@@ -588,6 +588,119 @@ static __global__ __launch_bounds__(256) void ws_gather_kernel(WsArgs w) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// (ii-b) A path that opened on a row sample (solve_core, "sample start"): the gradient at zero the first call worked
+// with is an estimate -- good enough to choose W, not to build the model on.  On W the exact one costs one read of
+// the gathered columns, not of X: c_k = -X_k^T y / n, and the loss at zero is y^T y / 2n.  Two launches: partial
+// sums over row blocks, then the sums go into g and gprev of every lane (all lanes stand at zero), the loss
+// into g[ld], the first entry of the objective history and PathCtl::loss_base.  No row weights (the caller checks).
+// ---------------------------------------------------------------------------------------------
+struct XtyArgs {
+  const WsCtl* ws;
+  const int32_t* idx;
+  const double* XW;
+  const double* y;
+  double* part;     // [nblk][WS_KCAP + 1]: per block the sums of every position and, last, of y^2
+  double* g;        // [lanes][ld + 16]
+  double* gprev;    // [lanes][ld]
+  double* z;        // [lanes][ld]: the model solves start from zero on W (the candidate of the first call is a step along the estimate)
+  PathCtl* ctl;
+  const int* done;
+  int64_t n, ld;
+  double inv_n;
+  int n_lanes, nblk;
+};
+static __global__ __launch_bounds__(512) void ws_xty_partial_kernel(XtyArgs a) {
+  if (*a.done) return;
+  __shared__ double red[8][WS_KCAP];
+  __shared__ double red_yy[8];
+  const int K = a.ws->K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t rows = (a.n + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * rows, i1 = i0 + rows < a.n ? i0 + rows : a.n;
+  // a wavefront per row (rows i0 + wave, + 8, ...), a lane per position of each chunk of 64: the loads of a row are one
+  // contiguous segment, and eight rows are in flight per workgroup
+  double acc[WS_KCAP / 64];
+#pragma unroll
+  for (int c = 0; c < WS_KCAP / 64; ++c) acc[c] = 0.0;
+  double yy = 0.0;
+#pragma unroll 4
+  for (int64_t i = i0 + wave; i < i1; i += 8) {
+    const double yi = a.y[i];
+    yy = __builtin_fma(yi, yi, yy);
+#pragma unroll
+    for (int c = 0; c < WS_KCAP / 64; ++c) {
+      const int k = lane + 64 * c;
+      if (64 * c < K) acc[c] = __builtin_fma(k < K ? a.XW[i * WS_KCAP + k] : 0.0, yi, acc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < WS_KCAP / 64; ++c) red[wave][lane + 64 * c] = acc[c];
+  if (lane == 0) red_yy[wave] = yy;
+  __syncthreads();
+  double* out = a.part + (int64_t)blockIdx.x * (WS_KCAP + 1);
+  const int k = threadIdx.x;
+  if (k < K) {
+    double sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += red[w][k];
+    out[k] = sum;
+  }
+  if (k == WS_KCAP - 1) {
+    double sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += red_yy[w];
+    out[WS_KCAP] = sum;
+  }
+}
+// grid: WS_KCAP / 128 workgroups of 512 threads -- 128 positions each, four threads per position that take every
+// fourth row block (eight loads in flight each: one thread per position walked the 512 blocks one load at a time, 122 us)
+static __global__ __launch_bounds__(512) void ws_xty_apply_kernel(XtyArgs a) {
+  if (*a.done) return;
+  __shared__ double red[4][128];
+  __shared__ double ry[512];
+  const int K = a.ws->K;
+  const int kl = threadIdx.x & 127, q = threadIdx.x >> 7;
+  const int k = (int)blockIdx.x * 128 + kl;
+  if ((int)blockIdx.x * 128 >= K) return;  // (uniform for the workgroup)
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (k < K) {
+    int b = q;
+    for (; b + 28 < a.nblk; b += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += a.part[(int64_t)(b + 4 * u) * (WS_KCAP + 1) + k];
+    }
+    for (; b < a.nblk; b += 4) s[0] += a.part[(int64_t)b * (WS_KCAP + 1) + k];
+  }
+  red[q][kl] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  if (blockIdx.x == 0) ry[threadIdx.x] = (int)threadIdx.x < a.nblk ? a.part[(int64_t)threadIdx.x * (WS_KCAP + 1) + WS_KCAP] : 0.0;
+  __syncthreads();
+  if (q == 0 && k < K) {
+    const int j = a.idx[k];
+    if (j >= 0) {
+      const double c = -((red[0][kl] + red[1][kl]) + (red[2][kl] + red[3][kl])) * a.inv_n;
+      for (int l = 0; l < a.n_lanes; ++l) {
+        a.g[(int64_t)l * (a.ld + 16) + j] = c;
+        a.gprev[(int64_t)l * a.ld + j] = c;
+        a.z[(int64_t)l * a.ld + j] = 0.0;
+      }
+    }
+  }
+  if (blockIdx.x == 0) {  // the loss at zero: the row blocks' sums of y^2, folded in a fixed order (nblk <= 512)
+    for (int off = 256; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off) ry[threadIdx.x] += ry[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x < (unsigned)a.n_lanes) {
+      const int l = threadIdx.x;
+      const double loss0 = 0.5 * ry[0] * a.inv_n;
+      a.g[(int64_t)l * (a.ld + 16) + a.ld] = loss0;
+      a.ctl[l].hist[0] = loss0;  // (the penalty at zero is zero)
+      a.ctl[l].loss_base = loss0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // (iii) partial Grams with v_mfma_f64_16x16x4_f64.  Grid (nblk, n_sets); 8 wavefronts per
 // workgroup laid out 4 x 2, each owning a 4 x 4 block of 16x16 output tiles, so a workgroup covers
 // 256 x 128 of the 512 x 512 capacity at a time and walks the slices that exist (2 row halves x 4 column
