@@ -1618,9 +1618,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   {
     bool cold = true;
     for (int l = 0; l < B; ++l) cold = cold && lanes[l].beta0 == nullptr;
-    if (cold && shared_path && interleave && use_ws && !ws_late && !sharded && !cov_on && split && !any_rw && !ds->rw &&
-        !custom_scale && expected > 0 && o.max_iter >= 4 && n >= 65536 && getenv("SLM_NO_SAMPLE_START") == nullptr)
-      n_sample = n / 8;
+    if (cold && shared_path && (interleave || !getenv("SLM_SAMPLE_START_INTERLEAVED_ONLY")) && use_ws && !ws_late && !sharded && !cov_on && split && !any_rw && !ds->rw &&
+        !custom_scale && expected > 0 && o.max_iter >= 4 && !(o.flags & SLM_FLAG_FISTA_ONLY) && getenv("SLM_NO_SAMPLE_START") == nullptr) {
+      int64_t least = 65536;  // (below it a pass costs little more than the launches of the sample's)
+      if (const char* e = getenv("SLM_SAMPLE_START_MIN_ROWS")) least = std::max<int64_t>(64, atoll(e));  // (tests)
+      if (n >= least) n_sample = n / 8;
+    }
   }
   const int64_t prof_off = n_sample > 0 ? 1 : 0;  // (the pass on the sample is no launch of the roofline's kernel on X)
   bool results_queued = false, results_final = false;  // the result copies were queued early / and hold the final state

@@ -715,8 +715,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       ctl->iter = iter + 1;
       atomicMax(&a.gdone[2], iter + 1);  // GlobalCtl::hard: lets the host give a hard problem the working set
       ctl->t = new_t;
-      ctl->have_base = new_have_base;
-      ctl->n_hist = new_n_hist;
+      // (a call on an estimated gradient leaves no base behind: the first true gradient starts the history, and a
+      //  rejection can never fall back on the estimate)
+      ctl->have_base = a.provisional ? 0 : new_have_base;
+      ctl->n_hist = a.provisional ? 0 : new_n_hist;
       ctl->pen_z = new_pen_z;
       ctl->mu_rq = new_mu_rq;
 #pragma unroll
@@ -1137,8 +1139,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
       ctl->iter = iter + 1;
       atomicMax(&a.gdone[2], iter + 1);
       ctl->t = new_t;
-      ctl->have_base = new_have_base;
-      ctl->n_hist = new_n_hist;
+      // (a call on an estimated gradient leaves no base behind: the first true gradient starts the history, and a
+      //  rejection can never fall back on the estimate)
+      ctl->have_base = a.provisional ? 0 : new_have_base;
+      ctl->n_hist = a.provisional ? 0 : new_n_hist;
       ctl->pen_z = new_pen_z;
       ctl->mu_rq = new_mu_rq;
 #pragma unroll

@@ -465,3 +465,56 @@ def test_lanes_that_share_a_gram_give_the_same_bits_every_time():
     for run in runs[1:]:
         for a, b in zip(runs[0], run):
             np.testing.assert_array_equal(a.betas, b.betas)
+
+
+def test_cold_shared_paths_open_on_a_row_sample(eng, monkeypatch):
+    """Sample start (solve_core): a cold shared path chooses its first working set from an eighth of the rows, builds the
+    model with the exact X_W^T y, and lets the first pass over X verify the first band -- one pass fewer, the same
+    coefficients.  A head of rows that says nothing about the rest (here: rows ordered by |y|, the sample sees the
+    smallest targets only) may cost that pass again, never a digit."""
+    rng = np.random.default_rng(17)
+    n, p = 70000, 320
+    X = rng.standard_normal((n, p))
+    beta = np.zeros(p)
+    beta[rng.choice(p, 12, replace=False)] = rng.uniform(1, 6, 12) * rng.choice([-1, 1], 12)
+    y = X @ beta + 2.0 * rng.standard_normal(n)
+    amax = np.max(np.abs(X.T @ y)) / n
+    pts = [(a, 0, 0) for a in np.geomspace(amax, 5e-3 * amax, 40)]
+    with eng.dataset(X, y) as ds:
+        fast = ds.solve_path(pts, tol=1e-10, lanes=16, flags=WS)
+        monkeypatch.setenv("SLM_NO_SAMPLE_START", "1")
+        full = ds.solve_path(pts, tol=1e-10, lanes=16, flags=WS)
+        monkeypatch.delenv("SLM_NO_SAMPLE_START")
+        plain = ds.solve_path(pts, tol=1e-11, lanes=4, flags=NO_WS)
+    assert fast.converged and full.converged and plain.converged
+    assert fast.grad_launches == full.grad_launches - 1, (fast.grad_launches, full.grad_launches)
+    assert rel_inf(fast.betas, plain.betas) < 1e-8 and rel_inf(full.betas, plain.betas) < 1e-8
+
+    # small problems (the sample forced on), heads of rows that mislead, group penalties on contiguous ranges
+    monkeypatch.setenv("SLM_SAMPLE_START_MIN_ROWS", "64")
+    for case in range(6):
+        n, p = int(rng.integers(1500, 6000)), int(rng.integers(120, 700))
+        X = rng.standard_normal((n, p))
+        beta = np.zeros(p)
+        nz = rng.choice(p, int(rng.integers(3, 30)), replace=False)
+        beta[nz] = rng.standard_normal(len(nz)) * 3
+        y = X @ beta + rng.standard_normal(n)
+        if case % 2 == 0:  # the sample sees the rows with the smallest targets only
+            order = np.argsort(np.abs(y))
+            X, y = np.ascontiguousarray(X[order]), y[order]
+        groups = None if case < 3 else rng.integers(0, 25, p)
+        lanes = int(rng.choice([4, 8, 16]))
+        with eng.dataset(X, y) as ds:
+            if groups is not None:
+                ds.set_groups(groups, 25)
+                c = X.T @ y / n
+                top = np.max(np.sqrt(np.bincount(groups, weights=c * c, minlength=25)))
+                pts = [(0.0, a, 0.0) for a in np.geomspace(top, 0.02 * top, 24)]
+            else:
+                amax = np.max(np.abs(X.T @ y)) / n
+                pts = [(a, 0, 0) for a in np.geomspace(amax, 0.01 * amax, 33)]
+            r = ds.solve_path(pts, tol=1e-10, lanes=lanes, flags=WS)
+            q = ds.solve_path(pts, tol=1e-11, lanes=min(lanes, 4), flags=NO_WS)
+        assert r.converged and q.converged, case
+        assert np.all(r.n_iter >= 1), case
+        assert rel_inf(r.betas, q.betas) < 1e-7, (case, rel_inf(r.betas, q.betas))
