@@ -1605,7 +1605,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     expected = 1 + most;
   }
   // ---- sample start ------------------------------------------------------------------------------------------------
-  // A cold path on the interleaved lanes used to open with a pass over X for the gradient at zero, of which the solve
+  // A cold path -- no lane brings a warm start -- used to open with a pass over X for the gradient at zero, of which the solve
   // uses two things: the choice of the first working set, and -- on it -- the exact linear term of the model.  The choice
   // needs the ranking of |X_j^T y|, which an eighth of the rows gives (a feature that enters on the first band of alphas
   // stands far above the sampling noise); the linear term on W is X_W^T y, one read of the gathered columns.  So the path
@@ -1614,11 +1614,15 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // 4 passes per 50-alpha path instead of 5.  What the sample ranks wrongly the verification finds (a miss: the columns
   // are appended and the point is verified again, as after any pass) -- rows in an order that makes their head
   // unrepresentative cost a pass, not a digit.  SLM_NO_SAMPLE_START=1 opens on all rows.
+  // Paths only: their first band sits at the top of the alpha range, where what enters stands far above the sampling
+  // noise.  A single cold point at a small alpha admits features the sample cannot tell from noise -- measured on the
+  // headline's data (tools/single_fit_big.py): 1.51 -> 1.01 ms at 0.3 alpha_max, 1.53 -> 1.91 ms at 0.05 (a miss and its
+  // append on top of the sample's launches), 2.33 -> 1.92 ms at 0.005; SLM_SAMPLE_START_ALL=1 takes that gamble.
   int64_t n_sample = 0;
   {
     bool cold = true;
     for (int l = 0; l < B; ++l) cold = cold && lanes[l].beta0 == nullptr;
-    if (cold && shared_path && (interleave || !getenv("SLM_SAMPLE_START_INTERLEAVED_ONLY")) && use_ws && !ws_late && !sharded && !cov_on && split && !any_rw && !ds->rw &&
+    if (cold && (shared_path || getenv("SLM_SAMPLE_START_ALL")) && use_ws && !ws_late && !sharded && !cov_on && split && !any_rw && !ds->rw &&
         !custom_scale && expected > 0 && o.max_iter >= 4 && !(o.flags & SLM_FLAG_FISTA_ONLY) && getenv("SLM_NO_SAMPLE_START") == nullptr) {
       int64_t least = 65536;  // (below it a pass costs little more than the launches of the sample's)
       if (const char* e = getenv("SLM_SAMPLE_START_MIN_ROWS")) least = std::max<int64_t>(64, atoll(e));  // (tests)
