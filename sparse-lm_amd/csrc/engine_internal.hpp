@@ -98,7 +98,7 @@ static const int kMaxTailE = 64;  // the tail kernels cover p <= 1024 * 64
 static const int64_t kMaxChunks = 64 * 8 * 10;  // largest row the fused kernel covers (p <= 10240)
 const SplitKernel* pick_split_kernel(int64_t p2);
 int xtr_max_row_blocks(int cus, int64_t ld);
-int launch_xtr(int cus, SplitArgs& a, hipStream_t s);
+int launch_xtr(int cus, SplitArgs& a, hipStream_t s, bool sample = false);
 const GradKernel* pick_grad_kernel(int64_t p2, int B);
 
 // ------------------------------------------------------------------------------------------------

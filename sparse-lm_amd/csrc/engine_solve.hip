@@ -77,7 +77,7 @@ int xtr_max_row_blocks(int cus, int64_t ld) {  // (sizes the partial buffer: the
   return std::max(1, 2 * cus / xb);
 }
 // sets a.xrows; returns the number of row blocks (= blocks of `partial` to reduce)
-int launch_xtr(int cus, SplitArgs& a, hipStream_t s) {
+int launch_xtr(int cus, SplitArgs& a, hipStream_t s, bool sample) {
   const int xb = (int)((a.ld + XTR_CB - 1) / XTR_CB);
   double per_cu = 1.0;
   if (const char* e = getenv("SLM_XTR_WGS_PER_CU")) {  // (A/B runs: workgroups per CU, up to 2)
@@ -89,7 +89,8 @@ int launch_xtr(int cus, SplitArgs& a, hipStream_t s) {
   rows = (rows + 7) / 8 * 8;
   const int yb = (int)((a.n + rows - 1) / rows);  // <= want
   a.xrows = (int)rows;
-  hipLaunchKernelGGL(xtr_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+  if (sample) hipLaunchKernelGGL(xtr_sample_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+  else hipLaunchKernelGGL(xtr_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
   return yb;
 }
 
@@ -260,7 +261,7 @@ int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y
   }
   // (SLM_FLAG_PROFILE brackets the kernel that streams X, the one the roofline is quoted on)
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
-  const int xblk = launch_xtr(ds->eng->cus, a, s);
+  const int xblk = launch_xtr(ds->eng->cus, a, s, n_rows > 0 && ctl != nullptr);  // (rows of a sample start: solve_core)
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
   ReduceArgs ra;
   ra.partial = ds->partial;

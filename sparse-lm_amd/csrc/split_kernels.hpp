@@ -345,7 +345,7 @@ constexpr int XTR_CW = 128;                    // columns per wavefront
 constexpr int XTR_CB = XTR_WAVES * XTR_CW;     // columns per workgroup
 constexpr int XTR_U = 2;                       // 4-row steps per batch
 
-static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a) {
+__device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
   static_assert(SPLIT_RSTRIDE == 16 && SPLIT_LANES <= 16, "a row of R is the 16-wide B operand");
   if (a.done != nullptr && *a.done != 0) return;
   const int lane = threadIdx.x & 63;
@@ -451,6 +451,11 @@ static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(Spli
         }
   }
 }
+
+static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a) { xtr_mfma_body(a); }
+// the same product over the head of the rows only (solve_core's sample start): a name of its own, so that a profile's
+// per-kernel statistics of xtr_mfma_kernel are those of passes over all of X
+static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_sample_kernel(SplitArgs a) { xtr_mfma_body(a); }
 
 // ---------------------------------------------------------------------------------------------
 // The first half on the matrix cores as well: R[row][l] = w_l,row (x_row . z_l - y_row) for ALL sixteen lane
