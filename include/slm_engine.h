@@ -273,6 +273,16 @@ typedef struct slm_solve_stats {
  * queues iterations and polls a flag.  betas_out: n_points x p (C-order, host);
  * group_norms_out: n_points x G (nullable); infos: n_points (nullable); stats nullable.
  * n_points == 1 is the plain _solve().
+ *
+ * Two things the solves of a dataset do with what the data already told them (working-set solves on a large X; every
+ * reported point is verified by a gradient over all rows under the unchanged rule either way):
+ *  - carried start: when beta0 of every lane is, bit for bit, the solution the dataset's LAST solve reported for that
+ *    lane -- over the same rows and row weights; the penalty may differ: the rounds of an Adaptive* estimator
+ *    (model/_adaptive_lasso.py:206-232), a refit -- the solve starts at the point whose gradient the engine still holds
+ *    (within the tolerance of beta0) and does not run its first pass over the data.  SLM_NO_CARRY=1 turns it off.
+ *  - sample start: a path on several lanes without a warm start opens on the first eighth of the rows -- enough to
+ *    rank the features for the first working set, on which the model's linear term is then formed exactly from the
+ *    gathered columns; nothing is accepted on the estimate.  SLM_NO_SAMPLE_START=1 opens on all rows.
  */
 int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,
                    int32_t n_points, const slm_solve_opts* opts, const double* beta0,
