@@ -33,8 +33,21 @@ static __global__ __launch_bounds__(256) void cov_pack_kernel(const double* z, i
 // rows of G listed in `idx` can contribute: the workgroups then read those rows (a.xrows_ws of the list each: indices first,
 // then all loads of the block at once) -- 8 K ld bytes, 12 MB at K = 300, instead of the 200 MB of G, 8-10 us instead of 37
 // per row set and pass.  Plain steps (zsup = 0), a working set under construction, or no working set at all: every row.
-static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void cov_gz_mfma_kernel(SplitArgs a) {
+// The row sets of a call (the folds its lanes train on) go in ONE launch, a grid slice (blockIdx.z) each: their products are
+// independent, and one after the other each was too small to fill the device (2.3 launches of 25 us per pass of config 4's
+// grid where one of 30 does; the same for the two kernels that finish a pass).
+struct CovBatch {
+  const double* G[SLM_MAX_LANES];   // per row set: the Gram [ld][ld] ...
+  const double* c[SLM_MAX_LANES];   // ... X^T W y / n [ld] ...
+  double yy[SLM_MAX_LANES];         // ... and y^T W y / n
+  int32_t set_of[SLM_MAX_LANES];    // row set of lane l
+  int64_t part_stride;              // doubles between the partial sums of two row sets
+};
+
+static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void cov_gz_mfma_kernel(SplitArgs a, CovBatch cb) {
   if (a.done != nullptr && *a.done != 0) return;
+  a.X = cb.G[blockIdx.z];
+  a.partial += (int64_t)blockIdx.z * cb.part_stride;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   int bx = (int)blockIdx.x, by = (int)blockIdx.y;
@@ -163,22 +176,21 @@ static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void cov_gz_mfma_kernel(S
 }
 
 struct CovFinishArgs {
-  const double* partial;  // [nblk][16][ld] of xtr_mfma_kernel
-  const double* c;        // [ld]
+  const double* partial;  // [row sets][nblk][16][ld] of cov_gz_mfma_kernel
   const double* z;        // [lanes][ld]
   double* g;              // [lanes][ld + 16]
   const int* done;
   int nblk;
   int64_t ld;
-  uint32_t lane_mask;     // lanes of THIS row set
-  double yy;              // y^T W y / n of the row set
 };
 
 // grid = (ld / 16, lanes): g_l[col] = sum_blk partial[blk][l][col] - c[col]   (fixed order: bit-identical run to run)
-static __global__ __launch_bounds__(256) void cov_reduce_kernel(CovFinishArgs a) {
+static __global__ __launch_bounds__(256) void cov_reduce_kernel(CovFinishArgs a, CovBatch cb) {
   if (a.done != nullptr && *a.done != 0) return;
   const int lane = blockIdx.y;
-  if (!((a.lane_mask >> lane) & 1u)) return;
+  const int set = cb.set_of[lane];
+  a.partial += (int64_t)set * cb.part_stride;
+  const double* c = cb.c[set];
   __shared__ double lds[16][17];
   const int tid = threadIdx.x, cl = tid & 15, slice = tid >> 4;
   const int64_t col = (int64_t)blockIdx.x * 16 + cl;
@@ -190,27 +202,28 @@ static __global__ __launch_bounds__(256) void cov_reduce_kernel(CovFinishArgs a)
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += lds[k][cl];
-    a.g[(int64_t)lane * (a.ld + 16) + col] = t - a.c[col];
+    a.g[(int64_t)lane * (a.ld + 16) + col] = t - c[col];
   }
 }
 
 // grid = lanes, 256 threads: loss_l = 1/2 sum_j z_j (g_j - c_j) + 1/2 yy  (g = G z - c already), into g_l[ld]
-static __global__ __launch_bounds__(256) void cov_loss_kernel(CovFinishArgs a) {
+static __global__ __launch_bounds__(256) void cov_loss_kernel(CovFinishArgs a, CovBatch cb) {
   if (a.done != nullptr && *a.done != 0) return;
   const int lane = blockIdx.x;
-  if (!((a.lane_mask >> lane) & 1u)) return;
+  const double* c = cb.c[cb.set_of[lane]];
+  const double yy = cb.yy[cb.set_of[lane]];
   __shared__ double red[256];
   const double* z = a.z + (int64_t)lane * a.ld;
   double* g = a.g + (int64_t)lane * (a.ld + 16);
   double s = 0.0;
-  for (int64_t j = threadIdx.x; j < a.ld; j += 256) s = __builtin_fma(z[j], g[j] - a.c[j], s);
+  for (int64_t j = threadIdx.x; j < a.ld; j += 256) s = __builtin_fma(z[j], g[j] - c[j], s);
   red[threadIdx.x] = s;
   __syncthreads();
   for (int w = 128; w >= 1; w >>= 1) {
     if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) g[a.ld] = 0.5 * red[0] + 0.5 * a.yy;
+  if (threadIdx.x == 0) g[a.ld] = 0.5 * red[0] + 0.5 * yy;
 }
 
 // The working set's Gram under covariance passes: G_WW is a sub-matrix of the row set's Gram -- no gathered columns, no

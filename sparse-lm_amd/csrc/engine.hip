@@ -346,7 +346,7 @@ static void dataset_free(slm_dataset* ds) {
   ds->cov.clear();
   ds->cov_all_hold.reset();
   ds->cov_all = nullptr;
-  dfree(ds->cov_Z); dfree(ds->cov_fp);
+  dfree(ds->cov_Z); dfree(ds->cov_fp); dfree(ds->cov_partial);
   if (ds->h_split) (void)hipHostFree(ds->h_split);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   if (ds->h_vec) (void)hipHostFree(ds->h_vec);
@@ -432,6 +432,7 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
   A(dalloc(&ds->yzero, n));
   if (ds->gk[0]->D < 0) A(dalloc(&ds->rvec, n));
   A(dalloc(&ds->partial, partial_elems));
+  ds->partial_elems = partial_elems;
   A(dalloc(&ds->loss_partial, loss_elems));
   A(dalloc(&ds->g, ML * (ld + 16)));
   A(dalloc(&ds->z, ML * ld));

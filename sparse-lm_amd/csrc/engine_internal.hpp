@@ -231,6 +231,9 @@ struct slm_dataset {
   std::shared_ptr<CovBlocks> cov_all_hold;
   double* cov_all = nullptr;  // X^T X of all rows, unscaled (the minuend of fold Grams), built on first use (= cov_all_hold->G)
   double* cov_Z = nullptr;    // [ld][16] the lanes' points, lane-minor
+  double* cov_partial = nullptr;  // partial sums of a covariance pass over more row sets than `partial` holds
+  int cov_partial_sets = 0;
+  size_t partial_elems = 0;   // doubles in `partial`
   double* cov_fp = nullptr;   // [2 * kMaxLanes + 2] fingerprints / scalars on their way to the host
   double* split_state = nullptr;  // [3 ld + 2 + record] slm_solve_standardized_sgl: gamma, u, rho, valid; outputs
   double* h_split = nullptr;      // its page-locked staging: a, b, warm start in; coefficients, group norms, record out

@@ -96,7 +96,7 @@ int launch_xtr(int cus, SplitArgs& a, hipStream_t s, bool sample) {
 
 // the product of a covariance pass (cov_gz_mfma_kernel): xtr_mfma_kernel's grid; when only the working set's rows are read a
 // workgroup row takes the next multiple of four of WS_KCAP / row blocks list entries (at most 32: eight steps in registers)
-static int launch_cov_gz(int cus, SplitArgs& a, hipStream_t s) {
+static int launch_cov_gz(int cus, SplitArgs& a, hipStream_t s, const CovBatch& cb, int n_sets) {
   const int xb = (int)((a.ld + XTR_CB - 1) / XTR_CB);
   const int64_t want = std::max<int64_t>(1, xtr_max_row_blocks(cus, a.ld) / 2);
   int64_t rows = (a.n + want - 1) / want;
@@ -105,7 +105,7 @@ static int launch_cov_gz(int cus, SplitArgs& a, hipStream_t s) {
   a.xrows = (int)rows;
   const int per = ((WS_KCAP + yb - 1) / yb + 3) / 4 * 4;
   a.xrows_ws = (a.ctl != nullptr && per <= 32) ? per : 0;
-  hipLaunchKernelGGL(cov_gz_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+  hipLaunchKernelGGL(cov_gz_mfma_kernel, dim3(xb, yb, (unsigned)n_sets), dim3(XTR_WAVES * 64), 0, s, a, cb);
   return yb;
 }
 
@@ -291,29 +291,46 @@ static int enqueue_gradient_cov(slm_dataset* ds, int B, const int* entry_of, con
   const int64_t ld = ds->ld;
   hipLaunchKernelGGL(cov_pack_kernel, dim3((unsigned)((ld * SPLIT_RSTRIDE + 255) / 256)), dim3(256), 0, s, ds->z, ld, B, ds->cov_Z, done);
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
-  bool seen[SLM_MAX_LANES] = {};
+  // the row sets of the call, in order of their first lane
+  CovBatch cb;
+  memset(&cb, 0, sizeof(cb));
+  int n_sets = 0, entry_of_set[SLM_MAX_LANES];
   for (int l = 0; l < B; ++l) {
-    if (seen[l]) continue;
-    uint32_t mask = 0;
-    for (int m = l; m < B; ++m)
-      if (entry_of[m] == entry_of[l]) {
-        mask |= 1u << m;
-        seen[m] = true;
-      }
-    const slm_dataset::CovEntry& e = ds->cov[(size_t)entry_of[l]];
-    SplitArgs a;
-    memset(&a, 0, sizeof(a));
-    a.X = e.G; a.R = ds->cov_Z; a.partial = ds->partial; a.done = done;
-    a.n = ld; a.ld = ld; a.p2 = (int)(ld / 2); a.n_lanes = B;
-    // (points the model solver produced are zero outside the working set: only its rows of G are read then)
-    if (ctl && wa && wa->ws && !getenv("SLM_COV_ALL_ROWS")) { a.ctl = ctl; a.ws = wa->ws; a.idx = wa->idx; }
-    const int xblk = launch_cov_gz(ds->eng->cus, a, s);
-    CovFinishArgs f;
-    f.partial = ds->partial; f.c = e.c; f.z = ds->z; f.g = ds->g; f.done = done; f.nblk = xblk; f.ld = ld;
-    f.lane_mask = mask; f.yy = e.yy;
-    hipLaunchKernelGGL(cov_reduce_kernel, dim3((unsigned)(ld / 16), (unsigned)B), dim3(256), 0, s, f);
-    hipLaunchKernelGGL(cov_loss_kernel, dim3((unsigned)B), dim3(256), 0, s, f);
+    int st = -1;
+    for (int k = 0; k < n_sets && st < 0; ++k)
+      if (entry_of_set[k] == entry_of[l]) st = k;
+    if (st < 0) {
+      st = n_sets++;
+      entry_of_set[st] = entry_of[l];
+      const slm_dataset::CovEntry& e = ds->cov[(size_t)entry_of[l]];
+      cb.G[st] = e.G; cb.c[st] = e.c; cb.yy[st] = e.yy;
+    }
+    cb.set_of[l] = st;
   }
+  // partial sums: one block of [row blocks][16][ld] per row set (the gradient's own buffer holds one or two)
+  const int64_t blocks_most = std::max<int64_t>(1, xtr_max_row_blocks(ds->eng->cus, ld) / 2);
+  cb.part_stride = blocks_most * SPLIT_LANES * ld;
+  double* partial = ds->partial;
+  if ((size_t)n_sets * (size_t)cb.part_stride > ds->partial_elems) {
+    if (ds->cov_partial_sets < n_sets) {
+      dfree(ds->cov_partial);
+      ds->cov_partial_sets = 0;
+      SLM_TRY(dalloc(&ds->cov_partial, (size_t)n_sets * (size_t)cb.part_stride));
+      ds->cov_partial_sets = n_sets;
+    }
+    partial = ds->cov_partial;
+  }
+  SplitArgs a;
+  memset(&a, 0, sizeof(a));
+  a.R = ds->cov_Z; a.partial = partial; a.done = done;
+  a.n = ld; a.ld = ld; a.p2 = (int)(ld / 2); a.n_lanes = B;
+  // (points the model solver produced are zero outside the working set: only its rows of G are read then)
+  if (ctl && wa && wa->ws && !getenv("SLM_COV_ALL_ROWS")) { a.ctl = ctl; a.ws = wa->ws; a.idx = wa->idx; }
+  const int xblk = launch_cov_gz(ds->eng->cus, a, s, cb, n_sets);
+  CovFinishArgs f;
+  f.partial = partial; f.z = ds->z; f.g = ds->g; f.done = done; f.nblk = xblk; f.ld = ld;
+  hipLaunchKernelGGL(cov_reduce_kernel, dim3((unsigned)(ld / 16), (unsigned)B), dim3(256), 0, s, f, cb);
+  hipLaunchKernelGGL(cov_loss_kernel, dim3((unsigned)B), dim3(256), 0, s, f, cb);
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
   return SLM_OK;
 }
