@@ -699,6 +699,7 @@ extern "C" int slm_dataset_set_groups(slm_dataset* ds, const int32_t* gid, int32
     return SLM_OK;
   HIP_TRY(hipSetDevice(ds->eng->device));
   HIP_TRY(hipStreamSynchronize(ds->eng->stream));
+  ds->ws_carry_valid = false;  // (the working set's group tables belong to the old structure)
   if (!gid) {
     ds->h_gid.clear();
     return set_singleton_groups(ds);

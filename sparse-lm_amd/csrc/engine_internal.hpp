@@ -278,6 +278,12 @@ struct slm_dataset {
   };
   bool carry_valid = false;
   int carry_lanes = 0;
+  // ... and the working set it ended with (WsCtl, idx / pos, XW, the Grams): a carried start may take it over when the
+  // lanes form the same row sets (ws_ctl_carry_kernel)
+  bool ws_carry_valid = false;
+  bool ws_carry_cov = false;   // its Grams were sub-matrices of the row sets' Grams (covariance passes)
+  int ws_carry_sets = 0;
+  int ws_carry_set_of[SLM_MAX_LANES] = {};
   CarryLane carry_lane[SLM_MAX_LANES];
   std::vector<double> carry_out;  // [carry_lanes][p]: the solutions the last solve reported
 };

@@ -707,6 +707,7 @@ extern "C" int slm_eval_sse_sparse(slm_dataset* ds, const int32_t* cols, int32_t
     HIP_TRY(hipMemcpyAsync(ds->rw_lanes, row_weight, sizeof(double) * n, hipMemcpyHostToDevice, s));
   }
   // scratch shared with the working set (every solve re-initialises that state)
+  ds->ws_carry_valid = false;  // (this call gathers its own columns into the working set's buffers)
   if (!ds->ws_idx) SLM_TRY(dalloc(&ds->ws_idx, WS_KCAP));
   if (!ds->ws_XW) SLM_TRY(dalloc(&ds->ws_XW, (size_t)n * WS_KCAP));
   SLM_TRY(ensure_xt(ds));
@@ -1131,6 +1132,24 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
   }
   ds->carry_valid = false;  // (this solve rewrites the state; it describes its own end below)
+  // the row sets of the lanes' Grams (lanes with the same row weights -- same host pointer: the folds of a CV grid -- and
+  // the same 1/n scaling share one), as ws_setup forms them
+  int ws_set_of[SLM_MAX_LANES] = {}, ws_set_lane[SLM_MAX_LANES] = {}, ws_n_sets = 0;
+  for (int l = 0; l < B && l < kMaxLanes; ++l) {
+    int found = -1;
+    for (int m = 0; m < l && found < 0; ++m)
+      if (lanes[m].row_weight == lanes[l].row_weight && lanes[m].n_eff == lanes[l].n_eff) found = ws_set_of[m];
+    if (found < 0) {
+      found = ws_n_sets;
+      ws_set_lane[ws_n_sets++] = l;
+    }
+    ws_set_of[l] = found;
+  }
+  // a carried start on the same row sets takes over the working set too (ws_ctl_carry_kernel)
+  bool ws_carry = carry && ds->ws_carry_valid && ws_policy(ds, o.flags) == 2 && ws_n_sets == ds->ws_carry_sets &&
+                  ds->ws_sets >= ws_n_sets && ds->ws_carry_cov == cov_on && getenv("SLM_NO_WS_CARRY") == nullptr;
+  for (int l = 0; l < B && ws_carry; ++l) ws_carry = ws_set_of[l] == ds->ws_carry_set_of[l];
+  ds->ws_carry_valid = false;
   PathCtl* h = ds->h_stage;  // (lives as long as the dataset: the upload below is asynchronous)
   memset(h, 0, sizeof(ds->h_stage));
   SetupArgs su;
@@ -1252,7 +1271,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   hipLaunchKernelGGL(solve_setup_kernel, dim3(128), dim3(256), 0, s, su);
   HIP_TRY(hipMemcpyAsync(ds->ctl, h, sizeof(PathCtl) * B, hipMemcpyHostToDevice, s));
   static_assert(offsetof(DevCtl, lane) >= offsetof(DevCtl, ws) + sizeof(WsCtl) && offsetof(DevCtl, g) == 0, "g, ws, lane");
-  HIP_TRY(hipMemsetAsync(ds->dctl, 0, offsetof(DevCtl, lane), s));  // stop words and working-set counters
+  // stop words and working-set counters (a working set taken over from the solve before keeps its block: ws_setup)
+  HIP_TRY(hipMemsetAsync(ds->dctl, 0, ws_carry ? offsetof(DevCtl, ws) : offsetof(DevCtl, lane), s));
   if (L_on_device) {  // the power steps are still in flight: their result goes into the control blocks on the device
     SeedArgs sa;
     sa.ctl = ds->ctl; sa.lambda = L_kept ? ds->lambda + ds->lane_cap : ds->lambda; sa.n_lanes = B; sa.margin = 1.08;
@@ -1415,18 +1435,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   auto ws_setup = [&](bool late) -> int {
     // lanes with the same row weights (same host pointer: the folds of a CV grid) and the same 1/n
     // scaling share one Gram
-    int set_of[SLM_MAX_LANES] = {}, set_lane[SLM_MAX_LANES] = {};
-    int n_sets = 0;
-    for (int l = 0; l < B; ++l) {
-      int found = -1;
-      for (int m = 0; m < l && found < 0; ++m)
-        if (lanes[m].row_weight == lanes[l].row_weight && lanes[m].n_eff == lanes[l].n_eff) found = set_of[m];
-      if (found < 0) {
-        found = n_sets;
-        set_lane[n_sets++] = l;
-      }
-      set_of[l] = found;
-    }
+    const int* set_of = ws_set_of;
+    const int* set_lane = ws_set_lane;
+    const int n_sets = ws_n_sets;
     const int ws_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n / 64));  // (2 MiB of partials each)
     // (each on its own: slm_eval_sse_sparse may already have brought idx and XW in)
     if (!ds->ws_idx) SLM_TRY(dalloc(&ds->ws_idx, WS_KCAP));
@@ -1450,7 +1461,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     SLM_TRY(ensure_xt(ds));
     // (initialised on the device: a host-side copy would need the stream drained before its buffer goes away)
     if (late) HIP_TRY(hipMemsetAsync(ds->ws_ctl, 0, sizeof(WsCtl), s));  // (a fresh solve has cleared it already)
-    hipLaunchKernelGGL(ws_ctl_init_kernel, dim3(1), dim3(64), 0, s, ds->ws_ctl, 24);
+    if (ws_carry && !late) hipLaunchKernelGGL(ws_ctl_carry_kernel, dim3(1), dim3(256), 0, s, ds->ws_ctl, 24);
+    else hipLaunchKernelGGL(ws_ctl_init_kernel, dim3(1), dim3(64), 0, s, ds->ws_ctl, 24);
     wa.ws = ds->ws_ctl;
     wa.idx = ds->ws_idx; wa.pos = ds->ws_pos; wa.gs = ds->ws_gs; wa.gl = ds->ws_gl;
     wa.score = ds->ws_score; wa.XW = ds->ws_XW; wa.part = ds->ws_part; wa.Gm = ds->ws_G;
@@ -1490,6 +1502,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // no memory for the working-set buffers: the plain iteration still works (unless this solve runs
   // more lanes than the fused kernels serve, which only the split pass can do)
   auto ws_release = [&]() {
+    ds->ws_carry_valid = false;
     dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
     dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->ws_nt);
     ds->ws_sets = 0;
@@ -1868,6 +1881,12 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
     ds->carry_lanes = B;
     ds->carry_valid = true;
+    if (use_ws && snap.ws.valid && !snap.ws.building && !snap.ws.disabled && !snap.ws.stale) {
+      ds->ws_carry_valid = true;
+      ds->ws_carry_cov = cov_on;
+      ds->ws_carry_sets = ws_n_sets;
+      for (int l = 0; l < kMaxLanes; ++l) ds->ws_carry_set_of[l] = l < B ? ws_set_of[l] : 0;
+    }
   }
   return SLM_OK;
 }

@@ -99,6 +99,9 @@ struct WsCtl {
   int32_t repeats[SLM_MAX_LANES];     // ... and how many times in a row it was that point WITH the same columns
   int32_t last_cols[SLM_MAX_LANES];   // columns W held at each lane's last refinement (growth resets the count)
   double Lw[SLM_MAX_LANES];  // lambda_max estimate per Gram (0 = not yet computed)
+  int32_t carried;    // this solve took over the working set of the solve before it (ws_ctl_carry_kernel): its first
+                      // selection may append as much as a fresh one would choose
+  int32_t pad2_;
 };
 
 struct WsArgs {
@@ -140,6 +143,37 @@ static __global__ void ws_ctl_init_kernel(WsCtl* ws, int max_builds) {
     ws->max_builds = max_builds;
   }
   if (threadIdx.x < SLM_MAX_LANES) ws->last_point[threadIdx.x] = -1;
+}
+
+// state of a solve that starts where the dataset's last solve ended (solve_core: carried start, same lanes, same row
+// sets): that solve's working set is still in place -- the columns' indices and positions, the gathered columns, the
+// Grams, which depend on X and the rows alone -- and the penalty has changed, not the data.  The counters and per-solve
+// records start afresh; W, its size and the Grams' lambda_max stay, and the first selection appends what the new
+// penalty lets in instead of choosing, gathering and multiplying everything again (config 5's re-weighted solves: 0.8 ms
+// of gather + Gram + reduce each).  One workgroup of 256.
+static __global__ __launch_bounds__(256) void ws_ctl_carry_kernel(WsCtl* ws, int max_builds) {
+  __shared__ int keep_i[2];
+  __shared__ double keep_L[SLM_MAX_LANES];
+  if (threadIdx.x == 0) {
+    keep_i[0] = ws->K;
+    keep_i[1] = ws->Kreal;
+  }
+  if (threadIdx.x < SLM_MAX_LANES) keep_L[threadIdx.x] = ws->Lw[threadIdx.x];
+  __syncthreads();
+  int32_t* words = reinterpret_cast<int32_t*>(ws);
+  for (int e = threadIdx.x; e < (int)(sizeof(WsCtl) / sizeof(int32_t)); e += 256) words[e] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws->K = keep_i[0];
+    ws->Kreal = keep_i[1];
+    ws->valid = 1;
+    ws->carried = 1;
+    ws->max_builds = max_builds;
+  }
+  if (threadIdx.x < SLM_MAX_LANES) {
+    ws->Lw[threadIdx.x] = keep_L[threadIdx.x];
+    ws->last_point[threadIdx.x] = -1;
+  }
 }
 
 // exclusive prefix sum of one int per thread over the 1024-thread workgroup
@@ -330,10 +364,12 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
 
   // scores and the two counts come from ws_score_kernel (many workgroups, launched just before)
   double sweep[2] = {(double)ws->sweep_new, (double)ws->sweep_miss};
+  const bool carried = ws->carried != 0;  // (first selection of a solve on its predecessor's W)
   __syncthreads();
   if (tid == 0) {
     ws->sweep_new = 0;
     ws->sweep_miss = 0;
+    ws->carried = 0;
   }
   const double inf = __builtin_huge_val();
   const bool miss = had_w && sweep[1] != 0.0;
@@ -437,7 +473,9 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
   if (append) {
     // newcomers: at most w.append_max per pass, the likeliest first (a feature left out that enters
     // anyway shows up as a miss and is appended then)
-    const double cap = (double)(miss ? 4 * w.append_max : w.append_max);  // a lane is stuck: be generous
+    // (a lane is stuck: be generous; the first selection of a solve that took over its predecessor's W: as many as a
+    //  fresh selection would take -- appended columns cost their own gather and Gram rows only)
+    const double cap = (double)(carried ? max(w.k_init, 4 * w.append_max) : (miss ? 4 * w.append_max : w.append_max));
     if (sweep[0] <= cap) {
       n_sel = sweep[0];
     } else {

@@ -518,3 +518,53 @@ def test_cold_shared_paths_open_on_a_row_sample(eng, monkeypatch):
         assert r.converged and q.converged, case
         assert np.all(r.n_iter >= 1), case
         assert rel_inf(r.betas, q.betas) < 1e-7, (case, rel_inf(r.betas, q.betas))
+
+
+def test_re_weighted_solves_take_over_the_working_set(eng, monkeypatch):
+    """A solve that starts where the last one ended, on the same row sets, keeps that solve's working set -- columns,
+    gathered copies, Grams: X and the rows have not changed, the penalty has -- and appends what the new penalty lets in:
+    the same solutions as with a fresh selection (SLM_NO_WS_CARRY=1), never more passes, no build."""
+    rng = np.random.default_rng(23)
+    n, p, G = 4000, 900, 90
+    X = rng.standard_normal((n, p))
+    groups = np.repeat(np.arange(G), p // G)
+    beta = np.zeros(p)
+    for g in rng.choice(G, 8, replace=False):
+        beta[groups == g] = rng.standard_normal(p // G) * 2
+    y = X @ beta + rng.standard_normal(n)
+    c = X.T @ y / n
+    alpha = 0.08 * np.max(np.sqrt(np.bincount(groups, weights=c * c)))
+    masks = [(np.arange(n) % 4 != f).astype(float) for f in range(3)]
+
+    def rounds(ds):
+        ds.set_groups(groups, G)
+        specs = [dict(points=[(0.0, 1.0, 0.0)], b=alpha * np.ones(G), row_weight=m, n_eff=int(m.sum())) for m in masks]
+        out, stats = [], []
+        for _ in range(4):
+            res = ds.solve_lanes(specs, tol=1e-10, flags=WS, want_group_norms=True)
+            assert all(r.converged for r in res)
+            out.append([r.betas[0].copy() for r in res])
+            stats.append((res[0].grad_launches, res[0].ws_builds, res[0].ws_appends))
+            for sp, r in zip(specs, res):
+                sp["b"] = alpha * (alpha / (r.group_norms[0] + 1e-3))
+                sp["beta0"] = r.betas[0].copy()
+        return out, stats
+
+    with eng.dataset(X, y) as ds:
+        kept, st_kept = rounds(ds)
+    monkeypatch.setenv("SLM_NO_WS_CARRY", "1")
+    with eng.dataset(X, y) as ds:
+        fresh, st_fresh = rounds(ds)
+    monkeypatch.delenv("SLM_NO_WS_CARRY")
+    assert st_kept[0] == st_fresh[0] and st_fresh[1][1] >= 1  # (the first solve is the same; later ones used to build anew)
+    for k in range(1, 4):
+        assert st_kept[k][1] == 0, st_kept  # no build in a solve that took the set over
+        assert st_kept[k][0] <= st_fresh[k][0], (st_kept, st_fresh)
+    for a_round, b_round in zip(kept, fresh):
+        for u, v in zip(a_round, b_round):
+            assert rel_inf(u, v) < 1e-7
+    # against the oracle, the last round's first fold
+    tr = masks[0] > 0
+    gn_prev = np.sqrt(np.bincount(groups, weights=kept[2][0] ** 2, minlength=G))
+    want = oracle.fista(X[tr], y[tr], 0.0, alpha * (alpha / (gn_prev + 1e-3)), 0.0, groups, G, tol=1e-13, max_iter=200000)[0]
+    assert rel_inf(kept[3][0], want) < 1e-6

@@ -1,7 +1,8 @@
 """Random sequences of solves on ONE dataset -- penalties, warm starts, row masks, targets, lane counts, flags changing
-from call to call the way estimators and searches change them -- with carried starts allowed, against the same sequence
-with SLM_NO_CARRY=1 on a second dataset: the same solutions to the solver's tolerance, never more passes, fewer where a
-call starts at the solution before it.  Usage: carry_fuzz.py [seeds ...]."""
+from call to call the way estimators and searches change them -- with carried starts allowed (and, under
+FLAG_WORKING_SET, the working set taken over with them), against the same sequence with SLM_NO_CARRY=1 on a second
+dataset: the same solutions to the solver's tolerance, never more passes, fewer where a call starts at the solution
+before it.  Usage: carry_fuzz.py [seeds ...]."""
 import os, sys
 import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -31,12 +32,16 @@ def run(seed):
         for step in range(14):
             again = prev is not None and last is not None and rng.random() < 0.5  # the next round of the same cells
             lanes = prev[0] if again else int(rng.integers(1, 5))
-            kind = rng.integers(0, 6)
+            kind = rng.integers(0, 8)
             flags = 0
             if kind == 4:
                 flags = _engine.FLAG_NO_WORKING_SET
             if kind == 5 and rng.random() < 0.5:
                 flags = _engine.FLAG_FISTA_ONLY
+            if kind >= 6:  # the working set from the first pass: a carried start then takes over the set as well
+                flags = _engine.FLAG_WORKING_SET
+            if again and prev[2] == _engine.FLAG_WORKING_SET and rng.random() < 0.8:
+                flags = prev[2]
             mask_of = prev[1] if again else ([int(rng.integers(0, 3)) for _ in range(lanes)] if rng.random() < 0.4 else None)
             if rng.random() < 0.15:
                 ynew = y + rng.standard_normal(n) * 0.1
@@ -55,7 +60,7 @@ def run(seed):
                     m = masks[mask_of[l]]
                     spec["row_weight"], spec["n_eff"] = (m.copy() if rng.random() < 0.5 else m), int(m.sum())
                 specs.append(spec)
-            prev = (lanes, mask_of)
+            prev = (lanes, mask_of, flags)
             tol = 1e-9
             ra = A.solve_lanes(specs, tol=tol, flags=flags, max_iter=20000)
             os.environ["SLM_NO_CARRY"] = "1"
