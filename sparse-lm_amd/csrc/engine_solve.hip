@@ -1483,8 +1483,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     // measured on the headline path (tools/ws_sweep.py, 24 combinations within 8 % of each other):
     // theta 0.85 / look-ahead 2 / 16 newcomers per pass / 112 initial columns was the fastest
     wa.lookahead = 2;
-    wa.append_max = interleave ? 48 : 16;  // interleaved lanes need the next band of the path at once
-    wa.k_init = ds->singleton ? 112 : 256;  // groups bring their features in blocks (config 3: 12.4 vs 29.6 ms per path)
+    wa.append_max = 48;  // (interleaved lanes need the next band of the path at once; elsewhere 16 cost a pass now and then)
+    // The first selection.  A path that walks down from alpha_max on interleaved lanes starts small: 112 columns (160: the
+    // same; 208: 4.0 ms per headline path against 3.65).  Everything else -- groups, which bring their features in blocks,
+    // and lanes that start cold at an alpha of their own (single fits, the pieces of a grid's paths), where nothing limits
+    // what is active at the first point -- starts with up to 384: a selection cut short is repaired at 48 columns per pass,
+    // and every repair is a pass over X.  Measured, round 4: config 5's cold solve 5 -> 2 passes (13.2 -> 8.3 ms per fit
+    // of three solves), one cold Lasso point with 300 informative features 5-7 -> 2-4 passes; configs 3 and 4 unchanged.
+    wa.k_init = (ds->singleton && shared_path) ? 112 : 384;
     // tuning knobs (tools/ws_sweep.py)
     if (const char* th = getenv("SLM_WS_THETA")) {
       const double v = atof(th);

@@ -8,7 +8,8 @@ from bench import make_coef
 from sparselm_amd import _engine
 eng = _engine.get_engine(0)
 n, p = 100_000, 5_000
-ds = eng.synthetic_dataset(n, p, seed=1000, coef=make_coef(p, 50, seed=0), noise_sd=10.0)
+k_inf = int(sys.argv[1]) if len(sys.argv) > 1 else 50  # informative features
+ds = eng.synthetic_dataset(n, p, seed=1000, coef=make_coef(p, k_inf, seed=0), noise_sd=10.0)
 g0, _, _ = ds.gradient(None, reps=20)
 amax = float(np.max(np.abs(g0)))
 for frac in (0.3, 0.05, 0.005):
