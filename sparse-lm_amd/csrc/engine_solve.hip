@@ -1485,12 +1485,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     wa.lookahead = 2;
     wa.append_max = 48;  // (interleaved lanes need the next band of the path at once; elsewhere 16 cost a pass now and then)
     // The first selection.  A path that walks down from alpha_max on interleaved lanes starts small: 112 columns (160: the
-    // same; 208: 4.0 ms per headline path against 3.65).  Everything else -- groups, which bring their features in blocks,
-    // and lanes that start cold at an alpha of their own (single fits, the pieces of a grid's paths), where nothing limits
-    // what is active at the first point -- starts with up to 384: a selection cut short is repaired at 48 columns per pass,
-    // and every repair is a pass over X.  Measured, round 4: config 5's cold solve 5 -> 2 passes (13.2 -> 8.3 ms per fit
-    // of three solves), one cold Lasso point with 300 informative features 5-7 -> 2-4 passes; configs 3 and 4 unchanged.
-    wa.k_init = (ds->singleton && shared_path) ? 112 : 384;
+    // same; 208: 4.0 ms per headline path against 3.65).  Lanes that start cold at an alpha of their own (single fits, the
+    // pieces of a grid's paths) have nothing that limits what is active at their first point: up to 256 columns -- a
+    // selection cut short is repaired at 48 columns per pass, and every repair is a pass over X (one cold Lasso point with
+    // 300 informative features: 3-5 passes from 112 columns, 2-4 from 256; 384 costs a sparse fit at a noise-level alpha
+    // a millisecond of Gram and model solves on 330 noise columns, tools/single_fit_big.py).  Groups bring their features
+    // in blocks: up to 384 (config 5's cold solve: 5 passes from 256 columns, 2 from 384 -- 13.2 -> 8.3 ms per fit of three
+    // solves; configs 3 and 4 the same either way).
+    wa.k_init = ds->singleton ? (shared_path ? 112 : 256) : 384;
     // tuning knobs (tools/ws_sweep.py)
     if (const char* th = getenv("SLM_WS_THETA")) {
       const double v = atof(th);
