@@ -712,17 +712,34 @@ with eng.dataset(np.asfortranarray(X), y) as ds:
     out["digest"] = h.hexdigest()
     out["converged"] = all(r.converged for r in res) and shared.converged
     out["passes"] = [int(r.grad_launches) for r in res + [shared]]
+# the re-weighted rounds of two lanes inside one on-chip launch (slm_solve_lanes_reweighted), through the same two bindings
+Xs, ys = X[:90, :40], y[:90]
+with eng.dataset(Xs, ys) as ds:
+    ds.set_groups(np.arange(40) // 4, 10)
+    gw = rng.uniform(0.5, 2.0, 10)
+    specs = [dict(points=np.ones((3, 3)), a=0.2 * np.ones(40), b=np.zeros(10), d=np.zeros(10), reweight=(0.2, None, 0.2, 1e-6, 1e-10, 40, 0)),
+             dict(points=np.ones((4, 3)), a=np.zeros(40), b=0.3 * np.ones(10), d=0.1 * np.ones(10), reweight=(0.0, 0.3 * gw, 0.3, 1e-6, 1e-10, 0, 10))]
+    results, rounds = ds.solve_lanes_reweighted(specs, tol=1e-10)
+    h = hashlib.sha256()
+    for r, k in zip(results, rounds):
+        h.update(np.ascontiguousarray(r.betas[:k]).tobytes())
+        h.update(np.ascontiguousarray(r.group_norms[:k]).tobytes())
+    out["rounds"] = [int(k) for k in rounds]
+    out["rounds_digest"] = h.hexdigest()
 print(json.dumps(out))
 '''
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     got = {}
     for name, env in (("binding", {}), ("ctypes", {"SLM_NO_BINDING": "1"})):
-        run = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        base = {k: v for k, v in os.environ.items() if k != "SLM_NO_BINDING"}  # (the suite itself may run on ctypes only)
+        run = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(base, **env), capture_output=True, text=True, timeout=600)
         assert run.returncode == 0, run.stderr[-2000:]
         got[name] = json.loads(run.stdout.strip().splitlines()[-1])
     assert got["binding"]["binding"] is True and got["ctypes"]["binding"] is False
     assert got["binding"]["converged"] and got["ctypes"]["converged"]
     assert got["binding"]["digest"] == got["ctypes"]["digest"] and got["binding"]["passes"] == got["ctypes"]["passes"]
+    assert got["binding"]["rounds"] == got["ctypes"]["rounds"] and got["binding"]["rounds_digest"] == got["ctypes"]["rounds_digest"]
+    assert all(k >= 1 for k in got["binding"]["rounds"])
 
 
 # ---- carried starts (solve_core): a solve that starts where the last one ended skips its first pass over the data -----
