@@ -7,8 +7,14 @@
 // ------------------------------------------------------------------------------------------------
 // covariance passes: the Gram of a row set
 // ------------------------------------------------------------------------------------------------
-// C = A^T A for the row-major rows x ld block A (cov_syrk_kernel: the square with its mirror, for one row set at a time;
-// the folds of a K-fold split go through cov_syrk_packed_kernel, cov_folds_begin)
+// C = A^T A for the row-major rows x ld block A, the square with its mirror.  One row set at a time used to mean
+// cov_syrk_kernel<3>, a 96-column tile pair per workgroup over ALL the rows: 56 ms for the 100 000 x 5 000 of the headline
+// (46 TFLOP/s) and 12 ms whatever the width below 1 600 columns (a dozen tile pairs do not fill the device).  The rows are
+// cut into up to sixteen chunks instead, the batched kernel of the folds (cov_syrk_packed_kernel: 69 TFLOP/s, the batch is
+// what fills the device) multiplies each, and the packed triangles are summed in a fixed order and unpacked.  Chunks are
+// multiples of sixteen rows read in place -- the ring's last prefetch then reads rows that follow in the block and are never
+// multiplied -- but for the last, which is copied behind zero rows (cov_syrk_padded_rows).  SLM_COV_TILE=3/4: the old kernel
+// (tests compare the two).
 static int cov_gram(slm_dataset* ds, const double* A, int64_t rows, double* C) {
   slm_engine* eng = ds->eng;
   hipStream_t s = eng->stream;
@@ -17,13 +23,56 @@ static int cov_gram(slm_dataset* ds, const double* A, int64_t rows, double* C) {
     HIP_TRY(hipMemsetAsync(C, 0, sizeof(double) * (size_t)ld * ld, s));
     return SLM_OK;
   }
-  int side = cov_tile_for(ld, eng->cus);
-  if (const char* e = getenv("SLM_COV_TILE")) side = atoi(e) == 3 ? 3 : 4;  // (A/B runs, tests: 96 or 128 columns per workgroup)
-  const int nt = (int)((ld + 32 * side - 1) / (32 * side));
-  const dim3 grid((unsigned)(nt * (nt + 1) / 2));
-  if (side == 3) hipLaunchKernelGGL(cov_syrk_kernel<3>, grid, dim3(256), 0, s, A, rows, ld, C);
-  else hipLaunchKernelGGL(cov_syrk_kernel<4>, grid, dim3(256), 0, s, A, rows, ld, C);
-  return check_launch();
+  if (const char* e = getenv("SLM_COV_TILE")) {
+    const int side = atoi(e) == 3 ? 3 : 4;  // (96 or 128 columns per workgroup)
+    const int nt = (int)((ld + 32 * side - 1) / (32 * side));
+    const dim3 grid((unsigned)(nt * (nt + 1) / 2));
+    if (side == 3) hipLaunchKernelGGL(cov_syrk_kernel<3>, grid, dim3(256), 0, s, A, rows, ld, C);
+    else hipLaunchKernelGGL(cov_syrk_kernel<4>, grid, dim3(256), 0, s, A, rows, ld, C);
+    return check_launch();
+  }
+  const int n_tiles = cov_syrk_tiles(ld);
+  const int wgs = (n_tiles + 3) / 4;
+  int B = (int)std::min<int64_t>(kMaxLanes, std::max<int64_t>(4, (4 * (int64_t)eng->cus + wgs - 1) / wgs));  // ~four rounds of workgroups
+  B = (int)std::max<int64_t>(1, std::min<int64_t>(B, rows / 64));
+  const int64_t chunk = B > 1 ? (rows / B) / 16 * 16 : 0;            // rows of chunks 0 .. B - 2 (in place)
+  const int64_t last = rows - (int64_t)(B - 1) * chunk;              // rows of the last one (copied, padded)
+  const size_t tri = ((size_t)ld * (size_t)(ld + 1) / 2 + 15) / 16 * 16;
+  const int64_t last_pad = cov_syrk_padded_rows(last);
+  double *packed = nullptr, *tail = nullptr, *sum = nullptr;
+  int rc = dalloc(&packed, (size_t)B * tri);
+  if (rc == SLM_OK) rc = dalloc(&tail, (size_t)last_pad * (size_t)ld);
+  if (rc == SLM_OK && B > 1) rc = dalloc(&sum, tri);
+  if (rc == SLM_OK) {
+    const double* src = A + (size_t)(B - 1) * (size_t)chunk * (size_t)ld;
+    hipError_t he = hipMemcpyAsync(tail, src, sizeof(double) * (size_t)last * (size_t)ld, hipMemcpyDeviceToDevice, s);
+    if (he == hipSuccess && last_pad > last)
+      he = hipMemsetAsync(tail + (size_t)last * (size_t)ld, 0, sizeof(double) * (size_t)(last_pad - last) * (size_t)ld, s);
+    if (he != hipSuccess) rc = fail(SLM_ERR_HIP, "covariance build: %s", hipGetErrorString(he));
+  }
+  if (rc == SLM_OK) {
+    SyrkBatch sb;
+    memset(&sb, 0, sizeof(sb));
+    for (int b = 0; b < B; ++b) {
+      sb.A[b] = b + 1 < B ? A + (size_t)b * (size_t)chunk * (size_t)ld : tail;
+      sb.rows[b] = b + 1 < B ? chunk : last;
+      sb.P[b] = packed + (size_t)b * tri;
+    }
+    hipLaunchKernelGGL(cov_syrk_packed_kernel, dim3((unsigned)wgs, (unsigned)B), dim3(256), 0, s, sb, ld, n_tiles);
+    const double* total = packed;
+    if (B > 1) {
+      hipLaunchKernelGGL(cov_sum_kernel, dim3(1024), dim3(256), 0, s, packed, B, (int64_t)tri, (int64_t)tri, sum);
+      total = sum;
+    }
+    const int64_t nt32 = (ld + 31) / 32;
+    hipLaunchKernelGGL(cov_unpack_kernel, dim3((unsigned)(nt32 * (nt32 + 1) / 2)), dim3(256), 0, s, total, (const double*)nullptr, 1.0, ld, C);
+    rc = check_launch();
+  }
+  (void)hipStreamSynchronize(s);  // (the staging blocks go back to the pool below)
+  dfree(packed);
+  dfree(tail);
+  dfree(sum);
+  return rc;
 }
 
 // the Gram of the rows `rows_host[0..count)` of X (gathered into a block of its own), unscaled, into C
