@@ -40,7 +40,7 @@ if want & {"grams", "grid"}:
         t0 = time.perf_counter()
         c4.ds.covariance(w, int(w.sum()))
         eng.synchronize()
-        note(f"one more row set (33 333 rows left out; cov_syrk_kernel): {1e3 * (time.perf_counter() - t0):.2f} ms")
+        note(f"one more row set (33 333 rows left out; its rows in chunks through cov_syrk_packed_kernel): {1e3 * (time.perf_counter() - t0):.2f} ms")
     if "grid" in want:
         c4.flags |= _engine.FLAG_COVARIANCE
         calls = c4.calls_of(1, 0)
