@@ -62,6 +62,16 @@ static __global__ __launch_bounds__(256) void copy_rows_kernel(const double* __r
   }
 }
 
+// out[l] = sum over the row blocks of loss_partial[blk][l] (the split pass's residual kernels leave sum_i w_i e_i^2 of every
+// block there), in block order: the weighted SSE of sixteen coefficient vectors after ONE read of X (slm_eval_sse)
+static __global__ void sse_from_blocks_kernel(const double* __restrict__ loss_partial, int nblk, int lanes_stride, double* __restrict__ out) {
+  const int l = threadIdx.x;
+  if (l >= lanes_stride) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += loss_partial[(int64_t)b * lanes_stride + l];
+  out[l] = s;
+}
+
 // lane 0's copy of a per-lane vector -> lanes 1 .. n_lanes-1 (stride ld)
 static __global__ __launch_bounds__(256) void broadcast_lanes_kernel(double* v, int64_t count, int64_t ld, int n_lanes) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;

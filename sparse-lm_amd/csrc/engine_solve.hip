@@ -650,6 +650,36 @@ extern "C" int slm_eval_sse(slm_dataset* ds, const double* Z, int32_t m, const d
   int maxB = kMaxLanes;
   while (maxB > 1 && !ds->gk[maxB - 1]) --maxB;
   std::vector<double> losses(kMaxLanes);
+  // More vectors than a fused pass takes (four at p = 5 000): the residual half of the split pass forms X z - y for SIXTEEN
+  // per read of X and leaves the blocks' sums of w e^2 behind -- all a score needs.  (The dense ends of a grid's paths,
+  // whose joint support is beyond slm_eval_sse_sparse: 50 candidates of a fold in 4 reads instead of 13.)
+  if (m > maxB && ds->sk != nullptr && !row_sharded(ds) && split_usable(ds) && getenv("SLM_EVAL_FUSED") == nullptr &&
+      (ds->sk->rowdot != nullptr || (ensure_xt(ds) == SLM_OK && ds->XT && ds->XT_ready))) {
+    const int nblk = ds->split_nblk;
+    if (!ds->R) {
+      SLM_TRY(dalloc(&ds->R, (size_t)n * SPLIT_RSTRIDE));
+      HIP_TRY(hipMemsetAsync(ds->R, 0, sizeof(double) * (size_t)n * SPLIT_RSTRIDE, s));
+    }
+    for (int32_t k0 = 0; k0 < m; k0 += kMaxLanes) {
+      const int B = std::min<int32_t>(kMaxLanes, m - k0);
+      HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * kMaxLanes * ld, s));
+      HIP_TRY(hipMemcpy2DAsync(ds->z, sizeof(double) * ld, Z + (size_t)k0 * p, sizeof(double) * p, sizeof(double) * p, B, hipMemcpyHostToDevice, s));
+      SplitArgs a;
+      memset(&a, 0, sizeof(a));
+      a.X = ds->X; a.y = ds->y; a.rw = ls.rw; a.rw_stride = ls.rw_stride; a.z = ds->z; a.R = ds->R;
+      a.partial = ds->partial; a.loss_partial = ds->loss_partial;
+      a.n = n; a.ld = ld; a.rows_base = n / nblk; a.rows_rem = n % nblk;
+      a.p2 = (int)(ld / 2);
+      a.n_lanes = B;
+      launch_rowdot(ds, ds->sk, nblk, B, a, s);
+      hipLaunchKernelGGL(sse_from_blocks_kernel, dim3(1), dim3(64), 0, s, ds->loss_partial, nblk, SPLIT_LANES, ds->partial);
+      SLM_TRY(check_launch());
+      HIP_TRY(hipMemcpyAsync(losses.data(), ds->partial, sizeof(double) * kMaxLanes, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      for (int l = 0; l < B; ++l) sse_out[k0 + l] = losses[l];
+    }
+    return SLM_OK;
+  }
   for (int32_t k0 = 0; k0 < m; k0 += maxB) {
     const int B = std::min<int32_t>(maxB, m - k0);  // kernel variants exist for every B <= maxB
     ls.B = B;

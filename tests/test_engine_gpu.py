@@ -840,3 +840,24 @@ def test_randomised_call_sequences_with_and_without_carried_starts():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "0 calls more than a pass worse" in out.stdout
+
+
+def test_dense_hold_out_scores_of_many_vectors_match_numpy(eng, monkeypatch):
+    """slm_eval_sse with more vectors than a fused pass takes: sixteen per read of X through the residual half of the split
+    pass (the blocks' sums of w e^2) -- against numpy, and against the fused route (SLM_EVAL_FUSED=1), with a test mask."""
+    rng = np.random.default_rng(31)
+    n, p, m = 3001, 733, 37
+    X = rng.standard_normal((n, p))
+    y = rng.standard_normal(n)
+    Z = rng.standard_normal((m, p)) * (rng.random((m, p)) < 0.9)  # dense: the joint support is all of the columns
+    mask = (rng.random(n) < 0.3).astype(float)
+    with eng.dataset(X, y) as ds:
+        for w in (None, mask):
+            got = ds.eval_sse(Z, row_weight=w, sparse=False)
+            ww = np.ones(n) if w is None else w
+            want = np.array([np.sum(ww * (X @ z - y) ** 2) for z in Z])
+            npt.assert_allclose(got, want, rtol=1e-11)
+            monkeypatch.setenv("SLM_EVAL_FUSED", "1")
+            fused = ds.eval_sse(Z, row_weight=w, sparse=False)
+            monkeypatch.delenv("SLM_EVAL_FUSED")
+            npt.assert_allclose(got, fused, rtol=1e-11)
