@@ -72,6 +72,17 @@ static __global__ void sse_from_blocks_kernel(const double* __restrict__ loss_pa
   out[l] = s;
 }
 
+// flags |= 1 where v holds a NaN, |= 2 where it holds an infinity (slm_dataset_nonfinite)
+static __global__ __launch_bounds__(256) void nonfinite_kernel(const double* __restrict__ v, int64_t count, int* __restrict__ flags) {
+  int f = 0;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x) {
+    const double x = v[e];
+    if (x != x) f |= 1;
+    else if (x - x != 0.0) f |= 2;
+  }
+  if (f) atomicOr(flags, f);
+}
+
 // lane 0's copy of a per-lane vector -> lanes 1 .. n_lanes-1 (stride ld)
 static __global__ __launch_bounds__(256) void broadcast_lanes_kernel(double* v, int64_t count, int64_t ld, int n_lanes) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;

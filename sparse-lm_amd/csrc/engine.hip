@@ -578,6 +578,27 @@ extern "C" int slm_dataset_create_device(slm_engine* eng, const double* dX, int6
   return SLM_OK;
 }
 
+extern "C" int slm_dataset_nonfinite(slm_dataset* ds, int32_t* kind_out) {
+  if (!ds || !kind_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  hipStream_t s = ds->eng->stream;
+  int* flags = nullptr;
+  SLM_TRY(dalloc(&flags, 1));
+  int rc = SLM_OK;
+  hipError_t e = hipMemsetAsync(flags, 0, sizeof(int), s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)(ds->eng->cus * 8)), dim3(256), 0, s, ds->X, (int64_t)ds->n * ds->ld, flags);
+    e = hipGetLastError();
+  }
+  int host = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&host, flags, sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) rc = fail(SLM_ERR_HIP, "scan of X failed: %s", hipGetErrorString(e));
+  dfree(flags);
+  *kind_out = host;
+  return rc;
+}
+
 // A copy of (X, y, row weights) on another engine of the same device: a second stream's own dataset without a
 // second trip over PCIe.  Group structure is not carried over (the caller sets it again).
 extern "C" int slm_dataset_clone(slm_dataset* src, slm_engine* eng, slm_dataset** out) {

@@ -67,8 +67,10 @@ class DatasetCache:
             h.update(np.ascontiguousarray(row_weight, dtype=np.float64))
         return (os.getpid(), engine.device_id, X.shape, fortran, row_weight is not None, bool(center), h.digest())
 
-    def acquire(self, engine, X, y, row_weight, center):
-        """(dataset, x_mean, y_mean, key): from the cache when the same content was uploaded before."""
+    def acquire(self, engine, X, y, row_weight, center, check_finite=False):
+        """(dataset, x_mean, y_mean, key): from the cache when the same content was uploaded before.  ``check_finite``: the
+        caller skipped the host-side scan of X (``fit`` on large arrays): it is made on the device copy, before anything is
+        done to it, and raises scikit-learn's ValueError."""
         key = self._key(engine, X, y, row_weight, center)
         if key is not None:
             with self._lock:
@@ -78,8 +80,13 @@ class DatasetCache:
                     self._clock += 1
                     item[4] = self._clock
                     self.hits += 1
+                    if check_finite and item[0].nonfinite():  # (uploaded by a caller that had not asked)
+                        item[3] = False
+                        raise ValueError("Input X contains NaN or infinity.")
                     return item[0], item[1], item[2], key
         ds = engine.dataset(X, y, row_weight=row_weight)
+        if check_finite:
+            raise_if_nonfinite(ds)
         # fit_intercept: centre the device copy in place (no centred host copy of X is ever made)
         x_mean, y_mean = ds.center() if center else (None, None)
         self.misses += 1
@@ -137,20 +144,33 @@ def dataset_cache() -> DatasetCache:
     return _dataset_cache
 
 
+def raise_if_nonfinite(ds):
+    """scikit-learn's error for a design with a NaN or an infinity (``sklearn.utils.validation._assert_all_finite``), from a
+    scan of the device copy; the dataset is closed on the way out."""
+    kind = ds.nonfinite()
+    if kind:
+        ds.close()
+        if kind & 1:
+            raise ValueError("Input X contains NaN.")
+        raise ValueError("Input X contains infinity or a value too large for dtype('float64').")
+
+
 class SolveProblem:
     """Device-resident problem: upload once, solve many penalties (adaptive loops, paths); the dataset itself
     outlives the problem in the ``DatasetCache``."""
 
-    def __init__(self, backend, X, y, gidx, n_groups, options, row_weight=None, center=False, cache=True):
+    def __init__(self, backend, X, y, gidx, n_groups, options, row_weight=None, center=False, cache=True, check_finite=False):
         self.backend = backend
         self.options = options
         self.p = X.shape[1]
         self.n_groups = n_groups
         eng = _engine.get_engine(options.get("device"))
         if cache:
-            self.ds, self.x_mean, self.y_mean, self._key = _dataset_cache.acquire(eng, X, y, row_weight, center)
+            self.ds, self.x_mean, self.y_mean, self._key = _dataset_cache.acquire(eng, X, y, row_weight, center, check_finite)
         else:  # a dataset of its own: the caller is going to change its targets (set_targets)
             self.ds = eng.dataset(X, y, row_weight=row_weight)
+            if check_finite:
+                raise_if_nonfinite(self.ds)
             self.x_mean, self.y_mean = self.ds.center() if center else (None, None)
             self._key = None
         self._private = not cache
@@ -247,8 +267,9 @@ class HipBackend:
     # slm_dataset_center): the estimator hands over the raw validated arrays
     native_preprocessing = True
 
-    def problem(self, X, y, gidx, n_groups, options, row_weight=None, center=False, cache=True) -> SolveProblem:
-        return SolveProblem(self, X, y, gidx, n_groups, options, row_weight=row_weight, center=center, cache=cache)
+    def problem(self, X, y, gidx, n_groups, options, row_weight=None, center=False, cache=True, check_finite=False) -> SolveProblem:
+        return SolveProblem(self, X, y, gidx, n_groups, options, row_weight=row_weight, center=center, cache=cache,
+                            check_finite=check_finite)
 
 
 _backend = HipBackend()

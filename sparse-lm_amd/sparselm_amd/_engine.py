@@ -42,7 +42,7 @@ FLAG_ON_CHIP = 128  # problems whose Gram matrix fits a workgroup: one launch pe
 FLAG_COVARIANCE = 256  # passes from the Grams of the call's row sets (Dataset.covariance; csrc/cov_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 13  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 14  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -58,6 +58,7 @@ ABI_SYMBOLS = (
     "slm_dataset_create",
     "slm_dataset_create_device",
     "slm_dataset_create_synthetic",
+    "slm_dataset_nonfinite",
     "slm_dataset_destroy",
     "slm_dataset_shape",
     "slm_dataset_download",
@@ -246,6 +247,7 @@ def load_library():
             "slm_dataset_create": [vp, vp, i64, i64, i64, i64, vp, vp, P(vp)],
             "slm_dataset_create_device": [vp, vp, i64, i64, i64, vp, vp, P(vp)],
             "slm_dataset_create_synthetic": [vp, i64, i64, C.c_uint64, i64, vp, dbl, P(vp)],
+            "slm_dataset_nonfinite": [vp, P(i32)],
             "slm_host_alloc": [C.c_size_t, P(vp)],
             "slm_host_free": [vp],
             "slm_dataset_destroy": [vp],
@@ -637,6 +639,12 @@ class Dataset:
         y = np.empty(self.n) if want_y else None
         _check(self._lib.slm_dataset_download(self._h, _ptr(X), _ptr(y)))
         return X, y
+
+    def nonfinite(self) -> int:
+        """``slm_dataset_nonfinite``: 0 when the uploaded X is finite throughout, bit 0 for a NaN, bit 1 for an infinity."""
+        kind = C.c_int32()
+        _check(self._lib.slm_dataset_nonfinite(self._h, C.byref(kind)))
+        return int(kind.value)
 
     def center(self):
         """Centre the device copy of (X, y) in place by the row-weighted means; returns (x_mean, y_mean)."""

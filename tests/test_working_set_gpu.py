@@ -568,3 +568,33 @@ def test_re_weighted_solves_take_over_the_working_set(eng, monkeypatch):
     gn_prev = np.sqrt(np.bincount(groups, weights=kept[2][0] ** 2, minlength=G))
     want = oracle.fista(X[tr], y[tr], 0.0, alpha * (alpha / (gn_prev + 1e-3)), 0.0, groups, G, tol=1e-13, max_iter=200000)[0]
     assert rel_inf(kept[3][0], want) < 1e-6
+
+
+def test_fit_scans_large_designs_for_nan_and_infinity_on_the_device(monkeypatch):
+    """`fit` leaves the NaN / infinity scan of a LARGE X to the device copy (model/_base.py: two thirds of a 4 GB fit were
+    numpy's sum in check_array): the same ValueError as scikit-learn's, before anything is solved; clean data fit as before."""
+    from sparselm_amd import model
+    from sparselm_amd.model import _base
+
+    rng = np.random.default_rng(41)
+    n, p = 1500, 800  # 1.2 M entries: above the threshold
+    X = rng.standard_normal((n, p))
+    y = X[:, :5] @ rng.uniform(1, 3, 5) + rng.standard_normal(n)
+    assert X.size >= _base._DEVICE_SCAN_FROM
+    fitted = model.Lasso(alpha=0.05, fit_intercept=True).fit(X, y)
+    monkeypatch.setattr(_base, "_DEVICE_SCAN_FROM", 1 << 62)  # the host's scan, as for small arrays
+    on_host = model.Lasso(alpha=0.05, fit_intercept=True).fit(X, y)
+    monkeypatch.undo()
+    np.testing.assert_array_equal(fitted.coef_, on_host.coef_)
+    assert fitted.intercept_ == on_host.intercept_
+    for bad, word in ((np.nan, "NaN"), (np.inf, "infinity"), (-np.inf, "infinity")):
+        Xb = X.copy()
+        Xb[rng.integers(n), rng.integers(p)] = bad
+        for est in (model.Lasso(alpha=0.05), model.GroupLasso(groups=np.arange(p) // 8, alpha=0.05, fit_intercept=True),
+                    model.AdaptiveLasso(alpha=0.05)):
+            with pytest.raises(ValueError, match=word):
+                est.fit(Xb, y)
+    yb = y.copy()
+    yb[3] = np.nan
+    with pytest.raises(ValueError, match="NaN"):
+        model.Lasso(alpha=0.05).fit(X, yb)  # (targets are scanned on the host as always)
