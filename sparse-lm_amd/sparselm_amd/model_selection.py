@@ -382,6 +382,8 @@ class _DeviceGrid:
         X, y, groups = indexable(X, y, groups)
         self.X = X = np.asarray(X, dtype=np.float64)
         self.y = y = np.asarray(y, dtype=np.float64)
+        if not np.all(np.isfinite(y)):  # (X is scanned on the device copy, open())
+            raise ValueError("Input y contains NaN or infinity.")
         n, p = X.shape
         cv = check_cv(search.cv, y, classifier=is_classifier(est))
         self.splits = splits = list(cv.split(X, y, groups))
@@ -435,6 +437,7 @@ class _DeviceGrid:
         Xd = np.hstack([self.X, np.ones((n, 1))]) if self.intercept else self.X
         eng = self.engine if self.engine is not None else _engine.get_engine()
         ds = eng.dataset(Xd, self.y)
+        _backend.raise_if_nonfinite(ds)  # (what every cell's fit would raise: scikit-learn's ValueError, from a scan of the device copy)
         if eng.comm_ranks() > 1:  # grid mode among ranks: every rank holds all rows
             ds.set_replicated(True)
         if self.gidx is not None:
@@ -450,7 +453,7 @@ class _DeviceGrid:
             return self.open()
         n = self.X.shape[0]
         Xd = np.hstack([self.X, np.ones((n, 1))]) if self.intercept else self.X
-        item = _backend.dataset_cache().acquire(_engine.get_engine(), Xd, self.y, None, False)
+        item = _backend.dataset_cache().acquire(_engine.get_engine(), Xd, self.y, None, False, check_finite=True)
         if item[3] is None:  # (too large for the cache: the search owns the dataset)
             return self.adopt(item[0])
         self.adopt(item[0])

@@ -617,3 +617,27 @@ def test_grid_values_are_told_apart_by_content_not_by_repr():
         warnings.simplefilter("ignore")
         grid = _DeviceGrid(search, X, y, None)
     assert len(grid.combos) == 2 and sorted(len(c) for c in grid.combos) == [2, 2]
+
+
+@pytest.mark.gpu
+def test_device_search_refuses_a_design_with_nan_or_infinity(golden):
+    """The device path of the search stands in for every cell's `fit`, whose validation would raise on a NaN or an infinity
+    in X: the same ValueError, from a scan of the device copy (small and large designs alike), and for y from the host."""
+    X, y = golden["l1_X"].copy(), golden["l1_y"].copy()
+    grid = {"alpha": [1.0, 0.3, 0.1]}
+    for bad, word in ((np.nan, "NaN"), (np.inf, "infinity")):
+        Xb = X.copy()
+        Xb[3, 1] = bad
+        with pytest.raises(ValueError, match=word):
+            GridSearchCV(Lasso(), grid, cv=3).fit(Xb, y)
+    rng = np.random.default_rng(3)
+    Xl = rng.standard_normal((1400, 900))  # (a design of the size from which `fit` itself leaves the scan to the device)
+    yl = Xl[:, :4] @ np.ones(4) + rng.standard_normal(1400)
+    Xl[700, 450] = np.nan
+    with pytest.raises(ValueError, match="NaN"):
+        GridSearchCV(Lasso(), grid, cv=3).fit(Xl, yl)
+    yb = y.copy()
+    yb[0] = np.inf
+    with pytest.raises(ValueError):
+        GridSearchCV(Lasso(), grid, cv=3).fit(X, yb)
+    assert GridSearchCV(Lasso(), grid, cv=3).fit(X, y).best_params_["alpha"] in grid["alpha"]  # (clean data: as before)
