@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 14
+#define SLM_ABI_VERSION 15
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -229,6 +229,10 @@ typedef struct slm_path_point {
                                         results to rounding; ignored where a Gram is missing, on row-sharded datasets and
                                         for calls the on-chip solver takes                                            */
 
+#define SLM_FLAG_NO_MODEL_GRAM 512u   /* lanes whose solutions outgrow the working set's 512 columns finish with plain
+                                        steps (two reads of X each) instead of rounds on the model Gram -- for
+                                        measurements: the results agree to the tolerance either way              */
+
 typedef struct slm_solve_opts {
   double tol;          /* relative distance to the minimiser a point is accepted at: stop when the KKT
                           residual ||G(z)||_2 (prox-gradient mapping) <= tol * mu * ||beta||_2, mu the
@@ -271,6 +275,14 @@ typedef struct slm_solve_stats {
   int64_t ws_inner_iters; /* proximal-gradient iterations of the model solver, all refinements */
   int64_t ws_direct_steps;/* direct (Cholesky) steps of the model solver: exact minimisation over the
                              face of the iterate, taken when the iteration is slow (ill-conditioned faces) */
+  int64_t mg_rounds;      /* (lane, pass) pairs in which a lane beyond the working set took its next point from
+                             the model Gram (an fp16 product of the whole of X^T W X / n: mg_kernels.hpp) instead
+                             of a plain step; 0: the model Gram was not used                              */
+  int64_t mg_inner_iters; /* proximal-gradient iterations on the model Gram, all lanes (one read of the
+                             8 p^2-byte matrix each, for sixteen lanes)                                    */
+  int64_t mg_rejected;    /* proposals from the model Gram that the true objective rejected              */
+  double mg_build_ms;     /* host wall clock spent building the model Gram inside this call (0: it was
+                             there already, or not used)                                                  */
 } slm_solve_stats;
 
 /*
@@ -421,6 +433,21 @@ int slm_dataset_covariance_clear(slm_dataset* ds);
 /* Diagnostic (tests): Gram `index` (oldest first) to the host -- G_out p x p (C-order), c_out length p (either may be NULL),
  * scalars_out = {y^T W y / n_eff, n_eff, the two fingerprint sums of the row weights}. */
 int slm_dataset_covariance_download(slm_dataset* ds, int32_t index, double* G_out, double* c_out, double scalars_out[4]);
+
+/*
+ * The model Gram (csrc/mg_kernels.hpp): G~ ~ X^T W X / n of the dataset's own rows and row weights from ONE product on the
+ * fp16 matrix cores (columns scaled by powers of two, fp32 accumulation over chunks of rows, chunks summed in fp64):
+ * relative error ~1e-4, built in a few milliseconds where the fp64 Gram of slm_dataset_covariance takes ten times as
+ * long.  It only ever PROPOSES points: lanes of a working-set solve whose solutions outgrow the working set's 512 columns
+ * take their next point from proximal-gradient steps on it (one read of its 8 p^2 bytes per step for sixteen lanes) and
+ * every proposal is verified by a pass over X in fp64 under the unchanged acceptance test and stopping rule -- the
+ * reference's solve has no density regime either (src/sparselm/model/_base.py:512-519).  Solves build it themselves when
+ * they need it (slm_solve_stats.mg_*; SLM_FLAG_NO_MODEL_GRAM keeps them from it) and it stays with the dataset; this
+ * entry point builds it now -- e.g. before the paths of a search -- and, for tests, hands it to the host: G_out ld x ld
+ * (C-order, ld = p rounded up to a multiple of 16) or NULL.  SLM_ERR_UNSUPPORTED on row-sharded datasets and for
+ * p > 16 384.
+ */
+int slm_dataset_model_gram(slm_dataset* ds, double* G_out);
 /* On an engine with a communicator a dataset is a row block of one tall matrix (the row-sharded mode below) unless it is
  * marked as a replica: every rank then holds ALL rows, solves its own lanes without any per-pass collective (grid mode), and
  * the communicator only carries the folds' Grams (slm_dataset_covariance_folds). */

@@ -48,7 +48,7 @@ def build_binding(force: bool = False) -> str:
     return BINDING
 
 
-UNITS = ("engine.hip", "engine_solve.hip", "engine_cov.hip")  # handles / memory / communicators; solve loop; Grams
+UNITS = ("engine.hip", "engine_solve.hip", "engine_cov.hip", "engine_mg.hip")  # handles / memory / communicators; solve loop; Grams; model Gram
 
 
 def build(force: bool = False, extra_flags=()) -> str:

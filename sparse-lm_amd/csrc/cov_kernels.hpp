@@ -44,8 +44,8 @@ struct CovBatch {
   int64_t part_stride;              // doubles between the partial sums of two row sets
 };
 
-static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void cov_gz_mfma_kernel(SplitArgs a, CovBatch cb) {
-  if (a.done != nullptr && *a.done != 0) return;
+// (the loop is a function of its own: mg_gz_kernel, mg_kernels.hpp, runs it on the model Gram)
+__device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
   a.X = cb.G[blockIdx.z];
   a.partial += (int64_t)blockIdx.z * cb.part_stride;
   const int lane = threadIdx.x & 63;
@@ -173,6 +173,11 @@ static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void cov_gz_mfma_kernel(S
           if (col < ld) out[col] = acc[2 * c + e][r];
         }
   }
+}
+
+static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void cov_gz_mfma_kernel(SplitArgs a, CovBatch cb) {
+  if (a.done != nullptr && *a.done != 0) return;
+  cov_gz_body(a, cb);
 }
 
 struct CovFinishArgs {

@@ -347,6 +347,7 @@ static void dataset_free(slm_dataset* ds) {
   ds->cov_all_hold.reset();
   ds->cov_all = nullptr;
   dfree(ds->cov_Z); dfree(ds->cov_fp); dfree(ds->cov_partial);
+  mg_free(ds);
   if (ds->h_split) (void)hipHostFree(ds->h_split);
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   if (ds->h_vec) (void)hipHostFree(ds->h_vec);
@@ -483,6 +484,7 @@ static int upload_row_weights(slm_dataset* ds, const double* rw_host) {
   ds->L_valid = false;
   ds->sketch_valid = false;
   ds->carry_valid = false;
+  mg_invalidate(ds);
   if (!rw_host) {
     dfree(ds->rw);
     ds->rw_max = 1.0;
@@ -707,6 +709,7 @@ extern "C" int slm_dataset_set_global_rows(slm_dataset* ds, int64_t n_global) {
   ds->L_valid = false;
   ds->sketch_valid = false;
   ds->carry_valid = false;
+  mg_invalidate(ds);
   return SLM_OK;
 }
 

@@ -30,6 +30,7 @@
 #include "small_kernels.hpp"
 #include "small_split_kernels.hpp"
 #include "cov_kernels.hpp"
+#include "mg_kernels.hpp"
 
 using namespace slm;
 
@@ -168,7 +169,8 @@ static const int kSnapInfos = 64;
 // round trips on a 5 ms path.
 struct DevCtl {
   GlobalCtl g;
-  WsCtl ws;  // (next to g: one fill clears both at the start of a solve)
+  MgCtl mg;  // model-Gram rounds (mg_kernels.hpp); cleared with g at the start of every solve
+  WsCtl ws;  // (next to them: one fill clears all three at the start of a solve; a working set taken over keeps its block)
   PathCtl lane[SLM_MAX_CELLS];
   slm_point_info infos[kSnapInfos];  // the per-point records of solves of up to kSnapInfos points ride along
 };
@@ -240,6 +242,12 @@ struct slm_dataset {
   double* stop_words = nullptr;  // [STOP_WORDS] row-sharded mode: the vector the ranks all-reduce after every pass
   double* XT = nullptr;  // column-major copy of X in tiles of 32 rows (tile_columns_kernel), built on first use
   bool XT_ready = false, XT_failed = false;
+  // model Gram (mg_kernels.hpp, engine_mg.hip): G~ ~ X^T W X / n_global of the dataset's own rows and weights from an fp16
+  // product, built when a solve's lanes outgrow the working set and kept for the later solves of the dataset
+  double* mg_G = nullptr;    // [ld][ld]
+  double* mg_vec = nullptr;  // [4][kMaxLanes][ld]: iterate, evaluation point and the last point / model gradient of the inner iteration
+  bool mg_ready = false, mg_failed = false;
+  double mg_build_ms = 0.0;  // device time of the last build (events)
   int ws_sets = 0;  // Gram copies allocated
   // gradient launch, per lane count B = 1..kMaxLanes (index B-1); gk == nullptr => unsupported
   const GradKernel* gk[SLM_MAX_LANES] = {};
@@ -327,3 +335,9 @@ int cov_fingerprints(slm_dataset* ds, const double* const* w, int count, double*
 int cov_find(const slm_dataset* ds, double fp1, double fp2, double n_eff);
 void cov_pending_drop(slm_dataset* ds);  // (engine_cov.hip)
 int set_singleton_groups(slm_dataset* ds);
+// model Gram (engine_mg.hip)
+bool mg_possible(const slm_dataset* ds);
+int mg_build(slm_dataset* ds);          // queues the build on the engine's stream (no-op when the Gram is there)
+void mg_invalidate(slm_dataset* ds);    // X, the row weights or the scaling changed
+void mg_free(slm_dataset* ds);
+int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner_iters, const int* done);

@@ -520,6 +520,7 @@ extern "C" int slm_dataset_center(slm_dataset* ds, double* x_mean_out, double* y
   ds->sketch_valid = false;
   ds->carry_valid = false;
   ds->XT_ready = false;  // X changed in place: the column-major copy is rebuilt on next use
+  mg_invalidate(ds);     // ... and so is the model Gram
   return SLM_OK;
 }
 
@@ -1698,6 +1699,38 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       if (n >= least) n_sample = n / 8;
     }
   }
+  // ---- model Gram (mg_kernels.hpp) -----------------------------------------------------------------------------------
+  // Lanes whose solutions outgrow the working set used to finish with plain steps, two reads of X each.  When a snapshot
+  // shows that this has begun (WsCtl::outgrown: a selection did not fit the working set's 512 columns), the
+  // model Gram of the dataset is built -- once, it stays with the dataset -- and every later pass is followed by a round
+  // of proximal-gradient steps on it for the lanes the working set does not serve (mg_enqueue_round).  From then on the
+  // host looks at every pass's snapshot before it queues the next: a round is sized by what the last one needed.
+  const char* mg_env = getenv("SLM_MG");
+  const bool mg_forced = mg_env != nullptr && mg_env[0] == '2';  // (tests: any size, from the first snapshot on)
+  const bool mg_ok = use_ws && split && (big_x || mg_forced) && !sharded && !cov_on && !any_rw && !custom_scale && !(o.flags & SLM_FLAG_NO_MODEL_GRAM) &&
+                     (size_t)ds->lane_cap >= (size_t)kMaxLanes && mg_possible(ds);
+  bool mg_on = false;
+  int mg_inner = 20;
+  double mg_build_ms = 0.0;
+  auto mg_wanted = [&](const DevCtl& c) -> bool {
+    if (mg_forced) return true;
+    // (capacity, not difficulty: a lane that spends passes on an ill-conditioned face inside the working set is served by
+    //  the model solver's direct steps, and the set must stay free to be selected afresh there)
+    return c.ws.outgrown > 0 || c.ws.overflows > 0 || c.ws.disabled != 0;
+  };
+  auto mg_consider = [&](const DevCtl& c) -> int {
+    if (!mg_ok || mg_on || !mg_wanted(c)) return SLM_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = mg_build(ds);
+    if (rc == SLM_OK) {
+      mg_on = true;
+      wa.keep_full = 1;  // (from here on the working set serves what it holds: enqueue_refinement passes wa by value)
+      mg_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } else if (rc != SLM_ERR_OOM) {
+      return rc;
+    }
+    return SLM_OK;  // (no memory for it: the solve goes on with plain steps)
+  };
   const int64_t prof_off = n_sample > 0 ? 1 : 0;  // (the pass on the sample is no launch of the roofline's kernel on X)
   bool results_queued = false, results_final = false;  // the result copies were queued early / and hold the final state
   int final_slot = 0;          // the snapshot in which the host saw `done`
@@ -1707,7 +1740,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       // (a solve with an expected end queues all of its passes at once: launches behind the device-side stop flag return
       //  at once, and every snapshot in between -- a copy, an event, 6 us of idle stream around them -- told the host
       //  nothing it acts on)
-      const int this_chunk = expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(64, expected - enq) : 1);
+      const int this_chunk = mg_on ? 1 : (expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(64, expected - enq) : 1));
       for (int i = 0; i < this_chunk; ++i) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profile && enq >= prof_off && (enq - prof_off) % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time
@@ -1736,7 +1769,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         ++enq;
         // behind the pass the solve is expected to end with, the six launches of the refinement would only find
         // out that there is nothing left to refine (30 us): they follow once the snapshot says otherwise
-        deferred = expected > 0 && enq == expected && !sharded;
+        deferred = (expected > 0 && enq == expected && !sharded) || mg_on;
         if (!deferred) enqueue_refinement();
         fix_start = false;
       }
@@ -1749,7 +1782,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     // remain to be fetched.  Polling one chunk behind cost a queued pass that returned at once (eighteen launches,
     // 0.09 ms) and four blocking copies (0.2 ms of host round trips) on every 5 ms path.  A solve that overruns
     // gets a few more passes polled this way, then the pipelined polls.
-    const bool at_end = expected > 0 && enq >= expected && enq < expected + 4;
+    const bool at_end = mg_on || (expected > 0 && enq >= expected && enq < expected + 4);
     HIP_TRY(hipEventRecord(ds->ev[slot], s));
     // behind the pass the solve is expected to end with, the results set off at once: when it does end there they are
     // under way while the host still reads the snapshot (37 us of idle stream per path); when it does not, they are
@@ -1780,9 +1813,29 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         done = true;
         final_slot = slot;
         results_final = results_queued && enq == expected;  // (queued behind exactly this pass)
-      } else if (deferred) {  // the solve goes on: what was held back, then the next pass
-        enqueue_refinement();
-        deferred = false;
+      } else {  // the solve goes on: what was held back, then the next pass
+        const DevCtl& now = ds->hctl[slot].c;
+        if (const char* trc = getenv("SLM_TRACE"))
+          if (trc[0] == '3') {  // one line per polled pass: where every lane stands, the working set, the model Gram's rounds
+            fprintf(stderr, "[slm] pass %lld at %.3f ms: K %d builds %d appends %d misses %d stale %d refined %d | mg on %d rounds %d inner %d most %d rej %d | lanes (point.iter/flags):",
+                    (long long)enq, t_mark(), now.ws.Kreal, now.ws.builds, now.ws.appends, now.ws.misses, now.ws.stale, now.ws.refined, (int)mg_on,
+                    now.mg.rounds, now.mg.inner_iters, now.mg.most_iters, now.mg.rejected);
+            for (int l = 0; l < B; ++l)
+              fprintf(stderr, " %d.%d%s%s%s", now.lane[l].point, now.lane[l].iter, now.lane[l].done ? "d" : "", now.lane[l].zsup ? "w" : "",
+                      now.mg.lane[l].active ? "m" : "");
+            fprintf(stderr, "\n");
+          }
+        SLM_TRY(mg_consider(now));
+        if (deferred) {
+          enqueue_refinement();
+          deferred = false;
+        }
+        if (mg_on) {
+          // (a round that left a lane short of its tolerance -- an ill-conditioned face -- is followed by one twice as long:
+          //  an inner iteration costs a twentieth of a pass)
+          if (now.mg.rounds > 0) mg_inner = now.mg.most_iters >= mg_inner ? std::min(96, 2 * mg_inner) : std::max(8, std::min(96, (int)now.mg.most_iters + 4));
+          SLM_TRY(mg_enqueue_round(ds, ta, B, mg_inner, done_flag));
+        }
       }
     } else if (pending[other]) {
       HIP_TRY(hipEventSynchronize(ds->ev[other]));
@@ -1791,6 +1844,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         done = true;
         final_slot = other;
       }
+      if (!done) SLM_TRY(mg_consider(ds->hctl[other].c));  // (rounds follow the passes queued from here on)
       if (!done && ws_late && ds->hctl[other].c.g.hard >= kWsLateIters) {
         const int rc = ws_setup(true);  // (waits for the stream: the queued passes simply finish first)
         ws_late = false;
@@ -1852,6 +1906,10 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     stats->lipschitz_ms = lipschitz_ms;
     stats->ws_builds = stats->ws_appends = stats->ws_refined = stats->ws_misses = stats->ws_columns = 0;
     stats->ws_inner_iters = stats->ws_direct_steps = 0;
+    stats->mg_rounds = snap.mg.rounds;
+    stats->mg_inner_iters = snap.mg.inner_iters;
+    stats->mg_rejected = snap.mg.rejected;
+    stats->mg_build_ms = mg_build_ms;
     if (use_ws) {
       const WsCtl& wc = snap.ws;
       stats->ws_builds = wc.builds;

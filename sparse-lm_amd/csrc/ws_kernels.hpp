@@ -101,7 +101,10 @@ struct WsCtl {
   double Lw[SLM_MAX_LANES];  // lambda_max estimate per Gram (0 = not yet computed)
   int32_t carried;    // this solve took over the working set of the solve before it (ws_ctl_carry_kernel): its first
                       // selection may append as much as a fresh one would choose
-  int32_t pad2_;
+  int32_t outgrown;   // selections that did not fit: appends that would pass WS_KCAP, non-zeros alone beyond it -- the solve's
+                      // lanes are outgrowing the working set (solve_core turns the model-Gram rounds on, mg_kernels.hpp)
+  int32_t served[SLM_MAX_LANES];  // lanes the model solver moved since the model-Gram rounds last looked (mg_begin_kernel,
+                                  // mg_kernels.hpp: what the working set serves is not served twice)
 };
 
 struct WsArgs {
@@ -133,7 +136,8 @@ struct WsArgs {
   int32_t k_init;      // a fresh selection is cut down to this size (or to its non-zeros)
   int32_t bb_steps;    // the model solver opens with spectral steps (SLM_WS_BB=0: accelerated steps throughout)
   int32_t one_solver;  // SLM_WS_ONE_SOLVER=1: every lane goes to the solver with direct steps (measurements)
-  int32_t pad_;
+  int32_t keep_full;   // a selection that does not fit leaves W as it is (`stale`: the lanes it no longer covers are served by
+                       // the model-Gram rounds) instead of selecting, gathering and multiplying afresh pass after pass
 };
 
 // state of a fresh solve (the block is zeroed first): a build is requested, no lane has been refined yet
@@ -486,6 +490,23 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
       return;
     }
     if ((double)k_old + n_sel > (double)WS_KCAP) {  // does not fit: select afresh
+      if (tid == 0) ws->outgrown += 1;
+      if (w.keep_full) {
+        // the model-Gram rounds serve what W does not cover.  Where the non-zeros of the live lanes alone fill most of
+        // the capacity -- a path whose solutions are outgrowing the set for good -- a fresh selection would be outgrown
+        // again a pass later (gather + Gram of 500 columns, 2-3 ms a time): W stays as it is.  Where they do not -- W is
+        // full of candidates that never entered, the way strongly correlated designs fill it -- the selection goes ahead
+        // as it always did: those lanes are best served by W's own model solver and its direct steps.
+        double nz_now, smax_unused;
+        count_at(inf, false, &nz_now, &smax_unused);
+        if (nz_now > 0.75 * (double)WS_KCAP) {
+          if (tid == 0) {
+            ws->request = 0;
+            ws->stale = 1;
+          }
+          return;
+        }
+      }
       append = false;
       thr = w.theta;
     }
@@ -499,6 +520,7 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
       // without one, try again after the next pass and give up after 50 tries
       if (tid == 0) {
         ws->overflows += 1;
+        ws->outgrown += 1;
         if (had_w) {
           ws->request = 0;
           ws->stale = 1;
@@ -1887,6 +1909,7 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
     else ctl->t = 1.0;
     ctl->zzero = 0;
     ws->last_point[lane_id] = point_now;
+    ws->served[lane_id] = 1;
     ws->repeats[lane_id] = reps + 1;
     ws->last_cols[lane_id] = ws->Kreal;
     // (the lanes of a set end within microseconds of each other: read-compare-write let the smaller of two bounds

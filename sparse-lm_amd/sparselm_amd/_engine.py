@@ -40,9 +40,10 @@ FLAG_WORKING_SET = 32  # force the Gram-assisted refinement even for small X
 FLAG_NO_WORKING_SET = 64
 FLAG_ON_CHIP = 128  # problems whose Gram matrix fits a workgroup: one launch per call (csrc/small_kernels.hpp)
 FLAG_COVARIANCE = 256  # passes from the Grams of the call's row sets (Dataset.covariance; csrc/cov_kernels.hpp)
+FLAG_NO_MODEL_GRAM = 512  # lanes beyond the working set's 512 columns take plain steps, no rounds on the model Gram (csrc/mg_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 14  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 15  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -85,6 +86,7 @@ ABI_SYMBOLS = (
     "slm_dataset_covariance_count",
     "slm_dataset_covariance_clear",
     "slm_dataset_covariance_download",
+    "slm_dataset_model_gram",
     "slm_dataset_set_replicated",
     "slm_comm_unique_id",
     "slm_comm_init",
@@ -151,6 +153,10 @@ class _SolveStats(C.Structure):
         ("ws_columns", C.c_int64),
         ("ws_inner_iters", C.c_int64),
         ("ws_direct_steps", C.c_int64),
+        ("mg_rounds", C.c_int64),
+        ("mg_inner_iters", C.c_int64),
+        ("mg_rejected", C.c_int64),
+        ("mg_build_ms", C.c_double),
     ]
 
 
@@ -289,6 +295,7 @@ def load_library():
             "slm_dataset_covariance_count": [vp, P(i32)],
             "slm_dataset_covariance_clear": [vp],
             "slm_dataset_covariance_download": [vp, i32, vp, vp, vp],
+            "slm_dataset_model_gram": [vp, vp],
             "slm_dataset_set_replicated": [vp, i32],
             "slm_comm_unique_id": [vp],
             "slm_comm_init": [vp, i32, i32, vp],
@@ -417,7 +424,8 @@ def lane_points(segments) -> tuple[np.ndarray, np.ndarray]:
 
 
 _STATS_FIELDS = ("grad_launches", "grad_timed", "grad_ms_total", "wall_ms", "lipschitz_ms", "ws_builds", "ws_appends",
-                 "ws_refined", "ws_misses", "ws_columns", "ws_inner_iters", "ws_direct_steps")
+                 "ws_refined", "ws_misses", "ws_columns", "ws_inner_iters", "ws_direct_steps", "mg_rounds", "mg_inner_iters",
+                 "mg_rejected", "mg_build_ms")
 
 
 class PathResult:
@@ -430,7 +438,9 @@ class PathResult:
     was accepted with): arrays of n_points; ``L``: inverse step at the last point; ``converged``; and the statistics of the
     call, shared by its lanes: ``grad_launches``, ``grad_timed``, ``grad_ms_total``, ``wall_ms``, ``lipschitz_ms``,
     ``ws_builds`` (working sets selected from scratch; 0: refinement not used), ``ws_appends``, ``ws_refined``,
-    ``ws_misses``, ``ws_columns`` (columns in the working set at the end), ``ws_inner_iters``, ``ws_direct_steps``."""
+    ``ws_misses``, ``ws_columns`` (columns in the working set at the end), ``ws_inner_iters``, ``ws_direct_steps``,
+    ``mg_rounds`` / ``mg_inner_iters`` / ``mg_rejected`` / ``mg_build_ms`` (the model Gram: rounds of lanes beyond the
+    working set, their inner iterations, proposals the true objective rejected, build time inside the call)."""
 
     __slots__ = ("betas", "group_norms", "_infos", "_stats")
 
@@ -456,7 +466,7 @@ class PathResult:
             v = self._stats[_STATS_FIELDS.index(name)]
         except ValueError:
             raise AttributeError(name) from None
-        return float(v) if name in ("grad_ms_total", "wall_ms", "lipschitz_ms") else int(v)
+        return float(v) if name in ("grad_ms_total", "wall_ms", "lipschitz_ms", "mg_build_ms") else int(v)
 
 
 def _stats_tuple(stats) -> tuple:
@@ -944,6 +954,15 @@ class Dataset:
         sc = np.empty(4)
         _check(self._lib.slm_dataset_covariance_download(self._h, int(index), _ptr(G), _ptr(c), _ptr(sc)))
         return G, c, {"yy": float(sc[0]), "n_eff": float(sc[1]), "fingerprint": (float(sc[2]), float(sc[3]))}
+
+    def model_gram(self, download: bool = False):
+        """Build the model Gram of the dataset now (``csrc/mg_kernels.hpp``: ``X^T W X / n`` from an fp16 product, what lanes
+        beyond the working set's 512 columns iterate on between two passes over X; solves build it themselves when they
+        need it).  ``download=True`` returns it as an (ld, ld) array (tests)."""
+        ld = (self.p + 15) // 16 * 16
+        G = np.empty((ld, ld)) if download else None
+        _check(self._lib.slm_dataset_model_gram(self._h, _ptr(G) if download else None))
+        return G
 
     def set_replicated(self, replicated: bool = True):
         """On an engine with a communicator: this dataset holds ALL rows (grid mode), not a row block -- no per-pass
