@@ -244,9 +244,14 @@ struct slm_dataset {
   bool XT_ready = false, XT_failed = false;
   // model Gram (mg_kernels.hpp, engine_mg.hip): G~ ~ X^T W X / n_global of the dataset's own rows and weights from an fp16
   // product, built when a solve's lanes outgrow the working set and kept for the later solves of the dataset
-  double* mg_G = nullptr;    // [ld][ld]
-  double* mg_vec = nullptr;  // [4][kMaxLanes][ld]: iterate, evaluation point and the last point / model gradient of the inner iteration
-  bool mg_ready = false, mg_failed = false;
+  struct MgEntry {           // one per row set, found again like the Grams of covariance passes: by the fingerprint of its row weights
+    double* G = nullptr;     // [ld][ld]
+    double fp1 = 0.0, fp2 = 0.0, n_eff = 0.0;
+    bool own = false;        // the dataset's own rows and weights (no fingerprint: lanes that bring neither weights nor scaling)
+  };
+  std::vector<MgEntry> mg;   // oldest first; at most kMgEntries (the oldest goes when another row set needs the room)
+  double* mg_vec = nullptr;  // [5][kMaxLanes][ld]: iterate, evaluation point, the last point / model gradient of the inner iteration, the product
+  bool mg_failed = false;
   double mg_build_ms = 0.0;  // device time of the last build (events)
   int ws_sets = 0;  // Gram copies allocated
   // gradient launch, per lane count B = 1..kMaxLanes (index B-1); gk == nullptr => unsupported
@@ -336,8 +341,14 @@ int cov_find(const slm_dataset* ds, double fp1, double fp2, double n_eff);
 void cov_pending_drop(slm_dataset* ds);  // (engine_cov.hip)
 int set_singleton_groups(slm_dataset* ds);
 // model Gram (engine_mg.hip)
+static const int kMgEntries = 8;
 bool mg_possible(const slm_dataset* ds);
-int mg_build(slm_dataset* ds);          // queues the build on the engine's stream (no-op when the Gram is there)
+// the model Gram of a row set -- w: its row weights on the device (nullptr: the dataset's own), n_eff its scaling, (fp1, fp2) the
+// fingerprint of w (ignored for the dataset's own) -- built if it is not there yet; entry_out: its index in ds->mg
+int mg_ensure(slm_dataset* ds, const double* w, double n_eff, bool own, double fp1, double fp2, int* entry_out);
 void mg_invalidate(slm_dataset* ds);    // X, the row weights or the scaling changed
 void mg_free(slm_dataset* ds);
-int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner_iters, const int* done);
+// one round: begin, inner_iters x (products, sums, step), finish.  entry_of_set[s]: the entry of the s-th row set of the call,
+// set_of[l] the row set of lane l
+int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner_iters, const int* done, int n_sets, const int* entry_of_set,
+                     const int* set_of);

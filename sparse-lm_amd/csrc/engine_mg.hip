@@ -4,8 +4,8 @@
 // non-zeros than its 512 columns.
 #include "engine_internal.hpp"
 
-// Where the model Gram can exist: a matrix worth a pass (the same bound as the working set's), rows short enough for the
-// 8 ld^2 bytes, the dataset's own rows (a row-sharded dataset would have to all-reduce 8 ld^2 bytes: not built).
+// Where the model Gram can exist: rows short enough for its 8 ld^2 bytes, all rows on this device (a row-sharded dataset
+// would have to all-reduce 8 ld^2 bytes per row set: not built).
 bool mg_possible(const slm_dataset* ds) {
   if (const char* e = getenv("SLM_MG"))
     if (e[0] == '0') return false;
@@ -15,29 +15,25 @@ bool mg_possible(const slm_dataset* ds) {
   return true;
 }
 
-void mg_invalidate(slm_dataset* ds) { ds->mg_ready = false; }
-
-void mg_free(slm_dataset* ds) {
-  dfree(ds->mg_G);
-  dfree(ds->mg_vec);
-  ds->mg_ready = false;
+void mg_invalidate(slm_dataset* ds) {
+  for (auto& e : ds->mg) dfree(e.G);
+  ds->mg.clear();
 }
 
-// G~ for the dataset's rows and row weights, scaled by 1 / n_global like every gradient of the dataset's own lanes.
-// Queued on the engine's stream: column maxima (one read of X), the fp16 operand (one read of the column-major copy),
-// the product in chunks of rows, the sum of the chunks.  The operand and the chunks' partial tiles are scratch, given back
-// to the pool behind the last kernel that reads them (the pool hands blocks out again in stream order of this engine only
-// after the free -- which the stream wait below precedes).
-int mg_build(slm_dataset* ds) {
-  if (ds->mg_ready) return SLM_OK;
+void mg_free(slm_dataset* ds) {
+  mg_invalidate(ds);
+  dfree(ds->mg_vec);
+}
+
+// G~ = X^T W X / n_eff into G.  Queued on the engine's stream: column maxima (one read of X), the fp16 operand with the
+// square roots of the row weights folded in (one read of the column-major copy), the product in chunks of rows, the sum of
+// the chunks.  The operand and the chunks' partial tiles are scratch; the stream is drained before they go back to the pool.
+static int mg_build(slm_dataset* ds, const double* w, double n_eff, double* G) {
   slm_engine* eng = ds->eng;
   hipStream_t s = eng->stream;
   const int64_t n = ds->n, ld = ds->ld;
   SLM_TRY(ensure_xt(ds));
-  if (!ds->XT || !ds->XT_ready) {
-    ds->mg_failed = true;
-    return fail(SLM_ERR_OOM, "no column-major copy of X: the model Gram is not built");
-  }
+  if (!ds->XT || !ds->XT_ready) return fail(SLM_ERR_OOM, "no column-major copy of X: the model Gram is not built");
   const int64_t row_tiles = (n + 31) / 32;
   const int64_t n_pad = (n + MG_BK - 1) / MG_BK * MG_BK;
   const int64_t p_pad = (ld + MG_TILE - 1) / MG_TILE * MG_TILE;
@@ -52,16 +48,11 @@ int mg_build(slm_dataset* ds) {
   auto need = [&](int r) {
     if (rc == SLM_OK) rc = r;
   };
-  if (!ds->mg_G) need(dalloc(&ds->mg_G, (size_t)ld * (size_t)ld));
-  if (!ds->mg_vec) need(dalloc(&ds->mg_vec, 4 * (size_t)kMaxLanes * (size_t)ld));
-  if (!ds->cov_Z) need(dalloc(&ds->cov_Z, (size_t)ld * SPLIT_RSTRIDE));
   need(dalloc(&cmax, (size_t)ld));
   need(dalloc(&XTh, (size_t)p_pad * (size_t)n_pad));
   need(dalloc(&P, (size_t)n_chunks * (size_t)n_tiles * MG_TILE * MG_TILE));
-  if (rc != SLM_OK) {  // no memory: the solve goes on as it would have without the model
+  if (rc != SLM_OK) {
     dfree(cmax); dfree(XTh); dfree(P);
-    mg_free(ds);
-    ds->mg_failed = true;
     (void)hipGetLastError();
     return rc;
   }
@@ -73,7 +64,6 @@ int mg_build(slm_dataset* ds) {
     (void)hipEventRecord(e0, s);
   }
   (void)hipMemsetAsync(cmax, 0, sizeof(unsigned long long) * (size_t)ld, s);
-  (void)hipMemsetAsync(ds->cov_Z, 0, sizeof(double) * (size_t)ld * SPLIT_RSTRIDE, s);
   {
     const int64_t rows_per_block = 64;
     hipLaunchKernelGGL(mg_colmax_kernel, dim3((unsigned)((n + rows_per_block - 1) / rows_per_block)), dim3(256), 0, s, (const double*)ds->X, n, ld,
@@ -81,22 +71,23 @@ int mg_build(slm_dataset* ds) {
   }
   {
     MgConvArgs c;
-    c.XT = ds->XT; c.cmax = cmax; c.rw = ds->rw; c.n = n; c.ld = ld; c.row_tiles = row_tiles; c.XTh = XTh; c.n_pad = n_pad; c.p_pad = p_pad;
+    c.XT = ds->XT; c.cmax = cmax; c.rw = w; c.n = n; c.ld = ld; c.row_tiles = row_tiles; c.XTh = XTh; c.n_pad = n_pad; c.p_pad = p_pad;
     hipLaunchKernelGGL(mg_convert_kernel, dim3((unsigned)(n_pad / 64), (unsigned)((p_pad + 255) / 256)), dim3(256), 0, s, c);
   }
   {
     MgSyrkArgs a;
     a.M = XTh; a.n_pad = n_pad; a.k_chunk = k_chunk; a.n_tiles = n_tiles; a.n_chunks = n_chunks; a.P = P;
-    hipLaunchKernelGGL(mg_syrk_f16_kernel, dim3((unsigned)((int64_t)n_tiles * n_chunks)), dim3(256), 0, s, a);
+    const char* e = getenv("SLM_MG_SYRK");  // (0: the register-staged form, for A/B runs)
+    if (e && e[0] == '0') hipLaunchKernelGGL(mg_syrk_f16_kernel, dim3((unsigned)((int64_t)n_tiles * n_chunks)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(mg_syrk_f16_dma_kernel, dim3((unsigned)((int64_t)n_tiles * n_chunks)), dim3(256), 0, s, a);
   }
   {
     MgReduceArgs r;
-    r.P = P; r.cmax = cmax; r.n_tiles = n_tiles; r.n_chunks = n_chunks; r.ld = ld; r.inv_n = 1.0 / (double)ds->n_global; r.G = ds->mg_G;
+    r.P = P; r.cmax = cmax; r.n_tiles = n_tiles; r.n_chunks = n_chunks; r.ld = ld; r.inv_n = 1.0 / n_eff; r.G = G;
     hipLaunchKernelGGL(mg_reduce_kernel, dim3((unsigned)n_tiles, 16), dim3(256), 0, s, r);
   }
   rc = check_launch();
   if (timed) (void)hipEventRecord(e1, s);
-  // (the scratch goes back to the pool only when the kernels that read it are through)
   hipError_t e = hipStreamSynchronize(s);
   dfree(cmax); dfree(XTh); dfree(P);
   if (timed) {
@@ -108,21 +99,51 @@ int mg_build(slm_dataset* ds) {
             (long long)n, n_chunks, n_tiles, ds->mg_build_ms);
   }
   if (e != hipSuccess) return fail(SLM_ERR_HIP, "model Gram: %s", hipGetErrorString(e));
-  if (rc != SLM_OK) return rc;
-  ds->mg_ready = true;
+  return rc;
+}
+
+int mg_ensure(slm_dataset* ds, const double* w, double n_eff, bool own, double fp1, double fp2, int* entry_out) {
+  for (size_t i = 0; i < ds->mg.size(); ++i) {
+    const slm_dataset::MgEntry& e = ds->mg[i];
+    if (e.n_eff == n_eff && (own ? e.own : (!e.own && e.fp1 == fp1 && e.fp2 == fp2))) {
+      *entry_out = (int)i;
+      return SLM_OK;
+    }
+  }
+  const int64_t ld = ds->ld;
+  int rc = SLM_OK;
+  if (!ds->mg_vec) rc = dalloc(&ds->mg_vec, 5 * (size_t)kMaxLanes * (size_t)ld);
+  if (rc == SLM_OK && !ds->cov_Z) {
+    rc = dalloc(&ds->cov_Z, (size_t)ld * SPLIT_RSTRIDE);
+    if (rc == SLM_OK) (void)hipMemsetAsync(ds->cov_Z, 0, sizeof(double) * (size_t)ld * SPLIT_RSTRIDE, ds->eng->stream);
+  }
+  slm_dataset::MgEntry ne;
+  if (rc == SLM_OK) rc = dalloc(&ne.G, (size_t)ld * (size_t)ld);
+  if (rc == SLM_OK) rc = mg_build(ds, own ? ds->rw : w, n_eff, ne.G);
+  if (rc != SLM_OK) {  // no memory: the solve goes on as it would have without the model
+    dfree(ne.G);
+    if (rc == SLM_ERR_OOM) ds->mg_failed = true;
+    (void)hipGetLastError();
+    return rc;
+  }
+  ne.fp1 = fp1; ne.fp2 = fp2; ne.n_eff = n_eff; ne.own = own;
+  ds->mg.push_back(ne);
+  *entry_out = (int)ds->mg.size() - 1;
   return SLM_OK;
 }
 
 #define SLM_MG_STEP(N) hipLaunchKernelGGL(mg_step_kernel<N>, dim3((unsigned)n_lanes), dim3(TAIL_THREADS), 0, s, ta, m)
 
-// One round for the lanes the working set did not serve: begin, `inner_iters` x (product G~ D, step), finish.  Everything
-// returns at once for lanes that take no part, and the products return at once when no lane iterates any more.
-int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner_iters, const int* done) {
+// One round for the lanes the working set did not serve: begin, `inner_iters` x (products G~_s D for the row sets of the call,
+// their sums over the row blocks, step), finish.  Everything returns at once for lanes that take no part, and the products
+// return at once when no lane iterates any more.
+int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner_iters, const int* done, int n_sets, const int* entry_of_set,
+                     const int* set_of) {
   hipStream_t s = ds->eng->stream;
   const int64_t ld = ds->ld;
   SplitArgs a;
   memset(&a, 0, sizeof(a));
-  a.R = ds->cov_Z; a.partial = ds->partial; a.done = done;
+  a.R = ds->cov_Z; a.done = done;
   a.n = ld; a.ld = ld; a.p2 = (int)(ld / 2); a.n_lanes = n_lanes;
   const int xb = (int)((ld + XTR_CB - 1) / XTR_CB);
   const int64_t want = std::max<int64_t>(1, xtr_max_row_blocks(ds->eng->cus, ld) / 2);
@@ -131,26 +152,44 @@ int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner
   const int yb = (int)((ld + rows - 1) / rows);
   a.xrows = (int)rows;
   a.xrows_ws = 0;
-  if ((size_t)yb * SPLIT_LANES * (size_t)ld > ds->partial_elems) return fail(SLM_ERR_UNSUPPORTED, "model Gram: partial buffer too small");
   CovBatch cb;
   memset(&cb, 0, sizeof(cb));
-  cb.G[0] = ds->mg_G;
-  cb.part_stride = 0;
+  for (int st = 0; st < n_sets; ++st) cb.G[st] = ds->mg[(size_t)entry_of_set[st]].G;
+  for (int l = 0; l < kMaxLanes; ++l) cb.set_of[l] = l < n_lanes ? set_of[l] : 0;
+  cb.part_stride = (int64_t)yb * SPLIT_LANES * ld;
+  // partial sums: one block of [row blocks][16][ld] per row set (the gradient's own buffer holds two)
+  double* partial = ds->partial;
+  if ((size_t)n_sets * (size_t)cb.part_stride > ds->partial_elems) {
+    if (ds->cov_partial_sets < n_sets || !ds->cov_partial) {
+      dfree(ds->cov_partial);
+      ds->cov_partial_sets = 0;
+      // (sized like a covariance pass's: enqueue_gradient_cov shares the buffer)
+      const int64_t blocks_most = std::max<int64_t>(1, xtr_max_row_blocks(ds->eng->cus, ld) / 2);
+      SLM_TRY(dalloc(&ds->cov_partial, (size_t)n_sets * (size_t)(blocks_most * SPLIT_LANES * ld)));
+      ds->cov_partial_sets = n_sets;
+    }
+    partial = ds->cov_partial;
+  }
+  a.partial = partial;
   MgArgs m;
   memset(&m, 0, sizeof(m));
   m.mg = &ds->dctl->mg;
   m.ws = ds->ws_ctl;
-  m.partial = ds->partial;
+  m.partial = partial;
+  m.part_stride = cb.part_stride;
+  for (int l = 0; l < kMaxLanes; ++l) m.set_of[l] = cb.set_of[l];
   m.nblk = yb;
   m.Z = ds->cov_Z;
   m.x = ds->mg_vec;
   m.v = ds->mg_vec + (size_t)kMaxLanes * ld;
   m.vprev = ds->mg_vec + 2 * (size_t)kMaxLanes * ld;
   m.gvprev = ds->mg_vec + 3 * (size_t)kMaxLanes * ld;
+  m.gd = ds->mg_vec + 4 * (size_t)kMaxLanes * ld;
   hipLaunchKernelGGL(mg_begin_kernel, dim3((unsigned)n_lanes), dim3(TAIL_THREADS), 0, s, ta, m);
   const int E = (ta.p + TAIL_THREADS - 1) / TAIL_THREADS;
   for (int it = 0; it < inner_iters; ++it) {
-    hipLaunchKernelGGL(mg_gz_kernel, dim3(xb, yb, 1), dim3(XTR_WAVES * 64), 0, s, a, cb, (const MgCtl*)m.mg);
+    hipLaunchKernelGGL(mg_gz_kernel, dim3(xb, yb, (unsigned)n_sets), dim3(XTR_WAVES * 64), 0, s, a, cb, (const MgCtl*)m.mg);
+    hipLaunchKernelGGL(mg_gsum_kernel, dim3((unsigned)((ld + 255) / 256), (unsigned)n_lanes), dim3(256), 0, s, m, ld, done);
     switch (E) {
       case 1: SLM_MG_STEP(1); break;
       case 2: SLM_MG_STEP(2); break;
@@ -176,10 +215,11 @@ extern "C" int slm_dataset_model_gram(slm_dataset* ds, double* G_out) {
   if (row_sharded(ds) || ds->ld > MG_MAX_LD || ds->n < 64)
     return fail(SLM_ERR_UNSUPPORTED, "the model Gram is built for unsharded datasets of 64 rows or more and p <= %d", MG_MAX_LD);
   ds->mg_failed = false;
-  SLM_TRY(mg_build(ds));
+  int entry = -1;
+  SLM_TRY(mg_ensure(ds, nullptr, (double)ds->n_global, true, 0.0, 0.0, &entry));
   if (G_out) {
     HIP_TRY(hipStreamSynchronize(ds->eng->stream));
-    HIP_TRY(hipMemcpy(G_out, ds->mg_G, sizeof(double) * (size_t)ds->ld * (size_t)ds->ld, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(G_out, ds->mg[(size_t)entry].G, sizeof(double) * (size_t)ds->ld * (size_t)ds->ld, hipMemcpyDeviceToHost));
   }
   return SLM_OK;
 }

@@ -1707,11 +1707,49 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // host looks at every pass's snapshot before it queues the next: a round is sized by what the last one needed.
   const char* mg_env = getenv("SLM_MG");
   const bool mg_forced = mg_env != nullptr && mg_env[0] == '2';  // (tests: any size, from the first snapshot on)
-  const bool mg_ok = use_ws && split && (big_x || mg_forced) && !sharded && !cov_on && !any_rw && !custom_scale && !(o.flags & SLM_FLAG_NO_MODEL_GRAM) &&
-                     (size_t)ds->lane_cap >= (size_t)kMaxLanes && mg_possible(ds);
+  // (the model Grams of a dataset are kept within 6 GB: sixteen row sets at p = 5 000, seven at 10 000)
+  const int mg_cap = (int)std::max<double>(1.0, std::min<double>((double)kMgEntries, 6.0e9 / (8.0 * (double)ld * (double)ld)));
+  const bool mg_ok = use_ws && split && (big_x || mg_forced) && !sharded && !cov_on && !(o.flags & SLM_FLAG_NO_MODEL_GRAM) &&
+                     (size_t)ds->lane_cap >= (size_t)kMaxLanes && ws_n_sets <= mg_cap && mg_possible(ds);
   bool mg_on = false;
   int mg_inner = 20;
   double mg_build_ms = 0.0;
+  int mg_entry_of_set[SLM_MAX_LANES] = {};
+  // the model Gram of every row set of the call (ws_set_of: lanes with the same row weights and scaling share one), found
+  // by the fingerprint of the row weights as the lanes brought them, or built
+  auto mg_sets = [&]() -> int {
+    const double* wdev[SLM_MAX_LANES];
+    double fp[2 * SLM_MAX_LANES] = {};
+    int n_fp = 0, fp_at[SLM_MAX_LANES];
+    for (int st = 0; st < ws_n_sets; ++st) {
+      const int l = ws_set_lane[st];
+      fp_at[st] = -1;
+      if (lanes[l].row_weight != nullptr) {
+        fp_at[st] = n_fp;
+        wdev[n_fp++] = ls.rw + (int64_t)l * ls.rw_stride;
+      }
+    }
+    if (n_fp > 0) SLM_TRY(cov_fingerprints(ds, wdev, n_fp, fp));
+    int missing = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      // (first round: is there room for what is missing?  if not, every entry goes and all of the call's are built)
+      if (pass == 1 && (int)ds->mg.size() + missing > mg_cap) mg_invalidate(ds);
+      for (int st = 0; st < ws_n_sets; ++st) {
+        const int l = ws_set_lane[st];
+        const bool own = lanes[l].row_weight == nullptr;
+        const double ne = ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global;
+        const double f1 = own ? 0.0 : fp[2 * fp_at[st]], f2 = own ? 0.0 : fp[2 * fp_at[st] + 1];
+        if (pass == 0) {
+          bool have = false;
+          for (const auto& e : ds->mg) have = have || (e.n_eff == ne && (own ? e.own : (!e.own && e.fp1 == f1 && e.fp2 == f2)));
+          missing += have ? 0 : 1;
+        } else {
+          SLM_TRY(mg_ensure(ds, own ? nullptr : ls.rw + (int64_t)l * ls.rw_stride, ne, own, f1, f2, &mg_entry_of_set[st]));
+        }
+      }
+    }
+    return SLM_OK;
+  };
   auto mg_wanted = [&](const DevCtl& c) -> bool {
     if (mg_forced) return true;
     // (capacity, not difficulty: a lane that spends passes on an ill-conditioned face inside the working set is served by
@@ -1721,7 +1759,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   auto mg_consider = [&](const DevCtl& c) -> int {
     if (!mg_ok || mg_on || !mg_wanted(c)) return SLM_OK;
     const auto t0 = std::chrono::steady_clock::now();
-    const int rc = mg_build(ds);
+    const int rc = mg_sets();
     if (rc == SLM_OK) {
       mg_on = true;
       wa.keep_full = 1;  // (from here on the working set serves what it holds: enqueue_refinement passes wa by value)
@@ -1827,14 +1865,18 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
           }
         SLM_TRY(mg_consider(now));
         if (deferred) {
-          enqueue_refinement();
+          // (once the working set is frozen and no live lane stands on it any more -- the dense end of a path -- its
+          //  seven launches would only find that out again, 70 us a pass: the rounds below serve every lane)
+          bool ws_serves = !(mg_on && now.ws.stale != 0 && wa.keep_full != 0);
+          for (int l = 0; l < B && !ws_serves; ++l) ws_serves = !now.lane[l].done && !now.lane[l].idle && now.lane[l].zsup != 0;
+          if (ws_serves) enqueue_refinement();
           deferred = false;
         }
         if (mg_on) {
           // (a round that left a lane short of its tolerance -- an ill-conditioned face -- is followed by one twice as long:
           //  an inner iteration costs a twentieth of a pass)
-          if (now.mg.rounds > 0) mg_inner = now.mg.most_iters >= mg_inner ? std::min(96, 2 * mg_inner) : std::max(8, std::min(96, (int)now.mg.most_iters + 4));
-          SLM_TRY(mg_enqueue_round(ds, ta, B, mg_inner, done_flag));
+          if (now.mg.rounds > 0) mg_inner = now.mg.most_iters >= mg_inner ? std::min(96, 2 * mg_inner) : std::max(6, std::min(96, (int)now.mg.most_iters + 2));
+          SLM_TRY(mg_enqueue_round(ds, ta, B, mg_inner, done_flag, ws_n_sets, mg_entry_of_set, ws_set_of));
         }
       }
     } else if (pending[other]) {

@@ -42,7 +42,7 @@ constexpr int MG_MAX_LD = 16384;           // the Gram is 8 ld^2 bytes: 2 GB at 
 constexpr int MG_CHUNK_ROWS = 6400;        // rows per fp32 accumulation (chunks are summed in fp64): 100 steps of MG_BK
 constexpr int MG_ROUNDS_PER_POINT = 12;    // rounds a lane may spend on one path point before it is left to plain steps
 constexpr int MG_REJECT_LIMIT = 2;         // proposals for one path point the true objective may reject before the point is left to plain steps
-constexpr double MG_ETA = 2e-5;            // inner stop relative to the move ||x - z0||: below the model's own error
+constexpr double MG_ETA = 5e-5;            // inner stop relative to the move ||x - z0||: below the model's own error (~1.5e-4 of the move)
 
 struct MgLane {
   int32_t active;     // the inner iteration of this round runs for the lane
@@ -262,6 +262,103 @@ static __global__ __launch_bounds__(256) void mg_syrk_f16_kernel(MgSyrkArgs a) {
       }
 }
 
+// The same product with the operands brought into LDS by the DMA path (global_load_lds_dwordx4: no staging registers, no
+// ds_write -- the 16-byte LDS stores of the kernel above cost more LDS cycles than its fragment reads), two buffers, the
+// next step's tiles in flight while the current one is multiplied, one barrier per step.  A DMA instruction fills 1 KiB of
+// LDS in lane order, so the tiles are stored unpadded ([128 rows][64 halves]) and the 16-byte pieces of a row are swizzled
+// instead -- piece c of row R sits in slot c ^ ((R >> 1) & 7), applied to the SOURCE address of the load and to the
+// fragment read -- which puts the sixteen rows of a ds_read_b128 group on sixteen different slots again.
+static __global__ __launch_bounds__(256) void mg_syrk_f16_dma_kernel(MgSyrkArgs a) {
+  __shared__ __attribute__((aligned(1024))) _Float16 lds[2][2][MG_TILE * MG_BK];  // [buffer][operand]: 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t m;
+  {
+    const int64_t total = gridDim.x, lin = blockIdx.x;
+    const int64_t xcd = lin & 7, slot = lin >> 3, base = total >> 3, rem = total & 7;
+    m = xcd * base + (xcd < rem ? xcd : rem) + slot;
+  }
+  const int chunk = (int)(m / a.n_tiles), tile = (int)(m - (int64_t)chunk * a.n_tiles);
+  int I = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+  while (I * (I + 1) / 2 > tile) --I;
+  while ((I + 1) * (I + 2) / 2 <= tile) ++I;
+  const int J = tile - I * (I + 1) / 2;
+  const int64_t k0 = (int64_t)chunk * a.k_chunk;
+  const int64_t k1 = k0 + a.k_chunk < a.n_pad ? k0 + a.k_chunk : a.n_pad;
+  // DMA: wave w, instruction q fills piece P = 4 w + q (rows 8 P ... 8 P + 7); lane -> (row 8 P + (lane >> 3), slot lane & 7)
+  const _Float16* srcA[4];
+  const _Float16* srcB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = 8 * (4 * wave + q) + (lane >> 3);
+    const int piece = (lane & 7) ^ ((row >> 1) & 7);
+    srcA[q] = a.M + ((int64_t)I * MG_TILE + row) * a.n_pad + 8 * piece;
+    srcB[q] = a.M + ((int64_t)J * MG_TILE + row) * a.n_pad + 8 * piece;
+  }
+  auto dma = [&](int buf, int64_t k) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[q] + k),
+                                       (__attribute__((address_space(3))) void*)(&lds[buf][0][(4 * wave + q) * 512]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[q] + k),
+                                       (__attribute__((address_space(3))) void*)(&lds[buf][1][(4 * wave + q) * 512]), 16, 0, 0);
+    }
+  };
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  mg_f16v acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+  // fragment addresses (halves) inside an operand's tile, per 16-row step kk: row R, piece 2 kk + h in slot (2 kk + h) ^ ((R >> 1) & 7)
+  int ra[2], rb[2], sa[2], sb[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int RA = 64 * wr + 32 * t + r, RB = 64 * wc + 32 * t + r;
+    ra[t] = RA * MG_BK; sa[t] = (RA >> 1) & 7;
+    rb[t] = RB * MG_BK; sb[t] = (RB >> 1) & 7;
+  }
+  if (k0 < k1) {
+    dma(0, k0);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t k = k0; k < k1; k += MG_BK) {
+      if (k + MG_BK < k1) dma(cur ^ 1, k + MG_BK);
+      const _Float16* As = lds[cur][0];
+      const _Float16* Bs = lds[cur][1];
+#pragma unroll
+      for (int kk = 0; kk < MG_BK / 16; ++kk) {
+        mg_h8 af[2], bf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          af[t] = *reinterpret_cast<const mg_h8*>(As + ra[t] + 8 * ((2 * kk + h) ^ sa[t]));
+          bf[t] = *reinterpret_cast<const mg_h8*>(Bs + rb[t] + 8 * ((2 * kk + h) ^ sb[t]));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+      __syncthreads();  // (drains the DMA of the next step, and every wavefront is done with this step's buffer)
+      cur ^= 1;
+    }
+  }
+  float* out = a.P + ((int64_t)chunk * a.n_tiles + tile) * (MG_TILE * MG_TILE);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = 64 * wr + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int col = 64 * wc + 32 * ni + r;
+        out[row * MG_TILE + col] = acc[mi][ni][e];
+      }
+}
+
 // (4) G~[i][j] = 2^(e_i + e_j) / n_eff * sum over the chunks (in order, in fp64) of P[chunk][tile][i][j], and its mirror.
 // grid (n_tiles, 16): a 32 x 32 corner of the tile per workgroup; of a diagonal tile only the lower half is taken (and
 // mirrored), so every entry of G~ is written once and the matrix is symmetric to the bit.
@@ -315,8 +412,11 @@ static __global__ __launch_bounds__(256) void mg_reduce_kernel(MgReduceArgs a) {
 struct MgArgs {
   MgCtl* mg;
   WsCtl* ws;              // nullable: WsCtl::served tells which lanes the working set's model solver moved this round
-  const double* partial;  // [nblk][16][ld] of the product G~ D
+  const double* partial;  // [row sets][nblk][16][ld] of the products G~_s D
+  int64_t part_stride;    // doubles between the partial sums of two row sets
+  int32_t set_of[SLM_MAX_LANES];  // row set of lane l
   int nblk;
+  double* gd;             // [16][ld] the product, summed over its row blocks (mg_gsum_kernel)
   double* Z;              // [ld][16] D = v - z0, lane-minor: the B operand of the product
   double* x;              // [16][ld] iterate
   double* v;              // [16][ld] point the model gradient is evaluated at
@@ -337,6 +437,31 @@ static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void mg_gz_kernel(SplitAr
   if (a.done != nullptr && *a.done != 0) return;
   if (!mg_any_active(mg)) return;
   cov_gz_body(a, cb);
+}
+
+// The product's partial sums folded over the row blocks, in block order: gd[l][j] = sum_b partial[b][l][j].  A kernel of
+// its own, grid (ld / 256, lanes): the 16 MB of partial sums are then read by the whole chip -- inside mg_step_kernel
+// every lane's workgroup pulled its megabyte through ONE compute unit, 20 us of a 33 us call.
+static __global__ __launch_bounds__(256) void mg_gsum_kernel(MgArgs m, int64_t ld, const int* done) {
+  if (done != nullptr && *done != 0) return;
+  const int lane_id = blockIdx.y;
+  const MgLane* ml = &m.mg->lane[lane_id];
+  if (ml->active == 0 || ml->settled != 0) return;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= ld) return;
+  const double* part = m.partial + (int64_t)m.set_of[lane_id] * m.part_stride + (int64_t)lane_id * ld + j;
+  const int64_t bstride = (int64_t)SPLIT_LANES * ld;
+  double acc = 0.0;
+  int b = 0;
+  for (; b + 8 <= m.nblk; b += 8) {
+    double q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = part[(int64_t)(b + u) * bstride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += q[u];
+  }
+  for (; b < m.nblk; ++b) acc += part[(int64_t)b * bstride];
+  m.gd[(int64_t)lane_id * ld + j] = acc;
 }
 
 // Start of a round, one workgroup per lane, after the pass's tail kernel and the working set's model solver: does the lane
@@ -457,14 +582,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void mg_step_kernel(TailArgs a, MgArg
   // ---- model gradient at v, the step's argument into the image, curvature along the last move of v --------------
   //  s[4] = ||v - v_prev||^2   s[5] = ||gv - gv_prev||^2   s[6] = <v - v_prev, gv - gv_prev>
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const double* part = m.partial + (int64_t)lane_id * a.ld;
-  const int64_t bstride = (int64_t)SPLIT_LANES * a.ld;
   const double inv_ls = 1.0 / Ls;
-  // the model gradient: g0 + the product's partial sums over the row blocks, in block order.  All loads of a round of
-  // blocks for ALL of the thread's features go out together (block loop outside, features inside: with the loops the other
-  // way round a call was E x nblk / 4 dependent round trips to the Infinity Cache -- 35 of them, 20 us of a 33 us call)
-  auto finish_feature = [&](int j, bool ok, double gd) {
-    const double gv = g0[j] + gd;
+  // the model gradient: g0 + the product (mg_gsum_kernel has folded its partial sums)
+  const double* gdv = m.gd + off;
+  tail_for<E>(tid, p, [&](int j, bool ok) {
+    const double gv = g0[j] + gdv[j];
     const double vj = v[j];
     if (ok) {
       if (have_prev) {
@@ -477,43 +599,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void mg_step_kernel(TailArgs a, MgArg
       vp[j] = vj;
       us[j] = vj - gv * inv_ls;
     }
-  };
-  if constexpr (E > 0) {
-    constexpr int U = E <= 5 ? 4 : 2;  // blocks per round: U x E loads in flight per thread
-    double acc[E];
-    int jj[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      acc[e] = 0.0;
-      const int j = tid + e * TAIL_THREADS;
-      jj[e] = j < p ? j : 0;
-    }
-    int b = 0;
-    for (; b + U <= m.nblk; b += U) {
-      double q[U][E];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int e = 0; e < E; ++e) q[u][e] = part[(int64_t)(b + u) * bstride + jj[e]];
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc[e] += q[u][e];
-      }
-    }
-    for (; b < m.nblk; ++b) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) acc[e] += part[(int64_t)b * bstride + jj[e]];
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) finish_feature(jj[e], tid + e * TAIL_THREADS < p, acc[e]);
-  } else {
-    for (int j = tid; j < p; j += TAIL_THREADS) {
-      double gd = 0.0;
-      for (int b = 0; b < m.nblk; ++b) gd += part[(int64_t)b * bstride + j];
-      finish_feature(j, true, gd);
-    }
-  }
+  });
   // ---- prox of the lane's penalty at its current path point, step 1 / Ls, in the image --------------------------
   tail_for<E>(tid, p, [&](int j, bool ok) {
     double uu = soft(us[j], inv_ls * pt.sa * a.a0[j]);
