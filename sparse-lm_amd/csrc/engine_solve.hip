@@ -1711,12 +1711,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   const int mg_cap = (int)std::max<double>(1.0, std::min<double>((double)kMgEntries, 6.0e9 / (8.0 * (double)ld * (double)ld)));
   const bool mg_ok = use_ws && split && (big_x || mg_forced) && !sharded && !cov_on && !(o.flags & SLM_FLAG_NO_MODEL_GRAM) &&
                      (size_t)ds->lane_cap >= (size_t)kMaxLanes && ws_n_sets <= mg_cap && mg_possible(ds);
+  if (mg_ok && mg_forced) expected = 0;  // (tests: polled from the first chunk on, so that short solves reach the rounds too)
   bool mg_on = false;
   int mg_inner = 20;
   double mg_build_ms = 0.0;
   int mg_entry_of_set[SLM_MAX_LANES] = {};
   // the model Gram of every row set of the call (ws_set_of: lanes with the same row weights and scaling share one), found
   // by the fingerprint of the row weights as the lanes brought them, or built
+  int mg_built = 0;  // model Grams this call had to build
   auto mg_sets = [&]() -> int {
     const double* wdev[SLM_MAX_LANES];
     double fp[2 * SLM_MAX_LANES] = {};
@@ -1734,6 +1736,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     for (int pass = 0; pass < 2; ++pass) {
       // (first round: is there room for what is missing?  if not, every entry goes and all of the call's are built)
       if (pass == 1 && (int)ds->mg.size() + missing > mg_cap) mg_invalidate(ds);
+      if (pass == 1) mg_built += missing;
       for (int st = 0; st < ws_n_sets; ++st) {
         const int l = ws_set_lane[st];
         const bool own = lanes[l].row_weight == nullptr;
@@ -1763,7 +1766,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (rc == SLM_OK) {
       mg_on = true;
       wa.keep_full = 1;  // (from here on the working set serves what it holds: enqueue_refinement passes wa by value)
-      mg_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (mg_built > 0) mg_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     } else if (rc != SLM_ERR_OOM) {
       return rc;
     }

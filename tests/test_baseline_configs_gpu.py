@@ -66,8 +66,9 @@ def test_config2_lasso_path_full_size_is_kkt_certified(eng):
 def test_headline_path_with_a_dense_end_leaves_the_working_set_and_stays_certified(eng):
     """The headline shape on data whose path ends far beyond the 512 columns a working set holds (noise 100,
     floor 1e-3 alpha_max: thousands of non-zeros, the regime of profiles/*_headline_soak.log): the first points
-    are refined, the dense rest runs as plain steps on the sixteen-lane split pass -- against the plain four-lane
-    iteration of the same data and the optimality conditions."""
+    are refined on the working set, the dense rest takes its points from rounds on the model Gram (csrc/mg_kernels.hpp;
+    round 4: plain steps on the sixteen-lane split pass, 56 passes) -- against the plain four-lane iteration of the same
+    data, the same call without the model Gram, and the optimality conditions."""
     rng = np.random.default_rng(8)
     coef = np.zeros(P)
     coef[rng.choice(P, 145, replace=False)] = 100.0 * rng.standard_normal(145)
@@ -78,11 +79,16 @@ def test_headline_path_with_a_dense_end_leaves_the_working_set_and_stays_certifi
         pts = [(a, 0.0, 0.0) for a in alphas]
         res = ds.solve_path(pts, lanes=16)
         ref = ds.solve_path(pts, lanes=4, flags=_engine.FLAG_NO_WORKING_SET, tol=1e-9)
-        assert res.converged and ref.converged
+        plain = ds.solve_path(pts, lanes=16, flags=_engine.FLAG_NO_MODEL_GRAM)
+        assert res.converged and ref.converged and plain.converged
         nnz = (res.betas != 0).sum(axis=1)
         assert nnz[-1] >= 2000 and res.ws_builds >= 1 and res.ws_refined >= 16
-        assert res.grad_launches < ref.grad_launches
+        # the dense regime: two passes per band of sixteen points where the plain steps took eight to twelve
+        # (measured: 14-15 passes with the rounds, 56 without, 150 on four plain lanes)
+        assert res.mg_rounds > 0 and res.mg_rejected == 0 and plain.mg_rounds == 0
+        assert res.grad_launches <= 20 and plain.grad_launches >= 2 * res.grad_launches and res.grad_launches < ref.grad_launches
         assert np.max(np.abs(res.betas - ref.betas)) < 1e-6 * np.max(np.abs(ref.betas))
+        assert np.max(np.abs(plain.betas - ref.betas)) < 1e-6 * np.max(np.abs(ref.betas))
         gidx, G = oracle.group_index(None, P)
         zero = np.zeros(G)
         for k in (10, 30, 49):  # sparse, at the cap, dense
