@@ -524,6 +524,10 @@ def leg_config4_dense(eng, n, p, noise_sd=100.0):
         for call in calls:
             c4.run_call(c4.ds, call, keep_x)
         seconds, passes = min(c4.run(calls) for _ in range(2))
+        from sparselm_amd import _engine
+        c4.flags |= _engine.FLAG_NO_MODEL_GRAM  # round 4's route: plain sixteen-lane passes beyond the working set
+        seconds_plain, passes_plain = c4.run(calls)
+        c4.flags &= ~_engine.FLAG_NO_MODEL_GRAM
         nnz = sorted(int(np.count_nonzero(keep_x[(u, c4.K - 1)])) for u in range(len(c4.units)))
         above = sum(int(np.count_nonzero(b)) > 512 for b in keep_x.values())
         build = c4.build_covariance()
@@ -531,7 +535,8 @@ def leg_config4_dense(eng, n, p, noise_sd=100.0):
             c4.run_call(c4.ds, call, keep_c)
         seconds_c, passes_c = min(c4.run(calls) for _ in range(2))
         worst = max(float(np.max(np.abs(keep_c[k] - keep_x[k])) / max(float(np.max(np.abs(keep_x[k]))), 1e-300)) for k in keep_x)
-        return {"seconds": seconds, "passes": passes, "seconds_covariance": seconds_c, "passes_covariance": passes_c,
+        return {"seconds": seconds, "passes": passes, "seconds_without_model_gram": seconds_plain, "passes_without_model_gram": passes_plain,
+                "seconds_covariance": seconds_c, "passes_covariance": passes_c,
                 "covariance_build_s": build, "nnz_last_min_median_max": [nnz[0], nnz[len(nnz) // 2], nnz[-1]],
                 "points_above_512_nonzeros": above, "worst_rel_inf_diff": worst, "noise_sd": noise_sd}
     finally:
@@ -592,8 +597,8 @@ def soak_case(seed, p):
 def leg_soak(eng, n, p, K, tol, lanes, seeds=range(4, 16)):
     """The headline path on a DISTRIBUTION of datasets of the headline shape, not on the one the value is quoted on:
     twelve seeds of `soak_case` (five of them noise-fitting paths whose ends outgrow the 512-column working set and
-    finish as plain steps on the sixteen-lane split pass).  Every path is checked against the plain four-lane
-    iteration of the same data (no working set, tol 1e-9)."""
+    take their points from rounds on the model Gram; round 4: plain steps on the sixteen-lane split pass).  Every path is
+    checked against the plain four-lane iteration of the same data (no working set, tol 1e-9)."""
     from sparselm_amd import _engine
 
     rows = []
@@ -603,7 +608,10 @@ def leg_soak(eng, n, p, K, tol, lanes, seeds=range(4, 16)):
             g0, _ = ds.gradient(None)
             amax = float(np.max(np.abs(g0)))
             pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, lo * amax, K)]
-            ds.solve_path(pts, tol=tol, lanes=lanes, flags=_engine.FLAG_FRESH_L)  # (one-off costs of a fresh dataset)
+            eng.synchronize()
+            t0 = time.perf_counter()
+            first = ds.solve_path(pts, tol=tol, lanes=lanes, flags=_engine.FLAG_FRESH_L)  # (one-off costs of a fresh dataset:
+            first_ms = 1e3 * (time.perf_counter() - t0)                                   #  column-major copy, work space, model Gram)
             best = None
             for _ in range(2):
                 eng.synchronize()
@@ -613,7 +621,15 @@ def leg_soak(eng, n, p, K, tol, lanes, seeds=range(4, 16)):
                 best = dt if best is None else min(best, dt)
             q = ds.solve_path(pts, lanes=4, flags=_engine.FLAG_NO_WORKING_SET, tol=1e-9)
             err = float(np.max(np.abs(r.betas - q.betas)) / max(float(np.max(np.abs(q.betas))), 1e-300))
+            plain_ms = plain_passes = None
+            if r.mg_rounds > 0:  # the same path with plain steps beyond the working set (round 4's route)
+                t0 = time.perf_counter()
+                w = ds.solve_path(pts, tol=tol, lanes=lanes, flags=_engine.FLAG_FRESH_L | _engine.FLAG_NO_MODEL_GRAM)
+                plain_ms, plain_passes = 1e3 * (time.perf_counter() - t0), int(w.grad_launches)
             rows.append({"seed": int(seed), "informative": k, "noise": noise, "floor": lo, "ms": 1e3 * best,
+                         "first_solve_ms": first_ms, "model_gram_build_ms": float(first.mg_build_ms), "model_gram_rounds": int(r.mg_rounds),
+                         "model_gram_inner_iters": int(r.mg_inner_iters), "model_gram_rejected": int(r.mg_rejected),
+                         "ms_without_model_gram": plain_ms, "passes_without_model_gram": plain_passes,
                          "fits_per_s": K / best, "passes": int(r.grad_launches), "plain_passes": int(q.grad_launches),
                          "nnz_last": int(np.count_nonzero(r.betas[-1])), "ws_columns": int(r.ws_columns),
                          "converged": bool(r.converged and q.converged), "rel_inf_err_vs_plain": err})
@@ -984,6 +1000,25 @@ def main():
             bytes_per_grad = 8.0 * (n * p + 2 * n + 2 * p * lanes_used)
         t_grad_ms = grad_ms / max(1, grad_timed)
         achieved = bytes_per_grad / (t_grad_ms * 1e-3) / 1e9 if t_grad_ms > 0 else 0.0
+        # after the timed region, same dataset, same run: (i) the whole gradient unit of the split pass under the same HIP
+        # events -- residuals of the sixteen lane slots (resid_mfma_kernel, and rowdot_mfma_kernel's empty launch) + X^T R --
+        # charged ONE W; (ii) the read-only stream ceiling of THIS device on THIS copy of X (plain 16-byte loads, summed up)
+        unit_ms = ceiling_gbs = ceiling_ms = None
+        if split:
+            os.environ["SLM_PROFILE_UNIT"] = "1"
+            try:
+                u_ms, u_n = 0.0, 0
+                for _ in range(2):
+                    ru = ds.solve_path(points, tol=args.tol, flags=flags, lanes=args.lanes)
+                    u_ms += ru.grad_ms_total
+                    u_n += ru.grad_timed
+                unit_ms = u_ms / max(1, u_n)
+            finally:
+                del os.environ["SLM_PROFILE_UNIT"]
+        try:
+            ceiling_gbs, ceiling_ms = ds.read_ceiling(reps=5)
+        except Exception:  # noqa: BLE001 -- a measurement beside the line, never its condition
+            pass
         secs = [r["seconds"] for r in per_rank]
         out = {
             "metric": "fits/sec over 50-alpha Lasso path at n=100k p=5k",
@@ -1038,6 +1073,15 @@ def main():
                 "kernel": (f"xtr_mfma_kernel (X^T R of the split pass on the matrix cores, lanes={lanes_used})" if split
                            else f"grad_fused_kernel (lanes={lanes_used})"),
                 "avg_kernel_ms": t_grad_ms,
+                "gradient_unit_ms": unit_ms,
+                "gradient_unit_frac": (bytes_per_grad / (unit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if unit_ms else None,
+                "gradient_unit_what": "residuals of the sixteen lane slots (resid_mfma_kernel on the gathered columns) + xtr_mfma_kernel, "
+                "one bracket of HIP events per pass (SLM_PROFILE_UNIT=1), charged the same algorithmic bytes: what a 16-lane gradient costs",
+                "read_stream_ceiling_gbs": ceiling_gbs,
+                "read_stream_ceiling_ms_per_sweep": ceiling_ms,
+                "frac_of_read_stream_ceiling": (achieved / ceiling_gbs) if ceiling_gbs else None,
+                "read_stream_ceiling_what": "slm_dataset_read_ceiling: the device copy of X swept by plain 16-byte loads that are only "
+                "summed up, same device, same run (the guide's 6.29 TB/s is a float4 COPY; `peak` stays the 8 TB/s of the data sheet)",
                 "launches": grad_launches,
                 "launches_timed_with_hip_events": grad_timed,
                 "algorithmic_bytes_per_launch": bytes_per_grad,
@@ -1178,9 +1222,13 @@ def main():
                     if q.get("seconds"):
                         legs[name] = {
                             "what": "config 4's grid with noise 100 (every path ends at thousands of non-zeros; the 512-column "
-                            "working set gives up on a quarter of the points and the lanes go on with plain sixteen-lane passes, "
-                            "two reads of X each), over X and from the folds' Grams (SLM_FLAG_COVARIANCE); one GPU, rank 0",
+                            "working set gives up on a quarter of the points): over X -- those points on rounds on the folds' model "
+                            "Grams (five fp16 products, built inside the first call that needs them and kept; *_without_model_gram: "
+                            "plain sixteen-lane passes of two reads of X, round 4's route) -- and from the folds' fp64 Grams "
+                            "(SLM_FLAG_COVARIANCE); one GPU, rank 0",
                             "seconds_per_grid": q["seconds"], "fits_per_s": 2500.0 / q["seconds"], "passes": q["passes"],
+                            "seconds_per_grid_without_model_gram": q.get("seconds_without_model_gram"),
+                            "passes_without_model_gram": q.get("passes_without_model_gram"),
                             "covariance": {"seconds_per_grid": q["seconds_covariance"], "fits_per_s": 2500.0 / q["seconds_covariance"],
                                            "passes": q["passes_covariance"], "build_s": q["covariance_build_s"],
                                            "speedup": q["seconds"] / q["seconds_covariance"]},
@@ -1212,6 +1260,23 @@ def main():
                         "worst_rel_inf_err_vs_plain_iteration": max(c["rel_inf_err_vs_plain"] for c in cases),
                         "all_converged": all(c["converged"] for c in cases),
                         "median_ms_dense_end": (sorted(c["ms"] for c in dense)[len(dense) // 2] if dense else None),
+                        "model_gram": {
+                            "what": "paths whose ends outgrow the working set take their points from rounds on the model Gram "
+                            "(csrc/mg_kernels.hpp: an fp16 MFMA product of all of X^T X / n, built once per dataset inside the first "
+                            "solve that needs it; every proposal verified by a pass over X in fp64).  ms / passes: the steady state "
+                            "(Gram there); first_solve_ms: the fresh dataset's first path, build included; *_without: the same "
+                            "paths with SLM_FLAG_NO_MODEL_GRAM (plain sixteen-lane passes of two reads, round 4's route)",
+                            "seeds": [c["seed"] for c in cases if c["model_gram_rounds"] > 0],
+                            "ms": [round(c["ms"], 2) for c in cases if c["model_gram_rounds"] > 0],
+                            "passes": [c["passes"] for c in cases if c["model_gram_rounds"] > 0],
+                            "first_solve_ms": [round(c["first_solve_ms"], 2) for c in cases if c["model_gram_rounds"] > 0],
+                            "build_ms": [round(c["model_gram_build_ms"], 2) for c in cases if c["model_gram_rounds"] > 0],
+                            "ms_without": [round(c["ms_without_model_gram"], 2) for c in cases if c["model_gram_rounds"] > 0],
+                            "passes_without": [c["passes_without_model_gram"] for c in cases if c["model_gram_rounds"] > 0],
+                            "rejected_proposals": sum(c["model_gram_rejected"] for c in cases),
+                        },
+                        "worst_first_solve_fits_per_s": min(K / (1e-3 * c["first_solve_ms"]) for c in cases),
+                        "worst_fits_per_s_without_model_gram": min([K / (1e-3 * c["ms_without_model_gram"]) for c in cases if c["ms_without_model_gram"]] or [0.0]) or None,
                         "median_ms_sparse_end": sorted(c["ms"] for c in cases if c["nnz_last"] <= 512)[(len(cases) - len(dense)) // 2]
                         if len(dense) < len(cases) else None,
                     }
@@ -1282,6 +1347,9 @@ def main():
             "config3_referee_rel_inf_err": pick("config3_path", "referee", "beta_rel_inf_err_gpu_vs_oracle"),
             "soak_median_fits_per_s": pick("soak", "median_fits_per_s"),
             "soak_worst_fits_per_s": pick("soak", "worst_fits_per_s"),
+            "soak_worst_first_solve_fits_per_s": pick("soak", "worst_first_solve_fits_per_s"),
+            "soak_worst_fits_per_s_without_model_gram": pick("soak", "worst_fits_per_s_without_model_gram"),
+            "config4_dense_regime_over_x_without_model_gram_s": pick("config4_grid_dense_regime", "seconds_per_grid_without_model_gram"),
             "plain_fista_fits_per_s": pick("plain_fista", "fits_per_s"),
             "plain_fista_passes": pick("plain_fista", "passes"),
             "plain_fista_roofline_frac_per_unit": pick("plain_fista", "roofline_frac_per_unit_one_W"),

@@ -435,6 +435,13 @@ int slm_dataset_covariance_clear(slm_dataset* ds);
 int slm_dataset_covariance_download(slm_dataset* ds, int32_t index, double* G_out, double* c_out, double scalars_out[4]);
 
 /*
+ * Measurement: the rate at which THIS device streams the dataset's copy of X through plain 16-byte loads that are only
+ * summed up (`reps` sweeps after one warm-up, HIP events) -- the read-only ceiling the passes over X are read against
+ * (bench.py `roofline.read_stream_ceiling_gbs`; SURVEY Appendix D asks for it, the reference has no counterpart).
+ */
+int slm_dataset_read_ceiling(slm_dataset* ds, int32_t reps, double* gbs_out, double* ms_out);
+
+/*
  * The model Gram (csrc/mg_kernels.hpp): G~ ~ X^T W X / n of the dataset's own rows and row weights from ONE product on the
  * fp16 matrix cores (columns scaled by powers of two, fp32 accumulation over chunks of rows, chunks summed in fp64):
  * relative error ~1e-4, built in a few milliseconds where the fp64 Gram of slm_dataset_covariance takes ten times as

@@ -50,6 +50,49 @@ static __global__ __launch_bounds__(256) void tile_columns_kernel(const double* 
   }
 }
 
+// Read-only stream over a buffer (slm_dataset_read_ceiling): the rate the memory system delivers to plain 16-byte loads
+// with nothing to do but add them up -- the ceiling a pass over X is to be read against on THIS device (SURVEY Appendix D;
+// the microarchitecture guide's 6.29 TB/s is a float4 COPY, half of whose traffic is stores).  Every workgroup walks a
+// contiguous part of the buffer, a wavefront 1 KiB per load instruction, U instructions in flight per thread; one sum per
+// workgroup so that nothing is optimised away.  The host tries several (workgroups per CU, U, cached / non-temporal) and
+// reports the best: a ceiling is the best stream found, not one guess at it.
+// RR: the workgroups take the chunks of U x 4 KiB in turn (at any moment the chip reads one window of the buffer) instead
+// of a contiguous part each
+template <int U, bool NT, bool RR = false>
+__global__ __launch_bounds__(256) void read_stream_kernel(const double* __restrict__ src, int64_t count2 /* 16-byte pieces */,
+                                                          double* __restrict__ sink) {
+  const d2* p = reinterpret_cast<const d2*>(src);
+  const int64_t per = (count2 + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = RR ? (int64_t)blockIdx.x * (U * 256) : (int64_t)blockIdx.x * per;
+  const int64_t hi = RR ? count2 : (lo + per < count2 ? lo + per : count2);
+  const int64_t step = RR ? (int64_t)gridDim.x * (U * 256) : (int64_t)U * 256;
+  double a0 = 0.0, a1 = 0.0;
+  int64_t i = lo + threadIdx.x;
+  for (; i + (int64_t)(U - 1) * 256 < hi; i += step) {
+    d2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + u * 256) : p[i + u * 256];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a0 += v[u].x;
+      a1 += v[u].y;
+    }
+  }
+  if (!RR || blockIdx.x == 0) {  // (the tail: a few KiB at most)
+    if (RR) i = (count2 / (U * 256)) * (U * 256) + threadIdx.x;
+    for (; i < hi; i += 256) {
+      const d2 v = p[i];
+      a0 += v.x;
+      a1 += v.y;
+    }
+  }
+  const double t = wave_sum_all(a0 + a1);
+  __shared__ double w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) sink[blockIdx.x] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+
 // Row-major copy with different leading dimensions (device -> device), pad columns left untouched.
 static __global__ __launch_bounds__(256) void copy_rows_kernel(const double* __restrict__ src, int64_t n,
                                                         int64_t p, int64_t lds_, double* __restrict__ dst,

@@ -253,6 +253,10 @@ int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y
   a.n = nr; a.ld = ds->ld; a.rows_base = nr / nblk; a.rows_rem = nr % nblk;
   a.p2 = (int)(ds->ld / 2);
   a.n_lanes = ls.B;
+  // (SLM_PROFILE_UNIT=1: the bracket of SLM_FLAG_PROFILE opens here -- the whole gradient unit, residuals and X^T R, not the
+  //  stream over X alone: bench.py's roofline.gradient_unit_frac)
+  const bool unit = ev_start != nullptr && getenv("SLM_PROFILE_UNIT") != nullptr;
+  if (unit) HIP_TRY(hipEventRecord(ev_start, s));
   launch_rowdot(ds, sk, nblk, ls.B, a, s);
   if (wa && ctl) {  // residuals from the gathered columns: matrix cores (SLM_RESID_VEC=1: a row per thread)
     const char* env = getenv("SLM_RESID_VEC");
@@ -260,7 +264,7 @@ int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y
     else hipLaunchKernelGGL(resid_mfma_kernel, dim3(nblk), dim3(RM_WAVES * 64), 0, s, a);
   }
   // (SLM_FLAG_PROFILE brackets the kernel that streams X, the one the roofline is quoted on)
-  if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
+  if (ev_start && !unit) HIP_TRY(hipEventRecord(ev_start, s));
   const int xblk = launch_xtr(ds->eng->cus, a, s, n_rows > 0 && ctl != nullptr);  // (rows of a sample start: solve_core)
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
   ReduceArgs ra;
@@ -621,6 +625,67 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
     (void)hipEventDestroy(e1);
     SLM_TRY(check_launch());
   }
+  return SLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the read-only stream ceiling of this device, measured on the dataset's own copy of X
+// ------------------------------------------------------------------------------------------------
+extern "C" int slm_dataset_read_ceiling(slm_dataset* ds, int32_t reps, double* gbs_out, double* ms_out) {
+  if (!ds || !gbs_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  if (reps < 1) reps = 1;
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  hipStream_t s = ds->eng->stream;
+  const int64_t count2 = ds->n * ds->ld / 2;  // (ld is a multiple of 16)
+  const int cus = ds->eng->cus;
+  double* sink = nullptr;
+  SLM_TRY(dalloc(&sink, (size_t)cus * 16));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  typedef void (*Kernel)(const double*, int64_t, double*);
+  struct Form { Kernel fn; int per_cu; const char* name; };
+  const Form forms[] = {
+      {read_stream_kernel<8, true>, 1, "1 workgroup per CU, 8 loads in flight, non-temporal"},
+      {read_stream_kernel<8, true>, 2, "2 per CU, 8, non-temporal"},
+      {read_stream_kernel<8, true>, 4, "4 per CU, 8, non-temporal"},
+      {read_stream_kernel<16, true>, 1, "1 per CU, 16, non-temporal"},
+      {read_stream_kernel<16, true>, 2, "2 per CU, 16, non-temporal"},
+      {read_stream_kernel<8, false>, 2, "2 per CU, 8, cached"},
+      {read_stream_kernel<8, false>, 4, "4 per CU, 8, cached"},
+      {read_stream_kernel<4, true>, 8, "8 per CU, 4, non-temporal"},
+      {read_stream_kernel<8, true, true>, 1, "1 per CU, 8, non-temporal, chunks in turn"},
+      {read_stream_kernel<8, true, true>, 2, "2 per CU, 8, non-temporal, chunks in turn"},
+      {read_stream_kernel<8, true, true>, 4, "4 per CU, 8, non-temporal, chunks in turn"},
+      {read_stream_kernel<16, true, true>, 2, "2 per CU, 16, non-temporal, chunks in turn"},
+      {read_stream_kernel<4, false, true>, 8, "8 per CU, 4, cached, chunks in turn"},
+  };
+  double best = 1e300;
+  const char* best_name = "";
+  const bool trace = getenv("SLM_TRACE") != nullptr;
+  for (const Form& f : forms) {
+    const int blocks = cus * f.per_cu;
+    hipLaunchKernelGGL(f.fn, dim3(blocks), dim3(256), 0, s, (const double*)ds->X, count2, sink);  // warm
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(f.fn, dim3(blocks), dim3(256), 0, s, (const double*)ds->X, count2, sink);
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    const double per = (double)ms / reps;
+    if (trace) fprintf(stderr, "[slm] read stream, %s: %.4f ms per sweep = %.0f GB/s\n", f.name, per, 16.0 * (double)count2 / (per * 1e-3) / 1e9);
+    if (per < best) {
+      best = per;
+      best_name = f.name;
+    }
+  }
+  (void)best_name;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  dfree(sink);
+  SLM_TRY(check_launch());
+  if (ms_out) *ms_out = best;
+  *gbs_out = 16.0 * (double)count2 / (best * 1e-3) / 1e9;
   return SLM_OK;
 }
 

@@ -87,6 +87,7 @@ ABI_SYMBOLS = (
     "slm_dataset_covariance_clear",
     "slm_dataset_covariance_download",
     "slm_dataset_model_gram",
+    "slm_dataset_read_ceiling",
     "slm_dataset_set_replicated",
     "slm_comm_unique_id",
     "slm_comm_init",
@@ -296,6 +297,7 @@ def load_library():
             "slm_dataset_covariance_clear": [vp],
             "slm_dataset_covariance_download": [vp, i32, vp, vp, vp],
             "slm_dataset_model_gram": [vp, vp],
+            "slm_dataset_read_ceiling": [vp, i32, P(dbl), P(dbl)],
             "slm_dataset_set_replicated": [vp, i32],
             "slm_comm_unique_id": [vp],
             "slm_comm_init": [vp, i32, i32, vp],
@@ -954,6 +956,13 @@ class Dataset:
         sc = np.empty(4)
         _check(self._lib.slm_dataset_covariance_download(self._h, int(index), _ptr(G), _ptr(c), _ptr(sc)))
         return G, c, {"yy": float(sc[0]), "n_eff": float(sc[1]), "fingerprint": (float(sc[2]), float(sc[3]))}
+
+    def read_ceiling(self, reps: int = 5) -> tuple[float, float]:
+        """(GB/s, ms per sweep) of a read-only stream over the device copy of X: plain 16-byte loads, summed up -- the ceiling
+        the passes over X are read against on this device."""
+        gbs, ms = C.c_double(), C.c_double()
+        _check(self._lib.slm_dataset_read_ceiling(self._h, int(reps), C.byref(gbs), C.byref(ms)))
+        return float(gbs.value), float(ms.value)
 
     def model_gram(self, download: bool = False):
         """Build the model Gram of the dataset now (``csrc/mg_kernels.hpp``: ``X^T W X / n`` from an fp16 product, what lanes
