@@ -840,6 +840,7 @@ def leg_rowshard(eng, rank, world, n_rank, p, reps=2):
             beta = None
             passes = 0
             eng.synchronize()
+            c_before = eng.comm_collectives()
             t0 = time.perf_counter()
             for _ in range(3):
                 res = ds.solve_path([(0.0, 1.0, 0.0)], b=w, beta0=beta, tol=1e-8, want_group_norms=True)
@@ -850,7 +851,13 @@ def leg_rowshard(eng, rank, world, n_rank, p, reps=2):
             dt = time.perf_counter() - t0
             out = {"seconds_per_fit": dt, "passes": passes, "converged": bool(res.converged),
                    "active_groups": int(np.sum(res.group_norms[0] > 0)), "rccl_ranks": comm_ranks, "device": eng.device_id,
-                   "beta_checksum": float(np.sum(beta * np.arange(1, p + 1)))}
+                   "beta_checksum": float(np.sum(beta * np.arange(1, p + 1))),
+                   "collectives_per_pass_incl_first": (eng.comm_collectives() - c_before) / max(1, passes)}
+        # the two collectives of a pass on their own, on this communicator: the lanes' gradients (one lane: ld + 16 doubles) and
+        # the working set's Gram parts with the stop words behind them (512 x 512 + 16); per collective, back to back
+        ld = (p + 15) // 16 * 16
+        out["collective_us"] = {"gradient_1_lane": eng.comm_all_reduce_us(ld + 16), "gram_parts_and_stop_words": eng.comm_all_reduce_us(512 * 512 + 16),
+                                "packed_in_one": eng.comm_all_reduce_us(ld + 16 + 512 * 512 + 16), "stop_words_alone": eng.comm_all_reduce_us(16)}
         return out
     finally:
         if ds is not None:
@@ -1319,6 +1326,8 @@ def main():
                         "active_groups": parts[0]["active_groups"],
                         "ranks_hold_identical_coefficients": max(sums) == min(sums),
                         "rows_per_s": world * args.rowshard_rows * parts[0]["passes"] / max(secs),
+                        "collective_us": parts[0].get("collective_us"),
+                        "collectives_per_pass_incl_first": parts[0].get("collectives_per_pass_incl_first"),
                     }
     if out is not None:
         # the legs' headline figures once more as plain scalars (a reader that keeps only the shallow part of the line
@@ -1332,8 +1341,27 @@ def main():
             return v if isinstance(v, (int, float, str, bool)) else None
 
         e8 = ("config4_grid_emulated_world8", "shared_grams")
+        # THE strong-scaling figure of a multi-GPU run: BASELINE config 4's grid, total work fixed, dealt to the ranks (the weak
+        # headline `value` is independent paths per GPU and scales trivially).  The driver computes efficiency from the
+        # per-N values of this object; at N = 1 it is the one-GPU time the emulated shares are compared with.
+        c4_s, c4_cov_s = pick("config4_grid", "seconds_per_grid"), pick("config4_grid", "covariance", "seconds_per_grid")
+        if c4_s:
+            out["strong_scaling"] = {
+                "metric": "fits/sec over the 2500-fit SparseGroupLasso grid of BASELINE config 4 (5 folds x 10 l1_ratio x 50 alpha, n=100k p=5k)",
+                "scaling": "strong", "n_gpus": world, "unit": "fits/s", "higher_is_better": True,
+                "value": 2500.0 / c4_s, "seconds_per_grid": c4_s, "route": "over X (path points dealt to the lane slots of all ranks, no collective)",
+                "value_from_fold_grams": (2500.0 / c4_cov_s) if c4_cov_s else None, "seconds_per_grid_from_fold_grams": c4_cov_s,
+                "note": "measured on this run's ranks; with one rank, extra_legs.config4_grid_emulated_world8 holds the eight-rank shares "
+                "as timed one after the other on this GPU -- an emulation, not a measurement on eight devices",
+            }
+        if world > 1 and pick("rowshard", "rccl_ranks") is not None:
+            # a run on several devices whose row-sharded leg did not join them all is a failed run, said so in the line
+            out["rowshard_joined_all_ranks"] = bool(pick("rowshard", "rccl_ranks") == world)
         out["summary"] = {k: v for k, v in {
-            "config4_one_gpu_over_x_s": pick("config4_grid", "seconds_per_grid"),
+            "config4_strong_scaling_fits_per_s": (2500.0 / c4_s) if c4_s else None,
+            "config4_strong_scaling_seconds_per_grid": c4_s,
+            "config4_strong_scaling_n_gpus": world if c4_s else None,
+            "config4_one_gpu_over_x_s": pick("config4_grid", "seconds_per_grid") if world == 1 else None,
             "config4_one_gpu_from_grams_s": pick("config4_grid", "covariance", "seconds_per_grid"),
             "config4_grams_build_s": pick("config4_grid", "covariance", "build_s"),
             "config4_one_gpu_from_grams_three_streams_s": pick("config4_grid", "covariance", "seconds_per_grid_streams"),
@@ -1360,12 +1388,16 @@ def main():
             "rowshard_seconds_per_fit": pick("rowshard", "seconds_per_fit"),
             "rowshard_rccl_ranks": pick("rowshard", "rccl_ranks"),
             "rowshard_status": pick("rowshard", "status"),
+            "rowshard_collective_us_gradient": pick("rowshard", "collective_us", "gradient_1_lane"),
+            "rowshard_collective_us_gram_parts": pick("rowshard", "collective_us", "gram_parts_and_stop_words"),
             "sklearn_lasso_path_fits_per_s": ((out.get("cpu_baseline") or {}).get("sklearn_lasso_path") or {}).get("value"),
             "gpu_vs_sklearn_rel_inf_err": ((out.get("cpu_baseline") or {}).get("sklearn_lasso_path") or {}).get("beta_rel_inf_err_gpu_vs_sklearn"),
             "path_level_roofline_frac": out["roofline"]["path_level"]["frac"],
         }.items() if v is not None}
         # (the summary last but for the legs it condenses: a reader of the line's tail sees it whole)
         ordered = {k: v for k, v in out.items() if k not in ("extra_legs", "summary")}
+        if world > 1 and out.get("rowshard_joined_all_ranks") is False:
+            os.write(2, b"[bench] the row-sharded leg's RCCL communicator did not join every rank\n")
         if "extra_legs" in out:
             ordered["extra_legs"] = out["extra_legs"]
         ordered["summary"] = out["summary"]

@@ -478,6 +478,10 @@ int slm_comm_info(slm_engine* eng, int32_t* rank_out, int32_t* n_ranks_out);
    on it at every quiescent point (the row-sharded state machine takes its stop decision from a word the
    ranks all-reduce after every pass, so that they do whatever their own states say). */
 int slm_comm_collectives(slm_engine* eng, int64_t* count_out);
+/* Measurement: microseconds per all-reduce of `count` doubles on the engine's communicator (`reps` of them on its stream,
+ * after one warm-up, HIP events) -- the per-collective floor of a row-sharded pass (bench.py `rowshard.collective_us`).
+ * Every rank of the communicator calls it with the same arguments. */
+int slm_comm_all_reduce_probe(slm_engine* eng, int64_t count, int32_t reps, double* us_out);
 /*
  * In-process communicator: the n_ranks engines (one process, ONE device, each driven by its own host
  * thread) become the ranks of a row-sharded job; the all-reduce is a rendezvous of their streams with the

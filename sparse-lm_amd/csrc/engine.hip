@@ -788,6 +788,38 @@ extern "C" int slm_comm_collectives(slm_engine* eng, int64_t* count_out) {
   return SLM_OK;
 }
 
+// Measurement: `reps` all-reduces of `count` doubles on the engine's communicator, one after the other on its stream
+// (after one warm-up), by HIP events: microseconds per collective -- the latency floor a row-sharded pass pays per
+// collective (bench.py `rowshard.collective_us`).  Every rank of the communicator must call it with the same arguments.
+extern "C" int slm_comm_all_reduce_probe(slm_engine* eng, int64_t count, int32_t reps, double* us_out) {
+  if (!eng || !us_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  if (!eng->sharded()) return fail(SLM_ERR_COMM, "the engine has no communicator");
+  if (count < 1 || reps < 1) return fail(SLM_ERR_BAD_ARG, "count and reps must be positive");
+  HIP_TRY(hipSetDevice(eng->device));
+  double* buf = nullptr;
+  SLM_TRY(dalloc(&buf, (size_t)count));
+  HIP_TRY(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)count, eng->stream));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  int rc = all_reduce_sum(eng, buf, (size_t)count);
+  if (rc == SLM_OK) {
+    (void)hipEventRecord(e0, eng->stream);
+    for (int r = 0; r < reps && rc == SLM_OK; ++r) rc = all_reduce_sum(eng, buf, (size_t)count);
+    (void)hipEventRecord(e1, eng->stream);
+  }
+  hipError_t e = hipStreamSynchronize(eng->stream);
+  float ms = 0.f;
+  if (rc == SLM_OK && e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  dfree(buf);
+  if (rc != SLM_OK) return rc;
+  if (e != hipSuccess) return fail(SLM_ERR_HIP, "all-reduce probe: %s", hipGetErrorString(e));
+  *us_out = 1e3 * (double)ms / reps;
+  return SLM_OK;
+}
+
 static void local_comm_release(LocalComm* lc) {
   bool last = false;
   {

@@ -93,6 +93,7 @@ ABI_SYMBOLS = (
     "slm_comm_init",
     "slm_comm_info",
     "slm_comm_collectives",
+    "slm_comm_all_reduce_probe",
     "slm_comm_init_local",
     "slm_dataset_set_global_rows",
     "slm_comm_destroy",
@@ -303,6 +304,7 @@ def load_library():
             "slm_comm_init": [vp, i32, i32, vp],
             "slm_comm_info": [vp, P(i32), P(i32)],
             "slm_comm_collectives": [vp, P(i64)],
+            "slm_comm_all_reduce_probe": [vp, i64, i32, P(dbl)],
             "slm_comm_init_local": [P(vp), i32, dbl],
             "slm_dataset_set_global_rows": [vp, i64],
             "slm_comm_destroy": [vp],
@@ -597,6 +599,12 @@ class Engine:
         n = C.c_int64()
         _check(self._lib.slm_comm_collectives(self._h, C.byref(n)))
         return int(n.value)
+
+    def comm_all_reduce_us(self, count: int, reps: int = 20) -> float:
+        """Microseconds per all-reduce of ``count`` doubles on this engine's communicator (every rank calls it alike)."""
+        us = C.c_double()
+        _check(self._lib.slm_comm_all_reduce_probe(self._h, int(count), int(reps), C.byref(us)))
+        return float(us.value)
 
     # -- diagnostics ------------------------------------------------------------------------------
     def dense_spd_solve(self, H, rhs):
