@@ -30,22 +30,46 @@ def _stale(out=OUT, deps=None) -> bool:
     return newest > os.path.getmtime(out)
 
 
-def build_binding(force: bool = False) -> str:
-    """The compiled Python binding of the hot calls (pybind11, g++): links against libslm_hip.so next to it."""
+SAN_BINDING = os.path.join(OUT_DIR, "san", "_slm_binding.so")  # the same module under ASan + UBSan (tools/sanitize.sh)
+
+
+def build_binding(force: bool = False, sanitize: bool = False) -> str:
+    """The compiled Python binding of the hot calls (pybind11, g++): links against libslm_hip.so next to it.
+    ``sanitize``: a second copy built with ``-fsanitize=address,undefined`` under ``_lib/san/`` -- host code only, for the
+    container (``SLM_BINDING_PATH`` points the loader at it; the sanitizer runtimes have to be preloaded into python)."""
     src = os.path.join(CSRC, "binding.cpp")
-    if not force and not _stale(BINDING, [src, OUT]):
-        return BINDING
+    out = SAN_BINDING if sanitize else BINDING
+    if not force and not _stale(out, [src, OUT]):
+        return out
     import sysconfig
 
     import pybind11
 
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    extra = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"] if sanitize else ["-O2"]
     cmd = [
-        CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+        CXX, *extra, "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
         f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}",
-        src, "-o", BINDING, f"-L{OUT_DIR}", "-lslm_hip", "-Wl,-rpath,$ORIGIN",
+        src, "-o", out, f"-L{OUT_DIR}", "-lslm_hip", "-Wl,-rpath,$ORIGIN" + ("/.." if sanitize else ""),
     ]
     subprocess.run(cmd, check=True)
-    return BINDING
+    return out
+
+
+def _binding_or_warn(force: bool) -> None:
+    """The binding is an accelerator of the Python side, not a condition of the engine: without pybind11 or the Python
+    headers the ctypes route (sparselm_amd/_engine.py) serves every call.  (__graft_entry__.build() asserts it is there.)"""
+    try:
+        build_binding(force)
+        if os.environ.get("SLM_SANITIZE"):
+            build_binding(force, sanitize=True)
+    except (ImportError, OSError, subprocess.CalledProcessError) as exc:
+        import warnings
+
+        for stale in (BINDING, SAN_BINDING):  # (a module of another ABI must not be found later)
+            if os.path.exists(stale):
+                os.remove(stale)
+        warnings.warn(f"the compiled binding was not built ({exc!r}); the ctypes route serves every call", RuntimeWarning)
 
 
 UNITS = ("engine.hip", "engine_solve.hip", "engine_cov.hip", "engine_mg.hip")  # handles / memory / communicators; solve loop; Grams; model Gram
@@ -53,7 +77,7 @@ UNITS = ("engine.hip", "engine_solve.hip", "engine_cov.hip", "engine_mg.hip")  #
 
 def build(force: bool = False, extra_flags=()) -> str:
     if not force and not _stale():
-        build_binding(False)
+        _binding_or_warn(False)
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
     obj_dir = os.path.join(HERE, "build")
@@ -69,7 +93,7 @@ def build(force: bool = False, extra_flags=()) -> str:
     with ThreadPoolExecutor(max_workers=len(UNITS)) as pool:  # (the units compile side by side: 38 s instead of 60)
         objs = list(pool.map(compile_unit, UNITS))
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT, "-ldl"], check=True)
-    build_binding(True)
+    _binding_or_warn(True)
     return OUT
 
 

@@ -134,68 +134,43 @@ static size_t pool_idle_cap() {
   }();
   return cap;
 }
+// (the ledger itself -- which block waits, which is evicted -- is host_logic.hpp's PoolLedger: no device call in it, run
+//  under the sanitizers by tests/host_logic_test.cpp)
 struct DevicePool {
   std::mutex m;
-  std::vector<std::pair<int, std::pair<size_t, void*>>> idle;  // (device, (bytes, block))
-  std::vector<std::pair<void*, std::pair<int, size_t>>> live;  // pooled blocks in use: block -> (device, bytes)
-  size_t idle_bytes = 0;
+  slm_host::PoolLedger book;
 };
 static DevicePool g_pool;
-
-static void pool_flush_locked() {
-  for (auto& e : g_pool.idle) (void)hipFree(e.second.second);
-  g_pool.idle.clear();
-  g_pool.idle_bytes = 0;
-}
 
 hipError_t pool_malloc(void** out, size_t bytes) {
   if (bytes < kPoolMinBytes) return hipMalloc(out, bytes);
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lk(g_pool.m);
-  for (size_t i = 0; i < g_pool.idle.size(); ++i) {
-    if (g_pool.idle[i].first == dev && g_pool.idle[i].second.first == bytes) {
-      *out = g_pool.idle[i].second.second;
-      g_pool.idle.erase(g_pool.idle.begin() + (long)i);
-      g_pool.idle_bytes -= bytes;
-      g_pool.live.push_back({*out, {dev, bytes}});
-      return hipSuccess;
-    }
+  if (void* p = g_pool.book.take(dev, bytes)) {
+    *out = p;
+    return hipSuccess;
   }
   hipError_t e = hipMalloc(out, bytes);
-  if (e == hipErrorOutOfMemory && !g_pool.idle.empty()) {
+  if (e == hipErrorOutOfMemory && !g_pool.book.idle.empty()) {
     (void)hipGetLastError();
-    pool_flush_locked();
+    for (void* p : g_pool.book.flush()) (void)hipFree(p);
     e = hipMalloc(out, bytes);
   }
-  if (e == hipSuccess) g_pool.live.push_back({*out, {dev, bytes}});
+  if (e == hipSuccess) g_pool.book.adopt(*out, dev, bytes);
   return e;
 }
 
 void pool_free(void* p) {
+  std::vector<void*> evict;
+  bool kept;
   {
     std::lock_guard<std::mutex> lk(g_pool.m);
-    for (size_t i = 0; i < g_pool.live.size(); ++i) {
-      if (g_pool.live[i].first == p) {
-        const int dev = g_pool.live[i].second.first;
-        const size_t bytes = g_pool.live[i].second.second;
-        g_pool.live.erase(g_pool.live.begin() + (long)i);
-        if (!getenv("SLM_NO_DEVICE_POOL") && bytes <= pool_idle_cap()) {
-          // (over the cap: the blocks that have waited longest go back to the driver first)
-          while (g_pool.idle_bytes + bytes > pool_idle_cap() && !g_pool.idle.empty()) {
-            (void)hipFree(g_pool.idle.front().second.second);
-            g_pool.idle_bytes -= g_pool.idle.front().second.first;
-            g_pool.idle.erase(g_pool.idle.begin());
-          }
-          g_pool.idle.push_back({dev, {bytes, p}});
-          g_pool.idle_bytes += bytes;
-          return;
-        }
-        break;
-      }
-    }
+    // (over the cap: the blocks that have waited longest go back to the driver first)
+    kept = g_pool.book.give_back(p, pool_idle_cap(), getenv("SLM_NO_DEVICE_POOL") == nullptr, &evict);
   }
-  (void)hipFree(p);
+  for (void* q : evict) (void)hipFree(q);
+  if (!kept) (void)hipFree(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -285,19 +260,7 @@ extern "C" int slm_engine_destroy(slm_engine* eng) {
   if (eng->stream) (void)hipStreamDestroy(eng->stream);
   {  // (the recycled blocks do not outlive the engines that could use them)
     std::lock_guard<std::mutex> lk(g_pool.m);
-    bool other = false;
-    for (auto& e : g_pool.live) other = other || e.second.first == eng->device;
-    if (!other) {
-      for (size_t i = 0; i < g_pool.idle.size();) {
-        if (g_pool.idle[i].first == eng->device) {
-          (void)hipFree(g_pool.idle[i].second.second);
-          g_pool.idle_bytes -= g_pool.idle[i].second.first;
-          g_pool.idle.erase(g_pool.idle.begin() + (long)i);
-        } else {
-          ++i;
-        }
-      }
-    }
+    for (void* q : g_pool.book.retire_device(eng->device)) (void)hipFree(q);
   }
   delete eng;
   return SLM_OK;

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/slm_engine.h"
+#include "host_logic.hpp"
 #include "data_kernels.hpp"
 #include "grad_kernel.hpp"
 #include "tail_kernels.hpp"

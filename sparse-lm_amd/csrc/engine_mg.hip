@@ -38,7 +38,7 @@ static int mg_build(slm_dataset* ds, const double* w, double n_eff, double* G) {
   const int64_t n_pad = (n + MG_BK - 1) / MG_BK * MG_BK;
   const int64_t p_pad = (ld + MG_TILE - 1) / MG_TILE * MG_TILE;
   const int side = (int)(p_pad / MG_TILE);
-  const int n_tiles = side * (side + 1) / 2;
+  const int n_tiles = slm_host::triangle_tiles(side);
   const int64_t k_chunk = MG_CHUNK_ROWS;
   const int n_chunks = (int)((n_pad + k_chunk - 1) / k_chunk);
   unsigned long long* cmax = nullptr;
@@ -145,12 +145,9 @@ int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner
   memset(&a, 0, sizeof(a));
   a.R = ds->cov_Z; a.done = done;
   a.n = ld; a.ld = ld; a.p2 = (int)(ld / 2); a.n_lanes = n_lanes;
-  const int xb = (int)((ld + XTR_CB - 1) / XTR_CB);
-  const int64_t want = std::max<int64_t>(1, xtr_max_row_blocks(ds->eng->cus, ld) / 2);
-  int64_t rows = (ld + want - 1) / want;
-  rows = (rows + 7) / 8 * 8;
-  const int yb = (int)((ld + rows - 1) / rows);
-  a.xrows = (int)rows;
+  const slm_host::XtrGrid g = slm_host::xtr_grid(ld, ld, XTR_CB, xtr_max_row_blocks(ds->eng->cus, ld) / 2);  // (as a covariance pass's)
+  const int xb = g.xb, yb = g.yb;
+  a.xrows = g.rows;
   a.xrows_ws = 0;
   CovBatch cb;
   memset(&cb, 0, sizeof(cb));

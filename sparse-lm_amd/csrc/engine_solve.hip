@@ -73,22 +73,18 @@ const SplitKernel* pick_split_kernel(int64_t p2) {
 // against 0.592 ms at n = 100k, p = 5k; tools/xtr_wgs_probe.py): twice as many row streams open at once, and the
 // kernel has the bytes in flight it needs with four wavefronts.  SLM_XTR_WGS_PER_CU=2 brings the old grid back.
 int xtr_max_row_blocks(int cus, int64_t ld) {  // (sizes the partial buffer: the larger of the two grids)
-  const int xb = (int)((ld + XTR_CB - 1) / XTR_CB);
-  return std::max(1, 2 * cus / xb);
+  return slm_host::xtr_row_blocks_most(cus, ld, XTR_CB);
 }
 // sets a.xrows; returns the number of row blocks (= blocks of `partial` to reduce)
 int launch_xtr(int cus, SplitArgs& a, hipStream_t s, bool sample) {
-  const int xb = (int)((a.ld + XTR_CB - 1) / XTR_CB);
   double per_cu = 1.0;
   if (const char* e = getenv("SLM_XTR_WGS_PER_CU")) {  // (A/B runs: workgroups per CU, up to 2)
     const double f = atof(e);
     if (f > 0.0 && f <= 2.0) per_cu = f;
   }
-  const int64_t want = std::max<int64_t>(1, (int64_t)(xtr_max_row_blocks(cus, a.ld) * per_cu / 2.0));
-  int64_t rows = (a.n + want - 1) / want;
-  rows = (rows + 7) / 8 * 8;
-  const int yb = (int)((a.n + rows - 1) / rows);  // <= want
-  a.xrows = (int)rows;
+  const slm_host::XtrGrid g = slm_host::xtr_grid(a.n, a.ld, XTR_CB, (int64_t)(xtr_max_row_blocks(cus, a.ld) * per_cu / 2.0));
+  const int xb = g.xb, yb = g.yb;
+  a.xrows = g.rows;
   if (sample) hipLaunchKernelGGL(xtr_sample_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
   else hipLaunchKernelGGL(xtr_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
   return yb;
@@ -97,12 +93,9 @@ int launch_xtr(int cus, SplitArgs& a, hipStream_t s, bool sample) {
 // the product of a covariance pass (cov_gz_mfma_kernel): xtr_mfma_kernel's grid; when only the working set's rows are read a
 // workgroup row takes the next multiple of four of WS_KCAP / row blocks list entries (at most 32: eight steps in registers)
 static int launch_cov_gz(int cus, SplitArgs& a, hipStream_t s, const CovBatch& cb, int n_sets) {
-  const int xb = (int)((a.ld + XTR_CB - 1) / XTR_CB);
-  const int64_t want = std::max<int64_t>(1, xtr_max_row_blocks(cus, a.ld) / 2);
-  int64_t rows = (a.n + want - 1) / want;
-  rows = (rows + 7) / 8 * 8;
-  const int yb = (int)((a.n + rows - 1) / rows);  // <= want
-  a.xrows = (int)rows;
+  const slm_host::XtrGrid g = slm_host::xtr_grid(a.n, a.ld, XTR_CB, xtr_max_row_blocks(cus, a.ld) / 2);
+  const int xb = g.xb, yb = g.yb;
+  a.xrows = g.rows;
   const int per = ((WS_KCAP + yb - 1) / yb + 3) / 4 * 4;
   a.xrows_ws = (a.ctl != nullptr && per <= 32) ? per : 0;
   hipLaunchKernelGGL(cov_gz_mfma_kernel, dim3(xb, yb, (unsigned)n_sets), dim3(XTR_WAVES * 64), 0, s, a, cb);
@@ -352,11 +345,7 @@ int cov_fingerprints(slm_dataset* ds, const double* const* w, int count, double*
   return SLM_OK;
 }
 
-int cov_find(const slm_dataset* ds, double fp1, double fp2, double n_eff) {
-  for (size_t i = 0; i < ds->cov.size(); ++i)
-    if (ds->cov[i].fp1 == fp1 && ds->cov[i].fp2 == fp2 && ds->cov[i].n_eff == n_eff) return (int)i;
-  return -1;
-}
+int cov_find(const slm_dataset* ds, double fp1, double fp2, double n_eff) { return slm_host::find_by_fingerprint(ds->cov, fp1, fp2, n_eff); }
 
 // E = features per thread of the one-workgroup-per-lane tail kernel (p <= 1024 * E).  Up to E = 6 everything a thread
 // needs of its features stays in registers; rows of more than 6 144 columns take the streaming form of the same kernel,
@@ -1231,15 +1220,15 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // the row sets of the lanes' Grams (lanes with the same row weights -- same host pointer: the folds of a CV grid -- and
   // the same 1/n scaling share one), as ws_setup forms them
   int ws_set_of[SLM_MAX_LANES] = {}, ws_set_lane[SLM_MAX_LANES] = {}, ws_n_sets = 0;
-  for (int l = 0; l < B && l < kMaxLanes; ++l) {
-    int found = -1;
-    for (int m = 0; m < l && found < 0; ++m)
-      if (lanes[m].row_weight == lanes[l].row_weight && lanes[m].n_eff == lanes[l].n_eff) found = ws_set_of[m];
-    if (found < 0) {
-      found = ws_n_sets;
-      ws_set_lane[ws_n_sets++] = l;
+  {
+    const void* rwp[SLM_MAX_LANES];
+    int64_t nef[SLM_MAX_LANES];
+    const int nl = std::min<int>(B, kMaxLanes);
+    for (int l = 0; l < nl; ++l) {
+      rwp[l] = lanes[l].row_weight;
+      nef[l] = lanes[l].n_eff;
     }
-    ws_set_of[l] = found;
+    ws_n_sets = slm_host::row_sets(nl, rwp, nef, ws_set_of, ws_set_lane);
   }
   // a carried start on the same row sets takes over the working set too (ws_ctl_carry_kernel)
   bool ws_carry = carry && ds->ws_carry_valid && ws_policy(ds, o.flags) == 2 && ws_n_sets == ds->ws_carry_sets &&
@@ -1324,19 +1313,16 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     h[l].stride = 1;
     h[l].tail_pt = -1;
     if (shared_path && interleave) {  // lane l takes points l, l + B, l + 2B, ... of the whole path
-      h[l].point = l;
-      h[l].pt_lo = l;
-      h[l].n_points = (int32_t)total_points;
-      h[l].stride = B;
       // The points beyond the last full band (two of a 50-point path on sixteen lanes) go to the LAST lanes -- the
       // ones that have just solved their neighbours -- not to the first, which would reach them from sixteen points
       // up the path: there the features of the last decade of alpha cannot be told yet, the first verification
-      // misses and a large append follows (0.33 ms on the headline path).
-      const int64_t rem = total_points % B, n_reg = total_points - rem;
-      if (rem > 0 && n_reg >= 2 * (int64_t)B && !getenv("SLM_NO_TAIL_BAND")) {
-        h[l].n_points = (int32_t)n_reg;
-        if (l >= B - rem) h[l].tail_pt = (int32_t)(n_reg + (l - (B - rem)));
-      }
+      // misses and a large append follows (0.33 ms on the headline path).  (host_logic.hpp: interleaved_walk)
+      const slm_host::LaneWalk w = slm_host::interleaved_walk(l, B, total_points, getenv("SLM_NO_TAIL_BAND") == nullptr);
+      h[l].point = w.first;
+      h[l].pt_lo = w.first;
+      h[l].n_points = w.n_points;
+      h[l].stride = w.stride;
+      h[l].tail_pt = w.tail_pt;
     } else if (shared_path) {  // global indices: [off, off + n_points)
       h[l].point = (int32_t)off;
       h[l].pt_lo = (int32_t)off;
@@ -1734,7 +1720,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     int64_t most = 0;
     for (int l = 0; l < B; ++l) {
       int64_t mine = lanes[l].n_points;
-      if (shared_path && interleave) mine = (h[l].n_points - l + B - 1) / B + (h[l].tail_pt >= 0 ? 1 : 0);
+      if (shared_path && interleave) mine = slm_host::interleaved_points(slm_host::LaneWalk{h[l].pt_lo, h[l].n_points, h[l].stride, h[l].tail_pt});
       most = std::max<int64_t>(most, mine);
     }
     expected = 1 + most;
@@ -1773,7 +1759,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   const char* mg_env = getenv("SLM_MG");
   const bool mg_forced = mg_env != nullptr && mg_env[0] == '2';  // (tests: any size, from the first snapshot on)
   // (the model Grams of a dataset are kept within 6 GB: sixteen row sets at p = 5 000, seven at 10 000)
-  const int mg_cap = (int)std::max<double>(1.0, std::min<double>((double)kMgEntries, 6.0e9 / (8.0 * (double)ld * (double)ld)));
+  const int mg_cap = slm_host::model_gram_cap(ld, 6.0e9, kMgEntries);
   const bool mg_ok = use_ws && split && (big_x || mg_forced) && !sharded && !cov_on && !(o.flags & SLM_FLAG_NO_MODEL_GRAM) &&
                      (size_t)ds->lane_cap >= (size_t)kMaxLanes && ws_n_sets <= mg_cap && mg_possible(ds);
   if (mg_ok && mg_forced) expected = 0;  // (tests: polled from the first chunk on, so that short solves reach the rounds too)

@@ -1,0 +1,208 @@
+// The host-side bookkeeping of the engine that touches no device: the recycling pool's ledger, the row sets of a call's
+// lanes, the walk of interleaved lanes over a shared path, the launch geometry of the X^T R pass, the look-up of a row
+// set's Gram, the tile numbering of the model Gram's triangle.  Kept free of HIP types so that g++ compiles it alone:
+// tests/host_logic_test.cpp runs every function under AddressSanitizer + UndefinedBehaviorSanitizer in the build
+// container (tools/sanitize.sh; GPU sanitizers are not available on the pool), and engine*.hip include THIS file -- what
+// is tested is what runs.  (Reference counterpart: none -- the reference keeps no device state; SURVEY section 5 asks for
+// the sanitizer coverage.)
+#pragma once
+#include <stddef.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+#if defined(__HIPCC__)
+#define SLM_HD __host__ __device__
+#else
+#define SLM_HD
+#endif
+
+namespace slm_host {
+
+// ---------------------------------------------------------------------------------------------
+// Ledger of the pool of large device blocks (engine.hip: pool_malloc / pool_free).  A freed block waits in a list of its
+// exact (device, size); the next request of that shape takes it.  At most `cap` bytes wait; over the cap the blocks that
+// have waited longest are released first.  The ledger never calls an allocator: `take` / `give_back` say what to do.
+// ---------------------------------------------------------------------------------------------
+struct PoolLedger {
+  struct Idle { int dev; size_t bytes; void* block; };
+  struct Live { void* block; int dev; size_t bytes; };
+  std::vector<Idle> idle;  // oldest first
+  std::vector<Live> live;  // pooled blocks in use
+  size_t idle_bytes = 0;
+
+  // a waiting block of exactly (dev, bytes), moved to the live list; nullptr: the caller allocates and calls adopt()
+  void* take(int dev, size_t bytes) {
+    for (size_t i = 0; i < idle.size(); ++i) {
+      if (idle[i].dev == dev && idle[i].bytes == bytes) {
+        void* p = idle[i].block;
+        idle.erase(idle.begin() + (long)i);
+        idle_bytes -= bytes;
+        live.push_back({p, dev, bytes});
+        return p;
+      }
+    }
+    return nullptr;
+  }
+  void adopt(void* p, int dev, size_t bytes) { live.push_back({p, dev, bytes}); }
+
+  // A block comes back.  Returns true when the ledger keeps it (it now waits); false: the caller releases it (not one of
+  // the pool's, pooling switched off, or larger than the cap).  `evict` receives the blocks that have to make room,
+  // oldest first: the caller releases them.
+  bool give_back(void* p, size_t cap, bool pooling, std::vector<void*>* evict) {
+    for (size_t i = 0; i < live.size(); ++i) {
+      if (live[i].block != p) continue;
+      const int dev = live[i].dev;
+      const size_t bytes = live[i].bytes;
+      live.erase(live.begin() + (long)i);
+      if (!pooling || bytes > cap) return false;
+      while (idle_bytes + bytes > cap && !idle.empty()) {
+        evict->push_back(idle.front().block);
+        idle_bytes -= idle.front().bytes;
+        idle.erase(idle.begin());
+      }
+      idle.push_back({dev, bytes, p});
+      idle_bytes += bytes;
+      return true;
+    }
+    return false;
+  }
+  // the waiting blocks of a device whose last engine is going, for release -- unless a pooled block of that device is still
+  // in use (a dataset outlives the engine that is being destroyed: its blocks come back later and may wait again)
+  std::vector<void*> retire_device(int dev) {
+    std::vector<void*> out;
+    for (const Live& e : live)
+      if (e.dev == dev) return out;
+    for (size_t i = 0; i < idle.size();) {
+      if (idle[i].dev == dev) {
+        out.push_back(idle[i].block);
+        idle_bytes -= idle[i].bytes;
+        idle.erase(idle.begin() + (long)i);
+      } else {
+        ++i;
+      }
+    }
+    return out;
+  }
+  // every waiting block, for release (the driver ran out of memory); the list is empty afterwards
+  std::vector<void*> flush() {
+    std::vector<void*> out;
+    for (const Idle& e : idle) out.push_back(e.block);
+    idle.clear();
+    idle_bytes = 0;
+    return out;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Row sets of a call: lanes that bring the same row weights (same host pointer: the grid rows of one CV fold) and the same
+// 1/n scaling share one Gram (working set, model Gram, covariance pass).  set_of[l]: the set of lane l; set_lane[s]: the
+// first lane of set s.  Returns the number of sets.
+// ---------------------------------------------------------------------------------------------
+inline int row_sets(int n_lanes, const void* const* row_weight, const int64_t* n_eff, int* set_of, int* set_lane) {
+  int n_sets = 0;
+  for (int l = 0; l < n_lanes; ++l) {
+    int found = -1;
+    for (int m = 0; m < l && found < 0; ++m)
+      if (row_weight[m] == row_weight[l] && n_eff[m] == n_eff[l]) found = set_of[m];
+    if (found < 0) {
+      found = n_sets;
+      set_lane[n_sets++] = l;
+    }
+    set_of[l] = found;
+  }
+  return n_sets;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Interleaved lanes of a shared path (solve_core): lane l takes points l, l + B, l + 2 B, ... of `total` points.  The
+// points beyond the last full band go to the LAST lanes (`tail_pt`), which have just solved their neighbours -- unless
+// there are fewer than two full bands, where every lane simply strides to the end.
+// ---------------------------------------------------------------------------------------------
+struct LaneWalk {
+  int32_t first;     // first point
+  int32_t n_points;  // end (exclusive) of the regular walk
+  int32_t stride;
+  int32_t tail_pt;   // one more point after the walk, or -1
+};
+inline LaneWalk interleaved_walk(int lane, int B, int64_t total, bool tail_band) {
+  LaneWalk w;
+  w.first = lane;
+  w.n_points = (int32_t)total;
+  w.stride = B;
+  w.tail_pt = -1;
+  const int64_t rem = total % B, n_reg = total - rem;
+  if (tail_band && rem > 0 && n_reg >= 2 * (int64_t)B) {
+    w.n_points = (int32_t)n_reg;
+    if (lane >= B - rem) w.tail_pt = (int32_t)(n_reg + (lane - (B - rem)));
+  }
+  return w;
+}
+// points lane `lane` solves under that walk (what `expected` passes are counted from)
+inline int64_t interleaved_points(const LaneWalk& w) {
+  const int64_t regular = w.n_points > w.first ? ((int64_t)w.n_points - w.first + w.stride - 1) / w.stride : 0;
+  return regular + (w.tail_pt >= 0 ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grid of the X^T R pass on the matrix cores (launch_xtr / launch_cov_gz): column blocks of `col_block`, row blocks of a
+// multiple of 8 rows, about `want` of them.
+// ---------------------------------------------------------------------------------------------
+struct XtrGrid { int xb, yb, rows; };
+inline int xtr_row_blocks_most(int cus, int64_t ld, int col_block) {
+  const int xb = (int)((ld + col_block - 1) / col_block);
+  return std::max(1, 2 * cus / xb);
+}
+inline XtrGrid xtr_grid(int64_t n, int64_t ld, int col_block, int64_t want) {
+  XtrGrid g;
+  g.xb = (int)((ld + col_block - 1) / col_block);
+  if (want < 1) want = 1;
+  int64_t rows = (n + want - 1) / want;
+  rows = (rows + 7) / 8 * 8;
+  g.rows = (int)rows;
+  g.yb = (int)((n + rows - 1) / rows);  // <= want
+  return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A row set's Gram among those a dataset keeps: by the two fingerprint sums of its row weights and its scaling.
+// ---------------------------------------------------------------------------------------------
+template <typename Entry>
+inline int find_by_fingerprint(const std::vector<Entry>& entries, double fp1, double fp2, double n_eff) {
+  for (size_t i = 0; i < entries.size(); ++i)
+    if (entries[i].fp1 == fp1 && entries[i].fp2 == fp2 && entries[i].n_eff == n_eff) return (int)i;
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tiles of a lower triangle, row by row: tile t = (I, J <= I), t = I (I + 1) / 2 + J.  (The kernels of the model Gram
+// compute the same pair from a float square root and correct it by one; this is the integer statement they are tested
+// against.)
+// ---------------------------------------------------------------------------------------------
+inline void triangle_tile(int t, int* I_out, int* J_out) {
+  int I = 0;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  *I_out = I;
+  *J_out = t - I * (I + 1) / 2;
+}
+inline int triangle_tiles(int side) { return side * (side + 1) / 2; }
+// the form the kernels use (mg_syrk_f16_*_kernel, mg_reduce_kernel, the model solver's factor assembly): a float square
+// root, corrected by at most one step either way -- exact for every t the engine can ask for (tested up to 2^24)
+SLM_HD inline void triangle_tile_fast(int t, int* I_out, int* J_out) {
+  int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while (I * (I + 1) / 2 > t) --I;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  *I_out = I;
+  *J_out = t - I * (I + 1) / 2;
+}
+
+// model Grams a dataset may keep: kept within `budget_bytes` (8 ld^2 each), at least one, at most `most`
+inline int model_gram_cap(int64_t ld, double budget_bytes, int most) {
+  const double each = 8.0 * (double)ld * (double)ld;
+  return (int)std::max<double>(1.0, std::min<double>((double)most, budget_bytes / each));
+}
+
+}  // namespace slm_host

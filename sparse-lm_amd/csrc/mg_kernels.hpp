@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "cov_kernels.hpp"
+#include "host_logic.hpp"
 #include "split_kernels.hpp"
 #include "tail_kernels.hpp"
 #include "ws_kernels.hpp"
@@ -187,10 +188,8 @@ static __global__ __launch_bounds__(256) void mg_syrk_f16_kernel(MgSyrkArgs a) {
     m = xcd * base + (xcd < rem ? xcd : rem) + slot;
   }
   const int chunk = (int)(m / a.n_tiles), tile = (int)(m - (int64_t)chunk * a.n_tiles);
-  int I = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
-  while (I * (I + 1) / 2 > tile) --I;
-  while ((I + 1) * (I + 2) / 2 <= tile) ++I;
-  const int J = tile - I * (I + 1) / 2;
+  int I, J;
+  slm_host::triangle_tile_fast(tile, &I, &J);  // (host_logic.hpp: tile t = (I, J <= I) of the lower triangle)
   const int64_t k0 = (int64_t)chunk * a.k_chunk;
   const int64_t k1 = k0 + a.k_chunk < a.n_pad ? k0 + a.k_chunk : a.n_pad;
   // staging: thread -> (row (tid >> 3) + 32 u, 16-byte piece tid & 7)
@@ -279,10 +278,8 @@ static __global__ __launch_bounds__(256) void mg_syrk_f16_dma_kernel(MgSyrkArgs 
     m = xcd * base + (xcd < rem ? xcd : rem) + slot;
   }
   const int chunk = (int)(m / a.n_tiles), tile = (int)(m - (int64_t)chunk * a.n_tiles);
-  int I = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
-  while (I * (I + 1) / 2 > tile) --I;
-  while ((I + 1) * (I + 2) / 2 <= tile) ++I;
-  const int J = tile - I * (I + 1) / 2;
+  int I, J;
+  slm_host::triangle_tile_fast(tile, &I, &J);  // (host_logic.hpp: tile t = (I, J <= I) of the lower triangle)
   const int64_t k0 = (int64_t)chunk * a.k_chunk;
   const int64_t k1 = k0 + a.k_chunk < a.n_pad ? k0 + a.k_chunk : a.n_pad;
   // DMA: wave w, instruction q fills piece P = 4 w + q (rows 8 P ... 8 P + 7); lane -> (row 8 P + (lane >> 3), slot lane & 7)
@@ -373,10 +370,8 @@ struct MgReduceArgs {
 static __global__ __launch_bounds__(256) void mg_reduce_kernel(MgReduceArgs a) {
   __shared__ double tile[32][33];
   const int t = blockIdx.x;
-  int I = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-  while (I * (I + 1) / 2 > t) --I;
-  while ((I + 1) * (I + 2) / 2 <= t) ++I;
-  const int J = t - I * (I + 1) / 2;
+  int I, J;
+  slm_host::triangle_tile_fast(t, &I, &J);
   const int sy = blockIdx.y >> 2, sx = blockIdx.y & 3;
   if (I == J && sx > sy) return;  // (above the diagonal)
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;

@@ -327,7 +327,8 @@ def load_binding():
     global _binding
     if _binding is None:
         lib = load_library()
-        path = os.path.join(_LIB_DIR, "_slm_binding.so")
+        # (SLM_BINDING_PATH: another build of the same module -- tools/sanitize.sh loads the ASan + UBSan one)
+        path = os.environ.get("SLM_BINDING_PATH") or os.path.join(_LIB_DIR, "_slm_binding.so")
         if os.environ.get("SLM_NO_BINDING") or os.environ.get("SLM_HIP_LIBRARY") or not os.path.exists(path):
             _binding = False
         else:
@@ -337,9 +338,16 @@ def load_binding():
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
             if mod.abi_version() != lib.slm_abi_version() or mod.info_record_bytes() != _INFO_DTYPE.itemsize:
-                raise EngineError(f"{path} does not match libslm_hip.so: rebuild with `python sparse-lm_amd/build.py --force`")
-            mod.set_error_types(EngineError, NonFiniteError)
-            _binding = mod
+                # a module left over from another ABI: an accelerator that does not fit is not used (ctypes serves every
+                # call), and says so once
+                import warnings
+
+                warnings.warn(f"{path} does not match libslm_hip.so (rebuild with `python sparse-lm_amd/build.py --force`): "
+                              "falling back on the ctypes binding", RuntimeWarning)
+                _binding = False
+            else:
+                mod.set_error_types(EngineError, NonFiniteError)
+                _binding = mod
     return _binding or None
 
 

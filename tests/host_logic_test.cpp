@@ -1,0 +1,201 @@
+// CPU test of csrc/host_logic.hpp -- the engine's device-free bookkeeping -- meant to run under AddressSanitizer and
+// UndefinedBehaviorSanitizer (tools/sanitize.sh; tests/test_host_logic_cpu.py builds and runs it plainly in the CPU suite).
+// Every check is against an independent statement of what the function must do; a randomised pool run models the
+// allocator with malloc/free so that a double release or a leak is the sanitizers' to find.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <map>
+#include <random>
+#include <set>
+
+#include "../sparse-lm_amd/csrc/host_logic.hpp"
+
+using namespace slm_host;
+
+static int failures = 0;
+#define CHECK(cond)                                                           \
+  do {                                                                        \
+    if (!(cond)) {                                                            \
+      fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); \
+      ++failures;                                                             \
+    }                                                                         \
+  } while (0)
+
+static void test_pool() {
+  PoolLedger book;
+  std::mt19937_64 rng(1);
+  const size_t sizes[] = {64u << 20, 200u << 20, 1000u << 20, 4000ull << 20};
+  const size_t cap = 6000ull << 20;
+  std::vector<std::pair<void*, std::pair<int, size_t>>> mine;  // blocks the "engine" holds
+  std::set<void*> released;
+  size_t driver_allocs = 0, reused = 0;
+  for (int step = 0; step < 20000; ++step) {
+    const bool alloc = mine.empty() || (rng() % 100 < 55 && mine.size() < 40);
+    if (alloc) {
+      const int dev = (int)(rng() % 2);
+      const size_t bytes = sizes[rng() % 4];
+      void* p = book.take(dev, bytes);
+      if (!p) {
+        p = malloc(16);  // (stands for hipMalloc of `bytes`)
+        ++driver_allocs;
+        book.adopt(p, dev, bytes);
+      } else {
+        ++reused;
+      }
+      for (auto& m : mine) CHECK(m.first != p);  // never handed out twice
+      mine.push_back({p, {dev, bytes}});
+    } else {
+      const size_t i = rng() % mine.size();
+      void* p = mine[i].first;
+      mine.erase(mine.begin() + (long)i);
+      std::vector<void*> evict;
+      const bool kept = book.give_back(p, cap, true, &evict);
+      for (void* q : evict) {
+        CHECK(q != p);
+        free(q);
+      }
+      if (!kept) free(p);
+      CHECK(book.idle_bytes <= cap);
+      size_t sum = 0;
+      for (auto& e : book.idle) sum += e.bytes;
+      CHECK(sum == book.idle_bytes);
+    }
+    CHECK(book.live.size() == mine.size());
+  }
+  CHECK(reused > 1000 && driver_allocs > 10);
+  // a block that is not the pool's, pooling off, a block over the cap
+  {
+    std::vector<void*> evict;
+    int dummy;
+    CHECK(!book.give_back(&dummy, cap, true, &evict) && evict.empty());
+    void* p = malloc(16);
+    book.adopt(p, 0, 64u << 20);
+    CHECK(!book.give_back(p, cap, false, &evict));
+    free(p);
+    p = malloc(16);
+    book.adopt(p, 0, cap + 1);
+    CHECK(!book.give_back(p, cap, true, &evict));
+    free(p);
+  }
+  // retire a device: nothing while one of its blocks is in use, everything once none is
+  for (auto& m : mine) {
+    std::vector<void*> evict;
+    if (!book.give_back(m.first, cap, true, &evict)) free(m.first);
+    for (void* q : evict) free(q);
+  }
+  mine.clear();
+  void* busy = malloc(16);
+  book.adopt(busy, 1, 64u << 20);
+  CHECK(book.retire_device(1).empty());
+  {
+    std::vector<void*> evict;
+    if (!book.give_back(busy, cap, true, &evict)) free(busy);
+    for (void* q : evict) free(q);
+  }
+  for (void* q : book.retire_device(1)) free(q);
+  for (auto& e : book.idle) CHECK(e.dev == 0);
+  for (void* q : book.flush()) free(q);
+  CHECK(book.idle.empty() && book.idle_bytes == 0 && book.live.empty());
+}
+
+static void test_row_sets() {
+  double w0[4], w1[4];
+  const void* rw[16] = {w0, w0, nullptr, w1, w0, nullptr, w1, w1, w0, nullptr, nullptr, w1, w0, w0, w1, nullptr};
+  int64_t ne[16];
+  for (int l = 0; l < 16; ++l) ne[l] = rw[l] == w0 ? 80 : (rw[l] == w1 ? 80 : 0);
+  ne[13] = 70;  // same weights, another scaling: a set of its own
+  int set_of[16], set_lane[16];
+  const int n = row_sets(16, rw, ne, set_of, set_lane);
+  CHECK(n == 4);
+  for (int l = 0; l < 16; ++l) {
+    CHECK(set_of[l] >= 0 && set_of[l] < n);
+    const int rep = set_lane[set_of[l]];
+    CHECK(rep <= l && rw[rep] == rw[l] && ne[rep] == ne[l]);
+    for (int m = 0; m < 16; ++m) CHECK((set_of[m] == set_of[l]) == (rw[m] == rw[l] && ne[m] == ne[l]));
+  }
+  for (int s = 0; s + 1 < n; ++s) CHECK(set_lane[s] < set_lane[s + 1]);  // in order of their first lane
+  CHECK(row_sets(1, rw, ne, set_of, set_lane) == 1 && set_of[0] == 0 && set_lane[0] == 0);
+}
+
+static void test_interleaved() {
+  for (int B = 1; B <= 16; ++B)
+    for (int64_t total = B; total <= 200; ++total)
+      for (int tail = 0; tail < 2; ++tail) {
+        std::vector<int> seen((size_t)total, 0);
+        int64_t most = 0;
+        for (int l = 0; l < B; ++l) {
+          const LaneWalk w = interleaved_walk(l, B, total, tail != 0);
+          int64_t mine = 0;
+          for (int k = w.first; k < w.n_points; k += w.stride) {
+            seen[(size_t)k] += 1;
+            ++mine;
+          }
+          if (w.tail_pt >= 0) {
+            CHECK(w.tail_pt >= w.n_points && w.tail_pt < total);
+            seen[(size_t)w.tail_pt] += 1;
+            ++mine;
+          }
+          CHECK(mine == interleaved_points(w));
+          most = std::max(most, mine);
+        }
+        for (int64_t k = 0; k < total; ++k) CHECK(seen[(size_t)k] == 1);  // every point exactly once
+        CHECK(most == (total + B - 1) / B);                               // and no lane walks more than its share
+      }
+  const LaneWalk w = interleaved_walk(15, 16, 50, true);  // the headline: 48 regular points, 48 and 49 go to lanes 14, 15
+  CHECK(w.n_points == 48 && w.tail_pt == 49 && interleaved_walk(14, 16, 50, true).tail_pt == 48 && interleaved_walk(13, 16, 50, true).tail_pt == -1);
+}
+
+static void test_grid() {
+  for (int cus : {1, 64, 256, 304})
+    for (int64_t ld : {16, 512, 528, 5008, 10240, 16384})
+      for (int64_t n : {1, 7, 8, 9, 1000, 5008, 100000, 1000003}) {
+        const int most = xtr_row_blocks_most(cus, ld, 512);
+        CHECK(most >= 1);
+        for (int64_t want : {(int64_t)0, (int64_t)1, (int64_t)(most / 2), (int64_t)most}) {
+          const XtrGrid g = xtr_grid(n, ld, 512, want);
+          CHECK(g.xb * 512 >= ld && (g.xb - 1) * 512 < ld);
+          CHECK(g.rows % 8 == 0 && g.rows >= 8);
+          CHECK((int64_t)g.yb * g.rows >= n && (int64_t)(g.yb - 1) * g.rows < n);  // the blocks cover the rows, none is empty
+          CHECK(g.yb <= std::max<int64_t>(1, want));
+        }
+      }
+}
+
+struct Entry { double fp1, fp2, n_eff; };
+static void test_find_and_tiles() {
+  std::vector<Entry> e = {{1.0, 2.0, 80.0}, {1.0, 2.0, 70.0}, {3.0, 2.0, 80.0}};
+  CHECK(find_by_fingerprint(e, 1.0, 2.0, 70.0) == 1 && find_by_fingerprint(e, 3.0, 2.0, 80.0) == 2);
+  CHECK(find_by_fingerprint(e, 1.0, 2.5, 80.0) == -1 && find_by_fingerprint(std::vector<Entry>(), 0, 0, 0) == -1);
+  int t = 0;
+  for (int I = 0; I < 300; ++I)
+    for (int J = 0; J <= I; ++J, ++t) {
+      int a, b, c, d;
+      triangle_tile(t, &a, &b);
+      triangle_tile_fast(t, &c, &d);
+      CHECK(a == I && b == J && c == I && d == J);
+    }
+  CHECK(triangle_tiles(300) == t);
+  for (int tt : {(1 << 24) - 1, 1 << 24, 8256 * 16 - 1, 33550336}) {  // far beyond any triangle the engine builds
+    int a, b, c, d;
+    triangle_tile(tt, &a, &b);
+    triangle_tile_fast(tt, &c, &d);
+    CHECK(a == c && b == d && a * (a + 1) / 2 + b == tt && b <= a);
+  }
+  CHECK(model_gram_cap(5008, 6.0e9, 16) == 16 && model_gram_cap(10000, 6.0e9, 16) == 7 && model_gram_cap(16384, 6.0e9, 16) == 2 &&
+        model_gram_cap(100000, 6.0e9, 16) == 1);
+}
+
+int main() {
+  test_pool();
+  test_row_sets();
+  test_interleaved();
+  test_grid();
+  test_find_and_tiles();
+  if (failures) {
+    fprintf(stderr, "host_logic_test: %d check(s) failed\n", failures);
+    return 1;
+  }
+  printf("host_logic_test: ok\n");
+  return 0;
+}

@@ -116,6 +116,8 @@ def test_compiled_binding_loads_and_agrees_with_python_on_the_secant_factors():
     b = _engine.load_binding()
     assert b is not None, "build it: python sparse-lm_amd/build.py"
     assert b.abi_version() == _engine.ABI_VERSION and b.info_record_bytes() == _engine._INFO_DTYPE.itemsize
+    if __import__("os").environ.get("SLM_EXPECT_SANITIZED_BINDING"):  # (tools/sanitize.sh: the ASan + UBSan build is the one under test)
+        assert b.__file__.endswith("san/_slm_binding.so"), b.__file__
     rng = np.random.default_rng(0)
     for K in (1, 2, 3, 10, 50):
         al = np.geomspace(1, 1e-3, K)
