@@ -1333,7 +1333,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       const slm_reweight& r = rules[l];
       h[l].rw_coef = r.coef_scale; h[l].rw_numer = r.numerator; h[l].rw_eps = r.eps; h[l].rw_tol = r.tol;
       h[l].rw_ncoef = r.n_coef; h[l].rw_ngroup = r.n_group;
-      h[l].rw_on = (r.coef_scale != 0.0 ? 1 : 0) | (r.group_scale ? 2 : 0);
+      // (by what the rule covers, not by the value of its scale: a zero scale -- AdaptiveLasso(alpha=0) -- renews the weights
+      //  to what they were, the round is counted and the rounds end on `moved <= tol` as the loop of calls does after one)
+      h[l].rw_on = (r.n_coef > 0 ? 1 : 0) | ((r.group_scale && r.n_group > 0) ? 2 : 0);
       if (r.group_scale)  // (gscale: the general path's scratch for group factors, free on chip; pageable source: staged by the runtime)
         HIP_TRY(hipMemcpyAsync(ds->gscale + (size_t)l * G, r.group_scale, sizeof(double) * (size_t)r.n_group, hipMemcpyHostToDevice, s));
     }
@@ -1467,7 +1469,11 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       // a round the kernel did not settle ends the lane's rounds there: the caller runs its own loop (over slm_solve_lanes,
       // whose general path takes what the chip gives up) -- nothing half-done is handed back
       if (unconverged) return fail(SLM_ERR_UNSUPPORTED, "a re-weighted round was not settled on chip");
-      for (int l = 0; l < B; ++l) rounds_out[l] = snap.lane[l].rounds;
+      for (int l = 0; l < B; ++l) {
+        // (a rule that covers nothing runs no round: the caller's loop takes the call rather than an index of -1)
+        if (snap.lane[l].rounds < 1) return fail(SLM_ERR_UNSUPPORTED, "lane %d: the re-weighting rule covers no weight", l);
+        rounds_out[l] = snap.lane[l].rounds;
+      }
     }
     if (unconverged && getenv("SLM_ON_CHIP_NO_FALLBACK") == nullptr) {  // (the variable: diagnostics -- the on-chip records as they are)
       if (const char* trc = getenv("SLM_TRACE"))

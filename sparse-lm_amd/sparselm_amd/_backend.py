@@ -73,6 +73,7 @@ class DatasetCache:
         done to it, and raises scikit-learn's ValueError."""
         key = self._key(engine, X, y, row_weight, center)
         if key is not None:
+            hit = None
             with self._lock:
                 item = self._items.get(key)
                 if item is not None and not item[3] and getattr(item[0], "_h", None):
@@ -80,10 +81,18 @@ class DatasetCache:
                     self._clock += 1
                     item[4] = self._clock
                     self.hits += 1
-                    if check_finite and item[0].nonfinite():  # (uploaded by a caller that had not asked)
-                        item[3] = False
-                        raise ValueError("Input X contains NaN or infinity.")
-                    return item[0], item[1], item[2], key
+                    hit = item
+            if hit is not None:
+                if check_finite:  # (uploaded by a caller that had not asked: the scan -- a kernel, a copy, a wait -- runs outside the lock)
+                    ds = hit[0]
+                    try:
+                        raise_if_nonfinite(ds)  # scikit-learn's messages; closes the dataset on the way out
+                    except ValueError:
+                        with self._lock:  # a design that is not finite does not stay in the cache
+                            if self._items.get(key) is hit:
+                                del self._items[key]
+                        raise
+                return hit[0], hit[1], hit[2], key
         ds = engine.dataset(X, y, row_weight=row_weight)
         if check_finite:
             raise_if_nonfinite(ds)

@@ -456,7 +456,11 @@ class _DeviceGrid:
         item = _backend.dataset_cache().acquire(_engine.get_engine(), Xd, self.y, None, False, check_finite=True)
         if item[3] is None:  # (too large for the cache: the search owns the dataset)
             return self.adopt(item[0])
-        self.adopt(item[0])
+        try:
+            self.adopt(item[0])
+        except BaseException:  # (e.g. set_groups refused the labels: the entry must not stay marked as in use for ever)
+            _backend.dataset_cache().release(*item)
+            raise
         return _Cached(item)
 
     def adopt(self, ds):
@@ -547,8 +551,13 @@ class _DeviceGrid:
         eng = getattr(ds, "engine", None)
         shared = world > 1 and eng is not None and eng.comm_ranks() == world  # the ranks build the Grams together
         n_effs = [int(m.sum()) for m in self.train_masks]
-        if want == "auto" and hasattr(ds, "covariance_count") and ds.covariance_count() >= self.n_splits:
-            # (a leased dataset: an earlier line of the search built them -- the entries are found by their fingerprints)
+        if (want == "auto" and getattr(self.search, "_lease", None) is not None and world == 1 and hasattr(ds, "covariance_count")
+                and ds.covariance_count() >= self.n_splits):
+            # (a LEASED dataset -- the lines of one LineSearchCV, same cv, same masks: an earlier line built these very Grams and
+            #  the entries are found by their fingerprints.  Not for a dataset that merely comes out of the cache with Grams of
+            #  some other search on it -- other splits: every fold would be built afresh, mask by mask -- and not among ranks,
+            #  where the count is one rank's state and the build a collective: there the cost model below decides, from
+            #  quantities that are the same on every rank)
             want = True
         if want == "auto":
             points = sum(len(idx) for call in calls for lane in call for _, idx in lane)

@@ -381,3 +381,21 @@ def test_adaptive_searches_with_rounds_on_chip_equal_the_host_loop(kind, monkeyp
     np.testing.assert_array_equal(on_chip.best_estimator_.coef_, host.best_estimator_.coef_)
     np.testing.assert_array_equal(on_chip.best_estimator_.adaptive_weights_, host.best_estimator_.adaptive_weights_)
     assert on_chip.best_estimator_.n_iter_ == host.best_estimator_.n_iter_
+
+
+def test_a_rule_with_a_zero_scale_still_counts_its_round(monkeypatch):
+    """AdaptiveLasso(alpha=0): the rule's coefficient scale is zero, the renewed weights are the old ones (zero) and the loop
+    ends after ONE round -- as the reference's loop does (model/_adaptive_lasso.py:206-232: `n_iter_` = 1), and as the
+    loop of calls does here (SLM_HOST_ROUNDS=1).  (Round-4 advice: the kernel used to count no round at all there, the
+    estimator then indexed its results with -1 and reported `n_iter_` = 0.)"""
+    from sparselm_amd.model import AdaptiveLasso
+
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((40, 12))
+    y = X @ rng.standard_normal(12) + 0.1 * rng.standard_normal(40)
+    chip = AdaptiveLasso(alpha=0.0, max_iter=4, fit_intercept=False).fit(X, y)
+    monkeypatch.setenv("SLM_HOST_ROUNDS", "1")
+    host = AdaptiveLasso(alpha=0.0, max_iter=4, fit_intercept=False).fit(X, y)
+    assert chip.n_iter_ == host.n_iter_ == 1
+    np.testing.assert_allclose(chip.coef_, host.coef_, rtol=0, atol=1e-9 * np.max(np.abs(host.coef_)))
+    np.testing.assert_allclose(chip.coef_, np.linalg.lstsq(X, y, rcond=None)[0], rtol=0, atol=1e-6 * np.max(np.abs(host.coef_)))

@@ -25,4 +25,4 @@ TMP=$(mktemp -d)
   python -m pytest "$R/tests/test_binding_cpu.py" "$R/tests/test_abi.py" -q -p no:cacheprovider 2>&1 | tail -15
   echo "exit code: ${PIPESTATUS[0]}"
 } 2>&1 | tee "$LOG"
-rm -rf "$TMP"
+rm -rf "$TMP" "$R/sparse-lm_amd/sparselm_amd/_lib/san"   # (the sanitized module is for this script only: it does not travel to the GPU box)
