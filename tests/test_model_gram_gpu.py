@@ -116,3 +116,19 @@ def test_lanes_with_their_own_row_masks_take_the_model_gram_of_their_fold(eng, m
     a_last = lanes[3]["points"][-1][0]
     bo, _ = oracle.fista(X[m > 0], y[m > 0], a_last, 0.0, 0.0, gidx, Gn, beta0=q[3].betas[-1], tol=1e-13)
     assert np.max(np.abs(r[3].betas[-1] - bo)) < 1e-6 * np.max(np.abs(bo))
+
+
+def test_randomised_cross_check_of_the_rounds():
+    """tools/mg_fuzz.py: the rounds forced on over random penalty kinds, group sizes, 9-16 lanes, shared paths and lanes with
+    fold masks, iid / correlated / duplicated / badly scaled designs, more columns than rows, dataset row weights: every
+    call against the same call without the rounds and against one plain lane (1e-6, or the same objective where the
+    minimiser is not unique)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "mg_fuzz.py"), "60", "11"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "MG FUZZ cases 60" in out.stdout and "flagged 0" in out.stdout
+    assert "with rounds 0 " not in out.stdout  # (the rounds did run)
