@@ -299,8 +299,17 @@ class Config4:
             amax = min(bmax / (1 - r), amax1 / r)
             al = np.geomspace(amax, 1e-3 * amax, self.K)
             self.unit_pts.append(np.c_[r * al, (1 - r) * al, 0 * al])
-        self.lanes = _engine.MAX_LANES
         self.flags = 0  # solve flags of every call (build_covariance() adds FLAG_COVARIANCE)
+
+    @property
+    def lanes(self):
+        """lanes per call, as the engine serves them under the current flags: thirty-two over X (two halves on one read of X),
+        sixteen from the folds' Grams"""
+        return getattr(self, "_lanes", None) or self.ds.max_lanes(self.flags)
+
+    @lanes.setter
+    def lanes(self, value):
+        self._lanes = value
 
     def build_covariance(self):
         """One Gram per fold on the first engine's dataset (slm_dataset_covariance); seconds spent."""
@@ -324,6 +333,8 @@ class Config4:
             pts, gam = _engine.lane_points([self.unit_pts[u][idx] for u, idx in lane])
             f = self.units[lane[0][0]][0]
             specs.append(dict(points=pts, extrap=gam, row_weight=self.masks[f], n_eff=int(self.masks[f].sum())))
+        if (self.flags & _engine.FLAG_COVARIANCE) and len(specs) > _engine.MAX_LANES:
+            raise RuntimeError("config 4: calls planned for the pass over X (32 lanes) cannot take their gradients from the Grams: plan again")
         out = d.solve_lanes(specs, flags=self.flags)
         if not all(o.converged for o in out):
             raise RuntimeError("config 4: a path did not converge")
@@ -423,6 +434,7 @@ def leg_config4_grid(eng, rank, world, n, p, device_id=0, streams=3, emulate_wor
         # the rank's share from the Grams of the five folds (SLM_FLAG_COVARIANCE), the Grams' cost beside it
         try:
             out["covariance_build_s"] = c4.build_covariance()
+            mine = c4.calls_of(world, rank)  # (sixteen lanes a call from here on)
             c4.run(mine)
             out["seconds_covariance"], out["passes_covariance"] = min(c4.run(mine) for _ in range(2))
             if n_streams > 1:  # copies made now share the Grams (slm_dataset_clone)
@@ -531,6 +543,7 @@ def leg_config4_dense(eng, n, p, noise_sd=100.0):
         nnz = sorted(int(np.count_nonzero(keep_x[(u, c4.K - 1)])) for u in range(len(c4.units)))
         above = sum(int(np.count_nonzero(b)) > 512 for b in keep_x.values())
         build = c4.build_covariance()
+        calls = c4.calls_of(1, 0)  # (sixteen lanes a call from here on)
         for call in calls:
             c4.run_call(c4.ds, call, keep_c)
         seconds_c, passes_c = min(c4.run(calls) for _ in range(2))

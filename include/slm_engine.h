@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 15
+#define SLM_ABI_VERSION 16
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -318,9 +318,13 @@ int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point
  * the fused kernels go up to 4 at p = 5000 (6 up to 3072 columns: z and the accumulators of every
  * lane live in registers); on rows of up to 5120 columns working-set solves, and any solve on a large X
  * (n * ld >= 2^26 doubles), use the split pass, whose two halves -- residuals, then X^T R -- run on the
- * matrix cores for SLM_MAX_LANES lanes per read of X.  slm_dataset_max_lanes() tells.
+ * matrix cores for sixteen lanes per read of X.  slm_dataset_max_lanes() tells.  Working-set solves on such rows take up
+ * to SLM_MAX_LANES = 32 lanes: two halves of sixteen, whose X^T R is ONE read of X for all thirty-two (a row of X in
+ * registers is multiplied by both halves' residuals: 0.70 ms against 0.57 at 100k x 5k) -- what slm_solve_path_lanes runs
+ * a long path on (50 points: two verifying passes instead of four); covariance passes and row-sharded solves stay at
+ * sixteen.
  */
-#define SLM_MAX_LANES 16
+#define SLM_MAX_LANES 32
 /* ... and of a call the on-chip solver takes (SLM_FLAG_ON_CHIP on a dataset of p <= 128, n * ld <= 2^17): a workgroup per
  * lane, so the cells of a small grid search -- (candidate, fold) pairs, 50 in the reference's README example -- go in ONE
  * call.  slm_dataset_max_lanes() tells which of the two limits applies; a point the kernel does not settle sends the call

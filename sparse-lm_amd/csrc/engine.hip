@@ -384,7 +384,7 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
     ds->split_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n));  // one ring workgroup per CU
     // (xtr_mfma_kernel's row blocks; the residual kernels' split_nblk blocks only write R and loss_partial)
     partial_elems = std::max(partial_elems, (size_t)xtr_max_row_blocks(eng->cus, ld) * SPLIT_LANES * (size_t)ld);
-    loss_elems = std::max(loss_elems, (size_t)ds->split_nblk * SPLIT_LANES);
+    loss_elems = std::max(loss_elems, (size_t)ds->split_nblk * SPLIT_LANES * SPLIT_HALVES);
   }
 
   int rc = SLM_OK;

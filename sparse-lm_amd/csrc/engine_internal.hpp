@@ -252,6 +252,7 @@ struct slm_dataset {
   };
   std::vector<MgEntry> mg;   // oldest first; at most kMgEntries (the oldest goes when another row set needs the room)
   double* mg_vec = nullptr;  // [5][kMaxLanes][ld]: iterate, evaluation point, the last point / model gradient of the inner iteration, the product
+  double* mg_Z = nullptr;    // [halves][ld][16] the lanes' moves D = v - z0, lane-minor (the product's B operand)
   bool mg_failed = false;
   double mg_build_ms = 0.0;  // device time of the last build (events)
   int ws_sets = 0;  // Gram copies allocated

@@ -23,6 +23,7 @@ void mg_invalidate(slm_dataset* ds) {
 void mg_free(slm_dataset* ds) {
   mg_invalidate(ds);
   dfree(ds->mg_vec);
+  dfree(ds->mg_Z);
 }
 
 // G~ = X^T W X / n_eff into G.  Queued on the engine's stream: column maxima (one read of X), the fp16 operand with the
@@ -113,9 +114,9 @@ int mg_ensure(slm_dataset* ds, const double* w, double n_eff, bool own, double f
   const int64_t ld = ds->ld;
   int rc = SLM_OK;
   if (!ds->mg_vec) rc = dalloc(&ds->mg_vec, 5 * (size_t)kMaxLanes * (size_t)ld);
-  if (rc == SLM_OK && !ds->cov_Z) {
-    rc = dalloc(&ds->cov_Z, (size_t)ld * SPLIT_RSTRIDE);
-    if (rc == SLM_OK) (void)hipMemsetAsync(ds->cov_Z, 0, sizeof(double) * (size_t)ld * SPLIT_RSTRIDE, ds->eng->stream);
+  if (rc == SLM_OK && !ds->mg_Z) {  // (a plane per half of the lanes; its own block: a covariance pass's Z has one)
+    rc = dalloc(&ds->mg_Z, (size_t)ld * SPLIT_RSTRIDE * SPLIT_HALVES);
+    if (rc == SLM_OK) (void)hipMemsetAsync(ds->mg_Z, 0, sizeof(double) * (size_t)ld * SPLIT_RSTRIDE * SPLIT_HALVES, ds->eng->stream);
   }
   slm_dataset::MgEntry ne;
   if (rc == SLM_OK) rc = dalloc(&ne.G, (size_t)ld * (size_t)ld);
@@ -143,7 +144,7 @@ int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner
   const int64_t ld = ds->ld;
   SplitArgs a;
   memset(&a, 0, sizeof(a));
-  a.R = ds->cov_Z; a.done = done;
+  a.done = done;
   a.n = ld; a.ld = ld; a.p2 = (int)(ld / 2); a.n_lanes = n_lanes;
   const slm_host::XtrGrid g = slm_host::xtr_grid(ld, ld, XTR_CB, xtr_max_row_blocks(ds->eng->cus, ld) / 2);  // (as a covariance pass's)
   const int xb = g.xb, yb = g.yb;
@@ -154,29 +155,32 @@ int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner
   for (int st = 0; st < n_sets; ++st) cb.G[st] = ds->mg[(size_t)entry_of_set[st]].G;
   for (int l = 0; l < kMaxLanes; ++l) cb.set_of[l] = l < n_lanes ? set_of[l] : 0;
   cb.part_stride = (int64_t)yb * SPLIT_LANES * ld;
-  // partial sums: one block of [row blocks][16][ld] per row set (the gradient's own buffer holds two)
+  // partial sums: one block of [row blocks][16][ld] per half of the lanes and row set (the gradient's own buffer holds two)
+  const int halves = (n_lanes + SPLIT_LANES - 1) / SPLIT_LANES;
+  const int blocks = halves * n_sets;
   double* partial = ds->partial;
-  if ((size_t)n_sets * (size_t)cb.part_stride > ds->partial_elems) {
-    if (ds->cov_partial_sets < n_sets || !ds->cov_partial) {
+  if ((size_t)blocks * (size_t)cb.part_stride > ds->partial_elems) {
+    if (ds->cov_partial_sets < blocks || !ds->cov_partial) {
       dfree(ds->cov_partial);
       ds->cov_partial_sets = 0;
       // (sized like a covariance pass's: enqueue_gradient_cov shares the buffer)
       const int64_t blocks_most = std::max<int64_t>(1, xtr_max_row_blocks(ds->eng->cus, ld) / 2);
-      SLM_TRY(dalloc(&ds->cov_partial, (size_t)n_sets * (size_t)(blocks_most * SPLIT_LANES * ld)));
-      ds->cov_partial_sets = n_sets;
+      SLM_TRY(dalloc(&ds->cov_partial, (size_t)blocks * (size_t)(blocks_most * SPLIT_LANES * ld)));
+      ds->cov_partial_sets = blocks;
     }
     partial = ds->cov_partial;
   }
-  a.partial = partial;
   MgArgs m;
   memset(&m, 0, sizeof(m));
   m.mg = &ds->dctl->mg;
   m.ws = ds->ws_ctl;
   m.partial = partial;
   m.part_stride = cb.part_stride;
+  m.n_sets = n_sets;
+  m.z_plane = (int64_t)ld * SPLIT_RSTRIDE;
   for (int l = 0; l < kMaxLanes; ++l) m.set_of[l] = cb.set_of[l];
   m.nblk = yb;
-  m.Z = ds->cov_Z;
+  m.Z = ds->mg_Z;
   m.x = ds->mg_vec;
   m.v = ds->mg_vec + (size_t)kMaxLanes * ld;
   m.vprev = ds->mg_vec + 2 * (size_t)kMaxLanes * ld;
@@ -185,7 +189,11 @@ int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner
   hipLaunchKernelGGL(mg_begin_kernel, dim3((unsigned)n_lanes), dim3(TAIL_THREADS), 0, s, ta, m);
   const int E = (ta.p + TAIL_THREADS - 1) / TAIL_THREADS;
   for (int it = 0; it < inner_iters; ++it) {
-    hipLaunchKernelGGL(mg_gz_kernel, dim3(xb, yb, (unsigned)n_sets), dim3(XTR_WAVES * 64), 0, s, a, cb, (const MgCtl*)m.mg);
+    for (int h = 0; h < halves; ++h) {  // (the product is sixteen lanes wide: a launch per half, its own plane of Z and block of sums)
+      a.R = ds->mg_Z + (size_t)h * (size_t)m.z_plane;
+      a.partial = partial + (size_t)h * (size_t)n_sets * (size_t)cb.part_stride;
+      hipLaunchKernelGGL(mg_gz_kernel, dim3(xb, yb, (unsigned)n_sets), dim3(XTR_WAVES * 64), 0, s, a, cb, (const MgCtl*)m.mg, h);
+    }
     hipLaunchKernelGGL(mg_gsum_kernel, dim3((unsigned)((ld + 255) / 256), (unsigned)n_lanes), dim3(256), 0, s, m, ld, done);
     switch (E) {
       case 1: SLM_MG_STEP(1); break;

@@ -82,11 +82,18 @@ int launch_xtr(int cus, SplitArgs& a, hipStream_t s, bool sample) {
     const double f = atof(e);
     if (f > 0.0 && f <= 2.0) per_cu = f;
   }
+  const bool wide = a.lane_slots > SPLIT_LANES;  // thirty-two lanes: both planes of R per row of X
+  if (wide) per_cu = 1.0;                        // (its partial sums fill the buffer at one workgroup per CU)
   const slm_host::XtrGrid g = slm_host::xtr_grid(a.n, a.ld, XTR_CB, (int64_t)(xtr_max_row_blocks(cus, a.ld) * per_cu / 2.0));
   const int xb = g.xb, yb = g.yb;
   a.xrows = g.rows;
-  if (sample) hipLaunchKernelGGL(xtr_sample_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
-  else hipLaunchKernelGGL(xtr_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+  if (wide) {
+    if (sample) hipLaunchKernelGGL(xtr32_sample_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+    else hipLaunchKernelGGL(xtr32_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+  } else {
+    if (sample) hipLaunchKernelGGL(xtr_sample_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+    else hipLaunchKernelGGL(xtr_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+  }
   return yb;
 }
 
@@ -208,11 +215,12 @@ static void launch_rowdot(slm_dataset* ds, const SplitKernel* sk, int nblk, int 
   // Measured at n = 100k, p = 5k (tools/rowdot_probe.py): matrix cores 0.75-0.80 ms whatever the lane count;
   // vector kernel 0.62 ms for one lane, 0.81 ms for five, 3.1 ms for sixteen (four reads of X).
   const char* env = getenv("SLM_ROWDOT_RING");
-  const bool ring = sk->rowdot != nullptr && (env ? env[0] == '1' : B <= ROWDOT_LANES);
+  const int halves = (B + SPLIT_LANES - 1) / SPLIT_LANES;
+  const bool ring = sk->rowdot != nullptr && halves == 1 && (env ? env[0] == '1' : B <= ROWDOT_LANES);
   a.lane0 = 0;
   if ((!ring || sk->rowdot == nullptr) && ds->XT && ds->XT_ready) {
     a.XT = ds->XT;
-    hipLaunchKernelGGL(rowdot_mfma_kernel, dim3(nblk), dim3(XZ_WAVES * 64), 0, s, a);
+    hipLaunchKernelGGL(rowdot_mfma_kernel, dim3(nblk, halves), dim3(XZ_WAVES * 64), 0, s, a);  // (a half of sixteen lanes per read of the copy)
   } else if (sk->rowdot != nullptr) {
     hipLaunchKernelGGL(sk->rowdot, dim3(nblk, (B + ROWDOT_LANES - 1) / ROWDOT_LANES), dim3(sk->W * 64), 0, s, a);
   }
@@ -233,13 +241,16 @@ int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y
   hipStream_t s = ds->eng->stream;
   const SplitKernel* sk = ds->sk;
   const int nblk = ds->split_nblk;
-  if (!ds->R) {
-    SLM_TRY(dalloc(&ds->R, (size_t)ds->n * SPLIT_RSTRIDE));
-    HIP_TRY(hipMemsetAsync(ds->R, 0, sizeof(double) * (size_t)ds->n * SPLIT_RSTRIDE, s));
+  if (!ds->R) {  // (a plane per half of the lanes)
+    SLM_TRY(dalloc(&ds->R, (size_t)ds->n * SPLIT_RSTRIDE * SPLIT_HALVES));
+    HIP_TRY(hipMemsetAsync(ds->R, 0, sizeof(double) * (size_t)ds->n * SPLIT_RSTRIDE * SPLIT_HALVES, s));
   }
+  const int halves = (ls.B + SPLIT_LANES - 1) / SPLIT_LANES;
+  if (halves > 1 && !(ds->XT && ds->XT_ready)) return fail(SLM_ERR_UNSUPPORTED, "more than %d lanes need the column-major copy of X", SPLIT_LANES);
   SplitArgs a;
   memset(&a, 0, sizeof(a));
   a.X = ds->X; a.y = y; a.rw = ls.rw; a.rw_stride = ls.rw_stride; a.z = ds->z; a.R = ds->R;
+  a.lane_slots = SPLIT_LANES * halves; a.r_plane = (int64_t)ds->n * SPLIT_RSTRIDE;
   a.partial = ds->partial; a.loss_partial = ds->loss_partial; a.done = done; a.ctl = ctl;
   if (wa) { a.XW = wa->XW; a.idx = wa->idx; a.ws = wa->ws; }
   const int64_t nr = n_rows > 0 ? n_rows : ds->n;
@@ -253,8 +264,8 @@ int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y
   launch_rowdot(ds, sk, nblk, ls.B, a, s);
   if (wa && ctl) {  // residuals from the gathered columns: matrix cores (SLM_RESID_VEC=1: a row per thread)
     const char* env = getenv("SLM_RESID_VEC");
-    if (env && env[0] == '1') hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(resid_mfma_kernel, dim3(nblk), dim3(RM_WAVES * 64), 0, s, a);
+    if (env && env[0] == '1' && halves == 1) hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(resid_mfma_kernel, dim3(nblk, halves), dim3(RM_WAVES * 64), 0, s, a);
   }
   // (SLM_FLAG_PROFILE brackets the kernel that streams X, the one the roofline is quoted on)
   if (ev_start && !unit) HIP_TRY(hipEventRecord(ev_start, s));
@@ -267,7 +278,7 @@ int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y
   ra.done = done;
   ra.nblk = xblk;
   ra.nblk_loss = nblk;
-  ra.n_lanes = SPLIT_LANES;  // partial rows are laid out for all lane slots of the split pass
+  ra.n_lanes = a.lane_slots;  // partial rows are laid out for all lane slots of the split pass
   ra.ld = ds->ld;
   for (int l = 0; l < kMaxLanes; ++l) {
     const double ne = ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global;
@@ -555,6 +566,7 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
       a.partial = ds->partial; a.loss_partial = ds->loss_partial;
       a.n = ds->n; a.ld = ds->ld; a.rows_base = ds->n / ds->split_nblk; a.rows_rem = ds->n % ds->split_nblk;
       a.p2 = (int)(ds->ld / 2); a.n_lanes = B;
+      a.lane_slots = SPLIT_LANES * ((B + SPLIT_LANES - 1) / SPLIT_LANES); a.r_plane = (int64_t)ds->n * SPLIT_RSTRIDE;
       hipEvent_t e0, e1;
       HIP_TRY(hipEventCreate(&e0));
       HIP_TRY(hipEventCreate(&e1));
@@ -695,14 +707,14 @@ extern "C" int slm_eval_sse(slm_dataset* ds, const double* Z, int32_t m, const d
     for (int64_t i = 0; i < n; ++i)
       if (!(row_weight[i] >= 0.0) || !std::isfinite(row_weight[i]))
         return fail(SLM_ERR_BAD_ARG, "row_weight[%lld] is negative or not finite", (long long)i);
-    if (!ds->rw_lanes) SLM_TRY(dalloc(&ds->rw_lanes, (size_t)kMaxLanes * n));
+    if (!ds->rw_lanes) SLM_TRY(dalloc(&ds->rw_lanes, (size_t)ds->lane_cap * n));
     HIP_TRY(hipMemcpyAsync(ds->rw_lanes, row_weight, sizeof(double) * n, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     ls.rw = ds->rw_lanes;
     ls.rw_stride = 0;  // every lane reads the same mask
   }
   for (int l = 0; l < kMaxLanes; ++l) ls.n_eff[l] = 0.5;  // loss_scale = 1/(2 n_eff) = 1  =>  g[ld] = SSE
-  int maxB = kMaxLanes;
+  int maxB = SPLIT_LANES;
   while (maxB > 1 && !ds->gk[maxB - 1]) --maxB;
   std::vector<double> losses(kMaxLanes);
   // More vectors than a fused pass takes (four at p = 5 000): the residual half of the split pass forms X z - y for SIXTEEN
@@ -712,12 +724,12 @@ extern "C" int slm_eval_sse(slm_dataset* ds, const double* Z, int32_t m, const d
       (ds->sk->rowdot != nullptr || (ensure_xt(ds) == SLM_OK && ds->XT && ds->XT_ready))) {
     const int nblk = ds->split_nblk;
     if (!ds->R) {
-      SLM_TRY(dalloc(&ds->R, (size_t)n * SPLIT_RSTRIDE));
-      HIP_TRY(hipMemsetAsync(ds->R, 0, sizeof(double) * (size_t)n * SPLIT_RSTRIDE, s));
+      SLM_TRY(dalloc(&ds->R, (size_t)n * SPLIT_RSTRIDE * SPLIT_HALVES));
+      HIP_TRY(hipMemsetAsync(ds->R, 0, sizeof(double) * (size_t)n * SPLIT_RSTRIDE * SPLIT_HALVES, s));
     }
-    for (int32_t k0 = 0; k0 < m; k0 += kMaxLanes) {
-      const int B = std::min<int32_t>(kMaxLanes, m - k0);
-      HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * kMaxLanes * ld, s));
+    for (int32_t k0 = 0; k0 < m; k0 += SPLIT_LANES) {  // (sixteen vectors per read of the copy: one half of the lane slots)
+      const int B = std::min<int32_t>(SPLIT_LANES, m - k0);
+      HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * SPLIT_LANES * ld, s));
       HIP_TRY(hipMemcpy2DAsync(ds->z, sizeof(double) * ld, Z + (size_t)k0 * p, sizeof(double) * p, sizeof(double) * p, B, hipMemcpyHostToDevice, s));
       SplitArgs a;
       memset(&a, 0, sizeof(a));
@@ -726,10 +738,11 @@ extern "C" int slm_eval_sse(slm_dataset* ds, const double* Z, int32_t m, const d
       a.n = n; a.ld = ld; a.rows_base = n / nblk; a.rows_rem = n % nblk;
       a.p2 = (int)(ld / 2);
       a.n_lanes = B;
+      a.lane_slots = SPLIT_LANES; a.r_plane = (int64_t)n * SPLIT_RSTRIDE;
       launch_rowdot(ds, ds->sk, nblk, B, a, s);
       hipLaunchKernelGGL(sse_from_blocks_kernel, dim3(1), dim3(64), 0, s, ds->loss_partial, nblk, SPLIT_LANES, ds->partial);
       SLM_TRY(check_launch());
-      HIP_TRY(hipMemcpyAsync(losses.data(), ds->partial, sizeof(double) * kMaxLanes, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(losses.data(), ds->partial, sizeof(double) * SPLIT_LANES, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       for (int l = 0; l < B; ++l) sse_out[k0 + l] = losses[l];
     }
@@ -738,7 +751,7 @@ extern "C" int slm_eval_sse(slm_dataset* ds, const double* Z, int32_t m, const d
   for (int32_t k0 = 0; k0 < m; k0 += maxB) {
     const int B = std::min<int32_t>(maxB, m - k0);  // kernel variants exist for every B <= maxB
     ls.B = B;
-    HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * kMaxLanes * ld, s));
+    HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * SPLIT_LANES * ld, s));
     for (int l = 0; l < B; ++l)
       HIP_TRY(hipMemcpyAsync(ds->z + (size_t)l * ld, Z + (size_t)(k0 + l) * p, sizeof(double) * p,
                              hipMemcpyHostToDevice, s));
@@ -788,7 +801,7 @@ extern "C" int slm_eval_sse_sparse(slm_dataset* ds, const int32_t* cols, int32_t
     for (int64_t i = 0; i < n; ++i)
       if (!(row_weight[i] >= 0.0) || !std::isfinite(row_weight[i]))
         return fail(SLM_ERR_BAD_ARG, "row_weight[%lld] is negative or not finite", (long long)i);
-    if (!ds->rw_lanes) SLM_TRY(dalloc(&ds->rw_lanes, (size_t)kMaxLanes * n));
+    if (!ds->rw_lanes) SLM_TRY(dalloc(&ds->rw_lanes, (size_t)ds->lane_cap * n));
     HIP_TRY(hipMemcpyAsync(ds->rw_lanes, row_weight, sizeof(double) * n, hipMemcpyHostToDevice, s));
   }
   // scratch shared with the working set (every solve re-initialises that state)
@@ -881,7 +894,17 @@ static bool small_ok(const slm_dataset* ds, uint32_t flags) {
 // set is on from the start
 static int max_lanes_for(slm_dataset* ds, uint32_t flags) {
   if (small_ok(ds, flags)) return ds->lane_cap;  // a workgroup per lane
-  if ((ws_policy(ds, flags) == 2 || (double)ds->n * (double)ds->ld >= 67108864.0) && split_usable(ds)) return SPLIT_LANES;
+  if ((ws_policy(ds, flags) == 2 || (double)ds->n * (double)ds->ld >= 67108864.0) && split_usable(ds)) {
+    // Two halves of sixteen on ONE read of X (xtr32_mfma_kernel, 0.71 ms against 0.57 at 100k x 5k) where the solve is a
+    // working-set solve over X on this device: lanes that advance a point per pass -- the units of a grid, the folds of a
+    // search -- then cost 0.6 of what they cost on sixteen (config 4 over X: 159 passes / 0.147 s -> 85 / 0.092 s).
+    // Covariance passes and row-sharded solves stay at sixteen; so do rows beyond 5120 columns (no ring variant:
+    // every residual from X is a read of the column-major copy per half).
+    if (ws_policy(ds, flags) == 2 && !(flags & SLM_FLAG_COVARIANCE) && !row_sharded(ds) && ds->sk != nullptr && ds->sk->rowdot != nullptr &&
+        getenv("SLM_NO_WIDE_LANES") == nullptr && ensure_xt(ds) == SLM_OK && ds->XT != nullptr)
+      return kMaxLanes;
+    return SPLIT_LANES;
+  }
   int B = kMaxLanes;
   while (B > 1 && !ds->gk[B - 1]) --B;
   return B;
@@ -952,7 +975,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   const GradKernel* gk_B = B <= kMaxLanes ? ds->gk[B - 1] : nullptr;
   const bool want_split = (ws_policy(ds, opts ? opts->flags : 0u) == 2 && !wide) ? (big_x || !gk_B) : (big_x && !gk_B);
   // (covariance passes are a form of the split pass: the flag asks for it whatever the size, where Grams exist)
-  const bool want_cov = opts && (opts->flags & SLM_FLAG_COVARIANCE) && !ds->cov.empty() && !row_sharded(ds);
+  const bool want_cov = opts && (opts->flags & SLM_FLAG_COVARIANCE) && !ds->cov.empty() && !row_sharded(ds) && B <= SPLIT_LANES;
   const bool split = (want_split || want_cov) && split_usable(ds);
   // Shared path with the working set on from the start: the lanes take the points of the path in turn
   // (lane l: l, l + B, ...) instead of contiguous ranges.  Every lane then starts near alpha_max, where
@@ -966,6 +989,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
                           !getenv("SLM_NO_INTERLEAVE");
   if (!split && !gk_B && !small_ok(ds, opts ? opts->flags : 0u))
     return fail(SLM_ERR_UNSUPPORTED, "no %d-lane gradient kernel covers p = %lld", B, (long long)ds->p);
+  // more than sixteen lanes: two halves on one read of X (xtr32_mfma_kernel) -- working-set solves on the split pass, all rows here
+  if (B > SPLIT_LANES && !small_ok(ds, opts ? opts->flags : 0u) && (!split || row_sharded(ds) || ws_policy(ds, opts ? opts->flags : 0u) != 2))
+    return fail(SLM_ERR_UNSUPPORTED, "%d lanes: more than %d need a working-set solve on the split pass of an unsharded dataset", B, SPLIT_LANES);
   if (split && B > ROWDOT_LANES) SLM_TRY(ensure_xt(ds));  // rowdot_mfma_kernel reads the column-major copy (optional)
   int64_t total_points = 0;
   bool any_rw = false, any_gn = false;
@@ -1833,6 +1859,21 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   bool results_queued = false, results_final = false;  // the result copies were queued early / and hold the final state
   int final_slot = 0;          // the snapshot in which the host saw `done`
   bool deferred = false;       // the refinement behind the last queued pass has not been queued yet
+  // SLM_TRACE=3: one line per polled snapshot -- where every lane stands, the working set, the model Gram's rounds
+  // (with SLM_TRACE_POLL=1 every pass is polled: a diagnostic, the queue then drains between passes)
+  const char* trc3 = getenv("SLM_TRACE");
+  const bool trace3 = trc3 != nullptr && trc3[0] == '3';
+  if (trace3 && getenv("SLM_TRACE_POLL") != nullptr && expected > 0) expected = n_sample > 0 ? 2 : 1;  // (the sample pass's refinement is never held back)
+  auto trace_pass = [&](const DevCtl& now) {
+    if (!trace3) return;
+    fprintf(stderr, "[slm] pass %lld at %.3f ms: K %d builds %d appends %d misses %d stale %d refined %d | mg on %d rounds %d inner %d most %d rej %d | lanes (point.iter/flags):",
+            (long long)enq, t_mark(), now.ws.Kreal, now.ws.builds, now.ws.appends, now.ws.misses, now.ws.stale, now.ws.refined, (int)mg_on,
+            now.mg.rounds, now.mg.inner_iters, now.mg.most_iters, now.mg.rejected);
+    for (int l = 0; l < B; ++l)
+      fprintf(stderr, " %d.%d%s%s%s", now.lane[l].point, now.lane[l].iter, now.lane[l].done ? "d" : "", now.lane[l].zsup ? "w" : "",
+              l < SLM_MAX_LANES && now.mg.lane[l].active ? "m" : "");
+    fprintf(stderr, "\n");
+  };
   while (!done) {
     {
       // (a solve with an expected end queues all of its passes at once: launches behind the device-side stop flag return
@@ -1880,7 +1921,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     // remain to be fetched.  Polling one chunk behind cost a queued pass that returned at once (eighteen launches,
     // 0.09 ms) and four blocking copies (0.2 ms of host round trips) on every 5 ms path.  A solve that overruns
     // gets a few more passes polled this way, then the pipelined polls.
-    const bool at_end = mg_on || (expected > 0 && enq >= expected && enq < expected + 4);
+    const bool at_end = mg_on || (expected > 0 && enq >= expected && (enq < expected + 4 || (trace3 && getenv("SLM_TRACE_POLL") != nullptr)));
     HIP_TRY(hipEventRecord(ds->ev[slot], s));
     // behind the pass the solve is expected to end with, the results set off at once: when it does end there they are
     // under way while the host still reads the snapshot (37 us of idle stream per path); when it does not, they are
@@ -1913,16 +1954,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         results_final = results_queued && enq == expected;  // (queued behind exactly this pass)
       } else {  // the solve goes on: what was held back, then the next pass
         const DevCtl& now = ds->hctl[slot].c;
-        if (const char* trc = getenv("SLM_TRACE"))
-          if (trc[0] == '3') {  // one line per polled pass: where every lane stands, the working set, the model Gram's rounds
-            fprintf(stderr, "[slm] pass %lld at %.3f ms: K %d builds %d appends %d misses %d stale %d refined %d | mg on %d rounds %d inner %d most %d rej %d | lanes (point.iter/flags):",
-                    (long long)enq, t_mark(), now.ws.Kreal, now.ws.builds, now.ws.appends, now.ws.misses, now.ws.stale, now.ws.refined, (int)mg_on,
-                    now.mg.rounds, now.mg.inner_iters, now.mg.most_iters, now.mg.rejected);
-            for (int l = 0; l < B; ++l)
-              fprintf(stderr, " %d.%d%s%s%s", now.lane[l].point, now.lane[l].iter, now.lane[l].done ? "d" : "", now.lane[l].zsup ? "w" : "",
-                      now.mg.lane[l].active ? "m" : "");
-            fprintf(stderr, "\n");
-          }
+        trace_pass(now);
         SLM_TRY(mg_consider(now));
         if (deferred) {
           // (once the working set is frozen and no live lane stands on it any more -- the dense end of a path -- its

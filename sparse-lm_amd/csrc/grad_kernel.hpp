@@ -553,8 +553,8 @@ struct ReduceArgs {
   int nblk_loss;  // row blocks of loss_partial (the split pass's residual kernels keep their own blocks)
   int n_lanes;
   int64_t ld;
-  double scale[16];       // 1/n_eff per lane (SLM_MAX_LANES)
-  double loss_scale[16];  // 1/(2 n_eff) per lane
+  double scale[32];       // 1/n_eff per lane (SLM_MAX_LANES)
+  double loss_scale[32];  // 1/(2 n_eff) per lane
 };
 
 // grid = (ld/16 + 1, n_lanes)

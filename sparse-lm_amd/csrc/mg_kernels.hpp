@@ -407,12 +407,14 @@ static __global__ __launch_bounds__(256) void mg_reduce_kernel(MgReduceArgs a) {
 struct MgArgs {
   MgCtl* mg;
   WsCtl* ws;              // nullable: WsCtl::served tells which lanes the working set's model solver moved this round
-  const double* partial;  // [row sets][nblk][16][ld] of the products G~_s D
+  const double* partial;  // [halves][row sets][nblk][16][ld] of the products G~_s D (a half: sixteen lanes, the width of the product)
   int64_t part_stride;    // doubles between the partial sums of two row sets
   int32_t set_of[SLM_MAX_LANES];  // row set of lane l
+  int n_sets;
+  int64_t z_plane;        // doubles between the two halves' planes of Z (ld x 16)
   int nblk;
   double* gd;             // [16][ld] the product, summed over its row blocks (mg_gsum_kernel)
-  double* Z;              // [ld][16] D = v - z0, lane-minor: the B operand of the product
+  double* Z;              // [halves][ld][16] D = v - z0, lane-minor: the B operand of the product, a plane per half of the lanes
   double* x;              // [16][ld] iterate
   double* v;              // [16][ld] point the model gradient is evaluated at
   double* vprev;          // [16][ld]
@@ -420,17 +422,18 @@ struct MgArgs {
 };
 
 // which lanes still iterate (one round of loads, a ballot)
-__device__ __forceinline__ bool mg_any_active(const MgCtl* mg) {
+__device__ __forceinline__ bool mg_any_active(const MgCtl* mg, int half) {
   const int l = threadIdx.x & 63;
   int on = 0;
-  if (l < SLM_MAX_LANES) on = (mg->lane[l].active != 0) & (mg->lane[l].settled == 0);
+  if (l < SPLIT_LANES) on = (mg->lane[SPLIT_LANES * half + l].active != 0) & (mg->lane[SPLIT_LANES * half + l].settled == 0);
   return __ballot(on != 0) != 0ull;
 }
 
-// the product of an inner iteration: cov_gz_mfma_kernel's loop on (G~, Z), skipped when no lane iterates any more
-static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void mg_gz_kernel(SplitArgs a, CovBatch cb, const MgCtl* mg) {
+// the product of an inner iteration for one half of the lanes: cov_gz_mfma_kernel's loop on (G~, that half's plane of Z),
+// skipped when no lane of the half iterates any more
+static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void mg_gz_kernel(SplitArgs a, CovBatch cb, const MgCtl* mg, int half) {
   if (a.done != nullptr && *a.done != 0) return;
-  if (!mg_any_active(mg)) return;
+  if (!mg_any_active(mg, half)) return;
   cov_gz_body(a, cb);
 }
 
@@ -444,7 +447,8 @@ static __global__ __launch_bounds__(256) void mg_gsum_kernel(MgArgs m, int64_t l
   if (ml->active == 0 || ml->settled != 0) return;
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= ld) return;
-  const double* part = m.partial + (int64_t)m.set_of[lane_id] * m.part_stride + (int64_t)lane_id * ld + j;
+  const int half = lane_id / SPLIT_LANES, l16 = lane_id % SPLIT_LANES;
+  const double* part = m.partial + ((int64_t)half * m.n_sets + m.set_of[lane_id]) * m.part_stride + (int64_t)l16 * ld + j;
   const int64_t bstride = (int64_t)SPLIT_LANES * ld;
   double acc = 0.0;
   int b = 0;
@@ -532,9 +536,9 @@ static __global__ __launch_bounds__(TAIL_THREADS) void mg_begin_kernel(TailArgs 
       if (j < a.p) {
         x[j] = zj[u];
         v[j] = zj[u];
-        m.Z[(int64_t)j * SPLIT_RSTRIDE + lane_id] = zj[u] - zo[u];
+        m.Z[(int64_t)(lane_id / SPLIT_LANES) * m.z_plane + (int64_t)j * SPLIT_RSTRIDE + lane_id % SPLIT_LANES] = zj[u] - zo[u];
       } else if (j < (int)a.ld) {
-        m.Z[(int64_t)j * SPLIT_RSTRIDE + lane_id] = 0.0;
+        m.Z[(int64_t)(lane_id / SPLIT_LANES) * m.z_plane + (int64_t)j * SPLIT_RSTRIDE + lane_id % SPLIT_LANES] = 0.0;
       }
     }
   }
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void mg_step_kernel(TailArgs a, MgArg
     if (ok) {
       x[j] = xn;
       v[j] = vn;
-      m.Z[(int64_t)j * SPLIT_RSTRIDE + lane_id] = vn - zo;
+      m.Z[(int64_t)(lane_id / SPLIT_LANES) * m.z_plane + (int64_t)j * SPLIT_RSTRIDE + lane_id % SPLIT_LANES] = vn - zo;
     }
   });
   if (tid == 0) {

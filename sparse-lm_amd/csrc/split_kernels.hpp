@@ -26,8 +26,13 @@
 
 namespace slm {
 
-constexpr int SPLIT_LANES = 16;    // lane slots of the split pass: the 16 columns of the MFMA B operand
-constexpr int SPLIT_RSTRIDE = 16;  // doubles per row of R (two 64-byte scalar loads)
+constexpr int SPLIT_LANES = 16;    // lane slots of one HALF of the split pass: the 16 columns of an MFMA B operand
+constexpr int SPLIT_RSTRIDE = 16;  // doubles per row of a plane of R (two 64-byte scalar loads)
+// A call of up to SLM_MAX_LANES = 32 lanes is two halves of sixteen: R has a plane per half ([halves][n][16]), the residual
+// kernels run per half (grid.y), and xtr_mfma_kernel multiplies every row of X it has loaded by BOTH planes -- thirty-two
+// lanes per read of X (measured: 0.70 ms against 0.57 for sixteen).  partial / loss_partial are [blocks][16 halves][...].
+constexpr int SPLIT_HALVES = SLM_MAX_LANES / SPLIT_LANES;
+static_assert(SLM_MAX_LANES % SPLIT_LANES == 0 && SPLIT_HALVES >= 1 && SPLIT_HALVES <= 2, "one or two halves of sixteen lanes");
 constexpr int ROWDOT_LANES = 5;    // lanes per launch of rowdot_ring_kernel (z + row in registers: 162 VGPRs)
 
 struct SplitArgs {
@@ -51,20 +56,25 @@ struct SplitArgs {
   int xrows;  // xtr_mfma_kernel: rows per workgroup row (multiple of 8); partial is then [gridDim.y][SPLIT_LANES][ld]
   int xrows_ws;  // cov_gz_mfma_kernel: listed rows per workgroup row when only the working set's rows are read (multiple of 4, <= 32)
   const double* XT;  // rowdot_mfma_kernel: column-major copy of X in tiles of 32 rows (tile_columns_kernel)
+  int lane_slots;    // lane slots of partial / loss_partial: 16 x halves of the call (0 = 16)
+  int64_t r_plane;   // doubles between the planes of R (the second half's residuals; 0 with one half)
 };
+__device__ __forceinline__ int split_slots(const SplitArgs& a) { return a.lane_slots > 0 ? a.lane_slots : SPLIT_LANES; }
 
 // which lanes take their residual from XW: live, flagged by ws_solve_kernel, and W still published
 // Which lane slots a residual kernel serves.  Lane l of every wavefront looks at control block l and the
 // wavefront votes: one round of loads.  (Walking the sixteen blocks in a loop with short-circuit tests made
 // every flag its own dependent load -- 11 us before rowdot_mfma_kernel found out it had nothing to do.)
-__device__ __forceinline__ void split_masks(const SplitArgs& a, unsigned& live, unsigned& on_ws) {
+// (`half`: the sixteen lanes 16 half ... 16 half + 15 of the call; bit l of a mask is lane 16 half + l)
+__device__ __forceinline__ void split_masks(const SplitArgs& a, unsigned& live, unsigned& on_ws, int half = 0) {
   const int l = threadIdx.x & 63;
+  const int L = SPLIT_LANES * half + l;
   int lv = 0, sp = 0;
-  if (l < a.n_lanes) {
+  if (l < SPLIT_LANES && L < a.n_lanes) {
     if (a.ctl == nullptr) {
       lv = 1;
     } else {
-      const int dn = a.ctl[l].done, id = a.ctl[l].idle, zs = a.ctl[l].zsup;
+      const int dn = a.ctl[L].done, id = a.ctl[L].idle, zs = a.ctl[L].zsup;
       lv = (dn == 0) & (id == 0);
       sp = lv & (zs != 0);
     }
@@ -73,15 +83,15 @@ __device__ __forceinline__ void split_masks(const SplitArgs& a, unsigned& live, 
   live = (unsigned)__ballot(lv != 0);
   on_ws = ws_ok ? (unsigned)__ballot(sp != 0) : 0u;
 }
-__device__ __forceinline__ unsigned split_ws_mask(const SplitArgs& a) {
+__device__ __forceinline__ unsigned split_ws_mask(const SplitArgs& a, int half = 0) {
   unsigned live, on_ws;
-  split_masks(a, live, on_ws);
+  split_masks(a, live, on_ws, half);
   return on_ws;
 }
 // lane slots whose residual has to come from X
-__device__ __forceinline__ unsigned split_x_mask(const SplitArgs& a) {
+__device__ __forceinline__ unsigned split_x_mask(const SplitArgs& a, int half = 0) {
   unsigned live, on_ws;
-  split_masks(a, live, on_ws);
+  split_masks(a, live, on_ws, half);
   return live & ~on_ws;
 }
 
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(256) void resid_ws_kernel(SplitArgs a) {
   }
   __syncthreads();
   if (tid < B && ((mask >> tid) & 1u))
-    a.loss_partial[b * SPLIT_LANES + tid] = lsum[0][tid] + lsum[1][tid] + lsum[2][tid] + lsum[3][tid];
+    a.loss_partial[b * split_slots(a) + tid] = lsum[0][tid] + lsum[1][tid] + lsum[2][tid] + lsum[3][tid];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
     if (tid < B && ((mask >> tid) & 1u)) {
       double t = 0.0;
       for (int w2 = 0; w2 < W; ++w2) t += red[tid * W + w2];
-      a.loss_partial[b * SPLIT_LANES + lane0 + tid] = t;
+      a.loss_partial[b * split_slots(a) + lane0 + tid] = t;
     }
     return;
   }
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
   if (tid == 0) {
 #pragma unroll
     for (int l = 0; l < B; ++l)
-      if ((mask >> l) & 1u) a.loss_partial[b * SPLIT_LANES + lane0 + l] = loss[l];
+      if ((mask >> l) & 1u) a.loss_partial[b * split_slots(a) + lane0 + l] = loss[l];
   }
 }
 
@@ -345,8 +355,10 @@ constexpr int XTR_CW = 128;                    // columns per wavefront
 constexpr int XTR_CB = XTR_WAVES * XTR_CW;     // columns per workgroup
 constexpr int XTR_U = 2;                       // 4-row steps per batch
 
+template <int H>
 __device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
-  static_assert(SPLIT_RSTRIDE == 16 && SPLIT_LANES <= 16, "a row of R is the 16-wide B operand");
+  static_assert(SPLIT_RSTRIDE == 16 && SPLIT_LANES <= 16, "a row of a plane of R is the 16-wide B operand");
+  static_assert(H == 1 || H == 2, "one or two planes of R");
   if (a.done != nullptr && *a.done != 0) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -374,15 +386,17 @@ __device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
     const int col = col0 + 32 * c + 2 * i16;
     coff[c] = col < ld - 2 ? col : ld - 2;
   }
-  slm_d4 acc[8];
+  slm_d4 acc[H][8];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) acc[t] = slm_d4{0.0, 0.0, 0.0, 0.0};
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[h][t] = slm_d4{0.0, 0.0, 0.0, 0.0};
   const int nb = (int)((r1 - r0) / (4 * XTR_U));  // full batches
   const double* xp = a.X + (r0 + kq) * a.ld;
   const double* rp = a.R + (r0 + kq) * SPLIT_RSTRIDE + i16;
   d2 xa[XTR_U][4], xb[XTR_U][4];
-  double ra[XTR_U], rb[XTR_U];
-  auto load = [&](d2(&xv)[XTR_U][4], double(&rv)[XTR_U], int b) {
+  double ra[H][XTR_U], rb[H][XTR_U];
+  auto load = [&](d2(&xv)[XTR_U][4], double(&rv)[H][XTR_U], int b) {
     const double* xq = xp + (int64_t)b * (4 * XTR_U) * a.ld;
     const double* rq = rp + (int64_t)b * (4 * XTR_U) * SPLIT_RSTRIDE;
 #pragma unroll
@@ -392,17 +406,20 @@ __device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
         const d2* src = reinterpret_cast<const d2*>(xq + (int64_t)u * 4 * a.ld + coff[c]);
         xv[u][c] = SLM_NT_LOADS ? __builtin_nontemporal_load(src) : *src;
       }
-      rv[u] = rq[u * 4 * SPLIT_RSTRIDE];
+#pragma unroll
+      for (int h = 0; h < H; ++h) rv[h][u] = rq[(int64_t)h * a.r_plane + u * 4 * SPLIT_RSTRIDE];
     }
   };
-  auto compute = [&](d2(&xv)[XTR_U][4], double(&rv)[XTR_U]) {
+  auto compute = [&](d2(&xv)[XTR_U][4], double(&rv)[H][XTR_U]) {
 #pragma unroll
     for (int u = 0; u < XTR_U; ++u)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].x, rv[u], acc[2 * c], 0, 0, 0);
-        acc[2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].y, rv[u], acc[2 * c + 1], 0, 0, 0);
-      }
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          acc[h][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].x, rv[h][u], acc[h][2 * c], 0, 0, 0);
+          acc[h][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].y, rv[h][u], acc[h][2 * c + 1], 0, 0, 0);
+        }
   };
   // (straight-line steady state, the odd batch peeled off: with `if (b + 1 < nb) load(...)` in the loop the compiler
   //  had to wait at the first product of a batch as if the batch behind it had not been asked for -- vmcnt(1) with
@@ -430,32 +447,43 @@ __device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
   for (int64_t row = r0 + (int64_t)nb * (4 * XTR_U); row < r1; row += 4) {
     const bool ok = row + kq < r1;
     const int64_t rr = ok ? row + kq : r1 - 1;
-    const double rv = ok ? a.R[rr * SPLIT_RSTRIDE + i16] : 0.0;
+    double rv[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) rv[h] = ok ? a.R[(int64_t)h * a.r_plane + rr * SPLIT_RSTRIDE + i16] : 0.0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const d2 x = *reinterpret_cast<const d2*>(a.X + rr * a.ld + coff[c]);
-      acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, rv, acc[2 * c], 0, 0, 0);
-      acc[2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, rv, acc[2 * c + 1], 0, 0, 0);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        acc[h][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, rv[h], acc[h][2 * c], 0, 0, 0);
+        acc[h][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, rv[h], acc[h][2 * c + 1], 0, 0, 0);
+      }
     }
   }
   if (i16 < SPLIT_LANES) {  // tile 2c+e holds columns col0 + 32 c + 2 i + e
-    double* out = a.partial + ((int64_t)by * SPLIT_LANES + i16) * a.ld;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int h = 0; h < H; ++h) {
+      double* out = a.partial + ((int64_t)by * (SPLIT_LANES * H) + SPLIT_LANES * h + i16) * a.ld;
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = col0 + 32 * c + 2 * (kq + 4 * r) + e;
-          if (col < ld) out[col] = acc[2 * c + e][r];
-        }
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int col = col0 + 32 * c + 2 * (kq + 4 * r) + e;
+            if (col < ld) out[col] = acc[h][2 * c + e][r];
+          }
+    }
   }
 }
 
-static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a) { xtr_mfma_body(a); }
+static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_mfma_kernel(SplitArgs a) { xtr_mfma_body<1>(a); }
+// thirty-two lanes per read of X: both planes of R against every row loaded (sixteen result tiles = 128 registers)
+static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void xtr32_mfma_kernel(SplitArgs a) { xtr_mfma_body<2>(a); }
 // the same product over the head of the rows only (solve_core's sample start): a name of its own, so that a profile's
 // per-kernel statistics of xtr_mfma_kernel are those of passes over all of X
-static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_sample_kernel(SplitArgs a) { xtr_mfma_body(a); }
+static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_sample_kernel(SplitArgs a) { xtr_mfma_body<1>(a); }
+static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void xtr32_sample_kernel(SplitArgs a) { xtr_mfma_body<2>(a); }
 
 // ---------------------------------------------------------------------------------------------
 // The first half on the matrix cores as well: R[row][l] = w_l,row (x_row . z_l - y_row) for ALL sixteen lane
@@ -535,8 +563,11 @@ __device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const
 static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 rows of the MFMA A operand");
   if (a.done != nullptr && *a.done != 0) return;
-  const unsigned mask = split_x_mask(a);
+  const int half = (int)blockIdx.y, L0 = SPLIT_LANES * half;  // (grid.y: the halves of the call; lane slot l here is lane L0 + l)
+  const unsigned mask = split_x_mask(a, half);
   if (mask == 0u) return;
+  a.R += (int64_t)half * a.r_plane;
+  const int LS = split_slots(a);
   __shared__ double red[XZ_WAVES][SPLIT_LANES];
   __shared__ double part[XZ_WAVES * XZ_T * 2 * 4 * 64];  // 64 KiB: the wavefronts' partial products of one step
   const int tid = threadIdx.x, lane = tid & 63;
@@ -547,7 +578,8 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(Split
 
   bool all_zero = a.ctl != nullptr;  // cold start: e = -y without reading X (as rowdot_ring_kernel)
   if (all_zero) {  // (lane l of every wavefront reads control block l: one round trip, not one per lane slot)
-    const bool moved = lane < a.n_lanes && ((mask >> lane) & 1u) && !a.ctl[lane < a.n_lanes ? lane : 0].zzero;
+    const bool in = lane < SPLIT_LANES && L0 + lane < a.n_lanes;
+    const bool moved = in && ((mask >> lane) & 1u) && !a.ctl[in ? L0 + lane : 0].zzero;
     all_zero = __ballot(moved) == 0ull;
   }
   if (all_zero) {
@@ -558,7 +590,7 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(Split
     const bool on = ((mask >> l) & 1u) != 0u;
     double ls = 0.0;
     const bool has_rw = a.rw != nullptr;
-    const double* rwp = has_rw ? a.rw + (int64_t)l * a.rw_stride : a.y;  // (no row weights: any readable address)
+    const double* rwp = has_rw ? a.rw + (int64_t)(L0 + l) * a.rw_stride : a.y;  // (no row weights: any readable address)
     for (int64_t i0 = tid >> 4; i0 < nrows; i0 += 8 * XZ_WAVES * 4) {  // eight rows per round: their loads go out together
       double yv[8], mv[8];
 #pragma unroll
@@ -585,7 +617,7 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(Split
     if (tid < SPLIT_LANES && ((mask >> tid) & 1u)) {
       double t = 0.0;
       for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2][tid];
-      a.loss_partial[b * SPLIT_LANES + tid] = t;
+      a.loss_partial[b * LS + L0 + tid] = t;
     }
     return;
   }
@@ -611,7 +643,7 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(Split
   const int gb = ngroups / XZ_WAVES, gr = ngroups % XZ_WAVES;
   const int g_lo = wave * gb + (wave < gr ? wave : gr);
   const int g_n = gb + (wave < gr ? 1 : 0);
-  const double* zp = a.z + (int64_t)(j < a.n_lanes ? j : a.n_lanes - 1) * a.ld + 4 * q + 16 * (int64_t)g_lo;
+  const double* zp = a.z + (int64_t)(L0 + j < a.n_lanes ? L0 + j : a.n_lanes - 1) * a.ld + 4 * q + 16 * (int64_t)g_lo;
   double loss[4] = {0.0, 0.0, 0.0, 0.0};  // of lane slots q, q + 4, q + 8, q + 12 over this lane's rows
   int t_at = 0;
   for (int st = 0; st < nsteps; ++st) {
@@ -643,7 +675,7 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(Split
 #pragma unroll
           for (int w2 = 0; w2 < XZ_WAVES; ++w2) v += part[(((w2 * XZ_T + t) * 2 + e) * 4 + r) * 64 + lane];
           if (in && ((mask >> l) & 1u)) {
-            const double m = a.rw ? a.rw[(int64_t)l * a.rw_stride + row] : 1.0;
+            const double m = a.rw ? a.rw[(int64_t)(L0 + l) * a.rw_stride + row] : 1.0;
             const double err = v - yi;
             const double res = err * m;
             a.R[row * SPLIT_RSTRIDE + l] = res;
@@ -666,7 +698,7 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(Split
   if (tid < SPLIT_LANES && ((mask >> tid) & 1u)) {
     double t = 0.0;
     for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2][tid];
-    a.loss_partial[b * SPLIT_LANES + tid] = t;
+    a.loss_partial[b * LS + L0 + tid] = t;
   }
 }
 
@@ -685,8 +717,10 @@ constexpr int RM_U = 4;  // 16-position groups per batch (two batches in flight)
 static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 columns of the MFMA B operand");
   if (a.done != nullptr && *a.done != 0) return;
-  const unsigned mask = split_ws_mask(a);
+  const int half = (int)blockIdx.y, L0 = SPLIT_LANES * half;  // (grid.y: the halves of the call)
+  const unsigned mask = split_ws_mask(a, half);
   if (mask == 0u) return;
+  a.R += (int64_t)half * a.r_plane;
   __shared__ double zw[WS_KCAP][SPLIT_LANES];  // 64 KiB
   __shared__ double lsum[RM_WAVES][SPLIT_LANES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -699,7 +733,7 @@ static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitA
   for (int e = tid; e < K * SPLIT_LANES; e += RM_WAVES * 64) {
     const int k = e >> 4, l = e & 15;
     const int j = a.idx[k];
-    zw[k][l] = (j >= 0 && l < a.n_lanes) ? a.z[(int64_t)l * a.ld + j] : 0.0;
+    zw[k][l] = (j >= 0 && L0 + l < a.n_lanes) ? a.z[(int64_t)(L0 + l) * a.ld + j] : 0.0;
   }
   __syncthreads();
   const int i16 = lane & 15, q = lane >> 4;
@@ -722,7 +756,7 @@ static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitA
       const int64_t row = row0 + q + 4 * r;
       const int64_t rc = row < rend ? row : rend - 1;
       yv[r] = a.y[rc];
-      mv[r] = rwp[has_rw ? (int64_t)i16 * a.rw_stride + rc : 0];
+      mv[r] = rwp[has_rw ? (int64_t)(L0 + i16) * a.rw_stride + rc : 0];
     }
     // (loads without conditions -- a group beyond K is read from the last one and not used: with the loads under
     //  `if (g0 + u < ngroups)` the compiler could not count them and drained the queue before every batch of MFMAs)
@@ -768,7 +802,7 @@ static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitA
   if (tid < SPLIT_LANES && ((mask >> tid) & 1u)) {
     double t = 0.0;
     for (int w2 = 0; w2 < RM_WAVES; ++w2) t += lsum[w2][tid];
-    a.loss_partial[b * SPLIT_LANES + tid] = t;
+    a.loss_partial[b * split_slots(a) + L0 + tid] = t;
   }
 }
 

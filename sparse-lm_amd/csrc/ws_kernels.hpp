@@ -263,34 +263,37 @@ static __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs
       const bool in_w = had_w && w.pos[j] >= 0;
       // all loads of all lanes first (unconditional, clamped to a lane that exists), then the arithmetic: with
       // the tests between them every lane cost two dependent round trips, 32 in a row (21 us per pass)
-      double zp[SLM_MAX_LANES], zz[SLM_MAX_LANES], aa[SLM_MAX_LANES], bb[SLM_MAX_LANES], gg[SLM_MAX_LANES];
+      // (sixteen lanes at a time: a call of thirty-two is two such rounds -- all of them in registers at once would be 320)
+      for (int l0 = 0; l0 < a.n_lanes; l0 += 16) {
+        double zp[16], zz[16], aa[16], bb[16], gg[16];
 #pragma unroll
-      for (int l = 0; l < SLM_MAX_LANES; ++l) {
-        const int ll = l < a.n_lanes ? l : 0;
-        const int64_t off = (int64_t)ll * a.ld;
-        zp[l] = a.zprev[off + j];
-        zz[l] = a.z[off + j];
-        aa[l] = a.a0[off + j];
-        bb[l] = a.b0[off + j];
-        gg[l] = a.g[(int64_t)ll * (a.ld + 16) + j];
-      }
+        for (int l = 0; l < 16; ++l) {
+          const int ll = l0 + l < a.n_lanes ? l0 + l : 0;
+          const int64_t off = (int64_t)ll * a.ld;
+          zp[l] = a.zprev[off + j];
+          zz[l] = a.z[off + j];
+          aa[l] = a.a0[off + j];
+          bb[l] = a.b0[off + j];
+          gg[l] = a.g[(int64_t)ll * (a.ld + 16) + j];
+        }
 #pragma unroll
-      for (int l = 0; l < SLM_MAX_LANES; ++l) {
-        if (l >= a.n_lanes || !lane_live[l]) continue;
-        if (!in_w && had_w && zz[l] != zp[l]) n_miss += 1;
-        if (zp[l] != 0.0) {
-          sc = inf;
-        } else {
-          const double thr = lane_sa[l] * aa[l] + lane_sb[l] * bb[l];
-          sc = fmax(sc, thr > 0.0 ? fabs(gg[l]) / thr : inf);
+        for (int l = 0; l < 16; ++l) {
+          if (l0 + l >= a.n_lanes || !lane_live[l0 + l]) continue;
+          if (!in_w && had_w && zz[l] != zp[l]) n_miss += 1;
+          if (zp[l] != 0.0) {
+            sc = inf;
+          } else {
+            const double thr = lane_sa[l0 + l] * aa[l] + lane_sb[l0 + l] * bb[l];
+            sc = fmax(sc, thr > 0.0 ? fabs(gg[l]) / thr : inf);
+          }
         }
       }
       if (sc >= w.theta && !in_w) n_new += 1;
       w.score[it] = sc;
     }
   } else {
-    static_assert(SLM_MAX_LANES == 16, "one thread per (group, lane): 16-thread teams");
-    const int l = tid & 15;
+    static_assert(SLM_MAX_LANES % 16 == 0, "16-thread teams: a thread per (group, lane of a half)");
+    const int l16 = tid & 15;
     const bool have = it < nitems;  // (a team is all in or all out)
     double sc = 0.0;
     bool in_w = false;
@@ -299,7 +302,9 @@ static __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs
       k0 = a.gstart[it];
       k1 = a.gstart[it + 1];
       in_w = had_w && w.pos[a.order[k0]] >= 0;
-      if (l < a.n_lanes && lane_live[l]) {
+    }
+    for (int l = l16; have && l < a.n_lanes; l += 16) {  // (a call of thirty-two lanes: two lanes per thread)
+      if (lane_live[l]) {
         const int64_t off = (int64_t)l * a.ld;
         const double* g = a.g + (int64_t)l * (a.ld + 16);
         double num = 0.0, rmax = 0.0;
@@ -316,12 +321,12 @@ static __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs
         }
         const double den = lane_sb[l] * a.b0[off + it];
         const double r = den > 0.0 ? sqrt(num) / den : rmax;
-        sc = act ? inf : r;
+        sc = fmax(sc, act ? inf : r);
       }
     }
 #pragma unroll
     for (int o = 8; o >= 1; o >>= 1) sc = fmax(sc, __shfl_xor(sc, o, 64));
-    if (have && l == 0) {
+    if (have && l16 == 0) {
       if (sc >= w.theta && !in_w) n_new += k1 - k0;
       w.score[it] = sc;
     }

@@ -43,7 +43,7 @@ FLAG_COVARIANCE = 256  # passes from the Grams of the call's row sets (Dataset.c
 FLAG_NO_MODEL_GRAM = 512  # lanes beyond the working set's 512 columns take plain steps, no rounds on the model Gram (csrc/mg_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 15  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 16  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -188,7 +188,8 @@ class _Reweight(C.Structure):
     ]
 
 
-MAX_LANES = 16
+MAX_LANES = 16  # lanes of a call of independent problems (a half of the split pass: the sixteen columns of an MFMA operand)
+MAX_LANES_WIDE = 32  # SLM_MAX_LANES: lanes a shared path may run on -- two halves on one read of X (xtr32_mfma_kernel)
 MAX_CELLS = 64  # SLM_MAX_CELLS: lanes of a call the on-chip solver takes (Dataset.max_lanes tells which limit applies)
 
 # numpy views of the two per-point structs (no per-point Python objects on the way in or out)
@@ -896,7 +897,7 @@ class Dataset:
         """
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         K = pts.shape[0]
-        lanes = max(1, min(int(lanes), MAX_LANES, K))
+        lanes = max(1, min(int(lanes), MAX_LANES_WIDE, K))  # (the engine takes as many of them as the dataset's kernels serve)
         common = dict(a=a, b=b, d=d)
         kw = dict(tol=tol, max_iter=max_iter, check_every=check_every, L=L, flags=flags,
                   want_group_norms=want_group_norms, extrapolate=extrapolate)

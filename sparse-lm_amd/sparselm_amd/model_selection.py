@@ -605,6 +605,13 @@ class _DeviceGrid:
         largest = max(self.plan(world), key=lambda cs: sum(len(idx) for call in cs for lane in call for _, idx in lane))
         if self.covariance(ds, largest, world):
             self.opts["flags"] = self.opts.get("flags", 0) | _engine.FLAG_COVARIANCE
+            # covariance passes serve sixteen lanes a call (a search over X may have been planned on thirty-two: the two halves
+            # of the split pass on one read of X): the same decision on every rank, so every rank plans again alike
+            cap = ds.max_lanes(self.opts["flags"])
+            if self.lanes > cap:
+                self.lanes = cap
+                self._plan_world = None
+                calls = self.plan(world)[rank]
         run = self._run_adaptive if self.adaptive else self._run_call
         unconverged = self.search._run_batches(ds, calls, lambda d, call: run(d, call, local), self)
         return local, unconverged

@@ -422,7 +422,7 @@ def test_the_shares_of_an_eight_rank_search_reproduce_the_one_rank_table(monkeyp
     est = SparseGroupLasso(groups=groups, solver_options={"tol": 1e-11})
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        search = GridSearchCV(est, grid, cv=cv)
+        search = GridSearchCV(est, grid, cv=cv, lanes=16)  # (the plan checked below is the sixteen-lane one; thirty-two: next test)
         one = search._device_cells(X, y, rank=0, world=1)
         shares = [search._device_cells(X, y, rank=r, world=8) for r in range(8)]
         fitted = GridSearchCV(est, grid, cv=cv).fit(X, y)

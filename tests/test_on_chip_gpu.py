@@ -135,8 +135,11 @@ def test_fifty_cells_in_one_launch(eng):
         ref = ds.solve_lanes(specs[:3], tol=1e-11)
         for a, b in zip(one[:3], ref):
             np.testing.assert_allclose(a.betas, b.betas, rtol=0, atol=1e-8 * np.max(np.abs(b.betas)))
-        with pytest.raises(ValueError):
+        # (seventeen lanes fit the engine's count since round 5 -- two halves of the split pass -- but not this dataset's kernels)
+        with pytest.raises((ValueError, NotImplementedError)):
             ds.solve_lanes(specs[:17], tol=1e-11, flags=_engine.FLAG_ON_CHIP | _engine.FLAG_FISTA_ONLY)
+        with pytest.raises(ValueError):
+            ds.solve_lanes(specs[:33], tol=1e-11, flags=_engine.FLAG_ON_CHIP | _engine.FLAG_FISTA_ONLY)
         with pytest.raises(ValueError):
             ds.solve_lanes(specs + specs[:15], tol=1e-11, flags=_engine.FLAG_ON_CHIP)
     # a dataset the on-chip solver does not take keeps the sixteen
