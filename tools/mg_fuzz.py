@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the model-Gram rounds (csrc/mg_kernels.hpp), forced on at sizes the plain iteration finishes
-(SLM_MG=2): penalty kinds, group sizes, 9-16 lanes (shared paths and independent lanes with fold masks), designs that are
+(SLM_MG=2): penalty kinds, group sizes, 9-32 lanes (shared paths and independent lanes with fold masks), designs that are
 correlated / have duplicated columns / more columns than rows, dataset row weights, paths that end dense.  Every call is
 compared with the same call without the rounds (FLAG_NO_MODEL_GRAM) and with one plain lane: 1e-6 rel-inf, or -- where the
 minimiser is not unique -- the same objective.   usage: mg_fuzz.py [cases] [seed]"""
@@ -50,7 +50,7 @@ for case in range(n_cases):
     elif kind == "group": pts = [(0, al, 0) for al in alphas]
     elif kind == "sgl": pts = [(0.4 * al, 0.6 * al, 0) for al in alphas]
     else: pts = [(0, al, 0.3) for al in alphas]
-    lanes = int(rng.integers(9, 17))
+    lanes = int(rng.integers(9, 33))  # (above sixteen: two halves on one read of X)
     tol = 1e-10
     with eng.dataset(X, y, row_weight=w_ds) as ds:
         if groups is not None: ds.set_groups(groups, G)

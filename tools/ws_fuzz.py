@@ -33,7 +33,7 @@ for case in range(n_cases):
     elif kind == "group": pts = [(0, al, 0) for al in alphas]
     elif kind == "sgl": pts = [(0.4 * al, 0.6 * al, 0) for al in alphas]
     else: pts = [(0, al, 0.3) for al in alphas]
-    lanes = int(rng.integers(1, 17))
+    lanes = int(rng.integers(1, 33))
     tol = 1e-10
     with eng.dataset(X, y) as ds:
         if groups is not None: ds.set_groups(groups, G)
