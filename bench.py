@@ -3,8 +3,9 @@
 
 A "step" is one complete path solve on one GPU: seed Lipschitz estimate (power iteration, re-done
 every step) + 50 converged alpha points (tol 1e-8), with (X, y) already resident in HBM.  The path
-is walked by `--lanes` (default 16) lanes that share every pass over X; `--lanes 1` is the strictly
-sequential warm-started path.  Set-up, before the W warm-up steps: the dataset is generated on the device, fifty
+is walked by lanes that share every pass over X -- as many as the engine chooses (`--lanes 0`, the default: eighteen
+for fifty points, sixteen on the matrix cores and two on the vector units beside them, three passes instead of
+four), or `--lanes N`; `--lanes 1` is the strictly sequential warm-started path.  Set-up, before the W warm-up steps: the dataset is generated on the device, fifty
 gradient launches bring the clocks up, and three untimed paths pay the dataset's one-off costs (column-major copy
 of X, work-space allocations, first block of the page-locked result pool; reported under
 `config.one_off_costs_outside_value_ms`).
@@ -900,7 +901,8 @@ def main():
     ap.add_argument("--p", type=int, default=5_000)
     ap.add_argument("--alphas", type=int, default=50)
     ap.add_argument("--tol", type=float, default=1e-8)
-    ap.add_argument("--lanes", type=int, default=16, help="ranges of the path advancing together on one pass over X")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes of the path advancing together on one pass over X (0: the engine's choice, "
+                    "slm_solve_path_lanes with n_lanes = 0 -- eighteen for 50 points: three passes instead of four)")
     ap.add_argument("--no-ws", action="store_true", help="disable the working-set refinement (A/B runs)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip the config-4 grid and row-sharded legs")
@@ -1012,12 +1014,16 @@ def main():
         # algorithmic bytes of one launch: X once, y once, per lane z read and g written
         # p = 5000: the fused kernels stop at four lanes; the split pass of working-set solves has sixteen
         # (and plain solves of more than four lanes on large X: the same two matrix-core halves)
-        split = (not args.no_ws and res.ws_builds > 0) or (min(args.lanes, K) > 4 and n * p >= 2**26 and p <= 10240)
-        lanes_used = max(1, min(args.lanes, 16 if split else 4))
-        if split:  # xtr_mfma_kernel: X once, the row residuals of 16 lane slots, 16 gradient rows out
-            bytes_per_grad = 8.0 * (n * p + 16 * n + 16 * p)
+        lanes_run = ds.path_lanes(K, flags) if args.lanes == 0 else min(args.lanes, K)  # (0: what the engine chose)
+        split = (not args.no_ws and res.ws_builds > 0) or (lanes_run > 4 and n * p >= 2**26 and p <= 10240)
+        lanes_used = max(1, min(lanes_run, 32 if split else 4))
+        if split:  # X once, the row residuals of the lane slots in use (sixteen on the matrix cores, the others beside them), as many gradient rows out
+            slots = max(16, lanes_used) if lanes_used <= 20 else 32
+            bytes_per_grad = 8.0 * (n * p + slots * n + slots * p)
         else:
             bytes_per_grad = 8.0 * (n * p + 2 * n + 2 * p * lanes_used)
+        xtr_name = ("xtr_mfma_kernel" if lanes_used <= 16 else "xtr18_mfma_kernel" if lanes_used <= 18 else
+                    "xtr20_mfma_kernel" if lanes_used <= 20 else "xtr32_mfma_kernel")
         t_grad_ms = grad_ms / max(1, grad_timed)
         achieved = bytes_per_grad / (t_grad_ms * 1e-3) / 1e9 if t_grad_ms > 0 else 0.0
         # after the timed region, same dataset, same run: (i) the whole gradient unit of the split pass under the same HIP
@@ -1059,7 +1065,8 @@ def main():
                 "n": n,
                 "p": p,
                 "n_alphas": K,
-                "lanes": args.lanes,
+                "lanes": lanes_run,
+                "lanes_chosen_by": "engine (slm_solve_path_lanes, n_lanes = 0)" if args.lanes == 0 else "--lanes",
                 "tol": args.tol,
                 "law": "make_regression(n_informative=50, noise=10): X~N(0,1) generated on device",
                 "parallelism": f"grid x{world} (independent paths, no collective)",
@@ -1087,15 +1094,16 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(n, p, lanes_used, "xtr_mfma_kernel" if split else "grad_fused_kernel")[0],
+                "traffic": measured_traffic(n, p, lanes_used, xtr_name if split else "grad_fused_kernel")[0],
                 "traffic_unit": "HBM bytes per launch (PMC, profiles/roofline_traffic.json)",
-                "traffic_note": measured_traffic(n, p, lanes_used, "xtr_mfma_kernel" if split else "grad_fused_kernel")[1],
-                "kernel": (f"xtr_mfma_kernel (X^T R of the split pass on the matrix cores, lanes={lanes_used})" if split
+                "traffic_note": measured_traffic(n, p, lanes_used, xtr_name if split else "grad_fused_kernel")[1],
+                "kernel": (f"{xtr_name} (X^T R of the split pass: sixteen lanes on the matrix cores"
+                           f"{', the others on the vector units beside them' if 16 < lanes_used <= 20 else ''}; lanes={lanes_used})" if split
                            else f"grad_fused_kernel (lanes={lanes_used})"),
                 "avg_kernel_ms": t_grad_ms,
                 "gradient_unit_ms": unit_ms,
                 "gradient_unit_frac": (bytes_per_grad / (unit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if unit_ms else None,
-                "gradient_unit_what": "residuals of the sixteen lane slots (resid_mfma_kernel on the gathered columns) + xtr_mfma_kernel, "
+                "gradient_unit_what": "residuals of the lane slots (resid_mfma_kernel on the gathered columns) + the X^T R kernel, "
                 "one bracket of HIP events per pass (SLM_PROFILE_UNIT=1), charged the same algorithmic bytes: what a 16-lane gradient costs",
                 "read_stream_ceiling_gbs": ceiling_gbs,
                 "read_stream_ceiling_ms_per_sweep": ceiling_ms,

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 16
+#define SLM_ABI_VERSION 17
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -371,12 +371,17 @@ int slm_solve_lanes_reweighted(slm_dataset* ds, const slm_lane* lanes, const slm
 /* How many lanes one slm_solve_lanes call on this dataset can take with these solve flags (callers
  * size their batches of CV folds / grid rows with it instead of probing for SLM_ERR_UNSUPPORTED). */
 int slm_dataset_max_lanes(slm_dataset* ds, uint32_t flags, int32_t* max_lanes_out);
+/* The lane count slm_solve_path_lanes takes for a path of n_points when the caller passes n_lanes = 0 (ABI 17). */
+int slm_dataset_path_lanes(slm_dataset* ds, int32_t n_points, uint32_t flags, int32_t* lanes_out);
 
 /*
  * ONE warm-started path walked by n_lanes lanes that share each pass over X: the path is cut into
  * n_lanes contiguous ranges (the first warm-started from beta0, the others cold); a lane that runs
  * out of points takes over the upper half of what the busiest lane has left, so the lanes finish
  * together whatever the per-point cost profile is.  Same outputs as slm_solve_path.
+ * n_lanes = 0 leaves the count to the engine (ABI 17): sixteen, or -- per-feature penalties on a large X, where a path
+ * costs ceil(n_points / n_lanes) passes -- eighteen or twenty when that saves a pass (lanes 17..20 ride on the vector
+ * units beside the sixteen on the matrix cores, the same read of X: a 50-point path takes three passes instead of four).
  */
 int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,
                          int32_t n_points, int32_t n_lanes, const slm_solve_opts* opts,

@@ -42,9 +42,13 @@ struct CovBatch {
   double yy[SLM_MAX_LANES];         // ... and y^T W y / n
   int32_t set_of[SLM_MAX_LANES];    // row set of lane l
   int64_t part_stride;              // doubles between the partial sums of two row sets
+  int64_t half_stride;              // cov_gz_body<2> (the model-Gram rounds of a call of more than sixteen lanes): doubles between
+                                    // the two halves' blocks of partial sums
 };
 
-// (the loop is a function of its own: mg_gz_kernel, mg_kernels.hpp, runs it on the model Gram)
+// (the loop is a function of its own: mg_gz_kernel, mg_kernels.hpp, runs it on the model Gram -- with H = 2 for both halves of a
+//  call of more than sixteen lanes on one read of the Gram: the second half's points in a second plane of Z, a.r_plane doubles on)
+template <int H = 1>
 __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
   a.X = cb.G[blockIdx.z];
   a.partial += (int64_t)blockIdx.z * cb.part_stride;
@@ -68,11 +72,13 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
     const int col = col0 + 32 * c + 2 * i16;
     coff[c] = col < ld - 2 ? col : ld - 2;
   }
-  slm_d4 acc[8];
+  slm_d4 acc[H][8];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) acc[t] = slm_d4{0.0, 0.0, 0.0, 0.0};
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[h][t] = slm_d4{0.0, 0.0, 0.0, 0.0};
   bool listed = false;
-  if (a.ctl != nullptr && a.ws != nullptr && a.xrows_ws > 0) {
+  if (H == 1 && a.ctl != nullptr && a.ws != nullptr && a.xrows_ws > 0) {
     unsigned live, on_ws;
     split_masks(a, live, on_ws);
     listed = live != 0u && live == on_ws && (int64_t)a.xrows_ws * (int64_t)gridDim.y >= (int64_t)a.ws->K;
@@ -101,8 +107,8 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
       const double z = rows[t] >= 0 ? rv[t] : 0.0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t][c].x, z, acc[2 * c], 0, 0, 0);
-        acc[2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t][c].y, z, acc[2 * c + 1], 0, 0, 0);
+        acc[0][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t][c].x, z, acc[0][2 * c], 0, 0, 0);
+        acc[0][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t][c].y, z, acc[0][2 * c + 1], 0, 0, 0);
       }
     }
   } else {
@@ -112,25 +118,28 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
     const double* xp = a.X + (r0 + kq) * a.ld;
     const double* rp = a.R + (r0 + kq) * SPLIT_RSTRIDE + i16;
     d2 xa[XTR_U][4], xb[XTR_U][4];
-    double ra[XTR_U], rb[XTR_U];
-    auto load = [&](d2(&xv)[XTR_U][4], double(&rv)[XTR_U], int b) {
+    double ra[H][XTR_U], rb[H][XTR_U];
+    auto load = [&](d2(&xv)[XTR_U][4], double(&rv)[H][XTR_U], int b) {
       const double* xq = xp + (int64_t)b * (4 * XTR_U) * a.ld;
       const double* rq = rp + (int64_t)b * (4 * XTR_U) * SPLIT_RSTRIDE;
 #pragma unroll
       for (int u = 0; u < XTR_U; ++u) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) xv[u][c] = *reinterpret_cast<const d2*>(xq + (int64_t)u * 4 * a.ld + coff[c]);
-        rv[u] = rq[u * 4 * SPLIT_RSTRIDE];
+#pragma unroll
+        for (int h = 0; h < H; ++h) rv[h][u] = rq[(int64_t)h * a.r_plane + u * 4 * SPLIT_RSTRIDE];
       }
     };
-    auto compute = [&](d2(&xv)[XTR_U][4], double(&rv)[XTR_U]) {
+    auto compute = [&](d2(&xv)[XTR_U][4], double(&rv)[H][XTR_U]) {
 #pragma unroll
       for (int u = 0; u < XTR_U; ++u)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].x, rv[u], acc[2 * c], 0, 0, 0);
-          acc[2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].y, rv[u], acc[2 * c + 1], 0, 0, 0);
-        }
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            acc[h][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].x, rv[h][u], acc[h][2 * c], 0, 0, 0);
+            acc[h][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].y, rv[h][u], acc[h][2 * c + 1], 0, 0, 0);
+          }
     };
     if (nb > 0) {
       load(xa, ra, 0);
@@ -152,32 +161,40 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
     for (int64_t row = r0 + (int64_t)nb * (4 * XTR_U); row < r1; row += 4) {
       const bool ok = row + kq < r1;
       const int64_t rr = ok ? row + kq : r1 - 1;
-      const double rv = ok ? a.R[rr * SPLIT_RSTRIDE + i16] : 0.0;
+      double rv[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) rv[h] = ok ? a.R[(int64_t)h * a.r_plane + rr * SPLIT_RSTRIDE + i16] : 0.0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const d2 x = *reinterpret_cast<const d2*>(a.X + rr * a.ld + coff[c]);
-        acc[2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, rv, acc[2 * c], 0, 0, 0);
-        acc[2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, rv, acc[2 * c + 1], 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          acc[h][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, rv[h], acc[h][2 * c], 0, 0, 0);
+          acc[h][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, rv[h], acc[h][2 * c + 1], 0, 0, 0);
+        }
       }
     }
   }
   if (i16 < SPLIT_LANES) {  // tile 2c+e holds columns col0 + 32 c + 2 i + e
-    double* out = a.partial + ((int64_t)by * SPLIT_LANES + i16) * a.ld;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int h = 0; h < H; ++h) {
+      double* out = a.partial + (int64_t)h * cb.half_stride + ((int64_t)by * SPLIT_LANES + i16) * a.ld;
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = col0 + 32 * c + 2 * (kq + 4 * r) + e;
-          if (col < ld) out[col] = acc[2 * c + e][r];
-        }
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int col = col0 + 32 * c + 2 * (kq + 4 * r) + e;
+            if (col < ld) out[col] = acc[h][2 * c + e][r];
+          }
+    }
   }
 }
 
 static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void cov_gz_mfma_kernel(SplitArgs a, CovBatch cb) {
   if (a.done != nullptr && *a.done != 0) return;
-  cov_gz_body(a, cb);
+  cov_gz_body<1>(a, cb);
 }
 
 struct CovFinishArgs {

@@ -189,10 +189,13 @@ int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner
   hipLaunchKernelGGL(mg_begin_kernel, dim3((unsigned)n_lanes), dim3(TAIL_THREADS), 0, s, ta, m);
   const int E = (ta.p + TAIL_THREADS - 1) / TAIL_THREADS;
   for (int it = 0; it < inner_iters; ++it) {
-    for (int h = 0; h < halves; ++h) {  // (the product is sixteen lanes wide: a launch per half, its own plane of Z and block of sums)
-      a.R = ds->mg_Z + (size_t)h * (size_t)m.z_plane;
-      a.partial = partial + (size_t)h * (size_t)n_sets * (size_t)cb.part_stride;
-      hipLaunchKernelGGL(mg_gz_kernel, dim3(xb, yb, (unsigned)n_sets), dim3(XTR_WAVES * 64), 0, s, a, cb, (const MgCtl*)m.mg, h);
+    if (halves == 2) {  // both halves' planes of Z against ONE read of every Gram
+      a.R = ds->mg_Z; a.r_plane = m.z_plane; a.partial = partial;
+      cb.half_stride = (int64_t)n_sets * cb.part_stride;
+      hipLaunchKernelGGL(mg_gz32_kernel, dim3(xb, yb, (unsigned)n_sets), dim3(XTR_WAVES * 64), 0, s, a, cb, (const MgCtl*)m.mg);
+    } else {
+      a.R = ds->mg_Z; a.partial = partial;
+      hipLaunchKernelGGL(mg_gz_kernel, dim3(xb, yb, (unsigned)n_sets), dim3(XTR_WAVES * 64), 0, s, a, cb, (const MgCtl*)m.mg, 0);
     }
     hipLaunchKernelGGL(mg_gsum_kernel, dim3((unsigned)((ld + 255) / 256), (unsigned)n_lanes), dim3(256), 0, s, m, ld, done);
     switch (E) {

@@ -87,7 +87,17 @@ int launch_xtr(int cus, SplitArgs& a, hipStream_t s, bool sample) {
   const slm_host::XtrGrid g = slm_host::xtr_grid(a.n, a.ld, XTR_CB, (int64_t)(xtr_max_row_blocks(cus, a.ld) * per_cu / 2.0));
   const int xb = g.xb, yb = g.yb;
   a.xrows = g.rows;
-  if (wide) {
+  // seventeen to twenty lanes: the lanes beyond sixteen on the vector units beside the sixteen on the matrix cores
+  // (xtr18 / xtr20_mfma_kernel: the price of sixteen; SLM_XTR_EXTRAS=0: both halves on the matrix cores)
+  const char* ex_env = getenv("SLM_XTR_EXTRAS");
+  const int extra = wide && !(ex_env && ex_env[0] == '0') ? a.n_lanes - SPLIT_LANES : 0;
+  if (wide && extra >= 1 && extra <= 2) {
+    if (sample) hipLaunchKernelGGL(xtr18_sample_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+    else hipLaunchKernelGGL(xtr18_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+  } else if (wide && extra >= 3 && extra <= 4) {
+    if (sample) hipLaunchKernelGGL(xtr20_sample_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+    else hipLaunchKernelGGL(xtr20_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
+  } else if (wide) {
     if (sample) hipLaunchKernelGGL(xtr32_sample_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
     else hipLaunchKernelGGL(xtr32_mfma_kernel, dim3(xb, yb), dim3(XTR_WAVES * 64), 0, s, a);
   } else {
@@ -220,7 +230,10 @@ static void launch_rowdot(slm_dataset* ds, const SplitKernel* sk, int nblk, int 
   a.lane0 = 0;
   if ((!ring || sk->rowdot == nullptr) && ds->XT && ds->XT_ready) {
     a.XT = ds->XT;
-    hipLaunchKernelGGL(rowdot_mfma_kernel, dim3(nblk, halves), dim3(XZ_WAVES * 64), 0, s, a);  // (a half of sixteen lanes per read of the copy)
+    // (thirty-two lanes: both halves against ONE read of the copy -- rowdot32_mfma_kernel; SLM_ROWDOT32=0: a read per half)
+    const char* e32 = getenv("SLM_ROWDOT32");
+    if (halves == 2 && !(e32 && e32[0] == '0')) hipLaunchKernelGGL(rowdot32_mfma_kernel, dim3(nblk, 1), dim3(XZ_WAVES * 64), 0, s, a);
+    else hipLaunchKernelGGL(rowdot_mfma_kernel, dim3(nblk, halves), dim3(XZ_WAVES * 64), 0, s, a);
   } else if (sk->rowdot != nullptr) {
     hipLaunchKernelGGL(sk->rowdot, dim3(nblk, (B + ROWDOT_LANES - 1) / ROWDOT_LANES), dim3(sk->W * 64), 0, s, a);
   }
@@ -536,18 +549,28 @@ extern "C" int slm_gradient(slm_dataset* ds, const double* z, double* g_out, dou
   if (!ds) return fail(SLM_ERR_BAD_ARG, "dataset is NULL");
   HIP_TRY(hipSetDevice(ds->eng->device));
   hipStream_t s = ds->eng->stream;
-  const LaneSetup ls = default_lanes(ds, 1);
   HIP_TRY(hipMemsetAsync(ds->z, 0, sizeof(double) * ds->ld, s));
   if (z) HIP_TRY(hipMemcpyAsync(ds->z, z, sizeof(double) * ds->p, hipMemcpyHostToDevice, s));
   const char* split_env = getenv("SLM_GRAD_SPLIT");  // tests: take the split pass (residuals from X)
   const bool use_split = split_env && split_env[0] == '1' && split_usable(ds);
   if (use_split) SLM_TRY(ensure_xt(ds));  // (so that tests and probes reach rowdot_mfma_kernel; optional copy)
+  // (tests of the split pass's wider forms: SLM_GRAD_LANES lanes all at z, the gradient of lane SLM_GRAD_LANE returned --
+  //  a lane of the second half: xtr32_mfma_kernel's second plane, or the vector units' share of xtr18 / xtr20_mfma_kernel)
+  int lanes_run = 1, lane_out = 0;
+  if (use_split && ds->XT && ds->XT_ready && (size_t)ds->lane_cap >= (size_t)kMaxLanes) {
+    if (const char* e = getenv("SLM_GRAD_LANES")) lanes_run = std::min(kMaxLanes, std::max(1, atoi(e)));
+    if (const char* e = getenv("SLM_GRAD_LANE")) lane_out = std::min(lanes_run - 1, std::max(0, atoi(e)));
+  }
+  const LaneSetup ls = default_lanes(ds, lanes_run);
+  for (int l = 1; l < lanes_run; ++l)
+    HIP_TRY(hipMemcpyAsync(ds->z + (size_t)l * ds->ld, ds->z, sizeof(double) * ds->ld, hipMemcpyDeviceToDevice, s));
   if (use_split) SLM_TRY(enqueue_gradient_split(ds, ls, ds->y, nullptr, nullptr, nullptr, nullptr, nullptr));
   else SLM_TRY(enqueue_gradient(ds, ls, ds->y, nullptr, nullptr, nullptr));
   SLM_TRY(check_launch());
   HIP_TRY(hipStreamSynchronize(s));
-  if (g_out) HIP_TRY(hipMemcpy(g_out, ds->g, sizeof(double) * ds->p, hipMemcpyDeviceToHost));
-  if (loss_out) HIP_TRY(hipMemcpy(loss_out, ds->g + ds->ld, sizeof(double), hipMemcpyDeviceToHost));
+  const double* g_lane = ds->g + (size_t)lane_out * (size_t)(ds->ld + 16);
+  if (g_out) HIP_TRY(hipMemcpy(g_out, g_lane, sizeof(double) * ds->p, hipMemcpyDeviceToHost));
+  if (loss_out) HIP_TRY(hipMemcpy(loss_out, g_lane + ds->ld, sizeof(double), hipMemcpyDeviceToHost));
   if (ms_out) {
     *ms_out = 0.0;
     if (reps < 1) reps = 1;
@@ -2138,14 +2161,36 @@ extern "C" int slm_solve_lanes_reweighted(slm_dataset* ds, const slm_lane* lanes
   return solve_core(ds, lanes, n_lanes, opts, stats, false, rules, rounds_out);
 }
 
+// the engine's choice of lanes for a shared path (n_lanes = 0): the fewest passes over X at the price of sixteen lanes
+static int auto_lanes(slm_dataset* ds, int32_t n_points, uint32_t fl) {
+  const int cap = max_lanes_for(ds, fl);
+  const bool interleaved = ds->singleton && ws_policy(ds, fl) == 2 && (double)ds->n * (double)ds->ld >= 67108864.0 &&
+                           !small_ok(ds, fl) && !getenv("SLM_NO_INTERLEAVE");
+  int B = slm_host::auto_path_lanes(n_points, cap, interleaved);
+  if (const char* e = getenv("SLM_AUTO_LANES")) B = std::max(1, std::min<int>(std::min(atoi(e), cap), n_points));  // (A/B runs)
+  return B;
+}
+extern "C" int slm_dataset_path_lanes(slm_dataset* ds, int32_t n_points, uint32_t flags, int32_t* lanes_out) {
+  if (!ds || !lanes_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  if (n_points <= 0) return fail(SLM_ERR_BAD_ARG, "n_points must be positive");
+  *lanes_out = auto_lanes(ds, n_points, flags);
+  return SLM_OK;
+}
+
 extern "C" int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,
                                     int32_t n_points, int32_t n_lanes, const slm_solve_opts* opts,
                                     const double* beta0, double* betas_out, double* group_norms_out,
                                     slm_point_info* infos, slm_solve_stats* stats) {
   if (!ds || !points || !betas_out) return fail(SLM_ERR_BAD_ARG, "NULL argument");
   if (n_points <= 0) return fail(SLM_ERR_BAD_ARG, "n_points must be positive");
-  int B = std::max(1, std::min<int>(std::min<int>(n_lanes, kMaxLanes), n_points));
-  B = std::min(B, max_lanes_for(ds, opts ? opts->flags : 0u));  // no kernel variant for (p, B): fewer lanes
+  const uint32_t fl = opts ? opts->flags : 0u;
+  int B;
+  if (n_lanes == 0) {  // the engine's choice (host_logic.hpp)
+    B = auto_lanes(ds, n_points, fl);
+  } else {
+    B = std::max(1, std::min<int>(std::min<int>(n_lanes, kMaxLanes), n_points));
+    B = std::min(B, max_lanes_for(ds, fl));  // no kernel variant for (p, B): fewer lanes
+  }
   slm_lane lanes[SLM_MAX_LANES];
   memset(lanes, 0, sizeof(lanes));
   int64_t lo = 0;

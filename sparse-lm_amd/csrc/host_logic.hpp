@@ -152,6 +152,32 @@ inline int64_t interleaved_points(const LaneWalk& w) {
 // multiple of 8 rows, about `want` of them.
 // ---------------------------------------------------------------------------------------------
 struct XtrGrid { int xb, yb, rows; };
+// ---------------------------------------------------------------------------------------------
+// Lanes of a shared path when the caller leaves the choice to the engine (slm_solve_path_lanes, n_lanes = 0).  A path on
+// interleaved lanes verifies one point per lane and pass, so its passes over X are ceil(points / lanes).  Sixteen lanes
+// are the width of the matrix cores' operand; seventeen to twenty cost the same read of X (the extra lanes run on the
+// vector units beside them: xtr18 / xtr20_mfma_kernel) -- 50 points: four passes on sixteen lanes, three on eighteen.
+// Beyond twenty a pass is dearer (both halves on the matrix cores) and the lanes look further down the path than the
+// first working set can know: measured worse on the headline shape (HISTORY round 5), so the choice stops at twenty.
+// `cap`: what the dataset's kernels serve (slm_dataset_max_lanes); `interleaved`: per-feature penalties on a
+// working-set solve over a large X (solve_core) -- other paths keep to sixteen, in contiguous ranges.
+// ---------------------------------------------------------------------------------------------
+inline int auto_path_lanes(int64_t n_points, int cap, bool interleaved) {
+  if (n_points < 1) n_points = 1;
+  int best = (int)std::min<int64_t>(std::min(cap, 16), n_points);
+  if (!interleaved || cap < 20 || n_points <= 16) return best;
+  int64_t best_passes = (n_points + 15) / 16;
+  for (int64_t lanes : {18, 20}) {
+    lanes = std::min(lanes, n_points);
+    const int64_t passes = (n_points + lanes - 1) / lanes;
+    if (passes < best_passes) {
+      best_passes = passes;
+      best = (int)lanes;
+    }
+  }
+  return best;
+}
+
 inline int xtr_row_blocks_most(int cus, int64_t ld, int col_block) {
   const int xb = (int)((ld + col_block - 1) / col_block);
   return std::max(1, 2 * cus / xb);

@@ -434,7 +434,14 @@ __device__ __forceinline__ bool mg_any_active(const MgCtl* mg, int half) {
 static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void mg_gz_kernel(SplitArgs a, CovBatch cb, const MgCtl* mg, int half) {
   if (a.done != nullptr && *a.done != 0) return;
   if (!mg_any_active(mg, half)) return;
-  cov_gz_body(a, cb);
+  cov_gz_body<1>(a, cb);
+}
+// both halves of a call of more than sixteen lanes on ONE read of the Gram (a.R: plane 0 of Z, a.r_plane on: plane 1)
+static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void mg_gz32_kernel(SplitArgs a, CovBatch cb, const MgCtl* mg) {
+  if (a.done != nullptr && *a.done != 0) return;
+  const bool on0 = mg_any_active(mg, 0), on1 = mg_any_active(mg, 1);
+  if (!on0 && !on1) return;
+  cov_gz_body<2>(a, cb);
 }
 
 // The product's partial sums folded over the row blocks, in block order: gd[l][j] = sum_b partial[b][l][j].  A kernel of

@@ -355,10 +355,18 @@ constexpr int XTR_CW = 128;                    // columns per wavefront
 constexpr int XTR_CB = XTR_WAVES * XTR_CW;     // columns per workgroup
 constexpr int XTR_U = 2;                       // 4-row steps per batch
 
-template <int H>
+// E > 0 (with H = 1): a call of 16 + E lanes, E <= 4 -- the sixteen lanes of plane 0 on the matrix cores as ever, the first E
+// slots of plane 1 on the VECTOR units against the same loads of X: ex[e][c] += x * R1[row][e], a thread's own rows (row
+// kq of every group of four) and its own eight columns, the four row classes summed by two shuffles at the end.  16 E / 2
+// v_fma_f64 per 4-row step beside its 8 MFMAs (fp64 vector and matrix rates are the same on this chip: a sixteenth of the
+// matrix work per extra lane), against a whole second set of MFMAs in xtr32_mfma_kernel: eighteen lanes at the price of
+// sixteen, which takes a 50-point path from four passes over X to three.
+template <int H, int E = 0>
 __device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
   static_assert(SPLIT_RSTRIDE == 16 && SPLIT_LANES <= 16, "a row of a plane of R is the 16-wide B operand");
   static_assert(H == 1 || H == 2, "one or two planes of R");
+  static_assert(E == 0 || (H == 1 && (E == 2 || E == 4)), "extras: pairs of slots of plane 1 beside the sixteen of plane 0");
+  constexpr int E2 = E > 0 ? E / 2 : 1;  // pairs of extra slots (16-byte loads of plane 1's rows)
   if (a.done != nullptr && *a.done != 0) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -396,7 +404,14 @@ __device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
   const double* rp = a.R + (r0 + kq) * SPLIT_RSTRIDE + i16;
   d2 xa[XTR_U][4], xb[XTR_U][4];
   double ra[H][XTR_U], rb[H][XTR_U];
-  auto load = [&](d2(&xv)[XTR_U][4], double(&rv)[H][XTR_U], int b) {
+  d2 ea[E2][XTR_U], eb[E2][XTR_U];  // (E > 0) plane 1's first E slots of this thread's rows
+  d2 ex[2 * E2][4];                 // (E > 0) extra lane e, column pair c: sums over this thread's rows
+#pragma unroll
+  for (int e = 0; e < 2 * E2; ++e)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ex[e][c] = d2{0.0, 0.0};
+  const double* rp1 = a.R + a.r_plane + (r0 + kq) * SPLIT_RSTRIDE;
+  auto load = [&](d2(&xv)[XTR_U][4], double(&rv)[H][XTR_U], d2(&ev)[E2][XTR_U], int b) {
     const double* xq = xp + (int64_t)b * (4 * XTR_U) * a.ld;
     const double* rq = rp + (int64_t)b * (4 * XTR_U) * SPLIT_RSTRIDE;
 #pragma unroll
@@ -408,11 +423,27 @@ __device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
       }
 #pragma unroll
       for (int h = 0; h < H; ++h) rv[h][u] = rq[(int64_t)h * a.r_plane + u * 4 * SPLIT_RSTRIDE];
+      if constexpr (E > 0) {
+        const d2* eq = reinterpret_cast<const d2*>(rp1 + ((int64_t)b * (4 * XTR_U) + u * 4) * SPLIT_RSTRIDE);
+#pragma unroll
+        for (int q = 0; q < E2; ++q) ev[q][u] = eq[q];
+      }
     }
   };
-  auto compute = [&](d2(&xv)[XTR_U][4], double(&rv)[H][XTR_U]) {
+  auto extras = [&](const d2(&x)[4], const d2(&ev)[E2]) {  // (the vector units' share of a 4-row step)
 #pragma unroll
-    for (int u = 0; u < XTR_U; ++u)
+    for (int q = 0; q < E2; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        ex[2 * q][c].x = __builtin_fma(x[c].x, ev[q].x, ex[2 * q][c].x);
+        ex[2 * q][c].y = __builtin_fma(x[c].y, ev[q].x, ex[2 * q][c].y);
+        ex[2 * q + 1][c].x = __builtin_fma(x[c].x, ev[q].y, ex[2 * q + 1][c].x);
+        ex[2 * q + 1][c].y = __builtin_fma(x[c].y, ev[q].y, ex[2 * q + 1][c].y);
+      }
+  };
+  auto compute = [&](d2(&xv)[XTR_U][4], double(&rv)[H][XTR_U], d2(&ev)[E2][XTR_U]) {
+#pragma unroll
+    for (int u = 0; u < XTR_U; ++u) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -420,6 +451,13 @@ __device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
           acc[h][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].x, rv[h][u], acc[h][2 * c], 0, 0, 0);
           acc[h][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].y, rv[h][u], acc[h][2 * c + 1], 0, 0, 0);
         }
+      if constexpr (E > 0) {
+        d2 eu[E2];
+#pragma unroll
+        for (int q = 0; q < E2; ++q) eu[q] = ev[q][u];
+        extras(xv[u], eu);
+      }
+    }
   };
   // (straight-line steady state, the odd batch peeled off: with `if (b + 1 < nb) load(...)` in the loop the compiler
   //  had to wait at the first product of a batch as if the batch behind it had not been asked for -- vmcnt(1) with
@@ -427,20 +465,20 @@ __device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
   //  profiles/r03a_xtr_peel_ab.txt: the kernel waits for the memory system, not for its own waits -- but they are what
   //  took rowdot_mfma_kernel, which has the same loop, from 0.69 to 0.60 ms)
   if (nb > 0) {
-    load(xa, ra, 0);
+    load(xa, ra, ea, 0);
     const int pairs = (nb - 1) >> 1;
     for (int k = 0; k < pairs; ++k) {
-      load(xb, rb, 2 * k + 1);
-      compute(xa, ra);
-      load(xa, ra, 2 * k + 2);
-      compute(xb, rb);
+      load(xb, rb, eb, 2 * k + 1);
+      compute(xa, ra, ea);
+      load(xa, ra, ea, 2 * k + 2);
+      compute(xb, rb, eb);
     }
     if ((nb - 1) & 1) {
-      load(xb, rb, nb - 1);
-      compute(xa, ra);
-      compute(xb, rb);
+      load(xb, rb, eb, nb - 1);
+      compute(xa, ra, ea);
+      compute(xb, rb, eb);
     } else {
-      compute(xa, ra);
+      compute(xa, ra, ea);
     }
   }
   // the last rows of the block (fewer than 8): 4-row steps, rows past the end contribute R = 0
@@ -450,20 +488,47 @@ __device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
     double rv[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) rv[h] = ok ? a.R[(int64_t)h * a.r_plane + rr * SPLIT_RSTRIDE + i16] : 0.0;
+    d2 x[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const d2 x = *reinterpret_cast<const d2*>(a.X + rr * a.ld + coff[c]);
+      x[c] = *reinterpret_cast<const d2*>(a.X + rr * a.ld + coff[c]);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        acc[h][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, rv[h], acc[h][2 * c], 0, 0, 0);
-        acc[h][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, rv[h], acc[h][2 * c + 1], 0, 0, 0);
+        acc[h][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[c].x, rv[h], acc[h][2 * c], 0, 0, 0);
+        acc[h][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[c].y, rv[h], acc[h][2 * c + 1], 0, 0, 0);
+      }
+    }
+    if constexpr (E > 0) {
+      d2 eu[E2];
+#pragma unroll
+      for (int q = 0; q < E2; ++q)
+        eu[q] = ok ? reinterpret_cast<const d2*>(a.R + a.r_plane + rr * SPLIT_RSTRIDE)[q] : d2{0.0, 0.0};
+      extras(x, eu);
+    }
+  }
+  constexpr int SLOTS = E > 0 ? 2 * SPLIT_LANES : SPLIT_LANES * H;  // lane slots of a row block of `partial`
+  if constexpr (E > 0) {
+    // the four row classes of a column pair sit in lanes i16, i16 + 16, i16 + 32, i16 + 48: summed in that fixed order
+    // (the same bits run to run); row class 0 stores
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      double* out = a.partial + ((int64_t)by * SLOTS + SPLIT_LANES + e) * a.ld;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        d2 v = ex[e][c];
+        v.x += __shfl_xor(v.x, 16, 64);
+        v.y += __shfl_xor(v.y, 16, 64);
+        v.x += __shfl_xor(v.x, 32, 64);
+        v.y += __shfl_xor(v.y, 32, 64);
+        const int col = col0 + 32 * c + 2 * i16;
+        if (kq == 0 && col < ld) *reinterpret_cast<d2*>(out + col) = v;
       }
     }
   }
   if (i16 < SPLIT_LANES) {  // tile 2c+e holds columns col0 + 32 c + 2 i + e
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      double* out = a.partial + ((int64_t)by * (SPLIT_LANES * H) + SPLIT_LANES * h + i16) * a.ld;
+      double* out = a.partial + ((int64_t)by * SLOTS + SPLIT_LANES * h + i16) * a.ld;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -484,6 +549,12 @@ static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void xtr32_mfma_kernel(Sp
 // per-kernel statistics of xtr_mfma_kernel are those of passes over all of X
 static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void xtr_sample_kernel(SplitArgs a) { xtr_mfma_body<1>(a); }
 static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void xtr32_sample_kernel(SplitArgs a) { xtr_mfma_body<2>(a); }
+// seventeen to twenty lanes: sixteen on the matrix cores, the others on the vector units (above); one workgroup per CU is
+// the launch's geometry anyway, so the extra sums may take the registers of a second one (256 did not hold them: scratch)
+static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void xtr18_mfma_kernel(SplitArgs a) { xtr_mfma_body<1, 2>(a); }
+static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void xtr20_mfma_kernel(SplitArgs a) { xtr_mfma_body<1, 4>(a); }
+static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void xtr18_sample_kernel(SplitArgs a) { xtr_mfma_body<1, 2>(a); }
+static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void xtr20_sample_kernel(SplitArgs a) { xtr_mfma_body<1, 4>(a); }
 
 // ---------------------------------------------------------------------------------------------
 // The first half on the matrix cores as well: R[row][l] = w_l,row (x_row . z_l - y_row) for ALL sixteen lane
@@ -508,15 +579,19 @@ constexpr int XZ_T = 4;
 // four z values of the first group.  The partial products go to part[t][e][r][lane] (`mine` points at this lane).
 // Straight-line steady state -- two batches of a group each, the second in flight while the first is multiplied -- with
 // the odd batch peeled off, so that every wait is an exact count.
-template <int NT>
-__device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const double* zp, int g_n, double* mine) {
-  slm_d4 acc[NT][2];
+// H: halves of the lanes served by ONE read of the copy (a second A operand -- the second half's z -- against the same loads)
+template <int NT, int H>
+__device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const double* const (&zp)[H], int g_n, double* mine) {
+  slm_d4 acc[H][NT][2];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t][0] = acc[t][1] = slm_d4{0.0, 0.0, 0.0, 0.0};
-  slm_d4 za, zb;
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[h][t][0] = acc[h][t][1] = slm_d4{0.0, 0.0, 0.0, 0.0};
+  slm_d4 za[H], zb[H];
   d2 xa[4][NT], xb[4][NT];
-  auto load = [&](slm_d4& zv, d2(&xv)[4][NT], int g) {
-    zv = *reinterpret_cast<const slm_d4*>(zp + 16 * g);
+  auto load = [&](slm_d4(&zv)[H], d2(&xv)[4][NT], int g) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) zv[h] = *reinterpret_cast<const slm_d4*>(zp[h] + 16 * g);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -525,14 +600,16 @@ __device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const
         xv[m][t] = SLM_NT_LOADS ? __builtin_nontemporal_load(src) : *src;
       }
   };
-  auto compute = [&](const slm_d4& zv, d2(&xv)[4][NT]) {
+  auto compute = [&](const slm_d4(&zv)[H], d2(&xv)[4][NT]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[m], xv[m][t].x, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[m], xv[m][t].y, acc[t][1], 0, 0, 0);
-      }
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          acc[h][t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[h][m], xv[m][t].x, acc[h][t][0], 0, 0, 0);
+          acc[h][t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[h][m], xv[m][t].y, acc[h][t][1], 0, 0, 0);
+        }
   };
   if (g_n > 0) {
     load(za, xa, 0);
@@ -552,24 +629,35 @@ __device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const
     }
   }
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int h = 0; h < H; ++h)
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mine[((t * 2 + e) * 4 + r) * 64] = acc[t][e][r];
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[(((h * XZ_T + t) * 2 + e) * 4 + r) * 64] = acc[h][t][e][r];
 }
 
 
-static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a) {
+// H = 1: the sixteen lanes of half blockIdx.y (a launch per half: grid.y).  H = 2: BOTH halves on one read of the copy
+// (grid.y = 1; a call of more than sixteen lanes whose second half needs residuals from X -- dense points of the model-Gram
+// rounds -- used to read the 4 GB twice).
+template <int H>
+__device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 rows of the MFMA A operand");
   if (a.done != nullptr && *a.done != 0) return;
-  const int half = (int)blockIdx.y, L0 = SPLIT_LANES * half;  // (grid.y: the halves of the call; lane slot l here is lane L0 + l)
-  const unsigned mask = split_x_mask(a, half);
-  if (mask == 0u) return;
-  a.R += (int64_t)half * a.r_plane;
+  const int half0 = H == 1 ? (int)blockIdx.y : 0;  // first half served here
+  unsigned mask[H];
+  bool any = false;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    mask[h] = split_x_mask(a, half0 + h);
+    any = any || mask[h] != 0u;
+  }
+  if (!any) return;
   const int LS = split_slots(a);
-  __shared__ double red[XZ_WAVES][SPLIT_LANES];
-  __shared__ double part[XZ_WAVES * XZ_T * 2 * 4 * 64];  // 64 KiB: the wavefronts' partial products of one step
+  __shared__ double red[XZ_WAVES][H * SPLIT_LANES];
+  __shared__ double part[H * XZ_WAVES * XZ_T * 2 * 4 * 64];  // 64 KiB per half: the wavefronts' partial products of one step
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t b = blockIdx.x;
@@ -578,46 +666,55 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(Split
 
   bool all_zero = a.ctl != nullptr;  // cold start: e = -y without reading X (as rowdot_ring_kernel)
   if (all_zero) {  // (lane l of every wavefront reads control block l: one round trip, not one per lane slot)
-    const bool in = lane < SPLIT_LANES && L0 + lane < a.n_lanes;
-    const bool moved = in && ((mask >> lane) & 1u) && !a.ctl[in ? L0 + lane : 0].zzero;
-    all_zero = __ballot(moved) == 0ull;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int L0 = SPLIT_LANES * (half0 + h);
+      const bool in = lane < SPLIT_LANES && L0 + lane < a.n_lanes;
+      const bool moved = in && ((mask[h] >> lane) & 1u) && !a.ctl[in ? L0 + lane : 0].zzero;
+      all_zero = all_zero && __ballot(moved) == 0ull;
+    }
   }
   if (all_zero) {
     // thread = (row of a group of XZ_WAVES * 4, lane slot): a wavefront stores four whole rows of R, 512 contiguous
     // bytes (one thread per row wrote its sixteen slots one by one, sixty-four lines per store instruction: 18 us
     // for the 12.8 MB of the headline problem's first pass)
     const int l = tid & 15;
-    const bool on = ((mask >> l) & 1u) != 0u;
-    double ls = 0.0;
     const bool has_rw = a.rw != nullptr;
-    const double* rwp = has_rw ? a.rw + (int64_t)(L0 + l) * a.rw_stride : a.y;  // (no row weights: any readable address)
-    for (int64_t i0 = tid >> 4; i0 < nrows; i0 += 8 * XZ_WAVES * 4) {  // eight rows per round: their loads go out together
-      double yv[8], mv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t i = i0 + u * (XZ_WAVES * 4);
-        const int64_t row = r0 + (i < nrows ? i : 0);
-        yv[u] = a.y[row];
-        mv[u] = rwp[row];
-      }
+    for (int h = 0; h < H; ++h) {
+      const int L0 = SPLIT_LANES * (half0 + h);
+      double* Rh = a.R + (int64_t)(half0 + h) * a.r_plane;
+      const bool on = ((mask[h] >> l) & 1u) != 0u;
+      double ls = 0.0;
+      const double* rwp = has_rw ? a.rw + (int64_t)(L0 + l) * a.rw_stride : a.y;  // (no row weights: any readable address)
+      for (int64_t i0 = tid >> 4; i0 < nrows; i0 += 8 * XZ_WAVES * 4) {  // eight rows per round: their loads go out together
+        double yv[8], mv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t i = i0 + u * (XZ_WAVES * 4);
-        if (on && i < nrows) {
-          const double e = -yv[u], m = has_rw ? mv[u] : 1.0;
-          a.R[(r0 + i) * SPLIT_RSTRIDE + l] = e * m;
-          ls = __builtin_fma(e * m, e, ls);
+        for (int u = 0; u < 8; ++u) {
+          const int64_t i = i0 + u * (XZ_WAVES * 4);
+          const int64_t row = r0 + (i < nrows ? i : 0);
+          yv[u] = a.y[row];
+          mv[u] = rwp[row];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t i = i0 + u * (XZ_WAVES * 4);
+          if (on && i < nrows) {
+            const double e = -yv[u], m = has_rw ? mv[u] : 1.0;
+            Rh[(r0 + i) * SPLIT_RSTRIDE + l] = e * m;
+            ls = __builtin_fma(e * m, e, ls);
+          }
         }
       }
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      if (lane < SPLIT_LANES) red[wave][h * SPLIT_LANES + lane] = ls;
     }
-    ls += __shfl_xor(ls, 16, 64);
-    ls += __shfl_xor(ls, 32, 64);
-    if (lane < SPLIT_LANES) red[wave][lane] = ls;
     __syncthreads();
-    if (tid < SPLIT_LANES && ((mask >> tid) & 1u)) {
+    if (tid < H * SPLIT_LANES && ((mask[tid / SPLIT_LANES] >> (tid % SPLIT_LANES)) & 1u)) {
       double t = 0.0;
       for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2][tid];
-      a.loss_partial[b * LS + L0 + tid] = t;
+      a.loss_partial[b * LS + SPLIT_LANES * half0 + tid] = t;
     }
     return;
   }
@@ -643,8 +740,17 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(Split
   const int gb = ngroups / XZ_WAVES, gr = ngroups % XZ_WAVES;
   const int g_lo = wave * gb + (wave < gr ? wave : gr);
   const int g_n = gb + (wave < gr ? 1 : 0);
-  const double* zp = a.z + (int64_t)(L0 + j < a.n_lanes ? L0 + j : a.n_lanes - 1) * a.ld + 4 * q + 16 * (int64_t)g_lo;
-  double loss[4] = {0.0, 0.0, 0.0, 0.0};  // of lane slots q, q + 4, q + 8, q + 12 over this lane's rows
+  const double* zp[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const int L = SPLIT_LANES * (half0 + h) + j;
+    zp[h] = a.z + (int64_t)(L < a.n_lanes ? L : a.n_lanes - 1) * a.ld + 4 * q + 16 * (int64_t)g_lo;
+  }
+  double loss[H][4];  // of lane slots q, q + 4, q + 8, q + 12 over this lane's rows
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) loss[h][r] = 0.0;
   int t_at = 0;
   for (int st = 0; st < nsteps; ++st) {
     const int nt = __builtin_amdgcn_readfirstlane(T / nsteps + (st < T % nsteps ? 1 : 0));
@@ -653,12 +759,12 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(Split
     //  could not count the loads in flight and put s_waitcnt vmcnt(0) before every pair of MFMAs -- the batch just
     //  asked for included: no overlap of loads and products at all)
     const double* xt0 = a.XT + (((t_lo + t_at) * a.ld + 4 * q + 16 * (int64_t)g_lo) << 5) + 2 * j;
-    double* mine = part + (size_t)wave * XZ_T * 2 * 4 * 64 + lane;
+    double* mine = part + (size_t)wave * (H * XZ_T * 2 * 4 * 64) + lane;
     switch (nt) {
-      case 1: rowdot_step<1>(xt0, a.ld, zp, g_n, mine); break;
-      case 2: rowdot_step<2>(xt0, a.ld, zp, g_n, mine); break;
-      case 3: rowdot_step<3>(xt0, a.ld, zp, g_n, mine); break;
-      default: rowdot_step<4>(xt0, a.ld, zp, g_n, mine); break;
+      case 1: rowdot_step<1, H>(xt0, a.ld, zp, g_n, mine); break;
+      case 2: rowdot_step<2, H>(xt0, a.ld, zp, g_n, mine); break;
+      case 3: rowdot_step<3, H>(xt0, a.ld, zp, g_n, mine); break;
+      default: rowdot_step<4, H>(xt0, a.ld, zp, g_n, mine); break;
     }
     __syncthreads();
     if (wave < nt) {  // wavefront t finishes tile t: result register r of lane l is lane slot (l >> 4) + 4 r, row 2 (l & 15) + e
@@ -669,17 +775,22 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(Split
         const bool in = row < a.n;
         const double yi = a.y[in ? row : 0];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int l = q + 4 * r;
-          double v = 0.0;
+        for (int h = 0; h < H; ++h) {
+          const int L0 = SPLIT_LANES * (half0 + h);
+          double* Rh = a.R + (int64_t)(half0 + h) * a.r_plane;
 #pragma unroll
-          for (int w2 = 0; w2 < XZ_WAVES; ++w2) v += part[(((w2 * XZ_T + t) * 2 + e) * 4 + r) * 64 + lane];
-          if (in && ((mask >> l) & 1u)) {
-            const double m = a.rw ? a.rw[(int64_t)(L0 + l) * a.rw_stride + row] : 1.0;
-            const double err = v - yi;
-            const double res = err * m;
-            a.R[row * SPLIT_RSTRIDE + l] = res;
-            loss[r] = __builtin_fma(res, err, loss[r]);
+          for (int r = 0; r < 4; ++r) {
+            const int l = q + 4 * r;
+            double v = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < XZ_WAVES; ++w2) v += part[(size_t)w2 * (H * XZ_T * 2 * 4 * 64) + (((h * XZ_T + t) * 2 + e) * 4 + r) * 64 + lane];
+            if (in && ((mask[h] >> l) & 1u)) {
+              const double m = a.rw ? a.rw[(int64_t)(L0 + l) * a.rw_stride + row] : 1.0;
+              const double err = v - yi;
+              const double res = err * m;
+              Rh[row * SPLIT_RSTRIDE + l] = res;
+              loss[h][r] = __builtin_fma(res, err, loss[h][r]);
+            }
           }
         }
       }
@@ -688,19 +799,24 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(Split
     t_at += nt;
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    double t = loss[r];
+  for (int h = 0; h < H; ++h)
 #pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-    if (j == 0) red[wave][q + 4 * r] = t;
-  }
+    for (int r = 0; r < 4; ++r) {
+      double t = loss[h][r];
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+      if (j == 0) red[wave][h * SPLIT_LANES + q + 4 * r] = t;
+    }
   __syncthreads();
-  if (tid < SPLIT_LANES && ((mask >> tid) & 1u)) {
+  if (tid < H * SPLIT_LANES && ((mask[tid / SPLIT_LANES] >> (tid % SPLIT_LANES)) & 1u)) {
     double t = 0.0;
     for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2][tid];
-    a.loss_partial[b * LS + L0 + tid] = t;
+    a.loss_partial[b * LS + SPLIT_LANES * half0 + tid] = t;
   }
 }
+
+static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a) { rowdot_mfma_body<1>(a); }
+static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot32_mfma_kernel(SplitArgs a) { rowdot_mfma_body<2>(a); }
 
 // ---------------------------------------------------------------------------------------------
 // The residuals from the gathered columns on the matrix cores: R[row][l] = w_l,row (XW_row . zW_l - y_row)

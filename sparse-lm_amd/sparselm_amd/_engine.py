@@ -43,7 +43,7 @@ FLAG_COVARIANCE = 256  # passes from the Grams of the call's row sets (Dataset.c
 FLAG_NO_MODEL_GRAM = 512  # lanes beyond the working set's 512 columns take plain steps, no rounds on the model Gram (csrc/mg_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 16  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 17  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -70,6 +70,7 @@ ABI_SYMBOLS = (
     "slm_dataset_set_groups",
     "slm_dataset_lipschitz",
     "slm_dataset_max_lanes",
+    "slm_dataset_path_lanes",
     "slm_gradient",
     "slm_eval_sse",
     "slm_eval_sse_sparse",
@@ -269,6 +270,7 @@ def load_library():
             "slm_dataset_set_groups": [vp, vp, i32],
             "slm_dataset_lipschitz": [vp, P(dbl)],
             "slm_dataset_max_lanes": [vp, C.c_uint32, P(i32)],
+            "slm_dataset_path_lanes": [vp, i32, C.c_uint32, P(i32)],
             "slm_gradient": [vp, vp, vp, P(dbl), i32, P(dbl)],
             "slm_eval_sse": [vp, vp, i32, vp, vp],
             "slm_eval_sse_sparse": [vp, vp, i32, vp, i32, vp, vp],
@@ -722,6 +724,12 @@ class Dataset:
         _check(self._lib.slm_dataset_max_lanes(self._h, int(flags), C.byref(out)))
         return int(out.value)
 
+    def path_lanes(self, n_points: int, flags: int = 0) -> int:
+        """The lane count ``solve_path(..., lanes=0)`` runs a path of ``n_points`` on (``slm_dataset_path_lanes``)."""
+        out = C.c_int32()
+        _check(self._lib.slm_dataset_path_lanes(self._h, int(n_points), int(flags), C.byref(out)))
+        return int(out.value)
+
     def lipschitz(self) -> float:
         L = C.c_double()
         _check(self._lib.slm_dataset_lipschitz(self._h, C.byref(L)))
@@ -894,10 +902,12 @@ class Dataset:
         (an alpha path), start point k from the secant prediction through the two previous solutions.
         ``lanes`` > 1 cuts the path into that many contiguous sub-paths that advance together, one
         pass over X serving all of them (the first point of every later sub-path starts cold).
+        ``lanes=0``: the engine's choice (``slm_solve_path_lanes`` with ``n_lanes = 0``: sixteen, or eighteen / twenty
+        where that saves a pass over a large X).
         """
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         K = pts.shape[0]
-        lanes = max(1, min(int(lanes), MAX_LANES_WIDE, K))  # (the engine takes as many of them as the dataset's kernels serve)
+        lanes = 0 if int(lanes) == 0 and K > 1 else max(1, min(int(lanes), MAX_LANES_WIDE, K))  # (the engine takes as many as the dataset's kernels serve)
         common = dict(a=a, b=b, d=d)
         kw = dict(tol=tol, max_iter=max_iter, check_every=check_every, L=L, flags=flags,
                   want_group_norms=want_group_norms, extrapolate=extrapolate)

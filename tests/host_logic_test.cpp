@@ -119,7 +119,7 @@ static void test_row_sets() {
 }
 
 static void test_interleaved() {
-  for (int B = 1; B <= 16; ++B)
+  for (int B = 1; B <= 32; ++B)  // (a shared path runs on up to thirty-two lanes)
     for (int64_t total = B; total <= 200; ++total)
       for (int tail = 0; tail < 2; ++tail) {
         std::vector<int> seen((size_t)total, 0);
@@ -144,6 +144,21 @@ static void test_interleaved() {
       }
   const LaneWalk w = interleaved_walk(15, 16, 50, true);  // the headline: 48 regular points, 48 and 49 go to lanes 14, 15
   CHECK(w.n_points == 48 && w.tail_pt == 49 && interleaved_walk(14, 16, 50, true).tail_pt == 48 && interleaved_walk(13, 16, 50, true).tail_pt == -1);
+}
+
+static void test_auto_lanes() {
+  // sixteen unless eighteen or twenty lanes save a pass of an interleaved path; never more than the kernels serve
+  CHECK(auto_path_lanes(50, 32, true) == 18 && auto_path_lanes(50, 32, false) == 16 && auto_path_lanes(50, 16, true) == 16);
+  CHECK(auto_path_lanes(100, 32, true) == 20 && auto_path_lanes(32, 32, true) == 16 && auto_path_lanes(36, 32, true) == 18);
+  CHECK(auto_path_lanes(40, 32, true) == 20 && auto_path_lanes(41, 32, true) == 16 && auto_path_lanes(7, 32, true) == 7);
+  CHECK(auto_path_lanes(1, 4, false) == 1 && auto_path_lanes(9, 4, false) == 4 && auto_path_lanes(0, 32, true) == 1);
+  for (int64_t k = 1; k <= 400; ++k)
+    for (int cap : {1, 4, 6, 16, 32})
+      for (int il = 0; il < 2; ++il) {
+        const int b = auto_path_lanes(k, cap, il != 0);
+        CHECK(b >= 1 && b <= cap && b <= k && b <= 20);
+        CHECK((k + b - 1) / b <= (k + std::min<int64_t>(std::min(cap, 16), k) - 1) / std::min<int64_t>(std::min(cap, 16), k));
+      }
 }
 
 static void test_grid() {
@@ -190,6 +205,7 @@ int main() {
   test_pool();
   test_row_sets();
   test_interleaved();
+  test_auto_lanes();
   test_grid();
   test_find_and_tiles();
   if (failures) {

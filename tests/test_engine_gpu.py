@@ -574,6 +574,33 @@ def test_split_gradient_matches_numpy(eng, n, p, rowdot, monkeypatch):
         npt.assert_allclose(loss, loss0, rtol=1e-12)
 
 
+@pytest.mark.parametrize("n,p", [(1, 1), (7, 40), (25, 30), (257, 129), (1000, 1000), (333, 1537), (4099, 48),
+                                 (20011, 600), (700, 5000), (513, 5120)])
+@pytest.mark.parametrize("lanes,lane", [(17, 16), (18, 17), (19, 18), (20, 19), (20, 3), (32, 16), (32, 31)])
+def test_split_gradient_of_the_lanes_beyond_sixteen_matches_numpy(eng, n, p, lanes, lane, monkeypatch):
+    # a call of 17-20 lanes: sixteen on the matrix cores, the others on the vector units beside them (xtr18 / xtr20_mfma_kernel);
+    # more: both planes of R on the matrix cores (xtr32_mfma_kernel).  SLM_GRAD_LANES lanes all at z, lane SLM_GRAD_LANE returned.
+    monkeypatch.setenv("SLM_GRAD_SPLIT", "1")
+    monkeypatch.setenv("SLM_ROWDOT_RING", "0")
+    monkeypatch.setenv("SLM_GRAD_LANES", str(lanes))
+    monkeypatch.setenv("SLM_GRAD_LANE", str(lane))
+    rng = np.random.default_rng(n * 37 + p + lanes)
+    X = rng.standard_normal((n, p))
+    y = rng.standard_normal(n)
+    z = rng.standard_normal(p)
+    w = rng.uniform(0.0, 2.0, n)
+    for rw in (None, w):
+        with eng.dataset(X, y, row_weight=rw) as ds:
+            if ds.max_lanes(_engine.FLAG_WORKING_SET) < lanes:
+                pytest.skip("this shape runs on the on-chip solver's lanes")
+            g, loss = ds.gradient(z)
+            g0, loss0 = ref_grad(X, y, z, rw)
+            assert rel_inf(g, g0) < 1e-12
+            npt.assert_allclose(loss, loss0, rtol=1e-12)
+            g2, _ = ds.gradient(z)
+            assert np.array_equal(g, g2)  # (fixed-order sums: the same bits)
+
+
 def test_sparse_hold_out_scoring_matches_dense_and_numpy(eng):
     # slm_eval_sse_sparse: gather the union of the supports once, score from those columns
     rng = np.random.default_rng(8)
