@@ -278,6 +278,7 @@ int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y
   if (wa && ctl) {  // residuals from the gathered columns: matrix cores (SLM_RESID_VEC=1: a row per thread)
     const char* env = getenv("SLM_RESID_VEC");
     if (env && env[0] == '1' && halves == 1) hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
+    else if (halves == 2 && getenv("SLM_NO_RESID32") == nullptr) hipLaunchKernelGGL(resid32_mfma_kernel, dim3(nblk, 1), dim3(RM_WAVES * 64), 0, s, a);  // (both halves on one read of the gathered columns)
     else hipLaunchKernelGGL(resid_mfma_kernel, dim3(nblk, halves), dim3(RM_WAVES * 64), 0, s, a);
   }
   // (SLM_FLAG_PROFILE brackets the kernel that streams X, the one the roofline is quoted on)
@@ -1818,6 +1819,23 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   const bool mg_ok = use_ws && split && (big_x || mg_forced) && !sharded && !cov_on && !(o.flags & SLM_FLAG_NO_MODEL_GRAM) &&
                      (size_t)ds->lane_cap >= (size_t)kMaxLanes && ws_n_sets <= mg_cap && mg_possible(ds);
   if (mg_ok && mg_forced) expected = 0;  // (tests: polled from the first chunk on, so that short solves reach the rounds too)
+  // A dataset that already holds the model Gram of every row set of this call (an earlier solve outgrew the working set
+  // and built them: the same path again, a refit, the next search on the data) will be served by the rounds the moment
+  // its selection stops fitting: the working set then stays as it is from the first overflow on, instead of being
+  // selected, gathered and multiplied afresh once (2-3 ms at 500 columns) before the host has seen the counter.
+  // (lanes on the dataset's own rows only: other row sets are told apart by fingerprints, a kernel and a round trip)
+  if (mg_ok && !mg_forced && !ds->mg.empty() && getenv("SLM_NO_MG_KEEP") == nullptr) {
+    bool all = ws_n_sets > 0;
+    for (int st = 0; st < ws_n_sets && all; ++st) {
+      const int l = ws_set_lane[st];
+      all = lanes[l].row_weight == nullptr;
+      const double ne = ls.n_eff[l] > 0 ? ls.n_eff[l] : (double)ds->n_global;
+      bool have = false;
+      for (const auto& e : ds->mg) have = have || (e.own && e.n_eff == ne);
+      all = all && have;
+    }
+    if (all) wa.keep_full = 1;
+  }
   bool mg_on = false;
   int mg_inner = 20;
   double mg_build_ms = 0.0;

@@ -830,15 +830,23 @@ static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot32_mfma_kernel(Spl
 constexpr int RM_WAVES = 8;   // (4: 30.6 us per pass on the headline path, 8 or 16: 26.6 us -- six 16-row tiles per wavefront were a chain of six)
 constexpr int RM_U = 4;  // 16-position groups per batch (two batches in flight)
 
-static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) {
+// H = 1: the sixteen lanes of half blockIdx.y.  H = 2: BOTH halves of a call of more than sixteen lanes on one read of the
+// gathered columns (a launch per half read them twice: 66 us against 40 on the headline path's eighteen lanes).
+template <int H>
+__device__ __forceinline__ void resid_mfma_body(SplitArgs& a) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 columns of the MFMA B operand");
   if (a.done != nullptr && *a.done != 0) return;
-  const int half = (int)blockIdx.y, L0 = SPLIT_LANES * half;  // (grid.y: the halves of the call)
-  const unsigned mask = split_ws_mask(a, half);
-  if (mask == 0u) return;
-  a.R += (int64_t)half * a.r_plane;
-  __shared__ double zw[WS_KCAP][SPLIT_LANES];  // 64 KiB
-  __shared__ double lsum[RM_WAVES][SPLIT_LANES];
+  const int half0 = H == 1 ? (int)blockIdx.y : 0;  // (grid.y: the halves of the call, one launch each; H = 2: both here)
+  unsigned mask[H];
+  bool any = false;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    mask[h] = split_ws_mask(a, half0 + h);
+    any = any || mask[h] != 0u;
+  }
+  if (!any) return;
+  __shared__ double zw[H][WS_KCAP][SPLIT_LANES];  // 64 KiB per half
+  __shared__ double lsum[RM_WAVES][H * SPLIT_LANES];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = a.ws->K;  // multiple of 16; positions >= Kreal hold zero columns
@@ -846,10 +854,14 @@ static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitA
   const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
   const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
   const int64_t rend = r0 + nrows;
-  for (int e = tid; e < K * SPLIT_LANES; e += RM_WAVES * 64) {
-    const int k = e >> 4, l = e & 15;
-    const int j = a.idx[k];
-    zw[k][l] = (j >= 0 && L0 + l < a.n_lanes) ? a.z[(int64_t)(L0 + l) * a.ld + j] : 0.0;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const int L0 = SPLIT_LANES * (half0 + h);
+    for (int e = tid; e < K * SPLIT_LANES; e += RM_WAVES * 64) {
+      const int k = e >> 4, l = e & 15;
+      const int j = a.idx[k];
+      zw[h][k][l] = (j >= 0 && L0 + l < a.n_lanes) ? a.z[(int64_t)(L0 + l) * a.ld + j] : 0.0;
+    }
   }
   __syncthreads();
   const int i16 = lane & 15, q = lane >> 4;
@@ -857,22 +869,30 @@ static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitA
   const double* rwp = has_rw ? a.rw : a.y;  // (no row weights: any readable address)
   const int ngroups = K >> 4;
   const int ntiles = (int)((nrows + 15) >> 4);
-  double loss = 0.0;  // of lane slot i16 over this lane's rows
+  double loss[H];  // of lane slot i16 (of each half) over this lane's rows
+#pragma unroll
+  for (int h = 0; h < H; ++h) loss[h] = 0.0;
   for (int t = wave; t < ntiles; t += RM_WAVES) {
     const int64_t row0 = r0 + 16 * (int64_t)t;
     const int64_t rl = row0 + i16 < rend ? row0 + i16 : rend - 1;  // (rows past the block are computed and dropped)
     const double* xp = a.XW + rl * WS_KCAP + 4 * q;
-    slm_d4 acc = slm_d4{0.0, 0.0, 0.0, 0.0};
+    slm_d4 acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[h] = slm_d4{0.0, 0.0, 0.0, 0.0};
     slm_d4 xa[RM_U], xb[RM_U];
     // targets and row weights of the four rows this lane finishes: asked for now, with the first columns (at the end
     // of the tile each pair was a round trip of its own before the row could be stored)
-    double yv[4], mv[4];
+    double yv[4], mv[H][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t row = row0 + q + 4 * r;
       const int64_t rc = row < rend ? row : rend - 1;
       yv[r] = a.y[rc];
-      mv[r] = rwp[has_rw ? (int64_t)(L0 + i16) * a.rw_stride + rc : 0];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int L = SPLIT_LANES * (half0 + h) + i16;
+        mv[h][r] = rwp[has_rw ? (int64_t)(L < a.n_lanes ? L : 0) * a.rw_stride + rc : 0];
+      }
     }
     // (loads without conditions -- a group beyond K is read from the last one and not used: with the loads under
     //  `if (g0 + u < ngroups)` the compiler could not count them and drained the queue before every batch of MFMAs)
@@ -884,10 +904,13 @@ static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitA
 #pragma unroll
       for (int u = 0; u < RM_U; ++u)
         if (g0 + u < ngroups) {
-          const double* zr = &zw[16 * (g0 + u) + 4 * q][i16];
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][m], zr[m * SPLIT_LANES], acc, 0, 0, 0);
+          for (int h = 0; h < H; ++h) {
+            const double* zr = &zw[h][16 * (g0 + u) + 4 * q][i16];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][m], zr[m * SPLIT_LANES], acc[h], 0, 0, 0);
+          }
         }
     };
     load(xa, 0);
@@ -897,29 +920,38 @@ static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitA
       load(xa, g0 + 2 * RM_U);
       compute(xb, g0 + RM_U);
     }
-    if ((mask >> i16) & 1u) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = row0 + q + 4 * r;
-        if (row < rend) {
-          const double m = has_rw ? mv[r] : 1.0;
-          const double err = acc[r] - yv[r];
-          const double res = err * m;
-          a.R[row * SPLIT_RSTRIDE + i16] = res;
-          loss = __builtin_fma(res, err, loss);
+    for (int h = 0; h < H; ++h)
+      if ((mask[h] >> i16) & 1u) {
+        double* Rh = a.R + (int64_t)(half0 + h) * a.r_plane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = row0 + q + 4 * r;
+          if (row < rend) {
+            const double m = has_rw ? mv[h][r] : 1.0;
+            const double err = acc[h][r] - yv[r];
+            const double res = err * m;
+            Rh[row * SPLIT_RSTRIDE + i16] = res;
+            loss[h] = __builtin_fma(res, err, loss[h]);
+          }
         }
       }
-    }
   }
-  loss += __shfl_xor(loss, 16, 64);
-  loss += __shfl_xor(loss, 32, 64);
-  if (lane < SPLIT_LANES) lsum[wave][lane] = loss;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    loss[h] += __shfl_xor(loss[h], 16, 64);
+    loss[h] += __shfl_xor(loss[h], 32, 64);
+    if (lane < SPLIT_LANES) lsum[wave][h * SPLIT_LANES + lane] = loss[h];
+  }
   __syncthreads();
-  if (tid < SPLIT_LANES && ((mask >> tid) & 1u)) {
+  if (tid < H * SPLIT_LANES && ((mask[tid / SPLIT_LANES] >> (tid % SPLIT_LANES)) & 1u)) {
     double t = 0.0;
     for (int w2 = 0; w2 < RM_WAVES; ++w2) t += lsum[w2][tid];
-    a.loss_partial[b * split_slots(a) + L0 + tid] = t;
+    a.loss_partial[b * split_slots(a) + SPLIT_LANES * half0 + tid] = t;
   }
 }
+
+static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) { resid_mfma_body<1>(a); }
+static __global__ __launch_bounds__(RM_WAVES * 64) void resid32_mfma_kernel(SplitArgs a) { resid_mfma_body<2>(a); }
 
 }  // namespace slm

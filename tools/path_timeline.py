@@ -6,7 +6,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 seq = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
-xs = [i for i, s in enumerate(seq) if "xtr_mfma" in s[0] or "grad_ring" in s[0]]
+xs = [i for i, s in enumerate(seq) if ("xtr" in s[0] and "_mfma_kernel" in s[0]) or "grad_ring" in s[0]]  # (xtr_, xtr18_, xtr20_, xtr32_mfma_kernel)
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 9
 start = max(0, xs[-back] - 45)
 t0 = seq[start][1]
