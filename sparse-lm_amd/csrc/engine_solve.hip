@@ -1675,11 +1675,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     return enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1);
   };
   int ws_comm_rc = 0;  // first RCCL error of the per-pass Gram all-reduce (checked after each chunk)
+  bool mg_handover = false;  // the rounds on the model Gram are on: tail points change hands (tail_handover_kernel)
   // everything that follows the gradient of one pass
   // (in two halves: behind the pass a solve is expected to end with, the second half waits for the verdict)
   auto enqueue_tail = [&]() {
     launch_tail(ta, s);
     if (shared_path && !interleave) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
+    // (the dense end of an interleaved path: finished lanes take over tail points their owners have not started)
+    if (shared_path && interleave && mg_handover) hipLaunchKernelGGL(tail_handover_kernel, dim3(1), dim3(64), 0, s, ta);
     if (sharded) {  // the ranks agree on "finished" before anything acts on it
       if (use_ws && wa.Gx) {
         // working-set solves: the stop words ride behind the staged Gram parts, in the one all-reduce of the refinement
@@ -1889,6 +1892,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     const int rc = mg_sets();
     if (rc == SLM_OK) {
       mg_on = true;
+      mg_handover = getenv("SLM_NO_HANDOVER") == nullptr;
       wa.keep_full = 1;  // (from here on the working set serves what it holds: enqueue_refinement passes wa by value)
       if (mg_built > 0) mg_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     } else if (rc != SLM_ERR_OOM) {

@@ -1200,6 +1200,41 @@ static __global__ __launch_bounds__(256) void steal_kernel(TailArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Interleaved lanes, dense end of a path (rounds on the model Gram: a point takes two or three passes there, and the lanes
+// that hold the deepest points of a band fall a pass or two behind the others).  The points beyond the last full band --
+// the tail points -- belong to the LAST lanes (host_logic.hpp: interleaved_walk), which are exactly those: the first lanes
+// finish their walk and sit idle while the last points of the path wait for their owners (two of ten passes of a
+// noise-fitting 50-point path served one or two lanes each).  So a lane that has finished takes over the tail point of a
+// lane that has not started it: the shallowest such point first, finished lanes in index order, ONE thread -- the
+// hand-over is reproducible.  The taker starts from its own last solution (what every lane does at its next point), with
+// its residual taken from X (zsup = 0: the working set may have changed since the lane last looked).  Launched behind the
+// tail kernel of every pass once the rounds are on (solve_core); before that the lanes finish their points together and
+// the static assignment -- short steps from the neighbours' solutions -- is the one that avoids misses.
+// ---------------------------------------------------------------------------------------------
+static __global__ void tail_handover_kernel(TailArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || a.gdone[0] != 0) return;
+  for (int l = 0; l < a.n_lanes; ++l) {
+    PathCtl* me = a.ctl + l;
+    if (!me->done || me->nonfinite) continue;
+    int best = -1;
+    for (int v = 0; v < a.n_lanes; ++v) {
+      const PathCtl* cv = a.ctl + v;
+      if (v == l || cv->done || cv->idle || cv->tail_pt < 0 || cv->point == cv->tail_pt) continue;
+      if (best < 0 || cv->tail_pt < a.ctl[best].tail_pt) best = v;
+    }
+    if (best < 0) return;  // (no tail point is waiting: none will be for the lanes after this one either)
+    PathCtl* cv = a.ctl + best;
+    me->point = cv->tail_pt;
+    me->tail_pt = cv->tail_pt;  // (the lane's range ends with it: fista_tail_kernel, range_end)
+    cv->tail_pt = -1;
+    me->zsup = 0;
+    me->steals += 1;
+    me->done = 0;
+    atomicSub(&a.gdone[1], 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row-sharded mode: the stop decision is taken from reduced data.  After the tail (and hand-out) kernels of a
 // pass every rank packs "I have finished" into a small vector, the vector is summed over the ranks, and
 // gdone[0] -- the flag every kernel and the host loop obey -- is set only when ALL ranks reported it.  The ranks

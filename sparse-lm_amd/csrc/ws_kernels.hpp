@@ -351,6 +351,10 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
   __shared__ double red[2][TAIL_WAVES];
   __shared__ int wave_tot[TAIL_WAVES];
   WsCtl* ws = w.ws;
+  // `served` is this pass's: set again by the model solver (launched behind this kernel) for the lanes it moves.  Left
+  // standing from pass to pass, the flags of the last pass the working set served everyone made the FIRST round on the
+  // model Gram sit out -- a whole pass over X between the overflow and the first proposal.
+  if (threadIdx.x < SLM_MAX_LANES) ws->served[threadIdx.x] = 0;
   if (a.gdone[0] != 0 || ws->disabled) return;
   const int tid = threadIdx.x;
   const int p = a.p, G = a.G;
