@@ -704,11 +704,11 @@ def leg_config3(eng, rank, world, n, p, tol, cpu_budget_s, steps=5):
         alphas = np.geomspace(bmax, 1e-3 * bmax, K)
         pts = np.c_[0 * alphas, alphas, 0 * alphas]
         for _ in range(2):
-            res = ds.solve_path(pts, tol=tol, lanes=16, flags=_engine.FLAG_FRESH_L)
+            res = ds.solve_path(pts, tol=tol, lanes=0, flags=_engine.FLAG_FRESH_L)  # (0: the engine's choice -- twenty-five for these fifty points in contiguous ranges)
         eng.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            res = ds.solve_path(pts, tol=tol, lanes=16, flags=_engine.FLAG_FRESH_L)
+            res = ds.solve_path(pts, tol=tol, lanes=0, flags=_engine.FLAG_FRESH_L)  # (0: the engine's choice -- twenty-five for these fifty points in contiguous ranges)
         eng.synchronize()
         dt = (time.perf_counter() - t0) / steps
         out = {"fits_per_s": K / dt, "ms_per_path": 1e3 * dt, "passes": int(res.grad_launches), "converged": bool(res.converged),

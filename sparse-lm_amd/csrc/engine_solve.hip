@@ -2186,9 +2186,9 @@ extern "C" int slm_solve_lanes_reweighted(slm_dataset* ds, const slm_lane* lanes
 // the engine's choice of lanes for a shared path (n_lanes = 0): the fewest passes over X at the price of sixteen lanes
 static int auto_lanes(slm_dataset* ds, int32_t n_points, uint32_t fl) {
   const int cap = max_lanes_for(ds, fl);
-  const bool interleaved = ds->singleton && ws_policy(ds, fl) == 2 && (double)ds->n * (double)ds->ld >= 67108864.0 &&
-                           !small_ok(ds, fl) && !getenv("SLM_NO_INTERLEAVE");
-  int B = slm_host::auto_path_lanes(n_points, cap, interleaved);
+  const bool big = ws_policy(ds, fl) == 2 && (double)ds->n * (double)ds->ld >= 67108864.0 && !small_ok(ds, fl);
+  const bool interleaved = ds->singleton && !getenv("SLM_NO_INTERLEAVE");  // (solve_core: per-feature penalties take the points in turn)
+  int B = slm_host::auto_path_lanes(n_points, cap, big, !interleaved);
   if (const char* e = getenv("SLM_AUTO_LANES")) B = std::max(1, std::min<int>(std::min(atoi(e), cap), n_points));  // (A/B runs)
   return B;
 }

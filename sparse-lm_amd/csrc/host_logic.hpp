@@ -153,28 +153,45 @@ inline int64_t interleaved_points(const LaneWalk& w) {
 // ---------------------------------------------------------------------------------------------
 struct XtrGrid { int xb, yb, rows; };
 // ---------------------------------------------------------------------------------------------
-// Lanes of a shared path when the caller leaves the choice to the engine (slm_solve_path_lanes, n_lanes = 0).  A path on
-// interleaved lanes verifies one point per lane and pass, so its passes over X are ceil(points / lanes).  Sixteen lanes
-// are the width of the matrix cores' operand; seventeen to twenty cost the same read of X (the extra lanes run on the
-// vector units beside them: xtr18 / xtr20_mfma_kernel) -- 50 points: four passes on sixteen lanes, three on eighteen.
-// Beyond twenty a pass is dearer (both halves on the matrix cores) and the lanes look further down the path than the
-// first working set can know: measured worse on the headline shape (HISTORY round 5), so the choice stops at twenty.
-// `cap`: what the dataset's kernels serve (slm_dataset_max_lanes); `interleaved`: per-feature penalties on a
-// working-set solve over a large X (solve_core) -- other paths keep to sixteen, in contiguous ranges.
+// Lanes of a shared path when the caller leaves the choice to the engine (slm_solve_path_lanes, n_lanes = 0).  A
+// working-set path over a large X verifies one point per lane and pass, so its passes over X are ceil(points / lanes),
+// and a pass costs: sixteen lanes -- the width of the matrix cores' operand -- 1.00; seventeen to twenty the same read
+// of X with the extra lanes on the vector units beside them (xtr18 / xtr20_mfma_kernel): 1.03; up to thirty-two both
+// halves on the matrix cores (xtr32_mfma_kernel): 1.22; and the chain of launches between two passes about 0.45 of a
+// pass whatever the count (0.58 / 0.60 / 0.71 ms and 0.25-0.3 ms at 100k x 5k).  The count with the cheapest path wins, the
+// fewest lanes among equals, the points spread evenly over the passes it needs.
+// `wide_ok`: lanes beyond twenty are an option -- paths in contiguous ranges (group penalties: config 3's 50 points take
+// two passes on twenty-five lanes, 4.24 -> 2.79 ms).  INTERLEAVED lanes (per-feature penalties, solve_core) stop at twenty:
+// beyond, a lane looks further down the path than the first working set can know -- measured on the headline shape,
+// 25-32 lanes: 4 passes with 3 misses, 3.5-4.7 ms against 2.9 on eighteen (HISTORY round 5).
+// `cap`: what the dataset's kernels serve (slm_dataset_max_lanes); `big`: a working-set solve over a large X at all --
+// elsewhere sixteen (or what the fused kernels' table has).
 // ---------------------------------------------------------------------------------------------
-inline int auto_path_lanes(int64_t n_points, int cap, bool interleaved) {
+inline int auto_path_lanes(int64_t n_points, int cap, bool big, bool wide_ok) {
   if (n_points < 1) n_points = 1;
-  int best = (int)std::min<int64_t>(std::min(cap, 16), n_points);
-  if (!interleaved || cap < 20 || n_points <= 16) return best;
-  int64_t best_passes = (n_points + 15) / 16;
-  for (int64_t lanes : {18, 20}) {
+  const int narrow = (int)std::min<int64_t>(std::min(cap, 16), n_points);
+  if (!big || cap < 20 || n_points <= 16) return narrow;
+  int best = narrow;
+  double best_cost = 1.45 * (double)((n_points + 15) / 16);
+  auto offer = [&](int64_t lanes) {
     lanes = std::min(lanes, n_points);
+    if (lanes <= 16 || lanes > cap) return;
     const int64_t passes = (n_points + lanes - 1) / lanes;
-    if (passes < best_passes) {
-      best_passes = passes;
+    const double cost = (double)passes * ((lanes <= 20 ? 1.03 : 1.22) + 0.45);
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
       best = (int)lanes;
     }
-  }
+  };
+  // (eighteen and twenty, not the fewest lanes that make the pass count: 50 points on seventeen interleaved lanes leave a
+  //  last band of sixteen that starts a whole stride up the path -- measured: a miss and a fourth pass)
+  offer(18);
+  offer(20);
+  if (wide_ok)  // the fewest lanes beyond twenty that do it in `passes`: the points spread evenly
+    for (int64_t passes = 1; passes <= (n_points + 20) / 21; ++passes) {
+      const int64_t lanes = (n_points + passes - 1) / passes;
+      if (lanes > 20 && lanes <= 32) offer(lanes);
+    }
   return best;
 }
 

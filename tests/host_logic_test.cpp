@@ -147,18 +147,25 @@ static void test_interleaved() {
 }
 
 static void test_auto_lanes() {
-  // sixteen unless eighteen or twenty lanes save a pass of an interleaved path; never more than the kernels serve
-  CHECK(auto_path_lanes(50, 32, true) == 18 && auto_path_lanes(50, 32, false) == 16 && auto_path_lanes(50, 16, true) == 16);
-  CHECK(auto_path_lanes(100, 32, true) == 20 && auto_path_lanes(32, 32, true) == 16 && auto_path_lanes(36, 32, true) == 18);
-  CHECK(auto_path_lanes(40, 32, true) == 20 && auto_path_lanes(41, 32, true) == 16 && auto_path_lanes(7, 32, true) == 7);
-  CHECK(auto_path_lanes(1, 4, false) == 1 && auto_path_lanes(9, 4, false) == 4 && auto_path_lanes(0, 32, true) == 1);
+  // (points, cap, working-set solve over a large X, lanes beyond twenty allowed)
+  // interleaved lanes: sixteen unless eighteen or twenty save a pass; never more than the kernels serve
+  CHECK(auto_path_lanes(50, 32, true, false) == 18 && auto_path_lanes(50, 32, false, false) == 16 && auto_path_lanes(50, 16, true, false) == 16);
+  CHECK(auto_path_lanes(100, 32, true, false) == 20 && auto_path_lanes(32, 32, true, false) == 16 && auto_path_lanes(36, 32, true, false) == 18);
+  CHECK(auto_path_lanes(40, 32, true, false) == 20 && auto_path_lanes(41, 32, true, false) == 16 && auto_path_lanes(7, 32, true, false) == 7);
+  CHECK(auto_path_lanes(1, 4, false, false) == 1 && auto_path_lanes(9, 4, false, true) == 4 && auto_path_lanes(0, 32, true, true) == 1);
+  // contiguous ranges: up to thirty-two -- 50 points in two passes of twenty-five
+  CHECK(auto_path_lanes(50, 32, true, true) == 25 && auto_path_lanes(60, 32, true, true) == 30 && auto_path_lanes(36, 32, true, true) == 18);
+  CHECK(auto_path_lanes(64, 32, true, true) == 32 && auto_path_lanes(100, 32, true, true) == 25 && auto_path_lanes(17, 32, true, true) == 17);
   for (int64_t k = 1; k <= 400; ++k)
     for (int cap : {1, 4, 6, 16, 32})
-      for (int il = 0; il < 2; ++il) {
-        const int b = auto_path_lanes(k, cap, il != 0);
-        CHECK(b >= 1 && b <= cap && b <= k && b <= 20);
-        CHECK((k + b - 1) / b <= (k + std::min<int64_t>(std::min(cap, 16), k) - 1) / std::min<int64_t>(std::min(cap, 16), k));
-      }
+      for (int big = 0; big < 2; ++big)
+        for (int wide = 0; wide < 2; ++wide) {
+          const int b = auto_path_lanes(k, cap, big != 0, wide != 0);
+          const int64_t narrow = std::min<int64_t>(std::min(cap, 16), k);
+          CHECK(b >= 1 && b <= cap && b <= k && b <= (wide ? 32 : 20));
+          CHECK((k + b - 1) / b <= (k + narrow - 1) / narrow);  // never more passes than sixteen lanes take
+          if (!big) CHECK(b == narrow);
+        }
 }
 
 static void test_grid() {

@@ -118,6 +118,36 @@ def test_lanes_with_their_own_row_masks_take_the_model_gram_of_their_fold(eng, m
     assert np.max(np.abs(r[3].betas[-1] - bo)) < 1e-6 * np.max(np.abs(bo))
 
 
+@pytest.mark.parametrize("lanes,K", [(18, 50), (16, 50), (20, 57), (7, 31)])
+def test_tail_points_change_hands_at_the_dense_end_of_an_interleaved_path(eng, monkeypatch, lanes, K):
+    """A shared path whose points beyond the last full band belong to the LAST lanes (interleaved_walk): once the rounds on
+    the model Gram are on, a lane that has finished takes over a tail point its owner has not started
+    (tail_handover_kernel).  Which lane solves a point changes nothing that is reported: against the same path without the
+    hand-over, against one plain lane, and the same bits run to run."""
+    monkeypatch.setenv("SLM_MG", "2")
+    rng = np.random.default_rng(lanes * 100 + K)
+    n, p = 4200, 660
+    X, y = _dense_problem(rng, n, p, 25, 80.0)
+    WS, PLAIN = _engine.FLAG_WORKING_SET, _engine.FLAG_NO_WORKING_SET
+    with eng.dataset(X, y) as ds:
+        g0, _ = ds.gradient(None)
+        amax = float(np.max(np.abs(g0)))
+        pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-3 * amax, K)]
+        with_h = ds.solve_path(pts, lanes=lanes, flags=WS, tol=1e-9)
+        again = ds.solve_path(pts, lanes=lanes, flags=WS, tol=1e-9)
+        monkeypatch.setenv("SLM_NO_HANDOVER", "1")
+        without = ds.solve_path(pts, lanes=lanes, flags=WS, tol=1e-9)
+        monkeypatch.delenv("SLM_NO_HANDOVER")
+        one = ds.solve_path(pts, lanes=1, flags=PLAIN, tol=1e-10)
+    assert with_h.converged and without.converged and one.converged and with_h.mg_rounds > 0
+    assert np.count_nonzero(with_h.betas[-1]) > 512  # (the end of the path lies beyond the working set)
+    assert with_h.grad_launches <= without.grad_launches + 1
+    scale = np.max(np.abs(one.betas))
+    assert np.max(np.abs(with_h.betas - without.betas)) < 1e-6 * scale
+    assert np.max(np.abs(with_h.betas - one.betas)) < 1e-6 * scale
+    assert np.array_equal(with_h.betas, again.betas)
+
+
 def test_randomised_cross_check_of_the_rounds():
     """tools/mg_fuzz.py: the rounds forced on over random penalty kinds, group sizes, 9-16 lanes, shared paths and lanes with
     fold masks, iid / correlated / duplicated / badly scaled designs, more columns than rows, dataset row weights: every

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The group-lasso path of BASELINE config 3's shape (n = 100k, p = 5k, 500 groups of 10, 50 alphas, 16 lanes: contiguous ranges
+"""The group-lasso path of BASELINE config 3's shape (n = 100k, p = 5k, 500 groups of 10, 50 alphas, the engine's choice of lanes: contiguous ranges
 with work stealing, the sample start) on many random datasets: converged, pass count, agreement with the plain four-lane
 iteration of the same data.  usage: group_soak.py [seeds]"""
 import os, sys, time
@@ -11,6 +11,7 @@ eng = _engine.get_engine(0)
 n, p, G = 100000, 5000, 500
 groups = np.repeat(np.arange(G), p // G)
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+LANES = int(os.environ.get("GROUP_SOAK_LANES", "0"))  # (0: the engine's choice -- twenty-five for fifty points in contiguous ranges)
 worst, bad, passes = 0.0, 0, []
 for seed in range(seeds):
     rng = np.random.default_rng(500 + seed)
@@ -27,8 +28,8 @@ for seed in range(seeds):
         g0, _ = ds.gradient(None)
         bmax = float(np.max(np.sqrt(np.bincount(gid, weights=g0 * g0, minlength=G))))
         pts = [(0.0, a, 0.0) for a in np.geomspace(bmax, lo * bmax, 50)]
-        ds.solve_path(pts, lanes=16)
-        t = time.perf_counter(); r = ds.solve_path(pts, lanes=16); dt = (time.perf_counter() - t) * 1e3
+        ds.solve_path(pts, lanes=LANES)
+        t = time.perf_counter(); r = ds.solve_path(pts, lanes=LANES); dt = (time.perf_counter() - t) * 1e3
         q = ds.solve_path(pts, lanes=4, flags=_engine.FLAG_NO_WORKING_SET, tol=1e-9)
         err = float(np.max(np.abs(r.betas - q.betas)) / max(np.max(np.abs(q.betas)), 1e-300))
         act = int(np.count_nonzero(np.bincount(gid, weights=np.abs(r.betas[-1]), minlength=G)))
