@@ -270,7 +270,7 @@ class Config4:
     """BASELINE config 4 as a device-resident problem: 5 folds x 10 l1_ratio, each a 50-alpha SparseGroupLasso path =
     2500 fits on make_regression-law data with 500 shuffled groups of 10 (25 informative).  `calls_of(world, rank)` is
     the share of one rank: the path POINTS of the 50 (fold, l1_ratio) units are dealt to the lane slots of all ranks by
-    `distributed.plan_lane_calls` (sixteen lanes per call; whole paths while there are more units than slots, evenly
+    `distributed.plan_lane_calls` (thirty-two lanes per call -- over X and from the Grams alike; whole paths while there are more units than slots, evenly
     spread pieces of paths otherwise).  Every rank generates the SAME (X, y) (same seed): X replicated per GPU, no
     data-path collective."""
 
@@ -304,8 +304,8 @@ class Config4:
 
     @property
     def lanes(self):
-        """lanes per call, as the engine serves them under the current flags: thirty-two over X (two halves on one read of X),
-        sixteen from the folds' Grams"""
+        """lanes per call, as the engine serves them under the current flags: thirty-two over X (two halves on one read of X)
+        and from the folds' Grams (the product of a Gram and the lanes' points: a launch per half)"""
         return getattr(self, "_lanes", None) or self.ds.max_lanes(self.flags)
 
     @lanes.setter
@@ -334,8 +334,6 @@ class Config4:
             pts, gam = _engine.lane_points([self.unit_pts[u][idx] for u, idx in lane])
             f = self.units[lane[0][0]][0]
             specs.append(dict(points=pts, extrap=gam, row_weight=self.masks[f], n_eff=int(self.masks[f].sum())))
-        if (self.flags & _engine.FLAG_COVARIANCE) and len(specs) > _engine.MAX_LANES:
-            raise RuntimeError("config 4: calls planned for the pass over X (32 lanes) cannot take their gradients from the Grams: plan again")
         out = d.solve_lanes(specs, flags=self.flags)
         if not all(o.converged for o in out):
             raise RuntimeError("config 4: a path did not converge")
@@ -435,7 +433,7 @@ def leg_config4_grid(eng, rank, world, n, p, device_id=0, streams=3, emulate_wor
         # the rank's share from the Grams of the five folds (SLM_FLAG_COVARIANCE), the Grams' cost beside it
         try:
             out["covariance_build_s"] = c4.build_covariance()
-            mine = c4.calls_of(world, rank)  # (sixteen lanes a call from here on)
+            mine = c4.calls_of(world, rank)  # (planned again: the flags have changed)
             c4.run(mine)
             out["seconds_covariance"], out["passes_covariance"] = min(c4.run(mine) for _ in range(2))
             if n_streams > 1:  # copies made now share the Grams (slm_dataset_clone)
@@ -544,7 +542,7 @@ def leg_config4_dense(eng, n, p, noise_sd=100.0):
         nnz = sorted(int(np.count_nonzero(keep_x[(u, c4.K - 1)])) for u in range(len(c4.units)))
         above = sum(int(np.count_nonzero(b)) > 512 for b in keep_x.values())
         build = c4.build_covariance()
-        calls = c4.calls_of(1, 0)  # (sixteen lanes a call from here on)
+        calls = c4.calls_of(1, 0)  # (planned again: the flags have changed)
         for call in calls:
             c4.run_call(c4.ds, call, keep_c)
         seconds_c, passes_c = min(c4.run(calls) for _ in range(2))

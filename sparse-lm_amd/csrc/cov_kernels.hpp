@@ -17,13 +17,14 @@
 namespace slm {
 
 // Z[j][l] = z_l[j] (lane-minor, the B operand of xtr_mfma_kernel); lane slots beyond n_lanes are zero
+// (grid.y: the halves of a call of more than sixteen lanes -- a plane of Z each, ld * 16 doubles apart)
 static __global__ __launch_bounds__(256) void cov_pack_kernel(const double* z, int64_t ld, int n_lanes, double* Z, const int* done) {
   if (done != nullptr && *done != 0) return;
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over ld * 16
   if (e >= ld * SPLIT_RSTRIDE) return;
   const int64_t j = e >> 4;
-  const int l = (int)(e & 15);
-  Z[e] = l < n_lanes ? z[(int64_t)l * ld + j] : 0.0;
+  const int l = SPLIT_LANES * (int)blockIdx.y + (int)(e & 15);
+  Z[(int64_t)blockIdx.y * ld * SPLIT_RSTRIDE + e] = l < n_lanes ? z[(int64_t)l * ld + j] : 0.0;
 }
 
 // The product of a covariance pass, partial[by][l][col] = sum_{row in block by} Z[row][l] G[row][col]: xtr_mfma_kernel's loop
@@ -78,10 +79,18 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[h][t] = slm_d4{0.0, 0.0, 0.0, 0.0};
   bool listed = false;
-  if (H == 1 && a.ctl != nullptr && a.ws != nullptr && a.xrows_ws > 0) {
-    unsigned live, on_ws;
-    split_masks(a, live, on_ws);
-    listed = live != 0u && live == on_ws && (int64_t)a.xrows_ws * (int64_t)gridDim.y >= (int64_t)a.ws->K;
+  if (a.ctl != nullptr && a.ws != nullptr && a.xrows_ws > 0) {
+    // (a.lane0: the first half of the call this launch serves -- enqueue_gradient_cov; H = 2: both halves here)
+    bool any_live = false, all_on = true;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      unsigned live, on_ws;
+      split_masks(a, live, on_ws, a.lane0 + h);
+      any_live = any_live || live != 0u;
+      all_on = all_on && live == on_ws;
+    }
+    if (!any_live) return;  // (lanes that have all finished: nothing to multiply)
+    listed = all_on && (int64_t)a.xrows_ws * (int64_t)gridDim.y >= (int64_t)a.ws->K;
   }
   if (listed) {
     const int K = a.ws->K;
@@ -94,21 +103,25 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
       rows[t] = (4 * t < a.xrows_ws && k < K) ? a.idx[k] : -1;
     }
     d2 xv[8][4];
-    double rv[8];
+    double rv[H][8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int64_t r = rows[t] >= 0 ? rows[t] : 0;  // (a row that is not there multiplies row 0 by zero)
 #pragma unroll
       for (int c = 0; c < 4; ++c) xv[t][c] = *reinterpret_cast<const d2*>(a.X + r * a.ld + coff[c]);
-      rv[t] = a.R[r * SPLIT_RSTRIDE + i16];
+#pragma unroll
+      for (int h = 0; h < H; ++h) rv[h][t] = a.R[(int64_t)h * a.r_plane + r * SPLIT_RSTRIDE + i16];
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const double z = rows[t] >= 0 ? rv[t] : 0.0;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc[0][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t][c].x, z, acc[0][2 * c], 0, 0, 0);
-        acc[0][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t][c].y, z, acc[0][2 * c + 1], 0, 0, 0);
+      for (int h = 0; h < H; ++h) {
+        const double z = rows[t] >= 0 ? rv[h][t] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[h][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t][c].x, z, acc[h][2 * c], 0, 0, 0);
+          acc[h][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[t][c].y, z, acc[h][2 * c + 1], 0, 0, 0);
+        }
       }
     }
   } else {
@@ -196,6 +209,12 @@ static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void cov_gz_mfma_kernel(S
   if (a.done != nullptr && *a.done != 0) return;
   cov_gz_body<1>(a, cb);
 }
+// a call of more than sixteen lanes: both halves' points (the planes of Z, a.r_plane doubles apart) against ONE read of
+// every Gram; partial sums of the second half cb.half_stride doubles on
+static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void cov_gz32_mfma_kernel(SplitArgs a, CovBatch cb) {
+  if (a.done != nullptr && *a.done != 0) return;
+  cov_gz_body<2>(a, cb);
+}
 
 struct CovFinishArgs {
   const double* partial;  // [row sets][nblk][16][ld] of cov_gz_mfma_kernel
@@ -211,13 +230,14 @@ static __global__ __launch_bounds__(256) void cov_reduce_kernel(CovFinishArgs a,
   if (a.done != nullptr && *a.done != 0) return;
   const int lane = blockIdx.y;
   const int set = cb.set_of[lane];
-  a.partial += (int64_t)set * cb.part_stride;
+  const int half = lane / SPLIT_LANES, l16 = lane % SPLIT_LANES;  // (a block of partial sums per half of the lanes and row set)
+  a.partial += (int64_t)half * cb.half_stride + (int64_t)set * cb.part_stride;
   const double* c = cb.c[set];
   __shared__ double lds[16][17];
   const int tid = threadIdx.x, cl = tid & 15, slice = tid >> 4;
   const int64_t col = (int64_t)blockIdx.x * 16 + cl;
   double s = 0.0;
-  for (int b = slice; b < a.nblk; b += 16) s += a.partial[((int64_t)b * SPLIT_LANES + lane) * a.ld + col];
+  for (int b = slice; b < a.nblk; b += 16) s += a.partial[((int64_t)b * SPLIT_LANES + l16) * a.ld + col];
   lds[slice][cl] = s;
   __syncthreads();
   if (slice == 0) {

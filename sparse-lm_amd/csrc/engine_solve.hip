@@ -115,7 +115,8 @@ static int launch_cov_gz(int cus, SplitArgs& a, hipStream_t s, const CovBatch& c
   a.xrows = g.rows;
   const int per = ((WS_KCAP + yb - 1) / yb + 3) / 4 * 4;
   a.xrows_ws = (a.ctl != nullptr && per <= 32) ? per : 0;
-  hipLaunchKernelGGL(cov_gz_mfma_kernel, dim3(xb, yb, (unsigned)n_sets), dim3(XTR_WAVES * 64), 0, s, a, cb);
+  if (a.r_plane != 0) hipLaunchKernelGGL(cov_gz32_mfma_kernel, dim3(xb, yb, (unsigned)n_sets), dim3(XTR_WAVES * 64), 0, s, a, cb);  // (both halves)
+  else hipLaunchKernelGGL(cov_gz_mfma_kernel, dim3(xb, yb, (unsigned)n_sets), dim3(XTR_WAVES * 64), 0, s, a, cb);
   return yb;
 }
 
@@ -311,7 +312,8 @@ static int enqueue_gradient_cov(slm_dataset* ds, int B, const int* entry_of, con
                                 hipEvent_t ev_stop, const PathCtl* ctl = nullptr, const WsArgs* wa = nullptr) {
   hipStream_t s = ds->eng->stream;
   const int64_t ld = ds->ld;
-  hipLaunchKernelGGL(cov_pack_kernel, dim3((unsigned)((ld * SPLIT_RSTRIDE + 255) / 256)), dim3(256), 0, s, ds->z, ld, B, ds->cov_Z, done);
+  const int halves = (B + SPLIT_LANES - 1) / SPLIT_LANES;  // (more than sixteen lanes: a plane of Z, a block of partial sums and a launch per half)
+  hipLaunchKernelGGL(cov_pack_kernel, dim3((unsigned)((ld * SPLIT_RSTRIDE + 255) / 256), (unsigned)halves), dim3(256), 0, s, ds->z, ld, B, ds->cov_Z, done);
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
   // the row sets of the call, in order of their first lane
   CovBatch cb;
@@ -332,13 +334,15 @@ static int enqueue_gradient_cov(slm_dataset* ds, int B, const int* entry_of, con
   // partial sums: one block of [row blocks][16][ld] per row set (the gradient's own buffer holds one or two)
   const int64_t blocks_most = std::max<int64_t>(1, xtr_max_row_blocks(ds->eng->cus, ld) / 2);
   cb.part_stride = blocks_most * SPLIT_LANES * ld;
+  cb.half_stride = (int64_t)n_sets * cb.part_stride;
+  const int blocks = halves * n_sets;
   double* partial = ds->partial;
-  if ((size_t)n_sets * (size_t)cb.part_stride > ds->partial_elems) {
-    if (ds->cov_partial_sets < n_sets) {
+  if ((size_t)blocks * (size_t)cb.part_stride > ds->partial_elems) {
+    if (ds->cov_partial_sets < blocks) {
       dfree(ds->cov_partial);
       ds->cov_partial_sets = 0;
-      SLM_TRY(dalloc(&ds->cov_partial, (size_t)n_sets * (size_t)cb.part_stride));
-      ds->cov_partial_sets = n_sets;
+      SLM_TRY(dalloc(&ds->cov_partial, (size_t)blocks * (size_t)cb.part_stride));
+      ds->cov_partial_sets = blocks;
     }
     partial = ds->cov_partial;
   }
@@ -348,6 +352,9 @@ static int enqueue_gradient_cov(slm_dataset* ds, int B, const int* entry_of, con
   a.n = ld; a.ld = ld; a.p2 = (int)(ld / 2); a.n_lanes = B;
   // (points the model solver produced are zero outside the working set: only its rows of G are read then)
   if (ctl && wa && wa->ws && !getenv("SLM_COV_ALL_ROWS")) { a.ctl = ctl; a.ws = wa->ws; a.idx = wa->idx; }
+  // (more than sixteen lanes: both planes of Z against ONE read of every Gram -- cov_gz32_mfma_kernel)
+  a.lane0 = 0;
+  a.r_plane = halves > 1 ? ld * SPLIT_RSTRIDE : 0;
   const int xblk = launch_cov_gz(ds->eng->cus, a, s, cb, n_sets);
   CovFinishArgs f;
   f.partial = partial; f.z = ds->z; f.g = ds->g; f.done = done; f.nblk = xblk; f.ld = ld;
@@ -922,9 +929,10 @@ static int max_lanes_for(slm_dataset* ds, uint32_t flags) {
     // Two halves of sixteen on ONE read of X (xtr32_mfma_kernel, 0.71 ms against 0.57 at 100k x 5k) where the solve is a
     // working-set solve over X on this device: lanes that advance a point per pass -- the units of a grid, the folds of a
     // search -- then cost 0.6 of what they cost on sixteen (config 4 over X: 159 passes / 0.147 s -> 85 / 0.092 s).
-    // Covariance passes and row-sharded solves stay at sixteen; so do rows beyond 5120 columns (no ring variant:
+    // Covariance passes take thirty-two as well (a launch of the Gram product per half: 13-37 us each against the chain
+    // of a whole pass saved).  Row-sharded solves stay at sixteen; so do rows beyond 5120 columns (no ring variant:
     // every residual from X is a read of the column-major copy per half).
-    if (ws_policy(ds, flags) == 2 && !(flags & SLM_FLAG_COVARIANCE) && !row_sharded(ds) && ds->sk != nullptr && ds->sk->rowdot != nullptr &&
+    if (ws_policy(ds, flags) == 2 && !row_sharded(ds) && ds->sk != nullptr && ds->sk->rowdot != nullptr &&
         getenv("SLM_NO_WIDE_LANES") == nullptr && ensure_xt(ds) == SLM_OK && ds->XT != nullptr)
       return kMaxLanes;
     return SPLIT_LANES;
@@ -999,7 +1007,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   const GradKernel* gk_B = B <= kMaxLanes ? ds->gk[B - 1] : nullptr;
   const bool want_split = (ws_policy(ds, opts ? opts->flags : 0u) == 2 && !wide) ? (big_x || !gk_B) : (big_x && !gk_B);
   // (covariance passes are a form of the split pass: the flag asks for it whatever the size, where Grams exist)
-  const bool want_cov = opts && (opts->flags & SLM_FLAG_COVARIANCE) && !ds->cov.empty() && !row_sharded(ds) && B <= SPLIT_LANES;
+  const bool want_cov = opts && (opts->flags & SLM_FLAG_COVARIANCE) && !ds->cov.empty() && !row_sharded(ds) && B <= kMaxLanes;
   const bool split = (want_split || want_cov) && split_usable(ds);
   // Shared path with the working set on from the start: the lanes take the points of the path in turn
   // (lane l: l, l + B, ...) instead of contiguous ranges.  Every lane then starts near alpha_max, where
@@ -1138,7 +1146,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     }
     if (cov_on) {
       for (int l = 0; l < B; ++l) cov_entry[l] = entry_of_set[uniq_of[l]];
-      if (!ds->cov_Z) SLM_TRY(dalloc(&ds->cov_Z, (size_t)ld * SPLIT_RSTRIDE));
+      if (!ds->cov_Z) SLM_TRY(dalloc(&ds->cov_Z, (size_t)ld * SPLIT_RSTRIDE * SPLIT_HALVES));
     }
   }
   // ---- Lipschitz constants -----------------------------------------------------------------------

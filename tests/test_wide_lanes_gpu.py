@@ -32,7 +32,7 @@ def test_max_lanes_tells_where_thirty_two_are_served(eng):
     X, y = _problem(rng, 900, 300, 10, 1.0)
     with eng.dataset(X, y) as ds:
         assert ds.max_lanes(WS) == _engine.MAX_LANES_WIDE == 32  # working-set solves on the split pass
-        assert ds.max_lanes(WS | _engine.FLAG_COVARIANCE) == 16  # covariance passes: a half
+        assert ds.max_lanes(WS | _engine.FLAG_COVARIANCE) == 32  # covariance passes as well: the Gram product a launch per half
         assert ds.max_lanes(PLAIN) <= 16
         pts = [(0.1, 0.0, 0.0)]
         with pytest.raises(ValueError):
@@ -77,6 +77,50 @@ def test_thirty_two_independent_lanes_with_fold_masks(eng, grouped):
         assert np.max(np.abs(wide[l].betas - q.betas)) < 1e-7 * np.max(np.abs(q.betas))
     gidx, Gn = oracle.group_index(gid, p)
     for l in (17, 30):
+        m = masks[l // 8]
+        sa, sb, sd = specs[l]["points"][-1]
+        bo, _ = oracle.fista(X[m > 0], y[m > 0], sa, sb, sd, gidx, Gn, beta0=wide[l].betas[-1], tol=1e-13)
+        assert np.max(np.abs(wide[l].betas[-1] - bo)) < 1e-6 * np.max(np.abs(bo))
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_thirty_two_lanes_on_covariance_passes(eng, grouped):
+    """The cells of a grid from the folds' Grams (SLM_FLAG_COVARIANCE), thirty-two to a call: every pass multiplies each fold's
+    Gram by both halves' points (a launch per half).  Against sixteen at a time, against the same lanes over X, against
+    oracle.fista on a fold's rows; lanes that finish early (short paths in the second half) leave their half idle."""
+    rng = np.random.default_rng(21 + grouped)
+    n, p = 2400, 420
+    X, y = _problem(rng, n, p, 18, 2.0)
+    fold = rng.integers(0, 4, n)
+    masks = [(fold != f).astype(float) for f in range(4)]
+    gid = rng.permutation(np.arange(p) % (p // 6)).astype(np.int32) if grouped else None
+    G = p // 6 if grouped else p
+    COV = _engine.FLAG_COVARIANCE
+    with eng.dataset(X, y) as ds:
+        if grouped:
+            ds.set_groups(gid, G)
+        ds.covariance_folds(masks, [int(m.sum()) for m in masks])
+        specs = []
+        for f in range(4):
+            m = masks[f]
+            c = X.T @ (m * y) / m.sum()
+            top = float(np.max(np.sqrt(np.bincount(gid, weights=c * c, minlength=G)))) if grouped else float(np.max(np.abs(c)))
+            for r in range(8):
+                al = np.geomspace(top, (0.02 + 0.01 * r) * top, 12 if f < 2 else 3 + r)  # (the second half: shorter paths, done early)
+                pts = np.c_[0.3 * al, 0.7 * al, 0 * al] if grouped else np.c_[al, 0 * al, 0 * al]
+                specs.append(dict(points=pts, row_weight=m, n_eff=int(m.sum())))
+        wide = ds.solve_lanes(specs, tol=1e-10, flags=WS | COV)
+        again = ds.solve_lanes(specs, tol=1e-10, flags=WS | COV)
+        half = ds.solve_lanes(specs[:16], tol=1e-10, flags=WS | COV) + ds.solve_lanes(specs[16:], tol=1e-10, flags=WS | COV)
+        over_x = ds.solve_lanes(specs, tol=1e-10, flags=WS)
+    assert len(wide) == 32 and all(r.converged for r in wide + half + over_x)
+    for a, b, c, d in zip(wide, half, again, over_x):
+        scale = np.max(np.abs(d.betas))
+        assert np.max(np.abs(a.betas - b.betas)) < 1e-7 * scale
+        assert np.max(np.abs(a.betas - d.betas)) < 1e-7 * scale
+        assert np.array_equal(a.betas, c.betas)
+    gidx, Gn = oracle.group_index(gid, p)
+    for l in (5, 19, 31):
         m = masks[l // 8]
         sa, sb, sd = specs[l]["points"][-1]
         bo, _ = oracle.fista(X[m > 0], y[m > 0], sa, sb, sd, gidx, Gn, beta0=wide[l].betas[-1], tol=1e-13)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# The profile set of round 5, collection: run on the GPU box from the repository root as `bash tools/r05_profile.sh <tag>` (e.g. r05c);
+# everything lands under gpurun_out/ (the only directory that travels back); tools/r05_condense.sh <tag> then writes profiles/<tag>_*.
+# Every rocprofv3 run has the program itself after `--`; counters run in passes of their own (kernel trace / stats only beside them).
+set -o pipefail
+TAG=${1:-r05c}
+R=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 6 --warmup 2 --cpu-budget 0 --no-extra"
+rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- $B > $R/gpurun_out/${TAG}_bench_under_rocprof.log 2> $R/gpurun_out/${TAG}_bench_under_rocprof.err && echo stats ok
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --no-extra > /dev/null 2>&1 && echo fetch ok
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --no-extra > /dev/null 2>&1 && echo write ok
+cd $R
+python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.log 2> gpurun_out/${TAG}_bench.err && echo bench ok
+python tools/lanes_sweep.py 16 17 18 19 20 22 25 26 32 0 > gpurun_out/${TAG}_lanes_sweep.log 2>&1 && echo lanes ok
+python tools/config3_lanes.py 16 18 20 25 32 0 > gpurun_out/${TAG}_config3_lanes.log 2>&1 && echo config3 ok
+python tools/headline_soak.py 96 > gpurun_out/${TAG}_headline_soak.log 2>&1 && echo soak ok
+python tools/group_soak.py 24 > gpurun_out/${TAG}_group_soak.log 2>&1 && echo group soak ok
+python tools/ws_fuzz.py 1500 17 > gpurun_out/${TAG}_ws_fuzz.log 2>&1; tail -2 gpurun_out/${TAG}_ws_fuzz.log
+python tools/mg_fuzz.py 80 5 > gpurun_out/${TAG}_mg_fuzz.log 2>&1; tail -2 gpurun_out/${TAG}_mg_fuzz.log
+python tools/carry_fuzz.py $(seq 0 19) > gpurun_out/${TAG}_carry_fuzz.log 2>&1; tail -2 gpurun_out/${TAG}_carry_fuzz.log
+python tools/covariance_fuzz.py 200 3 > gpurun_out/${TAG}_covariance_fuzz.log 2>&1; tail -2 gpurun_out/${TAG}_covariance_fuzz.log
+python tools/on_chip_fuzz.py 600 5 > gpurun_out/${TAG}_on_chip_fuzz.log 2>&1; tail -2 gpurun_out/${TAG}_on_chip_fuzz.log
+python tools/edge_cases.py > gpurun_out/${TAG}_edge_cases.log 2>&1; tail -2 gpurun_out/${TAG}_edge_cases.log
+echo collected: run tools/r05_condense.sh $TAG where gpurun_out/ has been merged back

@@ -10,12 +10,15 @@ import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 tag = sys.argv[1]
-n, p, lanes = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (100_000, 5_000, 16)
+n, p, lanes = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (100_000, 5_000, 18)
 src = "sparse-lm_amd/csrc/split_kernels.hpp"
-kernel = "slm::xtr_mfma_kernel(slm::SplitArgs)"
+# the kernel of the headline's passes: sixteen lanes on the matrix cores, up to four more on the vector units beside them
+kernel = ("slm::xtr_mfma_kernel(slm::SplitArgs)" if lanes <= 16 else "slm::xtr18_mfma_kernel(slm::SplitArgs)" if lanes <= 18 else
+          "slm::xtr20_mfma_kernel(slm::SplitArgs)" if lanes <= 20 else "slm::xtr32_mfma_kernel(slm::SplitArgs)")
+slots = max(16, lanes) if lanes <= 20 else 32
 counters = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_hbm_counters.json")))["kernels"][kernel]
 old = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
-algorithmic = 8.0 * (n * p + 16 * n + 16 * p)
+algorithmic = 8.0 * (n * p + slots * n + slots * p)
 out = {
     "workload": {"n": n, "p": p, "lanes": lanes},
     "kernel": kernel,
