@@ -299,7 +299,7 @@ typedef struct slm_solve_stats {
  *    lane -- over the same rows and row weights; the penalty may differ: the rounds of an Adaptive* estimator
  *    (model/_adaptive_lasso.py:206-232), a refit -- the solve starts at the point whose gradient the engine still holds
  *    (within the tolerance of beta0) and does not run its first pass over the data.  SLM_NO_CARRY=1 turns it off.
- *  - sample start: a path on several lanes without a warm start opens on the first eighth of the rows -- enough to
+ *  - sample start: a path on several lanes without a warm start opens on the first quarter of the rows -- enough to
  *    rank the features for the first working set, on which the model's linear term is then formed exactly from the
  *    gathered columns; nothing is accepted on the estimate.  SLM_NO_SAMPLE_START=1 opens on all rows.
  */

@@ -1651,6 +1651,7 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     if (const char* e = getenv("SLM_WS_BB")) wa.bb_steps = atoi(e) != 0;
     wa.one_solver = 0;
     if (const char* e = getenv("SLM_WS_ONE_SOLVER")) wa.one_solver = atoi(e) != 0;
+    wa.hard_call = getenv("SLM_HARD_CALLWIDE") != nullptr;
     return SLM_OK;
   };
   // no memory for the working-set buffers: the plain iteration still works (unless this solve runs
@@ -1795,9 +1796,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // ---- sample start ------------------------------------------------------------------------------------------------
   // A cold path -- no lane brings a warm start -- used to open with a pass over X for the gradient at zero, of which the solve
   // uses two things: the choice of the first working set, and -- on it -- the exact linear term of the model.  The choice
-  // needs the ranking of |X_j^T y|, which an eighth of the rows gives (a feature that enters on the first band of alphas
-  // stands far above the sampling noise); the linear term on W is X_W^T y, one read of the gathered columns.  So the path
-  // opens on the first n / 8 rows (70 us instead of 570), nothing is accepted on that estimate (TailArgs::provisional),
+  // needs the ranking of |X_j^T y|, which a quarter of the rows gives (a feature that enters on the first band of alphas
+  // stands above the sampling noise); the linear term on W is X_W^T y, one read of the gathered columns.  So the path
+  // opens on the first n / 4 rows (150 us instead of 570), nothing is accepted on that estimate (TailArgs::provisional),
   // the model of the first refinement is exact on W, and the first pass over ALL of X already verifies the first band:
   // 4 passes per 50-alpha path instead of 5.  What the sample ranks wrongly the verification finds (a miss: the columns
   // are appended and the point is verified again, as after any pass) -- rows in an order that makes their head
@@ -1814,7 +1815,17 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
         !custom_scale && expected > 0 && o.max_iter >= 4 && !(o.flags & SLM_FLAG_FISTA_ONLY) && getenv("SLM_NO_SAMPLE_START") == nullptr) {
       int64_t least = 65536;  // (below it a pass costs little more than the launches of the sample's)
       if (const char* e = getenv("SLM_SAMPLE_START_MIN_ROWS")) least = std::max<int64_t>(64, atoll(e));  // (tests)
-      if (n >= least) n_sample = n / 8;
+      // A quarter of the rows (round 4: an eighth).  The sample has to rank the features of the first band's DEEPEST point
+      // above the noise features: a gradient entry of the sample carries noise sd(y) / sqrt(rows) -- on the headline's law
+      // 3.7 from an eighth of the rows, 2.6 from a quarter -- and the largest of 5 000 noise entries is 3.7 sd: from an
+      // eighth the features entering at point 16-17 of eighteen lanes (|beta| about 9) sit INSIDE the noise features' range
+      // (67 of those above 9), from a quarter above it (2).  Measured over eight draws of the headline's law
+      // (tools/headline_data_seeds.py): eighteen lanes 34 passes / 4.43 ms per path on an eighth, 30 / 3.75 on a quarter,
+      // 27 / 3.39 on a half; sixteen lanes 4.11 / 3.89 / 3.78; the bench's own draw 2.86 either way; the soak law's twelve
+      // 91.6 -> 92.8 ms in total (a half: 98.2).  SLM_SAMPLE_DIV sets the divisor.
+      int div = 4;
+      if (const char* e = getenv("SLM_SAMPLE_DIV")) div = std::max(1, std::min(64, atoi(e)));
+      if (n >= least) n_sample = n / div;
     }
   }
   // ---- model Gram (mg_kernels.hpp) -----------------------------------------------------------------------------------
@@ -2108,8 +2119,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       stats->ws_direct_steps = wc.newton_steps;
       const char* trc = getenv("SLM_TRACE");
       if (trc && trc[0] == '2') {
-        fprintf(stderr, "[slm] working set: %d model-solver iterations over %d refinements, %d direct steps (%d refused, %d of them not positive definite), K = %d\n",
-                wc.inner_iters, wc.refined, wc.newton_steps, wc.newton_fails, wc.newton_nopd, wc.K);
+        fprintf(stderr, "[slm] working set: %d model-solver iterations over %d refinements, %d direct steps (%d refused, %d of them not positive definite), K = %d, lambda_max bound of the first Gram %.4g (seed L %.4g)\n",
+                wc.inner_iters, wc.refined, wc.newton_steps, wc.newton_fails, wc.newton_nopd, wc.K, wc.Lw[0], fin[0].L);
         fprintf(stderr, "[slm] model solver, lane 0, ms over the solve: set-up %.3f, lambda_max of a new Gram %.3f, start value %.3f, "
                 "iteration %.3f, acceptance + write-back %.3f\n", wc.solve_ticks[0] * 1e-5, wc.solve_ticks[1] * 1e-5,
                 wc.solve_ticks[2] * 1e-5, wc.solve_ticks[3] * 1e-5, wc.solve_ticks[4] * 1e-5);

@@ -654,7 +654,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void mg_step_kernel(TailArgs a, MgArg
     rq_n += 1;
   }
   bool redo = false;
-  if (have_prev && s[4] > 0.0 && sqrt(s[5] / s[4]) > L) {  // the bound was too low
+  if (have_prev && s[4] > 1e-20 * s[1] && s[4] > 0.0 && sqrt(s[5] / s[4]) > L) {  // the bound was too low (a move at the rounding level measures nothing)
     L = 1.05 * sqrt(s[5] / s[4]);
     if (!spectral) {  // an accelerated step of 1 / L was too long: again from x
       Ls = L;

@@ -105,6 +105,10 @@ struct WsCtl {
                       // lanes are outgrowing the working set (solve_core turns the model-Gram rounds on, mg_kernels.hpp)
   int32_t served[SLM_MAX_LANES];  // lanes the model solver moved since the model-Gram rounds last looked (mg_begin_kernel,
                                   // mg_kernels.hpp: what the working set serves is not served twice)
+  int32_t hard_lane[SLM_MAX_LANES];  // a refinement of THIS lane needed direct steps: its next ones start with them.  (Round 5:
+                                     // per lane, not per call -- one refinement of 31 iterations among the 84 of a path sent
+                                     // every later one of all eighteen lanes through two factorisations of 200 unknowns, 0.4 ms
+                                     // each where eight iterations take 20 us: 26 ms for an 8-pass path, soak seed 29)
 };
 
 struct WsArgs {
@@ -136,6 +140,7 @@ struct WsArgs {
   int32_t k_init;      // a fresh selection is cut down to this size (or to its non-zeros)
   int32_t bb_steps;    // the model solver opens with spectral steps (SLM_WS_BB=0: accelerated steps throughout)
   int32_t one_solver;  // SLM_WS_ONE_SOLVER=1: every lane goes to the solver with direct steps (measurements)
+  int32_t hard_call;   // SLM_HARD_CALLWIDE=1 (A/B runs): direct steps once needed start every later refinement of the CALL
   int32_t keep_full;   // a selection that does not fit leaves W as it is (`stale`: the lanes it no longer covers are served by
                        // the model-Gram rounds) instead of selecting, gathering and multiplying afresh pass after pass
 };
@@ -1066,7 +1071,8 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
   // discover their support in waves -- is a different matter from one the model cannot settle)
   const int reps = (ws->last_point[lane_id] == point_now && ws->last_cols[lane_id] == ws->Kreal) ? ws->repeats[lane_id] : 0;
   if (reps >= WS_MAX_REPEATS) return true;
-  if (!DIRECT && w.nt != nullptr && ws->hard != 0) {  // a solve of this call needed direct steps: so may this one
+  const int hard_now = w.hard_call ? ws->hard : ws->hard_lane[lane_id];
+  if (!DIRECT && w.nt != nullptr && hard_now != 0) {  // a refinement of this lane needed direct steps: so may this one
     if (tid == 0) ws->want_full[lane_id] = 1;
     return false;
   }
@@ -1735,9 +1741,17 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
   // direct mode: the iterate only moves by direct steps; the prox-gradient step of every round is just the
   // convergence test (taken when it passes).  Taking it regardless would wreck the next direct step: from a
   // face minimiser one prox-gradient step gives EVERY violator a tiny non-zero value, and a free set full of
-  // those solves for a direction that means nothing.  A solve starts in this mode when an earlier refinement
-  // of this call needed direct steps (WsCtl::hard, published between passes by ws_select_kernel).
-  bool direct_mode = direct_on && ws->hard != 0;
+  // those solves for a direction that means nothing.  A solve starts in this mode when an earlier refinement of ITS LANE
+  // of this call needed direct steps (WsCtl::hard_lane).
+  bool direct_mode = direct_on && hard_now != 0;
+  // the length scale of the problem on W: a gradient step from the expansion point, ||g0_W|| / L (what "rounding level" is
+  // measured against where the iterate itself is zero or dust)
+  double scale2;
+  {
+    double sg[1] = {mine ? g0 * g0 : 0.0};
+    block_sum<1>(sg, red);
+    scale2 = sg[0] / (Lw * Lw);
+  }
   // The first WS_BB_ITERS steps carry no momentum and take their length from the curvature along the move
   // before: on the well-conditioned faces of an easy path that is there in half the steps of the accelerated
   // iteration, which takes over if it is not.
@@ -1772,12 +1786,18 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
     v_prev = v;
     gv_prev = gv;
     have_prev = true;
-    if (s[4] > 1e-20 * s[1] && s[4] > 0.0) {  // (a move at the rounding level measures nothing)
+    if (s[4] > 1e-20 * fmax(s[1], scale2) && s[4] > 0.0) {  // (a move at the rounding level measures nothing)
       const double rq = s[6] / s[4];
       if (rq > 0.0 && (rq_n == 0 || rq < rq_min)) rq_min = rq;
       rq_n += 1;
     }
-    if (s[4] > 0.0 && sqrt(s[5] / s[4]) > L) {  // the bound was too low
+    // (a move at the rounding level measures no curvature either -- and "rounding level" has to be told on the scale of
+    //  the PROBLEM, not of the iterate: the point at alpha_max solves to rounding dust (|g_j| - alpha = 1e-16 for the
+    //  first feature), its moves are dust against dust, ||dg|| / ||dv|| of one of them sent L from 1.7 to 44 -- through
+    //  WsCtl::Lw for every later refinement of the call, whose Rayleigh quotients then all "said" ill-conditioned: 170
+    //  direct steps of 200 unknowns on an iid design, 26 ms for an 8-pass path, soak seed 29)
+    const bool real_move = s[4] > 1e-20 * fmax(s[1], scale2) && s[4] > 0.0;
+    if (real_move && sqrt(s[5] / s[4]) > L) {  // the bound was too low
       L = 1.05 * sqrt(s[5] / s[4]);
       if (!spectral) {  // an accelerated step of 1/L was too long: redo it from x (a spectral step claims nothing of L)
         Ls = L;
@@ -1797,7 +1817,9 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
       }
     }
     // (a spectral step is longer than 1/L and moves at least as far from the same point: the test is the stricter for it)
-    const bool inner_conv = sqrt(s[0]) <= WS_INNER_TOL * tol * sqrt(s[1]);
+    // (... or the step is rounding noise on the problem's scale, the floor of fista_tail_kernel's stopping rule: a solution
+    //  that IS dust -- the path's first point -- has converged, it does not iterate thirty times and take a direct step)
+    const bool inner_conv = sqrt(s[0]) <= fmax(WS_INNER_TOL * tol * sqrt(s[1]), kRoundFloor * (sqrt(scale2) + sqrt(s[1])));
     if (DIRECT && direct_mode && !inner_conv) {
       bool stepped = false;
       if (n_direct < WS_NEWTON_MAX) {
@@ -1928,7 +1950,10 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
     atomicAdd(&ws->inner_iters, n_inner);
     atomicAdd(&ws->iters_hist[n_inner < 31 ? n_inner : 31], 1);
     if (n_direct) atomicAdd(&ws->newton_steps, n_direct - n_direct_bad);
-    if (n_direct > n_direct_bad) ws->hard_next = 1;  // (same value from every lane: the order of the stores is immaterial)
+    if (n_direct > n_direct_bad) {
+      ws->hard_next = 1;  // (same value from every lane: the order of the stores is immaterial)
+      ws->hard_lane[lane_id] = 1;
+    }
     if (n_direct_bad) atomicAdd(&ws->newton_fails, n_direct_bad);
     // strong convexity on the face of the refined point, for the stopping rule of the pass that verifies it
     // (fista_tail_kernel): from the factor when a direct step stood, else from the iteration's own moves

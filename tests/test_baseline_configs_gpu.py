@@ -47,6 +47,12 @@ def test_config2_lasso_path_full_size_is_kkt_certified(eng):
         alphas = np.geomspace(amax, 1e-3 * amax, 50)
         res = ds.solve_path([(a, 0.0, 0.0) for a in alphas])
         assert res.converged
+        # the engine's choice of lanes (slm_solve_path_lanes, n_lanes = 0): eighteen for fifty single-feature points -- sixteen
+        # on the matrix cores, two on the vector units beside them -- three passes over X (sixteen lanes: four)
+        assert ds.path_lanes(50) == 18 and ds.path_lanes(16) == 16 and ds.path_lanes(100) == 20
+        auto = ds.solve_path([(a, 0.0, 0.0) for a in alphas], lanes=0)
+        assert auto.converged and auto.grad_launches <= 4
+        assert np.max(np.abs(auto.betas - res.betas)) < 1e-6 * np.max(np.abs(res.betas))
         # alpha_max comes from another kernel's gradient (different summation order): the first point is zero
         # up to that rounding
         assert np.max(np.abs(res.betas[0])) <= 1e-12 * np.max(np.abs(res.betas[-1]))
@@ -80,7 +86,10 @@ def test_headline_path_with_a_dense_end_leaves_the_working_set_and_stays_certifi
         res = ds.solve_path(pts, lanes=16)
         ref = ds.solve_path(pts, lanes=4, flags=_engine.FLAG_NO_WORKING_SET, tol=1e-9)
         plain = ds.solve_path(pts, lanes=16, flags=_engine.FLAG_NO_MODEL_GRAM)
-        assert res.converged and ref.converged and plain.converged
+        auto = ds.solve_path(pts, lanes=0)  # (eighteen lanes; the model Gram is in place: measured 9 passes, 16.4 ms)
+        assert res.converged and ref.converged and plain.converged and auto.converged
+        assert auto.mg_rounds > 0 and auto.grad_launches <= 12
+        assert np.max(np.abs(auto.betas - ref.betas)) < 1e-6 * np.max(np.abs(ref.betas))
         nnz = (res.betas != 0).sum(axis=1)
         assert nnz[-1] >= 2000 and res.ws_builds >= 1 and res.ws_refined >= 16
         # the dense regime: two passes per band of sixteen points where the plain steps took eight to twelve
@@ -110,6 +119,11 @@ def test_config3_group_lasso_path_full_size_is_kkt_certified(eng):
         alphas = np.geomspace(bmax, 1e-3 * bmax, 50)
         res = ds.solve_path([(0.0, a, 0.0) for a in alphas], want_group_norms=True)
         assert res.converged
+        # the engine's choice for a path in contiguous ranges: twenty-five lanes, two passes (sixteen lanes: four)
+        assert ds.path_lanes(50) == 25
+        auto = ds.solve_path([(0.0, a, 0.0) for a in alphas], lanes=0)
+        assert auto.converged and auto.grad_launches <= 3
+        assert np.max(np.abs(auto.betas - res.betas)) < 1e-6 * np.max(np.abs(res.betas))
         # alpha_max comes from another kernel's gradient (different summation order): the first point is zero
         # up to that rounding
         assert np.max(np.abs(res.betas[0])) <= 1e-12 * np.max(np.abs(res.betas[-1]))
