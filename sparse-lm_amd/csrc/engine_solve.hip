@@ -1652,6 +1652,14 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     wa.one_solver = 0;
     if (const char* e = getenv("SLM_WS_ONE_SOLVER")) wa.one_solver = atoi(e) != 0;
     wa.hard_call = getenv("SLM_HARD_CALLWIDE") != nullptr;
+    wa.miss_factor = 4;
+    if (const char* e = getenv("SLM_WS_MISS_FACTOR")) wa.miss_factor = std::max(1, std::min(8, atoi(e)));
+    // (0.5 left a first working set of 56-112 columns to the luck of the bisection: 65 on one draw of the headline's law, 102 on
+    //  another -- and the features of the first band's deepest points outside the small ones; 0.75: the soak law's twelve paths 92.6 -> 85.0 ms)
+    // (per-feature penalties only: groups come in blocks and start from 384 columns -- config 3's first set 250 -> 300 columns at
+    //  0.75, 2.79 -> 3.44 ms per path)
+    wa.fill = ds->singleton ? 0.75 : 0.5;
+    if (const char* e = getenv("SLM_WS_FILL")) wa.fill = std::max(0.1, std::min(1.0, atof(e)));
     return SLM_OK;
   };
   // no memory for the working-set buffers: the plain iteration still works (unless this solve runs

@@ -140,6 +140,8 @@ struct WsArgs {
   int32_t k_init;      // a fresh selection is cut down to this size (or to its non-zeros)
   int32_t bb_steps;    // the model solver opens with spectral steps (SLM_WS_BB=0: accelerated steps throughout)
   int32_t one_solver;  // SLM_WS_ONE_SOLVER=1: every lane goes to the solver with direct steps (measurements)
+  int32_t miss_factor; // an append after a miss may take this many times append_max (4)
+  double fill;         // a selection cut down to a cap stops bisecting its threshold once it holds this share of the cap
   int32_t hard_call;   // SLM_HARD_CALLWIDE=1 (A/B runs): direct steps once needed start every later refinement of the CALL
   int32_t keep_full;   // a selection that does not fit leaves W as it is (`stale`: the lanes it no longer covers are served by
                        // the model-Gram rounds) instead of selecting, gathering and multiplying afresh pass after pass
@@ -477,7 +479,7 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
       } else {
         hi = mid;
         n_hi = n_sel;
-        if (n_sel >= 0.5 * cap) break;  // close enough to the cap
+        if (n_sel >= w.fill * cap) break;  // close enough to the cap
       }
     }
     if (n_hi == 0.0) count_at(hi, only_new, &n_hi, &smax);
@@ -493,7 +495,7 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
     // anyway shows up as a miss and is appended then)
     // (a lane is stuck: be generous; the first selection of a solve that took over its predecessor's W: as many as a
     //  fresh selection would take -- appended columns cost their own gather and Gram rows only)
-    const double cap = (double)(carried ? max(w.k_init, 4 * w.append_max) : (miss ? 4 * w.append_max : w.append_max));
+    const double cap = (double)(carried ? max(w.k_init, 4 * w.append_max) : (miss ? w.miss_factor * w.append_max : w.append_max));
     if (sweep[0] <= cap) {
       n_sel = sweep[0];
     } else {
