@@ -86,15 +86,17 @@ def test_roofline_traffic_is_quoted_only_for_the_source_it_was_taken_on(tmp_path
     sys.path.insert(0, root)
     import bench
 
-    value, note = bench.measured_traffic(100_000, 5_000, 16, "xtr_mfma_kernel")
     recorded = json.load(open(os.path.join(root, "profiles", "roofline_traffic.json")))
+    lanes = recorded["workload"]["lanes"]  # (round 5: eighteen -- the engine's choice for the headline's fifty points)
+    kernel = recorded["kernel"].split("::")[1].split("(")[0]  # "slm::xtr18_mfma_kernel(slm::SplitArgs)" -> "xtr18_mfma_kernel"
+    value, note = bench.measured_traffic(100_000, 5_000, lanes, kernel)
     src = os.path.join(root, recorded["taken_on"]["kernel_source"])
     if hashlib.sha256(open(src, "rb").read()).hexdigest() == recorded["taken_on"]["kernel_source_sha256"]:
         assert value == recorded["hbm_bytes_per_launch"] and "PMC passes of commit" in note
     else:
         assert value is None and "has changed" in note
-    assert bench.measured_traffic(100_000, 5_000, 4, "xtr_mfma_kernel")[0] is None  # another workload
-    assert bench.measured_traffic(100_000, 5_000, 16, "grad_fused_kernel")[0] is None  # another kernel
+    assert bench.measured_traffic(100_000, 5_000, 4, kernel)[0] is None  # another workload
+    assert bench.measured_traffic(100_000, 5_000, lanes, "grad_fused_kernel")[0] is None  # another kernel
     # a changed source file: the figure is withheld, with the reason
     fake = tmp_path / "repo"
     (fake / "profiles").mkdir(parents=True)
@@ -102,7 +104,7 @@ def test_roofline_traffic_is_quoted_only_for_the_source_it_was_taken_on(tmp_path
     rec = dict(recorded, taken_on=dict(recorded["taken_on"], kernel_source="k.hpp"))
     (fake / "profiles" / "roofline_traffic.json").write_text(json.dumps(rec))
     monkeypatch.setattr(bench, "ROOT", str(fake))
-    value, note = bench.measured_traffic(100_000, 5_000, 16, "xtr_mfma_kernel")
+    value, note = bench.measured_traffic(100_000, 5_000, lanes, kernel)
     assert value is None and "has changed" in note
 
 

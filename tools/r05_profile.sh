@@ -15,6 +15,8 @@ cd $R
 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.log 2> gpurun_out/${TAG}_bench.err && echo bench ok
 python tools/lanes_sweep.py 16 17 18 19 20 22 25 26 32 0 > gpurun_out/${TAG}_lanes_sweep.log 2>&1 && echo lanes ok
 python tools/config3_lanes.py 16 18 20 25 32 0 > gpurun_out/${TAG}_config3_lanes.log 2>&1 && echo config3 ok
+python tools/headline_data_seeds.py > gpurun_out/${TAG}_headline_law_draws.log 2>&1 && echo draws ok
+for d in 8 4 2; do echo "SLM_SAMPLE_DIV=$d" >> gpurun_out/${TAG}_headline_law_draws.log; SLM_SAMPLE_DIV=$d python tools/headline_data_seeds.py >> gpurun_out/${TAG}_headline_law_draws.log 2>&1; done
 python tools/headline_soak.py 96 > gpurun_out/${TAG}_headline_soak.log 2>&1 && echo soak ok
 python tools/group_soak.py 24 > gpurun_out/${TAG}_group_soak.log 2>&1 && echo group soak ok
 python tools/ws_fuzz.py 1500 17 > gpurun_out/${TAG}_ws_fuzz.log 2>&1; tail -2 gpurun_out/${TAG}_ws_fuzz.log
