@@ -1375,7 +1375,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
       // ones that have just solved their neighbours -- not to the first, which would reach them from sixteen points
       // up the path: there the features of the last decade of alpha cannot be told yet, the first verification
       // misses and a large append follows (0.33 ms on the headline path).  (host_logic.hpp: interleaved_walk)
-      const slm_host::LaneWalk w = slm_host::interleaved_walk(l, B, total_points, getenv("SLM_NO_TAIL_BAND") == nullptr);
+      const slm_host::LaneWalk w = slm_host::interleaved_walk(l, B, total_points, getenv("SLM_NO_TAIL_BAND") == nullptr,
+                                                              getenv("SLM_NO_SLACK_DEEP") == nullptr);
       h[l].point = w.first;
       h[l].pt_lo = w.first;
       h[l].n_points = w.n_points;

@@ -128,13 +128,32 @@ struct LaneWalk {
   int32_t stride;
   int32_t tail_pt;   // one more point after the walk, or -1
 };
-inline LaneWalk interleaved_walk(int lane, int B, int64_t total, bool tail_band) {
+inline LaneWalk interleaved_walk(int lane, int B, int64_t total, bool tail_band, bool slack_deep = false) {
   LaneWalk w;
   w.first = lane;
   w.n_points = (int32_t)total;
   w.stride = B;
   w.tail_pt = -1;
   const int64_t rem = total % B, n_reg = total - rem;
+  // Three passes' worth of points with at least two lanes' worth of slack (50 points on 18 lanes: 54 slots): the slack goes
+  // to the lanes that hold the DEEPEST points of the first band -- the points the opening's row sample ranks least
+  // reliably -- which then own that one point and nothing else: a first verification that misses there is repeated beside
+  // the second band and delays nobody (as the last lanes of a uniform walk they owned the deepest point of EVERY band,
+  // and a miss at the first cost the whole path a pass: eight draws of the headline's law).  The other F lanes own three
+  // points each: l, l + B, and as their tail point B + F + l.
+  if (slack_deep && tail_band && total > 2 * (int64_t)B && total <= 3 * (int64_t)B) {
+    const int64_t e = (3 * (int64_t)B - total) / 2, F = B - e;
+    if (e >= 1 && F >= 1) {
+      if (lane >= F) {
+        w.n_points = (int32_t)B;  // (its walk ends with its first point)
+      } else {
+        w.n_points = (int32_t)(B + F);
+        const int64_t t = B + F + lane;
+        if (t < total) w.tail_pt = (int32_t)t;
+      }
+      return w;
+    }
+  }
   if (tail_band && rem > 0 && n_reg >= 2 * (int64_t)B) {
     w.n_points = (int32_t)n_reg;
     if (lane >= B - rem) w.tail_pt = (int32_t)(n_reg + (lane - (B - rem)));

@@ -121,11 +121,11 @@ static void test_row_sets() {
 static void test_interleaved() {
   for (int B = 1; B <= 32; ++B)  // (a shared path runs on up to thirty-two lanes)
     for (int64_t total = B; total <= 200; ++total)
-      for (int tail = 0; tail < 2; ++tail) {
+      for (int tail = 0; tail < 3; ++tail) {  // (2: the slack of a three-pass path to the deepest lanes of the first band)
         std::vector<int> seen((size_t)total, 0);
         int64_t most = 0;
         for (int l = 0; l < B; ++l) {
-          const LaneWalk w = interleaved_walk(l, B, total, tail != 0);
+          const LaneWalk w = interleaved_walk(l, B, total, tail != 0, tail == 2);
           int64_t mine = 0;
           for (int k = w.first; k < w.n_points; k += w.stride) {
             seen[(size_t)k] += 1;
@@ -142,6 +142,11 @@ static void test_interleaved() {
         for (int64_t k = 0; k < total; ++k) CHECK(seen[(size_t)k] == 1);  // every point exactly once
         CHECK(most == (total + B - 1) / B);                               // and no lane walks more than its share
       }
+  {  // 50 points on eighteen lanes: lanes 16 and 17 own points 16 and 17 alone, lane l < 16 owns l, 18 + l and 34 + l
+    const LaneWalk a = interleaved_walk(16, 18, 50, true, true), b = interleaved_walk(3, 18, 50, true, true);
+    CHECK(a.first == 16 && a.n_points == 18 && a.tail_pt == -1 && interleaved_points(a) == 1);
+    CHECK(b.first == 3 && b.n_points == 34 && b.stride == 18 && b.tail_pt == 37 && interleaved_points(b) == 3);
+  }
   const LaneWalk w = interleaved_walk(15, 16, 50, true);  // the headline: 48 regular points, 48 and 49 go to lanes 14, 15
   CHECK(w.n_points == 48 && w.tail_pt == 49 && interleaved_walk(14, 16, 50, true).tail_pt == 48 && interleaved_walk(13, 16, 50, true).tail_pt == -1);
 }
