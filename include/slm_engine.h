@@ -320,9 +320,9 @@ int slm_solve_path(slm_dataset* ds, const slm_penalty* pen, const slm_path_point
  * (n * ld >= 2^26 doubles), use the split pass, whose two halves -- residuals, then X^T R -- run on the
  * matrix cores for sixteen lanes per read of X.  slm_dataset_max_lanes() tells.  Working-set solves on such rows take up
  * to SLM_MAX_LANES = 32 lanes: two halves of sixteen, whose X^T R is ONE read of X for all thirty-two (a row of X in
- * registers is multiplied by both halves' residuals: 0.70 ms against 0.57 at 100k x 5k) -- what slm_solve_path_lanes runs
- * a long path on (50 points: two verifying passes instead of four); covariance passes and row-sharded solves stay at
- * sixteen.
+ * registers is multiplied by both halves' residuals: 0.60-0.71 ms against 0.57 at 100k x 5k); calls of 17 to 20 lanes cost
+ * what sixteen cost (lanes 17..20 ride on the vector units beside the sixteen on the matrix cores); covariance passes
+ * take thirty-two as well (both halves' points against one read of every Gram); row-sharded solves stay at sixteen.
  */
 #define SLM_MAX_LANES 32
 /* ... and of a call the on-chip solver takes (SLM_FLAG_ON_CHIP on a dataset of p <= 128, n * ld <= 2^17): a workgroup per
@@ -379,9 +379,10 @@ int slm_dataset_path_lanes(slm_dataset* ds, int32_t n_points, uint32_t flags, in
  * n_lanes contiguous ranges (the first warm-started from beta0, the others cold); a lane that runs
  * out of points takes over the upper half of what the busiest lane has left, so the lanes finish
  * together whatever the per-point cost profile is.  Same outputs as slm_solve_path.
- * n_lanes = 0 leaves the count to the engine (ABI 17): sixteen, or -- per-feature penalties on a large X, where a path
- * costs ceil(n_points / n_lanes) passes -- eighteen or twenty when that saves a pass (lanes 17..20 ride on the vector
- * units beside the sixteen on the matrix cores, the same read of X: a 50-point path takes three passes instead of four).
+ * n_lanes = 0 leaves the count to the engine (ABI 17), which weighs passes against their price: sixteen; eighteen or
+ * twenty where that saves a pass of a path over a large X (a 50-point path: three passes instead of four when no point
+ * meets a feature outside the working set); up to thirty-two for paths in contiguous ranges (group penalties: 50 points
+ * on twenty-five lanes, two passes).  slm_dataset_path_lanes() tells.
  */
 int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, const slm_path_point* points,
                          int32_t n_points, int32_t n_lanes, const slm_solve_opts* opts,
