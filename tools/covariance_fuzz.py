@@ -28,7 +28,7 @@ for case in range(cases):
     coef = np.where(rng.random(p) < 0.1, 3.0 * rng.standard_normal(p), 0.0)
     y = X @ coef + rng.uniform(0.1, 3.0) * rng.standard_normal(n)
     kind = str(rng.choice(["lasso", "group", "sgl", "ridged"])) if gsz > 1 else "lasso"
-    lanes = int(rng.integers(1, 17))
+    lanes = int(rng.integers(1, 33))  # (thirty-two on working-set solves: both halves against one read of every Gram)
     K = int(rng.integers(1, 9))
     nsets = int(rng.integers(1, 4))
     sets = []
