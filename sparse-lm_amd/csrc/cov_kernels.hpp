@@ -49,9 +49,19 @@ struct CovBatch {
 
 // (the loop is a function of its own: mg_gz_kernel, mg_kernels.hpp, runs it on the model Gram -- with H = 2 for both halves of a
 //  call of more than sixteen lanes on one read of the Gram: the second half's points in a second plane of Z, a.r_plane doubles on)
-template <int H = 1>
+// T: the Gram's element type -- double (the folds' Grams of covariance passes), or float (the model Gram, mg_kernels.hpp:
+// stored in fp32, widened on load, multiplied and summed in fp64 like the other)
+template <int H = 1, typename T = double>
 __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
-  a.X = cb.G[blockIdx.z];
+  const T* GX = reinterpret_cast<const T*>(cb.G[blockIdx.z]);
+  auto load2 = [&](int64_t at) -> d2 {  // two consecutive entries from element offset `at`
+    if constexpr (sizeof(T) == 8) {
+      return *reinterpret_cast<const d2*>(GX + at);
+    } else {
+      const float2 f = *reinterpret_cast<const float2*>(GX + at);
+      return d2{(double)f.x, (double)f.y};
+    }
+  };
   a.partial += (int64_t)blockIdx.z * cb.part_stride;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -108,7 +118,7 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
     for (int t = 0; t < 8; ++t) {
       const int64_t r = rows[t] >= 0 ? rows[t] : 0;  // (a row that is not there multiplies row 0 by zero)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) xv[t][c] = *reinterpret_cast<const d2*>(a.X + r * a.ld + coff[c]);
+      for (int c = 0; c < 4; ++c) xv[t][c] = load2(r * a.ld + coff[c]);
 #pragma unroll
       for (int h = 0; h < H; ++h) rv[h][t] = a.R[(int64_t)h * a.r_plane + r * SPLIT_RSTRIDE + i16];
     }
@@ -128,17 +138,17 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
     const int64_t r0 = (int64_t)by * a.xrows;
     const int64_t r1 = r0 + a.xrows < a.n ? r0 + a.xrows : a.n;
     const int nb = r1 > r0 ? (int)((r1 - r0) / (4 * XTR_U)) : 0;  // full batches
-    const double* xp = a.X + (r0 + kq) * a.ld;
+    const int64_t xp = (r0 + kq) * a.ld;  // (element offset into the Gram)
     const double* rp = a.R + (r0 + kq) * SPLIT_RSTRIDE + i16;
     d2 xa[XTR_U][4], xb[XTR_U][4];
     double ra[H][XTR_U], rb[H][XTR_U];
     auto load = [&](d2(&xv)[XTR_U][4], double(&rv)[H][XTR_U], int b) {
-      const double* xq = xp + (int64_t)b * (4 * XTR_U) * a.ld;
+      const int64_t xq = xp + (int64_t)b * (4 * XTR_U) * a.ld;
       const double* rq = rp + (int64_t)b * (4 * XTR_U) * SPLIT_RSTRIDE;
 #pragma unroll
       for (int u = 0; u < XTR_U; ++u) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xv[u][c] = *reinterpret_cast<const d2*>(xq + (int64_t)u * 4 * a.ld + coff[c]);
+        for (int c = 0; c < 4; ++c) xv[u][c] = load2(xq + (int64_t)u * 4 * a.ld + coff[c]);
 #pragma unroll
         for (int h = 0; h < H; ++h) rv[h][u] = rq[(int64_t)h * a.r_plane + u * 4 * SPLIT_RSTRIDE];
       }
@@ -179,7 +189,7 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
       for (int h = 0; h < H; ++h) rv[h] = ok ? a.R[(int64_t)h * a.r_plane + rr * SPLIT_RSTRIDE + i16] : 0.0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const d2 x = *reinterpret_cast<const d2*>(a.X + rr * a.ld + coff[c]);
+        const d2 x = load2(rr * a.ld + coff[c]);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           acc[h][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, rv[h], acc[h][2 * c], 0, 0, 0);

@@ -246,7 +246,7 @@ struct slm_dataset {
   // model Gram (mg_kernels.hpp, engine_mg.hip): G~ ~ X^T W X / n_global of the dataset's own rows and weights from an fp16
   // product, built when a solve's lanes outgrow the working set and kept for the later solves of the dataset
   struct MgEntry {           // one per row set, found again like the Grams of covariance passes: by the fingerprint of its row weights
-    double* G = nullptr;     // [ld][ld]
+    float* G = nullptr;      // [ld][ld], fp32: the product it came from is good to 1e-4 -- half the bytes of every step of a round
     double fp1 = 0.0, fp2 = 0.0, n_eff = 0.0;
     bool own = false;        // the dataset's own rows and weights (no fingerprint: lanes that bring neither weights nor scaling)
   };

@@ -29,7 +29,7 @@ void mg_free(slm_dataset* ds) {
 // G~ = X^T W X / n_eff into G.  Queued on the engine's stream: column maxima (one read of X), the fp16 operand with the
 // square roots of the row weights folded in (one read of the column-major copy), the product in chunks of rows, the sum of
 // the chunks.  The operand and the chunks' partial tiles are scratch; the stream is drained before they go back to the pool.
-static int mg_build(slm_dataset* ds, const double* w, double n_eff, double* G) {
+static int mg_build(slm_dataset* ds, const double* w, double n_eff, float* G) {
   slm_engine* eng = ds->eng;
   hipStream_t s = eng->stream;
   const int64_t n = ds->n, ld = ds->ld;
@@ -152,7 +152,7 @@ int mg_enqueue_round(slm_dataset* ds, const TailArgs& ta, int n_lanes, int inner
   a.xrows_ws = 0;
   CovBatch cb;
   memset(&cb, 0, sizeof(cb));
-  for (int st = 0; st < n_sets; ++st) cb.G[st] = ds->mg[(size_t)entry_of_set[st]].G;
+  for (int st = 0; st < n_sets; ++st) cb.G[st] = reinterpret_cast<const double*>(ds->mg[(size_t)entry_of_set[st]].G);  // (fp32: cov_gz_body<H, float>)
   for (int l = 0; l < kMaxLanes; ++l) cb.set_of[l] = l < n_lanes ? set_of[l] : 0;
   cb.part_stride = (int64_t)yb * SPLIT_LANES * ld;
   // partial sums: one block of [row blocks][16][ld] per half of the lanes and row set (the gradient's own buffer holds two)
@@ -227,7 +227,10 @@ extern "C" int slm_dataset_model_gram(slm_dataset* ds, double* G_out) {
   SLM_TRY(mg_ensure(ds, nullptr, (double)ds->n_global, true, 0.0, 0.0, &entry));
   if (G_out) {
     HIP_TRY(hipStreamSynchronize(ds->eng->stream));
-    HIP_TRY(hipMemcpy(G_out, ds->mg[(size_t)entry].G, sizeof(double) * (size_t)ds->ld * (size_t)ds->ld, hipMemcpyDeviceToHost));
+    const size_t count = (size_t)ds->ld * (size_t)ds->ld;
+    std::vector<float> host(count);  // (stored in fp32; the caller's array is fp64)
+    HIP_TRY(hipMemcpy(host.data(), ds->mg[(size_t)entry].G, sizeof(float) * count, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < count; ++i) G_out[i] = (double)host[i];
   }
   return SLM_OK;
 }

@@ -1845,8 +1845,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
   // host looks at every pass's snapshot before it queues the next: a round is sized by what the last one needed.
   const char* mg_env = getenv("SLM_MG");
   const bool mg_forced = mg_env != nullptr && mg_env[0] == '2';  // (tests: any size, from the first snapshot on)
-  // (the model Grams of a dataset are kept within 6 GB: sixteen row sets at p = 5 000, seven at 10 000)
-  const int mg_cap = slm_host::model_gram_cap(ld, 6.0e9, kMgEntries);
+  // (the model Grams of a dataset, fp32, are kept within 3 GB: sixteen row sets at p = 5 000, seven at 10 000)
+  const int mg_cap = slm_host::model_gram_cap(ld, 3.0e9, kMgEntries);
   const bool mg_ok = use_ws && split && (big_x || mg_forced) && !sharded && !cov_on && !(o.flags & SLM_FLAG_NO_MODEL_GRAM) &&
                      (size_t)ds->lane_cap >= (size_t)kMaxLanes && ws_n_sets <= mg_cap && mg_possible(ds);
   if (mg_ok && mg_forced) expected = 0;  // (tests: polled from the first chunk on, so that short solves reach the rounds too)

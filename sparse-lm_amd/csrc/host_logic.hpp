@@ -263,7 +263,7 @@ SLM_HD inline void triangle_tile_fast(int t, int* I_out, int* J_out) {
 
 // model Grams a dataset may keep: kept within `budget_bytes` (8 ld^2 each), at least one, at most `most`
 inline int model_gram_cap(int64_t ld, double budget_bytes, int most) {
-  const double each = 8.0 * (double)ld * (double)ld;
+  const double each = 4.0 * (double)ld * (double)ld;  // (fp32)
   return (int)std::max<double>(1.0, std::min<double>((double)most, budget_bytes / each));
 }
 

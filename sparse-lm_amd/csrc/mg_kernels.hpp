@@ -365,7 +365,7 @@ struct MgReduceArgs {
   int n_tiles, n_chunks;
   int64_t ld;
   double inv_n;
-  double* G;  // [ld][ld]
+  float* G;  // [ld][ld]  (fp32: the entries are good to 1e-4 of the columns' scales; sums in fp64 up to the store)
 };
 static __global__ __launch_bounds__(256) void mg_reduce_kernel(MgReduceArgs a) {
   __shared__ double tile[32][33];
@@ -386,9 +386,9 @@ static __global__ __launch_bounds__(256) void mg_reduce_kernel(MgReduceArgs a) {
     for (int c = 0; c < a.n_chunks; ++c) s += (double)src[(int64_t)c * a.n_tiles * (MG_TILE * MG_TILE)];
     const int ei = ig < a.ld ? mg_scale_exp(a.cmax[ig]) : 0;
     const double v = s * ldexp(a.inv_n, ei + ej);
-    tile[ty + 8 * rr][tx] = v;
+    tile[ty + 8 * rr][tx] = (double)(float)v;  // (the mirrored entry is the stored one: symmetric to the bit)
     const bool lower = !(I == J && col > row);
-    if (lower && ig < a.ld && jg < a.ld) a.G[ig * a.ld + jg] = v;
+    if (lower && ig < a.ld && jg < a.ld) a.G[ig * a.ld + jg] = (float)v;
   }
   __syncthreads();
 #pragma unroll
@@ -397,7 +397,7 @@ static __global__ __launch_bounds__(256) void mg_reduce_kernel(MgReduceArgs a) {
     const int col = 32 * sx + ty + 8 * rr, row = 32 * sy + tx;
     const int64_t ig = (int64_t)I * MG_TILE + row, jg2 = (int64_t)J * MG_TILE + col;
     const bool strictly_lower = !(I == J && col >= row);
-    if (strictly_lower && ig < a.ld && jg2 < a.ld) a.G[jg2 * a.ld + ig] = tile[tx][ty + 8 * rr];
+    if (strictly_lower && ig < a.ld && jg2 < a.ld) a.G[jg2 * a.ld + ig] = (float)tile[tx][ty + 8 * rr];
   }
 }
 
@@ -430,18 +430,22 @@ __device__ __forceinline__ bool mg_any_active(const MgCtl* mg, int half) {
 }
 
 // the product of an inner iteration for one half of the lanes: cov_gz_mfma_kernel's loop on (G~, that half's plane of Z),
-// skipped when no lane of the half iterates any more
+// skipped when no lane of the half iterates any more.  (G~ is stored in fp32 -- it is good to 1e-4 -- and widened on load:
+// half the footprint, sixteen row sets within 3 GB at p = 5 000.  The product itself stays in fp64: an fp32 form on
+// v_mfma_f32_16x16x4_f32 was built and measured -- the soak law's seven dense-ended paths 93.8 ms against 91.5, config 4's
+// dense grid 0.317 s against 0.322: the launch is bound by neither the matrix cores nor the Gram's bytes but by the 250
+// short workgroups of a 35 us kernel -- and removed.)
 static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void mg_gz_kernel(SplitArgs a, CovBatch cb, const MgCtl* mg, int half) {
   if (a.done != nullptr && *a.done != 0) return;
   if (!mg_any_active(mg, half)) return;
-  cov_gz_body<1>(a, cb);
+  cov_gz_body<1, float>(a, cb);
 }
 // both halves of a call of more than sixteen lanes on ONE read of the Gram (a.R: plane 0 of Z, a.r_plane on: plane 1)
 static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void mg_gz32_kernel(SplitArgs a, CovBatch cb, const MgCtl* mg) {
   if (a.done != nullptr && *a.done != 0) return;
   const bool on0 = mg_any_active(mg, 0), on1 = mg_any_active(mg, 1);
   if (!on0 && !on1) return;
-  cov_gz_body<2>(a, cb);
+  cov_gz_body<2, float>(a, cb);
 }
 
 // The product's partial sums folded over the row blocks, in block order: gd[l][j] = sum_b partial[b][l][j].  A kernel of

@@ -209,8 +209,8 @@ static void test_find_and_tiles() {
     triangle_tile_fast(tt, &c, &d);
     CHECK(a == c && b == d && a * (a + 1) / 2 + b == tt && b <= a);
   }
-  CHECK(model_gram_cap(5008, 6.0e9, 16) == 16 && model_gram_cap(10000, 6.0e9, 16) == 7 && model_gram_cap(16384, 6.0e9, 16) == 2 &&
-        model_gram_cap(100000, 6.0e9, 16) == 1);
+  CHECK(model_gram_cap(5008, 3.0e9, 16) == 16 && model_gram_cap(10000, 3.0e9, 16) == 7 && model_gram_cap(16384, 3.0e9, 16) == 2 &&
+        model_gram_cap(100000, 3.0e9, 16) == 1);
 }
 
 int main() {
