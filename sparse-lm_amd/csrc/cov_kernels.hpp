@@ -51,8 +51,24 @@ struct CovBatch {
 //  call of more than sixteen lanes on one read of the Gram: the second half's points in a second plane of Z, a.r_plane doubles on)
 // T: the Gram's element type -- double (the folds' Grams of covariance passes), or float (the model Gram, mg_kernels.hpp:
 // stored in fp32, widened on load, multiplied and summed in fp64 like the other)
+// `need_in`: bit h = half h of the launch has a lane that wants this product (the caller's own test -- mg_gz*_kernel: lanes
+// still iterating); the body adds what it can tell itself: a half none of whose lanes belongs to THIS row set (blockIdx.z)
+// -- or, with control blocks, none of whose live lanes does -- is not multiplied (a grid's lanes come fold by fold: of
+// five row sets and thirty-two lanes most (set, half) pairs are empty), and a workgroup with nothing to do returns before
+// it reads a byte.
 template <int H = 1, typename T = double>
-__device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
+__device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb, unsigned need_in = ~0u) {
+  unsigned need = need_in & ((1u << H) - 1u);
+  unsigned setmask[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const int l = (int)(threadIdx.x & 63);
+    const int L = SPLIT_LANES * (a.lane0 + h) + l;
+    const bool mine = l < SPLIT_LANES && L < a.n_lanes && cb.set_of[L < SLM_MAX_LANES ? L : 0] == (int)blockIdx.z;
+    setmask[h] = (unsigned)__ballot(mine);
+    if (setmask[h] == 0u) need &= ~(1u << h);
+  }
+  if (need == 0u) return;
   const T* GX = reinterpret_cast<const T*>(cb.G[blockIdx.z]);
   auto load2 = [&](int64_t at) -> d2 {  // two consecutive entries from element offset `at`
     if constexpr (sizeof(T) == 8) {
@@ -91,15 +107,17 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
   bool listed = false;
   if (a.ctl != nullptr && a.ws != nullptr && a.xrows_ws > 0) {
     // (a.lane0: the first half of the call this launch serves -- enqueue_gradient_cov; H = 2: both halves here)
-    bool any_live = false, all_on = true;
+    bool all_on = true;
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       unsigned live, on_ws;
       split_masks(a, live, on_ws, a.lane0 + h);
-      any_live = any_live || live != 0u;
+      live &= setmask[h];  // (this row set's lanes: the others' points are multiplied by THEIR Gram, in their grid slice)
+      on_ws &= setmask[h];
+      if (live == 0u) need &= ~(1u << h);
       all_on = all_on && live == on_ws;
     }
-    if (!any_live) return;  // (lanes that have all finished: nothing to multiply)
+    if (need == 0u) return;  // (lanes that have all finished: nothing to multiply)
     listed = all_on && (int64_t)a.xrows_ws * (int64_t)gridDim.y >= (int64_t)a.ws->K;
   }
   if (listed) {
@@ -126,6 +144,7 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
       for (int h = 0; h < H; ++h) {
+        if (!((need >> h) & 1u)) continue;
         const double z = rows[t] >= 0 ? rv[h][t] : 0.0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -160,6 +179,7 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
         for (int c = 0; c < 4; ++c)
 #pragma unroll
           for (int h = 0; h < H; ++h) {
+            if (H > 1 && !((need >> h) & 1u)) continue;  // (uniform for the workgroup)
             acc[h][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].x, rv[h][u], acc[h][2 * c], 0, 0, 0);
             acc[h][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][c].y, rv[h][u], acc[h][2 * c + 1], 0, 0, 0);
           }
@@ -192,6 +212,7 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
         const d2 x = load2(rr * a.ld + coff[c]);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
+          if (H > 1 && !((need >> h) & 1u)) continue;
           acc[h][2 * c] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, rv[h], acc[h][2 * c], 0, 0, 0);
           acc[h][2 * c + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, rv[h], acc[h][2 * c + 1], 0, 0, 0);
         }
@@ -201,6 +222,7 @@ __device__ __forceinline__ void cov_gz_body(SplitArgs a, const CovBatch& cb) {
   if (i16 < SPLIT_LANES) {  // tile 2c+e holds columns col0 + 32 c + 2 i + e
 #pragma unroll
     for (int h = 0; h < H; ++h) {
+      if (!((need >> h) & 1u)) continue;  // (nobody reads the sums of a half without lanes of this row set)
       double* out = a.partial + (int64_t)h * cb.half_stride + ((int64_t)by * SPLIT_LANES + i16) * a.ld;
 #pragma unroll
       for (int c = 0; c < 4; ++c)

@@ -422,10 +422,14 @@ struct MgArgs {
 };
 
 // which lanes still iterate (one round of loads, a ballot)
-__device__ __forceinline__ bool mg_any_active(const MgCtl* mg, int half) {
+// does a lane of this half still iterate -- on the row set of this grid slice (blockIdx.z)?  (the products of the other
+// row sets are theirs: of a grid's five folds and thirty-two lanes most (set, half) pairs have nobody)
+__device__ __forceinline__ bool mg_any_active(const MgCtl* mg, int half, const CovBatch& cb) {
   const int l = threadIdx.x & 63;
   int on = 0;
-  if (l < SPLIT_LANES) on = (mg->lane[SPLIT_LANES * half + l].active != 0) & (mg->lane[SPLIT_LANES * half + l].settled == 0);
+  if (l < SPLIT_LANES)
+    on = (mg->lane[SPLIT_LANES * half + l].active != 0) & (mg->lane[SPLIT_LANES * half + l].settled == 0) &
+         (cb.set_of[SPLIT_LANES * half + l] == (int)blockIdx.z);
   return __ballot(on != 0) != 0ull;
 }
 
@@ -437,15 +441,15 @@ __device__ __forceinline__ bool mg_any_active(const MgCtl* mg, int half) {
 // short workgroups of a 35 us kernel -- and removed.)
 static __global__ __launch_bounds__(XTR_WAVES * 64, 2) void mg_gz_kernel(SplitArgs a, CovBatch cb, const MgCtl* mg, int half) {
   if (a.done != nullptr && *a.done != 0) return;
-  if (!mg_any_active(mg, half)) return;
+  if (!mg_any_active(mg, half, cb)) return;
   cov_gz_body<1, float>(a, cb);
 }
 // both halves of a call of more than sixteen lanes on ONE read of the Gram (a.R: plane 0 of Z, a.r_plane on: plane 1)
 static __global__ __launch_bounds__(XTR_WAVES * 64, 1) void mg_gz32_kernel(SplitArgs a, CovBatch cb, const MgCtl* mg) {
   if (a.done != nullptr && *a.done != 0) return;
-  const bool on0 = mg_any_active(mg, 0), on1 = mg_any_active(mg, 1);
+  const bool on0 = mg_any_active(mg, 0, cb), on1 = mg_any_active(mg, 1, cb);
   if (!on0 && !on1) return;
-  cov_gz_body<2, float>(a, cb);
+  cov_gz_body<2, float>(a, cb, (on0 ? 1u : 0u) | (on1 ? 2u : 0u));  // (and of those only the halves with lanes of this row set)
 }
 
 // The product's partial sums folded over the row blocks, in block order: gd[l][j] = sum_b partial[b][l][j].  A kernel of
