@@ -1748,12 +1748,16 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
   bool direct_mode = direct_on && hard_now != 0;
   // the length scale of the problem on W: a gradient step from the expansion point, ||g0_W|| / L (what "rounding level" is
   // measured against where the iterate itself is zero or dust)
-  double scale2;
+  // (kept in LDS, not in a register across the loop: the kernel sits at the 128 registers of a 1 024-thread workgroup, and a
+  //  value more across the iteration was 12 bytes of scratch per thread)
+  __shared__ double scale2_s;
   {
     double sg[1] = {mine ? g0 * g0 : 0.0};
     block_sum<1>(sg, red);
-    scale2 = sg[0] / (Lw * Lw);
+    if (tid == 0) scale2_s = sg[0] / (Lw * Lw);
+    __syncthreads();
   }
+#define scale2 scale2_s
   // The first WS_BB_ITERS steps carry no momentum and take their length from the curvature along the move
   // before: on the well-conditioned faces of an easy path that is there in half the steps of the accelerated
   // iteration, which takes over if it is not.
@@ -1886,6 +1890,7 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
       }
     }
   }
+#undef scale2
   mark(3);
   if (!ok) return true;
   // An iteration that ran out of steps is accepted only if the model says its point is no worse than the start (two
