@@ -1659,7 +1659,9 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     //  another -- and the features of the first band's deepest points outside the small ones; 0.75: the soak law's twelve paths 92.6 -> 85.0 ms)
     // (per-feature penalties only: groups come in blocks and start from 384 columns -- config 3's first set 250 -> 300 columns at
     //  0.75, 2.79 -> 3.44 ms per path)
-    wa.fill = ds->singleton ? 0.75 : 0.5;
+    // (and shared paths only: a single cold fit pays for the larger first set without a band of points to serve with it --
+    //  1.45 -> 1.51 ms at 0.3 alpha_max, 2.46 -> 2.78 ms at 0.005, tools/single_fit_big.py)
+    wa.fill = (ds->singleton && shared_path) ? 0.75 : 0.5;
     if (const char* e = getenv("SLM_WS_FILL")) wa.fill = std::max(0.1, std::min(1.0, atof(e)));
     return SLM_OK;
   };
