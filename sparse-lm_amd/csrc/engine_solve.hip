@@ -233,7 +233,13 @@ static void launch_rowdot(slm_dataset* ds, const SplitKernel* sk, int nblk, int 
     a.XT = ds->XT;
     // (thirty-two lanes: both halves against ONE read of the copy -- rowdot32_mfma_kernel; SLM_ROWDOT32=0: a read per half)
     const char* e32 = getenv("SLM_ROWDOT32");
-    if (halves == 2 && !(e32 && e32[0] == '0')) hipLaunchKernelGGL(rowdot32_mfma_kernel, dim3(nblk, 1), dim3(XZ_WAVES * 64), 0, s, a);
+    // (seventeen to twenty lanes: the lanes beyond sixteen on the vector units beside the matrix cores' sixteen -- rowdot18 /
+    //  rowdot20_mfma_kernel, as for X^T R; SLM_XTR_EXTRAS=0: both halves on the matrix cores)
+    const char* exs = getenv("SLM_XTR_EXTRAS");
+    const bool extras = halves == 2 && B <= SPLIT_LANES + 4 && !(exs && exs[0] == '0');
+    if (extras && B <= SPLIT_LANES + 2) hipLaunchKernelGGL(rowdot18_mfma_kernel, dim3(nblk, 1), dim3(XZ_WAVES * 64), 0, s, a);
+    else if (extras) hipLaunchKernelGGL(rowdot20_mfma_kernel, dim3(nblk, 1), dim3(XZ_WAVES * 64), 0, s, a);
+    else if (halves == 2 && !(e32 && e32[0] == '0')) hipLaunchKernelGGL(rowdot32_mfma_kernel, dim3(nblk, 1), dim3(XZ_WAVES * 64), 0, s, a);
     else hipLaunchKernelGGL(rowdot_mfma_kernel, dim3(nblk, halves), dim3(XZ_WAVES * 64), 0, s, a);
   } else if (sk->rowdot != nullptr) {
     hipLaunchKernelGGL(sk->rowdot, dim3(nblk, (B + ROWDOT_LANES - 1) / ROWDOT_LANES), dim3(sk->W * 64), 0, s, a);

@@ -580,18 +580,34 @@ constexpr int XZ_T = 4;
 // Straight-line steady state -- two batches of a group each, the second in flight while the first is multiplied -- with
 // the odd batch peeled off, so that every wait is an exact count.
 // H: halves of the lanes served by ONE read of the copy (a second A operand -- the second half's z -- against the same loads)
-template <int NT, int H>
-__device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const double* const (&zp)[H], int g_n, double* mine) {
+// E > 0 (with H = 1): a call of 16 + E lanes, E <= 4 -- as in xtr18 / xtr20_mfma_kernel the extra lanes ride on the VECTOR units
+// against the loads the matrix cores' sixteen use: ex[e][t] += z_e[col] * XT[col][rows 2j, 2j + 1] for this lane's four
+// columns of a group, the four column classes (q) summed by two shuffles at the end, the wavefronts' column quarters through
+// `pe` (LDS: [e][tile][32 rows] per wavefront).  zpe[e]: this lane's four z values of extra lane e in the first group.
+template <int NT, int H, int E = 0>
+__device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const double* const (&zp)[H],
+                                            const double* const (&zpe)[E > 0 ? E : 1], int g_n, double* mine, double* pe) {
+  constexpr int EE = E > 0 ? E : 1;
   slm_d4 acc[H][NT][2];
 #pragma unroll
   for (int h = 0; h < H; ++h)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[h][t][0] = acc[h][t][1] = slm_d4{0.0, 0.0, 0.0, 0.0};
+  d2 ex[EE][NT];
+#pragma unroll
+  for (int e = 0; e < EE; ++e)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ex[e][t] = d2{0.0, 0.0};
   slm_d4 za[H], zb[H];
+  slm_d4 zea[EE], zeb[EE];
   d2 xa[4][NT], xb[4][NT];
-  auto load = [&](slm_d4(&zv)[H], d2(&xv)[4][NT], int g) {
+  auto load = [&](slm_d4(&zv)[H], slm_d4(&zev)[EE], d2(&xv)[4][NT], int g) {
 #pragma unroll
     for (int h = 0; h < H; ++h) zv[h] = *reinterpret_cast<const slm_d4*>(zp[h] + 16 * g);
+    if constexpr (E > 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) zev[e] = *reinterpret_cast<const slm_d4*>(zpe[e] + 16 * g);
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -600,32 +616,40 @@ __device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const
         xv[m][t] = SLM_NT_LOADS ? __builtin_nontemporal_load(src) : *src;
       }
   };
-  auto compute = [&](const slm_d4(&zv)[H], d2(&xv)[4][NT]) {
+  auto compute = [&](const slm_d4(&zv)[H], const slm_d4(&zev)[EE], d2(&xv)[4][NT]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int h = 0; h < H; ++h) {
           acc[h][t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[h][m], xv[m][t].x, acc[h][t][0], 0, 0, 0);
           acc[h][t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[h][m], xv[m][t].y, acc[h][t][1], 0, 0, 0);
         }
+        if constexpr (E > 0) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            ex[e][t].x = __builtin_fma(zev[e][m], xv[m][t].x, ex[e][t].x);
+            ex[e][t].y = __builtin_fma(zev[e][m], xv[m][t].y, ex[e][t].y);
+          }
+        }
+      }
   };
   if (g_n > 0) {
-    load(za, xa, 0);
+    load(za, zea, xa, 0);
     const int pairs = (g_n - 1) >> 1;
     for (int k = 0; k < pairs; ++k) {
-      load(zb, xb, 2 * k + 1);
-      compute(za, xa);
-      load(za, xa, 2 * k + 2);
-      compute(zb, xb);
+      load(zb, zeb, xb, 2 * k + 1);
+      compute(za, zea, xa);
+      load(za, zea, xa, 2 * k + 2);
+      compute(zb, zeb, xb);
     }
     if ((g_n - 1) & 1) {
-      load(zb, xb, g_n - 1);
-      compute(za, xa);
-      compute(zb, xb);
+      load(zb, zeb, xb, g_n - 1);
+      compute(za, zea, xa);
+      compute(zb, zeb, xb);
     } else {
-      compute(za, xa);
+      compute(za, zea, xa);
     }
   }
 #pragma unroll
@@ -636,28 +660,49 @@ __device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const
       for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mine[(((h * XZ_T + t) * 2 + e) * 4 + r) * 64] = acc[h][t][e][r];
+  if constexpr (E > 0) {
+    // the four column classes of a row pair sit in lanes j, j + 16, j + 32, j + 48: summed in that fixed order; class 0 stores
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        d2 v = ex[e][t];
+        v.x += __shfl_xor(v.x, 16, 64);
+        v.y += __shfl_xor(v.y, 16, 64);
+        v.x += __shfl_xor(v.x, 32, 64);
+        v.y += __shfl_xor(v.y, 32, 64);
+        if (lane < 16) *reinterpret_cast<d2*>(pe + (e * XZ_T + t) * 32 + 2 * lane) = v;
+      }
+  }
 }
 
 
 // H = 1: the sixteen lanes of half blockIdx.y (a launch per half: grid.y).  H = 2: BOTH halves on one read of the copy
 // (grid.y = 1; a call of more than sixteen lanes whose second half needs residuals from X -- dense points of the model-Gram
 // rounds -- used to read the 4 GB twice).
-template <int H>
+// E > 0 (H = 1, grid.y = 1): 16 + E lanes -- half 0 on the matrix cores, the first E lanes of half 1 on the vector units beside
+// them (rowdot_step): seventeen to twenty lanes at the price of sixteen, as in xtr18 / xtr20_mfma_kernel.
+template <int H, int E = 0>
 __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 rows of the MFMA A operand");
+  static_assert(E == 0 || (H == 1 && (E == 2 || E == 4)), "extras: the first lanes of half 1 beside the sixteen of half 0");
+  constexpr int HZ = E > 0 ? 2 : H;   // halves whose lanes this launch serves (masks, the cold start, the loss sums)
+  constexpr int EE = E > 0 ? E : 1;
   if (a.done != nullptr && *a.done != 0) return;
-  const int half0 = H == 1 ? (int)blockIdx.y : 0;  // first half served here
-  unsigned mask[H];
+  const int half0 = (H == 1 && E == 0) ? (int)blockIdx.y : 0;  // first half served here
+  unsigned mask[HZ];
   bool any = false;
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
+  for (int h = 0; h < HZ; ++h) {
     mask[h] = split_x_mask(a, half0 + h);
     any = any || mask[h] != 0u;
   }
   if (!any) return;
   const int LS = split_slots(a);
-  __shared__ double red[XZ_WAVES][H * SPLIT_LANES];
+  __shared__ double red[XZ_WAVES][HZ * SPLIT_LANES];
   __shared__ double part[H * XZ_WAVES * XZ_T * 2 * 4 * 64];  // 64 KiB per half: the wavefronts' partial products of one step
+  __shared__ double partE[E > 0 ? XZ_WAVES * E * XZ_T * 32 : 1];  // the extra lanes' sums of a step: [wavefront][e][tile][32 rows]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t b = blockIdx.x;
@@ -667,7 +712,7 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
   bool all_zero = a.ctl != nullptr;  // cold start: e = -y without reading X (as rowdot_ring_kernel)
   if (all_zero) {  // (lane l of every wavefront reads control block l: one round trip, not one per lane slot)
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
+    for (int h = 0; h < HZ; ++h) {
       const int L0 = SPLIT_LANES * (half0 + h);
       const bool in = lane < SPLIT_LANES && L0 + lane < a.n_lanes;
       const bool moved = in && ((mask[h] >> lane) & 1u) && !a.ctl[in ? L0 + lane : 0].zzero;
@@ -681,7 +726,7 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
     const int l = tid & 15;
     const bool has_rw = a.rw != nullptr;
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
+    for (int h = 0; h < HZ; ++h) {
       const int L0 = SPLIT_LANES * (half0 + h);
       double* Rh = a.R + (int64_t)(half0 + h) * a.r_plane;
       const bool on = ((mask[h] >> l) & 1u) != 0u;
@@ -711,7 +756,7 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
       if (lane < SPLIT_LANES) red[wave][h * SPLIT_LANES + lane] = ls;
     }
     __syncthreads();
-    if (tid < H * SPLIT_LANES && ((mask[tid / SPLIT_LANES] >> (tid % SPLIT_LANES)) & 1u)) {
+    if (tid < HZ * SPLIT_LANES && ((mask[tid / SPLIT_LANES] >> (tid % SPLIT_LANES)) & 1u)) {
       double t = 0.0;
       for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2][tid];
       a.loss_partial[b * LS + SPLIT_LANES * half0 + tid] = t;
@@ -746,11 +791,18 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
     const int L = SPLIT_LANES * (half0 + h) + j;
     zp[h] = a.z + (int64_t)(L < a.n_lanes ? L : a.n_lanes - 1) * a.ld + 4 * q + 16 * (int64_t)g_lo;
   }
+  const double* zpe[EE];  // (E > 0) extra lane e = lane 16 + e of the call
+#pragma unroll
+  for (int e = 0; e < EE; ++e) {
+    const int L = SPLIT_LANES + e;
+    zpe[e] = a.z + (int64_t)(L < a.n_lanes ? L : a.n_lanes - 1) * a.ld + 4 * q + 16 * (int64_t)g_lo;
+  }
   double loss[H][4];  // of lane slots q, q + 4, q + 8, q + 12 over this lane's rows
 #pragma unroll
   for (int h = 0; h < H; ++h)
 #pragma unroll
     for (int r = 0; r < 4; ++r) loss[h][r] = 0.0;
+  double lossE = 0.0;  // (E > 0, q < E) of extra lane q over this lane's rows
   int t_at = 0;
   for (int st = 0; st < nsteps; ++st) {
     const int nt = __builtin_amdgcn_readfirstlane(T / nsteps + (st < T % nsteps ? 1 : 0));
@@ -760,11 +812,12 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
     //  asked for included: no overlap of loads and products at all)
     const double* xt0 = a.XT + (((t_lo + t_at) * a.ld + 4 * q + 16 * (int64_t)g_lo) << 5) + 2 * j;
     double* mine = part + (size_t)wave * (H * XZ_T * 2 * 4 * 64) + lane;
+    double* pe = partE + (E > 0 ? (size_t)wave * (E * XZ_T * 32) : 0);
     switch (nt) {
-      case 1: rowdot_step<1, H>(xt0, a.ld, zp, g_n, mine); break;
-      case 2: rowdot_step<2, H>(xt0, a.ld, zp, g_n, mine); break;
-      case 3: rowdot_step<3, H>(xt0, a.ld, zp, g_n, mine); break;
-      default: rowdot_step<4, H>(xt0, a.ld, zp, g_n, mine); break;
+      case 1: rowdot_step<1, H, E>(xt0, a.ld, zp, zpe, g_n, mine, pe); break;
+      case 2: rowdot_step<2, H, E>(xt0, a.ld, zp, zpe, g_n, mine, pe); break;
+      case 3: rowdot_step<3, H, E>(xt0, a.ld, zp, zpe, g_n, mine, pe); break;
+      default: rowdot_step<4, H, E>(xt0, a.ld, zp, zpe, g_n, mine, pe); break;
     }
     __syncthreads();
     if (wave < nt) {  // wavefront t finishes tile t: result register r of lane l is lane slot (l >> 4) + 4 r, row 2 (l & 15) + e
@@ -793,6 +846,18 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
             }
           }
         }
+        if constexpr (E > 0) {  // lane group q < E finishes extra lane q of the tile: plane 1 of R, slot q
+          if (q < E && in && ((mask[1] >> q) & 1u)) {
+            double v = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < XZ_WAVES; ++w2) v += partE[(size_t)w2 * (E * XZ_T * 32) + (q * XZ_T + t) * 32 + 2 * j + e];
+            const double m = a.rw ? a.rw[(int64_t)(SPLIT_LANES + q) * a.rw_stride + row] : 1.0;
+            const double err = v - yi;
+            const double res = err * m;
+            a.R[a.r_plane + row * SPLIT_RSTRIDE + q] = res;
+            lossE = __builtin_fma(res, err, lossE);
+          }
+        }
       }
     }
     __syncthreads();  // (the next step overwrites the partial products)
@@ -807,8 +872,14 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
       for (int off = 8; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
       if (j == 0) red[wave][h * SPLIT_LANES + q + 4 * r] = t;
     }
+  if constexpr (E > 0) {
+    double t = lossE;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (j == 0) red[wave][SPLIT_LANES + q] = t;  // (q >= E: zero; slots beyond 16 + 3 are never read)
+  }
   __syncthreads();
-  if (tid < H * SPLIT_LANES && ((mask[tid / SPLIT_LANES] >> (tid % SPLIT_LANES)) & 1u)) {
+  if (tid < HZ * SPLIT_LANES && ((mask[tid / SPLIT_LANES] >> (tid % SPLIT_LANES)) & 1u)) {
     double t = 0.0;
     for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2][tid];
     a.loss_partial[b * LS + SPLIT_LANES * half0 + tid] = t;
@@ -817,6 +888,8 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
 
 static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a) { rowdot_mfma_body<1>(a); }
 static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot32_mfma_kernel(SplitArgs a) { rowdot_mfma_body<2>(a); }
+static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot18_mfma_kernel(SplitArgs a) { rowdot_mfma_body<1, 2>(a); }
+static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot20_mfma_kernel(SplitArgs a) { rowdot_mfma_body<1, 4>(a); }
 
 // ---------------------------------------------------------------------------------------------
 // The residuals from the gathered columns on the matrix cores: R[row][l] = w_l,row (XW_row . zW_l - y_row)
