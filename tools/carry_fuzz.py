@@ -70,6 +70,9 @@ def run(seed):
             ka, kb = ra[0].grad_launches, rb[0].grad_launches
             saved += kb - ka
             worse += ka > kb + 1
+            if os.environ.get("CARRY_FUZZ_VERBOSE"):
+                print(f"  seed {seed} call {step}: lanes={lanes} flags={flags} again={again} masks={mask_of} warm={[('beta0' in sp) for sp in specs]} "
+                      f"points={[len(sp['points']) for sp in specs]} passes carried={ka} plain={kb}", flush=True)
             for l, (u, v) in enumerate(zip(ra, rb)):
                 assert u.converged == v.converged, (seed, step, l)
                 scale = max(np.max(np.abs(v.betas[-1])), 1e-12)
