@@ -1013,6 +1013,34 @@ static __global__ __launch_bounds__(256) void ws_publish_kernel(WsArgs w) {
   }
 }
 
+// Workgroup sums of the model solver: only the threads of the first `nwc` wavefronts (4 or 8: the ones with q == 0, a
+// position each) bring a value, every thread gets bit-identical totals.  block_sum makes all sixteen wavefronts scan
+// their zeros and fold sixteen partial sums each: 1.8 us per iteration for seven values, issue-bound on the fp64 DPP adds
+// of four wavefronts per SIMD (in-kernel clock marks).  Here the scan runs where the values are, and a lane reads ONE
+// partial sum per value and folds it with its quad (or half-row) by commutative pairings.
+template <int NV>
+__device__ __forceinline__ void ws_sum(double (&v)[NV], double (*lds)[TAIL_WAVES], int nwc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < nwc) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum_lane63(v[k]);
+  }
+  __syncthreads();  // protect lds from the previous use
+  if (wave < nwc && lane == 63) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) lds[k][wave] = v[k];
+  }
+  __syncthreads();
+  if (nwc == 4) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = group_sum_all<4>(lds[k][lane & 3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = group_sum_all<8>(lds[k][lane & 7]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // (iv) refinement: one workgroup per lane minimises the penalised quadratic model over W.
 // Threads q KP + k work on working-set position k (q splits the matrix-vector product; TPC = 4 parts, or 2
@@ -1048,7 +1076,7 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
   if (!ws->valid || ws->building || ws->disabled) return true;
   const int tid = threadIdx.x;
   const int p = a.p;
-  const int K = ws->K;
+  const int K = __builtin_amdgcn_readfirstlane(ws->K);
   const int set = w.set_of[lane_id];
   const double* Gm = w.Gm + (int64_t)set * (WS_KCAP * WS_KCAP);
   {
@@ -1109,6 +1137,7 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
   const int KP = WS_THREADS >> tsh;
   const int k = tid & (KP - 1), q = tid >> (10 - tsh);
   static_assert(WS_THREADS == 1024, "q = tid >> (10 - tsh)");
+  const int nwc = KP >> 6;  // wavefronts whose threads account for a position (q == 0): 4 or 8 -- ws_sum
   const int j = k < K ? w.idx[k] : -1;
   const bool live = j >= 0;
   const bool mine = live && q == 0;  // the thread that accounts for position k in reductions
@@ -1138,16 +1167,17 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
       // Gram through L2 (K > WS_KLDS): the loads of a batch are issued together, then consumed in the same
       // order as before (one FMA chain).  Left to the compiler the loop ran one load at a time: 28 us per
       // product at K = 272 (in-kernel clock marks), i.e. 0.3 ms of power iteration per selection.
+      // (the last batch is a full one too, its entries past the end read the batch's first row again and count with a
+      //  factor of zero: left to a loop of its own the tail ran one load at a time, 0.2 us each -- twelve of them per
+      //  product at K = 176, half the power iteration)
       if (k < K) {
-        int c = q;
-        for (; c + 15 * TPC < K; c += 16 * TPC) {
+        for (int c = __builtin_amdgcn_readfirstlane(q); c < K; c += 16 * TPC) {
           double gv[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) gv[u] = Gm[(c + u * TPC) * WS_KCAP + k];
+          for (int u = 0; u < 16; ++u) gv[u] = Gm[(c + u * TPC < K ? c + u * TPC : c) * WS_KCAP + k];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) acc = __builtin_fma(gv[u], delta[c + u * TPC], acc);
+          for (int u = 0; u < 16; ++u) acc = __builtin_fma(gv[u], c + u * TPC < K ? delta[c + u * TPC] : 0.0, acc);
         }
-        for (; c < K; c += TPC) acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
       }
     } else {
       if (tid < 64) {  // compact list of the non-zero entries (wave 0, ballots)
@@ -1162,22 +1192,23 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
         if (tid == 0) nnz_s = basep;
       }
       __syncthreads();
-      const int nnz = nnz_s;
+      // (q, the list and its length are the same for all lanes of a wavefront: told to the compiler, the sixteen row
+      //  numbers and the in-range tests live in scalar registers)
+      const int nnz = __builtin_amdgcn_readfirstlane(nnz_s);
+      const int qs = __builtin_amdgcn_readfirstlane(q);
+      // (full batches to the end, as above: the headline's solves have 10-60 non-zeros, FEWER than the 16 TPC a batch
+      //  used to need -- every one of their products ran in the one-load-at-a-time tail, 2.4 us of a 5.6 us iteration.
+      //  Twelve per batch: sixteen cost the kernel without direct steps 28 bytes of scratch.)
       if (k < K) {
-        int m = q;
-        for (; m + 15 * TPC < nnz; m += 16 * TPC) {
-          int cc[16];
-          double gv[16];
+        for (int m = qs; m < nnz; m += 12 * TPC) {
+          int cc[12];
+          double gv[12];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) cc[u] = nz[m + u * TPC];
+          for (int u = 0; u < 12; ++u) cc[u] = __builtin_amdgcn_readfirstlane(nz[m + u * TPC < nnz ? m + u * TPC : m]);
 #pragma unroll
-          for (int u = 0; u < 16; ++u) gv[u] = Gm[cc[u] * WS_KCAP + k];
+          for (int u = 0; u < 12; ++u) gv[u] = Gm[cc[u] * WS_KCAP + k];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) acc = __builtin_fma(gv[u], delta[cc[u]], acc);
-        }
-        for (; m < nnz; m += TPC) {
-          const int c = nz[m];
-          acc = __builtin_fma(Gm[c * WS_KCAP + k], delta[c], acc);
+          for (int u = 0; u < 12; ++u) acc = __builtin_fma(gv[u], m + u * TPC < nnz ? delta[cc[u]] : 0.0, acc);
         }
       }
     }
@@ -1241,7 +1272,7 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
     for (int itp = 0; itp < 10; ++itp) {
       const double y = matvec(vec + z0, true);  // matvec works on (val - z0)
       double s[1] = {q == 0 && k < K ? y * y : 0.0};
-      block_sum<1>(s, red);
+      ws_sum<1>(s, red, nwc);
       lam = sqrt(s[0]);
       vec = lam > 0.0 ? y / lam : 0.0;
     }
@@ -1753,7 +1784,7 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
   __shared__ double scale2_s;
   {
     double sg[1] = {mine ? g0 * g0 : 0.0};
-    block_sum<1>(sg, red);
+    ws_sum<1>(sg, red, nwc);
     if (tid == 0) scale2_s = sg[0] / (Lw * Lw);
     __syncthreads();
   }
@@ -1784,7 +1815,7 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
         s[6] = dv * dg;
       }
     }
-    block_sum<7>(s, red);
+    ws_sum<7>(s, red, nwc);
     if (s[3] > 0.0 || !isfinite(s[0])) {
       ok = false;
       break;
@@ -1906,14 +1937,14 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
       const double d = x_start - z0;
       double s[2] = {mine ? d * (g0 + 0.5 * gd) : 0.0, 0.0};
       s[1] = pen_part(x_start);
-      block_sum<2>(s, red);
+      ws_sum<2>(s, red, nwc);
       m_start = s[0] + s[1];
     }
     const double gd = matvec(x, false);
     const double d = x - z0;
     double s[3] = {mine ? d * (g0 + 0.5 * gd) : 0.0, 0.0, mine && !isfinite(x) ? 1.0 : 0.0};
     s[1] = pen_part(x);
-    block_sum<3>(s, red);
+    ws_sum<3>(s, red, nwc);
     const double m_end = s[0] + s[1];
     if (s[2] > 0.0 || !(m_end <= m_start)) return true;
   }
