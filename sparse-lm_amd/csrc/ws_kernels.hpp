@@ -147,6 +147,19 @@ struct WsArgs {
                        // the model-Gram rounds) instead of selecting, gathering and multiplying afresh pass after pass
 };
 
+// The first words of the control block (request ... hard_next) and the call's stop word in ONE round trip: the first
+// WS_HEAD_WORDS + 1 threads fetch a word each into `hd`; the caller's barrier makes them visible.  (A kernel that reads
+// five words behind five tests waits five times; worth 1.2 us of ws_score_kernel's 15.6, nothing measurable in
+// ws_select_kernel, which keeps its plain reads.)
+constexpr int WS_HEAD_WORDS = 24;
+static_assert(offsetof(WsCtl, hard_next) / 4 < WS_HEAD_WORDS, "the words the pass kernels decide on");
+#define WS_HEAD(hd, field) ((hd)[offsetof(WsCtl, field) / 4])
+__device__ __forceinline__ void ws_head_load(const WsCtl* ws, const int* gdone, int32_t* hd) {
+  const int tid = threadIdx.x;
+  if (tid < WS_HEAD_WORDS) hd[tid] = reinterpret_cast<const int32_t*>(ws)[tid];
+  else if (tid == WS_HEAD_WORDS) hd[tid] = gdone ? gdone[0] : 0;
+}
+
 // state of a fresh solve (the block is zeroed first): a build is requested, no lane has been refined yet
 static __global__ void ws_ctl_init_kernel(WsCtl* ws, int max_builds) {
   if (threadIdx.x == 0) {
@@ -223,11 +236,18 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[16]*/, in
 // ---------------------------------------------------------------------------------------------
 static __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
   WsCtl* ws = w.ws;
-  if (a.gdone[0] != 0 || ws->disabled) return;
-  const bool had_w = ws->valid != 0;
-  if (!ws->request && !had_w) return;
-  if (ws->builds >= ws->max_builds || ws->appends >= 8 * ws->max_builds) return;
   const int tid = threadIdx.x;
+  // The words this kernel decides on, fetched TOGETHER (ws_head_load) instead of one after the other behind the tests they
+  // feed (`a || b` is two dependent round trips), and the lanes' point counts by a thread each instead of a loop per thread.
+  __shared__ int32_t hd[WS_HEAD_WORDS + 1];
+  __shared__ int lane_np[SLM_MAX_LANES];
+  ws_head_load(ws, a.gdone, hd);
+  if (tid >= 64 && tid < 64 + SLM_MAX_LANES) lane_np[tid - 64] = tid - 64 < a.n_lanes ? a.ctl[tid - 64].n_points : 0;
+  __syncthreads();
+  if (hd[WS_HEAD_WORDS] != 0 || WS_HEAD(hd, disabled)) return;
+  const bool had_w = WS_HEAD(hd, valid) != 0;
+  if (!WS_HEAD(hd, request) && !had_w) return;
+  if (WS_HEAD(hd, builds) >= WS_HEAD(hd, max_builds) || WS_HEAD(hd, appends) >= 8 * WS_HEAD(hd, max_builds)) return;
   const bool singleton = a.singleton != 0;
   const int nitems = singleton ? a.p : a.G;
   __shared__ int lane_live[SLM_MAX_LANES];
@@ -240,7 +260,7 @@ static __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs
       const PathCtl* c = a.ctl + tid;
       live = !(c->done || c->idle);
       int path_end = 0;
-      for (int l = 0; l < a.n_lanes; ++l) path_end = max(path_end, a.ctl[l].n_points);
+      for (int l = 0; l < SLM_MAX_LANES; ++l) path_end = max(path_end, lane_np[l]);
       const int end = a.steal ? path_end : c->pt_off + c->n_points;
       // (interleaved lanes jump `stride` points at a time: look at least as far as the next one)
       int look = min(c->pt_off + c->point + max(w.lookahead, c->stride), end - 1);
@@ -449,6 +469,7 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
     double s[1] = {v[0]};
     block_sum<1>(s, red);
     *n_sel = s[0];
+    if (smax == nullptr) return;  // (only the first count of a fitted threshold asks for it: two barriers less for the others)
     double m = v[1];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
@@ -473,7 +494,7 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
     double n_hi = 0.0;
     for (int k = 0; k < 14; ++k) {
       const double mid = 0.5 * (lo + hi);
-      count_at(mid, only_new, &n_sel, &smax);
+      count_at(mid, only_new, &n_sel, nullptr);
       if (n_sel > cap) {
         lo = mid;
       } else {
@@ -482,7 +503,7 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
         if (n_sel >= w.fill * cap) break;  // close enough to the cap
       }
     }
-    if (n_hi == 0.0) count_at(hi, only_new, &n_hi, &smax);
+    if (n_hi == 0.0) count_at(hi, only_new, &n_hi, nullptr);
     *n_out = n_hi;
     return hi;
   };
@@ -513,8 +534,8 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
         // again a pass later (gather + Gram of 500 columns, 2-3 ms a time): W stays as it is.  Where they do not -- W is
         // full of candidates that never entered, the way strongly correlated designs fill it -- the selection goes ahead
         // as it always did: those lanes are best served by W's own model solver and its direct steps.
-        double nz_now, smax_unused;
-        count_at(inf, false, &nz_now, &smax_unused);
+        double nz_now;
+        count_at(inf, false, &nz_now, nullptr);
         if (nz_now > 0.75 * (double)WS_KCAP) {
           if (tid == 0) {
             ws->request = 0;
@@ -528,7 +549,7 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
     }
   }
   if (!append) {
-    count_at(inf, false, &n_sel, &smax);
+    count_at(inf, false, &n_sel, nullptr);
     if (n_sel > (double)WS_KCAP) {
       // the non-zero coefficients of the expansion points alone do not fit (dense early iterates of
       // a cold start, a dense solution, or ONE lane whose plain steps went dense): with a W in place it
