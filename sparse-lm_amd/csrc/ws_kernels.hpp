@@ -242,7 +242,7 @@ static __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs
   __shared__ int32_t hd[WS_HEAD_WORDS + 1];
   __shared__ int lane_np[SLM_MAX_LANES];
   ws_head_load(ws, a.gdone, hd);
-  if (tid >= 64 && tid < 64 + SLM_MAX_LANES) lane_np[tid - 64] = tid - 64 < a.n_lanes ? a.ctl[tid - 64].n_points : 0;
+  if (tid < SLM_MAX_LANES) lane_np[tid] = tid < a.n_lanes ? a.ctl[tid].n_points : 0;  // (workgroups of 64 threads score groups)
   __syncthreads();
   if (hd[WS_HEAD_WORDS] != 0 || WS_HEAD(hd, disabled)) return;
   const bool had_w = WS_HEAD(hd, valid) != 0;
