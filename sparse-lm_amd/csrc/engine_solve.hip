@@ -1659,6 +1659,8 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     wa.one_solver = 0;
     if (const char* e = getenv("SLM_WS_ONE_SOLVER")) wa.one_solver = atoi(e) != 0;
     wa.hard_call = getenv("SLM_HARD_CALLWIDE") != nullptr;
+    wa.power_iters = 10;
+    if (const char* e = getenv("SLM_WS_POWER_ITERS")) wa.power_iters = std::max(1, std::min(40, atoi(e)));
     wa.miss_factor = 4;
     if (const char* e = getenv("SLM_WS_MISS_FACTOR")) wa.miss_factor = std::max(1, std::min(8, atoi(e)));
     // (0.5 left a first working set of 56-112 columns to the luck of the bisection: 65 on one draw of the headline's law, 102 on

@@ -142,6 +142,7 @@ struct WsArgs {
   int32_t one_solver;  // SLM_WS_ONE_SOLVER=1: every lane goes to the solver with direct steps (measurements)
   int32_t miss_factor; // an append after a miss may take this many times append_max (4)
   double fill;         // a selection cut down to a cap stops bisecting its threshold once it holds this share of the cap
+  int32_t power_iters; // power steps for lambda_max of a new Gram (SLM_WS_POWER_ITERS)
   int32_t hard_call;   // SLM_HARD_CALLWIDE=1 (A/B runs): direct steps once needed start every later refinement of the CALL
   int32_t keep_full;   // a selection that does not fit leaves W as it is (`stale`: the lanes it no longer covers are served by
                        // the model-Gram rounds) instead of selecting, gathering and multiplying afresh pass after pass
@@ -1290,7 +1291,7 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
   if (!(Lw > 0.0)) {
     double vec = (k < K) ? 1.0 + 0.37 * (double)(((k * 2654435761u) >> 24) & 0xffu) / 255.0 : 0.0;
     double lam = 0.0;
-    for (int itp = 0; itp < 10; ++itp) {
+    for (int itp = 0; itp < w.power_iters; ++itp) {
       const double y = matvec(vec + z0, true);  // matvec works on (val - z0)
       double s[1] = {q == 0 && k < K ? y * y : 0.0};
       ws_sum<1>(s, red, nwc);
