@@ -181,6 +181,8 @@ struct HostCtl {  // pinned snapshot the host polls
 
 void pool_free(void* p);
 
+constexpr size_t kSmallOutDoubles = 32768;  // 256 KiB of staged coefficients per dataset (on-chip calls)
+
 struct slm_dataset {
   slm_engine* eng = nullptr;
   int64_t n = 0, p = 0, ld = 0, n_global = 0;
@@ -271,6 +273,9 @@ struct slm_dataset {
   PathCtl* ctl = nullptr;    // [kMaxLanes]  (= dctl->lane)
   GlobalCtl* gctl = nullptr; //              (= &dctl->g)
   HostCtl* hctl = nullptr;   // pinned, 2 slots
+  double* h_small_out = nullptr;  // pinned, device-visible: the coefficients of an on-chip call are written here by the kernel
+                                  // itself (kSmallOutDoubles; solve_core: a copy command into the caller's pageable array
+                                  // costs more than the kernel's stores across the bus)
   hipEvent_t ev[2] = {nullptr, nullptr};
   // path buffers (grown on demand), concatenated over lanes
   int64_t cap_points = 0, cap_gn = 0;

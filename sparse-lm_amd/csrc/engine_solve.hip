@@ -1506,12 +1506,38 @@ static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, c
     const size_t lds = (size_t)SM_LDS_BYTES;
     sm.stage_doubles = (int)((lds - fixed - 64) / sizeof(double));
     SLM_TRY(allow_big_lds((const void*)small_solve_kernel, eng->device));
+    // The coefficients of a call that fits the dataset's pinned stage are stored there by the kernel itself and moved to
+    // the caller's arrays after the wait: a copy command into pageable memory is 20-40 us behind a 0.25 ms kernel
+    // (SLM_NO_SMALL_STAGE: the copy commands, for comparison).
+    bool staged_out = (size_t)total_points * (size_t)p <= kSmallOutDoubles && !any_gn && getenv("SLM_NO_SMALL_STAGE") == nullptr;
+    if (staged_out && !ds->h_small_out &&
+        hipHostMalloc((void**)&ds->h_small_out, sizeof(double) * kSmallOutDoubles, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      ds->h_small_out = nullptr;
+      staged_out = false;
+    }
+    if (staged_out) sm.t.betas_out = ds->h_small_out;
     hipLaunchKernelGGL(small_solve_kernel, dim3(B), dim3(SM_THREADS), lds, s, sm);
     SLM_TRY(check_launch());
     if (infos_in_snap) HIP_TRY(hipMemcpyAsync(&ds->hctl[0].c, ds->dctl, sizeof(DevCtl), hipMemcpyDeviceToHost, s));
     else HIP_TRY(hipMemcpyAsync(&ds->hctl[0].c, ds->dctl, offsetof(DevCtl, infos), hipMemcpyDeviceToHost, s));
-    SLM_TRY(enqueue_result_copies());
+    if (!staged_out) SLM_TRY(enqueue_result_copies());
+    else if (!infos_in_snap) {  // (records too many for the snapshot: they travel as before)
+      int64_t at_i = 0;
+      for (int l = 0; l < B; ++l) {
+        if (lanes[l].infos)
+          HIP_TRY(hipMemcpyAsync(lanes[l].infos, ds->infos + at_i, sizeof(slm_point_info) * (size_t)lanes[l].n_points, hipMemcpyDeviceToHost, s));
+        at_i += lanes[l].n_points;
+      }
+    }
     HIP_TRY(hipStreamSynchronize(s));
+    if (staged_out) {
+      int64_t at_o = 0;
+      for (int l = 0; l < B; ++l) {
+        memcpy(lanes[l].betas_out, ds->h_small_out + (size_t)at_o * p, sizeof(double) * (size_t)lanes[l].n_points * p);
+        at_o += lanes[l].n_points;
+      }
+    }
     const double t_small = t_mark();
     const DevCtl& snap = ds->hctl[0].c;
     bool nonfinite = false, unconverged = false;

@@ -59,16 +59,29 @@ struct SmallArgs {
 };
 
 __device__ __forceinline__ double sm_sum(double v) { return read_lane63(wave_sum_lane63(v)); }  // DPP scan, no LDS
-__device__ __forceinline__ double sm_min(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
-  return v;
+// Minimum / maximum over the wavefront with DPP moves, the pattern of wave_sum_lane63 (no LDS round trips: the xor
+// butterfly of __shfl_xor is six dependent ds_bpermute pairs, 0.25 us of a 1.7 us conjugate-gradient step).  A lane a move
+// does not reach (row_mask / out of range) keeps its own value, which is neutral for both.
+template <int CTRL, int ROW_MASK, bool IS_MIN>
+__device__ __forceinline__ double sm_dpp_fold(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  const double o = __hiloint2double(hi2, lo2);
+  return IS_MIN ? fmin(v, o) : fmax(v, o);
 }
-__device__ __forceinline__ double sm_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return v;
+template <bool IS_MIN>
+__device__ __forceinline__ double sm_extreme(double v) {
+  v = sm_dpp_fold<0x111, 0xf, IS_MIN>(v);  // row_shr:1
+  v = sm_dpp_fold<0x112, 0xf, IS_MIN>(v);  // row_shr:2
+  v = sm_dpp_fold<0x114, 0xf, IS_MIN>(v);  // row_shr:4
+  v = sm_dpp_fold<0x118, 0xf, IS_MIN>(v);  // row_shr:8
+  v = sm_dpp_fold<0x142, 0xa, IS_MIN>(v);  // row_bcast:15 into rows 1 and 3
+  v = sm_dpp_fold<0x143, 0xc, IS_MIN>(v);  // row_bcast:31 into rows 2 and 3
+  return read_lane63(v);
 }
+__device__ __forceinline__ double sm_min(double v) { return sm_extreme<true>(v); }
+__device__ __forceinline__ double sm_max(double v) { return sm_extreme<false>(v); }
 __device__ __forceinline__ void sm_lds_sync() {  // one wavefront: LDS writes before the reads that follow
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -490,7 +503,32 @@ static __global__ __launch_bounds__(SM_THREADS) void small_solve_kernel(SmallArg
 
   // y = G v for the vector held as (v0, v1): v goes through LDS (every lane needs all of it), the rows of G are read
   // along the lanes (symmetric: row m holds column m); the four wavefronts take a quarter of the rows each
+  // Up to 32 positions the product stays in THIS wavefront: lane (h, k) = (lane >> 5, lane & 31) sums the rows 16 h .. 16 h + 15
+  // of column k -- sixteen matrix entries and sixteen operand entries, all asked for at once -- and the halves meet in one
+  // cross-half move: no barrier, no helper wavefront (they keep waiting for a factorisation).  With the helpers a product of
+  // the reference's 25 x 30 fixture cost 0.78 us, two barriers around eight rows each, half of the kernel's time.
+  const bool one_wave = p <= 32;
   auto matvec = [&](double v0, double v1, double& y0, double& y1) {
+    if (one_wave) {
+      if (on0) vz[s0] = v0;
+      sm_lds_sync();
+      const int hh = lane >> 5, kk = lane & 31, kc = kk < p ? kk : 0;
+      double gv[16], zv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = 16 * hh + i, cc = c < p ? c : 0;
+        gv[i] = Gs[cc * p + kc];
+        zv[i] = vz[cc];
+      }
+      double e[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) e[i & 3] = __builtin_fma(gv[i], 16 * hh + i < p ? zv[i] : 0.0, e[i & 3]);
+      const double part = (e[0] + e[2]) + (e[1] + e[3]);
+      y0 = part + __shfl_xor(part, 32, 64);
+      y1 = 0.0;
+      __builtin_amdgcn_wave_barrier();  // (vz is written again by the next product: keep the reads above it)
+      return;
+    }
     if (on0) vz[s0] = v0;
     if (on1) vz[s1] = v1;
     if (lane == 0) sm_cmd = 1;
