@@ -928,24 +928,39 @@ static bool small_ok(const slm_dataset* ds, uint32_t flags) {
   return ds->p <= SM_PMAX && (double)ds->n * (double)ds->ld <= 131072.0 && !row_sharded(ds);
 }
 // most lanes one solve can run: the fused kernels' table, or the split pass's sixteen when the working
-// set is on from the start
-static int max_lanes_for(slm_dataset* ds, uint32_t flags) {
+// set is on from the start.  Host logic only -- no device call, no allocation: the answer to "how many lanes" must not
+// depend on which device is current, and must not queue work (the column-major copy of X that more than sixteen lanes
+// need is built by the solve that uses them: lanes_with_copy below).
+static bool split_possible(const slm_dataset* ds) {  // (split_usable without building anything)
+  return ds->sk != nullptr && (ds->sk->rowdot != nullptr || !ds->XT_failed);
+}
+static int max_lanes_for(const slm_dataset* ds, uint32_t flags) {
   if (small_ok(ds, flags)) return ds->lane_cap;  // a workgroup per lane
-  if ((ws_policy(ds, flags) == 2 || (double)ds->n * (double)ds->ld >= 67108864.0) && split_usable(ds)) {
+  if ((ws_policy(ds, flags) == 2 || (double)ds->n * (double)ds->ld >= 67108864.0) && split_possible(ds)) {
     // Two halves of sixteen on ONE read of X (xtr32_mfma_kernel, 0.71 ms against 0.57 at 100k x 5k) where the solve is a
     // working-set solve over X on this device: lanes that advance a point per pass -- the units of a grid, the folds of a
     // search -- then cost 0.6 of what they cost on sixteen (config 4 over X: 159 passes / 0.147 s -> 85 / 0.092 s).
     // Covariance passes take thirty-two as well (a launch of the Gram product per half: 13-37 us each against the chain
     // of a whole pass saved).  Row-sharded solves stay at sixteen; so do rows beyond 5120 columns (no ring variant:
     // every residual from X is a read of the column-major copy per half).
-    if (ws_policy(ds, flags) == 2 && !row_sharded(ds) && ds->sk != nullptr && ds->sk->rowdot != nullptr &&
-        getenv("SLM_NO_WIDE_LANES") == nullptr && ensure_xt(ds) == SLM_OK && ds->XT != nullptr)
+    if (ws_policy(ds, flags) == 2 && !row_sharded(ds) && ds->sk->rowdot != nullptr && getenv("SLM_NO_WIDE_LANES") == nullptr &&
+        !ds->XT_failed)
       return kMaxLanes;
     return SPLIT_LANES;
   }
   int B = kMaxLanes;
   while (B > 1 && !ds->gk[B - 1]) --B;
   return B;
+}
+// A lane count beyond sixteen as a solve can really take it: the column-major copy is built here, on the dataset's own
+// device, and a dataset that has no memory for it stays at sixteen (XT_failed: max_lanes_for then says so as well).
+static int lanes_with_copy(slm_dataset* ds, uint32_t flags, int want, int* lanes_out) {
+  *lanes_out = want;
+  if (want <= SPLIT_LANES || small_ok(ds, flags)) return SLM_OK;
+  HIP_TRY(hipSetDevice(ds->eng->device));
+  SLM_TRY(ensure_xt(ds));
+  if (ds->XT == nullptr) *lanes_out = SPLIT_LANES;
+  return SLM_OK;
 }
 
 static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, const slm_solve_opts* opts,
@@ -977,6 +992,7 @@ static int solve_without_chip(slm_dataset* ds, const slm_lane* lanes, int32_t B,
 static int solve_core(slm_dataset* ds, const slm_lane* lanes, int32_t n_lanes, const slm_solve_opts* opts,
                       slm_solve_stats* stats, bool shared_path, const slm_reweight* rules, int32_t* rounds_out) {
   if (!ds || !lanes) return fail(SLM_ERR_BAD_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(ds->eng->device));  // (before anything that may allocate or launch: split_usable / ensure_xt below)
   if (rules) {
     // re-weighted rounds run inside the on-chip kernel, nowhere else: other problems keep their loop on the caller's side
     if (!rounds_out) return fail(SLM_ERR_BAD_ARG, "rounds_out is NULL");
@@ -2248,7 +2264,7 @@ extern "C" int slm_solve_lanes_reweighted(slm_dataset* ds, const slm_lane* lanes
 }
 
 // the engine's choice of lanes for a shared path (n_lanes = 0): the fewest passes over X at the price of sixteen lanes
-static int auto_lanes(slm_dataset* ds, int32_t n_points, uint32_t fl) {
+static int auto_lanes(const slm_dataset* ds, int32_t n_points, uint32_t fl) {
   const int cap = max_lanes_for(ds, fl);
   const bool big = ws_policy(ds, fl) == 2 && (double)ds->n * (double)ds->ld >= 67108864.0 && !small_ok(ds, fl);
   const bool interleaved = ds->singleton && !getenv("SLM_NO_INTERLEAVE");  // (solve_core: per-feature penalties take the points in turn)
@@ -2277,6 +2293,7 @@ extern "C" int slm_solve_path_lanes(slm_dataset* ds, const slm_penalty* pen, con
     B = std::max(1, std::min<int>(std::min<int>(n_lanes, kMaxLanes), n_points));
     B = std::min(B, max_lanes_for(ds, fl));  // no kernel variant for (p, B): fewer lanes
   }
+  SLM_TRY(lanes_with_copy(ds, fl, B, &B));  // (more than sixteen: the column-major copy, or sixteen)
   slm_lane lanes[SLM_MAX_LANES];
   memset(lanes, 0, sizeof(lanes));
   int64_t lo = 0;

@@ -44,3 +44,21 @@ def test_defaults_of_the_contract():
     coef = bench.make_coef(5000, 50, seed=0)
     assert coef.shape == (5000,) and np.count_nonzero(coef) == 50
     np.testing.assert_array_equal(coef, bench.make_coef(5000, 50, seed=0))
+
+
+def test_strong_scaling_object_and_cpu_baseline_layout():
+    """The objects the contract line carries beside `value` (round-5 verdict, items 2 and 8): keys a reader may rely on."""
+    bench = _bench()
+    ss = bench.strong_scaling_object(0.09, 0.027, 8)
+    assert {"metric", "scaling", "n_gpus", "unit", "higher_is_better", "value", "seconds_per_grid", "route",
+            "value_from_fold_grams", "seconds_per_grid_from_fold_grams", "note"} <= set(ss)
+    assert ss["scaling"] == "strong" and ss["n_gpus"] == 8 and abs(ss["value"] - 2500.0 / 0.09) < 1e-9
+    assert bench.strong_scaling_object(0.09, None, 1)["value_from_fold_grams"] is None
+    port = {"value": 2.4, "unit": "fits/s", "cores": 16, "kind": "port", "sample": "first 49 ...", "beta_rel_inf_err_gpu_vs_oracle": 1e-8,
+            "cvxpy": {"status": "cvxpy unavailable on box"}}
+    assert bench.stock_first(dict(port), 50, 100000, 5000) == port  # (no scikit-learn figure: the port is the value)
+    both = dict(port, sklearn_lasso_path={"value": 18.5, "unit": "fits/s", "cores": 16, "seconds_per_path": 2.7, "what": "lasso_path(...)",
+                                          "beta_rel_inf_err_gpu_vs_sklearn": 2e-11})
+    cb = bench.stock_first(both, 50, 100000, 5000)
+    assert cb["kind"] == "stock" and cb["value"] == 18.5 and cb["port"]["kind"] == "port" and cb["port"]["value"] == 2.4
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and {"value", "unit", "cores", "kind", "sample"} <= set(cb["port"])

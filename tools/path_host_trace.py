@@ -16,10 +16,10 @@ amax = float(np.max(np.abs(g0)))
 pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-3 * amax, K)]
 flags = _engine.FLAG_FRESH_L
 for _ in range(4):
-    ds.solve_path(pts, tol=1e-8, lanes=16, flags=flags)
+    ds.solve_path(pts, tol=1e-8, lanes=0, flags=flags)
 t = []
 for _ in range(6):
     t0 = time.perf_counter()
-    r = ds.solve_path(pts, tol=1e-8, lanes=16, flags=flags)
+    r = ds.solve_path(pts, tol=1e-8, lanes=0, flags=flags)
     t.append(time.perf_counter() - t0)
     sys.stderr.write(f"[py] call {1e3 * t[-1]:.3f} ms, engine wall {r.wall_ms:.3f} ms\n")
