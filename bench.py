@@ -1143,16 +1143,12 @@ def main():
         # charged ONE W; (ii) the read-only stream ceiling of THIS device on THIS copy of X (plain 16-byte loads, summed up)
         unit_ms = ceiling_gbs = ceiling_ms = None
         if split:
-            os.environ["SLM_PROFILE_UNIT"] = "1"
-            try:
-                u_ms, u_n = 0.0, 0
-                for _ in range(2):
-                    ru = ds.solve_path(points, tol=args.tol, flags=flags, lanes=args.lanes)
-                    u_ms += ru.grad_ms_total
-                    u_n += ru.grad_timed
-                unit_ms = u_ms / max(1, u_n)
-            finally:
-                del os.environ["SLM_PROFILE_UNIT"]
+            u_ms, u_n = 0.0, 0
+            for _ in range(2):
+                ru = ds.solve_path(points, tol=args.tol, flags=flags | _engine.FLAG_PROFILE_UNIT, lanes=args.lanes)
+                u_ms += ru.grad_ms_total
+                u_n += ru.grad_timed
+            unit_ms = u_ms / max(1, u_n)
         try:
             ceiling_gbs, ceiling_ms = ds.read_ceiling(reps=5)
         except Exception:  # noqa: BLE001 -- a measurement beside the line, never its condition
@@ -1223,7 +1219,7 @@ def main():
                 "gradient_unit_ms": unit_ms,
                 "gradient_unit_frac": (bytes_per_grad / (unit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if unit_ms else None,
                 "gradient_unit_what": "residuals of the lane slots (resid_mfma_kernel on the gathered columns) + the X^T R kernel, "
-                "one bracket of HIP events per pass (SLM_PROFILE_UNIT=1), charged the same algorithmic bytes: what a 16-lane gradient costs",
+                "one bracket of HIP events per pass (SLM_FLAG_PROFILE_UNIT), charged the same algorithmic bytes: what a 16-lane gradient costs",
                 "read_stream_ceiling_gbs": ceiling_gbs,
                 "read_stream_ceiling_ms_per_sweep": ceiling_ms,
                 "kernel_frac_of_read_stream_ceiling": (achieved / ceiling_gbs) if ceiling_gbs else None,

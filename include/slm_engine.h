@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 17
+#define SLM_ABI_VERSION 18
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -75,6 +75,9 @@ int slm_engine_create(int device_id, slm_engine** out);
 int slm_engine_destroy(slm_engine* eng);
 /* Blocks until all work queued on the engine's stream has finished. */
 int slm_engine_synchronize(slm_engine* eng);
+/* The SLM_* environment variables are read once per process, when the library first needs one.
+   This reads them again: for tests and A/B tools that change a variable after the library was loaded. */
+int slm_reload_knobs(void);
 /* Device facts used by bench.py / DESIGN.md: out[0]=compute units, out[1]=LDS bytes per CU,
    out[2]=total HBM bytes, out[3]=free HBM bytes, out[4]=wavefront size, out[5]=clock kHz. */
 int slm_engine_device_info(slm_engine* eng, int64_t out[6], char* name_out, int name_len);
@@ -158,6 +161,28 @@ int slm_dataset_lipschitz(slm_dataset* ds, double* L_out);
  */
 int slm_gradient(slm_dataset* ds, const double* z, double* g_out, double* loss_out, int32_t reps,
                  double* ms_out);
+/*
+ * The same evaluation by a NAMED route of the engine -- how the parity tests reach the kernels of the split pass through
+ * the boundary (until ABI 17 they were switched by the environment variables SLM_GRAD_SPLIT / SLM_GRAD_LANES /
+ * SLM_GRAD_LANE / SLM_PROBE_LANES, read inside slm_gradient).  opts == NULL: slm_gradient.
+ *   route 0: the fused one-read kernel (two passes beyond 10 240 columns);
+ *   route 1: the split pass -- residuals of the lane slots from X (rowdot*_mfma_kernel, or the ring kernel), then X^T R for
+ *            all lane slots on one read of X (xtr*_mfma_kernel).  n_lanes (1..SLM_MAX_LANES) lanes all stand at z and the
+ *            gradient of lane `lane_out` is returned: a lane of the second half is xtr32's second plane, or the vector
+ *            units' share of xtr18 / xtr20.  More than one lane needs the column-major copy (built on first use).
+ *            Where the dataset has no split pass the call falls back to route 0.
+ *   probe_lanes: lanes of the timed launches behind `reps` / ms_out (<= 0: one); xtr_only: time X^T R alone (route 1).
+ * Reference counterpart: the gradient of the smooth term of /root/reference/src/sparselm/model/_lasso.py:109-121.
+ */
+typedef struct slm_gradient_opts {
+  int32_t route;
+  int32_t n_lanes;
+  int32_t lane_out;
+  int32_t probe_lanes;
+  int32_t xtr_only;
+} slm_gradient_opts;
+int slm_gradient_ex(slm_dataset* ds, const double* z, const slm_gradient_opts* opts, double* g_out, double* loss_out,
+                    int32_t reps, double* ms_out);
 
 /*
  * Weighted squared error of m coefficient vectors, as many per pass over X as the fused kernel
@@ -232,6 +257,10 @@ typedef struct slm_path_point {
 #define SLM_FLAG_NO_MODEL_GRAM 512u   /* lanes whose solutions outgrow the working set's 512 columns finish with plain
                                         steps (two reads of X each) instead of rounds on the model Gram -- for
                                         measurements: the results agree to the tolerance either way              */
+
+#define SLM_FLAG_PROFILE_UNIT 1024u   /* with SLM_FLAG_PROFILE: the bracket of HIP events opens before the residual kernels of
+                                        the split pass -- the whole gradient unit (residuals + X^T R), not the launch that
+                                        streams X alone (bench.py: roofline.frac)                                   */
 
 typedef struct slm_solve_opts {
   double tol;          /* relative distance to the minimiser a point is accepted at: stop when the KKT

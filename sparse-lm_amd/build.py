@@ -72,7 +72,7 @@ def _binding_or_warn(force: bool) -> None:
         warnings.warn(f"the compiled binding was not built ({exc!r}); the ctypes route serves every call", RuntimeWarning)
 
 
-UNITS = ("engine.hip", "engine_solve.hip", "engine_cov.hip", "engine_mg.hip")  # handles / memory / communicators; solve loop; Grams; model Gram
+UNITS = ("engine.hip", "engine_solve.hip", "engine_path.hip", "engine_cov.hip", "engine_mg.hip")  # handles / memory / communicators; kernel tables + launches of a pass; the solve loop; Grams; model Gram
 
 
 def build(force: bool = False, extra_flags=()) -> str:

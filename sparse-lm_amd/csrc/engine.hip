@@ -128,11 +128,8 @@ static const size_t kPoolMinBytes = (size_t)64 << 20;
 // memory no other allocator on the GPU can have (another rank sharing the device, torch, RCCL's buffers): enough for the two
 // or three blocks of the largest dataset shape seen lately, not a standing reservation
 static size_t pool_idle_cap() {
-  static const size_t cap = [] {
-    if (const char* e = getenv("SLM_DEVICE_POOL_GB")) return (size_t)(std::max(0.0, atof(e)) * (double)((size_t)1 << 30));
-    return (size_t)24 << 30;
-  }();
-  return cap;
+  const double gb = knobs().device_pool_gb;
+  return gb >= 0.0 ? (size_t)(gb * (double)((size_t)1 << 30)) : (size_t)24 << 30;
 }
 // (the ledger itself -- which block waits, which is evicted -- is host_logic.hpp's PoolLedger: no device call in it, run
 //  under the sanitizers by tests/host_logic_test.cpp)
@@ -167,7 +164,7 @@ void pool_free(void* p) {
   {
     std::lock_guard<std::mutex> lk(g_pool.m);
     // (over the cap: the blocks that have waited longest go back to the driver first)
-    kept = g_pool.book.give_back(p, pool_idle_cap(), getenv("SLM_NO_DEVICE_POOL") == nullptr, &evict);
+    kept = g_pool.book.give_back(p, pool_idle_cap(), knobs().device_pool, &evict);
   }
   for (void* q : evict) (void)hipFree(q);
   if (!kept) (void)hipFree(p);
@@ -177,6 +174,26 @@ void pool_free(void* p) {
 // library
 // ------------------------------------------------------------------------------------------------
 extern "C" int slm_abi_version(void) { return SLM_ABI_VERSION; }
+
+// The environment is read HERE and nowhere else: once, when the first caller asks (host_logic.hpp: Knobs), and again when
+// slm_reload_knobs says so (tests and A/B tools that change a variable after the library is loaded).
+static std::mutex g_knobs_m;
+static slm_host::Knobs g_knobs;
+static bool g_knobs_loaded = false;
+const slm_host::Knobs& knobs() {
+  std::lock_guard<std::mutex> lk(g_knobs_m);
+  if (!g_knobs_loaded) {
+    g_knobs = slm_host::Knobs::from([](const char* name) -> const char* { return getenv(name); });
+    g_knobs_loaded = true;
+  }
+  return g_knobs;
+}
+extern "C" int slm_reload_knobs(void) {
+  std::lock_guard<std::mutex> lk(g_knobs_m);
+  g_knobs = slm_host::Knobs::from([](const char* name) -> const char* { return getenv(name); });
+  g_knobs_loaded = true;
+  return SLM_OK;
+}
 
 extern "C" int slm_host_alloc(size_t bytes, void** out) {
   if (!out || bytes == 0) return fail(SLM_ERR_BAD_ARG, "slm_host_alloc: NULL out or zero size");
@@ -233,7 +250,7 @@ extern "C" int slm_engine_create(int device_id, slm_engine** out) {
     delete eng;
     return fail(SLM_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
   }
-  if (strncmp(eng->prop.gcnArchName, "gfx950", 6) != 0 && !getenv("SLM_ALLOW_ANY_ARCH")) {
+  if (strncmp(eng->prop.gcnArchName, "gfx950", 6) != 0 && !knobs().allow_any_arch) {
     std::string arch = eng->prop.gcnArchName;
     delete eng;
     return fail(SLM_ERR_NO_DEVICE, "device %d is %s; this library only carries gfx950 (MI355X) code",
@@ -368,7 +385,7 @@ static int dataset_alloc(slm_engine* eng, int64_t n, int64_t p, slm_dataset** ou
       if (e != hipSuccess || occ < 1) occ = 1;
     }
     int per_cu = occ;
-    if (const char* env = getenv("SLM_GRAD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(env));
+    if (knobs().grad_blocks_per_cu > 0) per_cu = knobs().grad_blocks_per_cu;
     int64_t nblk = (int64_t)eng->cus * per_cu;
     const int64_t steps = (n + gk->R - 1) / gk->R;
     nblk = std::max<int64_t>(1, std::min<int64_t>(nblk, steps));

@@ -23,8 +23,8 @@ static int cov_gram(slm_dataset* ds, const double* A, int64_t rows, double* C) {
     HIP_TRY(hipMemsetAsync(C, 0, sizeof(double) * (size_t)ld * ld, s));
     return SLM_OK;
   }
-  if (const char* e = getenv("SLM_COV_TILE")) {
-    const int side = atoi(e) == 3 ? 3 : 4;  // (96 or 128 columns per workgroup)
+  if (knobs().cov_tile != 0) {
+    const int side = knobs().cov_tile == 3 ? 3 : 4;  // (96 or 128 columns per workgroup)
     const int nt = (int)((ld + 32 * side - 1) / (32 * side));
     const dim3 grid((unsigned)(nt * (nt + 1) / 2));
     if (side == 3) hipLaunchKernelGGL(cov_syrk_kernel<3>, grid, dim3(256), 0, s, A, rows, ld, C);

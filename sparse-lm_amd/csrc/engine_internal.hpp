@@ -40,6 +40,8 @@ using namespace slm;
 // errors (engine.hip)
 // ------------------------------------------------------------------------------------------------
 int fail(int code, const char* fmt, ...);
+// the SLM_* environment knobs, read once per process (engine.hip; slm_reload_knobs reads them again)
+const slm_host::Knobs& knobs();
 
 #define HIP_TRY(expr)                                                                       \
   do {                                                                                      \
@@ -339,10 +341,23 @@ LaneSetup default_lanes(slm_dataset* ds, int B);
 int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done, hipEvent_t ev_start, hipEvent_t ev_stop,
                      int64_t n_rows = 0);
 int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done, const PathCtl* ctl, const WsArgs* wa,
-                           hipEvent_t ev_start, hipEvent_t ev_stop, int64_t n_rows = 0);
+                           hipEvent_t ev_start, hipEvent_t ev_stop, int64_t n_rows = 0, bool unit_bracket = false);
 bool split_usable(slm_dataset* ds);
 int ensure_xt(slm_dataset* ds);
 int check_launch();
+// (engine_solve.hip, used by the solve loop of engine_path.hip)
+void launch_rowdot(slm_dataset* ds, const SplitKernel* sk, int nblk, int B, SplitArgs& a, hipStream_t s);
+int enqueue_gradient_cov(slm_dataset* ds, int B, const int* entry_of, const int* done, hipEvent_t ev_start, hipEvent_t ev_stop,
+                         const PathCtl* ctl = nullptr, const WsArgs* wa = nullptr);
+void launch_tail(const TailArgs& ta, hipStream_t s);
+int sketch_iters();
+int64_t sketch_rows(int64_t n);
+int power_iteration(slm_dataset* ds, const LaneSetup& ls_in, double* L_out /*[B]*/, int iters, int64_t n_rows = 0);
+int estimate_lipschitz(slm_dataset* ds, double* L_out, int iters);
+int allow_big_lds(const void* fn, int device);
+static const int kProfStride = 3;  // SLM_FLAG_PROFILE times every 3rd gradient launch (a working-set path has ~5: two of them;
+                                   // an event pair costs ~12 us of stream around the launch it brackets)
+static const int kPowerItersSolve = 2;  // power steps for the seed L of a solve (see engine_solve.hip)
 int cov_fingerprints(slm_dataset* ds, const double* const* w, int count, double* out /* [2 * count] */);
 int cov_find(const slm_dataset* ds, double fp1, double fp2, double n_eff);
 void cov_pending_drop(slm_dataset* ds);  // (engine_cov.hip)

@@ -7,8 +7,7 @@
 // Where the model Gram can exist: rows short enough for its 8 ld^2 bytes, all rows on this device (a row-sharded dataset
 // would have to all-reduce 8 ld^2 bytes per row set: not built).
 bool mg_possible(const slm_dataset* ds) {
-  if (const char* e = getenv("SLM_MG"))
-    if (e[0] == '0') return false;
+  if (knobs().mg == 0) return false;
   if (ds->mg_failed) return false;
   if (ds->ld > MG_MAX_LD || ds->n < 64) return false;
   if (row_sharded(ds)) return false;
@@ -58,7 +57,7 @@ static int mg_build(slm_dataset* ds, const double* w, double n_eff, float* G) {
     return rc;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool timed = getenv("SLM_TRACE") != nullptr;
+  const bool timed = knobs().trace != 0;
   if (timed) {
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
@@ -78,8 +77,7 @@ static int mg_build(slm_dataset* ds, const double* w, double n_eff, float* G) {
   {
     MgSyrkArgs a;
     a.M = XTh; a.n_pad = n_pad; a.k_chunk = k_chunk; a.n_tiles = n_tiles; a.n_chunks = n_chunks; a.P = P;
-    const char* e = getenv("SLM_MG_SYRK");  // (0: the register-staged form, for A/B runs)
-    if (e && e[0] == '0') hipLaunchKernelGGL(mg_syrk_f16_kernel, dim3((unsigned)((int64_t)n_tiles * n_chunks)), dim3(256), 0, s, a);
+    if (knobs().mg_syrk == 0) hipLaunchKernelGGL  /* (SLM_MG_SYRK=0: the register-staged form, for A/B runs) */(mg_syrk_f16_kernel, dim3((unsigned)((int64_t)n_tiles * n_chunks)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(mg_syrk_f16_dma_kernel, dim3((unsigned)((int64_t)n_tiles * n_chunks)), dim3(256), 0, s, a);
   }
   {

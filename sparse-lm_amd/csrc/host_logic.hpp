@@ -9,6 +9,8 @@
 #include <stddef.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <utility>
@@ -266,5 +268,157 @@ inline int model_gram_cap(int64_t ld, double budget_bytes, int most) {
   const double each = 4.0 * (double)ld * (double)ld;  // (fp32)
   return (int)std::max<double>(1.0, std::min<double>((double)most, budget_bytes / each));
 }
+
+// ---------------------------------------------------------------------------------------------
+// Every SLM_* environment knob of the engine, read ONCE (the first engine of the process; slm_reload_knobs reads again --
+// tests and A/B tools that change a variable mid-process call it) into this struct: the solve loop decides on plain
+// fields, not on getenv.  `get(name)` returns the variable's text or nullptr (the engine passes getenv; the sanitizer test
+// a table).  None of them is needed in normal use; DESIGN.md section 7a says what each does.
+// ---------------------------------------------------------------------------------------------
+struct Knobs {
+  // kernels and launch geometry
+  bool split = true;             // SLM_SPLIT=0: no split pass
+  double xtr_wgs_per_cu = 1.0;   // SLM_XTR_WGS_PER_CU (0 < f <= 2)
+  bool xtr_extras = true;        // SLM_XTR_EXTRAS=0: 17-20 lanes on both matrix-core halves
+  int grad_ring = -1;            // SLM_GRAD_RING: 0 off, 1 for every lane count, -1 from three lanes
+  int grad_cfg[3] = {0, 0, 0};   // SLM_GRAD_CONFIG=W,C,R
+  int grad_blocks_per_cu = 0;    // SLM_GRAD_BLOCKS_PER_CU (0: the table's)
+  int rowdot_ring = -1;          // SLM_ROWDOT_RING: 0 / 1 forces, -1 by lane count
+  bool rowdot32 = true;          // SLM_ROWDOT32=0: a read of the copy per half
+  bool resid_vec = false;        // SLM_RESID_VEC=1: a row per thread
+  bool resid32 = true;           // SLM_NO_RESID32: a read of the gathered columns per half
+  bool cov_all_rows = false;     // SLM_COV_ALL_ROWS
+  int cov_tile = 0;              // SLM_COV_TILE=3/4 (0: the packed kernel)
+  int mg_syrk = -1;              // SLM_MG_SYRK=0: the register-staged product
+  // step-size seeds
+  int l_sketch_iters = 1;        // SLM_L_SKETCH_ITERS (1..16)
+  int l_sketch_div = 32;         // SLM_L_SKETCH_DIV (1..1024)
+  int power_iters = 0;           // SLM_POWER_ITERS (>= 2; 0: the caller's)
+  bool l_sketch = true;          // SLM_NO_L_SKETCH
+  bool sketch_cache = true;      // SLM_NO_SKETCH_CACHE
+  // routes of a solve
+  int ws = -1;                   // SLM_WS: 0 never, 1 from the first pass, -1 by size
+  bool on_chip = true;           // SLM_ON_CHIP=0
+  bool on_chip_fallback = true;  // SLM_ON_CHIP_NO_FALLBACK
+  bool small_stage = true;       // SLM_NO_SMALL_STAGE
+  bool wide_lanes = true;        // SLM_NO_WIDE_LANES
+  int auto_lanes = 0;            // SLM_AUTO_LANES (0: the engine's choice)
+  bool interleave = true;        // SLM_NO_INTERLEAVE
+  bool tail_band = true;         // SLM_NO_TAIL_BAND
+  bool slack_deep = true;        // SLM_NO_SLACK_DEEP
+  bool carry = true;             // SLM_NO_CARRY
+  bool ws_carry = true;          // SLM_NO_WS_CARRY
+  bool eval_fused = false;       // SLM_EVAL_FUSED
+  bool profile_unit = false;     // SLM_PROFILE_UNIT (slm_solve_opts.flags & SLM_FLAG_PROFILE_UNIT asks for the same per call)
+  // working set
+  bool direct = true;            // SLM_NO_DIRECT
+  double ws_theta = 0.85;        // SLM_WS_THETA (0 < v <= 1)
+  int ws_lookahead = 2;          // SLM_WS_LOOKAHEAD (0..64)
+  int ws_append = 48;            // SLM_WS_APPEND (1..512)
+  int ws_kinit = 0;              // SLM_WS_KINIT (16..512; 0: by penalty and path)
+  int ws_bb = 1;                 // SLM_WS_BB
+  int ws_one_solver = 0;         // SLM_WS_ONE_SOLVER
+  bool hard_callwide = false;    // SLM_HARD_CALLWIDE
+  int ws_power_iters = 10;       // SLM_WS_POWER_ITERS (1..40)
+  int ws_miss_factor = 4;        // SLM_WS_MISS_FACTOR (1..8)
+  double ws_fill = 0.0;          // SLM_WS_FILL (0.1..1; 0: by penalty and path)
+  // sample start
+  bool sample_start = true;      // SLM_NO_SAMPLE_START
+  bool sample_start_all = false; // SLM_SAMPLE_START_ALL
+  int64_t sample_min_rows = 65536;  // SLM_SAMPLE_START_MIN_ROWS (>= 64)
+  int sample_div = 4;            // SLM_SAMPLE_DIV (1..64)
+  // model Gram
+  int mg = -1;                   // SLM_MG: 0 off, 2 forced from the first snapshot (tests), -1 by capacity
+  bool mg_keep = true;           // SLM_NO_MG_KEEP
+  bool handover = true;          // SLM_NO_HANDOVER
+  // chain between two passes (round 6)
+  bool fuse_tail = true;         // SLM_NO_FUSED_TAIL: tail, scores and selection as launches of their own
+  bool fuse_resid = true;        // SLM_NO_FUSED_RESID: the two residual kernels as launches of their own
+  bool fuse_solve = true;        // SLM_NO_FUSED_SOLVE: the model solver with direct steps as a launch of its own
+  // memory, diagnostics
+  double device_pool_gb = -1.0;  // SLM_DEVICE_POOL_GB (< 0: the default cap)
+  bool device_pool = true;       // SLM_NO_DEVICE_POOL
+  bool allow_any_arch = false;   // SLM_ALLOW_ANY_ARCH
+  int trace = 0;                 // SLM_TRACE=1/2/3 (any other text: 1)
+  bool trace_poll = false;       // SLM_TRACE_POLL
+
+  template <typename Get>
+  static Knobs from(Get get) {
+    Knobs k;
+    auto text = [&](const char* name) -> const char* { return get(name); };
+    auto is_set = [&](const char* name) { return text(name) != nullptr; };
+    auto first = [&](const char* name) -> char { const char* e = text(name); return e ? e[0] : '\0'; };
+    auto as_int = [&](const char* name, int lo, int hi, int* out) {
+      if (const char* e = text(name)) *out = std::max(lo, std::min(hi, atoi(e)));
+    };
+    k.split = first("SLM_SPLIT") != '0';
+    if (const char* e = text("SLM_XTR_WGS_PER_CU")) {
+      const double f = atof(e);
+      if (f > 0.0 && f <= 2.0) k.xtr_wgs_per_cu = f;
+    }
+    k.xtr_extras = first("SLM_XTR_EXTRAS") != '0';
+    if (const char c = first("SLM_GRAD_RING")) k.grad_ring = c == '0' ? 0 : (c == '1' ? 1 : -1);
+    if (const char* e = text("SLM_GRAD_CONFIG")) {
+      int W = 0, C = 0, R = 0;
+      if (sscanf(e, "%d,%d,%d", &W, &C, &R) == 3) { k.grad_cfg[0] = W; k.grad_cfg[1] = C; k.grad_cfg[2] = R; }
+    }
+    if (const char* e = text("SLM_GRAD_BLOCKS_PER_CU")) k.grad_blocks_per_cu = std::max(1, atoi(e));
+    if (const char c = first("SLM_ROWDOT_RING")) k.rowdot_ring = c == '1' ? 1 : 0;
+    k.rowdot32 = first("SLM_ROWDOT32") != '0';
+    k.resid_vec = first("SLM_RESID_VEC") == '1';
+    k.resid32 = !is_set("SLM_NO_RESID32");
+    k.cov_all_rows = is_set("SLM_COV_ALL_ROWS");
+    if (const char* e = text("SLM_COV_TILE")) k.cov_tile = atoi(e);
+    if (first("SLM_MG_SYRK") == '0') k.mg_syrk = 0;
+    as_int("SLM_L_SKETCH_ITERS", 1, 16, &k.l_sketch_iters);
+    as_int("SLM_L_SKETCH_DIV", 1, 1024, &k.l_sketch_div);
+    if (const char* e = text("SLM_POWER_ITERS")) k.power_iters = std::max(2, atoi(e));
+    k.l_sketch = !is_set("SLM_NO_L_SKETCH");
+    k.sketch_cache = !is_set("SLM_NO_SKETCH_CACHE");
+    if (const char c = first("SLM_WS")) k.ws = c == '0' ? 0 : (c == '1' ? 1 : -1);
+    k.on_chip = first("SLM_ON_CHIP") != '0';
+    k.on_chip_fallback = !is_set("SLM_ON_CHIP_NO_FALLBACK");
+    k.small_stage = !is_set("SLM_NO_SMALL_STAGE");
+    k.wide_lanes = !is_set("SLM_NO_WIDE_LANES");
+    if (const char* e = text("SLM_AUTO_LANES")) k.auto_lanes = std::max(1, atoi(e));
+    k.interleave = !is_set("SLM_NO_INTERLEAVE");
+    k.tail_band = !is_set("SLM_NO_TAIL_BAND");
+    k.slack_deep = !is_set("SLM_NO_SLACK_DEEP");
+    k.carry = !is_set("SLM_NO_CARRY");
+    k.ws_carry = !is_set("SLM_NO_WS_CARRY");
+    k.eval_fused = is_set("SLM_EVAL_FUSED");
+    k.profile_unit = is_set("SLM_PROFILE_UNIT");
+    k.direct = !is_set("SLM_NO_DIRECT");
+    if (const char* e = text("SLM_WS_THETA")) {
+      const double v = atof(e);
+      if (v > 0.0 && v <= 1.0) k.ws_theta = v;
+    }
+    as_int("SLM_WS_LOOKAHEAD", 0, 64, &k.ws_lookahead);
+    as_int("SLM_WS_APPEND", 1, 512, &k.ws_append);
+    as_int("SLM_WS_KINIT", 16, 512, &k.ws_kinit);
+    if (const char* e = text("SLM_WS_BB")) k.ws_bb = atoi(e) != 0;
+    if (const char* e = text("SLM_WS_ONE_SOLVER")) k.ws_one_solver = atoi(e) != 0;
+    k.hard_callwide = is_set("SLM_HARD_CALLWIDE");
+    as_int("SLM_WS_POWER_ITERS", 1, 40, &k.ws_power_iters);
+    as_int("SLM_WS_MISS_FACTOR", 1, 8, &k.ws_miss_factor);
+    if (const char* e = text("SLM_WS_FILL")) k.ws_fill = std::max(0.1, std::min(1.0, atof(e)));
+    k.sample_start = !is_set("SLM_NO_SAMPLE_START");
+    k.sample_start_all = is_set("SLM_SAMPLE_START_ALL");
+    if (const char* e = text("SLM_SAMPLE_START_MIN_ROWS")) k.sample_min_rows = std::max<int64_t>(64, atoll(e));
+    as_int("SLM_SAMPLE_DIV", 1, 64, &k.sample_div);
+    if (const char c = first("SLM_MG")) k.mg = c == '0' ? 0 : (c == '2' ? 2 : -1);
+    k.mg_keep = !is_set("SLM_NO_MG_KEEP");
+    k.handover = !is_set("SLM_NO_HANDOVER");
+    k.fuse_tail = !is_set("SLM_NO_FUSED_TAIL");
+    k.fuse_resid = !is_set("SLM_NO_FUSED_RESID");
+    k.fuse_solve = !is_set("SLM_NO_FUSED_SOLVE");
+    if (const char* e = text("SLM_DEVICE_POOL_GB")) k.device_pool_gb = std::max(0.0, atof(e));
+    k.device_pool = !is_set("SLM_NO_DEVICE_POOL");
+    k.allow_any_arch = is_set("SLM_ALLOW_ANY_ARCH");
+    if (const char c = first("SLM_TRACE")) k.trace = (c >= '1' && c <= '3') ? c - '0' : 1;
+    k.trace_poll = is_set("SLM_TRACE_POLL");
+    return k;
+  }
+};
 
 }  // namespace slm_host

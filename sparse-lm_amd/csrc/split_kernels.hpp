@@ -683,14 +683,21 @@ __device__ __forceinline__ void rowdot_step(const double* xt0, int64_t ld, const
 // rounds -- used to read the 4 GB twice).
 // E > 0 (H = 1, grid.y = 1): 16 + E lanes -- half 0 on the matrix cores, the first E lanes of half 1 on the vector units beside
 // them (rowdot_step): seventeen to twenty lanes at the price of sixteen, as in xtr18 / xtr20_mfma_kernel.
+// doubles of LDS the body needs: the wavefronts' loss sums, their partial products of one step, the extra lanes' sums
 template <int H, int E = 0>
-__device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
+constexpr int rowdot_lds_doubles() {
+  return XZ_WAVES * (E > 0 ? 2 : H) * SPLIT_LANES + H * XZ_WAVES * XZ_T * 2 * 4 * 64 + (E > 0 ? XZ_WAVES * E * XZ_T * 32 : 1);
+}
+// (lds: rowdot_lds_doubles<H, E>() doubles; bx / nbx: this workgroup's row block and their number; by: the half served when a
+//  launch serves one half per grid row -- the kernels below pass blockIdx / gridDim, residuals_kernel its own split of the grid)
+template <int H, int E = 0>
+__device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a, double* lds, int bx, int nbx, int by) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 rows of the MFMA A operand");
   static_assert(E == 0 || (H == 1 && (E == 2 || E == 4)), "extras: the first lanes of half 1 beside the sixteen of half 0");
   constexpr int HZ = E > 0 ? 2 : H;   // halves whose lanes this launch serves (masks, the cold start, the loss sums)
   constexpr int EE = E > 0 ? E : 1;
   if (a.done != nullptr && *a.done != 0) return;
-  const int half0 = (H == 1 && E == 0) ? (int)blockIdx.y : 0;  // first half served here
+  const int half0 = (H == 1 && E == 0) ? by : 0;  // first half served here
   unsigned mask[HZ];
   bool any = false;
 #pragma unroll
@@ -700,12 +707,13 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
   }
   if (!any) return;
   const int LS = split_slots(a);
-  __shared__ double red[XZ_WAVES][HZ * SPLIT_LANES];
-  __shared__ double part[H * XZ_WAVES * XZ_T * 2 * 4 * 64];  // 64 KiB per half: the wavefronts' partial products of one step
-  __shared__ double partE[E > 0 ? XZ_WAVES * E * XZ_T * 32 : 1];  // the extra lanes' sums of a step: [wavefront][e][tile][32 rows]
+  constexpr int RS = HZ * SPLIT_LANES;  // red[wavefront][RS]
+  double* red = lds;
+  double* part = red + XZ_WAVES * RS;  // 64 KiB per half: the wavefronts' partial products of one step
+  double* partE = part + H * XZ_WAVES * XZ_T * 2 * 4 * 64;  // the extra lanes' sums of a step: [wavefront][e][tile][32 rows]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t b = blockIdx.x;
+  const int64_t b = bx;
   const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
   const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
 
@@ -753,12 +761,12 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
       }
       ls += __shfl_xor(ls, 16, 64);
       ls += __shfl_xor(ls, 32, 64);
-      if (lane < SPLIT_LANES) red[wave][h * SPLIT_LANES + lane] = ls;
+      if (lane < SPLIT_LANES) red[wave * RS + h * SPLIT_LANES + lane] = ls;
     }
     __syncthreads();
     if (tid < HZ * SPLIT_LANES && ((mask[tid / SPLIT_LANES] >> (tid % SPLIT_LANES)) & 1u)) {
       double t = 0.0;
-      for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2][tid];
+      for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2 * RS + tid];
       a.loss_partial[b * LS + SPLIT_LANES * half0 + tid] = t;
     }
     return;
@@ -772,7 +780,7 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
   // profiles/r03a_rowdot_counters.json.)
   const int j = lane & 15, q = lane >> 4;
   const int64_t tiles_all = (a.n + 31) >> 5;
-  const int64_t tb = tiles_all / gridDim.x, tr = tiles_all % gridDim.x;
+  const int64_t tb = tiles_all / nbx, tr = tiles_all % nbx;
   const int64_t t_lo = b * tb + (b < tr ? b : tr);
   const int T = (int)(tb + (b < tr ? 1 : 0));
   // A step = up to XZ_T adjacent tiles, taken by ALL wavefronts together: wavefront w contracts ITS quarter of the
@@ -870,26 +878,32 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a) {
       double t = loss[h][r];
 #pragma unroll
       for (int off = 8; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-      if (j == 0) red[wave][h * SPLIT_LANES + q + 4 * r] = t;
+      if (j == 0) red[wave * RS + h * SPLIT_LANES + q + 4 * r] = t;
     }
   if constexpr (E > 0) {
     double t = lossE;
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
-    if (j == 0) red[wave][SPLIT_LANES + q] = t;  // (q >= E: zero; slots beyond 16 + 3 are never read)
+    if (j == 0) red[wave * RS + SPLIT_LANES + q] = t;  // (q >= E: zero; slots beyond 16 + 3 are never read)
   }
   __syncthreads();
   if (tid < HZ * SPLIT_LANES && ((mask[tid / SPLIT_LANES] >> (tid % SPLIT_LANES)) & 1u)) {
     double t = 0.0;
-    for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2][tid];
+    for (int w2 = 0; w2 < XZ_WAVES; ++w2) t += red[w2 * RS + tid];
     a.loss_partial[b * LS + SPLIT_LANES * half0 + tid] = t;
   }
 }
 
-static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot_mfma_kernel(SplitArgs a) { rowdot_mfma_body<1>(a); }
-static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot32_mfma_kernel(SplitArgs a) { rowdot_mfma_body<2>(a); }
-static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot18_mfma_kernel(SplitArgs a) { rowdot_mfma_body<1, 2>(a); }
-static __global__ __launch_bounds__(XZ_WAVES * 64) void rowdot20_mfma_kernel(SplitArgs a) { rowdot_mfma_body<1, 4>(a); }
+#define SLM_ROWDOT_KERNEL(name, H, E)                                                                  \
+  static __global__ __launch_bounds__(XZ_WAVES * 64) void name(SplitArgs a) {                          \
+    __shared__ double lds[rowdot_lds_doubles<H, E>()];                                                 \
+    rowdot_mfma_body<H, E>(a, lds, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);                  \
+  }
+SLM_ROWDOT_KERNEL(rowdot_mfma_kernel, 1, 0)
+SLM_ROWDOT_KERNEL(rowdot32_mfma_kernel, 2, 0)
+SLM_ROWDOT_KERNEL(rowdot18_mfma_kernel, 1, 2)
+SLM_ROWDOT_KERNEL(rowdot20_mfma_kernel, 1, 4)
+#undef SLM_ROWDOT_KERNEL
 
 // ---------------------------------------------------------------------------------------------
 // The residuals from the gathered columns on the matrix cores: R[row][l] = w_l,row (XW_row . zW_l - y_row)
@@ -906,10 +920,12 @@ constexpr int RM_U = 4;  // 16-position groups per batch (two batches in flight)
 // H = 1: the sixteen lanes of half blockIdx.y.  H = 2: BOTH halves of a call of more than sixteen lanes on one read of the
 // gathered columns (a launch per half read them twice: 66 us against 40 on the headline path's eighteen lanes).
 template <int H>
-__device__ __forceinline__ void resid_mfma_body(SplitArgs& a) {
+constexpr int resid_lds_doubles() { return H * WS_KCAP * SPLIT_LANES + RM_WAVES * H * SPLIT_LANES; }
+template <int H>
+__device__ __forceinline__ void resid_mfma_body(SplitArgs& a, double* lds, int bx, int by) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 columns of the MFMA B operand");
   if (a.done != nullptr && *a.done != 0) return;
-  const int half0 = H == 1 ? (int)blockIdx.y : 0;  // (grid.y: the halves of the call, one launch each; H = 2: both here)
+  const int half0 = H == 1 ? by : 0;  // (grid.y: the halves of the call, one launch each; H = 2: both here)
   unsigned mask[H];
   bool any = false;
 #pragma unroll
@@ -918,12 +934,12 @@ __device__ __forceinline__ void resid_mfma_body(SplitArgs& a) {
     any = any || mask[h] != 0u;
   }
   if (!any) return;
-  __shared__ double zw[H][WS_KCAP][SPLIT_LANES];  // 64 KiB per half
-  __shared__ double lsum[RM_WAVES][H * SPLIT_LANES];
+  double* zw = lds;                                 // [H][WS_KCAP][SPLIT_LANES]: 64 KiB per half
+  double* lsum = lds + H * WS_KCAP * SPLIT_LANES;   // [RM_WAVES][H * SPLIT_LANES]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = a.ws->K;  // multiple of 16; positions >= Kreal hold zero columns
-  const int64_t b = blockIdx.x;
+  const int64_t b = bx;
   const int64_t r0 = b * a.rows_base + (b < a.rows_rem ? b : a.rows_rem);
   const int64_t nrows = a.rows_base + (b < a.rows_rem ? 1 : 0);
   const int64_t rend = r0 + nrows;
@@ -933,7 +949,7 @@ __device__ __forceinline__ void resid_mfma_body(SplitArgs& a) {
     for (int e = tid; e < K * SPLIT_LANES; e += RM_WAVES * 64) {
       const int k = e >> 4, l = e & 15;
       const int j = a.idx[k];
-      zw[h][k][l] = (j >= 0 && L0 + l < a.n_lanes) ? a.z[(int64_t)(L0 + l) * a.ld + j] : 0.0;
+      zw[(h * WS_KCAP + k) * SPLIT_LANES + l] = (j >= 0 && L0 + l < a.n_lanes) ? a.z[(int64_t)(L0 + l) * a.ld + j] : 0.0;
     }
   }
   __syncthreads();
@@ -979,7 +995,7 @@ __device__ __forceinline__ void resid_mfma_body(SplitArgs& a) {
         if (g0 + u < ngroups) {
 #pragma unroll
           for (int h = 0; h < H; ++h) {
-            const double* zr = &zw[h][16 * (g0 + u) + 4 * q][i16];
+            const double* zr = zw + (h * WS_KCAP + 16 * (g0 + u) + 4 * q) * SPLIT_LANES + i16;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
               acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[u][m], zr[m * SPLIT_LANES], acc[h], 0, 0, 0);
@@ -1014,17 +1030,44 @@ __device__ __forceinline__ void resid_mfma_body(SplitArgs& a) {
   for (int h = 0; h < H; ++h) {
     loss[h] += __shfl_xor(loss[h], 16, 64);
     loss[h] += __shfl_xor(loss[h], 32, 64);
-    if (lane < SPLIT_LANES) lsum[wave][h * SPLIT_LANES + lane] = loss[h];
+    if (lane < SPLIT_LANES) lsum[wave * (H * SPLIT_LANES) + h * SPLIT_LANES + lane] = loss[h];
   }
   __syncthreads();
   if (tid < H * SPLIT_LANES && ((mask[tid / SPLIT_LANES] >> (tid % SPLIT_LANES)) & 1u)) {
     double t = 0.0;
-    for (int w2 = 0; w2 < RM_WAVES; ++w2) t += lsum[w2][tid];
+    for (int w2 = 0; w2 < RM_WAVES; ++w2) t += lsum[w2 * (H * SPLIT_LANES) + tid];
     a.loss_partial[b * split_slots(a) + SPLIT_LANES * half0 + tid] = t;
   }
 }
 
-static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) { resid_mfma_body<1>(a); }
-static __global__ __launch_bounds__(RM_WAVES * 64) void resid32_mfma_kernel(SplitArgs a) { resid_mfma_body<2>(a); }
+static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitArgs a) {
+  __shared__ double lds[resid_lds_doubles<1>()];
+  resid_mfma_body<1>(a, lds, (int)blockIdx.x, (int)blockIdx.y);
+}
+static __global__ __launch_bounds__(RM_WAVES * 64) void resid32_mfma_kernel(SplitArgs a) {
+  __shared__ double lds[resid_lds_doubles<2>()];
+  resid_mfma_body<2>(a, lds, (int)blockIdx.x, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Both residual kernels of a pass in ONE launch (round 6): the first half of the grid forms the residuals of the lanes whose
+// points are supported on the working set from the gathered columns (resid_mfma_body), the second half those of the other
+// lanes from the column-major copy of X (rowdot_mfma_body: its four wavefronts; it returns at once when no lane needs X --
+// the usual pass of a working-set path, where the launch of its own was 4.8 us of the chain between two passes over X).
+// The two halves write disjoint lane slots of R and of loss_partial: no order between them is needed.  HR / ER: the form of
+// rowdot (both halves; extra lanes on the vector units), HS: of resid.
+// ---------------------------------------------------------------------------------------------
+template <int HR, int ER, int HS>
+__global__ __launch_bounds__(RM_WAVES * 64) void residuals_kernel(SplitArgs a) {
+  constexpr int NR = rowdot_lds_doubles<HR, ER>(), NS = resid_lds_doubles<HS>();
+  __shared__ double lds[NR > NS ? NR : NS];
+  const int nb = (int)gridDim.x >> 1;
+  if ((int)blockIdx.x < nb) {
+    resid_mfma_body<HS>(a, lds, (int)blockIdx.x, 0);
+  } else {
+    if (threadIdx.x >= XZ_WAVES * 64) return;  // (before any barrier: the body is written for four wavefronts)
+    rowdot_mfma_body<HR, ER>(a, lds, (int)blockIdx.x - nb, nb, 0);
+  }
+}
 
 }  // namespace slm

@@ -1075,23 +1075,44 @@ __device__ __forceinline__ void ws_sum(double (&v)[NV], double (*lds)[TAIL_WAVES
 // DIRECT instance launched right behind (WsCtl::want_full; returns false).  Most solves never take one, and the
 // kernel without the factorisation is a fifth of the code, keeps its registers (the full one spills 250 of them
 // at 128 per thread) and leaves no scratch lines for the end of the kernel to write back.
-template <bool GROUPED, bool DIRECT>
-__device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, double (*red)[TAIL_WAVES]) {
-  __shared__ double delta[WS_KCAP];
-  __shared__ double uim[WS_KCAP];
-  __shared__ int nz[WS_KCAP];
-  __shared__ int nnz_s;
-  __shared__ double part[WS_THREADS];
-  __shared__ double Gl[WS_KLDS * WS_KLDS];
+// LDS of the model solver: one block per workgroup, handed to ws_refine_lane by the kernel -- the instance with direct
+// steps and the one without are called from ONE kernel now (ws_solve_kernel<GROUPED, 2>) and use the same block one after
+// the other (as `__shared__` arrays of the function each instance had its own copy: twice 140 KB)
+struct WsSolveLds {
+  double delta[WS_KCAP];
+  double uim[WS_KCAP];
+  double part[WS_THREADS];
+  double Gl[WS_KLDS * WS_KLDS];
   // direct step (newton_kernels.hpp)
-  __shared__ NtShared nts;
-  __shared__ double nv[WS_KCAP];   // right-hand side / solution, indexed by rank in the face
-  __shared__ int act[WS_KCAP];     // position of the ii-th face coordinate
-  __shared__ int rank_of[WS_KCAP]; // rank of a position in the face, or -1
-  __shared__ int m_s;
-  __shared__ double xsl[WS_KCAP];  // direct step with group norms: the base point,
-  __shared__ double rgl[WS_KCAP];  // the norm of each position's group there,
-  __shared__ double pbl[WS_KCAP];  // and its group weight
+  NtShared nts;
+  double nv[WS_KCAP];   // right-hand side / solution, indexed by rank in the face
+  double xsl[WS_KCAP];  // direct step with group norms: the base point,
+  double rgl[WS_KCAP];  // the norm of each position's group there,
+  double pbl[WS_KCAP];  // and its group weight
+  double scale2;        // the length scale of the problem on W (see the iteration)
+  int nz[WS_KCAP];
+  int act[WS_KCAP];      // position of the ii-th face coordinate
+  int rank_of[WS_KCAP];  // rank of a position in the face, or -1
+  int nnz, m;
+};
+
+template <bool GROUPED, bool DIRECT>
+__device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, double (*red)[TAIL_WAVES], WsSolveLds& sh) {
+  double (&delta)[WS_KCAP] = sh.delta;
+  double (&uim)[WS_KCAP] = sh.uim;
+  int (&nz)[WS_KCAP] = sh.nz;
+  int& nnz_s = sh.nnz;
+  double (&part)[WS_THREADS] = sh.part;
+  double (&Gl)[WS_KLDS * WS_KLDS] = sh.Gl;
+  NtShared& nts = sh.nts;
+  double (&nv)[WS_KCAP] = sh.nv;
+  int (&act)[WS_KCAP] = sh.act;
+  int (&rank_of)[WS_KCAP] = sh.rank_of;
+  int& m_s = sh.m;
+  double (&xsl)[WS_KCAP] = sh.xsl;
+  double (&rgl)[WS_KCAP] = sh.rgl;
+  double (&pbl)[WS_KCAP] = sh.pbl;
+  double& scale2_s = sh.scale2;
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
   WsCtl* ws = w.ws;
@@ -1803,7 +1824,6 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
   // measured against where the iterate itself is zero or dust)
   // (kept in LDS, not in a register across the loop: the kernel sits at the 128 registers of a 1 024-thread workgroup, and a
   //  value more across the iteration was 12 bytes of scratch per thread)
-  __shared__ double scale2_s;
   {
     double sg[1] = {mine ? g0 * g0 : 0.0};
     ws_sum<1>(sg, red, nwc);
@@ -2024,21 +2044,39 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
   return true;
 }
 
-template <bool GROUPED, bool DIRECT>
+// MODE 0: the iteration alone (lanes that would take a direct step are left, untouched, with WsCtl::want_full set);
+// MODE 1: the solver with direct steps, for the lanes MODE 0 left (a launch of its own behind it: SLM_NO_FUSED_SOLVE);
+// MODE 2 (round 6): both in one launch -- a workgroup runs the light instance and, only if that leaves the lane, the full
+// one: most passes never take a direct step, and the second launch was 4.8 us of the chain between two passes for
+// finding that out.  (The light instance's code is the same either way: it shares the kernel, not its registers' live
+// ranges, with the factorisation.)
+template <bool GROUPED, int MODE>
 __global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs w) {
   __shared__ double red[8][TAIL_WAVES];
+  __shared__ WsSolveLds sh;
   const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
   if (ctl->done != 0 || ctl->idle != 0 || a.gdone[0] != 0) return;
   const unsigned long long tk_in = wall_clock64();
-  if (DIRECT) {  // only the lanes the light kernel left
+  if (MODE == 1) {  // only the lanes the light kernel left
     const int mine = w.ws->want_full[lane_id] | w.one_solver;
     __syncthreads();
     if (!mine) return;
     if (threadIdx.x == 0) w.ws->want_full[lane_id] = 0;
   }
   // (every return inside is taken by the whole workgroup)
-  if (!ws_refine_lane<GROUPED, DIRECT>(a, w, red)) return;
+  if (MODE == 0) {
+    if (!ws_refine_lane<GROUPED, false>(a, w, red, sh)) return;
+  } else if (MODE == 1) {
+    (void)ws_refine_lane<GROUPED, true>(a, w, red, sh);
+  } else {
+    const bool light = !(w.one_solver && w.nt != nullptr);
+    if (!light || !ws_refine_lane<GROUPED, false>(a, w, red, sh)) {
+      __syncthreads();  // (the light instance has written nothing of the solve: the block starts afresh)
+      if (threadIdx.x == 0) w.ws->want_full[lane_id] = 0;
+      (void)ws_refine_lane<GROUPED, true>(a, w, red, sh);
+    }
+  }
   __syncthreads();
   // Is the point the next pass evaluates zero outside W?  Then its residual needs only the gathered
   // columns (resid_ws_kernel) and the pass over X is the accumulate-only xtr_ring_kernel.

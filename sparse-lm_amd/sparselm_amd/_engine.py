@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 import weakref
 
@@ -40,10 +41,11 @@ FLAG_WORKING_SET = 32  # force the Gram-assisted refinement even for small X
 FLAG_NO_WORKING_SET = 64
 FLAG_ON_CHIP = 128  # problems whose Gram matrix fits a workgroup: one launch per call (csrc/small_kernels.hpp)
 FLAG_COVARIANCE = 256  # passes from the Grams of the call's row sets (Dataset.covariance; csrc/cov_kernels.hpp)
+FLAG_PROFILE_UNIT = 1024  # with FLAG_PROFILE: the event bracket spans residuals + X^T R, the whole gradient unit of the split pass
 FLAG_NO_MODEL_GRAM = 512  # lanes beyond the working set's 512 columns take plain steps, no rounds on the model Gram (csrc/mg_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 17  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 18  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -55,6 +57,7 @@ ABI_SYMBOLS = (
     "slm_engine_create",
     "slm_engine_destroy",
     "slm_engine_synchronize",
+    "slm_reload_knobs",
     "slm_engine_device_info",
     "slm_dataset_create",
     "slm_dataset_create_device",
@@ -72,6 +75,7 @@ ABI_SYMBOLS = (
     "slm_dataset_max_lanes",
     "slm_dataset_path_lanes",
     "slm_gradient",
+    "slm_gradient_ex",
     "slm_eval_sse",
     "slm_eval_sse_sparse",
     "slm_dense_spd_solve",
@@ -111,6 +115,11 @@ class NonFiniteError(EngineError):
 
 class _PenaltyStruct(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("d", C.c_void_p)]
+
+
+class _GradientOpts(C.Structure):
+    _fields_ = [("route", C.c_int32), ("n_lanes", C.c_int32), ("lane_out", C.c_int32), ("probe_lanes", C.c_int32),
+                ("xtr_only", C.c_int32)]
 
 
 class _PathPoint(C.Structure):
@@ -272,6 +281,8 @@ def load_library():
             "slm_dataset_max_lanes": [vp, C.c_uint32, P(i32)],
             "slm_dataset_path_lanes": [vp, i32, C.c_uint32, P(i32)],
             "slm_gradient": [vp, vp, vp, P(dbl), i32, P(dbl)],
+            "slm_gradient_ex": [vp, vp, P(_GradientOpts), vp, P(dbl), i32, P(dbl)],
+            "slm_reload_knobs": [],
             "slm_eval_sse": [vp, vp, i32, vp, vp],
             "slm_eval_sse_sparse": [vp, vp, i32, vp, i32, vp, vp],
             "slm_dense_spd_solve": [vp, vp, i32, vp, vp, P(dbl)],
@@ -542,6 +553,7 @@ class Engine:
 
     # -- datasets -----------------------------------------------------------------------------
     def dataset(self, X, y, row_weight=None) -> "Dataset":
+        _sync_knobs()
         X = np.asarray(X, dtype=np.float64)
         if X.ndim != 2:
             raise ValueError("X must be 2-D")
@@ -563,6 +575,7 @@ class Engine:
         return Dataset(self, h, n, p)
 
     def dataset_from_device(self, dX_ptr: int, n: int, p: int, ld: int, dy_ptr: int, drw_ptr: int = 0):
+        _sync_knobs()
         h = C.c_void_p()
         _check(
             self._lib.slm_dataset_create_device(
@@ -572,6 +585,7 @@ class Engine:
         return Dataset(self, h, n, p)
 
     def synthetic_dataset(self, n, p, seed, coef, noise_sd=0.0, row_offset=0) -> "Dataset":
+        _sync_knobs()
         coef = _f64(coef, "coef", (p,))
         h = C.c_void_p()
         _check(
@@ -679,6 +693,7 @@ class Dataset:
 
     def center(self):
         """Centre the device copy of (X, y) in place by the row-weighted means; returns (x_mean, y_mean)."""
+        _sync_knobs()
         xm = np.empty(self.p)
         ym = C.c_double()
         _check(self._lib.slm_dataset_center(self._h, _ptr(xm), C.byref(ym)))
@@ -720,38 +735,49 @@ class Dataset:
     def max_lanes(self, flags: int = 0) -> int:
         """Lanes one ``solve_lanes`` call can take here (16 in working-set solves on large X, else what the
         fused kernel table has for this p)."""
+        _sync_knobs()
         out = C.c_int32()
         _check(self._lib.slm_dataset_max_lanes(self._h, int(flags), C.byref(out)))
         return int(out.value)
 
     def path_lanes(self, n_points: int, flags: int = 0) -> int:
         """The lane count ``solve_path(..., lanes=0)`` runs a path of ``n_points`` on (``slm_dataset_path_lanes``)."""
+        _sync_knobs()
         out = C.c_int32()
         _check(self._lib.slm_dataset_path_lanes(self._h, int(n_points), int(flags), C.byref(out)))
         return int(out.value)
 
     def lipschitz(self) -> float:
+        _sync_knobs()
         L = C.c_double()
         _check(self._lib.slm_dataset_lipschitz(self._h, C.byref(L)))
         return L.value
 
-    def gradient(self, z=None, reps: int = 0):
-        """g = X^T W (X z - y)/n, loss = 1/(2n)||Xz - y||_W^2[, mean kernel ms over ``reps`` launches]."""
+    def gradient(self, z=None, reps: int = 0, split: bool = False, lanes: int = 1, lane: int = 0, probe_lanes: int = 1,
+                 xtr_only: bool = False):
+        """g = X^T W (X z - y)/n, loss = 1/(2n)||Xz - y||_W^2[, mean kernel ms over ``reps`` launches].
+
+        ``split=True``: by the split pass (residuals from X, then X^T R for all lane slots on one read) with ``lanes`` lanes
+        all standing at z, the gradient of lane ``lane`` returned -- how the parity tests reach xtr18 / xtr20 / xtr32 and the
+        rowdot kernels through the boundary (slm_gradient_ex); ``probe_lanes`` / ``xtr_only``: the timed launches."""
+        _sync_knobs()
         zz = None if z is None else _f64(z, "z", (self.p,))
         g = np.empty(self.p)
         loss = C.c_double()
         ms = C.c_double()
-        _check(
-            self._lib.slm_gradient(
-                self._h, _ptr(zz), _ptr(g), C.byref(loss), int(reps), C.byref(ms) if reps > 0 else None
-            )
-        )
+        if not split and lanes == 1 and probe_lanes == 1:
+            _check(self._lib.slm_gradient(self._h, _ptr(zz), _ptr(g), C.byref(loss), int(reps), C.byref(ms) if reps > 0 else None))
+        else:
+            o = _GradientOpts(1 if split else 0, int(lanes), int(lane), int(probe_lanes), 1 if xtr_only else 0)
+            _check(self._lib.slm_gradient_ex(self._h, _ptr(zz), C.byref(o), _ptr(g), C.byref(loss), int(reps),
+                                             C.byref(ms) if reps > 0 else None))
         return (g, loss.value, ms.value) if reps > 0 else (g, loss.value)
 
     def eval_sse(self, Z, row_weight=None, sparse=None) -> np.ndarray:
         """sum_i w_i (x_i . Z[k] - y_i)^2 for every row Z[k] of ``Z`` (m, p); ``row_weight`` is e.g. the
         test mask of a CV fold.  Rows with a joint support of at most 512 columns are scored from those
         columns (``sparse=False`` forces the dense route: ceil(m/4) passes over the resident X)."""
+        _sync_knobs()
         Z = _f64(np.atleast_2d(Z), "Z")
         if Z.shape[1] != self.p:
             raise ValueError(f"Z must have {self.p} columns")
@@ -789,6 +815,7 @@ class Dataset:
         number of training rows) and ``extrap`` (K_l secant factors, see ``lane_points``; default: derived from
         the points).  Returns one ``PathResult`` per lane (shared timing fields).
         """
+        _sync_knobs()
         nl = len(lanes)
         if not (1 <= nl <= MAX_CELLS):
             raise ValueError(f"between 1 and {MAX_CELLS} lanes, got {nl}")
@@ -905,6 +932,7 @@ class Dataset:
         ``lanes=0``: the engine's choice (``slm_solve_path_lanes`` with ``n_lanes = 0``: sixteen, or eighteen / twenty
         where that saves a pass over a large X).
         """
+        _sync_knobs()
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
         K = pts.shape[0]
         lanes = 0 if int(lanes) == 0 and K > 1 else max(1, min(int(lanes), MAX_LANES_WIDE, K))  # (the engine takes as many as the dataset's kernels serve)
@@ -946,12 +974,14 @@ class Dataset:
         """``slm_dataset_covariance``: build (or find) the Gram of the row set ``(row_weight, n_eff)`` -- what a lane
         brings as ``row_weight`` / ``n_eff`` -- so that solves with ``FLAG_COVARIANCE`` take their gradients from it
         instead of reading X.  Worth it when many solves share the row set (a fold of a large grid)."""
+        _sync_knobs()
         rw = None if row_weight is None else _f64(row_weight, "row_weight", (self.n,))
         _check(self._lib.slm_dataset_covariance(self._h, _ptr(rw), int(n_eff)))
 
     def covariance_folds(self, row_weights, n_effs):
         """``slm_dataset_covariance_folds``: the Grams of the training sets of a K-fold split at once -- where the test rows
         partition the rows, the Gram of all rows is the sum of the test rows' Grams and is never formed from X."""
+        _sync_knobs()
         rws = [_f64(w, "row_weight", (self.n,)) for w in row_weights]
         if not 1 <= len(rws) <= MAX_LANES:
             raise ValueError(f"between 1 and {MAX_LANES} row sets")
@@ -962,6 +992,7 @@ class Dataset:
     def covariance_folds_begin(self, row_weights, n_effs) -> bool:
         """First half of ``covariance_folds``: queues the products of THIS rank's rows (all rows without a communicator)
         and returns; False when the masks are no K-fold partition (nothing queued: use ``covariance``)."""
+        _sync_knobs()
         rws = [_f64(w, "row_weight", (self.n,)) for w in row_weights]
         if not 1 <= len(rws) <= MAX_LANES:
             raise ValueError(f"between 1 and {MAX_LANES} row sets")
@@ -987,6 +1018,7 @@ class Dataset:
     def read_ceiling(self, reps: int = 5) -> tuple[float, float]:
         """(GB/s, ms per sweep) of a read-only stream over the device copy of X: plain 16-byte loads, summed up -- the ceiling
         the passes over X are read against on this device."""
+        _sync_knobs()
         gbs, ms = C.c_double(), C.c_double()
         _check(self._lib.slm_dataset_read_ceiling(self._h, int(reps), C.byref(gbs), C.byref(ms)))
         return float(gbs.value), float(ms.value)
@@ -995,6 +1027,7 @@ class Dataset:
         """Build the model Gram of the dataset now (``csrc/mg_kernels.hpp``: ``X^T W X / n`` from an fp16 product, what lanes
         beyond the working set's 512 columns iterate on between two passes over X; solves build it themselves when they
         need it).  ``download=True`` returns it as an (ld, ld) array (tests)."""
+        _sync_knobs()
         ld = (self.p + 15) // 16 * 16
         G = np.empty((ld, ld)) if download else None
         _check(self._lib.slm_dataset_model_gram(self._h, _ptr(G) if download else None))
@@ -1019,6 +1052,7 @@ class Dataset:
         """``slm_solve_standardized_sgl``: the splitting for ``l1 + sum_g b_g ||X_g beta_g||_2`` with all sweeps in
         one launch.  Returns ``(beta, group_norms or None, info)``; ``NotImplementedError`` when the problem is not
         one the on-chip solver takes (the caller then runs the sweeps over ``solve_lanes``)."""
+        _sync_knobs()
         G = self.n_groups
         a_ = _f64(np.broadcast_to(a, (self.p,)), "a")
         b_ = _f64(np.broadcast_to(b, (G,)), "b")
@@ -1122,6 +1156,37 @@ def _close_engines():
 import atexit  # noqa: E402
 
 atexit.register(_close_engines)
+
+
+# The library reads the SLM_* environment variables once.  The Python layer notices when one of them changes afterwards
+# (os.environ[...] = ..., del os.environ[...], pytest's monkeypatch.setenv: all raise the audit events os.putenv /
+# os.unsetenv BEFORE the change lands) and has the library read them again at the next call into it -- so tests and tools
+# that flip a knob mid-process keep working without calling reload_knobs() themselves.
+_knobs_dirty = False
+
+
+def _env_audit(event, args):
+    global _knobs_dirty
+    if event == "os.putenv" or event == "os.unsetenv":
+        key = args[0]
+        if (isinstance(key, bytes) and key.startswith(b"SLM_")) or (isinstance(key, str) and key.startswith("SLM_")):
+            _knobs_dirty = True
+
+
+sys.addaudithook(_env_audit)
+
+
+def _sync_knobs() -> None:
+    global _knobs_dirty
+    if _knobs_dirty:
+        _knobs_dirty = False
+        reload_knobs()
+
+
+def reload_knobs() -> None:
+    """Have the library read the SLM_* environment variables again (it reads them once, when it first needs one): for tests
+    and tools that change a variable after the library was loaded."""
+    _check(load_library().slm_reload_knobs())
 
 
 def get_engine(device_id: int | None = None) -> Engine:

@@ -8,6 +8,7 @@
 #include <map>
 #include <random>
 #include <set>
+#include <string>
 
 #include "../sparse-lm_amd/csrc/host_logic.hpp"
 
@@ -213,6 +214,37 @@ static void test_find_and_tiles() {
         model_gram_cap(100000, 3.0e9, 16) == 1);
 }
 
+// the SLM_* knobs: read once into a struct (round-5 verdict, item 5) -- defaults, every kind of field, clamping, reload
+static void test_knobs() {
+  std::map<std::string, std::string> env;
+  auto get = [&](const char* name) -> const char* {
+    auto it = env.find(name);
+    return it == env.end() ? nullptr : it->second.c_str();
+  };
+  const Knobs d = Knobs::from(get);  // nothing set: what normal use runs with
+  CHECK(d.split && d.xtr_extras && d.rowdot32 && d.resid32 && d.on_chip && d.wide_lanes && d.interleave && d.carry && d.ws_carry);
+  CHECK(d.ws == -1 && d.mg == -1 && d.grad_ring == -1 && d.rowdot_ring == -1 && d.auto_lanes == 0 && d.trace == 0);
+  CHECK(d.ws_theta == 0.85 && d.ws_lookahead == 2 && d.ws_append == 48 && d.ws_kinit == 0 && d.ws_fill == 0.0 && d.ws_power_iters == 10);
+  CHECK(d.sample_start && !d.sample_start_all && d.sample_min_rows == 65536 && d.sample_div == 4 && d.l_sketch_div == 32 && d.l_sketch_iters == 1);
+  CHECK(d.device_pool && d.device_pool_gb < 0.0 && !d.allow_any_arch && d.xtr_wgs_per_cu == 1.0 && d.direct && d.mg_keep && d.handover);
+  CHECK(d.fuse_tail && d.fuse_resid && d.fuse_solve && !d.profile_unit && !d.eval_fused && d.power_iters == 0 && d.grad_cfg[0] == 0);
+  env["SLM_WS"] = "0"; env["SLM_MG"] = "2"; env["SLM_TRACE"] = "3"; env["SLM_TRACE_POLL"] = "1"; env["SLM_SPLIT"] = "0";
+  env["SLM_GRAD_CONFIG"] = "8,5,2"; env["SLM_WS_THETA"] = "0.7"; env["SLM_WS_APPEND"] = "9999"; env["SLM_WS_KINIT"] = "3";
+  env["SLM_SAMPLE_DIV"] = "0"; env["SLM_SAMPLE_START_MIN_ROWS"] = "10"; env["SLM_XTR_WGS_PER_CU"] = "7"; env["SLM_NO_CARRY"] = "";
+  env["SLM_DEVICE_POOL_GB"] = "-3"; env["SLM_ROWDOT_RING"] = "1"; env["SLM_GRAD_RING"] = "0"; env["SLM_AUTO_LANES"] = "20";
+  env["SLM_WS_FILL"] = "5"; env["SLM_POWER_ITERS"] = "1"; env["SLM_NO_FUSED_TAIL"] = "1"; env["SLM_ON_CHIP"] = "0";
+  Knobs k = Knobs::from(get);
+  CHECK(k.ws == 0 && k.mg == 2 && k.trace == 3 && k.trace_poll && !k.split && !k.on_chip && !k.fuse_tail && k.fuse_resid);
+  CHECK(k.grad_cfg[0] == 8 && k.grad_cfg[1] == 5 && k.grad_cfg[2] == 2 && k.ws_theta == 0.7);
+  CHECK(k.ws_append == 512 && k.ws_kinit == 16 && k.sample_div == 1 && k.sample_min_rows == 64);  // clamped to their ranges
+  CHECK(k.xtr_wgs_per_cu == 1.0);  // (outside (0, 2]: ignored)
+  CHECK(!k.carry && k.ws_carry && k.device_pool_gb == 0.0 && k.rowdot_ring == 1 && k.grad_ring == 0 && k.auto_lanes == 20);
+  CHECK(k.ws_fill == 1.0 && k.power_iters == 2);
+  env["SLM_WS"] = "1"; env["SLM_MG"] = "0"; env["SLM_TRACE"] = "yes"; env["SLM_WS_THETA"] = "1.5"; env.erase("SLM_SPLIT");
+  k = Knobs::from(get);  // a second read follows the environment (slm_reload_knobs)
+  CHECK(k.ws == 1 && k.mg == 0 && k.trace == 1 && k.ws_theta == 0.85 && k.split);
+}
+
 int main() {
   test_pool();
   test_row_sets();
@@ -220,6 +252,7 @@ int main() {
   test_auto_lanes();
   test_grid();
   test_find_and_tiles();
+  test_knobs();
   if (failures) {
     fprintf(stderr, "host_logic_test: %d check(s) failed\n", failures);
     return 1;

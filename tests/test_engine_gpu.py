@@ -552,10 +552,9 @@ def test_rccl_path_with_one_rank(golden):
                                  (20011, 600), (700, 5000), (513, 5120)])
 @pytest.mark.parametrize("rowdot", ["mfma", "ring"])
 def test_split_gradient_matches_numpy(eng, n, p, rowdot, monkeypatch):
-    # SLM_GRAD_SPLIT=1 routes slm_gradient through rowdot_mfma_kernel (or, SLM_ROWDOT_RING=1,
-    # rowdot_ring_kernel) + xtr_mfma_kernel (row blocks with fewer than 8 rows, a last block cut short, rows
-    # that end inside a 32-column chunk, row blocks that start on an odd row)
-    monkeypatch.setenv("SLM_GRAD_SPLIT", "1")
+    # route 1 of slm_gradient_ex: rowdot_mfma_kernel (or, SLM_ROWDOT_RING=1, rowdot_ring_kernel) + xtr_mfma_kernel (row
+    # blocks with fewer than 8 rows, a last block cut short, rows that end inside a 32-column chunk, row blocks that start
+    # on an odd row)
     monkeypatch.setenv("SLM_ROWDOT_RING", "1" if rowdot == "ring" else "0")
     rng = np.random.default_rng(n * 31 + p)
     X = rng.standard_normal((n, p))
@@ -563,12 +562,12 @@ def test_split_gradient_matches_numpy(eng, n, p, rowdot, monkeypatch):
     z = rng.standard_normal(p)
     w = rng.uniform(0.0, 2.0, n)
     with eng.dataset(X, y) as ds:
-        g, loss = ds.gradient(z)
+        g, loss = ds.gradient(z, split=True)
         g0, loss0 = ref_grad(X, y, z)
         assert rel_inf(g, g0) < 1e-12
         npt.assert_allclose(loss, loss0, rtol=1e-12)
     with eng.dataset(X, y, row_weight=w) as ds:
-        g, loss = ds.gradient(z)
+        g, loss = ds.gradient(z, split=True)
         g0, loss0 = ref_grad(X, y, z, w)
         assert rel_inf(g, g0) < 1e-12
         npt.assert_allclose(loss, loss0, rtol=1e-12)
@@ -579,11 +578,9 @@ def test_split_gradient_matches_numpy(eng, n, p, rowdot, monkeypatch):
 @pytest.mark.parametrize("lanes,lane", [(17, 16), (18, 17), (19, 18), (20, 19), (20, 3), (32, 16), (32, 31)])
 def test_split_gradient_of_the_lanes_beyond_sixteen_matches_numpy(eng, n, p, lanes, lane, monkeypatch):
     # a call of 17-20 lanes: sixteen on the matrix cores, the others on the vector units beside them (xtr18 / xtr20_mfma_kernel);
-    # more: both planes of R on the matrix cores (xtr32_mfma_kernel).  SLM_GRAD_LANES lanes all at z, lane SLM_GRAD_LANE returned.
-    monkeypatch.setenv("SLM_GRAD_SPLIT", "1")
+    # more: both planes of R on the matrix cores (xtr32_mfma_kernel).  `lanes` lanes all at z, lane `lane` returned: the
+    # arguments of slm_gradient_ex (until ABI 17 the environment switched them inside slm_gradient).
     monkeypatch.setenv("SLM_ROWDOT_RING", "0")
-    monkeypatch.setenv("SLM_GRAD_LANES", str(lanes))
-    monkeypatch.setenv("SLM_GRAD_LANE", str(lane))
     rng = np.random.default_rng(n * 37 + p + lanes)
     X = rng.standard_normal((n, p))
     y = rng.standard_normal(n)
@@ -593,11 +590,11 @@ def test_split_gradient_of_the_lanes_beyond_sixteen_matches_numpy(eng, n, p, lan
         with eng.dataset(X, y, row_weight=rw) as ds:
             if ds.max_lanes(_engine.FLAG_WORKING_SET) < lanes:
                 pytest.skip("this shape runs on the on-chip solver's lanes")
-            g, loss = ds.gradient(z)
+            g, loss = ds.gradient(z, split=True, lanes=lanes, lane=lane)
             g0, loss0 = ref_grad(X, y, z, rw)
             assert rel_inf(g, g0) < 1e-12
             npt.assert_allclose(loss, loss0, rtol=1e-12)
-            g2, _ = ds.gradient(z)
+            g2, _ = ds.gradient(z, split=True, lanes=lanes, lane=lane)
             assert np.array_equal(g, g2)  # (fixed-order sums: the same bits)
 
 

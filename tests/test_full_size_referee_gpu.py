@@ -61,8 +61,7 @@ def test_gradient_at_full_size_against_the_c_twin(eng, monkeypatch, n, p):
             assert np.max(np.abs(g - gr)) <= 1e-12 * scale, (n, p, float(np.max(np.abs(g - gr)) / scale))
             assert abs(loss - lr) <= 1e-12 * abs(lr)
         if p <= 5_000:  # the split pass (rowdot_mfma_kernel + xtr_mfma_kernel: the sixteen-lane route of large X)
-            monkeypatch.setenv("SLM_GRAD_SPLIT", "1")
-            g, loss = ds.gradient(zd)
+            g, loss = ds.gradient(zd, split=True)
             gr, lr = cref.gradient(X, y, zd)
             assert np.max(np.abs(g - gr)) <= 1e-12 * float(np.max(np.abs(gr)))
             assert abs(loss - lr) <= 1e-12 * abs(lr)

@@ -10,9 +10,9 @@ eng = _engine.get_engine(0)
 n, p = 100_000, 5_000
 ds = eng.synthetic_dataset(n, p, seed=1000, coef=make_coef(p, 50, seed=0), noise_sd=10.0)
 ds.gradient(None, reps=50)
-os.environ["SLM_GRAD_SPLIT"] = "1"; os.environ["SLM_PROBE_LANES"] = "16"; os.environ["SLM_GRAD_SPLIT_XTR_ONLY"] = "1"
 for rep in range(3):
     for k in ("2", "1.5", "1", "0.75", "0.5"):
         os.environ["SLM_XTR_WGS_PER_CU"] = k
-        _, _, ms = ds.gradient(None, reps=40)
+        _engine.reload_knobs()
+        _, _, ms = ds.gradient(None, reps=40, split=True, probe_lanes=16, xtr_only=True)
         print(f"xtr only, {k} workgroups per CU: {ms:.4f} ms -> {8*n*p/ms/1e6:.0f} GB/s", flush=True)
