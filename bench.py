@@ -749,6 +749,43 @@ def leg_literal_config2(eng, K, tol, lanes, twin=True):
     return out
 
 
+def leg_wide_rows(eng, n=50_000, p=20_000, K=32, tol=1e-8):
+    """Rows beyond 10 240 columns (round-5 verdict, item 4): a Lasso path at n = 50 000, p = 20 000 -- 8 GB of X -- on the split
+    pass: sixteen lanes and the working set like any other width (until round 6: one lane on the two-pass kernels, two reads
+    of X per gradient).  Per pass of the path: the X^T R kernel under HIP events against the algorithmic bytes of one
+    gradient of sixteen lane slots."""
+    from sparselm_amd import _engine
+
+    coef = make_coef(p, 50, seed=0)
+    with eng.synthetic_dataset(n, p, seed=77, coef=coef, noise_sd=10.0) as ds:
+        g0, _ = ds.gradient(None)
+        amax = float(np.max(np.abs(g0)))
+        pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-2 * amax, K)]
+        flags = _engine.FLAG_PROFILE | _engine.FLAG_FRESH_L
+        lanes = ds.path_lanes(K, flags)
+        for _ in range(2):
+            r = ds.solve_path(pts, tol=tol, lanes=0, flags=flags)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        ms_k, n_k = 0.0, 0
+        for _ in range(reps):
+            r = ds.solve_path(pts, tol=tol, lanes=0, flags=flags)
+            ms_k += r.grad_ms_total
+            n_k += r.grad_timed
+        eng.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        one = ds.solve_path(pts[:4], tol=tol, lanes=1, flags=flags)  # (one lane: the same route -- the split pass -- at this width)
+    slots = max(16, lanes) if lanes <= 20 else 32
+    bytes_per_pass = 8.0 * (n * p + slots * n + slots * p)
+    t_k = ms_k / max(1, n_k)
+    return {"n": n, "p": p, "alphas": K, "lanes": int(lanes), "ms_per_path": ms, "fits_per_s": K / (1e-3 * ms), "passes": int(r.grad_launches),
+            "converged": bool(r.converged and one.converged), "working_set_refinements": int(r.ws_refined),
+            "xtr_kernel_ms": t_k, "algorithmic_bytes_per_pass": bytes_per_pass,
+            "roofline_frac_per_pass": (bytes_per_pass / (t_k * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_k > 0 else None,
+            "one_lane_passes_4_points": int(one.grad_launches)}
+
+
 def leg_plain(eng, rank, n, p, K, tol, steps=3):
     """The headline path WITHOUT the working set, so that the kernel's contribution can be told from the algorithm's:
     `plain_fista` -- accelerated proximal gradient with restarts (the iteration the north star names), four lanes on the fused
@@ -1268,6 +1305,7 @@ def main():
                              # (every rank: with a process group up, GridSearchCV shards the search over the ranks and gathers)
                              ("config1_small", lambda: leg_config1_small()),
                              ("concurrent_paths", lambda: leg_concurrent_paths(eng, device_id, rank, n, p, K, args.tol, args.lanes)),
+                             ("wide_rows", lambda: leg_wide_rows(eng) if rank == 0 and world == 1 else {}),
                              ("literal_config2", lambda: leg_literal_config2(eng, K, args.tol, args.lanes, twin=args.cpu_budget > 0) if rank == 0 and world == 1 else {}),
                              ("rowshard", lambda: leg_rowshard(eng, rank, world, args.rowshard_rows, args.rowshard_cols))):
                 if args.legs and name not in args.legs.split(","):
@@ -1443,6 +1481,11 @@ def main():
                             "mean_ms_16_lanes": sum(ms16) / len(ms16),
                             "all_converged": all(c["converged"] and c["converged_16_lanes"] for c in cases),
                         }
+                elif name == "wide_rows":
+                    if parts[0].get("ms_per_path"):
+                        legs[name] = {"what": "a 32-alpha Lasso path at n = 50 000, p = 20 000 (rows beyond the fused kernels' 10 240 columns: the split "
+                                      "pass at any width, sixteen lanes and the working set; rank 0, one GPU); never part of `value`",
+                                      **{k: v for k, v in parts[0].items() if k != "ok"}}
                 elif name == "literal_config2":
                     if parts[0].get("ms_per_path"):
                         legs[name] = {k: v for k, v in parts[0].items() if k != "ok"}
@@ -1556,6 +1599,8 @@ def main():
             "cpu_stock_sklearn_lasso_path_fits_per_s": (out.get("cpu_baseline") or {}).get("value") if (out.get("cpu_baseline") or {}).get("kind") == "stock" else None,
             "cpu_port_c_twin_fits_per_s": ((out.get("cpu_baseline") or {}).get("port") or {}).get("value") if (out.get("cpu_baseline") or {}).get("kind") == "stock" else (out.get("cpu_baseline") or {}).get("value"),
             "gpu_vs_sklearn_rel_inf_err": (out.get("cpu_baseline") or {}).get("beta_rel_inf_err_gpu_vs_sklearn"),
+            "wide_rows_50000x20000_roofline_frac_per_pass": pick("wide_rows", "roofline_frac_per_pass"),
+            "wide_rows_50000x20000_ms_per_path": pick("wide_rows", "ms_per_path"),
             "literal_config2_ms_per_path": pick("literal_config2", "ms_per_path"),
             "literal_config2_passes": pick("literal_config2", "passes"),
             "literal_config2_worst_rel_inf_vs_c_twin": pick("literal_config2", "worst_rel_inf_vs_c_twin"),

@@ -154,7 +154,7 @@ struct SetupArgs {
   unsigned char a_mode[SLM_MAX_CELLS], b_mode[SLM_MAX_CELLS], d_mode[SLM_MAX_CELLS], beta_mode[SLM_MAX_CELLS];
 };
 
-static __global__ __launch_bounds__(256) void solve_setup_kernel(SetupArgs s) {
+__device__ __forceinline__ void solve_setup_body(const SetupArgs& s) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int64_t e = t0; e < (int64_t)s.max_lanes * s.ld; e += stride) {
@@ -187,6 +187,7 @@ static __global__ __launch_bounds__(256) void solve_setup_kernel(SetupArgs s) {
   unsigned long long* q = reinterpret_cast<unsigned long long*>(s.infos);
   for (int64_t e = t0; e < s.infos_bytes / 8; e += stride) q[e] = 0ull;
 }
+static __global__ __launch_bounds__(256) void solve_setup_kernel(SetupArgs s) { solve_setup_body(s); }
 
 static __global__ __launch_bounds__(256) void fill_kernel(double* dst, int64_t count, double value) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;

@@ -332,6 +332,7 @@ static void dataset_free(slm_dataset* ds) {
   if (ds->hctl) (void)hipHostFree(ds->hctl);
   if (ds->h_small_out) (void)hipHostFree(ds->h_small_out);
   if (ds->h_vec) (void)hipHostFree(ds->h_vec);
+  if (ds->h_stage) (void)hipHostFree(ds->h_stage);
   if (ds->h_pts) (void)hipHostFree(ds->h_pts);
   for (auto& e : ds->ev)
     if (e) (void)hipEventDestroy(e);

@@ -162,6 +162,7 @@ struct GlobalCtl {
   int32_t diverged;    // row-sharded mode: the ranks' control blocks differ (TailArgs::gdone[4]); ends the solve
   int32_t pad_[3];
 };
+static const int kWsMaxBuilds = 24;  // fresh selections of the working set per solve (WsCtl::max_builds; appends: eight times as many)
 static const int kWsLateIters = 12;  // passes on one point after which a small problem gets the working set
 
 static const int kSnapInfos = 64;
@@ -210,7 +211,8 @@ struct slm_dataset {
   double* ws_nt = nullptr;  // [kMaxLanes][NT_SCRATCH] factors of the model solver's direct steps
   double *sse_Z = nullptr, *sse_part = nullptr;  // slm_eval_sse_sparse: coefficient block, partial sums
   size_t sse_cap = 0;
-  PathCtl h_stage[SLM_MAX_CELLS];  // host staging of the control blocks of the solve in flight
+  PathCtl* h_stage = nullptr;  // [SLM_MAX_CELLS] page-locked, device-visible staging of the control blocks of the solve in
+                               // flight: solve_begin_kernel fetches them itself (allocated on first use)
   // page-locked staging of what the lanes of a call bring (penalty vectors, warm starts: [4][kMaxLanes][ld]; path points):
   // one transfer per kind instead of one per lane and kind -- sixteen lanes x (a, warm start, points) were 48 transfers of a
   // few hundred bytes, 0.25 ms of submissions before a 0.2 ms call of the on-chip solver
@@ -254,7 +256,8 @@ struct slm_dataset {
     double fp1 = 0.0, fp2 = 0.0, n_eff = 0.0;
     bool own = false;        // the dataset's own rows and weights (no fingerprint: lanes that bring neither weights nor scaling)
   };
-  std::vector<MgEntry> mg;   // oldest first; at most kMgEntries (the oldest goes when another row set needs the room)
+  std::vector<MgEntry> mg;   // oldest first; at most model_gram_cap() of them (mg_ensure: the oldest goes when a single build needs the
+                             // room; a solve whose row sets do not fit beside the kept ones drops them all first: PathCall::mg_sets)
   double* mg_vec = nullptr;  // [5][kMaxLanes][ld]: iterate, evaluation point, the last point / model gradient of the inner iteration, the product
   double* mg_Z = nullptr;    // [halves][ld][16] the lanes' moves D = v - z0, lane-minor (the product's B operand)
   bool mg_failed = false;

@@ -4,8 +4,8 @@
 // non-zeros than its 512 columns.
 #include "engine_internal.hpp"
 
-// Where the model Gram can exist: rows short enough for its 8 ld^2 bytes, all rows on this device (a row-sharded dataset
-// would have to all-reduce 8 ld^2 bytes per row set: not built).
+// Where the model Gram can exist: rows short enough for its 4 ld^2 bytes (fp32: 1 GB at the 16 384 columns of MG_MAX_LD), all
+// rows on this device (a row-sharded dataset would have to all-reduce 4 ld^2 bytes per row set: not built).
 bool mg_possible(const slm_dataset* ds) {
   if (knobs().mg == 0) return false;
   if (ds->mg_failed) return false;
@@ -57,11 +57,15 @@ static int mg_build(slm_dataset* ds, const double* w, double n_eff, float* G) {
     return rc;
   }
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool timed = knobs().trace != 0;
-  if (timed) {
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, s);
+  bool timed = knobs().trace != 0;
+  if (timed) {  // (a diagnostic: an event that cannot be made or recorded switches the timing off, nothing else)
+    timed = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventRecord(e0, s) == hipSuccess;
+    if (!timed) {
+      (void)hipGetLastError();
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      e0 = e1 = nullptr;
+    }
   }
   (void)hipMemsetAsync(cmax, 0, sizeof(unsigned long long) * (size_t)ld, s);
   {
@@ -86,7 +90,12 @@ static int mg_build(slm_dataset* ds, const double* w, double n_eff, float* G) {
     hipLaunchKernelGGL(mg_reduce_kernel, dim3((unsigned)n_tiles, 16), dim3(256), 0, s, r);
   }
   rc = check_launch();
-  if (timed) (void)hipEventRecord(e1, s);
+  if (timed && hipEventRecord(e1, s) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    timed = false;
+  }
   hipError_t e = hipStreamSynchronize(s);
   dfree(cmax); dfree(XTh); dfree(P);
   if (timed) {
@@ -110,6 +119,14 @@ int mg_ensure(slm_dataset* ds, const double* w, double n_eff, bool own, double f
     }
   }
   const int64_t ld = ds->ld;
+  // The cap (kMgEntries, and 3 GB of fp32 Grams: host_logic.hpp model_gram_cap) is this function's to keep, whoever calls: a
+  // solve makes room for ALL the row sets of its call before the first build (PathCall::mg_sets drops every entry when they
+  // do not fit beside the ones kept -- entries of one call must not evict each other), slm_dataset_model_gram builds one more
+  // own-rows entry at a time: here the OLDEST entry goes when the dataset is full.
+  while ((int)ds->mg.size() >= slm_host::model_gram_cap(ld, 3.0e9, kMgEntries) && !ds->mg.empty()) {
+    dfree(ds->mg.front().G);
+    ds->mg.erase(ds->mg.begin());
+  }
   int rc = SLM_OK;
   if (!ds->mg_vec) rc = dalloc(&ds->mg_vec, 5 * (size_t)kMaxLanes * (size_t)ld);
   if (rc == SLM_OK && !ds->mg_Z) {  // (a plane per half of the lanes; its own block: a covariance pass's Z has one)

@@ -13,7 +13,11 @@
 // Working-set refinement policy (see solve_core): 0 = never, 1 = when a path point turns out hard
 // (small problems), 2 = from the first pass.
 static int ws_policy(const slm_dataset* ds, uint32_t flags) {
-  if (ds->max_group > 64 || ds->n < 4) return 0;
+  // (a group has to fit the working set with room for others: up to half its capacity.  Until round 6 the bound was 64 -- the
+  //  width of a wavefront, not a property of the kernels: the model solver's group sums walk a group's members through LDS
+  //  whatever their number, the scores and the selection move groups as blocks -- and ONE larger group switched the working
+  //  set off for the whole dataset.)
+  if (ds->max_group > WS_KCAP / 2 || ds->n < 4) return 0;
   if (knobs().ws == 0 || (flags & SLM_FLAG_NO_WORKING_SET)) return 0;
   const bool big = (double)ds->n * (double)ds->ld >= 67108864.0;  // 2^26 doubles = 512 MiB
   return (big || (flags & SLM_FLAG_WORKING_SET) || knobs().ws == 1) ? 2 : 1;
@@ -137,6 +141,7 @@ struct PathCall {
   bool L_kept = false;       // ... in the dataset's kept slot (lambda[lane_cap]) rather than in lane 0's
   // ---- carried start, control blocks
   bool carry = false, ws_carry = false;
+  bool ws_begun = false;  // solve_begin_kernel has started the working set's state with the solve
   int ws_set_of[SLM_MAX_LANES], ws_set_lane[SLM_MAX_LANES], ws_n_sets = 0;
   PathCtl* h = nullptr;  // host staging of the control blocks
   bool infos_in_snap = false;
@@ -258,7 +263,10 @@ int PathCall::shape(const slm_solve_opts* opts) {
   const bool wide = ds->sk != nullptr && ds->sk->rowdot == nullptr;
   // (the fused kernels' table stops at SLM_MAX_LANES; calls of more lanes exist on the on-chip route only)
   const GradKernel* gk_B = B <= kMaxLanes ? ds->gk[B - 1] : nullptr;
-  const bool want_split = (ws_policy(ds, opts ? opts->flags : 0u) == 2 && !wide) ? (big_x || !gk_B) : (big_x && !gk_B);
+  // (rows beyond 10 240 columns: the fused table has only the two-pass kernels, two reads of X per gradient -- a working-set
+  //  solve takes the split pass there whatever the lane count: one read, and the residuals of points on W from the gathered columns)
+  const bool two_pass_only = gk_B != nullptr && gk_B->D < 0;
+  const bool want_split = (ws_policy(ds, opts ? opts->flags : 0u) == 2 && (!wide || two_pass_only)) ? (big_x || !gk_B) : (big_x && !gk_B);
   // (covariance passes are a form of the split pass: the flag asks for it whatever the size, where Grams exist)
   want_cov = opts && (opts->flags & SLM_FLAG_COVARIANCE) && !ds->cov.empty() && !row_sharded(ds) && B <= kMaxLanes;
   split = (want_split || want_cov) && split_usable(ds);
@@ -537,8 +545,12 @@ int PathCall::stage_lanes() {
                   ds->ws_sets >= ws_n_sets && ds->ws_carry_cov == cov_on && knobs().ws_carry;
   for (int l = 0; l < B && ws_carry; ++l) ws_carry = ws_set_of[l] == ds->ws_carry_set_of[l];
   ds->ws_carry_valid = false;
-  h = ds->h_stage;  // (lives as long as the dataset: the upload below is asynchronous)
-  memset(h, 0, sizeof(ds->h_stage));
+  if (!ds->h_stage) {  // (page-locked: the set-up kernel reads the control blocks from it)
+    hipError_t eh = hipHostMalloc((void**)&ds->h_stage, sizeof(PathCtl) * SLM_MAX_CELLS, hipHostMallocDefault);
+    if (eh != hipSuccess) return fail(SLM_ERR_OOM, "hipHostMalloc: %s", hipGetErrorString(eh));
+  }
+  h = ds->h_stage;  // (lives as long as the dataset: the kernel below reads it asynchronously)
+  memset(h, 0, sizeof(PathCtl) * SLM_MAX_CELLS);
   SetupArgs su;
   memset(&su, 0, sizeof(su));
   su.beta = ds->beta; su.z = ds->z; su.zprev = ds->zprev; su.gprev = ds->gprev;
@@ -652,18 +664,31 @@ int PathCall::stage_lanes() {
       if (up_hi[v] >= 0)
         HIP_TRY(hipMemcpyAsync(dev[v] + (size_t)up_lo[v] * ld, ds->h_vec + ((size_t)v * cap + up_lo[v]) * ld,
                                sizeof(double) * (size_t)(up_hi[v] - up_lo[v] + 1) * ld, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ds->pts, ds->h_pts, sizeof(slm_path_point) * (size_t)total_points, hipMemcpyHostToDevice, s));
   }
-  hipLaunchKernelGGL(solve_setup_kernel, dim3(128), dim3(256), 0, s, su);
-  HIP_TRY(hipMemcpyAsync(ds->ctl, h, sizeof(PathCtl) * B, hipMemcpyHostToDevice, s));
+  // the rest of the set-up in ONE launch: vectors, path points and control blocks (fetched from the page-locked staging by the
+  // kernel itself), the head of the control block cleared -- stop words and working-set counters; a working set taken over
+  // from the solve before keeps its block: ws_setup --, the step-size seed (the power steps are still in flight: their result
+  // goes into the control blocks on the device) and the working set's first state
   static_assert(offsetof(DevCtl, lane) >= offsetof(DevCtl, ws) + sizeof(WsCtl) && offsetof(DevCtl, g) == 0, "g, ws, lane");
-  // stop words and working-set counters (a working set taken over from the solve before keeps its block: ws_setup)
-  HIP_TRY(hipMemsetAsync(ds->dctl, 0, ws_carry ? offsetof(DevCtl, ws) : offsetof(DevCtl, lane), s));
-  if (L_on_device) {  // the power steps are still in flight: their result goes into the control blocks on the device
-    SeedArgs sa;
-    sa.ctl = ds->ctl; sa.lambda = L_kept ? ds->lambda + ds->lane_cap : ds->lambda; sa.n_lanes = B; sa.margin = 1.08;
-    for (int l = 0; l < kMaxLanes; ++l) sa.factor[l] = L_factor[l];
-    hipLaunchKernelGGL(seed_step_kernel, dim3(1), dim3(64), 0, s, sa);
+  {
+    BeginArgs bg;
+    memset(&bg, 0, sizeof(bg));
+    bg.h_ctl = h; bg.ctl = ds->ctl; bg.n_lanes = B;
+    bg.h_pts = ds->h_pts; bg.pts = ds->pts; bg.n_pts = total_points;
+    bg.head = reinterpret_cast<int32_t*>(ds->dctl);
+    bg.head_words = (int32_t)((ws_carry ? offsetof(DevCtl, ws) : offsetof(DevCtl, lane)) / sizeof(int32_t));
+    if (L_on_device) {
+      bg.lambda = L_kept ? ds->lambda + ds->lane_cap : ds->lambda;
+      bg.margin = 1.08;
+      for (int l = 0; l < kMaxLanes; ++l) bg.factor[l] = L_factor[l];
+    }
+    // (the working set's state where it starts with the solve: ws_setup then has nothing left to launch)
+    ws_begun = !small && !ws_carry && ws_policy(ds, o.flags) == 2;
+    if (ws_begun) {
+      bg.ws = &ds->dctl->ws;
+      bg.max_builds = kWsMaxBuilds;
+    }
+    hipLaunchKernelGGL(solve_begin_kernel, dim3(128), dim3(256), 0, s, su, bg);
   }
   tr[0] = t_mark();
   // (no wait here: the caller's buffers outlive the call, the control blocks are staged in the dataset, and
@@ -868,8 +893,8 @@ int PathCall::ws_setup(bool late) {
   SLM_TRY(ensure_xt(ds));
   // (initialised on the device: a host-side copy would need the stream drained before its buffer goes away)
   if (late) HIP_TRY(hipMemsetAsync(ds->ws_ctl, 0, sizeof(WsCtl), s));  // (a fresh solve has cleared it already)
-  if (ws_carry && !late) hipLaunchKernelGGL(ws_ctl_carry_kernel, dim3(1), dim3(256), 0, s, ds->ws_ctl, 24);
-  else hipLaunchKernelGGL(ws_ctl_init_kernel, dim3(1), dim3(64), 0, s, ds->ws_ctl, 24);
+  if (ws_carry && !late) hipLaunchKernelGGL(ws_ctl_carry_kernel, dim3(1), dim3(256), 0, s, ds->ws_ctl, kWsMaxBuilds);
+  else if (late || !ws_begun) hipLaunchKernelGGL(ws_ctl_init_kernel, dim3(1), dim3(64), 0, s, ds->ws_ctl, kWsMaxBuilds);  // (else: solve_begin_kernel has)
   wa.ws = ds->ws_ctl;
   wa.idx = ds->ws_idx; wa.pos = ds->ws_pos; wa.gs = ds->ws_gs; wa.gl = ds->ws_gl;
   wa.score = ds->ws_score; wa.XW = ds->ws_XW; wa.part = ds->ws_part; wa.Gm = ds->ws_G;
@@ -987,8 +1012,8 @@ void PathCall::enqueue_refinement() {
       const int bs = ds->singleton ? 256 : 64;
       const int64_t items = ds->singleton ? p : 16 * (int64_t)G;  // groups: one thread per (group, lane)
       hipLaunchKernelGGL(ws_score_kernel, dim3((unsigned)((items + bs - 1) / bs)), dim3(bs), 0, s, ta, wa);
+      hipLaunchKernelGGL(ws_select_kernel, dim3(1), dim3(WS_THREADS), 0, s, ta, wa);
     }
-    hipLaunchKernelGGL(ws_select_kernel, dim3(1), dim3(WS_THREADS), 0, s, ta, wa);
     if (cov_on) {
       // covariance passes: the working set's Gram is a sub-matrix of the row set's (no gathered columns, no product
       // over the rows; nothing reads XW in this mode -- the residuals of a pass are not formed at all)
@@ -1021,11 +1046,7 @@ void PathCall::enqueue_refinement() {
       hipLaunchKernelGGL(stop_apply_kernel, dim3(1), dim3(64), 0, s, ta.gdone, wa.Gx + gram_words);
     }
     // the iteration alone, then -- for the lanes it left -- the solver with direct steps (ws_refine_lane)
-    // (one launch for both instances -- ws_solve_kernel<., 2> -- unless there are no direct steps at all, or SLM_NO_FUSED_SOLVE)
-    if (wa.nt && knobs().fuse_solve) {
-      if (ds->singleton) hipLaunchKernelGGL((ws_solve_kernel<false, 2>), dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
-      else hipLaunchKernelGGL((ws_solve_kernel<true, 2>), dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
-    } else {
+    {
       if (wa.one_solver && wa.nt) {
       } else if (ds->singleton) hipLaunchKernelGGL((ws_solve_kernel<false, 0>), dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
       else hipLaunchKernelGGL((ws_solve_kernel<true, 0>), dim3(B), dim3(WS_THREADS), 0, s, ta, wa);
@@ -1239,7 +1260,7 @@ int PathCall::queue_chunk() {
       }
       fix_start = sample_pass;
       ++enq;
-      // behind the pass the solve is expected to end with, the six launches of the refinement would only find
+      // behind the pass the solve is expected to end with, the launches of the refinement would only find
       // out that there is nothing left to refine (30 us): they follow once the snapshot says otherwise
       deferred = (expected > 0 && enq == expected && !sharded) || mg_on;
       if (!deferred) enqueue_refinement();

@@ -55,13 +55,17 @@ static const int kTwoPassC = 4;  // column tile of xtr_kernel: 512 * 4 chunks = 
 // the column-major copy of X (`rowdot == nullptr`: the split pass is then only used when that copy exists).
 #define SLM_SK(C, D)                                                                                   \
   {8, C, SPLIT_LANES, D, rowdot_ring_kernel<8, C, ROWDOT_LANES, D>, resid_ws_kernel<SPLIT_LANES>}
-static const SplitKernel kSplit[] = {SLM_SK(1, 3), SLM_SK(2, 3), SLM_SK(3, 3), SLM_SK(4, 3), SLM_SK(5, 2),
-                                     {8, 10, SPLIT_LANES, 0, nullptr, resid_ws_kernel<SPLIT_LANES>}};
+static const SplitKernel kSplit[] = {SLM_SK(1, 3), SLM_SK(2, 3), SLM_SK(3, 3), SLM_SK(4, 3), SLM_SK(5, 2)};
+// Rows beyond 5120 columns, ANY width (round 6; until then the table stopped at 10 240 columns and wider rows had one lane on
+// the two-pass kernels, at most half of the roofline by construction): nothing in the split pass depends on the row length --
+// X^T R walks column blocks of 512, the residuals from X contract the column-major copy group by group, the working set's
+// kernels see its <= 512 columns -- so sixteen lanes and the working set serve p = 20 000 or 40 000 like 5 000.
+static const SplitKernel kSplitAnyWidth = {8, 0, SPLIT_LANES, 0, nullptr, resid_ws_kernel<SPLIT_LANES>};
 const SplitKernel* pick_split_kernel(int64_t p2) {
   if (!knobs().split) return nullptr;
   for (const auto& k : kSplit)
     if (64LL * k.W * k.C >= p2) return &k;
-  return nullptr;
+  return &kSplitAnyWidth;
 }
 
 // X^T R of the split pass on the matrix cores (xtr_mfma_kernel): grid = (column blocks of 512, row blocks), ONE
@@ -266,26 +270,11 @@ int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y
   //  stream over X alone: bench.py's roofline.gradient_unit_frac)
   const bool unit = ev_start != nullptr && (unit_bracket || knobs().profile_unit);
   if (unit) HIP_TRY(hipEventRecord(ev_start, s));
-  // Both residual kernels in one launch (residuals_kernel) where the pass takes the matrix-core forms of both: working-set
-  // solves with the column-major copy in place.  SLM_NO_FUSED_RESID, the ring / vector forms and the A/B knobs: two launches.
-  const slm_host::Knobs& kn = knobs();
-  const bool one_launch = wa && ctl && kn.fuse_resid && ds->XT && ds->XT_ready && !kn.resid_vec && kn.resid32 && kn.rowdot32 && kn.xtr_extras &&
-                          !(sk->rowdot != nullptr && halves == 1 && (kn.rowdot_ring >= 0 ? kn.rowdot_ring == 1 : ls.B <= ROWDOT_LANES));
-  if (one_launch) {
-    a.lane0 = 0;
-    a.XT = ds->XT;
-    const dim3 grid(2 * (unsigned)nblk), block(RM_WAVES * 64);
-    if (halves == 1) hipLaunchKernelGGL((residuals_kernel<1, 0, 1>), grid, block, 0, s, a);
-    else if (ls.B <= SPLIT_LANES + 2) hipLaunchKernelGGL((residuals_kernel<1, 2, 2>), grid, block, 0, s, a);
-    else if (ls.B <= SPLIT_LANES + 4) hipLaunchKernelGGL((residuals_kernel<1, 4, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((residuals_kernel<2, 0, 2>), grid, block, 0, s, a);
-  } else {
   launch_rowdot(ds, sk, nblk, ls.B, a, s);
   if (wa && ctl) {  // residuals from the gathered columns: matrix cores (SLM_RESID_VEC=1: a row per thread)
     if (knobs().resid_vec && halves == 1) hipLaunchKernelGGL(sk->resid, dim3(nblk), dim3(256), 0, s, a);
     else if (halves == 2 && knobs().resid32) hipLaunchKernelGGL(resid32_mfma_kernel, dim3(nblk, 1), dim3(RM_WAVES * 64), 0, s, a);  // (both halves on one read of the gathered columns)
     else hipLaunchKernelGGL(resid_mfma_kernel, dim3(nblk, halves), dim3(RM_WAVES * 64), 0, s, a);
-  }
   }
   // (SLM_FLAG_PROFILE brackets the kernel that streams X, the one the roofline is quoted on)
   if (ev_start && !unit) HIP_TRY(hipEventRecord(ev_start, s));

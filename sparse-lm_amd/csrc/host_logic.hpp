@@ -263,7 +263,7 @@ SLM_HD inline void triangle_tile_fast(int t, int* I_out, int* J_out) {
   *J_out = t - I * (I + 1) / 2;
 }
 
-// model Grams a dataset may keep: kept within `budget_bytes` (8 ld^2 each), at least one, at most `most`
+// model Grams a dataset may keep: kept within `budget_bytes` (4 ld^2 each: fp32), at least one, at most `most`
 inline int model_gram_cap(int64_t ld, double budget_bytes, int most) {
   const double each = 4.0 * (double)ld * (double)ld;  // (fp32)
   return (int)std::max<double>(1.0, std::min<double>((double)most, budget_bytes / each));
@@ -331,10 +331,6 @@ struct Knobs {
   int mg = -1;                   // SLM_MG: 0 off, 2 forced from the first snapshot (tests), -1 by capacity
   bool mg_keep = true;           // SLM_NO_MG_KEEP
   bool handover = true;          // SLM_NO_HANDOVER
-  // chain between two passes (round 6)
-  bool fuse_tail = true;         // SLM_NO_FUSED_TAIL: tail, scores and selection as launches of their own
-  bool fuse_resid = true;        // SLM_NO_FUSED_RESID: the two residual kernels as launches of their own
-  bool fuse_solve = true;        // SLM_NO_FUSED_SOLVE: the model solver with direct steps as a launch of its own
   // memory, diagnostics
   double device_pool_gb = -1.0;  // SLM_DEVICE_POOL_GB (< 0: the default cap)
   bool device_pool = true;       // SLM_NO_DEVICE_POOL
@@ -409,9 +405,6 @@ struct Knobs {
     if (const char c = first("SLM_MG")) k.mg = c == '0' ? 0 : (c == '2' ? 2 : -1);
     k.mg_keep = !is_set("SLM_NO_MG_KEEP");
     k.handover = !is_set("SLM_NO_HANDOVER");
-    k.fuse_tail = !is_set("SLM_NO_FUSED_TAIL");
-    k.fuse_resid = !is_set("SLM_NO_FUSED_RESID");
-    k.fuse_solve = !is_set("SLM_NO_FUSED_SOLVE");
     if (const char* e = text("SLM_DEVICE_POOL_GB")) k.device_pool_gb = std::max(0.0, atof(e));
     k.device_pool = !is_set("SLM_NO_DEVICE_POOL");
     k.allow_any_arch = is_set("SLM_ALLOW_ANY_ARCH");

@@ -39,7 +39,8 @@ typedef unsigned int mg_u4 __attribute__((ext_vector_type(4)));
 constexpr int MG_TILE = 128;               // result tile of a workgroup (four wavefronts, 64 x 64 each)
 constexpr int MG_BK = 64;                  // rows of X per step of the product
 constexpr int MG_LDS_STRIDE = MG_BK + 8;   // halves per LDS row: 144 bytes -- sixteen rows fall on sixteen different 16-byte slots
-constexpr int MG_MAX_LD = 16384;           // the Gram is 8 ld^2 bytes: 2 GB at most
+constexpr int MG_MAX_LD = 16384;           // the Gram is 4 ld^2 bytes (fp32): 1 GB at most; beyond, slm_dataset_model_gram refuses
+                                           // (SLM_ERR_UNSUPPORTED) and solves go on with plain steps: tests/test_width_limits_gpu.py
 constexpr int MG_CHUNK_ROWS = 6400;        // rows per fp32 accumulation (chunks are summed in fp64): 100 steps of MG_BK
 constexpr int MG_ROUNDS_PER_POINT = 12;    // rounds a lane may spend on one path point before it is left to plain steps
 constexpr int MG_REJECT_LIMIT = 2;         // proposals for one path point the true objective may reject before the point is left to plain steps

@@ -689,7 +689,9 @@ constexpr int rowdot_lds_doubles() {
   return XZ_WAVES * (E > 0 ? 2 : H) * SPLIT_LANES + H * XZ_WAVES * XZ_T * 2 * 4 * 64 + (E > 0 ? XZ_WAVES * E * XZ_T * 32 : 1);
 }
 // (lds: rowdot_lds_doubles<H, E>() doubles; bx / nbx: this workgroup's row block and their number; by: the half served when a
-//  launch serves one half per grid row -- the kernels below pass blockIdx / gridDim, residuals_kernel its own split of the grid)
+//  launch serves one half per grid row.  Round 6 ran this body and resid_mfma_body as the two halves of ONE grid: 6 us gained
+//  per headline path, whose launch of this kernel returns at once -- and 0.35 ms lost per pass of config 3's group path, where
+//  it works: under the 512-thread bound of the shared kernel its 256 registers per wavefront went to scratch memory.)
 template <int H, int E = 0>
 __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a, double* lds, int bx, int nbx, int by) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 rows of the MFMA A operand");
@@ -1047,27 +1049,6 @@ static __global__ __launch_bounds__(RM_WAVES * 64) void resid_mfma_kernel(SplitA
 static __global__ __launch_bounds__(RM_WAVES * 64) void resid32_mfma_kernel(SplitArgs a) {
   __shared__ double lds[resid_lds_doubles<2>()];
   resid_mfma_body<2>(a, lds, (int)blockIdx.x, 0);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Both residual kernels of a pass in ONE launch (round 6): the first half of the grid forms the residuals of the lanes whose
-// points are supported on the working set from the gathered columns (resid_mfma_body), the second half those of the other
-// lanes from the column-major copy of X (rowdot_mfma_body: its four wavefronts; it returns at once when no lane needs X --
-// the usual pass of a working-set path, where the launch of its own was 4.8 us of the chain between two passes over X).
-// The two halves write disjoint lane slots of R and of loss_partial: no order between them is needed.  HR / ER: the form of
-// rowdot (both halves; extra lanes on the vector units), HS: of resid.
-// ---------------------------------------------------------------------------------------------
-template <int HR, int ER, int HS>
-__global__ __launch_bounds__(RM_WAVES * 64) void residuals_kernel(SplitArgs a) {
-  constexpr int NR = rowdot_lds_doubles<HR, ER>(), NS = resid_lds_doubles<HS>();
-  __shared__ double lds[NR > NS ? NR : NS];
-  const int nb = (int)gridDim.x >> 1;
-  if ((int)blockIdx.x < nb) {
-    resid_mfma_body<HS>(a, lds, (int)blockIdx.x, 0);
-  } else {
-    if (threadIdx.x >= XZ_WAVES * 64) return;  // (before any barrier: the body is written for four wavefronts)
-    rowdot_mfma_body<HR, ER>(a, lds, (int)blockIdx.x - nb, nb, 0);
-  }
 }
 
 }  // namespace slm

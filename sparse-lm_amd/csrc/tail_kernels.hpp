@@ -242,14 +242,14 @@ __device__ __forceinline__ void for_each_group_sumsq(const double* src, const in
 // the smallest Rayleigh quotient along its moves), capped by the curvatures this kernel measures itself:
 // the smallest Barzilai-Borwein quotient accepted on this point and Lhat (spectral mode), L (FISTA mode).
 // Without any of these the rule is the classical ||prox step|| <= tol ||beta|| with a step 1/L.
+// (the body, for lane `lane_id`; fista_tail_kernel runs it for lane blockIdx.x)
 template <int E>
-__global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
+__device__ __forceinline__ void fista_tail_body(TailArgs a, const int lane_id) {
   __shared__ double red[9][TAIL_WAVES];
   // image of the thresholded vector for the group gathers: LDS up to 16K features, the per-lane
   // global scratch beyond (long-row fallback; the tail is negligible next to a two-pass gradient)
   constexpr bool US_IN_LDS = E <= 16;
   __shared__ double us_lds[US_IN_LDS ? E * TAIL_THREADS : 1];
-  const int lane_id = blockIdx.x;
   PathCtl* ctl = a.ctl + lane_id;
   if (ctl->done != 0 || ctl->idle != 0 || a.gdone[0] != 0) return;
   const int tid = threadIdx.x;
@@ -725,6 +725,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
       for (int k = 0; k < BB_HIST; ++k) ctl->hist[k] = hist[k];
     }
   }
+}
+
+template <int E>
+__global__ __launch_bounds__(TAIL_THREADS) void fista_tail_kernel(TailArgs a) {
+  fista_tail_body<E>(a, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -170,6 +170,63 @@ static __global__ void ws_ctl_init_kernel(WsCtl* ws, int max_builds) {
   if (threadIdx.x < SLM_MAX_LANES) ws->last_point[threadIdx.x] = -1;
 }
 
+// Everything a solve sets up on the device before its first pass, in ONE launch (round 6): the vectors (solve_setup_body), the
+// path points and the lanes' control blocks -- fetched by the kernel from the page-locked staging the host has just filled, not
+// by copy commands --, the head of the control block zeroed, the step-size seed written into the lanes' blocks
+// (seed_step_kernel's work) and the working set's state started (ws_ctl_init_kernel's).  They were six commands of the stream,
+// 4-6 us each, in front of every solve: a third of the 0.1 ms the device spent before the first pass of a headline path.
+struct BeginArgs {
+  const PathCtl* h_ctl;  // [n_lanes] page-locked, device-visible
+  PathCtl* ctl;
+  const slm_path_point* h_pts;  // [n_pts] page-locked, device-visible
+  slm_path_point* pts;
+  int64_t n_pts;
+  int32_t* head;       // the control block's first words (GlobalCtl, MgCtl[, WsCtl]) ...
+  int32_t head_words;  // ... this many of them are zeroed
+  const double* lambda;  // step-size estimate on the device (nullptr: the host has written L into h_ctl)
+  double margin;
+  double factor[SLM_MAX_LANES];
+  WsCtl* ws;           // nullptr: the working set's state is left alone (not used, taken over, or set up later)
+  int32_t max_builds;
+  int32_t n_lanes;
+};
+static __global__ __launch_bounds__(256) void solve_begin_kernel(SetupArgs s, BeginArgs b) {
+  solve_setup_body(s);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  {  // path points: four doubles each
+    static_assert(sizeof(slm_path_point) == 4 * sizeof(double), "points travel as doubles");
+    const double* src = reinterpret_cast<const double*>(b.h_pts);
+    double* dst = reinterpret_cast<double*>(b.pts);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < 4 * b.n_pts; e += stride) dst[e] = src[e];
+  }
+  if (blockIdx.x != 0) return;
+  for (int e = threadIdx.x; e < b.head_words; e += 256) b.head[e] = 0;
+  {
+    static_assert(sizeof(PathCtl) % sizeof(int32_t) == 0, "control blocks travel as words");
+    const int32_t* src = reinterpret_cast<const int32_t*>(b.h_ctl);
+    int32_t* dst = reinterpret_cast<int32_t*>(b.ctl);
+    const int words = b.n_lanes * (int)(sizeof(PathCtl) / sizeof(int32_t));
+    for (int e = threadIdx.x; e < words; e += 256) dst[e] = src[e];
+  }
+  __syncthreads();
+  if (b.lambda != nullptr && (int)threadIdx.x < b.n_lanes && threadIdx.x < SLM_MAX_LANES) {  // (seed_step_kernel)
+    const int l = threadIdx.x;
+    double L0 = b.lambda[0] * b.margin;
+    if (L0 <= 0.0) L0 = 1.0;  // X == 0
+    const double L = L0 * b.factor[l];
+    b.ctl[l].L = L;
+    b.ctl[l].ak = 1.25 * L;
+    b.ctl[l].Lhat = 0.5 * L0;
+  }
+  if (b.ws != nullptr) {  // (ws_ctl_init_kernel; the block was zeroed above)
+    if (threadIdx.x == 0) {
+      b.ws->request = 1;
+      b.ws->max_builds = b.max_builds;
+    }
+    if (threadIdx.x < SLM_MAX_LANES) b.ws->last_point[threadIdx.x] = -1;
+  }
+}
+
 // state of a solve that starts where the dataset's last solve ended (solve_core: carried start, same lanes, same row
 // sets): that solve's working set is still in place -- the columns' indices and positions, the gathered columns, the
 // Grams, which depend on X and the rows alone -- and the penalty has changed, not the data.  The counters and per-solve
@@ -235,7 +292,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot /*[16]*/, in
 // the path there).  Features that would enter by then are taken now; later ones are appended when
 // their time comes.  (Inside the one-workgroup select kernel this sweep cost 45-60 us per pass.)
 // ---------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) {
+// (the body, for the workgroup that scores items chunk * blockDim.x ...: ws_score_kernel runs it per blockIdx.x in workgroups
+//  of 256 (features) or 64 (groups) threads)
+__device__ __forceinline__ void ws_score_body(TailArgs a, WsArgs w, const int chunk) {
   WsCtl* ws = w.ws;
   const int tid = threadIdx.x;
   // The words this kernel decides on, fetched TOGETHER (ws_head_load) instead of one after the other behind the tests they
@@ -282,7 +341,7 @@ static __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs
   // features: one thread each.  Groups: SIXTEEN threads each, one per lane (a thread then walks the members
   // of its group for one lane: 10 x 4 scattered loads instead of 16 x 10 x 4; the lanes' scores meet in a
   // max over the 16 threads) -- 64-thread workgroups, four groups each.
-  const int gt = blockIdx.x * blockDim.x + tid;
+  const int gt = chunk * (int)blockDim.x + tid;
   const int it = singleton ? gt : gt >> 4;
   if (singleton) {
     if (it < nitems) {
@@ -369,13 +428,15 @@ static __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs
   }
 }
 
+static __global__ __launch_bounds__(256) void ws_score_kernel(TailArgs a, WsArgs w) { ws_score_body(a, w, (int)blockIdx.x); }
+
 // ---------------------------------------------------------------------------------------------
 // (i-b) choose W.  One workgroup.  Runs after ws_score_kernel in every pass; returns at once unless a
 // build was requested, a lane's plain step left the current W, or there are newcomers.  With a valid W the newcomers are
 // APPENDED (their columns and Gram rows are all that has to be produced); a fresh selection is made
 // at the start of a solve and when the appended set would exceed WS_KCAP.
 // ---------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArgs w) {
+__device__ __forceinline__ void ws_select_body(TailArgs a, WsArgs w) {
   __shared__ double red[2][TAIL_WAVES];
   __shared__ int wave_tot[TAIL_WAVES];
   WsCtl* ws = w.ws;
@@ -639,6 +700,8 @@ static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a
     }
   }
 }
+
+static __global__ __launch_bounds__(WS_THREADS) void ws_select_kernel(TailArgs a, WsArgs w) { ws_select_body(a, w); }
 
 // ---------------------------------------------------------------------------------------------
 // (ii) gather the new columns: XW[i][k] = X[i][idx[k]] for k >= k_new (0 for padding positions).
@@ -1075,9 +1138,7 @@ __device__ __forceinline__ void ws_sum(double (&v)[NV], double (*lds)[TAIL_WAVES
 // DIRECT instance launched right behind (WsCtl::want_full; returns false).  Most solves never take one, and the
 // kernel without the factorisation is a fifth of the code, keeps its registers (the full one spills 250 of them
 // at 128 per thread) and leaves no scratch lines for the end of the kernel to write back.
-// LDS of the model solver: one block per workgroup, handed to ws_refine_lane by the kernel -- the instance with direct
-// steps and the one without are called from ONE kernel now (ws_solve_kernel<GROUPED, 2>) and use the same block one after
-// the other (as `__shared__` arrays of the function each instance had its own copy: twice 140 KB)
+// LDS of the model solver: one block per workgroup, handed to ws_refine_lane by the kernel
 struct WsSolveLds {
   double delta[WS_KCAP];
   double uim[WS_KCAP];
@@ -2045,11 +2106,10 @@ __device__ __forceinline__ bool ws_refine_lane(TailArgs a, const WsArgs& w, doub
 }
 
 // MODE 0: the iteration alone (lanes that would take a direct step are left, untouched, with WsCtl::want_full set);
-// MODE 1: the solver with direct steps, for the lanes MODE 0 left (a launch of its own behind it: SLM_NO_FUSED_SOLVE);
-// MODE 2 (round 6): both in one launch -- a workgroup runs the light instance and, only if that leaves the lane, the full
-// one: most passes never take a direct step, and the second launch was 4.8 us of the chain between two passes for
-// finding that out.  (The light instance's code is the same either way: it shares the kernel, not its registers' live
-// ranges, with the factorisation.)
+// MODE 1: the solver with direct steps, for the lanes MODE 0 left -- a launch of its own behind it.  (Round 6 tried both in
+// one launch: the idle second launch is 4.8 us of the chain between two passes, but the light instance compiled into one
+// kernel with the factorisation was no faster for per-feature penalties and 0.35 ms per pass slower for grouped ones --
+// its registers went to scratch memory; tools/ab_knobs.py, profiles/r06_fusion_ab.txt.)
 template <bool GROUPED, int MODE>
 __global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs w) {
   __shared__ double red[8][TAIL_WAVES];
@@ -2067,15 +2127,8 @@ __global__ __launch_bounds__(WS_THREADS) void ws_solve_kernel(TailArgs a, WsArgs
   // (every return inside is taken by the whole workgroup)
   if (MODE == 0) {
     if (!ws_refine_lane<GROUPED, false>(a, w, red, sh)) return;
-  } else if (MODE == 1) {
-    (void)ws_refine_lane<GROUPED, true>(a, w, red, sh);
   } else {
-    const bool light = !(w.one_solver && w.nt != nullptr);
-    if (!light || !ws_refine_lane<GROUPED, false>(a, w, red, sh)) {
-      __syncthreads();  // (the light instance has written nothing of the solve: the block starts afresh)
-      if (threadIdx.x == 0) w.ws->want_full[lane_id] = 0;
-      (void)ws_refine_lane<GROUPED, true>(a, w, red, sh);
-    }
+    (void)ws_refine_lane<GROUPED, true>(a, w, red, sh);
   }
   __syncthreads();
   // Is the point the next pass evaluates zero outside W?  Then its residual needs only the gathered

@@ -105,6 +105,24 @@ def gather_results(local: dict[int, Any], n_units: int) -> list[Any] | None:
 _grid_engines: dict = {}
 
 
+def min_over_ranks(value: int) -> int:
+    """The smallest `value` among the ranks of the process group (the value itself without one): what every rank must use
+    where a per-rank answer -- the lanes a dataset's kernels serve, which depends on the device memory of THAT rank (the
+    column-major copy behind more than sixteen lanes) -- decides how work is dealt among the ranks."""
+    try:
+        import torch
+        import torch.distributed as dist
+    except ImportError:
+        return int(value)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64)
+    if dist.get_backend() == "nccl" and torch.cuda.is_available():
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 def grid_engine(rank: int, world_size: int):
     """The engine grid-mode searches of this process use among ``world_size`` ranks: a further engine (stream) on the
     rank's device with an RCCL communicator over all ranks, made once per process.  Datasets opened on it are marked as

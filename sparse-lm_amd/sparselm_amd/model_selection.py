@@ -474,7 +474,9 @@ class _DeviceGrid:
         return ds
 
     def _lanes_for(self, ds):
-        cap = ds.max_lanes(self.opts.get("flags", 0))
+        # (the cap the ranks PLAN with is the smallest any of them has: a rank without the memory for the column-major copy
+        #  serves sixteen lanes where its peers serve thirty-two, and ranks that plan on different caps deal the units differently)
+        cap = D.min_over_ranks(ds.max_lanes(self.opts.get("flags", 0)))
         return cap if self.search.lanes is None else max(1, min(int(self.search.lanes), cap))
 
     def _set_groups(self, ds):
@@ -607,7 +609,7 @@ class _DeviceGrid:
             self.opts["flags"] = self.opts.get("flags", 0) | _engine.FLAG_COVARIANCE
             # covariance passes serve sixteen lanes a call (a search over X may have been planned on thirty-two: the two halves
             # of the split pass on one read of X): the same decision on every rank, so every rank plans again alike
-            cap = ds.max_lanes(self.opts["flags"])
+            cap = D.min_over_ranks(ds.max_lanes(self.opts["flags"]))
             if self.lanes > cap:
                 self.lanes = cap
                 self._plan_world = None

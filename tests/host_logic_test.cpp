@@ -214,6 +214,35 @@ static void test_find_and_tiles() {
         model_gram_cap(100000, 3.0e9, 16) == 1);
 }
 
+// explicit sixteen-lane paths of 33 to 47 points under slack_deep (advisor, round 5): 48 slots, the slack goes to the lanes
+// that hold the deepest points of the first band -- they own that one point -- and every point is owned exactly once
+static void test_interleaved_sixteen_lanes() {
+  for (int total = 33; total <= 47; ++total) {
+    std::vector<int> owner(total, -1);
+    const int64_t e = (48 - total) / 2, F = 16 - e;
+    for (int lane = 0; lane < 16; ++lane) {
+      const LaneWalk w = interleaved_walk(lane, 16, total, true, true);
+      std::vector<int> pts;
+      for (int q = w.first; q < w.n_points; q += w.stride) pts.push_back(q);
+      if (w.tail_pt >= 0) pts.push_back(w.tail_pt);
+      CHECK((int64_t)pts.size() == interleaved_points(w));
+      if (e >= 1) {
+        if (lane >= F) CHECK(pts.size() == 1 && pts[0] == lane);  // the deepest points of the first band: one point each
+        else CHECK(pts.size() >= 2 && pts[0] == lane && pts[1] == 16 + lane);
+      }
+      for (int q : pts) {
+        CHECK(q >= 0 && q < total && owner[q] == -1);
+        if (q >= 0 && q < total) owner[q] = lane;
+      }
+    }
+    for (int q = 0; q < total; ++q) CHECK(owner[q] >= 0);
+    if (total == 40) {  // (the advisor's example: e = 4, lanes 12..15 own a single point; lanes 0..11 own l, 16 + l, 28 + l)
+      CHECK(interleaved_walk(12, 16, 40, true, true).tail_pt == -1 && interleaved_walk(12, 16, 40, true, true).n_points == 16);
+      CHECK(interleaved_walk(0, 16, 40, true, true).tail_pt == 28 && interleaved_walk(11, 16, 40, true, true).tail_pt == 39);
+    }
+  }
+}
+
 // the SLM_* knobs: read once into a struct (round-5 verdict, item 5) -- defaults, every kind of field, clamping, reload
 static void test_knobs() {
   std::map<std::string, std::string> env;
@@ -227,14 +256,14 @@ static void test_knobs() {
   CHECK(d.ws_theta == 0.85 && d.ws_lookahead == 2 && d.ws_append == 48 && d.ws_kinit == 0 && d.ws_fill == 0.0 && d.ws_power_iters == 10);
   CHECK(d.sample_start && !d.sample_start_all && d.sample_min_rows == 65536 && d.sample_div == 4 && d.l_sketch_div == 32 && d.l_sketch_iters == 1);
   CHECK(d.device_pool && d.device_pool_gb < 0.0 && !d.allow_any_arch && d.xtr_wgs_per_cu == 1.0 && d.direct && d.mg_keep && d.handover);
-  CHECK(d.fuse_tail && d.fuse_resid && d.fuse_solve && !d.profile_unit && !d.eval_fused && d.power_iters == 0 && d.grad_cfg[0] == 0);
+  CHECK(!d.profile_unit && !d.eval_fused && d.power_iters == 0 && d.grad_cfg[0] == 0);
   env["SLM_WS"] = "0"; env["SLM_MG"] = "2"; env["SLM_TRACE"] = "3"; env["SLM_TRACE_POLL"] = "1"; env["SLM_SPLIT"] = "0";
   env["SLM_GRAD_CONFIG"] = "8,5,2"; env["SLM_WS_THETA"] = "0.7"; env["SLM_WS_APPEND"] = "9999"; env["SLM_WS_KINIT"] = "3";
   env["SLM_SAMPLE_DIV"] = "0"; env["SLM_SAMPLE_START_MIN_ROWS"] = "10"; env["SLM_XTR_WGS_PER_CU"] = "7"; env["SLM_NO_CARRY"] = "";
   env["SLM_DEVICE_POOL_GB"] = "-3"; env["SLM_ROWDOT_RING"] = "1"; env["SLM_GRAD_RING"] = "0"; env["SLM_AUTO_LANES"] = "20";
-  env["SLM_WS_FILL"] = "5"; env["SLM_POWER_ITERS"] = "1"; env["SLM_NO_FUSED_TAIL"] = "1"; env["SLM_ON_CHIP"] = "0";
+  env["SLM_WS_FILL"] = "5"; env["SLM_POWER_ITERS"] = "1"; env["SLM_ON_CHIP"] = "0";
   Knobs k = Knobs::from(get);
-  CHECK(k.ws == 0 && k.mg == 2 && k.trace == 3 && k.trace_poll && !k.split && !k.on_chip && !k.fuse_tail && k.fuse_resid);
+  CHECK(k.ws == 0 && k.mg == 2 && k.trace == 3 && k.trace_poll && !k.split && !k.on_chip);
   CHECK(k.grad_cfg[0] == 8 && k.grad_cfg[1] == 5 && k.grad_cfg[2] == 2 && k.ws_theta == 0.7);
   CHECK(k.ws_append == 512 && k.ws_kinit == 16 && k.sample_div == 1 && k.sample_min_rows == 64);  // clamped to their ranges
   CHECK(k.xtr_wgs_per_cu == 1.0);  // (outside (0, 2]: ignored)
@@ -249,6 +278,7 @@ int main() {
   test_pool();
   test_row_sets();
   test_interleaved();
+  test_interleaved_sixteen_lanes();
   test_auto_lanes();
   test_grid();
   test_find_and_tiles();

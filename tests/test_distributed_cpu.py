@@ -89,6 +89,10 @@ def _shard_worker(rank, world_size, port, out_dir):
     part = torch.from_numpy(X[lo:hi].T @ (X[lo:hi] @ z - y[lo:hi]))
     dist.all_reduce(part)
     np.testing.assert_allclose(part.numpy(), X.T @ (X @ z - y), rtol=1e-12)
+    # the lane cap the ranks plan a search with: the smallest any rank serves (one rank without the memory for the
+    # column-major copy serves sixteen where its peers serve thirty-two)
+    assert D.min_over_ranks(32 if rank == 0 else 16) == 16
+    assert D.min_over_ranks(7) == 7
     dist.barrier()
     dist.destroy_process_group()
 
