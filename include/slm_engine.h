@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SLM_ABI_VERSION 18
+#define SLM_ABI_VERSION 19
 
 typedef enum slm_status {
   SLM_OK = 0,
@@ -312,6 +312,10 @@ typedef struct slm_solve_stats {
   int64_t mg_rejected;    /* proposals from the model Gram that the true objective rejected              */
   double mg_build_ms;     /* host wall clock spent building the model Gram inside this call (0: it was
                              there already, or not used)                                                  */
+  int64_t light_passes;   /* (ABI 19) re-verifications after a miss that were CERTIFIED PARTIAL passes instead of passes over
+                             X (csrc/light_kernels.hpp): exact gradient on the working set and on the borderline columns,
+                             a Cauchy-Schwarz certificate for the rest; not counted in grad_launches            */
+  int64_t light_columns;  /* borderline columns those passes read from the column-major copy, in all */
 } slm_solve_stats;
 
 /*
@@ -400,7 +404,8 @@ int slm_solve_lanes_reweighted(slm_dataset* ds, const slm_lane* lanes, const slm
 /* How many lanes one slm_solve_lanes call on this dataset can take with these solve flags (callers
  * size their batches of CV folds / grid rows with it instead of probing for SLM_ERR_UNSUPPORTED). */
 int slm_dataset_max_lanes(slm_dataset* ds, uint32_t flags, int32_t* max_lanes_out);
-/* The lane count slm_solve_path_lanes takes for a path of n_points when the caller passes n_lanes = 0 (ABI 17). */
+/* The lane count slm_solve_path_lanes takes for a path of n_points when the caller passes n_lanes = 0 (ABI 17: until then
+   n_lanes = 0 was clamped to one lane, the strictly sequential warm-started path; callers that want that pass 1). */
 int slm_dataset_path_lanes(slm_dataset* ds, int32_t n_points, uint32_t flags, int32_t* lanes_out);
 
 /*

@@ -119,7 +119,7 @@ py::object dict_get(const py::dict& d, const char* key) {
 py::tuple stats_tuple(const slm_solve_stats& st) {
   return py::make_tuple(st.grad_launches, st.grad_timed, st.grad_ms_total, st.wall_ms, st.lipschitz_ms, st.ws_builds, st.ws_appends,
                         st.ws_refined, st.ws_misses, st.ws_columns, st.ws_inner_iters, st.ws_direct_steps, st.mg_rounds, st.mg_inner_iters,
-                        st.mg_rejected, st.mg_build_ms);
+                        st.mg_rejected, st.mg_build_ms, st.light_passes, st.light_columns);
 }
 
 py::array info_bytes(int64_t count) {

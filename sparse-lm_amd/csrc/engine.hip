@@ -322,6 +322,7 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
   dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
   dfree(ds->ws_nt); dfree(ds->stop_words); dfree(ds->sse_Z); dfree(ds->sse_part); dfree(ds->split_state);
+  dfree(ds->colnorm); dfree(ds->lt_dR); dfree(ds->lt_d2); dfree(ds->lt_part); dfree(ds->lt_cols); dfree(ds->lt_stamp);
   cov_pending_drop(ds);
   ds->cov.clear();
   ds->cov_all_hold.reset();
@@ -691,6 +692,7 @@ extern "C" int slm_dataset_set_global_rows(slm_dataset* ds, int64_t n_global) {
   ds->L_valid = false;
   ds->sketch_valid = false;
   ds->carry_valid = false;
+  ds->colnorm_ready = false;  // (the norms are scaled by 1 / sqrt(n_global))
   mg_invalidate(ds);
   return SLM_OK;
 }

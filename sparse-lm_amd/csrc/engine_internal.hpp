@@ -28,6 +28,7 @@
 #include "tail_kernels.hpp"
 #include "ws_kernels.hpp"
 #include "split_kernels.hpp"
+#include "light_kernels.hpp"
 #include "small_kernels.hpp"
 #include "small_split_kernels.hpp"
 #include "cov_kernels.hpp"
@@ -174,6 +175,7 @@ static const int kSnapInfos = 64;
 struct DevCtl {
   GlobalCtl g;
   MgCtl mg;  // model-Gram rounds (mg_kernels.hpp); cleared with g at the start of every solve
+  LightCtl lt;  // certified partial passes (light_kernels.hpp); likewise
   WsCtl ws;  // (next to them: one fill clears all three at the start of a solve; a working set taken over keeps its block)
   PathCtl lane[SLM_MAX_CELLS];
   slm_point_info infos[kSnapInfos];  // the per-point records of solves of up to kSnapInfos points ride along
@@ -249,6 +251,12 @@ struct slm_dataset {
   double* stop_words = nullptr;  // [STOP_WORDS] row-sharded mode: the vector the ranks all-reduce after every pass
   double* XT = nullptr;  // column-major copy of X in tiles of 32 rows (tile_columns_kernel), built on first use
   bool XT_ready = false, XT_failed = false;
+  // certified partial passes (light_kernels.hpp): the column norms ||X_j|| / sqrt(n_global), built with the copy; the moves'
+  // residual changes, their block sums, the borderline columns and their partial products -- allocated on first use
+  double* colnorm = nullptr;
+  bool colnorm_ready = false;
+  double *lt_dR = nullptr, *lt_d2 = nullptr, *lt_part = nullptr;
+  int32_t *lt_cols = nullptr, *lt_stamp = nullptr;
   // model Gram (mg_kernels.hpp, engine_mg.hip): G~ ~ X^T W X / n_global of the dataset's own rows and weights from an fp16
   // product, built when a solve's lanes outgrow the working set and kept for the later solves of the dataset
   struct MgEntry {           // one per row set, found again like the Grams of covariance passes: by the fingerprint of its row weights
@@ -344,7 +352,7 @@ LaneSetup default_lanes(slm_dataset* ds, int B);
 int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done, hipEvent_t ev_start, hipEvent_t ev_stop,
                      int64_t n_rows = 0);
 int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done, const PathCtl* ctl, const WsArgs* wa,
-                           hipEvent_t ev_start, hipEvent_t ev_stop, int64_t n_rows = 0, bool unit_bracket = false);
+                           hipEvent_t ev_start, hipEvent_t ev_stop, int64_t n_rows = 0, bool unit_bracket = false, const int* skip = nullptr);
 bool split_usable(slm_dataset* ds);
 int ensure_xt(slm_dataset* ds);
 int check_launch();

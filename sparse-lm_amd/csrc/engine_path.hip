@@ -160,6 +160,10 @@ struct PathCall {
   int slot = 0, final_slot = 0;
   bool pending[2] = {false, false};
   bool done = false, results_queued = false, results_final = false, deferred = false, trace3 = false;
+  // ---- certified partial passes (light_kernels.hpp)
+  bool light_begun = false;         // the stamps of this solve have been cleared (first attempt)
+  const int* light_skip = nullptr;  // the flag the kernels of the pass being queued return on (LightCtl::ok), or nullptr
+  std::vector<char> prof_rec;  // profile slots recorded in THIS solve (a pass that may be skipped on the device is not timed)
   // ---- model Gram
   bool mg_forced = false, mg_ok = false, mg_on = false;
   int mg_cap = 0, mg_inner = 20, mg_built = 0;
@@ -186,6 +190,8 @@ struct PathCall {
   bool mg_wanted(const DevCtl& c) const;
   int mg_consider(const DevCtl& c);
   void trace_pass(const DevCtl& now) const;
+  bool light_eligible();
+  int enqueue_light_attempt();
   int queue_chunk();
   int pass_loop();
   int finish();
@@ -980,7 +986,7 @@ int PathCall::prepare_working_set() {
   // possible) when the working set runs from the start, the fused kernel otherwise
 int PathCall::enqueue_pass_gradient(hipEvent_t e0, hipEvent_t e1) {
   if (cov_on) return enqueue_gradient_cov(ds, B, cov_entry, done_flag, e0, e1, ds->ctl, use_ws ? &wa : nullptr);
-  if (split) return enqueue_gradient_split(ds, ls, ds->y, done_flag, ds->ctl, &wa, e0, e1, 0, (o.flags & SLM_FLAG_PROFILE_UNIT) != 0);
+  if (split) return enqueue_gradient_split(ds, ls, ds->y, done_flag, ds->ctl, &wa, e0, e1, 0, (o.flags & SLM_FLAG_PROFILE_UNIT) != 0, light_skip);
   return enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1);
 }
 
@@ -1219,13 +1225,53 @@ int PathCall::mg_consider(const DevCtl& c) {
 // SLM_TRACE=3: one line per polled snapshot -- where every lane stands, the working set, the model Gram's rounds
 void PathCall::trace_pass(const DevCtl& now) const {
   if (!trace3) return;
-  fprintf(stderr, "[slm] pass %lld at %.3f ms: K %d builds %d appends %d misses %d stale %d refined %d | mg on %d rounds %d inner %d most %d rej %d | lanes (point.iter/flags):",
+  fprintf(stderr, "[slm] pass %lld at %.3f ms: K %d builds %d appends %d misses %d stale %d refined %d | mg on %d rounds %d inner %d most %d rej %d | light %d of %d (last: %d columns, why %d, D %.3g) | lanes (point.iter/flags):",
           (long long)enq, t_mark(), now.ws.Kreal, now.ws.builds, now.ws.appends, now.ws.misses, now.ws.stale, now.ws.refined, (int)mg_on,
-          now.mg.rounds, now.mg.inner_iters, now.mg.most_iters, now.mg.rejected);
+          now.mg.rounds, now.mg.inner_iters, now.mg.most_iters, now.mg.rejected, now.lt.used, now.lt.attempts, now.lt.n_cols, now.lt.why, now.lt.D[0]);
   for (int l = 0; l < B; ++l)
     fprintf(stderr, " %d.%d%s%s%s", now.lane[l].point, now.lane[l].iter, now.lane[l].done ? "d" : "", now.lane[l].zsup ? "w" : "",
             l < SLM_MAX_LANES && now.mg.lane[l].active ? "m" : "");
   fprintf(stderr, "\n");
+}
+
+// A pass beyond the expected end of a working-set path re-verifies the few lanes whose last verification missed: such a pass
+// may be a CERTIFIED PARTIAL one (light_kernels.hpp) -- the host queues the attempt in front of the pass over X, the device
+// decides whether it stands (then the pass's kernels return at once) or stands down (then they run).  Per-feature penalties on
+// interleaved shared paths, the dataset's own unweighted rows, one device; not beside model-Gram rounds or covariance passes.
+bool PathCall::light_eligible() {
+  if (!knobs().light_pass || !shared_path || !interleave || !ds->singleton || !use_ws || ws_late || !split || cov_on || sharded || mg_on)
+    return false;
+  if (any_rw || ds->rw || custom_scale || B > kMaxLanes || !(expected > 0 && enq >= expected)) return false;
+  return ds->XT != nullptr && ds->XT_ready && ds->colnorm != nullptr && ds->colnorm_ready;
+}
+
+int PathCall::enqueue_light_attempt() {
+  const int nblk = ds->split_nblk;
+  if (!ds->lt_dR) SLM_TRY(dalloc(&ds->lt_dR, (size_t)n * LT_LANES));
+  if (!ds->lt_d2) SLM_TRY(dalloc(&ds->lt_d2, (size_t)nblk * LT_LANES));
+  if (!ds->lt_part) SLM_TRY(dalloc(&ds->lt_part, (size_t)nblk * LT_CAP * LT_LANES));
+  if (!ds->lt_cols) SLM_TRY(dalloc(&ds->lt_cols, (size_t)LT_CAP));
+  if (!ds->lt_stamp) SLM_TRY(dalloc(&ds->lt_stamp, (size_t)ld));
+  if (!light_begun) {  // (attempt numbers start at 1 with every solve: the stamps of the solve before mean nothing)
+    HIP_TRY(hipMemsetAsync(ds->lt_stamp, 0, sizeof(int32_t) * (size_t)ld, s));
+    light_begun = true;
+  }
+  LightArgs la;
+  memset(&la, 0, sizeof(la));
+  la.lt = &ds->dctl->lt; la.ctl = ds->ctl; la.done = done_flag; la.pts = ds->pts; la.ws = wa.ws; la.idx = wa.idx; la.pos = wa.pos;
+  la.XW = wa.XW; la.XT = ds->XT; la.Gm = wa.Gm; la.y = ds->y; la.colnorm = ds->colnorm;
+  la.z = ds->z; la.zprev = ds->zprev; la.gprev = ds->gprev; la.a0 = ds->a0; la.b0 = ds->b0; la.g = ds->g;
+  la.loss_partial = ds->loss_partial; la.dR = ds->lt_dR; la.d2_part = ds->lt_d2; la.cols = ds->lt_cols; la.stamp = ds->lt_stamp; la.part = ds->lt_part;
+  la.n = n; la.ld = ld; la.rows_base = n / nblk; la.rows_rem = n % nblk;
+  la.p = (int)p; la.n_lanes = B; la.slots = SPLIT_LANES * ((B + SPLIT_LANES - 1) / SPLIT_LANES); la.nblk = nblk;
+  la.inv_n = 1.0 / (double)ds->n_global;
+  hipLaunchKernelGGL(light_prepare_kernel, dim3(1), dim3(1024), 0, s, la);
+  hipLaunchKernelGGL(light_resid_kernel, dim3((unsigned)nblk), dim3(LT_WAVES * 64), 0, s, la);
+  hipLaunchKernelGGL(light_select_kernel, dim3(1), dim3(1024), 0, s, la);
+  const size_t lds = sizeof(double) * (size_t)(la.rows_base + 1) * LT_LANES;
+  hipLaunchKernelGGL(light_coldot_kernel, dim3((unsigned)nblk), dim3(256), lds, s, la);
+  hipLaunchKernelGGL(light_assemble_kernel, dim3(LT_LANES), dim3(1024), 0, s, la);
+  return SLM_OK;
 }
 
 // passes of one chunk: gradient, tail, (refinement), and the snapshot the host will read
@@ -1236,7 +1282,8 @@ int PathCall::queue_chunk() {
     const int this_chunk = mg_on ? 1 : (expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(64, expected - enq) : 1));
     for (int i = 0; i < this_chunk; ++i) {
       hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (profile && enq >= prof_off && (enq - prof_off) % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time
+      const bool light = light_eligible();  // (the pass over X of this step may be skipped on the device: not timed)
+      if (profile && !light && enq >= prof_off && (enq - prof_off) % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time
         const int64_t slot_id = (enq - prof_off) / kProfStride;
         while ((int64_t)ds->prof.size() < 2 * (slot_id + 1)) {
           hipEvent_t ev;
@@ -1245,7 +1292,11 @@ int PathCall::queue_chunk() {
         }
         e0 = ds->prof[2 * slot_id];
         e1 = ds->prof[2 * slot_id + 1];
+        if ((int64_t)prof_rec.size() <= slot_id) prof_rec.resize((size_t)slot_id + 1, 0);
+        prof_rec[(size_t)slot_id] = 1;
       }
+      if (light) SLM_TRY(enqueue_light_attempt());
+      light_skip = light ? &ds->dctl->lt.ok : nullptr;
       const bool sample_pass = n_sample > 0 && enq == 0;
       if (sample_pass) {
         LaneSetup part = ls;
@@ -1260,9 +1311,10 @@ int PathCall::queue_chunk() {
       }
       fix_start = sample_pass;
       ++enq;
-      // behind the pass the solve is expected to end with, the launches of the refinement would only find
-      // out that there is nothing left to refine (30 us): they follow once the snapshot says otherwise
-      deferred = (expected > 0 && enq == expected && !sharded) || mg_on;
+      // behind the pass the solve is expected to end with -- and behind the few re-verifications past it, which the host
+      // polls one by one (pass_loop: at_end) and which mostly end the solve -- the launches of the refinement would only find
+      // out that there is nothing left to refine (30-40 us): they follow once the snapshot says otherwise
+      deferred = (expected > 0 && enq >= expected && enq < expected + 4 && !sharded) || mg_on;
       if (!deferred) enqueue_refinement();
       fix_start = false;
     }
@@ -1383,7 +1435,11 @@ int PathCall::finish() {
     nonfinite = nonfinite || fin[l].nonfinite;
   }
   if (stats) {
-    stats->grad_launches = passes - (carry ? 1 : 0) - prof_off;  // launches over the data that did work (every launch serves all lanes)
+    // launches over the data that did work (every launch serves all lanes): passes the tail kernels saw, less the carried
+    // first one, the pass on the row sample, and the certified partial passes (no read of X)
+    stats->grad_launches = passes - (carry ? 1 : 0) - prof_off - snap.lt.used;
+    stats->light_passes = snap.lt.used;
+    stats->light_columns = snap.lt.cols_total;
     stats->grad_ms_total = 0.0;
     stats->grad_timed = 0;
     if (profile) {
@@ -1391,6 +1447,7 @@ int PathCall::finish() {
       int64_t cnt = 0;
       // iterations 0, kProfStride, 2 kProfStride, ... below `passes` did real work and were timed
       for (int64_t k = 0; k * kProfStride < passes - prof_off && 2 * k + 1 < (int64_t)ds->prof.size(); ++k) {
+        if (k >= (int64_t)prof_rec.size() || !prof_rec[(size_t)k]) continue;  // (not recorded in this solve)
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ds->prof[2 * k], ds->prof[2 * k + 1]) == hipSuccess) {
           tot += ms;

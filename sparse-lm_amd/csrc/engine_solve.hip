@@ -246,7 +246,7 @@ bool split_usable(slm_dataset* ds) {
 
 int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done,
                            const PathCtl* ctl, const WsArgs* wa, hipEvent_t ev_start,
-                           hipEvent_t ev_stop, int64_t n_rows, bool unit_bracket) {
+                           hipEvent_t ev_stop, int64_t n_rows, bool unit_bracket, const int* skip) {
   hipStream_t s = ds->eng->stream;
   const SplitKernel* sk = ds->sk;
   const int nblk = ds->split_nblk;
@@ -260,7 +260,7 @@ int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y
   memset(&a, 0, sizeof(a));
   a.X = ds->X; a.y = y; a.rw = ls.rw; a.rw_stride = ls.rw_stride; a.z = ds->z; a.R = ds->R;
   a.lane_slots = SPLIT_LANES * halves; a.r_plane = (int64_t)ds->n * SPLIT_RSTRIDE;
-  a.partial = ds->partial; a.loss_partial = ds->loss_partial; a.done = done; a.ctl = ctl;
+  a.partial = ds->partial; a.loss_partial = ds->loss_partial; a.done = done; a.ctl = ctl; a.skip = skip;
   if (wa) { a.XW = wa->XW; a.idx = wa->idx; a.ws = wa->ws; }
   const int64_t nr = n_rows > 0 ? n_rows : ds->n;
   a.n = nr; a.ld = ds->ld; a.rows_base = nr / nblk; a.rows_rem = nr % nblk;
@@ -287,6 +287,7 @@ int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y
   ra.done = done;
   ra.nblk = xblk;
   ra.nblk_loss = nblk;
+  ra.skip = skip;
   ra.n_lanes = a.lane_slots;  // partial rows are laid out for all lane slots of the split pass
   ra.ld = ds->ld;
   for (int l = 0; l < kMaxLanes; ++l) {
@@ -788,8 +789,22 @@ int ensure_xt(slm_dataset* ds) {
   }
   if (ds->XT && !ds->XT_ready) {
     ds->XT_ready = true;
+    ds->colnorm_ready = false;
     const dim3 grid((unsigned)row_tiles, (unsigned)((ld + 31) / 32));
     hipLaunchKernelGGL(tile_columns_kernel, grid, dim3(256), 0, s, (const double*)ds->X, n, ld, ds->XT);
+  }
+  // the column norms certified partial passes bound with (light_kernels.hpp): one read of the copy, kept beside it
+  // (unweighted own rows of one device: the only datasets such passes serve)
+  if (ds->XT && ds->XT_ready && !ds->colnorm_ready && !ds->rw && !row_sharded(ds) && knobs().light_pass) {
+    if (!ds->colnorm && pool_malloc((void**)&ds->colnorm, sizeof(double) * (size_t)ld) != hipSuccess) {
+      (void)hipGetLastError();
+      ds->colnorm = nullptr;
+    }
+    if (ds->colnorm) {
+      hipLaunchKernelGGL(colnorm_kernel, dim3((unsigned)((ld + 7) / 8)), dim3(256), 0, s, (const double*)ds->XT, n, ld, 1.0 / (double)ds->n_global,
+                         ds->colnorm);
+      ds->colnorm_ready = true;
+    }
   }
   return SLM_OK;
 }

@@ -555,11 +555,13 @@ struct ReduceArgs {
   int64_t ld;
   double scale[32];       // 1/n_eff per lane (SLM_MAX_LANES)
   double loss_scale[32];  // 1/(2 n_eff) per lane
+  const int* skip = nullptr;  // non-null and *skip != 0: the gradients are there already (light_kernels.hpp): return at once
 };
 
 // grid = (ld/16 + 1, n_lanes)
 static __global__ __launch_bounds__(256) void reduce_partials_kernel(ReduceArgs a) {
   if (a.done != nullptr && *a.done != 0) return;
+  if (a.skip != nullptr && *a.skip != 0) return;
   __shared__ double lds[16][17];
   const int tid = threadIdx.x;
   const int cl = tid & 15, slice = tid >> 4;

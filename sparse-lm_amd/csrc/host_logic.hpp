@@ -331,6 +331,7 @@ struct Knobs {
   int mg = -1;                   // SLM_MG: 0 off, 2 forced from the first snapshot (tests), -1 by capacity
   bool mg_keep = true;           // SLM_NO_MG_KEEP
   bool handover = true;          // SLM_NO_HANDOVER
+  bool light_pass = true;        // SLM_NO_LIGHT_PASS: every re-verification is a pass over X (light_kernels.hpp)
   // memory, diagnostics
   double device_pool_gb = -1.0;  // SLM_DEVICE_POOL_GB (< 0: the default cap)
   bool device_pool = true;       // SLM_NO_DEVICE_POOL
@@ -405,6 +406,7 @@ struct Knobs {
     if (const char c = first("SLM_MG")) k.mg = c == '0' ? 0 : (c == '2' ? 2 : -1);
     k.mg_keep = !is_set("SLM_NO_MG_KEEP");
     k.handover = !is_set("SLM_NO_HANDOVER");
+    k.light_pass = !is_set("SLM_NO_LIGHT_PASS");
     if (const char* e = text("SLM_DEVICE_POOL_GB")) k.device_pool_gb = std::max(0.0, atof(e));
     k.device_pool = !is_set("SLM_NO_DEVICE_POOL");
     k.allow_any_arch = is_set("SLM_ALLOW_ANY_ARCH");

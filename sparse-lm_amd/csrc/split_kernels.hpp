@@ -58,7 +58,12 @@ struct SplitArgs {
   const double* XT;  // rowdot_mfma_kernel: column-major copy of X in tiles of 32 rows (tile_columns_kernel)
   int lane_slots;    // lane slots of partial / loss_partial: 16 x halves of the call (0 = 16)
   int64_t r_plane;   // doubles between the planes of R (the second half's residuals; 0 with one half)
+  const int* skip;   // non-null and *skip != 0: this pass over X is not needed -- a certified partial pass has delivered the
+                     // lanes' gradients (light_kernels.hpp) -- and every kernel of it returns at once
 };
+__device__ __forceinline__ bool split_off(const SplitArgs& a) {
+  return (a.done != nullptr && *a.done != 0) || (a.skip != nullptr && *a.skip != 0);
+}
 __device__ __forceinline__ int split_slots(const SplitArgs& a) { return a.lane_slots > 0 ? a.lane_slots : SPLIT_LANES; }
 
 // which lanes take their residual from XW: live, flagged by ws_solve_kernel, and W still published
@@ -105,7 +110,7 @@ __device__ __forceinline__ unsigned split_x_mask(const SplitArgs& a, int half = 
 template <int B>
 __global__ __launch_bounds__(256) void resid_ws_kernel(SplitArgs a) {
   static_assert(B == SPLIT_LANES && B % 2 == 0, "one launch serves every lane slot");
-  if (a.done != nullptr && *a.done != 0) return;
+  if (split_off(a)) return;
   const unsigned mask = split_ws_mask(a);
   if (mask == 0u) return;
   __shared__ double zw[WS_KCAP][B];  // 64 KiB
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(W * 64) void rowdot_ring_kernel(SplitArgs a) {
   constexpr int RED = 2 * B * W * 8;
   static_assert(RING + RED <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   static_assert(D * C < 64, "too many DMA loads in flight for vmcnt");
-  if (a.done != nullptr && *a.done != 0) return;
+  if (split_off(a)) return;
   // lanes served here: live, not served by resid_ws_kernel, inside this launch's window of B lanes
   const int lane0 = a.lane0 + (int)blockIdx.y * B;  // grid.y = windows of B lanes (one launch for all of them)
   const unsigned mask = (split_x_mask(a) >> lane0) & ((1u << B) - 1u);
@@ -367,7 +372,7 @@ __device__ __forceinline__ void xtr_mfma_body(SplitArgs& a) {
   static_assert(H == 1 || H == 2, "one or two planes of R");
   static_assert(E == 0 || (H == 1 && (E == 2 || E == 4)), "extras: pairs of slots of plane 1 beside the sixteen of plane 0");
   constexpr int E2 = E > 0 ? E / 2 : 1;  // pairs of extra slots (16-byte loads of plane 1's rows)
-  if (a.done != nullptr && *a.done != 0) return;
+  if (split_off(a)) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   // XCD-aware tile order (for speed only): workgroups are handed to the 8 XCDs round-robin by linear id, and
@@ -698,7 +703,7 @@ __device__ __forceinline__ void rowdot_mfma_body(SplitArgs& a, double* lds, int 
   static_assert(E == 0 || (H == 1 && (E == 2 || E == 4)), "extras: the first lanes of half 1 beside the sixteen of half 0");
   constexpr int HZ = E > 0 ? 2 : H;   // halves whose lanes this launch serves (masks, the cold start, the loss sums)
   constexpr int EE = E > 0 ? E : 1;
-  if (a.done != nullptr && *a.done != 0) return;
+  if (split_off(a)) return;
   const int half0 = (H == 1 && E == 0) ? by : 0;  // first half served here
   unsigned mask[HZ];
   bool any = false;
@@ -926,7 +931,7 @@ constexpr int resid_lds_doubles() { return H * WS_KCAP * SPLIT_LANES + RM_WAVES 
 template <int H>
 __device__ __forceinline__ void resid_mfma_body(SplitArgs& a, double* lds, int bx, int by) {
   static_assert(SPLIT_LANES == 16 && SPLIT_RSTRIDE == 16, "lane slots are the 16 columns of the MFMA B operand");
-  if (a.done != nullptr && *a.done != 0) return;
+  if (split_off(a)) return;
   const int half0 = H == 1 ? by : 0;  // (grid.y: the halves of the call, one launch each; H = 2: both here)
   unsigned mask[H];
   bool any = false;

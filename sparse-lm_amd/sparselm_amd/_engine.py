@@ -45,7 +45,7 @@ FLAG_PROFILE_UNIT = 1024  # with FLAG_PROFILE: the event bracket spans residuals
 FLAG_NO_MODEL_GRAM = 512  # lanes beyond the working set's 512 columns take plain steps, no rounds on the model Gram (csrc/mg_kernels.hpp)
 
 COMM_ID_BYTES = 128
-ABI_VERSION = 18  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
+ABI_VERSION = 19  # SLM_ABI_VERSION of include/slm_engine.h this binding was written against
 
 # every symbol include/slm_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -169,6 +169,8 @@ class _SolveStats(C.Structure):
         ("mg_inner_iters", C.c_int64),
         ("mg_rejected", C.c_int64),
         ("mg_build_ms", C.c_double),
+        ("light_passes", C.c_int64),
+        ("light_columns", C.c_int64),
     ]
 
 
@@ -451,7 +453,7 @@ def lane_points(segments) -> tuple[np.ndarray, np.ndarray]:
 
 _STATS_FIELDS = ("grad_launches", "grad_timed", "grad_ms_total", "wall_ms", "lipschitz_ms", "ws_builds", "ws_appends",
                  "ws_refined", "ws_misses", "ws_columns", "ws_inner_iters", "ws_direct_steps", "mg_rounds", "mg_inner_iters",
-                 "mg_rejected", "mg_build_ms")
+                 "mg_rejected", "mg_build_ms", "light_passes", "light_columns")
 
 
 class PathResult:
@@ -466,7 +468,9 @@ class PathResult:
     ``ws_builds`` (working sets selected from scratch; 0: refinement not used), ``ws_appends``, ``ws_refined``,
     ``ws_misses``, ``ws_columns`` (columns in the working set at the end), ``ws_inner_iters``, ``ws_direct_steps``,
     ``mg_rounds`` / ``mg_inner_iters`` / ``mg_rejected`` / ``mg_build_ms`` (the model Gram: rounds of lanes beyond the
-    working set, their inner iterations, proposals the true objective rejected, build time inside the call)."""
+    working set, their inner iterations, proposals the true objective rejected, build time inside the call),
+    ``light_passes`` / ``light_columns`` (re-verifications after a miss that were certified partial passes instead of passes
+    over X -- csrc/light_kernels.hpp -- and the borderline columns they read; not counted in ``grad_launches``)."""
 
     __slots__ = ("betas", "group_norms", "_infos", "_stats")
 

@@ -22,7 +22,7 @@ for dseed in [int(s) for s in sys.argv[1:]] or [7, 1000]:
         sys.stderr.write(f"=== data seed {dseed}\n")
         r = ds.solve_path(pts, lanes=0, flags=_engine.FLAG_FRESH_L)
         nnz = [int(np.count_nonzero(b)) for b in r.betas]
-        sys.stderr.write(f"passes {r.grad_launches} builds {r.ws_builds} appends {r.ws_appends} misses {r.ws_misses} columns {r.ws_columns}\nnnz per point {nnz}\n")
+        sys.stderr.write(f"passes {r.grad_launches} light {r.light_passes} (columns {r.light_columns}) builds {r.ws_builds} appends {r.ws_appends} misses {r.ws_misses} columns {r.ws_columns}\nnnz per point {nnz}\n")
         # which features enter where, and how they rank in the gradient at zero
         order = np.argsort(-np.abs(g0))
         rank = np.empty(p, int); rank[order] = np.arange(p)
