@@ -291,12 +291,24 @@ static __global__ __launch_bounds__(1024) void light_select_kernel(LightArgs a) 
   __shared__ int wave_tot[TAIL_WAVES];
   const int tid = threadIdx.x;
   const int n_live = lt->n_live;
+  // the moves' lengths: a wavefront per live lane sums the row blocks' parts in a fixed order (four per lane of the wavefront,
+  // then the wavefront's tree) -- eight threads walking 256 blocks one after the other were 20 us of this kernel
+  __shared__ double d2_s[LT_LANES];
+  {
+    const int s = tid >> 6, i = tid & 63;
+    if (s < LT_LANES) {
+      double t = 0.0;
+      if (s < n_live)
+        for (int b = i; b < a.nblk; b += 64) t += a.d2_part[(int64_t)b * LT_LANES + s];
+      t = wave_sum_lane63(t);
+      if (i == 63) d2_s[s] = t;
+    }
+  }
+  __syncthreads();
   if (tid < LT_LANES) {
     double t = 0.0;
     if (tid < n_live) {
-      double s4[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int b = 0; b < a.nblk; ++b) s4[b & 3] += a.d2_part[(int64_t)b * LT_LANES + tid];
-      t = sqrt(((s4[0] + s4[1]) + (s4[2] + s4[3])) * a.inv_n);
+      t = sqrt(d2_s[tid] * a.inv_n);
       const int l = lt->lane_of[tid];
       const PathCtl* c = a.ctl + l;
       const slm_path_point pt = a.pts[c->pt_off + c->point];
@@ -312,18 +324,53 @@ static __global__ __launch_bounds__(1024) void light_select_kernel(LightArgs a) 
   const int j0 = tid * per, j1 = min(j0 + per, a.p);
   unsigned long long pick = 0ull;  // (per <= 64: p <= 65 536, the engine's bound)
   int mine = 0;
-  for (int j = j0; j < j1; ++j) {
-    if (a.pos[j] >= 0) continue;
-    const double cj = a.colnorm[j] * (1.0 + 1e-9) + 1e-300;
-    bool near = false;
-    for (int s = 0; s < n_live; ++s) {
-      const int64_t o = (int64_t)lane_s[s] * a.ld + j;
-      const double thr = sa_s[s] * a.a0[o] + sb_s[s] * a.b0[o];
-      near = near || !(fabs(a.gprev[o]) + cj * Ds[s] < thr * (1.0 - 1e-12));  // (NaN counts as near)
+  if (per <= 8) {
+    // this thread's features, everything they need asked for at once (feature by feature the scan was a chain of dependent
+    // round trips: 30 us at p = 5 000)
+    int ps[8];
+    double cn[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u < j1 ? j0 + u : 0;
+      ps[u] = a.pos[j];
+      cn[u] = a.colnorm[j] * (1.0 + 1e-9) + 1e-300;
     }
-    if (near) {
-      pick |= 1ull << (j - j0);
-      mine += 1;
+    bool near[8] = {false, false, false, false, false, false, false, false};
+    for (int sl = 0; sl < n_live; ++sl) {
+      double gv[8], av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t o = (int64_t)lane_s[sl] * a.ld + (j0 + u < j1 ? j0 + u : 0);
+        gv[u] = a.gprev[o];
+        av[u] = a.a0[o];
+        bv[u] = a.b0[o];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double thr = sa_s[sl] * av[u] + sb_s[sl] * bv[u];
+        near[u] = near[u] || !(fabs(gv[u]) + cn[u] * Ds[sl] < thr * (1.0 - 1e-12));  // (NaN counts as near)
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j0 + u < j1 && ps[u] < 0 && near[u]) {
+        pick |= 1ull << u;
+        mine += 1;
+      }
+  } else {
+    for (int j = j0; j < j1; ++j) {
+      if (a.pos[j] >= 0) continue;
+      const double cj = a.colnorm[j] * (1.0 + 1e-9) + 1e-300;
+      bool near = false;
+      for (int sl = 0; sl < n_live; ++sl) {
+        const int64_t o = (int64_t)lane_s[sl] * a.ld + j;
+        const double thr = sa_s[sl] * a.a0[o] + sb_s[sl] * a.b0[o];
+        near = near || !(fabs(a.gprev[o]) + cj * Ds[sl] < thr * (1.0 - 1e-12));
+      }
+      if (near) {
+        pick |= 1ull << (j - j0);
+        mine += 1;
+      }
     }
   }
   int total = 0;
