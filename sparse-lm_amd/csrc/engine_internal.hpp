@@ -350,7 +350,7 @@ struct LaneSetup {
 };
 LaneSetup default_lanes(slm_dataset* ds, int B);
 int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done, hipEvent_t ev_start, hipEvent_t ev_stop,
-                     int64_t n_rows = 0);
+                     int64_t n_rows = 0, const int* skip = nullptr);
 int enqueue_gradient_split(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done, const PathCtl* ctl, const WsArgs* wa,
                            hipEvent_t ev_start, hipEvent_t ev_stop, int64_t n_rows = 0, bool unit_bracket = false, const int* skip = nullptr);
 bool split_usable(slm_dataset* ds);

@@ -987,7 +987,7 @@ int PathCall::prepare_working_set() {
 int PathCall::enqueue_pass_gradient(hipEvent_t e0, hipEvent_t e1) {
   if (cov_on) return enqueue_gradient_cov(ds, B, cov_entry, done_flag, e0, e1, ds->ctl, use_ws ? &wa : nullptr);
   if (split) return enqueue_gradient_split(ds, ls, ds->y, done_flag, ds->ctl, &wa, e0, e1, 0, (o.flags & SLM_FLAG_PROFILE_UNIT) != 0, light_skip);
-  return enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1);
+  return enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1, 0, light_skip);
 }
 
   // everything that follows the gradient of one pass
@@ -1236,19 +1236,19 @@ void PathCall::trace_pass(const DevCtl& now) const {
 
 // A pass beyond the expected end of a working-set path re-verifies the few lanes whose last verification missed: such a pass
 // may be a CERTIFIED PARTIAL one (light_kernels.hpp) -- the host queues the attempt in front of the pass over X, the device
-// decides whether it stands (then the pass's kernels return at once) or stands down (then they run).  Per-feature penalties on
-// interleaved shared paths, the dataset's own unweighted rows, one device; not beside model-Gram rounds or covariance passes.
+// decides whether it stands (then the pass's kernels return at once) or stands down (then they run).  Shared paths over the
+// dataset's own unweighted rows, one device; not beside model-Gram rounds or covariance passes.
 bool PathCall::light_eligible() {
-  if (!knobs().light_pass || !shared_path || !interleave || !ds->singleton || !use_ws || ws_late || !split || cov_on || sharded || mg_on)
-    return false;
+  if (!knobs().light_pass || !shared_path || !use_ws || ws_late || cov_on || sharded || mg_on) return false;
   if (any_rw || ds->rw || custom_scale || B > kMaxLanes || !(expected > 0 && enq >= expected)) return false;
   return ds->XT != nullptr && ds->XT_ready && ds->colnorm != nullptr && ds->colnorm_ready;
 }
 
 int PathCall::enqueue_light_attempt() {
-  const int nblk = ds->split_nblk;
+  // row blocks of the attempt's own kernels: one per CU, more when a block's image of dR (8 lanes) would not fit 60 KB of LDS
+  const int nblk = (int)std::max<int64_t>(std::max<int64_t>(1, std::min<int64_t>(eng->cus, n)), (n + 959) / 960);
   if (!ds->lt_dR) SLM_TRY(dalloc(&ds->lt_dR, (size_t)n * LT_LANES));
-  if (!ds->lt_d2) SLM_TRY(dalloc(&ds->lt_d2, (size_t)nblk * LT_LANES));
+  if (!ds->lt_d2) SLM_TRY(dalloc(&ds->lt_d2, (size_t)nblk * (LT_LANES + kMaxLanes)));  // (+ the block sums of the losses)
   if (!ds->lt_part) SLM_TRY(dalloc(&ds->lt_part, (size_t)nblk * LT_CAP * LT_LANES));
   if (!ds->lt_cols) SLM_TRY(dalloc(&ds->lt_cols, (size_t)LT_CAP));
   if (!ds->lt_stamp) SLM_TRY(dalloc(&ds->lt_stamp, (size_t)ld));
@@ -1261,10 +1261,11 @@ int PathCall::enqueue_light_attempt() {
   la.lt = &ds->dctl->lt; la.ctl = ds->ctl; la.done = done_flag; la.pts = ds->pts; la.ws = wa.ws; la.idx = wa.idx; la.pos = wa.pos;
   la.XW = wa.XW; la.XT = ds->XT; la.Gm = wa.Gm; la.y = ds->y; la.colnorm = ds->colnorm;
   la.z = ds->z; la.zprev = ds->zprev; la.gprev = ds->gprev; la.a0 = ds->a0; la.b0 = ds->b0; la.g = ds->g;
-  la.loss_partial = ds->loss_partial; la.dR = ds->lt_dR; la.d2_part = ds->lt_d2; la.cols = ds->lt_cols; la.stamp = ds->lt_stamp; la.part = ds->lt_part;
+  la.loss_partial = ds->lt_d2 + (size_t)nblk * LT_LANES; la.dR = ds->lt_dR; la.d2_part = ds->lt_d2; la.cols = ds->lt_cols; la.stamp = ds->lt_stamp; la.part = ds->lt_part;
   la.n = n; la.ld = ld; la.rows_base = n / nblk; la.rows_rem = n % nblk;
   la.p = (int)p; la.n_lanes = B; la.slots = SPLIT_LANES * ((B + SPLIT_LANES - 1) / SPLIT_LANES); la.nblk = nblk;
   la.inv_n = 1.0 / (double)ds->n_global;
+  la.order = ds->order; la.gstart = ds->gstart; la.G = G; la.singleton = ds->singleton;
   hipLaunchKernelGGL(light_prepare_kernel, dim3(1), dim3(1024), 0, s, la);
   hipLaunchKernelGGL(light_resid_kernel, dim3((unsigned)nblk), dim3(LT_WAVES * 64), 0, s, la);
   hipLaunchKernelGGL(light_select_kernel, dim3(1), dim3(1024), 0, s, la);

@@ -153,7 +153,7 @@ LaneSetup default_lanes(slm_dataset* ds, int B) {
 // grad -> reduce (-> all-reduce) for B lanes on ONE pass over X:
 // g_l = X^T W_l (X z_l - y) / n_eff_l in ds->g + l*(ld+16), loss_l in g_l[ld].
 int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* y, const int* done,
-                     hipEvent_t ev_start, hipEvent_t ev_stop, int64_t n_rows) {
+                     hipEvent_t ev_start, hipEvent_t ev_stop, int64_t n_rows, const int* skip) {
   hipStream_t s = ds->eng->stream;
   const int B = ls.B;
   const GradKernel* gk = ds->gk[B - 1];
@@ -167,6 +167,7 @@ int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* y, cons
   a.partial = ds->partial;
   a.loss_partial = ds->loss_partial;
   a.done = done;
+  a.skip = skip;
   const int64_t nr = n_rows > 0 ? n_rows : ds->n;  // n_rows: only the first rows (sketched Lipschitz bound)
   a.n = nr;
   a.ld = ds->ld;
@@ -180,7 +181,7 @@ int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* y, cons
   } else {  // two-pass fallback (one lane; row weights shared)
     TwoPassArgs t;
     t.X = ds->X; t.y = y; t.rw = ls.rw; t.z = a.z; t.r = ds->rvec; t.partial = a.partial;
-    t.loss_partial = a.loss_partial; t.done = done; t.n = nr; t.ld = ds->ld;
+    t.loss_partial = a.loss_partial; t.done = done; t.skip = skip; t.n = nr; t.ld = ds->ld;
     t.rows_base = a.rows_base; t.rows_rem = a.rows_rem; t.p2 = a.p2;
     hipLaunchKernelGGL(rowdot_kernel, dim3(nblk), dim3(256), 0, s, t);
     const unsigned tiles = (unsigned)((a.p2 + 512 * kTwoPassC - 1) / (512 * kTwoPassC));
@@ -192,6 +193,7 @@ int enqueue_gradient(slm_dataset* ds, const LaneSetup& ls, const double* y, cons
   ra.loss_partial = a.loss_partial;
   ra.g = ds->g;
   ra.done = done;
+  ra.skip = skip;
   ra.nblk = nblk;
   ra.nblk_loss = nblk;
   ra.n_lanes = B;

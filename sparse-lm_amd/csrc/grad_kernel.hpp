@@ -41,6 +41,7 @@ struct GradArgs {
   int64_t rows_rem;      // n % gridDim.x
   int64_t rw_stride;     // 0: all lanes share rw[]; otherwise lane b reads rw[b*rw_stride + row]
   int p2;                // ld / 2: number of 16-byte chunks per row
+  const int* skip = nullptr;  // non-null and *skip != 0: this pass is not needed (light_kernels.hpp): return at once
 };
 
 #ifndef SLM_NT_LOADS
@@ -121,6 +122,7 @@ template <int W, int C, int R, int B>
 __global__ __launch_bounds__(W * 64) void grad_fused_kernel(GradArgs a) {
   constexpr int T = W * 64;
   if (a.done != nullptr && *a.done != 0) return;
+  if (a.skip != nullptr && *a.skip != 0) return;
 
   __shared__ double red[2][R][B][W];
 
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(W * 64) void grad_ring_kernel(GradArgs a) {
   static_assert(RING + RED <= 160 * 1024, "ring does not fit the 160 KiB LDS");
   static_assert(D * C < 64, "too many DMA loads in flight for vmcnt");
   if (a.done != nullptr && *a.done != 0) return;
+  if (a.skip != nullptr && *a.skip != 0) return;
 
   __shared__ __attribute__((aligned(16))) char smem[RING + RED];
   double* red = reinterpret_cast<double*>(smem + RING);  // [2][B][W]
@@ -442,10 +445,12 @@ struct TwoPassArgs {
   const int* done;
   int64_t n, ld, rows_base, rows_rem;
   int p2;
+  const int* skip = nullptr;
 };
 
 static __global__ __launch_bounds__(256) void rowdot_kernel(TwoPassArgs a) {
   if (a.done != nullptr && *a.done != 0) return;
+  if (a.skip != nullptr && *a.skip != 0) return;
   __shared__ double lsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t b = blockIdx.x;
@@ -488,6 +493,7 @@ static __global__ __launch_bounds__(256) void rowdot_kernel(TwoPassArgs a) {
 template <int C>
 __global__ __launch_bounds__(512) void xtr_kernel(TwoPassArgs a) {
   if (a.done != nullptr && *a.done != 0) return;
+  if (a.skip != nullptr && *a.skip != 0) return;
   constexpr int T = 512;
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x;

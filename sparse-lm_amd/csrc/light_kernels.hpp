@@ -21,8 +21,8 @@
 // minimiser to the same tolerance; a lane that misses again appends and tries again, with the slack carried along.
 // If a condition fails (a live lane off W, more than LT_LANES live lanes, more than LT_CAP borderline columns) the attempt
 // stands down on the device (LightCtl::ok = 0) and the pass over X queued right behind it runs as always; when it stands,
-// those kernels return at once (SplitArgs::skip).  Per-feature penalties, unweighted rows, one device (solve loop:
-// PathCall::light_eligible).  Reference counterpart: none -- /root/reference/src/sparselm/model/_base.py:512-519 hands the
+// those kernels return at once (SplitArgs::skip).  Per-feature and group penalties (a group is certified as a whole, see
+// light_select_kernel), shared paths over the dataset's own unweighted rows, one device (solve loop: PathCall::light_eligible).  Reference counterpart: none -- /root/reference/src/sparselm/model/_base.py:512-519 hands the
 // problem to cvxpy once; this is a property of the verification scheme of the engine.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -82,6 +82,10 @@ struct LightArgs {
   int64_t n, ld, rows_base, rows_rem;
   int p, n_lanes, slots, nblk;
   double inv_n;
+  // group structure (singleton != 0: every feature its own group)
+  const int* order;   // [p] feature of the k-th element in group-sorted order
+  const int* gstart;  // [G + 1]
+  int G, singleton;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -320,6 +324,68 @@ static __global__ __launch_bounds__(1024) void light_select_kernel(LightArgs a) 
     Ds[tid] = t;
   }
   __syncthreads();
+  if (!a.singleton) {
+    // Group penalties: a group outside W stays at zero at the new point iff || soft(g_g, a) ||_2 <= b_g, and every coordinate of
+    // the true gradient lies within c_j (S + D) of the base point's: the group is certified when
+    //     sqrt( sum_j max(|g_j(z)| + c_j (S + D) - a_j, 0)^2 ) < b_g        (b_g = 0: when that sum is exactly zero)
+    // for every live lane; otherwise ALL its members are borderline columns (groups enter the working set whole).
+    // A thread per group (tid, tid + 1024, ...), members in group-sorted order: the list is in group order.
+    const int gper = (a.G + 1023) / 1024;  // (<= 64)
+    unsigned long long gpick = 0ull;
+    int gmine = 0;
+    for (int u = 0; u < gper; ++u) {
+      const int g = tid + 1024 * u;
+      if (g >= a.G) break;
+      const int k0 = a.gstart[g], k1 = a.gstart[g + 1];
+      if (k1 <= k0 || a.pos[a.order[k0]] >= 0) continue;
+      bool near = false;
+      for (int sl = 0; sl < n_live && !near; ++sl) {
+        const int64_t lo = (int64_t)lane_s[sl] * a.ld;
+        double u2 = 0.0;
+        for (int k = k0; k < k1; ++k) {
+          const int j = a.order[k];
+          const double e = fabs(a.gprev[lo + j]) + (a.colnorm[j] * (1.0 + 1e-9) + 1e-300) * Ds[sl] - sa_s[sl] * a.a0[lo + j];
+          if (!(e <= 0.0)) u2 = __builtin_fma(e, e, u2);  // (NaN counts)
+        }
+        const double thr = sb_s[sl] * a.b0[lo + g];
+        near = thr > 0.0 ? !(sqrt(u2) < thr * (1.0 - 1e-12)) : !(u2 == 0.0);
+      }
+      if (near) {
+        gpick |= 1ull << u;
+        gmine += k1 - k0;
+      }
+    }
+    int gtotal = 0;
+    int gat = block_excl_scan(gmine, wave_tot, &gtotal);
+    __syncthreads();
+    const bool gfits = gtotal <= LT_CAP;
+    if (gfits)
+      for (int u = 0; u < gper; ++u)
+        if ((gpick >> u) & 1ull) {
+          const int g = tid + 1024 * u;
+          for (int k = a.gstart[g]; k < a.gstart[g + 1]; ++k) a.cols[gat++] = a.order[k];
+        }
+    if (tid == 0) {
+      if (gfits) {
+        lt->n_cols = gtotal;
+        lt->used += 1;
+        lt->cols_total += gtotal;
+        for (int sl = 0; sl < n_live; ++sl) {
+          lt->D[sl] = Ds[sl] - lt->slack[lane_s[sl]];
+          lt->slack[lane_s[sl]] = Ds[sl];
+          lt->epoch[lane_s[sl]] = lt->id;
+        }
+      } else {
+        lt->ok = 0;
+        lt->why = 3;
+        for (int l = 0; l < SLM_MAX_LANES; ++l) {
+          lt->slack[l] = 0.0;
+          lt->epoch[l] = 0;
+        }
+      }
+    }
+    return;
+  }
   const int per = (a.p + 1023) / 1024;
   const int j0 = tid * per, j1 = min(j0 + per, a.p);
   unsigned long long pick = 0ull;  // (per <= 64: p <= 65 536, the engine's bound)

@@ -95,3 +95,44 @@ def test_every_unread_column_satisfies_the_certificate(eng):
             assert np.max(np.abs(g[~on])) <= alphas[k] * (1 + 1e-7), (seed, k)
             assert np.max(np.abs(g[on] + alphas[k] * np.sign(beta[on]))) <= 1e-6 * alphas[0], (seed, k)
     assert hits > 0
+
+
+def test_group_paths_take_light_passes_too(eng, monkeypatch):
+    """Group and sparse-group penalties: a group outside the working set is certified as a whole -- the 2-norm of the largest
+    soft-thresholded gradient its coordinates can have stays below its weight -- or all its members are read.  Against the
+    route without light passes and against the oracle (model/_lasso.py:230-275, 616-639)."""
+    used = 0
+    # (small problems run the fused gradient kernels, not the split pass: the attempt stands in front of either)
+    for seed, l1 in ((0, 0.0), (2, 0.3), (4, 0.5), (6, 0.7)):
+        rng = np.random.default_rng(100 + seed)
+        n, p, gs = 9000, 1200, 10
+        G = p // gs
+        X = rng.standard_normal((n, p))
+        groups = rng.permutation(np.repeat(np.arange(G), gs)).astype(np.int32)
+        beta = np.zeros(p)
+        for g in rng.choice(G, 8, replace=False):
+            beta[groups == g] = rng.uniform(1.0, 4.0, gs) * rng.choice([-1.0, 1.0], gs)
+        y = X @ beta + 4.0 * rng.standard_normal(n)
+        g0 = X.T @ y / n
+        bmax = float(np.max(np.sqrt(np.bincount(groups, weights=g0 * g0, minlength=G))))
+        scales = np.geomspace(bmax, 1e-2 * bmax, 30)
+        pts = [(l1 * a, (1.0 - l1) * a, 0.0) for a in scales]
+        with eng.dataset(X, y) as ds:
+            ds.set_groups(groups, G)
+            # (three lanes, ten points each: a lane that misses late in its range re-verifies past the expected end)
+            light = ds.solve_path(pts, lanes=3, flags=_engine.FLAG_WORKING_SET | _engine.FLAG_FRESH_L)
+            monkeypatch.setenv("SLM_NO_LIGHT_PASS", "1")
+            full = ds.solve_path(pts, lanes=3, flags=_engine.FLAG_WORKING_SET | _engine.FLAG_FRESH_L)
+            monkeypatch.delenv("SLM_NO_LIGHT_PASS")
+        assert light.converged and full.converged and full.light_passes == 0
+        assert light.grad_launches <= full.grad_launches
+        used += light.light_passes
+        gidx, Gn = oracle.group_index(groups, p)
+        b = None
+        for k in (8, 20, 29):
+            b, _ = oracle.fista(X, y, pts[k][0], pts[k][1], 0.0, gidx, Gn, beta0=b, tol=1e-13)
+            top = float(np.max(np.abs(b)))
+            if top > 0:
+                assert np.max(np.abs(light.betas[k] - b)) <= 1e-6 * top, (seed, k)
+                assert np.max(np.abs(full.betas[k] - b)) <= 1e-6 * top, (seed, k)
+    assert used > 0
