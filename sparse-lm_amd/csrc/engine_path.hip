@@ -938,6 +938,7 @@ int PathCall::ws_setup(bool late) {
   wa.hard_call = kn.hard_callwide;
   wa.power_iters = kn.ws_power_iters;
   wa.miss_factor = kn.ws_miss_factor;
+  wa.miss_div = kn.ws_miss_div;
   // (0.5 left a first working set of 56-112 columns to the luck of the bisection: 65 on one draw of the headline's law, 102 on
   //  another -- and the features of the first band's deepest points outside the small ones; 0.75: the soak law's twelve paths 92.6 -> 85.0 ms)
   // (per-feature penalties only: groups come in blocks and start from 384 columns -- config 3's first set 250 -> 300 columns at

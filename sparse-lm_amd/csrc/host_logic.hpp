@@ -321,6 +321,7 @@ struct Knobs {
   bool hard_callwide = false;    // SLM_HARD_CALLWIDE
   int ws_power_iters = 10;       // SLM_WS_POWER_ITERS (1..40)
   int ws_miss_factor = 4;        // SLM_WS_MISS_FACTOR (1..8)
+  int ws_miss_div = 8;           // SLM_WS_MISS_DIV (1..4096): coordinates outside W per further append_max after a miss
   double ws_fill = 0.0;          // SLM_WS_FILL (0.1..1; 0: by penalty and path)
   // sample start
   bool sample_start = true;      // SLM_NO_SAMPLE_START
@@ -398,6 +399,7 @@ struct Knobs {
     k.hard_callwide = is_set("SLM_HARD_CALLWIDE");
     as_int("SLM_WS_POWER_ITERS", 1, 40, &k.ws_power_iters);
     as_int("SLM_WS_MISS_FACTOR", 1, 8, &k.ws_miss_factor);
+    as_int("SLM_WS_MISS_DIV", 1, 4096, &k.ws_miss_div);
     if (const char* e = text("SLM_WS_FILL")) k.ws_fill = std::max(0.1, std::min(1.0, atof(e)));
     k.sample_start = !is_set("SLM_NO_SAMPLE_START");
     k.sample_start_all = is_set("SLM_SAMPLE_START_ALL");

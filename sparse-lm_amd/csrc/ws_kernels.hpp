@@ -140,7 +140,8 @@ struct WsArgs {
   int32_t k_init;      // a fresh selection is cut down to this size (or to its non-zeros)
   int32_t bb_steps;    // the model solver opens with spectral steps (SLM_WS_BB=0: accelerated steps throughout)
   int32_t one_solver;  // SLM_WS_ONE_SOLVER=1: every lane goes to the solver with direct steps (measurements)
-  int32_t miss_factor; // an append after a miss may take this many times append_max (4)
+  int32_t miss_factor; // an append after a miss may take up to this many times append_max (4) ...
+  int32_t miss_div;    // ... one more append_max for every miss_div coordinates the plain steps moved outside W
   double fill;         // a selection cut down to a cap stops bisecting its threshold once it holds this share of the cap
   int32_t power_iters; // power steps for lambda_max of a new Gram (SLM_WS_POWER_ITERS)
   int32_t hard_call;   // SLM_HARD_CALLWIDE=1 (A/B runs): direct steps once needed start every later refinement of the CALL
@@ -578,7 +579,12 @@ __device__ __forceinline__ void ws_select_body(TailArgs a, WsArgs w) {
     // anyway shows up as a miss and is appended then)
     // (a lane is stuck: be generous; the first selection of a solve that took over its predecessor's W: as many as a
     //  fresh selection would take -- appended columns cost their own gather and Gram rows only)
-    const double cap = (double)(carried ? max(w.k_init, 4 * w.append_max) : (miss ? w.miss_factor * w.append_max : w.append_max));
+    // (how generous, by how far the lanes left W: a path whose supports outgrow W in waves -- dozens of coordinates a pass --
+    //  takes the full factor; ONE lane that met a feature or two at the deep end of a sparse path takes a single append_max:
+    //  at four it pulled 150 candidates that never entered into every later Gram and model solve, 0.2-0.3 ms per path on
+    //  three of nine draws of the headline's law, tools/ab_knobs_draws.py)
+    const int miss_mult = miss ? min(w.miss_factor, 1 + (int)sweep[1] / max(w.miss_div, 1)) : 1;
+    const double cap = (double)(carried ? max(w.k_init, 4 * w.append_max) : miss_mult * w.append_max);
     if (sweep[0] <= cap) {
       n_sel = sweep[0];
     } else {
