@@ -320,7 +320,7 @@ static void dataset_free(slm_dataset* ds) {
   dfree(ds->lambda); dfree(ds->dctl);
   dfree(ds->pts); dfree(ds->betas_out); dfree(ds->gn_out); dfree(ds->infos);
   dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
-  dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT);
+  dfree(ds->ws_score); dfree(ds->ws_XW); dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx); dfree(ds->XT); dfree(ds->ws_owner);
   dfree(ds->ws_nt); dfree(ds->stop_words); dfree(ds->sse_Z); dfree(ds->sse_part); dfree(ds->split_state);
   dfree(ds->colnorm); dfree(ds->lt_dR); dfree(ds->lt_d2); dfree(ds->lt_part); dfree(ds->lt_cols); dfree(ds->lt_stamp);
   cov_pending_drop(ds);

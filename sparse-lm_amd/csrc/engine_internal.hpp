@@ -210,6 +210,7 @@ struct slm_dataset {
   WsCtl* ws_ctl = nullptr;  // (inside dctl)
   int32_t *ws_idx = nullptr, *ws_pos = nullptr, *ws_gs = nullptr, *ws_gl = nullptr;
   double *ws_score = nullptr, *ws_XW = nullptr, *ws_part = nullptr, *ws_G = nullptr, *ws_Gx = nullptr;
+  int32_t* ws_owner = nullptr;  // [kMaxLanes][ws_nblk <= 512] ws_block_owner_kernel
   double* ws_nt = nullptr;  // [kMaxLanes][NT_SCRATCH] factors of the model solver's direct steps
   double *sse_Z = nullptr, *sse_part = nullptr;  // slm_eval_sse_sparse: coefficient block, partial sums
   size_t sse_cap = 0;

@@ -917,6 +917,13 @@ int PathCall::ws_setup(bool late) {
   }
   wa.n_sets = n_sets;
   wa.nblk = ws_nblk;
+  // row blocks on which a set's row weights are all zeros, or all ones like another set's: ws_block_owner_kernel
+  wa.owner = nullptr;
+  if (ls.rw != nullptr && !sharded && knobs().gram_owner && ws_nblk <= 512) {
+    if (!ds->ws_owner) SLM_TRY(dalloc(&ds->ws_owner, (size_t)kMaxLanes * 512));
+    hipLaunchKernelGGL(ws_block_owner_kernel, dim3((unsigned)ws_nblk), dim3(256), 0, s, ls.rw, ls.rw_stride, wa, ds->ws_owner);
+    wa.owner = ds->ws_owner;
+  }
   // measured on the headline path (tools/ws_sweep.py, 24 combinations within 8 % of each other):
   // theta 0.85 / look-ahead 2 / 16 newcomers per pass / 112 initial columns was the fastest
   // (append 48: interleaved lanes need the next band of the path at once; elsewhere 16 cost a pass now and then)
