@@ -20,11 +20,15 @@ if [ "$PART" = "1" ]; then
   python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.log 2> gpurun_out/${TAG}_bench.err && echo bench ok
   python tools/headline_data_seeds.py > gpurun_out/${TAG}_headline_law_draws.log 2>&1 && echo draws ok
   echo "SLM_NO_LIGHT_PASS=1" >> gpurun_out/${TAG}_headline_law_draws.log; SLM_NO_LIGHT_PASS=1 python tools/headline_data_seeds.py >> gpurun_out/${TAG}_headline_law_draws.log 2>&1
+  # nine draws, settings alternating on each: the defaults, no light passes, a miss always at four appends' worth (rounds 4-5), both
+  python tools/ab_knobs_draws.py "" "SLM_NO_LIGHT_PASS=1" "SLM_WS_MISS_DIV=1 SLM_WS_MISS_FACTOR=4" "SLM_NO_LIGHT_PASS=1 SLM_WS_MISS_DIV=1" 9 > gpurun_out/${TAG}_draws_ab.log 2>&1 && echo draws ab ok
 else
   python tools/lanes_sweep.py 16 18 20 25 32 0 > gpurun_out/${TAG}_lanes_sweep.log 2>&1 && echo lanes ok
   python tools/config3_lanes.py 16 20 25 32 0 > gpurun_out/${TAG}_config3_lanes.log 2>&1 && echo config3 ok
   python tools/headline_soak.py 48 > gpurun_out/${TAG}_headline_soak.log 2>&1 && echo soak ok
   python tools/group_soak.py 24 > gpurun_out/${TAG}_group_soak.log 2>&1 && echo group soak ok
+  bash tools/share_prof.sh 8 0 1 > gpurun_out/${TAG}_config4_share_kernels.log 2>&1 && echo shares ok
+  bash tools/share_prof.sh 1 0 > gpurun_out/${TAG}_config4_over_x_kernels.log 2>&1 && echo grid ok
   python tools/ws_fuzz.py 800 17 > gpurun_out/${TAG}_ws_fuzz.log 2>&1; tail -2 gpurun_out/${TAG}_ws_fuzz.log
   python tools/mg_fuzz.py 40 5 > gpurun_out/${TAG}_mg_fuzz.log 2>&1; tail -2 gpurun_out/${TAG}_mg_fuzz.log
   python tools/carry_fuzz.py $(seq 0 11) > gpurun_out/${TAG}_carry_fuzz.log 2>&1; tail -2 gpurun_out/${TAG}_carry_fuzz.log
