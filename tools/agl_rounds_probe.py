@@ -1,3 +1,4 @@
+"""AdaptiveGroupLasso on the on-chip solver, 25 x 30: how many re-weighting rounds each lane takes in one launch (in-launch re-weighting against the loop of calls)."""
 import os, sys, warnings
 import numpy as np
 sys.path.insert(0, "/root/repo/sparse-lm_amd")

@@ -1,3 +1,4 @@
+"""BASELINE config 4 on one GPU: its calls on one stream and dealt to two / three standing engines (HIP streams), over X and from the folds' Grams."""
 import sys, time
 sys.path[:0] = ['/root/repo', '/root/repo/sparse-lm_amd']
 import bench

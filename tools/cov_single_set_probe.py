@@ -1,3 +1,4 @@
+"""Covariance passes for ONE row set at several widths (p = 530, 1 530, 5 000): Gram build time and ms per path against passes over X."""
 import os, sys, time
 sys.path.insert(0, "/root/repo/sparse-lm_amd"); sys.path.insert(0, "/root/repo")
 import numpy as np

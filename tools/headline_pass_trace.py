@@ -1,3 +1,4 @@
+"""The headline path pass by pass (SLM_TRACE): lanes, points, working-set counters after every pass of one solve on the bench's dataset."""
 import os, sys
 import numpy as np
 ROOT = "/root/repo"

@@ -1,3 +1,4 @@
+"""cProfile of the README example (GridSearchCV over AdaptiveLasso, 100 x 80): where the host spends the time of the reference-sized case."""
 import cProfile, os, pstats, sys, time, warnings
 import numpy as np
 sys.path.insert(0, "/root/repo/sparse-lm_amd")

@@ -1,3 +1,4 @@
+"""The model solver's own account (SLM_TRACE=2 clock marks) on the dense-ended cases of the soak law: iterations, direct steps, ms per lane."""
 import os, sys, time
 import numpy as np
 ROOT = "/root/repo"
