@@ -876,7 +876,13 @@ int PathCall::ws_setup(bool late) {
   const int* set_of = ws_set_of;
   const int* set_lane = ws_set_lane;
   const int n_sets = ws_n_sets;
-  const int ws_nblk = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n / 64));  // (2 MiB of partials each)
+  const int ws_nblk_most = (int)std::max<int64_t>(1, std::min<int64_t>(eng->cus, n / 64));  // (2 MiB of partials each)
+  // Row sets that share partial Grams (ws_block_owner_kernel): the row blocks that are worked on are one per block plus the few
+  // where a set's weights change (two per contiguous fold) -- a handful more than there are CUs is a second round of workgroups
+  // for the stragglers, i.e. the time of two Grams for the work of one.  A few blocks fewer, and everything is one round.
+  // (whether or not SLM_NO_GRAM_OWNER switches the sharing off: the same blocks, the same sums, bit for bit)
+  const bool share_blocks = ls.rw != nullptr && !sharded && n_sets > 1;
+  const int ws_nblk = share_blocks ? std::max(1, std::min(ws_nblk_most, eng->cus - 2 * n_sets)) : ws_nblk_most;
   // (each on its own: slm_eval_sse_sparse may already have brought idx and XW in)
   if (!ds->ws_idx) SLM_TRY(dalloc(&ds->ws_idx, WS_KCAP));
   if (!ds->ws_gs) SLM_TRY(dalloc(&ds->ws_gs, WS_KCAP));
@@ -889,7 +895,7 @@ int PathCall::ws_setup(bool late) {
     dfree(ds->ws_part); dfree(ds->ws_G); dfree(ds->ws_Gx);
     ds->ws_sets = 0;
     if (sharded) SLM_TRY(dalloc(&ds->ws_Gx, (size_t)n_sets * WS_KCAP * WS_KCAP + STOP_WORDS));
-    SLM_TRY(dalloc(&ds->ws_part, (size_t)ws_nblk * n_sets * WS_KCAP * WS_KCAP));  // (ws_nblk depends on n only)
+    SLM_TRY(dalloc(&ds->ws_part, (size_t)ws_nblk_most * n_sets * WS_KCAP * WS_KCAP));  // (ws_nblk_most depends on n only)
     SLM_TRY(dalloc(&ds->ws_G, (size_t)n_sets * WS_KCAP * WS_KCAP));
     ds->ws_sets = n_sets;
   }
