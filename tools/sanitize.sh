@@ -4,10 +4,10 @@
 #   1. csrc/host_logic.hpp -- the engine's device-free bookkeeping, the file engine*.hip include -- through tests/host_logic_test.cpp;
 #   2. csrc/binding.cpp -- the pybind11 module of the hot calls -- built with the sanitizers (sparse-lm_amd/build.py, SLM_SANITIZE=1)
 #      and driven by tests/test_binding_cpu.py and tests/test_abi.py with the runtimes preloaded into python.
-# usage: bash tools/sanitize.sh [log]      (default log: profiles/r05_sanitizers.log)
+# usage: bash tools/sanitize.sh [log]      (default log: profiles/r06_sanitizers.log)
 set -o pipefail
 R=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$R/profiles/r05_sanitizers.log}
+LOG=${1:-$R/profiles/r06_sanitizers.log}
 CXX=${CXX:-g++}
 TMP=$(mktemp -d)
 {
