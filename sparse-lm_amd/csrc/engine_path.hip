@@ -157,6 +157,7 @@ struct PathCall {
   // ---- queue
   int chunk = 0;
   int64_t max_total = 0, enq = 0, expected = 0, n_sample = 0, prof_off = 0;
+  int64_t planned_end = 0;  // `expected` as the lanes' walks give it (tracing and tests move `expected` itself: how the host polls)
   int slot = 0, final_slot = 0;
   bool pending[2] = {false, false};
   bool done = false, results_queued = false, results_final = false, deferred = false, trace3 = false;
@@ -1011,6 +1012,9 @@ void PathCall::enqueue_tail() {
   if (shared_path && !interleave) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
   // (the dense end of an interleaved path: finished lanes take over tail points their owners have not started)
   if (shared_path && interleave && mg_handover) hipLaunchKernelGGL(tail_handover_kernel, dim3(1), dim3(64), 0, s, ta);
+  // (the sparse end: a lane that has fallen a pass behind gives its tail point to a lane that has finished)
+  else if (shared_path && interleave && use_ws && !ws_late && !sharded && planned_end > 0 && knobs().lag_handover)
+    hipLaunchKernelGGL(lag_handover_kernel, dim3(1), dim3(64), 0, s, ta, &ds->ws_ctl->builds, &ds->ws_ctl->stale, (int)(planned_end - enq - 1));
   if (sharded) {  // the ranks agree on "finished" before anything acts on it
     if (use_ws && wa.Gx) {
       // working-set solves: the stop words ride behind the staged Gram parts, in the one all-reduce of the refinement
@@ -1109,6 +1113,7 @@ void PathCall::plan_queue() {
       most = std::max<int64_t>(most, mine);
     }
     expected = 1 + most;
+    planned_end = expected;
   }
   // ---- sample start ------------------------------------------------------------------------------------------------
   // A cold path -- no lane brings a warm start -- used to open with a pass over X for the gradient at zero, of which the solve

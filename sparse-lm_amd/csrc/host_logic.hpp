@@ -333,6 +333,7 @@ struct Knobs {
   bool mg_keep = true;           // SLM_NO_MG_KEEP
   bool handover = true;          // SLM_NO_HANDOVER
   bool light_pass = true;        // SLM_NO_LIGHT_PASS: every re-verification is a pass over X (light_kernels.hpp)
+  bool lag_handover = true;      // SLM_NO_LAG_HANDOVER: a lane that has fallen behind keeps its tail point (tail_kernels.hpp)
   bool gram_owner = true;        // SLM_NO_GRAM_OWNER: every row set multiplies every row block of the gathered columns itself
   // memory, diagnostics
   double device_pool_gb = -1.0;  // SLM_DEVICE_POOL_GB (< 0: the default cap)
@@ -411,6 +412,7 @@ struct Knobs {
     k.handover = !is_set("SLM_NO_HANDOVER");
     k.light_pass = !is_set("SLM_NO_LIGHT_PASS");
     k.gram_owner = !is_set("SLM_NO_GRAM_OWNER");
+    k.lag_handover = !is_set("SLM_NO_LAG_HANDOVER");
     if (const char* e = text("SLM_DEVICE_POOL_GB")) k.device_pool_gb = std::max(0.0, atof(e));
     k.device_pool = !is_set("SLM_NO_DEVICE_POOL");
     k.allow_any_arch = is_set("SLM_ALLOW_ANY_ARCH");

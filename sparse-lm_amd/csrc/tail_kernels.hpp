@@ -1239,6 +1239,65 @@ static __global__ void tail_handover_kernel(TailArgs a) {
   }
 }
 
+// The same hand-over at the SPARSE end, for a lane that has fallen behind: a lane whose verification missed early in the path
+// repeats that point beside the next band and arrives at its tail point a pass after everybody else -- a whole pass over X
+// (and its chain: 0.9 ms of a 3 ms path) for one or two points, on one dataset in six of the headline's shape.  A lane is BEHIND
+// when the points it still has to have verified -- the one it stands on, its regular ones, its tail point -- outnumber the
+// passes left before the expected end of the path (`passes_left`: the host queues the passes and knows); a finished lane
+// then takes its tail point, as above.  The taker keeps `zsup` -- its solution lies on the working set as long as the set has
+// only been appended to since (one build, not stale): its residual comes from the gathered columns like everybody's, not
+// from a read of X of its own.  Lanes on schedule keep their points: short steps from the neighbours' solutions miss least.
+// `ws_builds`, `ws_stale`: words of the working set's control block (nullptr: no working set -- zsup is cleared).
+static __global__ __launch_bounds__(64) void lag_handover_kernel(TailArgs a, const int32_t* ws_builds, const int32_t* ws_stale, int passes_left) {
+  // one wavefront: lane l of it fetches the control words of path lane l (one round trip for all of them -- a single thread
+  // walking the blocks was 10 us a pass), the first decides from the copies; no finished lane, the usual case: nothing to do
+  __shared__ int s_done[SLM_MAX_LANES], s_want[SLM_MAX_LANES], s_tail[SLM_MAX_LANES];
+  const int l = threadIdx.x;
+  const int stop = a.gdone[0];
+  int done = 0, want = 0, tail = -1;
+  if (l < a.n_lanes) {
+    const PathCtl* c = a.ctl + l;
+    const int c_done = c->done, c_bad = c->nonfinite, c_idle = c->idle, c_tail = c->tail_pt, c_pt = c->point, c_end = c->n_points,
+              c_stride = c->stride;
+    done = c_done && !c_bad;
+    tail = c_tail;
+    if (!c_done && !c_idle && c_tail >= 0 && c_pt != c_tail) {
+      const int regular_left = c_pt < c_end ? (c_end - 1 - c_pt) / max(c_stride, 1) : 0;
+      want = 1 + regular_left + 1 > passes_left;  // (behind: more points to have verified than passes left)
+    }
+  }
+  // (all of them or none: with fewer finished lanes than tail points waiting, the pass the hand-over is meant to save is made
+  //  anyway, and the takers' long steps -- from their own last points, not from a neighbour's -- only risk misses of their own:
+  //  soak seed 13, four lanes behind and two free: the same four passes, a miss more, 0.3 ms)
+  const int n_done = __popcll(__ballot(done)), n_want = __popcll(__ballot(want));
+  if (stop != 0 || n_want == 0 || n_done < n_want) return;
+  if (l < SLM_MAX_LANES) {
+    s_done[l] = done;
+    s_want[l] = want;
+    s_tail[l] = tail;
+  }
+  __syncthreads();
+  if (l != 0) return;
+  const bool appended_only = ws_builds != nullptr && *ws_builds == 1 && *ws_stale == 0;
+  for (int t = 0; t < a.n_lanes; ++t) {
+    if (!s_done[t]) continue;
+    int best = -1;
+    for (int v = 0; v < a.n_lanes; ++v)
+      if (s_want[v] && (best < 0 || s_tail[v] < s_tail[best])) best = v;
+    if (best < 0) return;
+    PathCtl* me = a.ctl + t;
+    PathCtl* cv = a.ctl + best;
+    me->point = s_tail[best];
+    me->tail_pt = s_tail[best];
+    cv->tail_pt = -1;
+    s_want[best] = 0;
+    if (!appended_only) me->zsup = 0;
+    me->steals += 1;
+    me->done = 0;
+    atomicSub(&a.gdone[1], 1);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row-sharded mode: the stop decision is taken from reduced data.  After the tail (and hand-out) kernels of a
 // pass every rank packs "I have finished" into a small vector, the vector is summed over the ranks, and

@@ -257,12 +257,15 @@ static void test_knobs() {
   CHECK(d.sample_start && !d.sample_start_all && d.sample_min_rows == 65536 && d.sample_div == 4 && d.l_sketch_div == 32 && d.l_sketch_iters == 1);
   CHECK(d.device_pool && d.device_pool_gb < 0.0 && !d.allow_any_arch && d.xtr_wgs_per_cu == 1.0 && d.direct && d.mg_keep && d.handover);
   CHECK(!d.profile_unit && !d.eval_fused && d.power_iters == 0 && d.grad_cfg[0] == 0);
+  CHECK(d.light_pass && d.gram_owner && d.lag_handover && d.ws_miss_factor == 4 && d.ws_miss_div == 8);  // (round 6)
   env["SLM_WS"] = "0"; env["SLM_MG"] = "2"; env["SLM_TRACE"] = "3"; env["SLM_TRACE_POLL"] = "1"; env["SLM_SPLIT"] = "0";
   env["SLM_GRAD_CONFIG"] = "8,5,2"; env["SLM_WS_THETA"] = "0.7"; env["SLM_WS_APPEND"] = "9999"; env["SLM_WS_KINIT"] = "3";
   env["SLM_SAMPLE_DIV"] = "0"; env["SLM_SAMPLE_START_MIN_ROWS"] = "10"; env["SLM_XTR_WGS_PER_CU"] = "7"; env["SLM_NO_CARRY"] = "";
   env["SLM_DEVICE_POOL_GB"] = "-3"; env["SLM_ROWDOT_RING"] = "1"; env["SLM_GRAD_RING"] = "0"; env["SLM_AUTO_LANES"] = "20";
   env["SLM_WS_FILL"] = "5"; env["SLM_POWER_ITERS"] = "1"; env["SLM_ON_CHIP"] = "0";
+  env["SLM_NO_LIGHT_PASS"] = "1"; env["SLM_NO_GRAM_OWNER"] = ""; env["SLM_NO_LAG_HANDOVER"] = "1"; env["SLM_WS_MISS_DIV"] = "0"; env["SLM_WS_MISS_FACTOR"] = "99";
   Knobs k = Knobs::from(get);
+  CHECK(!k.light_pass && !k.gram_owner && !k.lag_handover && k.ws_miss_div == 1 && k.ws_miss_factor == 8);
   CHECK(k.ws == 0 && k.mg == 2 && k.trace == 3 && k.trace_poll && !k.split && !k.on_chip);
   CHECK(k.grad_cfg[0] == 8 && k.grad_cfg[1] == 5 && k.grad_cfg[2] == 2 && k.ws_theta == 0.7);
   CHECK(k.ws_append == 512 && k.ws_kinit == 16 && k.sample_div == 1 && k.sample_min_rows == 64);  // clamped to their ranges
