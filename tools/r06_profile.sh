@@ -22,7 +22,8 @@ if [ "$PART" = "1" ]; then
   python tools/headline_data_seeds.py > gpurun_out/${TAG}_headline_law_draws.log 2>&1 && echo draws ok
   echo "SLM_NO_LIGHT_PASS=1" >> gpurun_out/${TAG}_headline_law_draws.log; SLM_NO_LIGHT_PASS=1 python tools/headline_data_seeds.py >> gpurun_out/${TAG}_headline_law_draws.log 2>&1
   # nine draws, settings alternating on each: the defaults, no light passes, a miss always at four appends' worth (rounds 4-5), both
-  python tools/ab_knobs_draws.py "" "SLM_NO_LIGHT_PASS=1" "SLM_WS_MISS_DIV=1 SLM_WS_MISS_FACTOR=4" "SLM_NO_LIGHT_PASS=1 SLM_WS_MISS_DIV=1" 9 > gpurun_out/${TAG}_draws_ab.log 2>&1 && echo draws ab ok
+  python tools/ab_knobs_draws.py "" "SLM_NO_LIGHT_PASS=1" "SLM_WS_MISS_DIV=1 SLM_WS_MISS_FACTOR=4" "SLM_NO_LAG_HANDOVER=1" "SLM_NO_LIGHT_PASS=1 SLM_WS_MISS_DIV=1 SLM_NO_LAG_HANDOVER=1" 9 > gpurun_out/${TAG}_draws_ab.log 2>&1 && echo draws ab ok
+  python tools/ab_knobs_soak.py 30 "" "SLM_NO_LAG_HANDOVER=1" "SLM_WS_MISS_DIV=1" > gpurun_out/${TAG}_soak_ab.log 2>&1 && echo soak ab ok
 else
   python tools/lanes_sweep.py 16 18 20 25 32 0 > gpurun_out/${TAG}_lanes_sweep.log 2>&1 && echo lanes ok
   python tools/config3_lanes.py 16 20 25 32 0 > gpurun_out/${TAG}_config3_lanes.log 2>&1 && echo config3 ok
