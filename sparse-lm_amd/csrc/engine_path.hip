@@ -734,9 +734,9 @@ int PathCall::stage_lanes() {
   return SLM_OK;
 }
 
-  // results: lanes whose host buffers follow each other (the ranges of one shared path do) travel in one
-  // copy -- a device-to-host copy into pageable memory costs ~40 us before the first byte moves.  Queued on the
-  // solve's stream; the caller waits for it.
+// results: lanes whose host buffers follow each other (the ranges of one shared path do) travel in one
+// copy -- a device-to-host copy into pageable memory costs ~40 us before the first byte moves.  Queued on the
+// solve's stream; the caller waits for it.
 int PathCall::enqueue_result_copies() {
   int64_t at = 0;
   for (int l = 0; l < B;) {
@@ -764,7 +764,7 @@ int PathCall::enqueue_result_copies() {
   return SLM_OK;
 }
 
-  // ---- problems that fit a workgroup: one launch for the whole call (small_kernels.hpp) -------------------------
+// ---- problems that fit a workgroup: one launch for the whole call (small_kernels.hpp) -------------------------
 int PathCall::run_on_chip() {
   SmallArgs sm;
   memset(&sm, 0, sizeof(sm));
@@ -865,12 +865,12 @@ int PathCall::run_on_chip() {
   return SLM_OK;
 }
 
-  // ---- working-set refinement (ws_kernels.hpp) -----------------------------------------------------
-  // Worth it when a pass over X costs more than the one-workgroup model solve that replaces several
-  // of them; row-sharded datasets would need the Gram all-reduced (not built).
-  // Small problems start with plain steps (their passes cost less than a model solve) and switch the
-  // refinement on when a path point turns out to be hard (ws_late: more than kWsLateIters passes on
-  // one point -- ill-conditioned designs, where FISTA needs thousands).
+// ---- working-set refinement (ws_kernels.hpp) -----------------------------------------------------
+// Worth it when a pass over X costs more than the one-workgroup model solve that replaces several
+// of them; row-sharded datasets would need the Gram all-reduced (not built).
+// Small problems start with plain steps (their passes cost less than a model solve) and switch the
+// refinement on when a path point turns out to be hard (ws_late: more than kWsLateIters passes on
+// one point -- ill-conditioned designs, where FISTA needs thousands).
 int PathCall::ws_setup(bool late) {
   // lanes with the same row weights (same host pointer: the folds of a CV grid) and the same 1/n
   // scaling share one Gram
@@ -963,8 +963,8 @@ int PathCall::ws_setup(bool late) {
   return SLM_OK;
 }
 
-  // no memory for the working-set buffers: the plain iteration still works (unless this solve runs
-  // more lanes than the fused kernels serve, which only the split pass can do)
+// no memory for the working-set buffers: the plain iteration still works (unless this solve runs
+// more lanes than the fused kernels serve, which only the split pass can do)
 void PathCall::ws_release() {
   ds->ws_carry_valid = false;
   dfree(ds->ws_idx); dfree(ds->ws_pos); dfree(ds->ws_gs); dfree(ds->ws_gl);
@@ -997,16 +997,16 @@ int PathCall::prepare_working_set() {
   return SLM_OK;
 }
 
-  // the gradient of one pass: split pass (sixteen lane slots, residuals from the gathered columns where
-  // possible) when the working set runs from the start, the fused kernel otherwise
+// the gradient of one pass: split pass (sixteen lane slots, residuals from the gathered columns where
+// possible) when the working set runs from the start, the fused kernel otherwise
 int PathCall::enqueue_pass_gradient(hipEvent_t e0, hipEvent_t e1) {
   if (cov_on) return enqueue_gradient_cov(ds, B, cov_entry, done_flag, e0, e1, ds->ctl, use_ws ? &wa : nullptr);
   if (split) return enqueue_gradient_split(ds, ls, ds->y, done_flag, ds->ctl, &wa, e0, e1, 0, (o.flags & SLM_FLAG_PROFILE_UNIT) != 0, light_skip);
   return enqueue_gradient(ds, ls, ds->y, done_flag, e0, e1, 0, light_skip);
 }
 
-  // everything that follows the gradient of one pass
-  // (in two halves: behind the pass a solve is expected to end with, the second half waits for the verdict)
+// everything that follows the gradient of one pass
+// (in two halves: behind the pass a solve is expected to end with, the second half waits for the verdict)
 void PathCall::enqueue_tail() {
   launch_tail(ta, s);
   if (shared_path && !interleave) hipLaunchKernelGGL(steal_kernel, dim3(1), dim3(256), 0, s, ta);
@@ -1182,8 +1182,8 @@ void PathCall::plan_queue() {
   if (trace3 && knobs().trace_poll && expected > 0) expected = n_sample > 0 ? 2 : 1;  // (the sample pass's refinement is never held back)
 }
 
-  // the model Gram of every row set of the call (ws_set_of: lanes with the same row weights and scaling share one), found
-  // by the fingerprint of the row weights as the lanes brought them, or built
+// the model Gram of every row set of the call (ws_set_of: lanes with the same row weights and scaling share one), found
+// by the fingerprint of the row weights as the lanes brought them, or built
 int PathCall::mg_sets() {
   const double* wdev[SLM_MAX_LANES];
   double fp[2 * SLM_MAX_LANES] = {};
@@ -1296,51 +1296,51 @@ int PathCall::enqueue_light_attempt() {
 
 // passes of one chunk: gradient, tail, (refinement), and the snapshot the host will read
 int PathCall::queue_chunk() {
-    // (a solve with an expected end queues all of its passes at once: launches behind the device-side stop flag return
-    //  at once, and every snapshot in between -- a copy, an event, 6 us of idle stream around them -- told the host
-    //  nothing it acts on)
-    const int this_chunk = mg_on ? 1 : (expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(64, expected - enq) : 1));
-    for (int i = 0; i < this_chunk; ++i) {
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      const bool light = light_eligible();  // (the pass over X of this step may be skipped on the device: not timed)
-      if (profile && !light && enq >= prof_off && (enq - prof_off) % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time
-        const int64_t slot_id = (enq - prof_off) / kProfStride;
-        while ((int64_t)ds->prof.size() < 2 * (slot_id + 1)) {
-          hipEvent_t ev;
-          HIP_TRY(hipEventCreate(&ev));
-          ds->prof.push_back(ev);
-        }
-        e0 = ds->prof[2 * slot_id];
-        e1 = ds->prof[2 * slot_id + 1];
-        if ((int64_t)prof_rec.size() <= slot_id) prof_rec.resize((size_t)slot_id + 1, 0);
-        prof_rec[(size_t)slot_id] = 1;
+  // (a solve with an expected end queues all of its passes at once: launches behind the device-side stop flag return
+  //  at once, and every snapshot in between -- a copy, an event, 6 us of idle stream around them -- told the host
+  //  nothing it acts on)
+  const int this_chunk = mg_on ? 1 : (expected <= 0 ? chunk : (enq < expected ? (int)std::min<int64_t>(64, expected - enq) : 1));
+  for (int i = 0; i < this_chunk; ++i) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool light = light_eligible();  // (the pass over X of this step may be skipped on the device: not timed)
+    if (profile && !light && enq >= prof_off && (enq - prof_off) % kProfStride == 0) {  // sampled: an event pair costs ~8 us of stream time
+      const int64_t slot_id = (enq - prof_off) / kProfStride;
+      while ((int64_t)ds->prof.size() < 2 * (slot_id + 1)) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        ds->prof.push_back(ev);
       }
-      if (light) SLM_TRY(enqueue_light_attempt());
-      light_skip = light ? &ds->dctl->lt.ok : nullptr;
-      const bool sample_pass = n_sample > 0 && enq == 0;
-      if (sample_pass) {
-        LaneSetup part = ls;
-        for (int l = 0; l < kMaxLanes; ++l) part.n_eff[l] = (double)ds->n_global * (double)n_sample / (double)n;
-        SLM_TRY(enqueue_gradient_split(ds, part, ds->y, done_flag, ds->ctl, &wa, nullptr, nullptr, n_sample));
-        TailArgs first = ta;
-        first.provisional = 1;
-        launch_tail(first, s);
-      } else {
-        if (!(carry && enq == 0)) SLM_TRY(enqueue_pass_gradient(e0, e1));  // (a carried start has its first gradient)
-        enqueue_tail();
-      }
-      fix_start = sample_pass;
-      ++enq;
-      // behind the pass the solve is expected to end with -- and behind the few re-verifications past it, which the host
-      // polls one by one (pass_loop: at_end) and which mostly end the solve -- the launches of the refinement would only find
-      // out that there is nothing left to refine (30-40 us): they follow once the snapshot says otherwise
-      deferred = (expected > 0 && enq >= expected && enq < expected + 4 && !sharded) || mg_on;
-      if (!deferred) enqueue_refinement();
-      fix_start = false;
+      e0 = ds->prof[2 * slot_id];
+      e1 = ds->prof[2 * slot_id + 1];
+      if ((int64_t)prof_rec.size() <= slot_id) prof_rec.resize((size_t)slot_id + 1, 0);
+      prof_rec[(size_t)slot_id] = 1;
     }
-    SLM_TRY(check_launch());
-    if (ws_comm_rc != 0) return ws_comm_rc;  // (all_reduce_sum has set the message)
-    HIP_TRY(hipMemcpyAsync(&ds->hctl[slot].c, ds->dctl, sizeof(DevCtl), hipMemcpyDeviceToHost, s));
+    if (light) SLM_TRY(enqueue_light_attempt());
+    light_skip = light ? &ds->dctl->lt.ok : nullptr;
+    const bool sample_pass = n_sample > 0 && enq == 0;
+    if (sample_pass) {
+      LaneSetup part = ls;
+      for (int l = 0; l < kMaxLanes; ++l) part.n_eff[l] = (double)ds->n_global * (double)n_sample / (double)n;
+      SLM_TRY(enqueue_gradient_split(ds, part, ds->y, done_flag, ds->ctl, &wa, nullptr, nullptr, n_sample));
+      TailArgs first = ta;
+      first.provisional = 1;
+      launch_tail(first, s);
+    } else {
+      if (!(carry && enq == 0)) SLM_TRY(enqueue_pass_gradient(e0, e1));  // (a carried start has its first gradient)
+      enqueue_tail();
+    }
+    fix_start = sample_pass;
+    ++enq;
+    // behind the pass the solve is expected to end with -- and behind the few re-verifications past it, which the host
+    // polls one by one (pass_loop: at_end) and which mostly end the solve -- the launches of the refinement would only find
+    // out that there is nothing left to refine (30-40 us): they follow once the snapshot says otherwise
+    deferred = (expected > 0 && enq >= expected && enq < expected + 4 && !sharded) || mg_on;
+    if (!deferred) enqueue_refinement();
+    fix_start = false;
+  }
+  SLM_TRY(check_launch());
+  if (ws_comm_rc != 0) return ws_comm_rc;  // (all_reduce_sum has set the message)
+  HIP_TRY(hipMemcpyAsync(&ds->hctl[slot].c, ds->dctl, sizeof(DevCtl), hipMemcpyDeviceToHost, s));
   return SLM_OK;
 }
 
