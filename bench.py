@@ -664,7 +664,7 @@ def leg_soak(eng, n, p, K, tol, lanes, seeds=range(4, 16)):
 def leg_headline_draws(eng, n, p, K, tol, lanes, seeds=(7, 1001, 1002, 1003, 1004, 1005, 1006, 1007)):
     """The headline path on OTHER draws of the headline's own law (the same fifty coefficients, other X and noise): the
     dataset `value` is quoted on is one draw, and how many passes a path takes depends on the draw -- a lane's point that
-    meets a feature the working set did not hold is verified a pass later.  Per draw: passes and ms on the engine's choice
+    meets a feature the working set did not hold is verified a pass later.  Per draw: passes and ms (mean of five calls behind two warm-up calls) on the engine's choice
     of lanes (or --lanes) and on sixteen."""
     from sparselm_amd import _engine
 
@@ -677,13 +677,17 @@ def leg_headline_draws(eng, n, p, K, tol, lanes, seeds=(7, 1001, 1002, 1003, 100
             pts = [(a, 0.0, 0.0) for a in np.geomspace(amax, 1e-3 * amax, K)]
             row = {"data_seed": int(dseed)}
             for tag, ln in (("", lanes), ("_16_lanes", 16)):
-                ds.solve_path(pts, tol=tol, lanes=ln, flags=_engine.FLAG_FRESH_L)
+                # (steady state, like `value`, which has its warm-up steps: the first call on a fresh dataset makes the
+                #  column-major copy, the second still allocates what the first did not reach -- 5-14 ms and +0.03-0.6 ms
+                #  measured; from the third on the calls repeat to 0.02 ms)
+                for _ in range(2):
+                    ds.solve_path(pts, tol=tol, lanes=ln, flags=_engine.FLAG_FRESH_L)
                 eng.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(3):
+                for _ in range(5):
                     r = ds.solve_path(pts, tol=tol, lanes=ln, flags=_engine.FLAG_FRESH_L)
                 eng.synchronize()
-                row["ms" + tag] = 1e3 * (time.perf_counter() - t0) / 3
+                row["ms" + tag] = 1e3 * (time.perf_counter() - t0) / 5
                 row["passes" + tag] = int(r.grad_launches)
                 row["converged" + tag] = bool(r.converged)
             rows.append(row)
