@@ -97,6 +97,38 @@ def test_every_unread_column_satisfies_the_certificate(eng):
     assert hits > 0
 
 
+def test_weighted_l1_paths_take_light_passes_with_their_own_thresholds(eng, monkeypatch):
+    """Per-feature weights (the penalty of an AdaptiveLasso round, model/_adaptive_lasso.py:158-232: a_j = alpha * w_j): the
+    certificate compares with a_j, feature by feature.  Against the route without light passes and the oracle."""
+    used = 0
+    for seed in range(20, 26):
+        X, y = _noisy_problem(12_000, 1500, 25, seed)
+        n, p = X.shape
+        w = np.random.default_rng(seed).uniform(0.5, 2.0, p)
+        amax = float(np.max(np.abs(X.T @ y) / w) / n)
+        alphas = np.geomspace(amax, 1e-3 * amax, 50)
+        pts = [(a, 0.0, 0.0) for a in alphas]
+        flags = _engine.FLAG_WORKING_SET | _engine.FLAG_FRESH_L
+        with eng.dataset(X, y) as ds:
+            light = ds.solve_path(pts, a=w, lanes=18, flags=flags)
+            monkeypatch.setenv("SLM_NO_LIGHT_PASS", "1")
+            full = ds.solve_path(pts, a=w, lanes=18, flags=flags)
+            monkeypatch.delenv("SLM_NO_LIGHT_PASS")
+        assert light.converged and full.converged and full.light_passes == 0
+        assert light.grad_launches <= full.grad_launches
+        used += light.light_passes
+        top = np.max(np.abs(full.betas), axis=1)
+        for k in range(len(alphas)):
+            if top[k] > 0:
+                assert np.max(np.abs(light.betas[k] - full.betas[k])) <= 2e-7 * top[k], (seed, k)
+        gidx, G = oracle.group_index(None, p)
+        b = None
+        for k in (15, 35, 49):
+            b, _ = oracle.fista(X, y, alphas[k] * w, 0.0, 0.0, gidx, G, beta0=b, tol=1e-13)
+            assert np.max(np.abs(light.betas[k] - b)) <= 1e-6 * np.max(np.abs(b)), (seed, k)
+    assert used > 0
+
+
 def test_group_paths_take_light_passes_too(eng, monkeypatch):
     """Group and sparse-group penalties: a group outside the working set is certified as a whole -- the 2-norm of the largest
     soft-thresholded gradient its coordinates can have stays below its weight -- or all its members are read.  Against the
