@@ -1164,44 +1164,77 @@ __global__ __launch_bounds__(TAIL_THREADS) void fista_tail_stream_kernel(TailArg
 // ---------------------------------------------------------------------------------------------
 static __global__ __launch_bounds__(256) void steal_kernel(TailArgs a) {
   if (a.gdone[0] != 0) return;
-  __shared__ int took[SLM_MAX_LANES];
-  if (threadIdx.x == 0) {
-    for (int l = 0; l < a.n_lanes; ++l) {
-      took[l] = 0;
-      PathCtl* me = a.ctl + l;
-      if (!me->idle || me->done) continue;
-      int best = -1, best_rem = 0;
-      for (int v = 0; v < a.n_lanes; ++v) {
-        const PathCtl* cv = a.ctl + v;
-        if (v == l || cv->done || cv->idle) continue;
-        const int rem = cv->n_points - (cv->point + 1);  // points the victim has not started
-        if (rem > best_rem) {
-          best = v;
-          best_rem = rem;
-        }
-      }
-      if (best >= 0 && best_rem >= 1) {
-        PathCtl* cv = a.ctl + best;
-        const int hi = cv->n_points;
-        const int mid = hi - (best_rem + 1) / 2;
-        cv->n_points = mid;
-        me->point = mid;
-        me->pt_lo = mid;
-        me->n_points = hi;
-        me->steals += 1;
-        me->idle = 0;
-        me->zzero = 1;  // cold start: the tail kernel zeroed z when the lane went idle
-        took[l] = 1;
-      } else {
-        me->idle = 0;
-        me->done = 1;
-        if (atomicAdd(&a.gdone[1], 1) + 1 == a.n_lanes) a.gdone[a.done_slot] = 1;
-      }
-    }
+  // the words the hand-out looks at, fetched by a thread per lane in ONE round trip: thread 0 walking the control blocks by
+  // itself -- lanes x lanes dependent loads -- was 90 us behind the LAST pass of a 25-lane group path, where every lane is
+  // idle (3 % of config 3's path), 7 us elsewhere
+  __shared__ int s_idle[SLM_MAX_LANES], s_done[SLM_MAX_LANES], s_end[SLM_MAX_LANES], s_pt[SLM_MAX_LANES];
+  const int t = threadIdx.x;
+  if (t < a.n_lanes) {
+    const PathCtl* c = a.ctl + t;
+    s_idle[t] = c->idle;
+    s_done[t] = c->done;
+    s_end[t] = c->n_points;
+    s_pt[t] = c->point;
   }
   __syncthreads();
-  // (the tail kernel already zeroed beta and z of a lane that went idle: cold start is in place)
-  (void)took;
+  // nobody is busy -- behind the last pass of a path every lane is idle -- : nothing to hand out, all idle lanes retire, each by
+  // its own thread (the sequential walk below, lanes x lanes reads of the table, was 50 us of that case)
+  const bool mine_idle = t < a.n_lanes && s_idle[t] && !s_done[t];
+  const bool mine_busy = t < a.n_lanes && !s_idle[t] && !s_done[t];
+  static_assert(SLM_MAX_LANES <= 64, "one wavefront sees every lane");
+  if (t < 64) {
+    const unsigned long long busy = __ballot(mine_busy), idle = __ballot(mine_idle);
+    if (busy == 0ull) {
+      if (mine_idle) {
+        a.ctl[t].idle = 0;
+        a.ctl[t].done = 1;
+      }
+      const int n_ret = __popcll(idle);
+      if (t == 0 && n_ret > 0 && atomicAdd(&a.gdone[1], n_ret) + n_ret == a.n_lanes) a.gdone[a.done_slot] = 1;
+      return;
+    }
+  } else {
+    return;
+  }
+  if (t != 0) return;
+  int retired = 0;
+  for (int l = 0; l < a.n_lanes; ++l) {
+    if (!s_idle[l] || s_done[l]) continue;
+    PathCtl* me = a.ctl + l;
+    int best = -1, best_rem = 0;
+    for (int v = 0; v < a.n_lanes; ++v) {
+      if (v == l || s_done[v] || s_idle[v]) continue;
+      const int rem = s_end[v] - (s_pt[v] + 1);  // points the victim has not started
+      if (rem > best_rem) {
+        best = v;
+        best_rem = rem;
+      }
+    }
+    if (best >= 0 && best_rem >= 1) {
+      const int hi = s_end[best];
+      const int mid = hi - (best_rem + 1) / 2;
+      a.ctl[best].n_points = mid;
+      s_end[best] = mid;
+      me->point = mid;
+      me->pt_lo = mid;
+      me->n_points = hi;
+      me->steals += 1;
+      me->idle = 0;
+      me->zzero = 1;  // cold start: the tail kernel zeroed z (and beta) when the lane went idle
+      s_pt[l] = mid;
+      s_end[l] = hi;
+      s_idle[l] = 0;
+    } else {
+      me->idle = 0;
+      me->done = 1;
+      s_idle[l] = 0;
+      s_done[l] = 1;
+      retired += 1;
+    }
+  }
+  // (one addition for all the lanes that retire here: an atomic that returns its value is a round trip, twenty-five of them
+  //  behind the last pass of a path were most of what was left of this kernel)
+  if (retired > 0 && atomicAdd(&a.gdone[1], retired) + retired == a.n_lanes) a.gdone[a.done_slot] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------
