@@ -22,6 +22,7 @@
 // src/sparselm/model/_base.py:512-519); the idea is the covariance-update / working-set strategy
 // of coordinate-descent Lasso solvers, restated for the proximal-gradient state machine.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -791,16 +792,43 @@ static __global__ __launch_bounds__(512) void ws_xty_partial_kernel(XtyArgs a) {
 #pragma unroll
   for (int c = 0; c < WS_KCAP / 64; ++c) acc[c] = 0.0;
   double yy = 0.0;
-#pragma unroll 4
-  for (int64_t i = i0 + wave; i < i1; i += 8) {
-    const double yi = a.y[i];
-    yy = __builtin_fma(yi, yi, yy);
+  // The number of 64-column chunks is settled ONCE, outside the row loop, and the loads of four rows are issued together (a
+  // position past K reads position 0 of its chunk and counts with a factor of zero).  With the chunk test inside the loop the
+  // compiler kept one row in flight: 82 us at 384 columns where this takes 48, 22 -> 15 at 96 (tools/probes/xty_probe.hip).
+  auto rows4 = [&](auto NC) {
+    constexpr int C = decltype(NC)::value;
+    for (int64_t i = i0 + wave; i < i1; i += 32) {
+      double xv[4][C], yv[4];
 #pragma unroll
-    for (int c = 0; c < WS_KCAP / 64; ++c) {
-      const int k = lane + 64 * c;
-      if (64 * c < K) acc[c] = __builtin_fma(k < K ? a.XW[i * WS_KCAP + k] : 0.0, yi, acc[c]);
+      for (int r = 0; r < 4; ++r) {
+        const bool in = i + 8 * r < i1;
+        const int64_t ii = in ? i + 8 * r : i;
+        yv[r] = in ? a.y[ii] : 0.0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int k = lane + 64 * c;
+          xv[r][c] = a.XW[ii * WS_KCAP + (k < K ? k : 64 * c)];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        yy = __builtin_fma(yv[r], yv[r], yy);
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = __builtin_fma(lane + 64 * c < K ? xv[r][c] : 0.0, yv[r], acc[c]);
+      }
     }
+  };
+  switch ((K + 63) >> 6) {
+    case 1: rows4(std::integral_constant<int, 1>{}); break;
+    case 2: rows4(std::integral_constant<int, 2>{}); break;
+    case 3: rows4(std::integral_constant<int, 3>{}); break;
+    case 4: rows4(std::integral_constant<int, 4>{}); break;
+    case 5: rows4(std::integral_constant<int, 5>{}); break;
+    case 6: rows4(std::integral_constant<int, 6>{}); break;
+    case 7: rows4(std::integral_constant<int, 7>{}); break;
+    default: rows4(std::integral_constant<int, 8>{}); break;
   }
+  static_assert(WS_KCAP / 64 == 8, "eight chunks of 64 positions");
 #pragma unroll
   for (int c = 0; c < WS_KCAP / 64; ++c) red[wave][lane + 64 * c] = acc[c];
   if (lane == 0) red_yy[wave] = yy;
